@@ -1,0 +1,253 @@
+"""ctypes binding of the C ABI declared in include/cc_solver.h (libcc_hip.so).
+
+This is the boundary the parity tests and bench.py call through. There is no CPU fallback: if the
+shared library is missing, or no gfx950 device is usable, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcc_hip.so")
+
+K_NAMES = ["sweep", "decide", "elim", "solve", "allreduce"]
+TERMINATION = {0: "NO_CONVERGENCE", 1: "GRADIENT", 2: "PARAMETER", 3: "FUNCTION",
+               4: "FAILURE_INVALID_STEPS", 5: "MIN_RADIUS"}
+
+
+class CcError(RuntimeError):
+    pass
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("max_iterations", C.c_int32),
+        ("use_nonmonotonic_steps", C.c_int32),
+        ("max_consecutive_nonmonotonic_steps", C.c_int32),
+        ("jacobi_scaling", C.c_int32),
+        ("max_consecutive_invalid_steps", C.c_int32),
+        ("check_interval", C.c_int32),
+        ("function_tolerance", C.c_double),
+        ("gradient_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double),
+        ("initial_radius", C.c_double),
+        ("max_radius", C.c_double),
+        ("min_radius", C.c_double),
+        ("min_relative_decrease", C.c_double),
+        ("min_lm_diagonal", C.c_double),
+        ("max_lm_diagonal", C.c_double),
+        ("use_graph", C.c_int32),
+        ("profile_kernels", C.c_int32),
+    ]
+
+
+class Iteration(C.Structure):
+    _fields_ = [
+        ("cost", C.c_double),
+        ("cost_change", C.c_double),
+        ("model_cost_change", C.c_double),
+        ("relative_decrease", C.c_double),
+        ("gradient_max_norm", C.c_double),
+        ("step_norm", C.c_double),
+        ("radius", C.c_double),
+        ("accepted", C.c_int32),
+        ("valid", C.c_int32),
+    ]
+
+
+class Summary(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int32),
+        ("successful_steps", C.c_int32),
+        ("termination", C.c_int32),
+        ("log_len", C.c_int32),
+        ("initial_cost", C.c_double),
+        ("final_cost", C.c_double),
+        ("seconds", C.c_double),
+        ("log", C.POINTER(Iteration)),
+        ("log_capacity", C.c_int32),
+        ("sweeps", C.c_int32),
+        ("kernel_ms", C.c_double * 8),
+        ("kernel_launches", C.c_int32 * 8),
+    ]
+
+
+# every symbol include/cc_solver.h declares
+EXPORTED_SYMBOLS = [
+    "cc_options_init", "cc_last_error", "cc_version", "cc_device_count",
+    "cc_intrinsics_create", "cc_intrinsics_destroy", "cc_intrinsics_set_state",
+    "cc_intrinsics_reset", "cc_intrinsics_get_state", "cc_intrinsics_eval",
+    "cc_intrinsics_solve", "cc_intrinsics_optimize", "cc_comm_get_unique_id",
+    "cc_intrinsics_comm_init", "cc_partition_frames", "cc_distort", "cc_undistort",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CcError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.cc_last_error.restype = C.c_char_p
+        _lib.cc_version.restype = C.c_char_p
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise CcError(f"cc error {rc}: {lib().cc_last_error().decode()}")
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def default_options(**kw):
+    o = Options()
+    lib().cc_options_init(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def device_count():
+    return int(lib().cc_device_count())
+
+
+def partition_frames(frame_offsets, nranks):
+    off = np.ascontiguousarray(frame_offsets, dtype=np.int64)
+    first = np.zeros(nranks + 1, dtype=np.int64)
+    _check(lib().cc_partition_frames(C.c_int64(len(off) - 1), _p(off, C.c_int64), C.c_int32(nranks),
+                                     _p(first, C.c_int64)))
+    return first
+
+
+def _summary_dict(s, log):
+    names = [f[0] for f in Iteration._fields_]
+    return {
+        "iterations": s.iterations, "successful_steps": s.successful_steps,
+        "termination": TERMINATION.get(s.termination, str(s.termination)),
+        "initial_cost": s.initial_cost, "final_cost": s.final_cost, "seconds": s.seconds,
+        "sweeps": s.sweeps,
+        "kernel_ms": {K_NAMES[i]: s.kernel_ms[i] for i in range(len(K_NAMES))},
+        "kernel_launches": {K_NAMES[i]: s.kernel_launches[i] for i in range(len(K_NAMES))},
+        "log": [{k: getattr(log[i], k) for k in names} for i in range(s.log_len)],
+    }
+
+
+class IntrinsicsProblem:
+    """Handle on a single-camera intrinsics problem resident in HBM (cc_intrinsics_*)."""
+
+    def __init__(self, frame_offsets, uv, xyz, device=0):
+        self._h = C.c_void_p()
+        off = np.ascontiguousarray(frame_offsets, dtype=np.int64)
+        self.n_frames = len(off) - 1
+        self.n_obs = int(off[-1])
+        uv, xyz = _f32(uv), _f32(xyz)
+        assert uv.size == 2 * self.n_obs and xyz.size == 3 * self.n_obs
+        _check(lib().cc_intrinsics_create(C.c_int32(device), C.c_int64(self.n_frames),
+                                          _p(off, C.c_int64), _p(uv, C.c_float), _p(xyz, C.c_float),
+                                          C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().cc_intrinsics_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_state(self, intr, q, t, const_mask=0):
+        intr, q, t = _f64(intr), _f64(q), _f64(t)
+        assert intr.size == 9 and q.size == 4 * self.n_frames and t.size == 3 * self.n_frames
+        _check(lib().cc_intrinsics_set_state(self._h, _p(intr, C.c_double), C.c_uint32(const_mask),
+                                             _p(q, C.c_double), _p(t, C.c_double)))
+
+    def reset(self):
+        _check(lib().cc_intrinsics_reset(self._h))
+
+    def get_state(self):
+        intr = np.zeros(9)
+        q = np.zeros((self.n_frames, 4))
+        t = np.zeros((self.n_frames, 3))
+        _check(lib().cc_intrinsics_get_state(self._h, _p(intr, C.c_double), _p(q, C.c_double),
+                                             _p(t, C.c_double)))
+        return intr, q, t
+
+    def eval(self, want_blocks=True):
+        blocks = np.zeros((self.n_frames, 16, 16)) if want_blocks else None
+        cost = C.c_double()
+        _check(lib().cc_intrinsics_eval(self._h, _p(blocks, C.c_double) if want_blocks else None,
+                                        C.byref(cost)))
+        return cost.value, blocks
+
+    def solve(self, options=None, log_capacity=1024):
+        opt = options if options is not None else default_options()
+        log = (Iteration * max(1, log_capacity))()
+        s = Summary()
+        s.log = C.cast(log, C.POINTER(Iteration))
+        s.log_capacity = log_capacity
+        _check(lib().cc_intrinsics_solve(self._h, C.byref(opt), C.byref(s)))
+        return _summary_dict(s, log)
+
+    def comm_init(self, unique_id, rank, nranks):
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        _check(lib().cc_intrinsics_comm_init(self._h, buf, C.c_int32(rank), C.c_int32(nranks)))
+
+
+def comm_get_unique_id():
+    buf = (C.c_uint8 * 128)()
+    _check(lib().cc_comm_get_unique_id(buf))
+    return bytes(buf)
+
+
+def intrinsics_optimize(frame_offsets, uv, xyz, intr, q, t, const_mask=0, options=None, device=0,
+                        log_capacity=1024):
+    """One-shot cc_intrinsics_optimize. Returns (intr, q, t, summary)."""
+    off = np.ascontiguousarray(frame_offsets, dtype=np.int64)
+    F = len(off) - 1
+    uv, xyz = _f32(uv), _f32(xyz)
+    intr, q, t = _f64(intr).copy(), _f64(q).copy(), _f64(t).copy()
+    opt = options if options is not None else default_options()
+    log = (Iteration * max(1, log_capacity))()
+    s = Summary()
+    s.log = C.cast(log, C.POINTER(Iteration))
+    s.log_capacity = log_capacity
+    _check(lib().cc_intrinsics_optimize(C.byref(opt), C.c_int32(device), C.c_int64(F),
+                                        _p(off, C.c_int64), _p(uv, C.c_float), _p(xyz, C.c_float),
+                                        _p(intr, C.c_double), C.c_uint32(const_mask),
+                                        _p(q, C.c_double), _p(t, C.c_double), C.byref(s)))
+    return intr, q, t, _summary_dict(s, log)
+
+
+def distort(K, dist, xy, device=0):
+    xy = _f32(xy)
+    out = np.zeros_like(xy)
+    _check(lib().cc_distort(C.c_int32(device), _p(_f32(K), C.c_float), _p(_f32(dist), C.c_float),
+                            C.c_int64(xy.size // 2), _p(xy, C.c_float), _p(out, C.c_float)))
+    return out
+
+
+def undistort(K, dist, uv, device=0):
+    uv = _f32(uv)
+    out = np.zeros_like(uv)
+    _check(lib().cc_undistort(C.c_int32(device), _p(_f32(K), C.c_float), _p(_f32(dist), C.c_float),
+                              C.c_int64(uv.size // 2), _p(uv, C.c_float), _p(out, C.c_float)))
+    return out

@@ -1,0 +1,91 @@
+// cc_common.cpp -- error plumbing, option defaults and host-only helpers of the C ABI.
+#include "cc_common.hpp"
+
+#include <algorithm>
+#include <vector>
+
+namespace cc {
+
+std::string& last_error() {
+  static thread_local std::string s;
+  return s;
+}
+
+int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  last_error() = buf;
+  return code;
+}
+
+int select_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(CC_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= n) return fail(CC_ERR_BAD_ARGUMENT, "device %d out of range (0..%d)", device, n - 1);
+  hipDeviceProp_t prop;
+  CC_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    return fail(CC_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+  CC_HIP(hipSetDevice(device));
+  return CC_OK;
+}
+
+}  // namespace cc
+
+extern "C" {
+
+void cc_options_init(cc_options* o) {
+  o->max_iterations = 100;  // calibrator.cpp:319
+  o->use_nonmonotonic_steps = 1;  // calibrator.cpp:315
+  o->max_consecutive_nonmonotonic_steps = 5;
+  o->jacobi_scaling = 1;
+  o->max_consecutive_invalid_steps = 5;
+  o->check_interval = 4;
+  o->function_tolerance = 1e-6;
+  o->gradient_tolerance = 1e-10;
+  o->parameter_tolerance = 1e-8;
+  o->initial_radius = 1e4;
+  o->max_radius = 1e16;
+  o->min_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->use_graph = 1;
+  o->profile_kernels = 0;
+}
+
+const char* cc_last_error(void) { return cc::last_error().c_str(); }
+const char* cc_version(void) { return "camera_calibrator_amd 0.1 (gfx950, HIP)"; }
+
+int cc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// Contiguous frame ranges with (nearly) equal observation counts: frame f goes to the rank whose
+// ideal observation interval contains the midpoint of the frame's observation range.
+int cc_partition_frames(int64_t F, const int64_t* off, int32_t nranks, int64_t* first) {
+  if (F < 0 || !off || nranks < 1 || !first) return cc::fail(CC_ERR_BAD_ARGUMENT, "cc_partition_frames: bad arguments");
+  const int64_t N = off[F];
+  int64_t f = 0;
+  first[0] = 0;
+  for (int r = 1; r < nranks; ++r) {
+    // boundary r: first frame whose midpoint is at or beyond N * r / nranks
+    const double target = (double)N * r / nranks;
+    while (f < F && 0.5 * ((double)off[f] + (double)off[f + 1]) < target) ++f;
+    // keep every rank non-empty when there are enough frames
+    const int64_t min_f = std::min<int64_t>(F, r);
+    const int64_t max_f = std::max<int64_t>(min_f, F - (nranks - r));
+    first[r] = std::min(std::max(f, min_f), max_f);
+    f = first[r];
+  }
+  first[nranks] = F;
+  return CC_OK;
+}
+
+}  // extern "C"

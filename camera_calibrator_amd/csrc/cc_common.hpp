@@ -1,0 +1,209 @@
+// cc_common.hpp -- shared host/device definitions of the MI355X LM solver (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "../../include/cc_solver.h"
+
+namespace cc {
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+std::string& last_error();
+int fail(int code, const char* fmt, ...);
+
+#define CC_HIP(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return ::cc::fail(CC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                        __FILE__, __LINE__);                                                 \
+  } while (0)
+
+int select_device(int device);
+
+// ---------------------------------------------------------------------------------------------
+// Device-resident LM state machine.  All control decisions (step acceptance, radius update,
+// convergence tests) are taken on the device by a single thread of the `decide` kernel, so an
+// LM iteration is a fixed sequence of kernel launches that can be enqueued ahead / replayed
+// from a hipGraph; kernels turn into no-ops once `done` is set.
+// Semantics follow Ceres' TrustRegionMinimizer / LevenbergMarquardtStrategy /
+// TrustRegionStepEvaluator, which is what the reference runs (calibrator.cpp:314-324).
+// ---------------------------------------------------------------------------------------------
+struct LmOpts {
+  int32_t max_iterations, use_nonmonotonic_steps, max_consecutive_nonmonotonic_steps, jacobi_scaling;
+  int32_t max_consecutive_invalid_steps, pad0_;
+  double function_tolerance, gradient_tolerance, parameter_tolerance;
+  double initial_radius, max_radius, min_radius, min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
+};
+
+constexpr int kMaxShared = 64;  // max shared tangent size (intrinsics: 9, rig: 6*C <= 60)
+
+struct LmState {
+  int32_t done, term, iter, n_success, n_invalid;
+  int32_t cur;         // index (0/1) of the buffers holding the accepted point and its blocks
+  int32_t phase;       // 0: initial evaluation pending, 1: iterating
+  int32_t step_valid;  // set by the solve kernel: linear solve succeeded
+  int32_t num_nonmono, log_len, sweeps, pad_;
+  double radius, decrease_factor, x_cost, x_norm, gmax, initial_cost;
+  double minimum_cost, current_cost, reference_cost, candidate_cost, acc_ref, acc_cand;
+  double ds[kMaxShared];  // scaled shared step from the solve kernel
+  double ss[kMaxShared];  // Jacobi scale of the shared block (computed once)
+};
+
+__host__ inline void opts_from_public(const cc_options& o, LmOpts* d) {
+  d->max_iterations = o.max_iterations;
+  d->use_nonmonotonic_steps = o.use_nonmonotonic_steps;
+  d->max_consecutive_nonmonotonic_steps = o.max_consecutive_nonmonotonic_steps;
+  d->jacobi_scaling = o.jacobi_scaling;
+  d->max_consecutive_invalid_steps = o.max_consecutive_invalid_steps;
+  d->pad0_ = 0;
+  d->function_tolerance = o.function_tolerance;
+  d->gradient_tolerance = o.gradient_tolerance;
+  d->parameter_tolerance = o.parameter_tolerance;
+  d->initial_radius = o.initial_radius;
+  d->max_radius = o.max_radius;
+  d->min_radius = o.min_radius;
+  d->min_relative_decrease = o.min_relative_decrease;
+  d->min_lm_diagonal = o.min_lm_diagonal;
+  d->max_lm_diagonal = o.max_lm_diagonal;
+}
+
+#if defined(__HIPCC__)
+
+__device__ inline void lm_log(LmState& st, cc_iteration* log, int cap, double cost, double cc_,
+                              double mcc, double rd, double sn, int acc, int valid) {
+  if (log && st.log_len < cap) {
+    cc_iteration& it = log[st.log_len];
+    it.cost = cost; it.cost_change = cc_; it.model_cost_change = mcc; it.relative_decrease = rd;
+    it.gradient_max_norm = st.gmax; it.step_norm = sn; it.radius = st.radius; it.accepted = acc;
+    it.valid = valid;
+  }
+  st.log_len++;
+}
+
+// Initial evaluation bookkeeping (TrustRegionMinimizer::Init + IterationZero).
+__device__ inline void lm_init(LmState& st, const LmOpts& o, double cost, double x_norm, double gmax) {
+  st.x_cost = cost; st.initial_cost = cost; st.x_norm = x_norm; st.gmax = gmax;
+  st.minimum_cost = st.current_cost = st.reference_cost = st.candidate_cost = cost;
+  st.acc_ref = st.acc_cand = 0.0; st.num_nonmono = 0;
+  st.radius = o.initial_radius; st.decrease_factor = 2.0;
+  st.iter = 0; st.n_success = 0; st.n_invalid = 0; st.phase = 1; st.step_valid = 0;
+  if (gmax <= o.gradient_tolerance) { st.done = 1; st.term = CC_CONVERGENCE_GRADIENT; }
+  else if (o.max_iterations <= 0) { st.done = 1; st.term = CC_NO_CONVERGENCE; }
+}
+
+// One LM iteration's decision. Inputs are the globally reduced quantities of the candidate point.
+// Returns 1 if the candidate was accepted (buffers must flip; done by toggling st.cur here).
+__device__ inline void lm_decide(LmState& st, const LmOpts& o, cc_iteration* log, int log_cap,
+                                 double cand_cost, double q_model, double step2, double xnorm2_cand,
+                                 double gmax_cand) {
+  st.iter++;
+  const double mcc = -q_model;
+  const bool valid = st.step_valid && (mcc > 0.0) && isfinite(mcc);
+  if (!valid) {
+    // HandleInvalidStep + LevenbergMarquardtStrategy::StepIsInvalid
+    st.n_invalid++;
+    st.radius /= st.decrease_factor;
+    st.decrease_factor *= 2.0;
+    lm_log(st, log, log_cap, st.x_cost, 0.0, mcc, 0.0, 0.0, 0, 0);
+    if (st.n_invalid >= o.max_consecutive_invalid_steps) { st.done = 1; st.term = CC_FAILURE_INVALID_STEPS; }
+  } else {
+    st.n_invalid = 0;
+    const double step_norm = sqrt(step2);
+    if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
+    const double cost_change = st.x_cost - cand_cost;
+    if (step_norm <= o.parameter_tolerance * (st.x_norm + o.parameter_tolerance)) {
+      st.done = 1; st.term = CC_CONVERGENCE_PARAMETER;
+      lm_log(st, log, log_cap, st.x_cost, cost_change, mcc, 0.0, step_norm, 0, 1);
+    } else if (fabs(cost_change) <= o.function_tolerance * st.x_cost) {
+      st.done = 1; st.term = CC_CONVERGENCE_FUNCTION;
+      lm_log(st, log, log_cap, st.x_cost, cost_change, mcc, 0.0, step_norm, 0, 1);
+    } else {
+      // TrustRegionStepEvaluator::StepQuality
+      double quality;
+      if (!(cand_cost < 1.7976931348623157e308)) {
+        quality = -1.7976931348623157e308;
+      } else {
+        const double rel = (st.current_cost - cand_cost) / mcc;
+        const double hist = (st.reference_cost - cand_cost) / (st.acc_ref + mcc);
+        quality = fmax(rel, hist);
+      }
+      if (quality > o.min_relative_decrease) {
+        st.cur ^= 1;
+        st.x_cost = cand_cost;
+        st.x_norm = sqrt(xnorm2_cand);
+        st.gmax = gmax_cand;
+        const double q3 = 2.0 * quality - 1.0;
+        st.radius = fmin(o.max_radius, st.radius / fmax(1.0 / 3.0, 1.0 - q3 * q3 * q3));
+        st.decrease_factor = 2.0;
+        // TrustRegionStepEvaluator::StepAccepted
+        st.current_cost = cand_cost;
+        st.acc_cand += mcc;
+        st.acc_ref += mcc;
+        if (st.current_cost < st.minimum_cost) {
+          st.minimum_cost = st.current_cost; st.num_nonmono = 0;
+          st.candidate_cost = st.current_cost; st.acc_cand = 0.0;
+        } else {
+          st.num_nonmono++;
+          if (st.current_cost > st.candidate_cost) { st.candidate_cost = st.current_cost; st.acc_cand = 0.0; }
+        }
+        const int maxn = o.use_nonmonotonic_steps ? o.max_consecutive_nonmonotonic_steps : 0;
+        if (st.num_nonmono == maxn) { st.reference_cost = st.candidate_cost; st.acc_ref = st.acc_cand; }
+        st.n_success++;
+        lm_log(st, log, log_cap, st.x_cost, cost_change, mcc, quality, step_norm, 1, 1);
+        if (st.gmax <= o.gradient_tolerance) { st.done = 1; st.term = CC_CONVERGENCE_GRADIENT; }
+      } else {
+        st.radius /= st.decrease_factor;
+        st.decrease_factor *= 2.0;
+        lm_log(st, log, log_cap, st.x_cost, cost_change, mcc, quality, step_norm, 0, 1);
+      }
+    }
+  }
+  if (!st.done) {
+    if (st.iter >= o.max_iterations) { st.done = 1; st.term = CC_NO_CONVERGENCE; }
+    else if (st.radius < o.min_radius) { st.done = 1; st.term = CC_MIN_RADIUS; }
+  }
+  st.step_valid = 0;
+}
+
+// ---- small device math -------------------------------------------------------------------
+
+__device__ inline double rfl(double x) {  // wave-uniform value -> SGPR pair
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
+
+// Rotation matrix of q/|q| (ceres::QuaternionRotatePoint normalises; calibrator.cpp:201)
+__device__ inline void quat_to_R(const double* q, double* R) {
+  const double n = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const double w = q[0] * n, x = q[1] * n, y = q[2] * n, z = q[3] * n;
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z);     R[2] = 2 * (x * z + w * y);
+  R[3] = 2 * (x * y + w * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+  R[6] = 2 * (x * z - w * y);     R[7] = 2 * (y * z + w * x);     R[8] = 1 - 2 * (x * x + y * y);
+}
+
+// ceres::QuaternionManifold::Plus (calibrator.cpp:298)
+__device__ inline void quat_plus(const double* x, const double* d, double* out) {
+  const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  if (nd == 0.0) { out[0] = x[0]; out[1] = x[1]; out[2] = x[2]; out[3] = x[3]; return; }
+  const double s = sin(nd) / nd;
+  const double a0 = cos(nd), a1 = s * d[0], a2 = s * d[1], a3 = s * d[2];
+  out[0] = a0 * x[0] - a1 * x[1] - a2 * x[2] - a3 * x[3];
+  out[1] = a0 * x[1] + a1 * x[0] + a2 * x[3] - a3 * x[2];
+  out[2] = a0 * x[2] - a1 * x[3] + a2 * x[0] + a3 * x[1];
+  out[3] = a0 * x[3] + a1 * x[2] - a2 * x[1] + a3 * x[0];
+}
+
+__device__ inline double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
+
+#endif  // __HIPCC__
+
+}  // namespace cc

@@ -1,0 +1,166 @@
+/*
+ * cc_solver.h -- C ABI of the MI355X-native reprojection-error LM solver.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  It replaces, for
+ * the hot path only, what the reference builds out of ceres::Problem / ceres::Solve:
+ *   - cc_intrinsics_*  <->  Calibrator::Optimize            (/root/reference/src/calibrator.cpp:221-336)
+ *   - cc_rig_*         <->  ExtrinsicsCalibrator::Optimize  (/root/reference/src/extrinsics_calibrator.cpp:86-257)
+ *   - cc_distort / cc_undistort <-> Calibrator::Distort / Undistort (calibrator.cpp:118-166)
+ * The C++ classes in camera_calibrator_amd/csrc/ (same names and signatures as the reference's
+ * calibrator.hh / extrinsics_calibrator.hh) call these entry points; INTEGRATION.md shows the
+ * binding a maintainer of the reference would add.
+ *
+ * All entry points return 0 on success or a negative cc_status; cc_last_error() gives text.
+ * The library is HIP-only: there is no CPU fallback, every compute entry point fails with
+ * CC_ERR_NO_DEVICE when no gfx950 device is usable.
+ *
+ * Conventions (identical to the reference): intrinsics order fx fy px py k1 k2 p1 p2 k3
+ * (calibrator.cpp:168-179); quaternions w x y z (calibrator.cpp:277-278); observations and 3-D
+ * points are float32 as the reference API stores them (types.hh:10-15); parameters are fp64.
+ */
+#ifndef CC_SOLVER_H
+#define CC_SOLVER_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum cc_status {
+  CC_OK = 0,
+  CC_ERR_BAD_ARGUMENT = -1,
+  CC_ERR_NO_DEVICE = -2,
+  CC_ERR_HIP = -3,
+  CC_ERR_COMM = -4,
+  CC_ERR_STATE = -5
+} cc_status;
+
+/* Termination reasons (mirror Ceres' TerminationType + message for this path). */
+enum {
+  CC_NO_CONVERGENCE = 0,       /* max_iterations reached */
+  CC_CONVERGENCE_GRADIENT = 1,
+  CC_CONVERGENCE_PARAMETER = 2,
+  CC_CONVERGENCE_FUNCTION = 3,
+  CC_FAILURE_INVALID_STEPS = 4,
+  CC_MIN_RADIUS = 5
+};
+
+/* Solver options.  cc_options_init() sets the Ceres 2.x defaults overlaid with what the
+ * reference sets at calibrator.cpp:314-321 (non-monotonic steps, 100 iterations). Tolerances
+ * < 0 disable the corresponding test. */
+typedef struct cc_options {
+  int32_t max_iterations;                     /* 100 (calibrator.cpp:319); rig default 1000 (extrinsics_calibrator.cpp:211) */
+  int32_t use_nonmonotonic_steps;             /* 1 (calibrator.cpp:315) */
+  int32_t max_consecutive_nonmonotonic_steps; /* 5 */
+  int32_t jacobi_scaling;                     /* 1 */
+  int32_t max_consecutive_invalid_steps;      /* 5 */
+  int32_t check_interval;                     /* LM iterations enqueued per host poll of the device 'done' flag (4) */
+  double function_tolerance;                  /* 1e-6 */
+  double gradient_tolerance;                  /* 1e-10 */
+  double parameter_tolerance;                 /* 1e-8 */
+  double initial_radius;                      /* 1e4 */
+  double max_radius;                          /* 1e16 */
+  double min_radius;                          /* 1e-32 */
+  double min_relative_decrease;               /* 1e-3 */
+  double min_lm_diagonal;                     /* 1e-6 */
+  double max_lm_diagonal;                     /* 1e32 */
+  int32_t use_graph;                          /* 1: replay a captured hipGraph of check_interval iterations */
+  int32_t profile_kernels;                    /* 1: bracket every kernel launch with hipEvents (implies no graph) */
+} cc_options;
+
+typedef struct cc_iteration {
+  double cost;
+  double cost_change;
+  double model_cost_change;
+  double relative_decrease;
+  double gradient_max_norm;
+  double step_norm;
+  double radius;
+  int32_t accepted;
+  int32_t valid;
+} cc_iteration;
+
+enum { CC_K_SWEEP = 0, CC_K_DECIDE = 1, CC_K_ELIM = 2, CC_K_SOLVE = 3, CC_K_ALLREDUCE = 4, CC_K_COUNT = 8 };
+
+typedef struct cc_summary {
+  int32_t iterations;        /* LM iterations executed (accepted + rejected + invalid) */
+  int32_t successful_steps;
+  int32_t termination;
+  int32_t log_len;
+  double initial_cost;
+  double final_cost;
+  double seconds;            /* host wall time of the solve call, device work included */
+  cc_iteration* log;         /* caller-provided buffer (may be NULL) */
+  int32_t log_capacity;
+  int32_t sweeps;            /* Jacobian sweeps launched (1 initial + 1 per valid LM iteration) */
+  /* profile_kernels=1 only: per-kernel device time from hipEvents on the solver's stream */
+  double kernel_ms[CC_K_COUNT];      /* total ms per kernel kind */
+  int32_t kernel_launches[CC_K_COUNT];
+} cc_summary;
+
+void cc_options_init(cc_options* o);
+const char* cc_last_error(void);
+const char* cc_version(void);
+/* Number of usable HIP devices (0 if none); never touches the oracle or a CPU path. */
+int cc_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Single-camera intrinsics problem: 9 shared intrinsics + one (q,t) pose per frame.
+ * Frames are ragged: frame f owns observations [frame_offsets[f], frame_offsets[f+1]).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct cc_intrinsics cc_intrinsics;
+
+/* Uploads the observations to HBM (device `device`, a stream of its own). uv: 2N floats (pixels),
+ * xyz: 3N floats. */
+int cc_intrinsics_create(int32_t device, int64_t n_frames, const int64_t* frame_offsets,
+                         const float* uv, const float* xyz, cc_intrinsics** out);
+void cc_intrinsics_destroy(cc_intrinsics* h);
+
+/* Sets the current parameters (and remembers them as the initial state for cc_intrinsics_reset).
+ * const_mask bit i freezes intrinsic i (ForceDistortionToConstant(d) -> bit d+4, calibrator.cpp:338-340). */
+int cc_intrinsics_set_state(cc_intrinsics* h, const double* intr9, uint32_t const_mask,
+                            const double* q_wxyz, const double* t_xyz);
+int cc_intrinsics_reset(cc_intrinsics* h); /* device-side copy back to the last set_state */
+int cc_intrinsics_get_state(cc_intrinsics* h, double* intr9, double* q_wxyz, double* t_xyz);
+
+/* One Jacobian sweep at the current state: per-frame 16x16 Gram blocks
+ * G_f = sum_rows v v^T, v = [J_intr(9) J_pose(6) r] (row-major, blocks may be NULL) and the
+ * total cost 1/2 sum r^2. */
+int cc_intrinsics_eval(cc_intrinsics* h, double* blocks, double* cost);
+
+/* Runs the LM loop on the device from the current state. */
+int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* summary);
+
+/* One-shot convenience: create + set_state + solve + get_state + destroy. This is the call
+ * Calibrator::Optimize makes in place of calibrator.cpp:236-324. */
+int cc_intrinsics_optimize(const cc_options* opt, int32_t device, int64_t n_frames,
+                           const int64_t* frame_offsets, const float* uv, const float* xyz,
+                           double* intr9, uint32_t const_mask, double* q_wxyz, double* t_xyz,
+                           cc_summary* summary);
+
+/* Multi-GPU: one process per GPU, each owning a contiguous shard of frames. Rank 0 calls
+ * cc_comm_get_unique_id and broadcasts the 128 bytes (e.g. over torch.distributed); every rank
+ * then attaches its handle. Per LM iteration the handles all-reduce (RCCL, sum, fp64) only the
+ * reduced shared-parameter blocks (64 doubles after elimination, 64 after the sweep). */
+int cc_comm_get_unique_id(uint8_t id[128]);
+int cc_intrinsics_comm_init(cc_intrinsics* h, const uint8_t id[128], int32_t rank, int32_t nranks);
+
+/* Contiguous frame partition balanced by observation count (host logic, no GPU needed).
+ * first_frame has nranks+1 entries; rank r owns frames [first_frame[r], first_frame[r+1]). */
+int cc_partition_frames(int64_t n_frames, const int64_t* frame_offsets, int32_t nranks,
+                        int64_t* first_frame);
+
+/* ---------------------------------------------------------------------------------------------
+ * Point kernels of the Calibrator surface.
+ * ------------------------------------------------------------------------------------------- */
+/* Calibrator::Distort (calibrator.cpp:157-166): normalised -> pixel coordinates, float arithmetic
+ * with the reference's promotions. K: row-major 3x3, dist: k1 k2 p1 p2 k3. */
+int cc_distort(int32_t device, const float* K9, const float* dist5, int64_t n,
+               const float* xy_normalized, float* uv_out);
+/* Calibrator::Undistort (calibrator.cpp:118-155): pixel -> undistorted normalised coordinates. */
+int cc_undistort(int32_t device, const float* K9, const float* dist5, int64_t n, const float* uv,
+                 float* xy_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
