@@ -78,7 +78,7 @@ EXPORTED_SYMBOLS = [
     "cc_options_init", "cc_last_error", "cc_version", "cc_device_count",
     "cc_intrinsics_create", "cc_intrinsics_destroy", "cc_intrinsics_set_state",
     "cc_intrinsics_reset", "cc_intrinsics_get_state", "cc_intrinsics_eval",
-    "cc_intrinsics_solve", "cc_intrinsics_optimize", "cc_comm_get_unique_id",
+    "cc_intrinsics_solve", "cc_intrinsics_profile_sweep", "cc_intrinsics_optimize", "cc_comm_get_unique_id",
     "cc_intrinsics_comm_init", "cc_partition_frames", "cc_distort", "cc_undistort",
 ]
 
@@ -206,6 +206,11 @@ class IntrinsicsProblem:
         s.log_capacity = log_capacity
         _check(lib().cc_intrinsics_solve(self._h, C.byref(opt), C.byref(s)))
         return _summary_dict(s, log)
+
+    def profile_sweep(self, n=50):
+        ms = C.c_double()
+        _check(lib().cc_intrinsics_profile_sweep(self._h, C.c_int32(n), C.byref(ms)))
+        return ms.value
 
     def comm_init(self, unique_id, rank, nranks):
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))

@@ -268,20 +268,39 @@ __global__ __launch_bounds__(kSweepThreads, 2) void k_intr_sweep(IntrDev P) {
 // decide: MODE 0 = reduce + decide (single GPU), 1 = reduce only (-> vec_decide), 2 = decide only
 // vec_decide layout: [0..31] column sums of stats (col ST_GMAXP unused), [32 + rank] local gmax_p
 // ---------------------------------------------------------------------------------------------
+constexpr int kDecideThreads = 1024;
+constexpr int kStateDoubles = (int)(sizeof(LmState) / sizeof(double));
+static_assert(sizeof(LmState) % sizeof(double) == 0, "LmState must be a whole number of doubles");
+
 template <int MODE>
-__global__ __launch_bounds__(256) void k_intr_decide(IntrDev P) {
-  __shared__ double red[8][kStatsCols];
+__global__ __launch_bounds__(kDecideThreads) void k_intr_decide(IntrDev P) {
+  __shared__ double red[32][kStatsCols];
   __shared__ double sv[64];
-  LmState* st = P.state;
-  if (st->done) return;
+  __shared__ LmState sst;  // the state machine works on an LDS copy: one global round trip each way
   const int tid = threadIdx.x;
+  if (tid < kStateDoubles) reinterpret_cast<double*>(&sst)[tid] = reinterpret_cast<const double*>(P.state)[tid];
+  __syncthreads();
+  if (sst.done) return;
+  LmState* st = &sst;
   if (MODE != 2) {
     const bool skip = st->phase != 0 && !st->step_valid;  // sweep did not run: stats are stale
     const int col = tid & 31, grp = tid >> 5;
     double a = 0.0;
     if (!skip) {
-      if (col == ST_GMAXP) { for (int64_t f = grp; f < P.F; f += 8) a = fmax(a, P.stats[f * kStatsCols + col]); }
-      else { for (int64_t f = grp; f < P.F; f += 8) a += P.stats[f * kStatsCols + col]; }
+      // 32 row groups; 8 independent loads in flight per thread
+      const double* base = P.stats + col;
+      if (col == ST_GMAXP) {
+        for (int64_t f = grp; f < P.F; f += 32) a = fmax(a, base[f * kStatsCols]);
+      } else {
+        double acc8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int64_t f = grp;
+        for (; f + 7 * 32 < P.F; f += 8 * 32) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc8[u] += base[(f + u * 32) * kStatsCols];
+        }
+        for (int u = 0; f < P.F; f += 32, ++u) acc8[u] += base[f * kStatsCols];
+        a = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
+      }
     }
     red[grp][col] = a;
     if (tid < 64) sv[tid] = 0.0;
@@ -289,10 +308,10 @@ __global__ __launch_bounds__(256) void k_intr_decide(IntrDev P) {
     if (tid < 32) {
       double v = 0.0;
       if (tid == ST_GMAXP) {
-        for (int g2 = 0; g2 < 8; ++g2) v = fmax(v, red[g2][tid]);
+        for (int g2 = 0; g2 < 32; ++g2) v = fmax(v, red[g2][tid]);
         sv[32 + P.rank] = v;  // per-rank slot: a sum all-reduce then carries the max
       } else {
-        for (int g2 = 0; g2 < 8; ++g2) v += red[g2][tid];
+        for (int g2 = 0; g2 < 32; ++g2) v += red[g2][tid];
         sv[tid] = v;
       }
     }
@@ -305,37 +324,40 @@ __global__ __launch_bounds__(256) void k_intr_decide(IntrDev P) {
     if (tid < 64) sv[tid] = P.vec_decide[tid];
     __syncthreads();
   }
-  if (tid != 0) return;
-  const double* V = sv;
-  const LmOpts& o = *P.opts;
-  double gmax_p = 0.0;
-  for (int r = 0; r < P.nranks && r < 32; ++r) gmax_p = fmax(gmax_p, V[32 + r]);
-  if (st->phase == 0) {
-    const double* k = P.intr + st->cur * 16;
-    double xn2 = V[ST_XNORM2], gmax = gmax_p;
-    for (int i = 0; i < 9; ++i) {
-      xn2 += k[i] * k[i];
-      if (!(P.mask & (1u << i))) gmax = fmax(gmax, fabs(V[ST_GS + i]));
-      st->ss[i] = o.jacobi_scaling ? 1.0 / (1.0 + sqrt(V[ST_HDIAG + i])) : 1.0;
-    }
-    st->sweeps = 1;
-    lm_init(*st, o, V[ST_COST], sqrt(xn2), gmax);
-  } else {
-    const int cand = st->cur ^ 1;
-    const double* kc = P.intr + cand * 16;
-    const double* k0 = P.intr + st->cur * 16;
-    double step2 = V[ST_STEP2], xn2 = V[ST_XNORM2], gmax = gmax_p;
-    if (st->step_valid) {
-      st->sweeps++;
+  if (tid == 0) {
+    const double* V = sv;
+    const LmOpts o = *P.opts;
+    double gmax_p = 0.0;
+    for (int r = 0; r < P.nranks && r < 32; ++r) gmax_p = fmax(gmax_p, V[32 + r]);
+    if (st->phase == 0) {
+      const double* k = P.intr + st->cur * 16;
+      double xn2 = V[ST_XNORM2], gmax = gmax_p;
       for (int i = 0; i < 9; ++i) {
-        const double d = kc[i] - k0[i];
-        step2 += d * d;
-        xn2 += kc[i] * kc[i];
+        xn2 += k[i] * k[i];
         if (!(P.mask & (1u << i))) gmax = fmax(gmax, fabs(V[ST_GS + i]));
+        st->ss[i] = o.jacobi_scaling ? 1.0 / (1.0 + sqrt(V[ST_HDIAG + i])) : 1.0;
       }
+      st->sweeps = 1;
+      lm_init(*st, o, V[ST_COST], sqrt(xn2), gmax);
+    } else {
+      const int cand = st->cur ^ 1;
+      const double* kc = P.intr + cand * 16;
+      const double* k0 = P.intr + st->cur * 16;
+      double step2 = V[ST_STEP2], xn2 = V[ST_XNORM2], gmax = gmax_p;
+      if (st->step_valid) {
+        st->sweeps++;
+        for (int i = 0; i < 9; ++i) {
+          const double d = kc[i] - k0[i];
+          step2 += d * d;
+          xn2 += kc[i] * kc[i];
+          if (!(P.mask & (1u << i))) gmax = fmax(gmax, fabs(V[ST_GS + i]));
+        }
+      }
+      lm_decide(*st, o, P.log, P.log_cap, V[ST_COST], V[ST_QMODEL], step2, xn2, gmax);
     }
-    lm_decide(*st, o, P.log, P.log_cap, V[ST_COST], V[ST_QMODEL], step2, xn2, gmax);
   }
+  __syncthreads();
+  if (tid < kStateDoubles) reinterpret_cast<double*>(P.state)[tid] = reinterpret_cast<const double*>(&sst)[tid];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -462,13 +484,23 @@ __global__ __launch_bounds__(256) void k_intr_elim(IntrDev P) {
 // ---------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(64) void k_intr_solve(IntrDev P, int nblk) {
+  __shared__ double sv[64];
+  __shared__ double S[81];
+  __shared__ double b[9];
   LmState* st = P.state;
   if (st->done) return;
   const int tid = threadIdx.x;
-  __shared__ double sv[64];
+  const double radius = st->radius;
+  const double mn = P.opts->min_lm_diagonal, mx = P.opts->max_lm_diagonal;
   if (MODE != 2) {
-    double a = 0.0;
-    for (int b = 0; b < nblk; ++b) a += P.partial[b * 64 + tid];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int bb = 0;
+    for (; bb + 3 < nblk; bb += 4) {
+      a0 += P.partial[bb * 64 + tid]; a1 += P.partial[(bb + 1) * 64 + tid];
+      a2 += P.partial[(bb + 2) * 64 + tid]; a3 += P.partial[(bb + 3) * 64 + tid];
+    }
+    for (; bb < nblk; ++bb) a0 += P.partial[bb * 64 + tid];
+    const double a = (a0 + a1) + (a2 + a3);
     sv[tid] = a;
     if (MODE == 1) { P.vec_solve[tid] = a; return; }
   } else {
@@ -477,14 +509,12 @@ __global__ __launch_bounds__(64) void k_intr_solve(IntrDev P, int nblk) {
   __syncthreads();
   if (tid != 0) return;
   const double* V = sv;
-  const LmOpts& o = *P.opts;
   bool ok = !(V[63] > 0.0);
-  double S[81], b[9];
   int idx = 0;
   for (int j = 0; j < 9; ++j)
     for (int k = j; k < 9; ++k) { S[j * 9 + k] = S[k * 9 + j] = V[idx]; ++idx; }
   for (int j = 0; j < 9; ++j) {
-    S[j * 9 + j] += clampd(V[54 + j], o.min_lm_diagonal, o.max_lm_diagonal) / st->radius;
+    S[j * 9 + j] += clampd(V[54 + j], mn, mx) / radius;
     b[j] = V[45 + j];
   }
   for (int j = 0; j < 9; ++j)
@@ -499,10 +529,11 @@ __global__ __launch_bounds__(64) void k_intr_solve(IntrDev P, int nblk) {
     if (!(d > 0.0) || !isfinite(d)) { ok = false; break; }
     d = sqrt(d);
     S[j * 9 + j] = d;
+    const double inv = 1.0 / d;
     for (int i = j + 1; i < 9; ++i) {
       double a = S[i * 9 + j];
       for (int k = 0; k < j; ++k) a -= S[i * 9 + k] * S[j * 9 + k];
-      S[i * 9 + j] = a / d;
+      S[i * 9 + j] = a * inv;
     }
   }
   if (ok) {
@@ -570,9 +601,9 @@ static void enqueue_kernel(cc_intrinsics* h, int kind, int variant, bool profile
       hipLaunchKernelGGL(k_intr_sweep, dim3((unsigned)h->F), dim3(kSweepThreads), kSweepLdsBytes, h->stream, h->d);
       break;
     case CC_K_DECIDE:
-      if (variant == 0) hipLaunchKernelGGL(k_intr_decide<0>, dim3(1), dim3(256), 0, h->stream, h->d);
-      else if (variant == 1) hipLaunchKernelGGL(k_intr_decide<1>, dim3(1), dim3(256), 0, h->stream, h->d);
-      else hipLaunchKernelGGL(k_intr_decide<2>, dim3(1), dim3(256), 0, h->stream, h->d);
+      if (variant == 0) hipLaunchKernelGGL(k_intr_decide<0>, dim3(1), dim3(kDecideThreads), 0, h->stream, h->d);
+      else if (variant == 1) hipLaunchKernelGGL(k_intr_decide<1>, dim3(1), dim3(kDecideThreads), 0, h->stream, h->d);
+      else hipLaunchKernelGGL(k_intr_decide<2>, dim3(1), dim3(kDecideThreads), 0, h->stream, h->d);
       break;
     case CC_K_ELIM:
       hipLaunchKernelGGL(k_intr_elim, dim3(h->elim_blocks), dim3(256), 0, h->stream, h->d);
@@ -887,6 +918,35 @@ int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* sum
   for (auto e : h->events) hipEventDestroy(e);
   h->events.clear();
   h->event_kind.clear();
+  return CC_OK;
+}
+
+int cc_intrinsics_profile_sweep(cc_intrinsics* h, int32_t n, double* avg_ms) {
+  using namespace cc;
+  if (!h || n < 1 || !avg_ms) return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_profile_sweep: bad arguments");
+  CC_HIP(hipSetDevice(h->device));
+  CC_HIP(hipStreamSynchronize(h->stream));
+  LmState st;
+  CC_HIP(hipMemcpy(&st, h->d.state, sizeof(st), hipMemcpyDeviceToHost));
+  if (st.phase != 1 || st.iter < 1) return fail(CC_ERR_STATE, "cc_intrinsics_profile_sweep: run cc_intrinsics_solve first");
+  LmState run = st;
+  run.done = 0; run.step_valid = 1;
+  CC_HIP(hipMemcpy(h->d.state, &run, sizeof(run), hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  CC_HIP(hipEventCreate(&e0));
+  CC_HIP(hipEventCreate(&e1));
+  enqueue_kernel(h, CC_K_SWEEP, 0, false);  // warm
+  CC_HIP(hipEventRecord(e0, h->stream));
+  for (int i = 0; i < n; ++i) enqueue_kernel(h, CC_K_SWEEP, 0, false);
+  CC_HIP(hipEventRecord(e1, h->stream));
+  CC_HIP(hipGetLastError());
+  CC_HIP(hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  CC_HIP(hipEventElapsedTime(&ms, e0, e1));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  *avg_ms = (double)ms / n;
+  CC_HIP(hipMemcpy(h->d.state, &st, sizeof(st), hipMemcpyHostToDevice));
   return CC_OK;
 }
 

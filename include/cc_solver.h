@@ -130,6 +130,12 @@ int cc_intrinsics_eval(cc_intrinsics* h, double* blocks, double* cost);
 /* Runs the LM loop on the device from the current state. */
 int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* summary);
 
+/* Measurement aid: launches `n` steady-state Jacobian sweeps (candidate step + sweep, exactly the
+ * kernel an LM iteration runs) back to back on the solver's stream between two hipEvents and
+ * returns the average ms per launch. Needs a completed cc_intrinsics_solve with >= 1 iteration.
+ * The accepted point is left untouched. */
+int cc_intrinsics_profile_sweep(cc_intrinsics* h, int32_t n, double* avg_ms);
+
 /* One-shot convenience: create + set_state + solve + get_state + destroy. This is the call
  * Calibrator::Optimize makes in place of calibrator.cpp:236-324. */
 int cc_intrinsics_optimize(const cc_options* opt, int32_t device, int64_t n_frames,
