@@ -43,19 +43,19 @@ struct LmOpts {
   double initial_radius, max_radius, min_radius, min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
 };
 
-constexpr int kMaxShared = 64;  // max shared tangent size (intrinsics: 9, rig: 6*C <= 60)
-
-struct LmState {
+// Scalar control block of the LM state machine (lives in HBM, 144 bytes; the deciding thread works
+// on a register copy: one global round trip each way).
+struct LmCtl {
   int32_t done, term, iter, n_success, n_invalid;
-  int32_t cur;         // index (0/1) of the buffers holding the accepted point and its blocks
-  int32_t phase;       // 0: initial evaluation pending, 1: iterating
-  int32_t step_valid;  // set by the solve kernel: linear solve succeeded
-  int32_t num_nonmono, log_len, sweeps, pad_;
+  int32_t cur;           // index (0/1) of the buffers holding the accepted point and its blocks
+  int32_t phase;         // 0: initial evaluation pending, 1: iterating
+  int32_t step_valid;    // set by the solve kernel: the linear solve succeeded
+  int32_t cand_pending;  // a candidate point has been evaluated and awaits the decision
+  int32_t num_nonmono, log_len, sweeps;
   double radius, decrease_factor, x_cost, x_norm, gmax, initial_cost;
   double minimum_cost, current_cost, reference_cost, candidate_cost, acc_ref, acc_cand;
-  double ds[kMaxShared];  // scaled shared step from the solve kernel
-  double ss[kMaxShared];  // Jacobi scale of the shared block (computed once)
 };
+static_assert(sizeof(LmCtl) == 144, "LmCtl layout");
 
 __host__ inline void opts_from_public(const cc_options& o, LmOpts* d) {
   d->max_iterations = o.max_iterations;
@@ -77,7 +77,7 @@ __host__ inline void opts_from_public(const cc_options& o, LmOpts* d) {
 
 #if defined(__HIPCC__)
 
-__device__ inline void lm_log(LmState& st, cc_iteration* log, int cap, double cost, double cc_,
+__device__ inline void lm_log(LmCtl& st, cc_iteration* log, int cap, double cost, double cc_,
                               double mcc, double rd, double sn, int acc, int valid) {
   if (log && st.log_len < cap) {
     cc_iteration& it = log[st.log_len];
@@ -89,22 +89,24 @@ __device__ inline void lm_log(LmState& st, cc_iteration* log, int cap, double co
 }
 
 // Initial evaluation bookkeeping (TrustRegionMinimizer::Init + IterationZero).
-__device__ inline void lm_init(LmState& st, const LmOpts& o, double cost, double x_norm, double gmax) {
-  st.x_cost = cost; st.initial_cost = cost; st.x_norm = x_norm; st.gmax = gmax;
+// The gradient test of iteration 0 happens in the first solve kernel (it owns the gradient).
+__device__ inline void lm_init(LmCtl& st, const LmOpts& o, double cost, double x_norm) {
+  st.x_cost = cost; st.initial_cost = cost; st.x_norm = x_norm; st.gmax = 0.0;
   st.minimum_cost = st.current_cost = st.reference_cost = st.candidate_cost = cost;
   st.acc_ref = st.acc_cand = 0.0; st.num_nonmono = 0;
   st.radius = o.initial_radius; st.decrease_factor = 2.0;
-  st.iter = 0; st.n_success = 0; st.n_invalid = 0; st.phase = 1; st.step_valid = 0;
-  if (gmax <= o.gradient_tolerance) { st.done = 1; st.term = CC_CONVERGENCE_GRADIENT; }
-  else if (o.max_iterations <= 0) { st.done = 1; st.term = CC_NO_CONVERGENCE; }
+  st.iter = 0; st.n_success = 0; st.n_invalid = 0; st.phase = 1; st.step_valid = 0; st.cand_pending = 0;
+  st.sweeps = 1;
+  if (o.max_iterations <= 0) { st.done = 1; st.term = CC_NO_CONVERGENCE; }
 }
 
 // One LM iteration's decision. Inputs are the globally reduced quantities of the candidate point.
-// Returns 1 if the candidate was accepted (buffers must flip; done by toggling st.cur here).
-__device__ inline void lm_decide(LmState& st, const LmOpts& o, cc_iteration* log, int log_cap,
-                                 double cand_cost, double q_model, double step2, double xnorm2_cand,
-                                 double gmax_cand) {
+// An accepted candidate flips st.cur. The gradient-tolerance test of the new point is made by the
+// next solve kernel, which owns the reduced gradient (it also patches the log entry's gradient).
+__device__ inline void lm_decide(LmCtl& st, const LmOpts& o, cc_iteration* log, int log_cap,
+                                 double cand_cost, double q_model, double step2, double xnorm2_cand) {
   st.iter++;
+  if (st.step_valid) st.sweeps++;
   const double mcc = -q_model;
   const bool valid = st.step_valid && (mcc > 0.0) && isfinite(mcc);
   if (!valid) {
@@ -139,7 +141,6 @@ __device__ inline void lm_decide(LmState& st, const LmOpts& o, cc_iteration* log
         st.cur ^= 1;
         st.x_cost = cand_cost;
         st.x_norm = sqrt(xnorm2_cand);
-        st.gmax = gmax_cand;
         const double q3 = 2.0 * quality - 1.0;
         st.radius = fmin(o.max_radius, st.radius / fmax(1.0 / 3.0, 1.0 - q3 * q3 * q3));
         st.decrease_factor = 2.0;
@@ -158,7 +159,6 @@ __device__ inline void lm_decide(LmState& st, const LmOpts& o, cc_iteration* log
         if (st.num_nonmono == maxn) { st.reference_cost = st.candidate_cost; st.acc_ref = st.acc_cand; }
         st.n_success++;
         lm_log(st, log, log_cap, st.x_cost, cost_change, mcc, quality, step_norm, 1, 1);
-        if (st.gmax <= o.gradient_tolerance) { st.done = 1; st.term = CC_CONVERGENCE_GRADIENT; }
       } else {
         st.radius /= st.decrease_factor;
         st.decrease_factor *= 2.0;
@@ -171,6 +171,7 @@ __device__ inline void lm_decide(LmState& st, const LmOpts& o, cc_iteration* log
     else if (st.radius < o.min_radius) { st.done = 1; st.term = CC_MIN_RADIUS; }
   }
   st.step_valid = 0;
+  st.cand_pending = 0;
 }
 
 // ---- small device math -------------------------------------------------------------------

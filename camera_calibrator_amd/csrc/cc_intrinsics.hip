@@ -30,30 +30,37 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int kSweepThreads = 256;
-constexpr int kStageDoublesPerWave = 64 * 32;                       // 64 observations x 2 rows x 16
-constexpr int kSweepLdsBytes = 4 * kStageDoublesPerWave * 8 + 1024; // 4 waves of staging + scratch
-constexpr int kStatsCols = 32;
-constexpr int kZLStride = 96;
+constexpr int kStageDoublesPerWave = 64 * 16;  // 64 observations x one row (u or v) x 16 components
+constexpr int kSweepLdsBytes = (4 * kStageDoublesPerWave + 256) * 8;  // staging (reused for the block reduction) + prologue scratch
+constexpr int kStatsCols = 4;      // cost, q_model, step2, xnorm2
+constexpr int kYStride = 64;       // Y = A_pp^-1 [H_ps | g_p] (6 x 10) per frame
+constexpr int kPartialCols = 80;   // see k_intr_decide_elim
 constexpr int kElimMaxBlocks = 64;
+constexpr int kVecSolve = kPartialCols + 32;  // + one gmax slot per rank
 
-// stats columns written by the sweep, reduced by decide
-enum { ST_COST = 0, ST_QMODEL = 1, ST_STEP2 = 2, ST_XNORM2 = 3, ST_GMAXP = 4, ST_GS = 7, ST_HDIAG = 16 };
+enum { ST_COST = 0, ST_QMODEL = 1, ST_STEP2 = 2, ST_XNORM2 = 3 };
+// partial / vec_solve columns
+enum { PC_S = 0, PC_B = 45, PC_HDIAG = 54, PC_FAIL = 63, PC_GS = 64, PC_GMAXP = 73 };
 
 struct IntrDev {
   int64_t F, N;
   const float* uv;
   const float* xyz;
   const int64_t* off;
-  double* intr;     // [2][16]
-  double* pose;     // [2][F][8]
-  double* blocks;   // [2][F][256]
-  double* stats;    // [F][32]
-  double* sp;       // [F][8]  Jacobi scale of the pose block
-  double* ZL;       // [F][96] Z (6x10) then packed lower L (21)
-  double* partial;  // [kElimMaxBlocks][64]
-  double* vec_solve;   // [64]  reduced elimination sums (all-reduced across ranks)
-  double* vec_decide;  // [64]  reduced sweep statistics (all-reduced across ranks)
-  LmState* state;
+  double* intr;       // [2][16]
+  double* pose;       // [2][F][8]
+  double* blocks;     // [2][F][256]
+  double* stats;      // [F][4]
+  double* hd0;        // [F][16] diag of H_ss,f at the initial point (Jacobi scaling)
+  double* sp;         // [F][8]  Jacobi scale of the pose block
+  double* Y;          // [F][64]
+  double* partial;    // [kElimMaxBlocks][80]
+  double* vec_solve;  // [112] reduced elimination sums (all-reduced across ranks)
+  double* vec_decide; // [16]  reduced sweep statistics (all-reduced across ranks)
+  double* ds;         // [16] scaled shared step
+  double* ss;         // [16] Jacobi scale of the shared block
+  LmCtl* ctl;         // read by sweep / decide_elim, written by solve
+  LmCtl* ctl_next;    // written by decide_elim (block 0) and solve; polled by the host
   LmOpts* opts;
   cc_iteration* log;
   int32_t log_cap;
@@ -67,110 +74,180 @@ struct IntrDev {
 // (calibrator.cpp:70-95,183-219) with analytic derivatives.
 // k = fx fy px py k1 k2 p1 p2 k3 (calibrator.cpp:168-179); R = R(q/|q|).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void intr_rows(const double* k, const double* R, const double* t,
-                                          double X0, double X1, double X2, double u, double v,
-                                          uint32_t mask, double* vu, double* vv) {
-  const double a0 = R[0] * X0 + R[1] * X1 + R[2] * X2;
-  const double a1 = R[3] * X0 + R[4] * X1 + R[5] * X2;
-  const double a2 = R[6] * X0 + R[7] * X1 + R[8] * X2;
-  const double xc = a0 + t[0], yc = a1 + t[1], zc = a2 + t[2];
-  const double iz = 1.0 / zc;
-  const double x = xc * iz, y = yc * iz;
-  const double fx = k[0], fy = k[1], px = k[2], py = k[3];
+struct ObsCommon {  // per-observation quantities shared by the u-row and the v-row
+  double a0, a1, a2, x, y, iz, xy, r2, r4, r6, ax, ay, xd, yd, dxx, dxy, dyy;
+};
+
+__device__ __forceinline__ void obs_common(const double* k, const double* R, const double* t,
+                                           double X0, double X1, double X2, ObsCommon& c) {
+  c.a0 = R[0] * X0 + R[1] * X1 + R[2] * X2;
+  c.a1 = R[3] * X0 + R[4] * X1 + R[5] * X2;
+  c.a2 = R[6] * X0 + R[7] * X1 + R[8] * X2;
+  const double xc = c.a0 + t[0], yc = c.a1 + t[1], zc = c.a2 + t[2];
+  c.iz = 1.0 / zc;
+  c.x = xc * c.iz;
+  c.y = yc * c.iz;
   const double k1 = k[4], k2 = k[5], p1 = k[6], p2 = k[7], k3 = k[8];
-  const double xx = x * x, yy = y * y, xy = x * y;
-  const double r2 = xx + yy, r4 = r2 * r2, r6 = r4 * r2;
-  const double m = 1.0 + k1 * r2 + k2 * r4 + k3 * r6;
-  const double ax = r2 + 2.0 * xx, ay = r2 + 2.0 * yy;
-  const double xd = x * m + 2.0 * p1 * xy + p2 * ax;
-  const double yd = y * m + 2.0 * p2 * xy + p1 * ay;
-  vu[15] = fx * xd + px - u;
-  vv[15] = fy * yd + py - v;
-  vu[0] = xd;  vu[1] = 0.0; vu[2] = 1.0; vu[3] = 0.0;
-  vv[0] = 0.0; vv[1] = yd;  vv[2] = 0.0; vv[3] = 1.0;
-  const double fxx = fx * x, fyy = fy * y;
-  vu[4] = fxx * r2; vu[5] = fxx * r4; vu[6] = fx * 2.0 * xy; vu[7] = fx * ax; vu[8] = fxx * r6;
-  vv[4] = fyy * r2; vv[5] = fyy * r4; vv[6] = fy * ay; vv[7] = fy * 2.0 * xy; vv[8] = fyy * r6;
-  const double mp = k1 + 2.0 * k2 * r2 + 3.0 * k3 * r4;
-  const double dxx = m + 2.0 * mp * xx + 2.0 * p1 * y + 6.0 * p2 * x;
-  const double dxy = 2.0 * mp * xy + 2.0 * p1 * x + 2.0 * p2 * y;
-  const double dyy = m + 2.0 * mp * yy + 2.0 * p2 * x + 6.0 * p1 * y;
-  const double b00 = fx * dxx * iz, b01 = fx * dxy * iz, b02 = -(b00 * x + b01 * y);
-  const double b10 = fy * dxy * iz, b11 = fy * dyy * iz, b12 = -(b10 * x + b11 * y);
-  vu[9] = 2.0 * (b02 * a1 - b01 * a2); vu[10] = 2.0 * (b00 * a2 - b02 * a0); vu[11] = 2.0 * (b01 * a0 - b00 * a1);
-  vu[12] = b00; vu[13] = b01; vu[14] = b02;
-  vv[9] = 2.0 * (b12 * a1 - b11 * a2); vv[10] = 2.0 * (b10 * a2 - b12 * a0); vv[11] = 2.0 * (b11 * a0 - b10 * a1);
-  vv[12] = b10; vv[13] = b11; vv[14] = b12;
+  const double xx = c.x * c.x, yy = c.y * c.y;
+  c.xy = c.x * c.y;
+  c.r2 = xx + yy;
+  c.r4 = c.r2 * c.r2;
+  c.r6 = c.r4 * c.r2;
+  const double m = 1.0 + k1 * c.r2 + k2 * c.r4 + k3 * c.r6;
+  c.ax = c.r2 + 2.0 * xx;
+  c.ay = c.r2 + 2.0 * yy;
+  c.xd = c.x * m + 2.0 * p1 * c.xy + p2 * c.ax;
+  c.yd = c.y * m + 2.0 * p2 * c.xy + p1 * c.ay;
+  const double mp = k1 + 2.0 * k2 * c.r2 + 3.0 * k3 * c.r4;
+  c.dxx = m + 2.0 * mp * xx + 2.0 * p1 * c.y + 6.0 * p2 * c.x;
+  c.dxy = 2.0 * mp * c.xy + 2.0 * p1 * c.x + 2.0 * p2 * c.y;
+  c.dyy = m + 2.0 * mp * yy + 2.0 * p2 * c.x + 6.0 * p1 * c.y;
+}
+
+// row of the u residual: d (fx xd + px - u) / d [fx fy px py k1 k2 p1 p2 k3 | rot(3) t(3)], then r
+__device__ __forceinline__ void row_u(const double* k, const ObsCommon& c, double u, uint32_t mask, double* v) {
+  const double fx = k[0];
+  v[15] = fx * c.xd + k[2] - u;
+  v[0] = c.xd; v[1] = 0.0; v[2] = 1.0; v[3] = 0.0;
+  const double fxx = fx * c.x;
+  v[4] = fxx * c.r2; v[5] = fxx * c.r4; v[6] = fx * 2.0 * c.xy; v[7] = fx * c.ax; v[8] = fxx * c.r6;
+  const double b0 = fx * c.dxx * c.iz, b1 = fx * c.dxy * c.iz, b2 = -(b0 * c.x + b1 * c.y);
+  v[9] = 2.0 * (b2 * c.a1 - b1 * c.a2); v[10] = 2.0 * (b0 * c.a2 - b2 * c.a0); v[11] = 2.0 * (b1 * c.a0 - b0 * c.a1);
+  v[12] = b0; v[13] = b1; v[14] = b2;
 #pragma unroll
-  for (int c = 0; c < 9; ++c)
-    if (mask & (1u << c)) { vu[c] = 0.0; vv[c] = 0.0; }  // SubsetManifold (calibrator.cpp:305-312)
+  for (int j = 0; j < 9; ++j)
+    if (mask & (1u << j)) v[j] = 0.0;  // SubsetManifold (calibrator.cpp:305-312)
+}
+
+__device__ __forceinline__ void row_v(const double* k, const ObsCommon& c, double vm, uint32_t mask, double* v) {
+  const double fy = k[1];
+  v[15] = fy * c.yd + k[3] - vm;
+  v[0] = 0.0; v[1] = c.yd; v[2] = 0.0; v[3] = 1.0;
+  const double fyy = fy * c.y;
+  v[4] = fyy * c.r2; v[5] = fyy * c.r4; v[6] = fy * c.ay; v[7] = fy * 2.0 * c.xy; v[8] = fyy * c.r6;
+  const double b0 = fy * c.dxy * c.iz, b1 = fy * c.dyy * c.iz, b2 = -(b0 * c.x + b1 * c.y);
+  v[9] = 2.0 * (b2 * c.a1 - b1 * c.a2); v[10] = 2.0 * (b0 * c.a2 - b2 * c.a0); v[11] = 2.0 * (b1 * c.a0 - b0 * c.a1);
+  v[12] = b0; v[13] = b1; v[14] = b2;
+#pragma unroll
+  for (int j = 0; j < 9; ++j)
+    if (mask & (1u << j)) v[j] = 0.0;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// LDS accesses of one wave execute in order; the fence only stops the compiler from moving
+// the staged-row reads above the writes of other lanes (no instruction is emitted).
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+// stage one row per lane (16 doubles at row `lane`), 16-byte slots XOR-swizzled with (row & 7):
+// the ds_write_b128 groups (8 consecutive lanes) and the ds_read_b64 operand reads (two 32-lane
+// halves, each two consecutive rows) are both bank-conflict free.
+__device__ __forceinline__ void stage_row(double* stage, int lane, const double* v) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    d2 val;
+    val.x = v[2 * j];
+    val.y = v[2 * j + 1];
+    *reinterpret_cast<d2*>(&stage[lane * 16 + ((j ^ (lane & 7)) << 1)]) = val;
+  }
+}
+
+// 16 MFMAs over the 64 staged rows: MFMA m consumes rows 4m..4m+3; lane l supplies component
+// (l & 15) of row 4m + (l >> 4) as both the A[i][k] and the B[k][j] operand of the Gram product.
+__device__ __forceinline__ void gram_rows(const double* stage, int lane, d4& acc0, d4& acc1) {
+  const int c = lane & 15, sub = lane >> 4;
+#pragma unroll
+  for (int m = 0; m < 16; m += 2) {
+    const int r0 = 4 * m + sub, r1 = 4 * (m + 1) + sub;
+    const double a0 = stage[r0 * 16 + (((c >> 1) ^ (r0 & 7)) << 1) + (c & 1)];
+    const double a1 = stage[r1 * 16 + (((c >> 1) ^ (r1 & 7)) << 1) + (c & 1)];
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc1, 0, 0, 0);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
 // sweep: one workgroup (4 waves) per frame
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kSweepThreads, 2) void k_intr_sweep(IntrDev P) {
+__global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double* s_stage = reinterpret_cast<double*>(smem_raw);                 // [4][2048]
-  double* sm = s_stage + 4 * kStageDoublesPerWave;                        // [128] scratch
+  double* s_stage = reinterpret_cast<double*>(smem_raw);       // [4][1024]
+  double* s_blk = s_stage;                                      // [2048] cross-wave reduce + block copy (after the loop)
+  double* sm = s_stage + 4 * kStageDoublesPerWave;              // [256] prologue scratch
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t f = blockIdx.x;
-  LmState* st = P.state;
-  if (st->done) return;
-  const int phase = st->phase;
-  if (phase != 0 && !st->step_valid) return;
-  const int cur = st->cur, dst = phase == 0 ? cur : (cur ^ 1);
-  const double* intr_cur = P.intr + cur * 16;
-  const double* pose_cur = P.pose + ((size_t)cur * P.F + f) * 8;
+  const LmCtl* ctl = P.ctl;
+  if (ctl->done) return;
+  const int phase = ctl->phase;
+  if (phase != 0 && !ctl->step_valid) return;
+  const int cur = ctl->cur, dst = phase == 0 ? cur : (cur ^ 1);
 
-  // ---- prologue: candidate point of this frame -------------------------------------------
-  // sm[0..14] unscaled step (9 shared, 6 pose); sm[16..24] R; sm[25..27] t; sm[28..36] intr;
-  // sm[38] step^2; sm[39] |x_cand|^2 (pose part); sm[40..45] u
-  if (phase != 0 && tid < 6) {
-    const double* Z = P.ZL + f * kZLStride + tid * 10;
-    double u = Z[9];
+  // ---- prologue: candidate point of this frame. One global round trip gathers every input.
+  // sm[0..59] Y, [60..66] pose, [67..75] intr, [76..84] ds (scaled), [85..93] ss, [94..99] sp
+  // sm[100..114] unscaled step (9 shared, 6 pose); sm[116..124] R; [125..127] t; [128..136] intr_cand
+  // sm[138] step^2 (pose part), sm[139] |x_cand|^2 (pose part)
+  double g_old = 0.0;
+  if (tid < 100) {
+    double v;
+    if (tid < 60) v = phase != 0 ? P.Y[f * kYStride + tid] : 0.0;
+    else if (tid < 67) v = P.pose[((size_t)cur * P.F + f) * 8 + (tid - 60)];
+    else if (tid < 76) v = P.intr[cur * 16 + (tid - 67)];
+    else if (tid < 85) v = phase != 0 ? P.ds[tid - 76] : 0.0;
+    else if (tid < 94) v = phase != 0 ? P.ss[tid - 85] : 0.0;
+    else v = phase != 0 ? P.sp[f * 8 + (tid - 94)] : 0.0;
+    sm[tid] = v;
+  }
+  if (phase != 0) g_old = P.blocks[((size_t)cur * P.F + f) * 256 + tid];
+  __syncthreads();
+  if (tid < 6) {
+    const double* Yr = sm + tid * 10;
+    double a = Yr[9];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) u += Z[j] * st->ds[j];
-    sm[40 + tid] = u;
+    for (int j = 0; j < 9; ++j) a += Yr[j] * sm[76 + j];
+    sm[109 + tid] = -a * sm[94 + tid];
+  } else if (tid >= 8 && tid < 17) {
+    const int j = tid - 8;
+    const double d = (P.mask & (1u << j)) ? 0.0 : sm[76 + j] * sm[85 + j];
+    sm[100 + j] = d;
+    const double kc = sm[67 + j] + d;
+    sm[128 + j] = kc;
+    if (f == 0 && phase != 0) P.intr[dst * 16 + j] = kc;
   }
   __syncthreads();
   if (tid == 0) {
-    double q[4], t[3], kk[9];
-    for (int i = 0; i < 4; ++i) q[i] = pose_cur[i];
-    for (int i = 0; i < 3; ++i) t[i] = pose_cur[4 + i];
-    for (int i = 0; i < 9; ++i) kk[i] = intr_cur[i];
+    double q[4], t[3], dp[6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = sm[60 + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = sm[64 + i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dp[i] = sm[109 + i];
     double step2 = 0.0;
     if (phase != 0) {
-      const double* L = P.ZL + f * kZLStride + 60;  // packed lower: L[i(i+1)/2 + j]
-      double xs[6];
-      for (int i = 5; i >= 0; --i) {
-        double s = sm[40 + i];
-        for (int k2 = i + 1; k2 < 6; ++k2) s -= L[k2 * (k2 + 1) / 2 + i] * xs[k2];
-        xs[i] = s / L[i * (i + 1) / 2 + i];
-      }
-      double dp[6];
-      for (int i = 0; i < 6; ++i) { dp[i] = -xs[i] * P.sp[f * 8 + i]; sm[9 + i] = dp[i]; }
-      for (int j = 0; j < 9; ++j) {
-        const double d = (P.mask & (1u << j)) ? 0.0 : st->ds[j] * st->ss[j];
-        sm[j] = d;
-        kk[j] += d;
-      }
       double qn[4];
       quat_plus(q, dp, qn);
+#pragma unroll
       for (int i = 0; i < 4; ++i) { const double d = qn[i] - q[i]; step2 += d * d; q[i] = qn[i]; }
+#pragma unroll
       for (int i = 0; i < 3; ++i) { const double tn = t[i] + dp[3 + i]; const double d = tn - t[i]; step2 += d * d; t[i] = tn; }
       double* pose_dst = P.pose + ((size_t)dst * P.F + f) * 8;
+#pragma unroll
       for (int i = 0; i < 4; ++i) pose_dst[i] = q[i];
+#pragma unroll
       for (int i = 0; i < 3; ++i) pose_dst[4 + i] = t[i];
-      if (f == 0) for (int i = 0; i < 9; ++i) P.intr[dst * 16 + i] = kk[i];
     }
     double R[9];
     quat_to_R(q, R);
-    for (int i = 0; i < 9; ++i) sm[16 + i] = R[i];
-    for (int i = 0; i < 3; ++i) sm[25 + i] = t[i];
-    for (int i = 0; i < 9; ++i) sm[28 + i] = kk[i];
-    sm[38] = step2;
-    sm[39] = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + t[0] * t[0] + t[1] * t[1] + t[2] * t[2];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) sm[116 + i] = R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) sm[125 + i] = t[i];
+    sm[138] = step2;
+    sm[139] = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + t[0] * t[0] + t[1] * t[1] + t[2] * t[2];
   }
   __syncthreads();
 
@@ -179,212 +256,212 @@ __global__ __launch_bounds__(kSweepThreads, 2) void k_intr_sweep(IntrDev P) {
   double qterm = 0.0;
   if (phase != 0) {
     const int a = tid >> 4, b = tid & 15;
-    const double g = P.blocks[((size_t)cur * P.F + f) * 256 + tid];
-    if (a < 15) qterm = b < 15 ? 0.5 * sm[a] * g * sm[b] : sm[a] * g;
+    if (a < 15) qterm = b < 15 ? 0.5 * sm[100 + a] * g_old * sm[100 + b] : sm[100 + a] * g_old;
   }
 
   double R[9], tt[3], kk[9];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) R[i] = rfl(sm[16 + i]);
+  for (int i = 0; i < 9; ++i) R[i] = rfl(sm[116 + i]);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) tt[i] = rfl(sm[25 + i]);
+  for (int i = 0; i < 3; ++i) tt[i] = rfl(sm[125 + i]);
 #pragma unroll
-  for (int i = 0; i < 9; ++i) kk[i] = rfl(sm[28 + i]);
+  for (int i = 0; i < 9; ++i) kk[i] = rfl(sm[128 + i]);
   const uint32_t mask = P.mask;
 
-  // ---- main loop: 64 observations per wave per pass ----------------------------------------
+  // ---- main loop: 64 observations per wave per pass, no workgroup barrier -------------------
   const int64_t s0 = P.off[f], s1 = P.off[f + 1];
   const int npass = (int)((s1 - s0 + kSweepThreads - 1) / kSweepThreads);
   double* stage = s_stage + wave * kStageDoublesPerWave;
   const float2* uv2 = reinterpret_cast<const float2*>(P.uv);
-  d4 acc = {0.0, 0.0, 0.0, 0.0};
+  d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
   for (int p = 0; p < npass; ++p) {
     const int64_t idx = s0 + (int64_t)p * kSweepThreads + tid;
-    double vu[16], vv[16];
-    if (idx < s1) {
-      const float2 m = uv2[idx];
-      const float X0 = P.xyz[idx * 3], X1 = P.xyz[idx * 3 + 1], X2 = P.xyz[idx * 3 + 2];
-      intr_rows(kk, R, tt, (double)X0, (double)X1, (double)X2, (double)m.x, (double)m.y, mask, vu, vv);
-    } else {
+    const bool valid = idx < s1;  // only the last pass of a frame has idle lanes
+    const int64_t ic = valid ? idx : s0;
+    const float2 m = uv2[ic];
+    const float X0 = P.xyz[ic * 3], X1 = P.xyz[ic * 3 + 1], X2 = P.xyz[ic * 3 + 2];
+    ObsCommon oc;
+    obs_common(kk, R, tt, (double)X0, (double)X1, (double)X2, oc);
+    double v[16];
+    row_u(kk, oc, (double)m.x, mask, v);
+    if (!valid) {
 #pragma unroll
-      for (int c = 0; c < 16; ++c) { vu[c] = 0.0; vv[c] = 0.0; }
+      for (int c = 0; c < 16; ++c) v[c] = 0.0;
     }
-    // stage rows: lane o owns doubles [32 o, 32 o + 32); 16-byte slot j is XOR-swizzled with
-    // (o & 15) so both the b128 writes and the b64 MFMA-operand reads are bank-conflict free.
+    stage_row(stage, lane, v);
+    wave_lds_fence();
+    gram_rows(stage, lane, acc0, acc1);
+    wave_lds_fence();
+    row_v(kk, oc, (double)m.y, mask, v);
+    if (!valid) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      d2 val;
-      if (j < 8) { val.x = vu[2 * j]; val.y = vu[2 * j + 1]; }
-      else { val.x = vv[2 * j - 16]; val.y = vv[2 * j - 15]; }
-      *reinterpret_cast<d2*>(&stage[lane * 32 + ((j ^ (lane & 15)) << 1)]) = val;
+      for (int c = 0; c < 16; ++c) v[c] = 0.0;
     }
-    __syncthreads();
-    // MFMA m consumes rows 4m..4m+3 = observations 2m, 2m+1; lane l supplies component (l & 15)
-    // of row (l >> 4): A[i][k] and B[k][j] coincide for the Gram product.
-    const int pp = lane & 31, jj = pp >> 1, hh = pp & 1;
-#pragma unroll 8
-    for (int m = 0; m < 32; ++m) {
-      const int o = 2 * m + (lane >> 5);
-      const double a = stage[o * 32 + ((jj ^ (o & 15)) << 1) + hh];
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
-    }
-    __syncthreads();
+    stage_row(stage, lane, v);
+    wave_lds_fence();
+    gram_rows(stage, lane, acc0, acc1);
+    wave_lds_fence();
   }
 
   // ---- cross-wave reduction of the 16x16 block + model-cost term ---------------------------
   // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
-  double* red = s_stage;  // [4][256] + [256] q terms
+  __syncthreads();  // s_blk aliases the staging buffers
 #pragma unroll
-  for (int r = 0; r < 4; ++r) red[wave * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[r];
-  red[1024 + tid] = qterm;
+  for (int r = 0; r < 4; ++r) s_blk[wave * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc0[r] + acc1[r];
+  const double qw = wave_sum(qterm);
+  if (lane == 0) sm[140 + wave] = qw;
   __syncthreads();
-  const double g = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];
+  const double g = (s_blk[tid] + s_blk[256 + tid]) + (s_blk[512 + tid] + s_blk[768 + tid]);
   P.blocks[((size_t)dst * P.F + f) * 256 + tid] = g;
-  // q_f: tree over 256 terms (deterministic order)
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s) red[1024 + tid] += red[1024 + tid + s];
-    __syncthreads();
-  }
-  double* G = s_stage + 2048;  // full block for the stats threads
+  double* G = s_blk + 1024;  // full block for the few threads that derive per-frame scalars
   G[tid] = g;
   __syncthreads();
-  if (tid < kStatsCols) {
-    double v = 0.0;
-    if (tid == ST_COST) v = 0.5 * G[255];
-    else if (tid == ST_QMODEL) v = red[1024];
-    else if (tid == ST_STEP2) v = sm[38];
-    else if (tid == ST_XNORM2) v = sm[39];
-    else if (tid == ST_GMAXP) {
-      for (int i = 0; i < 6; ++i) v = fmax(v, fabs(G[(9 + i) * 16 + 15]));
-    } else if (tid >= ST_GS && tid < ST_GS + 9) v = G[(tid - ST_GS) * 16 + 15];
-    else if (tid >= ST_HDIAG && tid < ST_HDIAG + 9) v = G[(tid - ST_HDIAG) * 17];
-    P.stats[f * kStatsCols + tid] = v;
-  }
-  if (phase == 0 && tid < 6)
-    P.sp[f * 8 + tid] = P.opts->jacobi_scaling ? 1.0 / (1.0 + sqrt(G[(9 + tid) * 17])) : 1.0;
-}
-
-// ---------------------------------------------------------------------------------------------
-// decide: MODE 0 = reduce + decide (single GPU), 1 = reduce only (-> vec_decide), 2 = decide only
-// vec_decide layout: [0..31] column sums of stats (col ST_GMAXP unused), [32 + rank] local gmax_p
-// ---------------------------------------------------------------------------------------------
-constexpr int kDecideThreads = 1024;
-constexpr int kStateDoubles = (int)(sizeof(LmState) / sizeof(double));
-static_assert(sizeof(LmState) % sizeof(double) == 0, "LmState must be a whole number of doubles");
-
-template <int MODE>
-__global__ __launch_bounds__(kDecideThreads) void k_intr_decide(IntrDev P) {
-  __shared__ double red[32][kStatsCols];
-  __shared__ double sv[64];
-  __shared__ LmState sst;  // the state machine works on an LDS copy: one global round trip each way
-  const int tid = threadIdx.x;
-  if (tid < kStateDoubles) reinterpret_cast<double*>(&sst)[tid] = reinterpret_cast<const double*>(P.state)[tid];
-  __syncthreads();
-  if (sst.done) return;
-  LmState* st = &sst;
-  if (MODE != 2) {
-    const bool skip = st->phase != 0 && !st->step_valid;  // sweep did not run: stats are stale
-    const int col = tid & 31, grp = tid >> 5;
-    double a = 0.0;
-    if (!skip) {
-      // 32 row groups; 8 independent loads in flight per thread
-      const double* base = P.stats + col;
-      if (col == ST_GMAXP) {
-        for (int64_t f = grp; f < P.F; f += 32) a = fmax(a, base[f * kStatsCols]);
-      } else {
-        double acc8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        int64_t f = grp;
-        for (; f + 7 * 32 < P.F; f += 8 * 32) {
-#pragma unroll
-          for (int u = 0; u < 8; ++u) acc8[u] += base[(f + u * 32) * kStatsCols];
-        }
-        for (int u = 0; f < P.F; f += 32, ++u) acc8[u] += base[f * kStatsCols];
-        a = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
-      }
-    }
-    red[grp][col] = a;
-    if (tid < 64) sv[tid] = 0.0;
-    __syncthreads();
-    if (tid < 32) {
-      double v = 0.0;
-      if (tid == ST_GMAXP) {
-        for (int g2 = 0; g2 < 32; ++g2) v = fmax(v, red[g2][tid]);
-        sv[32 + P.rank] = v;  // per-rank slot: a sum all-reduce then carries the max
-      } else {
-        for (int g2 = 0; g2 < 32; ++g2) v += red[g2][tid];
-        sv[tid] = v;
-      }
-    }
-    __syncthreads();
-    if (MODE == 1) {
-      if (tid < 64) P.vec_decide[tid] = sv[tid];
-      return;
-    }
-  } else {
-    if (tid < 64) sv[tid] = P.vec_decide[tid];
-    __syncthreads();
-  }
   if (tid == 0) {
-    const double* V = sv;
-    const LmOpts o = *P.opts;
-    double gmax_p = 0.0;
-    for (int r = 0; r < P.nranks && r < 32; ++r) gmax_p = fmax(gmax_p, V[32 + r]);
-    if (st->phase == 0) {
-      const double* k = P.intr + st->cur * 16;
-      double xn2 = V[ST_XNORM2], gmax = gmax_p;
-      for (int i = 0; i < 9; ++i) {
-        xn2 += k[i] * k[i];
-        if (!(P.mask & (1u << i))) gmax = fmax(gmax, fabs(V[ST_GS + i]));
-        st->ss[i] = o.jacobi_scaling ? 1.0 / (1.0 + sqrt(V[ST_HDIAG + i])) : 1.0;
-      }
-      st->sweeps = 1;
-      lm_init(*st, o, V[ST_COST], sqrt(xn2), gmax);
-    } else {
-      const int cand = st->cur ^ 1;
-      const double* kc = P.intr + cand * 16;
-      const double* k0 = P.intr + st->cur * 16;
-      double step2 = V[ST_STEP2], xn2 = V[ST_XNORM2], gmax = gmax_p;
-      if (st->step_valid) {
-        st->sweeps++;
-        for (int i = 0; i < 9; ++i) {
-          const double d = kc[i] - k0[i];
-          step2 += d * d;
-          xn2 += kc[i] * kc[i];
-          if (!(P.mask & (1u << i))) gmax = fmax(gmax, fabs(V[ST_GS + i]));
-        }
-      }
-      lm_decide(*st, o, P.log, P.log_cap, V[ST_COST], V[ST_QMODEL], step2, xn2, gmax);
-    }
+    double* st = P.stats + f * kStatsCols;
+    st[ST_COST] = 0.5 * G[255];
+    st[ST_QMODEL] = (sm[140] + sm[141]) + (sm[142] + sm[143]);
+    st[ST_STEP2] = sm[138];
+    st[ST_XNORM2] = sm[139];
   }
-  __syncthreads();
-  if (tid < kStateDoubles) reinterpret_cast<double*>(P.state)[tid] = reinterpret_cast<const double*>(&sst)[tid];
+  if (phase == 0) {
+    if (tid < 6) P.sp[f * 8 + tid] = P.opts->jacobi_scaling ? 1.0 / (1.0 + sqrt(G[(9 + tid) * 17])) : 1.0;
+    else if (tid >= 16 && tid < 25) P.hd0[f * 16 + (tid - 16)] = G[(tid - 16) * 17];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
-// elim: 16 lanes per frame. Output slots (64): [0..44] upper triangle of the reduced 9x9 system
-// (row-major pairs j<=k), [45..53] reduced rhs, [54..62] diag of the scaled H_ss, [63] failures.
+// stats reduction over frames (column sums of stats[F][4] and, in phase 0, hd0[F][16]).
+// Deterministic: fixed assignment of rows to threads, fixed combination tree.
+// Result: out[0..3] stats sums, out[4..12] sum of hd0 columns 0..8 (zero when !want_hd).
+// All threads of the 256-thread block must call; result valid for every thread after return.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void reduce_frame_stats(const IntrDev& P, bool want_stats, bool want_hd,
+                                                   double* s_w /*[4][16]*/, double* out /*[16] shared*/) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // stats: thread t -> column t & 3, row group t >> 2 (64 groups)
+  double a = 0.0;
+  if (want_stats) {
+    const int col = tid & 3;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int64_t f = tid >> 2;
+    for (; f + 3 * 64 < P.F; f += 4 * 64) {
+      a0 += P.stats[f * kStatsCols + col];
+      a1 += P.stats[(f + 64) * kStatsCols + col];
+      a2 += P.stats[(f + 128) * kStatsCols + col];
+      a3 += P.stats[(f + 192) * kStatsCols + col];
+    }
+    for (; f < P.F; f += 64) a0 += P.stats[f * kStatsCols + col];
+    a = (a0 + a1) + (a2 + a3);
+  }
+  // combine the 16 row groups of a wave that share a column (lane bits 2..5)
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
+  double h = 0.0;
+  if (want_hd) {
+    // hd0: thread t -> column t & 15, row group t >> 4 (16 groups)
+    const int col = tid & 15;
+    double h0 = 0, h1 = 0;
+    int64_t f = tid >> 4;
+    for (; f + 16 < P.F; f += 32) { h0 += P.hd0[f * 16 + col]; h1 += P.hd0[(f + 16) * 16 + col]; }
+    for (; f < P.F; f += 16) h0 += P.hd0[f * 16 + col];
+    h = h0 + h1;
+  }
+#pragma unroll
+  for (int o = 16; o < 64; o <<= 1) h += __shfl_xor(h, o, 64);
+  if (lane < 4) s_w[wave * 16 + lane] = a;
+  if (lane < 9) s_w[64 + wave * 16 + lane] = h;
+  __syncthreads();
+  if (tid < 4) out[tid] = (s_w[tid] + s_w[16 + tid]) + (s_w[32 + tid] + s_w[48 + tid]);
+  else if (tid >= 4 && tid < 13) {
+    const int c = tid - 4;
+    out[tid] = (s_w[64 + c] + s_w[64 + 16 + c]) + (s_w[64 + 32 + c] + s_w[64 + 48 + c]);
+  }
+  __syncthreads();
+}
+
+// multi-GPU only: local reduction -> vec_decide, which is then all-reduced
+__global__ __launch_bounds__(256) void k_intr_stats_reduce(IntrDev P) {
+  __shared__ double s_w[128];
+  __shared__ double s_out[16];
+  const LmCtl* ctl = P.ctl;
+  if (ctl->done) return;
+  const int phase = ctl->phase;
+  const bool need = phase == 0 || (ctl->cand_pending && ctl->step_valid);
+  reduce_frame_stats(P, need, phase == 0, s_w, s_out);
+  if (threadIdx.x < 16) P.vec_decide[threadIdx.x] = (need && threadIdx.x < 13) ? s_out[threadIdx.x] : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// decide + elim.  Every block reduces the (small) per-frame statistics itself and takes the same
+// trust-region decision on a register copy of the control block; block 0 publishes it. Then the
+// block eliminates the pose blocks of its frames: 16 lanes per frame.
+// Output row per block (80 columns): [0..44] upper triangle of the reduced 9x9 system (row-major
+// pairs j<=k), [45..53] reduced rhs, [54..62] diag of the scaled H_ss, [63] Cholesky failures,
+// [64..72] unscaled shared gradient, [73] max |pose gradient| (max-combined), rest 0.
+// MODE 0: reduce stats inline (single GPU); MODE 2: stats come all-reduced in vec_decide.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // i >= j
 
-__global__ __launch_bounds__(256) void k_intr_elim(IntrDev P) {
+template <int MODE>
+__global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P) {
   __shared__ double Zs[16][64];
-  __shared__ double red[16][64];
+  __shared__ double red[16][kPartialCols];
+  __shared__ double s_w[128];
+  __shared__ double s_tot[16];
   __shared__ double s_ss[16];
+  __shared__ LmCtl s_ctl;
   __shared__ unsigned char pj[48], pk[48];
-  LmState* st = P.state;
-  if (st->done) return;
   const int tid = threadIdx.x, g = tid >> 4, l = tid & 15;
-  const int cur = st->cur;
-  const double radius = st->radius;
-  const double mn = P.opts->min_lm_diagonal, mx = P.opts->max_lm_diagonal;
-  if (tid < 16) s_ss[tid] = tid < 9 ? st->ss[tid] : 0.0;
+  const LmCtl* ctl = P.ctl;
+  if (ctl->done) return;
+  const int phase = ctl->phase;
+  const bool pending = ctl->cand_pending != 0;
+  const bool need = phase == 0 || (pending && ctl->step_valid);
+  if (MODE == 0) {
+    reduce_frame_stats(P, need, phase == 0, s_w, s_tot);
+  } else {
+    if (tid < 16) s_tot[tid] = P.vec_decide[tid];
+    __syncthreads();
+  }
   if (tid == 0) {
+    LmCtl c = *ctl;
+    const LmOpts o = *P.opts;
+    cc_iteration* log = blockIdx.x == 0 ? P.log : nullptr;
+    if (phase == 0) {
+      const double* k = P.intr + c.cur * 16;
+      double xn2 = s_tot[ST_XNORM2];
+      for (int i = 0; i < 9; ++i) {
+        xn2 += k[i] * k[i];
+        const double sc = o.jacobi_scaling ? 1.0 / (1.0 + sqrt(s_tot[4 + i])) : 1.0;
+        s_ss[i] = sc;
+        if (blockIdx.x == 0) P.ss[i] = sc;
+      }
+      lm_init(c, o, s_tot[ST_COST], sqrt(xn2));
+    } else if (pending) {
+      double step2 = s_tot[ST_STEP2], xn2 = s_tot[ST_XNORM2];
+      if (c.step_valid) {
+        const double* kc = P.intr + (c.cur ^ 1) * 16;
+        const double* k0 = P.intr + c.cur * 16;
+        for (int i = 0; i < 9; ++i) { const double d = kc[i] - k0[i]; step2 += d * d; xn2 += kc[i] * kc[i]; }
+      }
+      lm_decide(c, o, log, P.log_cap, s_tot[ST_COST], s_tot[ST_QMODEL], step2, xn2);
+    }
+    s_ctl = c;
+    if (blockIdx.x == 0) *P.ctl_next = c;
+  }
+  if (phase != 0 && tid < 9) s_ss[tid] = P.ss[tid];
+  if (tid == 32) {
     int o = 0;
     for (int j = 0; j < 9; ++j)
       for (int k = j; k < 9; ++k) { pj[o] = (unsigned char)j; pk[o] = (unsigned char)k; ++o; }
   }
   __syncthreads();
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  if (s_ctl.done) return;
+  const int cur = s_ctl.cur;
+  const double radius = s_ctl.radius;
+  const double mn = P.opts->min_lm_diagonal, mx = P.opts->max_lm_diagonal;
+
+  double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // slots l*5 + r
   for (int64_t base = (int64_t)blockIdx.x * 16; base < P.F; base += (int64_t)gridDim.x * 16) {
     const int64_t f = base + g;
     const bool valid = f < P.F;
@@ -400,7 +477,7 @@ __global__ __launch_bounds__(256) void k_intr_elim(IntrDev P) {
         for (int j = 0; j <= i; ++j) L[tri(i, j)] = s[i] * G[(9 + i) * 16 + 9 + j] * s[j];
 #pragma unroll
       for (int i = 0; i < 6; ++i) L[tri(i, i)] += clampd(L[tri(i, i)], mn, mx) / radius;
-      // in-place Cholesky (lower), fully unrolled so L stays in registers
+      // in-place Cholesky (lower), fully unrolled so L stays in registers (redundant per lane)
       bool ok = true;
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
@@ -421,9 +498,10 @@ __global__ __launch_bounds__(256) void k_intr_elim(IntrDev P) {
       }
       if (!ok) fail = 1.0;
       if (l < 10) {
+        // column l of [H_ps | g_p]: z = L^-1 w (for the Schur sums), y = L^-T z (for the back-substitution)
         const int col = l < 9 ? l : 15;
         const double sc = l < 9 ? s_ss[l] : 1.0;
-        double z[6];
+        double z[6], y[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
           double a = s[i] * G[(9 + i) * 16 + col] * sc;
@@ -432,22 +510,25 @@ __global__ __launch_bounds__(256) void k_intr_elim(IntrDev P) {
           z[i] = a / L[tri(i, i)];
         }
 #pragma unroll
+        for (int i = 5; i >= 0; --i) {
+          double a = z[i];
+#pragma unroll
+          for (int k = i + 1; k < 6; ++k) a -= L[tri(k, i)] * y[k];
+          y[i] = a / L[tri(i, i)];
+        }
+#pragma unroll
         for (int i = 0; i < 6; ++i) {
           Zs[g][i * 10 + l] = z[i];
-          P.ZL[f * kZLStride + i * 10 + l] = z[i];
+          P.Y[f * kYStride + i * 10 + l] = y[i];
         }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 21; ++e)
-          if (l == 10 + (e >> 2)) P.ZL[f * kZLStride + 60 + e] = L[e];
       }
     }
     __syncthreads();
     if (valid) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int o = l * 4 + r;
-        double a;
+      for (int r = 0; r < 5; ++r) {
+        const int o = l * 5 + r;
+        double a = 0.0;
         if (o < 45) {
           const int j = pj[o], k = pk[o];
           a = s_ss[j] * G[j * 16 + k] * s_ss[k];
@@ -461,98 +542,156 @@ __global__ __launch_bounds__(256) void k_intr_elim(IntrDev P) {
         } else if (o < 63) {
           const int j = o - 54;
           a = s_ss[j] * s_ss[j] * G[j * 17];
-        } else {
+        } else if (o == PC_FAIL) {
           a = fail;
+        } else if (o < PC_GS + 9) {
+          a = G[(o - PC_GS) * 16 + 15];
+        } else if (o == PC_GMAXP) {
+          for (int i = 0; i < 6; ++i) a = fmax(a, fabs(G[(9 + i) * 16 + 15]));
         }
-        acc[r] += a;
+        if (o == PC_GMAXP) acc[r] = fmax(acc[r], a); else acc[r] += a;
       }
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) red[g][l * 4 + r] = acc[r];
+  for (int r = 0; r < 5; ++r) red[g][l * 5 + r] = acc[r];
   __syncthreads();
-  if (tid < 64) {
+  if (tid < kPartialCols) {
     double a = 0.0;
-    for (int g2 = 0; g2 < 16; ++g2) a += red[g2][tid];
-    P.partial[blockIdx.x * 64 + tid] = a;
+    if (tid == PC_GMAXP) { for (int g2 = 0; g2 < 16; ++g2) a = fmax(a, red[g2][tid]); }
+    else { for (int g2 = 0; g2 < 16; ++g2) a += red[g2][tid]; }
+    P.partial[blockIdx.x * kPartialCols + tid] = a;
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// solve: MODE 0 = reduce + solve, 1 = reduce only (-> vec_solve), 2 = solve only
+// solve (one block): reduce the elimination partials, add the LM diagonal, 9x9 Cholesky in
+// registers, gradient-tolerance test of the accepted point; publishes the control block for the
+// sweep. MODE 0: reduce + solve; 1: reduce only (-> vec_solve, then all-reduced); 2: solve only.
+// vec_solve: [0..79] column sums (col 73 unused), [80 + rank] this rank's max |pose gradient|.
 // ---------------------------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(64) void k_intr_solve(IntrDev P, int nblk) {
-  __shared__ double sv[64];
-  __shared__ double S[81];
-  __shared__ double b[9];
-  LmState* st = P.state;
-  if (st->done) return;
+__global__ __launch_bounds__(128) void k_intr_solve(IntrDev P, int nblk) {
+  __shared__ double sv[kVecSolve];
   const int tid = threadIdx.x;
-  const double radius = st->radius;
-  const double mn = P.opts->min_lm_diagonal, mx = P.opts->max_lm_diagonal;
+  const LmCtl* cn = P.ctl_next;
+  const int done = cn->done, phase = cn->phase;
+  const bool active = !done && phase != 0;
   if (MODE != 2) {
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int bb = 0;
-    for (; bb + 3 < nblk; bb += 4) {
-      a0 += P.partial[bb * 64 + tid]; a1 += P.partial[(bb + 1) * 64 + tid];
-      a2 += P.partial[(bb + 2) * 64 + tid]; a3 += P.partial[(bb + 3) * 64 + tid];
+    if (tid < kVecSolve) sv[tid] = 0.0;
+    __syncthreads();
+    if (active && tid < kPartialCols) {
+      double a;
+      if (tid == PC_GMAXP) {
+        a = 0.0;
+        for (int b = 0; b < nblk; ++b) a = fmax(a, P.partial[b * kPartialCols + tid]);
+        sv[kPartialCols + P.rank] = a;
+      } else {
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        int b = 0;
+        for (; b + 3 < nblk; b += 4) {
+          a0 += P.partial[b * kPartialCols + tid]; a1 += P.partial[(b + 1) * kPartialCols + tid];
+          a2 += P.partial[(b + 2) * kPartialCols + tid]; a3 += P.partial[(b + 3) * kPartialCols + tid];
+        }
+        for (; b < nblk; ++b) a0 += P.partial[b * kPartialCols + tid];
+        sv[tid] = (a0 + a1) + (a2 + a3);
+      }
     }
-    for (; bb < nblk; ++bb) a0 += P.partial[bb * 64 + tid];
-    const double a = (a0 + a1) + (a2 + a3);
-    sv[tid] = a;
-    if (MODE == 1) { P.vec_solve[tid] = a; return; }
+    __syncthreads();
+    if (MODE == 1) {
+      if (tid < kVecSolve) P.vec_solve[tid] = sv[tid];
+      return;
+    }
   } else {
-    sv[tid] = P.vec_solve[tid];
+    if (tid < kVecSolve) sv[tid] = P.vec_solve[tid];
+    __syncthreads();
   }
-  __syncthreads();
   if (tid != 0) return;
-  const double* V = sv;
-  bool ok = !(V[63] > 0.0);
-  int idx = 0;
-  for (int j = 0; j < 9; ++j)
-    for (int k = j; k < 9; ++k) { S[j * 9 + k] = S[k * 9 + j] = V[idx]; ++idx; }
-  for (int j = 0; j < 9; ++j) {
-    S[j * 9 + j] += clampd(V[54 + j], mn, mx) / radius;
-    b[j] = V[45 + j];
+  LmCtl c = *cn;
+  if (active) {
+    const LmOpts o = *P.opts;
+    const double* V = sv;
+    // gradient of the accepted point: max-norm over the tangent coordinates
+    double gmax = 0.0;
+    for (int r = 0; r < P.nranks && r < 32; ++r) gmax = fmax(gmax, V[kPartialCols + r]);
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+      if (!(P.mask & (1u << j))) gmax = fmax(gmax, fabs(V[PC_GS + j]));
+    c.gmax = gmax;
+    if (c.log_len > 0 && c.log_len <= P.log_cap && P.log[c.log_len - 1].accepted)
+      P.log[c.log_len - 1].gradient_max_norm = gmax;
+    if (gmax <= o.gradient_tolerance) {
+      c.done = 1;
+      c.term = CC_CONVERGENCE_GRADIENT;
+    } else {
+      bool ok = !(V[PC_FAIL] > 0.0);
+      double A[45], b[9];
+      {
+        int idx = 0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+#pragma unroll
+          for (int k = j; k < 9; ++k) { A[tri(k, j)] = V[idx]; ++idx; }
+      }
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        A[tri(j, j)] += clampd(V[PC_HDIAG + j], o.min_lm_diagonal, o.max_lm_diagonal) / c.radius;
+        b[j] = V[PC_B + j];
+      }
+#pragma unroll
+      for (int j = 0; j < 9; ++j)
+        if (P.mask & (1u << j)) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) {
+            if (k < j) A[tri(j, k)] = 0.0;
+            if (k > j) A[tri(k, j)] = 0.0;
+          }
+          A[tri(j, j)] = 1.0;
+          b[j] = 0.0;
+        }
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        double d = A[tri(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= A[tri(j, k)] * A[tri(j, k)];
+        ok = ok && (d > 0.0) && isfinite(d);
+        d = sqrt(d);
+        A[tri(j, j)] = d;
+        const double inv = 1.0 / d;
+#pragma unroll
+        for (int i = j + 1; i < 9; ++i) {
+          double a = A[tri(i, j)];
+#pragma unroll
+          for (int k = 0; k < j; ++k) a -= A[tri(i, k)] * A[tri(j, k)];
+          A[tri(i, j)] = a * inv;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        double a = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) a -= A[tri(i, k)] * b[k];
+        b[i] = a / A[tri(i, i)];
+      }
+#pragma unroll
+      for (int i = 8; i >= 0; --i) {
+        double a = b[i];
+#pragma unroll
+        for (int k = i + 1; k < 9; ++k) a -= A[tri(k, i)] * b[k];
+        b[i] = a / A[tri(i, i)];
+      }
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        P.ds[i] = -b[i];
+        ok = ok && isfinite(b[i]);
+      }
+      c.step_valid = ok ? 1 : 0;
+      c.cand_pending = 1;
+    }
   }
-  for (int j = 0; j < 9; ++j)
-    if (P.mask & (1u << j)) {
-      for (int k = 0; k < 9; ++k) S[j * 9 + k] = S[k * 9 + j] = 0.0;
-      S[j * 9 + j] = 1.0;
-      b[j] = 0.0;
-    }
-  for (int j = 0; j < 9 && ok; ++j) {
-    double d = S[j * 9 + j];
-    for (int k = 0; k < j; ++k) d -= S[j * 9 + k] * S[j * 9 + k];
-    if (!(d > 0.0) || !isfinite(d)) { ok = false; break; }
-    d = sqrt(d);
-    S[j * 9 + j] = d;
-    const double inv = 1.0 / d;
-    for (int i = j + 1; i < 9; ++i) {
-      double a = S[i * 9 + j];
-      for (int k = 0; k < j; ++k) a -= S[i * 9 + k] * S[j * 9 + k];
-      S[i * 9 + j] = a * inv;
-    }
-  }
-  if (ok) {
-    for (int i = 0; i < 9; ++i) {
-      double a = b[i];
-      for (int k = 0; k < i; ++k) a -= S[i * 9 + k] * b[k];
-      b[i] = a / S[i * 9 + i];
-    }
-    for (int i = 8; i >= 0; --i) {
-      double a = b[i];
-      for (int k = i + 1; k < 9; ++k) a -= S[k * 9 + i] * b[k];
-      b[i] = a / S[i * 9 + i];
-    }
-    for (int i = 0; i < 9; ++i) {
-      st->ds[i] = -b[i];
-      ok = ok && isfinite(b[i]);
-    }
-  }
-  st->step_valid = ok ? 1 : 0;
+  *P.ctl = c;
+  *P.ctl_next = c;
 }
 
 }  // namespace cc
@@ -579,8 +718,8 @@ struct cc_intrinsics {
   double* init_intr = nullptr;  // [16]
   double* init_pose = nullptr;  // [F][8]
   bool have_state = false;
-  cc::LmState* h_state = nullptr;  // pinned
-  hipGraphExec_t graph = nullptr;
+  cc::LmCtl* h_ctl = nullptr;  // pinned
+  hipGraphExec_t graph[2] = {nullptr, nullptr};  // [0]: 1 + check_interval triples, [1]: check_interval triples
   int graph_iters = 0;
   cc::Comm* comm = nullptr;
   std::vector<hipEvent_t> events;
@@ -589,86 +728,58 @@ struct cc_intrinsics {
 
 namespace cc {
 
-static void enqueue_kernel(cc_intrinsics* h, int kind, int variant, bool profile) {
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (profile) {
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    hipEventRecord(e0, h->stream);
-  }
-  switch (kind) {
-    case CC_K_SWEEP:
-      hipLaunchKernelGGL(k_intr_sweep, dim3((unsigned)h->F), dim3(kSweepThreads), kSweepLdsBytes, h->stream, h->d);
-      break;
-    case CC_K_DECIDE:
-      if (variant == 0) hipLaunchKernelGGL(k_intr_decide<0>, dim3(1), dim3(kDecideThreads), 0, h->stream, h->d);
-      else if (variant == 1) hipLaunchKernelGGL(k_intr_decide<1>, dim3(1), dim3(kDecideThreads), 0, h->stream, h->d);
-      else hipLaunchKernelGGL(k_intr_decide<2>, dim3(1), dim3(kDecideThreads), 0, h->stream, h->d);
-      break;
-    case CC_K_ELIM:
-      hipLaunchKernelGGL(k_intr_elim, dim3(h->elim_blocks), dim3(256), 0, h->stream, h->d);
-      break;
-    case CC_K_SOLVE:
-      if (variant == 0) hipLaunchKernelGGL(k_intr_solve<0>, dim3(1), dim3(64), 0, h->stream, h->d, h->elim_blocks);
-      else if (variant == 1) hipLaunchKernelGGL(k_intr_solve<1>, dim3(1), dim3(64), 0, h->stream, h->d, h->elim_blocks);
-      else hipLaunchKernelGGL(k_intr_solve<2>, dim3(1), dim3(64), 0, h->stream, h->d, h->elim_blocks);
-      break;
-    default: break;
-  }
-  if (profile) {
-    hipEventRecord(e1, h->stream);
-    h->events.push_back(e0);
-    h->events.push_back(e1);
-    h->event_kind.push_back(kind);
-  }
+static void drop_graphs(cc_intrinsics* h) {
+  for (auto& g : h->graph)
+    if (g) { hipGraphExecDestroy(g); g = nullptr; }
 }
 
-static int enqueue_allreduce(cc_intrinsics* h, double* buf, bool profile) {
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (profile) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, h->stream); }
-  const int rc = comm_allreduce_sum(h->comm, buf, 64, h->stream);
-  if (profile) {
-    hipEventRecord(e1, h->stream);
-    h->events.push_back(e0); h->events.push_back(e1); h->event_kind.push_back(CC_K_ALLREDUCE);
+struct Probe {  // optional hipEvent bracket around one launch
+  cc_intrinsics* h; int kind; bool on; hipEvent_t e0 = nullptr, e1 = nullptr;
+  Probe(cc_intrinsics* h_, int kind_, bool on_) : h(h_), kind(kind_), on(on_) {
+    if (on) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, h->stream); }
   }
-  return rc;
+  ~Probe() {
+    if (on) { hipEventRecord(e1, h->stream); h->events.push_back(e0); h->events.push_back(e1); h->event_kind.push_back(kind); }
+  }
+};
+
+static void launch_sweep(cc_intrinsics* h, bool profile) {
+  Probe p(h, CC_K_SWEEP, profile);
+  hipLaunchKernelGGL(k_intr_sweep, dim3((unsigned)h->F), dim3(kSweepThreads), kSweepLdsBytes, h->stream, h->d);
 }
 
-// sweep + decide (also used for the initial evaluation)
-static int enqueue_sweep_decide(cc_intrinsics* h, bool profile) {
-  enqueue_kernel(h, CC_K_SWEEP, 0, profile);
+// one triple: solve -> sweep -> decide+elim (the very first triple of a solve is the initial evaluation)
+static int enqueue_triple(cc_intrinsics* h, bool profile) {
   if (h->comm) {
-    enqueue_kernel(h, CC_K_DECIDE, 1, profile);
-    if (int rc = enqueue_allreduce(h, h->d.vec_decide, profile)) return rc;
-    enqueue_kernel(h, CC_K_DECIDE, 2, profile);
+    { Probe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_intr_solve<1>, dim3(1), dim3(128), 0, h->stream, h->d, h->elim_blocks); }
+    { Probe p(h, CC_K_ALLREDUCE, profile); if (int rc = comm_allreduce_sum(h->comm, h->d.vec_solve, kVecSolve, h->stream)) return rc; }
+    { Probe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_intr_solve<2>, dim3(1), dim3(128), 0, h->stream, h->d, h->elim_blocks); }
   } else {
-    enqueue_kernel(h, CC_K_DECIDE, 0, profile);
+    Probe p(h, CC_K_SOLVE, profile);
+    hipLaunchKernelGGL(k_intr_solve<0>, dim3(1), dim3(128), 0, h->stream, h->d, h->elim_blocks);
+  }
+  launch_sweep(h, profile);
+  if (h->comm) {
+    { Probe p(h, CC_K_DECIDE, profile); hipLaunchKernelGGL(k_intr_stats_reduce, dim3(1), dim3(256), 0, h->stream, h->d); }
+    { Probe p(h, CC_K_ALLREDUCE, profile); if (int rc = comm_allreduce_sum(h->comm, h->d.vec_decide, 16, h->stream)) return rc; }
+    { Probe p(h, CC_K_ELIM, profile); hipLaunchKernelGGL(k_intr_decide_elim<2>, dim3(h->elim_blocks), dim3(256), 0, h->stream, h->d); }
+  } else {
+    Probe p(h, CC_K_ELIM, profile);
+    hipLaunchKernelGGL(k_intr_decide_elim<0>, dim3(h->elim_blocks), dim3(256), 0, h->stream, h->d);
   }
   return 0;
 }
 
-static int enqueue_iteration(cc_intrinsics* h, bool profile) {
-  enqueue_kernel(h, CC_K_ELIM, 0, profile);
-  if (h->comm) {
-    enqueue_kernel(h, CC_K_SOLVE, 1, profile);
-    if (int rc = enqueue_allreduce(h, h->d.vec_solve, profile)) return rc;
-    enqueue_kernel(h, CC_K_SOLVE, 2, profile);
-  } else {
-    enqueue_kernel(h, CC_K_SOLVE, 0, profile);
-  }
-  return enqueue_sweep_decide(h, profile);
+static int write_ctl(cc_intrinsics* h, const LmCtl& c) {
+  CC_HIP(hipMemcpyAsync(h->d.ctl, &c, sizeof(c), hipMemcpyHostToDevice, h->stream));
+  CC_HIP(hipMemcpyAsync(h->d.ctl_next, &c, sizeof(c), hipMemcpyHostToDevice, h->stream));
+  return 0;
 }
 
-static int reset_device_state(cc_intrinsics* h, const cc_options& o) {
-  LmOpts lo;
-  opts_from_public(o, &lo);
-  CC_HIP(hipMemcpyAsync(h->d.opts, &lo, sizeof(lo), hipMemcpyHostToDevice, h->stream));
-  CC_HIP(hipMemsetAsync(h->d.state, 0, sizeof(LmState), h->stream));
-  CC_HIP(hipMemsetAsync(h->d.vec_decide, 0, 64 * sizeof(double), h->stream));
-  CC_HIP(hipMemsetAsync(h->d.vec_solve, 0, 64 * sizeof(double), h->stream));
-  // current point lives in buffer 0
-  CC_HIP(hipMemcpyAsync(h->d.intr, h->init_intr, 16 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-  CC_HIP(hipMemcpyAsync(h->d.pose, h->init_pose, (size_t)h->F * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+static int read_ctl(cc_intrinsics* h, LmCtl* c) {
+  CC_HIP(hipMemcpyAsync(h->h_ctl, h->d.ctl_next, sizeof(LmCtl), hipMemcpyDeviceToHost, h->stream));
+  CC_HIP(hipStreamSynchronize(h->stream));
+  *c = *h->h_ctl;
   return 0;
 }
 
@@ -706,12 +817,16 @@ int cc_intrinsics_create(int32_t device, int64_t F, const int64_t* off, const fl
   CC_HIP(hipMalloc(&d.pose, (size_t)2 * F * 8 * sizeof(double)));
   CC_HIP(hipMalloc(&d.blocks, (size_t)2 * F * 256 * sizeof(double)));
   CC_HIP(hipMalloc(&d.stats, (size_t)F * kStatsCols * sizeof(double)));
+  CC_HIP(hipMalloc(&d.hd0, (size_t)F * 16 * sizeof(double)));
   CC_HIP(hipMalloc(&d.sp, (size_t)F * 8 * sizeof(double)));
-  CC_HIP(hipMalloc(&d.ZL, (size_t)F * kZLStride * sizeof(double)));
-  CC_HIP(hipMalloc(&d.partial, (size_t)kElimMaxBlocks * 64 * sizeof(double)));
-  CC_HIP(hipMalloc(&d.vec_solve, 64 * sizeof(double)));
-  CC_HIP(hipMalloc(&d.vec_decide, 64 * sizeof(double)));
-  CC_HIP(hipMalloc(&d.state, sizeof(LmState)));
+  CC_HIP(hipMalloc(&d.Y, (size_t)F * kYStride * sizeof(double)));
+  CC_HIP(hipMalloc(&d.partial, (size_t)kElimMaxBlocks * kPartialCols * sizeof(double)));
+  CC_HIP(hipMalloc(&d.vec_solve, kVecSolve * sizeof(double)));
+  CC_HIP(hipMalloc(&d.vec_decide, 16 * sizeof(double)));
+  CC_HIP(hipMalloc(&d.ds, 16 * sizeof(double)));
+  CC_HIP(hipMalloc(&d.ss, 16 * sizeof(double)));
+  CC_HIP(hipMalloc(&d.ctl, sizeof(LmCtl)));
+  CC_HIP(hipMalloc(&d.ctl_next, sizeof(LmCtl)));
   CC_HIP(hipMalloc(&d.opts, sizeof(LmOpts)));
   d.log_cap = 4096;
   CC_HIP(hipMalloc(&d.log, (size_t)d.log_cap * sizeof(cc_iteration)));
@@ -720,8 +835,16 @@ int cc_intrinsics_create(int32_t device, int64_t F, const int64_t* off, const fl
   CC_HIP(hipMemset(d.intr, 0, 2 * 16 * sizeof(double)));
   CC_HIP(hipMemset(d.pose, 0, (size_t)2 * F * 8 * sizeof(double)));
   CC_HIP(hipMemset(d.sp, 0, (size_t)F * 8 * sizeof(double)));
-  CC_HIP(hipMemset(d.ZL, 0, (size_t)F * kZLStride * sizeof(double)));
-  CC_HIP(hipHostMalloc(&h->h_state, sizeof(LmState), hipHostMallocDefault));
+  CC_HIP(hipMemset(d.hd0, 0, (size_t)F * 16 * sizeof(double)));
+  CC_HIP(hipMemset(d.Y, 0, (size_t)F * kYStride * sizeof(double)));
+  CC_HIP(hipMemset(d.stats, 0, (size_t)F * kStatsCols * sizeof(double)));
+  CC_HIP(hipMemset(d.ds, 0, 16 * sizeof(double)));
+  CC_HIP(hipMemset(d.ss, 0, 16 * sizeof(double)));
+  CC_HIP(hipMemset(d.vec_solve, 0, kVecSolve * sizeof(double)));
+  CC_HIP(hipMemset(d.vec_decide, 0, 16 * sizeof(double)));
+  CC_HIP(hipMemset(d.ctl, 0, sizeof(LmCtl)));
+  CC_HIP(hipMemset(d.ctl_next, 0, sizeof(LmCtl)));
+  CC_HIP(hipHostMalloc(&h->h_ctl, sizeof(LmCtl), hipHostMallocDefault));
   h->elim_blocks = (int)std::min<int64_t>(kElimMaxBlocks, (F + 15) / 16);
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_intr_sweep),
                              hipFuncAttributeMaxDynamicSharedMemorySize, kSweepLdsBytes));
@@ -733,15 +856,15 @@ void cc_intrinsics_destroy(cc_intrinsics* h) {
   if (!h) return;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
-  if (h->graph) hipGraphExecDestroy(h->graph);
+  cc::drop_graphs(h);
   if (h->comm) cc::comm_destroy(h->comm);
   cc::IntrDev& d = h->d;
   hipFree((void*)d.uv); hipFree((void*)d.xyz); hipFree((void*)d.off);
-  hipFree(d.intr); hipFree(d.pose); hipFree(d.blocks); hipFree(d.stats); hipFree(d.sp);
-  hipFree(d.ZL); hipFree(d.partial); hipFree(d.vec_solve); hipFree(d.vec_decide);
-  hipFree(d.state); hipFree(d.opts); hipFree(d.log);
+  hipFree(d.intr); hipFree(d.pose); hipFree(d.blocks); hipFree(d.stats); hipFree(d.hd0); hipFree(d.sp);
+  hipFree(d.Y); hipFree(d.partial); hipFree(d.vec_solve); hipFree(d.vec_decide); hipFree(d.ds); hipFree(d.ss);
+  hipFree(d.ctl); hipFree(d.ctl_next); hipFree(d.opts); hipFree(d.log);
   hipFree(h->init_intr); hipFree(h->init_pose);
-  if (h->h_state) hipHostFree(h->h_state);
+  if (h->h_ctl) hipHostFree(h->h_ctl);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
@@ -761,10 +884,7 @@ int cc_intrinsics_set_state(cc_intrinsics* h, const double* intr9, uint32_t mask
   CC_HIP(hipStreamSynchronize(h->stream));
   CC_HIP(hipMemcpy(h->init_intr, k, sizeof(k), hipMemcpyHostToDevice));
   CC_HIP(hipMemcpy(h->init_pose, pose.data(), pose.size() * sizeof(double), hipMemcpyHostToDevice));
-  if (h->d.mask != (mask & 0x1ffu) && h->graph) {  // kernel arguments are baked into the graph
-    hipGraphExecDestroy(h->graph);
-    h->graph = nullptr;
-  }
+  if (h->d.mask != (mask & 0x1ffu)) drop_graphs(h);  // kernel arguments are baked into the graphs
   h->d.mask = mask & 0x1ffu;
   h->have_state = true;
   return cc_intrinsics_reset(h);
@@ -774,10 +894,11 @@ int cc_intrinsics_reset(cc_intrinsics* h) {
   using namespace cc;
   if (!h || !h->have_state) return fail(CC_ERR_STATE, "cc_intrinsics_reset: no state set");
   CC_HIP(hipSetDevice(h->device));
-  cc_options o;
-  cc_options_init(&o);
-  if (int rc = reset_device_state(h, o)) return rc;
-  CC_HIP(hipStreamSynchronize(h->stream));
+  LmCtl c{};
+  if (int rc = write_ctl(h, c)) return rc;
+  // current point lives in buffer 0
+  CC_HIP(hipMemcpyAsync(h->d.intr, h->init_intr, 16 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  CC_HIP(hipMemcpyAsync(h->d.pose, h->init_pose, (size_t)h->F * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   return CC_OK;
 }
 
@@ -785,10 +906,9 @@ int cc_intrinsics_get_state(cc_intrinsics* h, double* intr9, double* q, double* 
   using namespace cc;
   if (!h) return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_get_state: NULL handle");
   CC_HIP(hipSetDevice(h->device));
-  CC_HIP(hipStreamSynchronize(h->stream));
-  LmState st;
-  CC_HIP(hipMemcpy(&st, h->d.state, sizeof(st), hipMemcpyDeviceToHost));
-  const int cur = st.cur & 1;
+  LmCtl c;
+  if (int rc = read_ctl(h, &c)) return rc;
+  const int cur = c.cur & 1;
   if (intr9) CC_HIP(hipMemcpy(intr9, h->d.intr + cur * 16, 9 * sizeof(double), hipMemcpyDeviceToHost));
   if (q || t) {
     std::vector<double> pose((size_t)h->F * 8);
@@ -805,15 +925,15 @@ int cc_intrinsics_eval(cc_intrinsics* h, double* blocks, double* cost) {
   using namespace cc;
   if (!h || !h->have_state) return fail(CC_ERR_STATE, "cc_intrinsics_eval: no state set");
   CC_HIP(hipSetDevice(h->device));
-  CC_HIP(hipStreamSynchronize(h->stream));
-  // evaluate at the accepted point without disturbing it: phase 0 sweep writes into buffer `cur`
-  LmState st;
-  CC_HIP(hipMemcpy(&st, h->d.state, sizeof(st), hipMemcpyDeviceToHost));
-  LmState ev = st;
-  ev.done = 0; ev.phase = 0;
-  CC_HIP(hipMemcpy(h->d.state, &ev, sizeof(ev), hipMemcpyHostToDevice));
-  enqueue_kernel(h, CC_K_SWEEP, 0, false);
+  // evaluate at the accepted point without disturbing it: a phase-0 sweep writes into buffer `cur`
+  LmCtl st;
+  if (int rc = read_ctl(h, &st)) return rc;
+  LmCtl ev{};
+  ev.cur = st.cur & 1;
+  CC_HIP(hipMemcpyAsync(h->d.ctl, &ev, sizeof(ev), hipMemcpyHostToDevice, h->stream));
+  launch_sweep(h, false);
   CC_HIP(hipGetLastError());
+  CC_HIP(hipMemcpyAsync(h->d.ctl, &st, sizeof(st), hipMemcpyHostToDevice, h->stream));
   CC_HIP(hipStreamSynchronize(h->stream));
   const int cur = st.cur & 1;
   if (blocks)
@@ -825,7 +945,6 @@ int cc_intrinsics_eval(cc_intrinsics* h, double* blocks, double* cost) {
     for (int64_t f = 0; f < h->F; ++f) c += stats[f * kStatsCols + ST_COST];
     *cost = c;
   }
-  CC_HIP(hipMemcpy(h->d.state, &st, sizeof(st), hipMemcpyHostToDevice));
   return CC_OK;
 }
 
@@ -840,57 +959,56 @@ int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* sum
   const bool profile = o.profile_kernels != 0;
   const bool use_graph = o.use_graph && !profile && !h->comm;
   CC_HIP(hipSetDevice(h->device));
-  // restart from the accepted point of the previous run (buffer `cur`), not from buffer 0
+  // continue from the accepted point of the previous run: move it to buffer 0, fresh control block
   {
-    CC_HIP(hipStreamSynchronize(h->stream));
-    LmState st;
-    CC_HIP(hipMemcpy(&st, h->d.state, sizeof(st), hipMemcpyDeviceToHost));
+    LmCtl st;
+    if (int rc = read_ctl(h, &st)) return rc;
     if (st.cur & 1) {
-      CC_HIP(hipMemcpy(h->d.intr, h->d.intr + 16, 16 * sizeof(double), hipMemcpyDeviceToDevice));
-      CC_HIP(hipMemcpy(h->d.pose, h->d.pose + (size_t)h->F * 8, (size_t)h->F * 8 * sizeof(double), hipMemcpyDeviceToDevice));
+      CC_HIP(hipMemcpyAsync(h->d.intr, h->d.intr + 16, 16 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+      CC_HIP(hipMemcpyAsync(h->d.pose, h->d.pose + (size_t)h->F * 8, (size_t)h->F * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     }
     LmOpts lo;
     opts_from_public(o, &lo);
     CC_HIP(hipMemcpyAsync(h->d.opts, &lo, sizeof(lo), hipMemcpyHostToDevice, h->stream));
-    CC_HIP(hipMemsetAsync(h->d.state, 0, sizeof(LmState), h->stream));
-    CC_HIP(hipMemsetAsync(h->d.vec_decide, 0, 64 * sizeof(double), h->stream));
-    CC_HIP(hipMemsetAsync(h->d.vec_solve, 0, 64 * sizeof(double), h->stream));
+    LmCtl c{};
+    if (int rc = write_ctl(h, c)) return rc;
   }
   for (auto e : h->events) hipEventDestroy(e);
   h->events.clear();
   h->event_kind.clear();
 
-  if (int rc = enqueue_sweep_decide(h, profile)) return rc;
-  CC_HIP(hipGetLastError());
-
-  if (use_graph && (!h->graph || h->graph_iters != o.check_interval)) {
-    if (h->graph) { hipGraphExecDestroy(h->graph); h->graph = nullptr; }
-    hipGraph_t g = nullptr;
-    CC_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    for (int i = 0; i < o.check_interval; ++i) enqueue_iteration(h, false);
-    CC_HIP(hipStreamEndCapture(h->stream, &g));
-    CC_HIP(hipGraphInstantiate(&h->graph, g, nullptr, nullptr, 0));
-    hipGraphDestroy(g);
+  if (use_graph && (!h->graph[0] || h->graph_iters != o.check_interval)) {
+    drop_graphs(h);
+    for (int gi = 0; gi < 2; ++gi) {
+      hipGraph_t g = nullptr;
+      CC_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+      const int n = o.check_interval + (gi == 0 ? 1 : 0);
+      for (int i = 0; i < n; ++i) enqueue_triple(h, false);
+      CC_HIP(hipStreamEndCapture(h->stream, &g));
+      CC_HIP(hipGraphInstantiate(&h->graph[gi], g, nullptr, nullptr, 0));
+      hipGraphDestroy(g);
+    }
     h->graph_iters = o.check_interval;
   }
 
+  // The first chunk holds the initial evaluation plus check_interval iterations.
   int launched = 0;
-  while (true) {
-    CC_HIP(hipMemcpyAsync(h->h_state, h->d.state, sizeof(LmState), hipMemcpyDeviceToHost, h->stream));
-    CC_HIP(hipStreamSynchronize(h->stream));
-    if (h->h_state->done) break;
-    if (launched > o.max_iterations + o.check_interval)
-      return fail(CC_ERR_STATE, "LM loop did not terminate (iter=%d)", h->h_state->iter);
+  LmCtl st;
+  for (int chunk = 0;; ++chunk) {
+    const int n = o.check_interval + (chunk == 0 ? 1 : 0);
     if (use_graph) {
-      CC_HIP(hipGraphLaunch(h->graph, h->stream));
+      CC_HIP(hipGraphLaunch(h->graph[chunk == 0 ? 0 : 1], h->stream));
     } else {
-      for (int i = 0; i < o.check_interval; ++i)
-        if (int rc = enqueue_iteration(h, profile)) return rc;
+      for (int i = 0; i < n; ++i)
+        if (int rc = enqueue_triple(h, profile)) return rc;
       CC_HIP(hipGetLastError());
     }
-    launched += o.check_interval;
+    launched += n;
+    if (int rc = read_ctl(h, &st)) return rc;
+    if (st.done) break;
+    if (launched > o.max_iterations + 2 * o.check_interval + 2)
+      return fail(CC_ERR_STATE, "LM loop did not terminate (iter=%d)", st.iter);
   }
-  const LmState& st = *h->h_state;
   if (summary) {
     cc_iteration* user_log = summary->log;
     const int cap = summary->log_capacity;
@@ -925,19 +1043,18 @@ int cc_intrinsics_profile_sweep(cc_intrinsics* h, int32_t n, double* avg_ms) {
   using namespace cc;
   if (!h || n < 1 || !avg_ms) return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_profile_sweep: bad arguments");
   CC_HIP(hipSetDevice(h->device));
-  CC_HIP(hipStreamSynchronize(h->stream));
-  LmState st;
-  CC_HIP(hipMemcpy(&st, h->d.state, sizeof(st), hipMemcpyDeviceToHost));
+  LmCtl st;
+  if (int rc = read_ctl(h, &st)) return rc;
   if (st.phase != 1 || st.iter < 1) return fail(CC_ERR_STATE, "cc_intrinsics_profile_sweep: run cc_intrinsics_solve first");
-  LmState run = st;
+  LmCtl run = st;
   run.done = 0; run.step_valid = 1;
-  CC_HIP(hipMemcpy(h->d.state, &run, sizeof(run), hipMemcpyHostToDevice));
+  CC_HIP(hipMemcpyAsync(h->d.ctl, &run, sizeof(run), hipMemcpyHostToDevice, h->stream));
   hipEvent_t e0, e1;
   CC_HIP(hipEventCreate(&e0));
   CC_HIP(hipEventCreate(&e1));
-  enqueue_kernel(h, CC_K_SWEEP, 0, false);  // warm
+  launch_sweep(h, false);  // warm
   CC_HIP(hipEventRecord(e0, h->stream));
-  for (int i = 0; i < n; ++i) enqueue_kernel(h, CC_K_SWEEP, 0, false);
+  for (int i = 0; i < n; ++i) launch_sweep(h, false);
   CC_HIP(hipEventRecord(e1, h->stream));
   CC_HIP(hipGetLastError());
   CC_HIP(hipStreamSynchronize(h->stream));
@@ -946,7 +1063,7 @@ int cc_intrinsics_profile_sweep(cc_intrinsics* h, int32_t n, double* avg_ms) {
   hipEventDestroy(e0);
   hipEventDestroy(e1);
   *avg_ms = (double)ms / n;
-  CC_HIP(hipMemcpy(h->d.state, &st, sizeof(st), hipMemcpyHostToDevice));
+  CC_HIP(hipMemcpy(h->d.ctl, &st, sizeof(st), hipMemcpyHostToDevice));
   return CC_OK;
 }
 
@@ -969,7 +1086,7 @@ int cc_intrinsics_comm_init(cc_intrinsics* h, const uint8_t id[128], int32_t ran
     return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_comm_init: bad arguments (nranks must be 1..32)");
   CC_HIP(hipSetDevice(h->device));
   if (h->comm) { comm_destroy(h->comm); h->comm = nullptr; }
-  if (h->graph) { hipGraphExecDestroy(h->graph); h->graph = nullptr; }
+  drop_graphs(h);
   if (int rc = comm_create(id, rank, nranks, &h->comm)) return rc;
   h->d.rank = rank;
   h->d.nranks = nranks;
