@@ -341,17 +341,18 @@ __device__ __forceinline__ void reduce_frame_stats(const IntrDev& P, bool want_s
   // stats: thread t -> column t & 3, row group t >> 2 (64 groups)
   double a = 0.0;
   if (want_stats) {
+    // 16 independent loads in flight per thread: one round trip per 1024 frames
     const int col = tid & 3;
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    int64_t f = tid >> 2;
-    for (; f + 3 * 64 < P.F; f += 4 * 64) {
-      a0 += P.stats[f * kStatsCols + col];
-      a1 += P.stats[(f + 64) * kStatsCols + col];
-      a2 += P.stats[(f + 128) * kStatsCols + col];
-      a3 += P.stats[(f + 192) * kStatsCols + col];
+    for (int64_t fb = tid >> 2; fb < P.F; fb += 16 * 64) {
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int64_t f = fb + u * 64;
+        v[u] = f < P.F ? P.stats[f * kStatsCols + col] : 0.0;
+      }
+      a += (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
+           (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
     }
-    for (; f < P.F; f += 64) a0 += P.stats[f * kStatsCols + col];
-    a = (a0 + a1) + (a2 + a3);
   }
   // combine the 16 row groups of a wave that share a column (lane bits 2..5)
 #pragma unroll
@@ -360,11 +361,15 @@ __device__ __forceinline__ void reduce_frame_stats(const IntrDev& P, bool want_s
   if (want_hd) {
     // hd0: thread t -> column t & 15, row group t >> 4 (16 groups)
     const int col = tid & 15;
-    double h0 = 0, h1 = 0;
-    int64_t f = tid >> 4;
-    for (; f + 16 < P.F; f += 32) { h0 += P.hd0[f * 16 + col]; h1 += P.hd0[(f + 16) * 16 + col]; }
-    for (; f < P.F; f += 16) h0 += P.hd0[f * 16 + col];
-    h = h0 + h1;
+    for (int64_t fb = tid >> 4; fb < P.F; fb += 8 * 16) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t f = fb + u * 16;
+        v[u] = f < P.F ? P.hd0[f * 16 + col] : 0.0;
+      }
+      h += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
   }
 #pragma unroll
   for (int o = 16; o < 64; o <<= 1) h += __shfl_xor(h, o, 64);
@@ -479,6 +484,7 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P) {
       for (int i = 0; i < 6; ++i) L[tri(i, i)] += clampd(L[tri(i, i)], mn, mx) / radius;
       // in-place Cholesky (lower), fully unrolled so L stays in registers (redundant per lane)
       bool ok = true;
+      double Li[6];  // 1 / L_jj
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
         double d = L[tri(j, j)];
@@ -488,6 +494,7 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P) {
         d = sqrt(d);
         L[tri(j, j)] = d;
         const double inv = 1.0 / d;
+        Li[j] = inv;
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
           double a = L[tri(i, j)];
@@ -507,14 +514,14 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P) {
           double a = s[i] * G[(9 + i) * 16 + col] * sc;
 #pragma unroll
           for (int k = 0; k < i; ++k) a -= L[tri(i, k)] * z[k];
-          z[i] = a / L[tri(i, i)];
+          z[i] = a * Li[i];
         }
 #pragma unroll
         for (int i = 5; i >= 0; --i) {
           double a = z[i];
 #pragma unroll
           for (int k = i + 1; k < 6; ++k) a -= L[tri(k, i)] * y[k];
-          y[i] = a / L[tri(i, i)];
+          y[i] = a * Li[i];
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -571,9 +578,12 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P) {
 // sweep. MODE 0: reduce + solve; 1: reduce only (-> vec_solve, then all-reduced); 2: solve only.
 // vec_solve: [0..79] column sums (col 73 unused), [80 + rank] this rank's max |pose gradient|.
 // ---------------------------------------------------------------------------------------------
+constexpr int kSolveThreads = 8 * kPartialCols;
+
 template <int MODE>
-__global__ __launch_bounds__(128) void k_intr_solve(IntrDev P, int nblk) {
+__global__ __launch_bounds__(kSolveThreads) void k_intr_solve(IntrDev P, int nblk) {
   __shared__ double sv[kVecSolve];
+  __shared__ double s_part[8][kPartialCols];
   const int tid = threadIdx.x;
   const LmCtl* cn = P.ctl_next;
   const int done = cn->done, phase = cn->phase;
@@ -581,21 +591,33 @@ __global__ __launch_bounds__(128) void k_intr_solve(IntrDev P, int nblk) {
   if (MODE != 2) {
     if (tid < kVecSolve) sv[tid] = 0.0;
     __syncthreads();
+    {
+      // thread -> (column, row group): all rows of the partials are fetched in one round trip
+      const int col = tid % kPartialCols, grp = tid / kPartialCols;
+      double a = 0.0;
+      if (active) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int b = grp + 8 * u;
+          v[u] = b < nblk ? P.partial[b * kPartialCols + col] : 0.0;
+        }
+        if (col == PC_GMAXP) a = fmax(fmax(fmax(v[0], v[1]), fmax(v[2], v[3])), fmax(fmax(v[4], v[5]), fmax(v[6], v[7])));
+        else a = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      }
+      s_part[grp][col] = a;
+    }
+    __syncthreads();
     if (active && tid < kPartialCols) {
       double a;
       if (tid == PC_GMAXP) {
         a = 0.0;
-        for (int b = 0; b < nblk; ++b) a = fmax(a, P.partial[b * kPartialCols + tid]);
+        for (int g2 = 0; g2 < 8; ++g2) a = fmax(a, s_part[g2][tid]);
         sv[kPartialCols + P.rank] = a;
       } else {
-        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        int b = 0;
-        for (; b + 3 < nblk; b += 4) {
-          a0 += P.partial[b * kPartialCols + tid]; a1 += P.partial[(b + 1) * kPartialCols + tid];
-          a2 += P.partial[(b + 2) * kPartialCols + tid]; a3 += P.partial[(b + 3) * kPartialCols + tid];
-        }
-        for (; b < nblk; ++b) a0 += P.partial[b * kPartialCols + tid];
-        sv[tid] = (a0 + a1) + (a2 + a3);
+        a = ((s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid])) +
+            ((s_part[4][tid] + s_part[5][tid]) + (s_part[6][tid] + s_part[7][tid]));
+        sv[tid] = a;
       }
     }
     __syncthreads();
@@ -751,12 +773,12 @@ static void launch_sweep(cc_intrinsics* h, bool profile) {
 // one triple: solve -> sweep -> decide+elim (the very first triple of a solve is the initial evaluation)
 static int enqueue_triple(cc_intrinsics* h, bool profile) {
   if (h->comm) {
-    { Probe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_intr_solve<1>, dim3(1), dim3(128), 0, h->stream, h->d, h->elim_blocks); }
+    { Probe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_intr_solve<1>, dim3(1), dim3(kSolveThreads), 0, h->stream, h->d, h->elim_blocks); }
     { Probe p(h, CC_K_ALLREDUCE, profile); if (int rc = comm_allreduce_sum(h->comm, h->d.vec_solve, kVecSolve, h->stream)) return rc; }
-    { Probe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_intr_solve<2>, dim3(1), dim3(128), 0, h->stream, h->d, h->elim_blocks); }
+    { Probe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_intr_solve<2>, dim3(1), dim3(kSolveThreads), 0, h->stream, h->d, h->elim_blocks); }
   } else {
     Probe p(h, CC_K_SOLVE, profile);
-    hipLaunchKernelGGL(k_intr_solve<0>, dim3(1), dim3(128), 0, h->stream, h->d, h->elim_blocks);
+    hipLaunchKernelGGL(k_intr_solve<0>, dim3(1), dim3(kSolveThreads), 0, h->stream, h->d, h->elim_blocks);
   }
   launch_sweep(h, profile);
   if (h->comm) {

@@ -1,0 +1,78 @@
+"""Host-side checks of the C-ABI library that need no GPU: it loads, exports every symbol
+include/cc_solver.h declares, its host logic (frame partition, option defaults) is right, and
+compute entry points fail loudly when no device exists (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from camera_calibrator_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "cc_solver.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = capi.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 15
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    assert sorted(capi.EXPORTED_SYMBOLS) == declared
+
+
+def test_option_defaults_match_reference_call_site():
+    o = capi.default_options()
+    assert (o.max_iterations, o.use_nonmonotonic_steps) == (100, 1)          # calibrator.cpp:315,319
+    assert (o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance) == (1e-6, 1e-10, 1e-8)
+    assert (o.initial_radius, o.max_radius, o.min_radius) == (1e4, 1e16, 1e-32)
+    assert (o.min_lm_diagonal, o.max_lm_diagonal, o.min_relative_decrease) == (1e-6, 1e32, 1e-3)
+
+
+def test_struct_layouts_match_header():
+    import ctypes as C
+    assert C.sizeof(capi.Options) == 6 * 4 + 9 * 8 + 2 * 4
+    assert C.sizeof(capi.Iteration) == 7 * 8 + 2 * 4
+    assert C.sizeof(capi.Summary) == 4 * 4 + 3 * 8 + 8 + 2 * 4 + 8 * 8 + 8 * 4
+
+
+@pytest.mark.parametrize("nranks", [1, 2, 3, 4, 8])
+def test_partition_frames_uniform(nranks):
+    off = np.arange(0, 1001) * 500
+    first = capi.partition_frames(off, nranks)
+    assert first[0] == 0 and first[-1] == 1000 and np.all(np.diff(first) > 0)
+    counts = np.diff(off[first])
+    assert counts.max() - counts.min() <= 500
+
+
+def test_partition_frames_ragged_and_degenerate():
+    rng = np.random.default_rng(0)
+    sizes = rng.integers(1, 400, size=137)
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    for nranks in (2, 5, 8):
+        first = capi.partition_frames(off, nranks)
+        assert first[0] == 0 and first[-1] == 137 and np.all(np.diff(first) >= 1)
+        counts = np.diff(off[first])
+        assert counts.max() <= off[-1] / nranks + 400
+    # more ranks than frames: trailing ranks get empty shards, nothing is lost
+    first = capi.partition_frames([0, 10, 20], 4)
+    assert first[0] == 0 and first[-1] == 2 and np.all(np.diff(first) >= 0)
+
+
+def test_bad_arguments_are_reported():
+    with pytest.raises(capi.CcError):
+        capi.partition_frames([0, 1], 0)
+
+
+@pytest.mark.skipif(capi.device_count() > 0, reason="only meaningful without a GPU")
+def test_compute_entry_points_fail_loudly_without_gpu():
+    with pytest.raises(capi.CcError, match="no HIP device|no CPU fallback"):
+        capi.IntrinsicsProblem([0, 4], np.zeros((4, 2)), np.zeros((4, 3)))
+    with pytest.raises(capi.CcError):
+        capi.distort(np.eye(3), np.zeros(5), np.zeros((3, 2)))
