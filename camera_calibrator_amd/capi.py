@@ -80,6 +80,8 @@ EXPORTED_SYMBOLS = [
     "cc_intrinsics_reset", "cc_intrinsics_get_state", "cc_intrinsics_eval",
     "cc_intrinsics_solve", "cc_intrinsics_profile_sweep", "cc_intrinsics_optimize", "cc_comm_get_unique_id",
     "cc_intrinsics_comm_init", "cc_partition_frames", "cc_distort", "cc_undistort",
+    "cc_rig_create", "cc_rig_destroy", "cc_rig_set_state", "cc_rig_reset", "cc_rig_solve",
+    "cc_rig_get_state", "cc_rig_eval", "cc_rig_optimize",
 ]
 
 _lib = None
@@ -240,6 +242,96 @@ def intrinsics_optimize(frame_offsets, uv, xyz, intr, q, t, const_mask=0, option
                                         _p(intr, C.c_double), C.c_uint32(const_mask),
                                         _p(q, C.c_double), _p(t, C.c_double), C.byref(s)))
     return intr, q, t, _summary_dict(s, log)
+
+
+HUBER_A = float(np.float32(3.0) / np.float32(500.0))  # extrinsics_calibrator.cpp:176
+
+
+class RigProblem:
+    """Handle on a rig pose problem resident in HBM (cc_rig_*)."""
+
+    def __init__(self, n_cams, frame_offsets, obs_cam, obs_world, obs_uv, world_xyz, cam_frozen,
+                 huber_a=HUBER_A, device=0):
+        self._h = C.c_void_p()
+        off = np.ascontiguousarray(frame_offsets, dtype=np.int64)
+        self.n_cams, self.n_frames, self.n_obs = int(n_cams), len(off) - 1, int(off[-1])
+        obs_cam = np.ascontiguousarray(obs_cam, dtype=np.uint32)
+        obs_world = np.ascontiguousarray(obs_world, dtype=np.uint64)
+        obs_uv, world_xyz = _f32(obs_uv), _f32(world_xyz)
+        frozen = np.ascontiguousarray(cam_frozen, dtype=np.uint8)
+        _check(lib().cc_rig_create(C.c_int32(device), C.c_int64(n_cams), C.c_int64(self.n_frames),
+                                   C.c_int64(world_xyz.size // 3), _p(off, C.c_int64),
+                                   _p(obs_cam, C.c_uint32), _p(obs_world, C.c_uint64),
+                                   _p(obs_uv, C.c_float), _p(world_xyz, C.c_float),
+                                   _p(frozen, C.c_uint8), C.c_double(huber_a), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().cc_rig_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_state(self, cam_q, cam_t, frame_q, frame_t):
+        cam_q, cam_t, frame_q, frame_t = _f64(cam_q), _f64(cam_t), _f64(frame_q), _f64(frame_t)
+        assert cam_q.size == 4 * self.n_cams and frame_q.size == 4 * self.n_frames
+        _check(lib().cc_rig_set_state(self._h, _p(cam_q, C.c_double), _p(cam_t, C.c_double),
+                                      _p(frame_q, C.c_double), _p(frame_t, C.c_double)))
+
+    def reset(self):
+        _check(lib().cc_rig_reset(self._h))
+
+    def solve(self, options=None, log_capacity=2048):
+        opt = options if options is not None else default_options(max_iterations=1000)
+        log = (Iteration * max(1, log_capacity))()
+        s = Summary()
+        s.log = C.cast(log, C.POINTER(Iteration))
+        s.log_capacity = log_capacity
+        _check(lib().cc_rig_solve(self._h, C.byref(opt), C.byref(s)))
+        return _summary_dict(s, log)
+
+    def get_state(self, want_cost=True):
+        cq, ct = np.zeros((self.n_cams, 4)), np.zeros((self.n_cams, 3))
+        fq, ft = np.zeros((self.n_frames, 4)), np.zeros((self.n_frames, 3))
+        cost = np.zeros(self.n_obs) if want_cost else None
+        _check(lib().cc_rig_get_state(self._h, _p(cq, C.c_double), _p(ct, C.c_double), _p(fq, C.c_double),
+                                      _p(ft, C.c_double), _p(cost, C.c_double) if want_cost else None))
+        return cq, ct, fq, ft, cost
+
+    def eval(self):
+        c = C.c_double()
+        _check(lib().cc_rig_eval(self._h, C.byref(c)))
+        return c.value
+
+
+def rig_optimize(n_cams, frame_offsets, obs_cam, obs_world, obs_uv, world_xyz, cam_q, cam_t, cam_frozen,
+                 frame_q, frame_t, huber_a=HUBER_A, options=None, device=0, log_capacity=2048):
+    """One-shot cc_rig_optimize. Returns (cam_q, cam_t, frame_q, frame_t, obs_cost, summary)."""
+    off = np.ascontiguousarray(frame_offsets, dtype=np.int64)
+    F = len(off) - 1
+    obs_cam = np.ascontiguousarray(obs_cam, dtype=np.uint32)
+    obs_world = np.ascontiguousarray(obs_world, dtype=np.uint64)
+    obs_uv, world_xyz = _f32(obs_uv), _f32(world_xyz)
+    frozen = np.ascontiguousarray(cam_frozen, dtype=np.uint8)
+    cam_q, cam_t = _f64(cam_q).copy(), _f64(cam_t).copy()
+    frame_q, frame_t = _f64(frame_q).copy(), _f64(frame_t).copy()
+    cost = np.zeros(len(obs_cam))
+    opt = options if options is not None else default_options(max_iterations=1000)
+    log = (Iteration * max(1, log_capacity))()
+    s = Summary()
+    s.log = C.cast(log, C.POINTER(Iteration))
+    s.log_capacity = log_capacity
+    _check(lib().cc_rig_optimize(C.byref(opt), C.c_int32(device), C.c_int64(n_cams), C.c_int64(F),
+                                 C.c_int64(world_xyz.size // 3), _p(off, C.c_int64), _p(obs_cam, C.c_uint32),
+                                 _p(obs_world, C.c_uint64), _p(obs_uv, C.c_float), _p(world_xyz, C.c_float),
+                                 _p(cam_q, C.c_double), _p(cam_t, C.c_double), _p(frozen, C.c_uint8),
+                                 _p(frame_q, C.c_double), _p(frame_t, C.c_double), C.c_double(huber_a),
+                                 _p(cost, C.c_double), C.byref(s)))
+    return cam_q, cam_t, frame_q, frame_t, cost, _summary_dict(s, log)
 
 
 def distort(K, dist, xy, device=0):

@@ -19,6 +19,7 @@
 // base+i); poses double[2][F][8]; Gram blocks double[2][F][256] (2 KiB per frame, double
 // buffered: accepted point / candidate); per-frame stats double[F][32]; Z,L double[F][96].
 #include "cc_common.hpp"
+#include "cc_device.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -26,11 +27,7 @@
 
 namespace cc {
 
-typedef double d4 __attribute__((ext_vector_type(4)));
-typedef double d2 __attribute__((ext_vector_type(2)));
-
 constexpr int kSweepThreads = 256;
-constexpr int kStageDoublesPerWave = 64 * 16;  // 64 observations x one row (u or v) x 16 components
 constexpr int kSweepLdsBytes = (4 * kStageDoublesPerWave + 256) * 8;  // staging (reused for the block reduction) + prologue scratch
 constexpr int kStatsCols = 4;      // cost, q_model, step2, xnorm2
 constexpr int kYStride = 64;       // Y = A_pp^-1 [H_ps | g_p] (6 x 10) per frame
@@ -131,43 +128,6 @@ __device__ __forceinline__ void row_v(const double* k, const ObsCommon& c, doubl
 #pragma unroll
   for (int j = 0; j < 9; ++j)
     if (mask & (1u << j)) v[j] = 0.0;
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-
-// LDS accesses of one wave execute in order; the fence only stops the compiler from moving
-// the staged-row reads above the writes of other lanes (no instruction is emitted).
-__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
-
-// stage one row per lane (16 doubles at row `lane`), 16-byte slots XOR-swizzled with (row & 7):
-// the ds_write_b128 groups (8 consecutive lanes) and the ds_read_b64 operand reads (two 32-lane
-// halves, each two consecutive rows) are both bank-conflict free.
-__device__ __forceinline__ void stage_row(double* stage, int lane, const double* v) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    d2 val;
-    val.x = v[2 * j];
-    val.y = v[2 * j + 1];
-    *reinterpret_cast<d2*>(&stage[lane * 16 + ((j ^ (lane & 7)) << 1)]) = val;
-  }
-}
-
-// 16 MFMAs over the 64 staged rows: MFMA m consumes rows 4m..4m+3; lane l supplies component
-// (l & 15) of row 4m + (l >> 4) as both the A[i][k] and the B[k][j] operand of the Gram product.
-__device__ __forceinline__ void gram_rows(const double* stage, int lane, d4& acc0, d4& acc1) {
-  const int c = lane & 15, sub = lane >> 4;
-#pragma unroll
-  for (int m = 0; m < 16; m += 2) {
-    const int r0 = 4 * m + sub, r1 = 4 * (m + 1) + sub;
-    const double a0 = stage[r0 * 16 + (((c >> 1) ^ (r0 & 7)) << 1) + (c & 1)];
-    const double a1 = stage[r1 * 16 + (((c >> 1) ^ (r1 & 7)) << 1) + (c & 1)];
-    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc1, 0, 0, 0);
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -405,8 +365,6 @@ __global__ __launch_bounds__(256) void k_intr_stats_reduce(IntrDev P) {
 // [64..72] unscaled shared gradient, [73] max |pose gradient| (max-combined), rest 0.
 // MODE 0: reduce stats inline (single GPU); MODE 2: stats come all-reduced in vec_decide.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // i >= j
-
 template <int MODE>
 __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P) {
   __shared__ double Zs[16][64];

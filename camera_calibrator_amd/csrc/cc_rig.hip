@@ -1,0 +1,1103 @@
+// cc_rig.hip -- multi-camera rig pose bundle adjustment on MI355X (gfx950).
+//
+// Replaces the ceres::Problem/ceres::Solve block of ExtrinsicsCalibrator::Optimize
+// (/root/reference/src/extrinsics_calibrator.cpp:92-225): shared block = one 6-dof pose per camera
+// (camera_T_rig), one 6-dof pose per observation frame (rig_T_world), constant world points,
+// residuals in normalised coordinates, ceres::HuberLoss(3/500).
+//
+// Observations are regrouped on the host into (frame, camera) groups; one workgroup sweeps one
+// group and produces its 16x16 Gram block of [J_cam(6) J_frame(6) r 0 0 0] rows with the same
+// LDS-staged v_mfma_f64_16x16x4_f64 contraction as the intrinsics problem. Per LM iteration:
+//   solve  : reduce elimination partials, dense (6C)x(6C) Cholesky in LDS, camera candidates
+//   update : per frame, back-substitute the pose step, candidate pose (QuaternionManifold::Plus)
+//   sweep  : per group, residuals + Jacobian rows + Huber scaling -> Gram block, cost, model term
+//   init   : (first evaluation only) Jacobi scaling of the shared block, trust-region state
+//   decide+elim : trust-region decision; per frame 6x6 Cholesky and Schur complement partials
+#include <algorithm>
+#include <chrono>
+#include <numeric>
+#include <vector>
+
+#include "cc_common.hpp"
+#include "cc_device.hpp"
+
+namespace cc {
+
+constexpr int kRigMaxCams = 10;
+constexpr int kRigMaxS = 6 * kRigMaxCams;
+constexpr int kRigThreads = 256;
+constexpr int kRigOwn = 8;  // partial-row columns owned per thread of the elim kernel (PC <= 2048)
+constexpr int kRigSweepLdsBytes = (4 * kStageDoublesPerWave + 256) * 8;
+constexpr int kRigMaxElimBlocks = 128;
+
+struct RigDev {
+  int64_t F, N, NG;
+  int32_t C, S, SW, NP, PC;  // cameras, 6C, 6C+1, S(S+1)/2, partial-row columns
+  int32_t pc_b, pc_hd, pc_fail, pc_gs, pc_gmax;
+  int32_t nblk;
+  const float* uv;        // [N] float2, (frame, camera)-sorted
+  const int32_t* widx;    // [N] world point index
+  const float* wxyz;      // [3P]
+  const int64_t* goff;    // [NG+1] observation range of each group
+  const int32_t* gframe;  // [NG]
+  const int32_t* gcam;    // [NG]
+  const int64_t* fgoff;   // [F+1] group range of each frame
+  const int32_t* cam_goff;   // [C+1]
+  const int32_t* cam_glist;  // [NG] groups of each camera
+  const uint8_t* cam_fixed;  // [C] frozen or unobserved
+  const uint8_t* pair_p;     // [NP] (p,q), p <= q, row-major upper triangle
+  const uint8_t* pair_q;
+  double* cam;      // [2][C][8] q(4) t(3)
+  double* pose;     // [2][F][8]
+  double* camrec;   // [C][32] R(9) t(3) unscaled step(6)
+  double* frec;     // [F][32] R(9) t(3) unscaled step(6)
+  double* gblocks;  // [2][NG][256]
+  double* gstats;   // [NG][2] cost, model term
+  double* fstats;   // [F][2] step^2, |x|^2
+  double* ghd0;     // [NG][8] diag of H_cc at the initial point
+  double* sp;       // [F][8]
+  double* ss;       // [64]
+  double* ds;       // [64] scaled shared step
+  double* Y;        // [F][6*SW]
+  double* partial;  // [nblk][PC]
+  double* shared_stats;  // [4] step^2 and |x|^2 of the shared block (candidate)
+  LmCtl* ctl;
+  LmCtl* ctl_next;
+  LmOpts* opts;
+  cc_iteration* log;
+  int32_t log_cap;
+  double huber_a;
+};
+
+// ceres::HuberLoss(a) + Corrector (rho'' <= 0): residual and Jacobian scaled by sqrt(rho')
+__device__ __forceinline__ void huber(double a, double s, double& rho, double& sr) {
+  const double b = a * a;
+  if (s > b) {
+    const double r = sqrt(s);
+    rho = 2.0 * a * r - b;
+    sr = sqrt(fmax(2.2250738585072014e-308, a / r));
+  } else {
+    rho = s;
+    sr = 1.0;
+  }
+}
+
+struct RigObs {  // per-observation quantities shared by both rows
+  double b0, b1, b2, a0, a1, a2, x, y, iz, ru, rv;
+};
+
+// ReprojectionErrorExtrinsics::operator() (extrinsics_calibrator.cpp:51-84)
+__device__ __forceinline__ void rig_common(const double* Rf, const double* tf, const double* Rc, const double* tc,
+                                           double X0, double X1, double X2, double u, double v, RigObs& o) {
+  o.b0 = Rf[0] * X0 + Rf[1] * X1 + Rf[2] * X2;
+  o.b1 = Rf[3] * X0 + Rf[4] * X1 + Rf[5] * X2;
+  o.b2 = Rf[6] * X0 + Rf[7] * X1 + Rf[8] * X2;
+  const double r0 = o.b0 + tf[0], r1 = o.b1 + tf[1], r2 = o.b2 + tf[2];
+  o.a0 = Rc[0] * r0 + Rc[1] * r1 + Rc[2] * r2;
+  o.a1 = Rc[3] * r0 + Rc[4] * r1 + Rc[5] * r2;
+  o.a2 = Rc[6] * r0 + Rc[7] * r1 + Rc[8] * r2;
+  const double xc = o.a0 + tc[0], yc = o.a1 + tc[1], zc = o.a2 + tc[2];
+  o.iz = 1.0 / zc;
+  o.x = xc * o.iz;
+  o.y = yc * o.iz;
+  o.ru = o.x - u;
+  o.rv = o.y - v;
+}
+
+// row = sr * [d res / d cam rot(3) t(3) | d res / d frame rot(3) t(3) | res | 0 0 0],
+// B = d res / d x_cam for this row.
+__device__ __forceinline__ void rig_row(const RigObs& o, const double* Rc, double B0, double B1, double B2,
+                                        double res, double sr, bool cam_fixed, double* v) {
+  v[0] = 2.0 * (B2 * o.a1 - B1 * o.a2); v[1] = 2.0 * (B0 * o.a2 - B2 * o.a0); v[2] = 2.0 * (B1 * o.a0 - B0 * o.a1);
+  v[3] = B0; v[4] = B1; v[5] = B2;
+  const double m0 = B0 * Rc[0] + B1 * Rc[3] + B2 * Rc[6];
+  const double m1 = B0 * Rc[1] + B1 * Rc[4] + B2 * Rc[7];
+  const double m2 = B0 * Rc[2] + B1 * Rc[5] + B2 * Rc[8];
+  v[6] = 2.0 * (m2 * o.b1 - m1 * o.b2); v[7] = 2.0 * (m0 * o.b2 - m2 * o.b0); v[8] = 2.0 * (m1 * o.b0 - m0 * o.b1);
+  v[9] = m0; v[10] = m1; v[11] = m2;
+  v[12] = res;
+  v[13] = 0.0; v[14] = 0.0; v[15] = 0.0;
+#pragma unroll
+  for (int c = 0; c < 13; ++c) v[c] *= sr;
+  if (cam_fixed) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) v[c] = 0.0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// sweep: one workgroup per (frame, camera) group
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kRigThreads, 4) void k_rig_sweep(RigDev P) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* s_stage = reinterpret_cast<double*>(smem_raw);
+  double* s_blk = s_stage;
+  double* sm = s_stage + 4 * kStageDoublesPerWave;  // [256]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t g = blockIdx.x;
+  const LmCtl* ctl = P.ctl;
+  if (ctl->done) return;
+  const int phase = ctl->phase;
+  if (phase != 0 && !ctl->step_valid) return;
+  const int cur = ctl->cur, dst = phase == 0 ? cur : (cur ^ 1);
+  const int f = P.gframe[g], c = P.gcam[g];
+  const bool fixed = P.cam_fixed[c] != 0;
+  // sm[0..31] camera record, sm[32..63] frame record
+  if (tid < 32) sm[tid] = P.camrec[c * 32 + tid];
+  else if (tid < 64) sm[tid] = P.frec[(size_t)f * 32 + (tid - 32)];
+  double g_old = 0.0;
+  if (phase != 0) g_old = P.gblocks[((size_t)cur * P.NG + g) * 256 + tid];
+  __syncthreads();
+  // model-cost term of the group: d = [dc(6) df(6)], q = d^T g + 1/2 d^T H d over the 12x12 block
+  double qterm = 0.0;
+  if (phase != 0) {
+    const int a = tid >> 4, b = tid & 15;
+    if (a < 12) {
+      const double da = a < 6 ? sm[12 + a] : sm[32 + 12 + (a - 6)];
+      if (b < 12) {
+        const double db = b < 6 ? sm[12 + b] : sm[32 + 12 + (b - 6)];
+        qterm = 0.5 * da * g_old * db;
+      } else if (b == 12) {
+        qterm = da * g_old;
+      }
+    }
+  }
+  double Rc[9], tc[3], Rf[9], tf[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { Rc[i] = rfl(sm[i]); Rf[i] = rfl(sm[32 + i]); }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { tc[i] = rfl(sm[9 + i]); tf[i] = rfl(sm[32 + 9 + i]); }
+  const double ha = P.huber_a;
+
+  const int64_t s0 = P.goff[g], s1 = P.goff[g + 1];
+  const int npass = (int)((s1 - s0 + kRigThreads - 1) / kRigThreads);
+  double* stage = s_stage + wave * kStageDoublesPerWave;
+  const float2* uv2 = reinterpret_cast<const float2*>(P.uv);
+  d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+  double cost = 0.0;
+  for (int p = 0; p < npass; ++p) {
+    const int64_t idx = s0 + (int64_t)p * kRigThreads + tid;
+    const bool valid = idx < s1;
+    const int64_t ic = valid ? idx : s0;
+    const float2 m = uv2[ic];
+    const int64_t w = P.widx[ic];
+    const float X0 = P.wxyz[w * 3], X1 = P.wxyz[w * 3 + 1], X2 = P.wxyz[w * 3 + 2];
+    RigObs o;
+    rig_common(Rf, tf, Rc, tc, (double)X0, (double)X1, (double)X2, (double)m.x, (double)m.y, o);
+    double rho, sr;
+    huber(ha, o.ru * o.ru + o.rv * o.rv, rho, sr);
+    if (valid) cost += 0.5 * rho;
+    double v[16];
+    rig_row(o, Rc, o.iz, 0.0, -o.x * o.iz, o.ru, sr, fixed, v);
+    if (!valid) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = 0.0;
+    }
+    stage_row(stage, lane, v);
+    wave_lds_fence();
+    gram_rows(stage, lane, acc0, acc1);
+    wave_lds_fence();
+    rig_row(o, Rc, 0.0, o.iz, -o.y * o.iz, o.rv, sr, fixed, v);
+    if (!valid) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = 0.0;
+    }
+    stage_row(stage, lane, v);
+    wave_lds_fence();
+    gram_rows(stage, lane, acc0, acc1);
+    wave_lds_fence();
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) s_blk[wave * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc0[r] + acc1[r];
+  const double qw = wave_sum(qterm), cw = wave_sum(cost);
+  if (lane == 0) { sm[140 + wave] = qw; sm[144 + wave] = cw; }
+  __syncthreads();
+  const double gv = (s_blk[tid] + s_blk[256 + tid]) + (s_blk[512 + tid] + s_blk[768 + tid]);
+  P.gblocks[((size_t)dst * P.NG + g) * 256 + tid] = gv;
+  if (tid == 0) {
+    P.gstats[g * 2] = (sm[144] + sm[145]) + (sm[146] + sm[147]);
+    P.gstats[g * 2 + 1] = (sm[140] + sm[141]) + (sm[142] + sm[143]);
+  }
+  if (phase == 0 && (tid >> 4) < 6 && (tid & 15) == (tid >> 4)) P.ghd0[g * 8 + (tid >> 4)] = gv;  // diag of H_cc
+}
+
+// ---------------------------------------------------------------------------------------------
+// update: per frame, back-substitute the pose step and form the candidate pose. 16 lanes/frame.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rig_update(RigDev P) {
+  const LmCtl* ctl = P.ctl;
+  if (ctl->done) return;
+  const int phase = ctl->phase;
+  if (phase != 0 && !ctl->step_valid) return;
+  const int cur = ctl->cur, dst = phase == 0 ? cur : (cur ^ 1);
+  const int tid = threadIdx.x, l = tid & 15;
+  const int64_t f = (int64_t)blockIdx.x * 16 + (tid >> 4);
+  const bool valid = f < P.F;
+  const int64_t fc = valid ? f : 0;
+  double u[6] = {0, 0, 0, 0, 0, 0};
+  if (phase != 0) {
+    const double* Yf = P.Y + (size_t)fc * 6 * P.SW;
+    for (int k = l; k < P.SW; k += 16) {
+      const double d = k < P.S ? P.ds[k] : 1.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) u[i] += Yf[i * P.SW + k] * d;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) u[i] += __shfl_xor(u[i], o, 64);
+    }
+  }
+  if (!valid || l != 0) return;
+  const bool active = P.fgoff[f + 1] > P.fgoff[f];
+  const double* pc = P.pose + ((size_t)cur * P.F + f) * 8;
+  double q[4] = {pc[0], pc[1], pc[2], pc[3]}, t[3] = {pc[4], pc[5], pc[6]};
+  double dp[6] = {0, 0, 0, 0, 0, 0};
+  double step2 = 0.0;
+  if (phase != 0) {
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) dp[i] = -u[i] * P.sp[f * 8 + i];
+      double qn[4];
+      quat_plus(q, dp, qn);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const double d = qn[i] - q[i]; step2 += d * d; q[i] = qn[i]; }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { const double tn = t[i] + dp[3 + i]; const double d = tn - t[i]; step2 += d * d; t[i] = tn; }
+    }
+    double* pd = P.pose + ((size_t)dst * P.F + f) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pd[i] = q[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pd[4 + i] = t[i];
+  }
+  double R[9];
+  quat_to_R(q, R);
+  double* rec = P.frec + (size_t)f * 32;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) rec[i] = R[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) rec[9 + i] = t[i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) rec[12 + i] = dp[i];
+  P.fstats[f * 2] = step2;
+  P.fstats[f * 2 + 1] = active ? q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + t[0] * t[0] + t[1] * t[1] + t[2] * t[2] : 0.0;
+}
+
+// deterministic block-wide sum of one value per thread (256 threads); result valid for thread 0
+__device__ __forceinline__ double block_sum256(double v, double* s4) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (s4[0] + s4[1]) + (s4[2] + s4[3]);
+}
+
+// column sums of gstats[NG][2] and fstats[F][2] -> out[0..3] = cost, q, step2, xnorm2 (all threads)
+__device__ __forceinline__ void rig_reduce_stats(const RigDev& P, bool want, double* s4, double* out) {
+  const int tid = threadIdx.x;
+  double a[4] = {0, 0, 0, 0};
+  if (want) {
+    for (int64_t i = tid; i < P.NG; i += 256) { a[0] += P.gstats[i * 2]; a[1] += P.gstats[i * 2 + 1]; }
+    for (int64_t i = tid; i < P.F; i += 256) { a[2] += P.fstats[i * 2]; a[3] += P.fstats[i * 2 + 1]; }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double s = block_sum256(a[k], s4);
+    if (tid == 0) out[k] = s;
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// init (one block, first evaluation only): Jacobi scale of the shared block, trust-region state
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rig_init(RigDev P) {
+  __shared__ double s4[4];
+  __shared__ double s_out[4];
+  __shared__ double s_ss[kRigMaxS];
+  const LmCtl* ctl = P.ctl;
+  if (ctl->done || ctl->phase != 0) return;
+  const int tid = threadIdx.x;
+  rig_reduce_stats(P, true, s4, s_out);
+  const bool jac = P.opts->jacobi_scaling != 0;
+  for (int c = 0; c < P.C; ++c) {
+    double h[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = P.cam_goff[c] + tid; k < P.cam_goff[c + 1]; k += 256) {
+      const int g = P.cam_glist[k];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) h[i] += P.ghd0[(size_t)g * 8 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const double s = block_sum256(h[i], s4);
+      if (tid == 0) s_ss[c * 6 + i] = jac ? 1.0 / (1.0 + sqrt(s)) : 1.0;
+    }
+  }
+  __syncthreads();
+  if (tid < P.S) P.ss[tid] = s_ss[tid];
+  if (tid == 0) {
+    LmCtl c = *ctl;
+    const LmOpts o = *P.opts;
+    double xn2 = s_out[3];
+    for (int cc2 = 0; cc2 < P.C; ++cc2)
+      if (!P.cam_fixed[cc2])
+        for (int i = 0; i < 7; ++i) { const double v = P.cam[((size_t)c.cur * P.C + cc2) * 8 + i]; xn2 += v * v; }
+    lm_init(c, o, s_out[0], sqrt(xn2));
+    *P.ctl = c;
+    *P.ctl_next = c;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// decide + elim. All 256 threads of a block work on one frame at a time; the block loops over its
+// frames. Each thread owns up to kRigOwn columns of the partial row and accumulates them in
+// registers across frames (no atomics, deterministic).
+// Partial row: [0..NP) upper triangle of the reduced (6C)x(6C) system, [pc_b..) rhs, [pc_hd..) diag of
+// the scaled H_ss, [pc_fail] Cholesky failures, [pc_gs..) unscaled shared gradient, [pc_gmax] max |g_frame|.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rig_decide_elim(RigDev P) {
+  __shared__ double LG[kRigMaxCams][256];
+  __shared__ double Zl[6][kRigMaxS + 4];
+  __shared__ double s_A[28];  // 21 packed H_ff entries + 6 g_f
+  __shared__ double s_ss[kRigMaxS];
+  __shared__ double s4[4];
+  __shared__ double s_tot[4];
+  __shared__ int s_slot[kRigMaxCams];   // camera -> slot of its group in this frame (-1: absent)
+  __shared__ int s_cam[kRigMaxCams];    // slot -> camera
+  __shared__ LmCtl s_ctl;
+  const int tid = threadIdx.x;
+  const LmCtl* ctl = P.ctl;
+  if (ctl->done || ctl->phase == 0) return;
+  const bool pending = ctl->cand_pending != 0;
+  rig_reduce_stats(P, pending && ctl->step_valid, s4, s_tot);
+  if (tid == 0) {
+    LmCtl c = *ctl;
+    const LmOpts o = *P.opts;
+    if (pending) {
+      double step2 = s_tot[2], xn2 = s_tot[3];
+      if (c.step_valid) { step2 += P.shared_stats[0]; xn2 += P.shared_stats[1]; }
+      lm_decide(c, o, blockIdx.x == 0 ? P.log : nullptr, P.log_cap, s_tot[0], s_tot[1], step2, xn2);
+    }
+    s_ctl = c;
+    if (blockIdx.x == 0) *P.ctl_next = c;
+  }
+  if (tid < P.S) s_ss[tid] = P.ss[tid];
+  __syncthreads();
+  if (s_ctl.done) return;
+  const int cur = s_ctl.cur;
+  const double radius = s_ctl.radius;
+  const double mn = P.opts->min_lm_diagonal, mx = P.opts->max_lm_diagonal;
+
+  // static description of the columns this thread owns
+  int op[kRigOwn], oq[kRigOwn];
+#pragma unroll
+  for (int r = 0; r < kRigOwn; ++r) {
+    const int o = tid + 256 * r;
+    op[r] = -1; oq[r] = -1;
+    if (o < P.NP) { op[r] = P.pair_p[o]; oq[r] = P.pair_q[o]; }
+  }
+  double acc[kRigOwn];
+#pragma unroll
+  for (int r = 0; r < kRigOwn; ++r) acc[r] = 0.0;
+
+  for (int64_t f = blockIdx.x; f < P.F; f += gridDim.x) {
+    const int64_t g0 = P.fgoff[f];
+    const int ng = (int)(P.fgoff[f + 1] - g0);
+    if (ng == 0) continue;  // uniform across the block
+    if (tid < kRigMaxCams) s_slot[tid] = -1;
+    __syncthreads();
+    if (tid < ng) { const int cam = P.gcam[g0 + tid]; s_cam[tid] = cam; s_slot[cam] = tid; }
+    for (int s = 0; s < ng; ++s) LG[s][tid] = P.gblocks[((size_t)cur * P.NG + g0 + s) * 256 + tid];
+    __syncthreads();
+    // frame block: A = sum over groups of H_ff (rows/cols 6..11), g_f = sum of column 12
+    if (tid < 21 + 6) {
+      double a = 0.0;
+      if (tid < 21) {
+        int i = 0;
+        while (tri(i + 1, 0) <= tid) ++i;
+        const int j = tid - tri(i, 0);
+        for (int s = 0; s < ng; ++s) a += LG[s][(6 + i) * 16 + 6 + j];
+      } else {
+        const int i = tid - 21;
+        for (int s = 0; s < ng; ++s) a += LG[s][(6 + i) * 16 + 12];
+      }
+      s_A[tid] = a;
+    }
+    __syncthreads();
+    double sf[6], L[21], Li[6];
+    if (ctl->phase == 1 && s_ctl.iter == 0 && !pending) {
+      // first elimination after the initial evaluation: Jacobi scale of this frame's pose block
+#pragma unroll
+      for (int i = 0; i < 6; ++i) sf[i] = P.opts->jacobi_scaling ? 1.0 / (1.0 + sqrt(s_A[tri(i, i)])) : 1.0;
+      if (tid < 6) P.sp[f * 8 + tid] = sf[tid];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) sf[i] = P.sp[f * 8 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) L[tri(i, j)] = sf[i] * s_A[tri(i, j)] * sf[j];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) L[tri(i, i)] += clampd(L[tri(i, i)], mn, mx) / radius;
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      double d = L[tri(j, j)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) d -= L[tri(j, k)] * L[tri(j, k)];
+      ok = ok && (d > 0.0) && isfinite(d);
+      d = sqrt(d);
+      L[tri(j, j)] = d;
+      const double inv = 1.0 / d;
+      Li[j] = inv;
+#pragma unroll
+      for (int i = j + 1; i < 6; ++i) {
+        double a = L[tri(i, j)];
+#pragma unroll
+        for (int k = 0; k < j; ++k) a -= L[tri(i, k)] * L[tri(j, k)];
+        L[tri(i, j)] = a * inv;
+      }
+    }
+    // columns of [H_fs | g_f]: column k < S belongs to camera k/6 (zero if absent), column S is g_f
+    if (tid < P.SW) {
+      const int k = tid;
+      double w[6];
+      if (k < P.S) {
+        const int cam = k / 6, a = k - cam * 6, slot = s_slot[cam];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[i] = slot >= 0 ? sf[i] * LG[slot][a * 16 + 6 + i] * s_ss[k] : 0.0;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[i] = sf[i] * s_A[21 + i];
+      }
+      double z[6], y[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        double a = w[i];
+#pragma unroll
+        for (int kk = 0; kk < i; ++kk) a -= L[tri(i, kk)] * z[kk];
+        z[i] = a * Li[i];
+      }
+#pragma unroll
+      for (int i = 5; i >= 0; --i) {
+        double a = z[i];
+#pragma unroll
+        for (int kk = i + 1; kk < 6; ++kk) a -= L[tri(kk, i)] * y[kk];
+        y[i] = a * Li[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        Zl[i][k] = z[i];
+        P.Y[((size_t)f * 6 + i) * P.SW + k] = y[i];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kRigOwn; ++r) {
+      const int o = tid + 256 * r;
+      if (o >= P.PC) continue;
+      double a = 0.0;
+      if (o < P.NP) {
+        const int p = op[r], q = oq[r];
+        const int cp = p / 6, cq = q / 6;
+        const int sp_ = s_slot[cp], sq_ = s_slot[cq];
+        if (sp_ >= 0 && sq_ >= 0) {
+          if (cp == cq) a = s_ss[p] * LG[sp_][(p - cp * 6) * 16 + (q - cq * 6)] * s_ss[q];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) a -= Zl[i][p] * Zl[i][q];
+        }
+        acc[r] += a;
+      } else if (o < P.pc_hd) {
+        const int p = o - P.pc_b, cp = p / 6, sl = s_slot[cp];
+        if (sl >= 0) {
+          a = s_ss[p] * LG[sl][(p - cp * 6) * 16 + 12];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) a -= Zl[i][p] * Zl[i][P.S];
+        }
+        acc[r] += a;
+      } else if (o < P.pc_fail) {
+        const int p = o - P.pc_hd, cp = p / 6, sl = s_slot[cp];
+        if (sl >= 0) a = s_ss[p] * s_ss[p] * LG[sl][(p - cp * 6) * 17];
+        acc[r] += a;
+      } else if (o == P.pc_fail) {
+        acc[r] += ok ? 0.0 : 1.0;
+      } else if (o < P.pc_gmax) {
+        const int p = o - P.pc_gs, cp = p / 6, sl = s_slot[cp];
+        if (sl >= 0) a = LG[sl][(p - cp * 6) * 16 + 12];
+        acc[r] += a;
+      } else {
+        for (int i = 0; i < 6; ++i) a = fmax(a, fabs(s_A[21 + i]));
+        acc[r] = fmax(acc[r], a);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < kRigOwn; ++r) {
+    const int o = tid + 256 * r;
+    if (o < P.PC) P.partial[(size_t)blockIdx.x * P.PC + o] = acc[r];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// solve (one block of 256): reduce the partial rows, dense Cholesky of the reduced system in
+// LDS, gradient test, camera candidates. In phase 0 it only prepares the camera records.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rig_solve(RigDev P) {
+  __shared__ double A[kRigMaxS][kRigMaxS + 1];
+  __shared__ double b[kRigMaxS];
+  __shared__ double hd[kRigMaxS];
+  __shared__ double gs[kRigMaxS];
+  __shared__ double s_misc[4];  // fail, gmax
+  __shared__ int s_ok;
+  __shared__ double s4[4];
+  const int tid = threadIdx.x;
+  const LmCtl* cn = P.ctl_next;
+  const int done = cn->done, phase = cn->phase, cur = cn->cur;
+  const int S = P.S;
+  if (done) {
+    if (tid == 0) *P.ctl = *cn;
+    return;
+  }
+  bool step_ok = false, converged = false;
+  double gmax = 0.0;
+  if (phase != 0) {
+    // ---- reduce partial rows: column o handled by thread o % 256
+    for (int o = tid; o < P.PC; o += 256) {
+      double a = 0.0;
+      if (o == P.pc_gmax) { for (int r = 0; r < P.nblk; ++r) a = fmax(a, P.partial[(size_t)r * P.PC + o]); }
+      else {
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        int r = 0;
+        for (; r + 3 < P.nblk; r += 4) {
+          a0 += P.partial[(size_t)r * P.PC + o]; a1 += P.partial[(size_t)(r + 1) * P.PC + o];
+          a2 += P.partial[(size_t)(r + 2) * P.PC + o]; a3 += P.partial[(size_t)(r + 3) * P.PC + o];
+        }
+        for (; r < P.nblk; ++r) a0 += P.partial[(size_t)r * P.PC + o];
+        a = (a0 + a1) + (a2 + a3);
+      }
+      if (o < P.NP) { const int p = P.pair_p[o], q = P.pair_q[o]; A[p][q] = a; A[q][p] = a; }
+      else if (o < P.pc_hd) b[o - P.pc_b] = a;
+      else if (o < P.pc_fail) hd[o - P.pc_hd] = a;
+      else if (o == P.pc_fail) s_misc[0] = a;
+      else if (o < P.pc_gmax) gs[o - P.pc_gs] = a;
+      else s_misc[1] = a;
+    }
+    __syncthreads();
+    const LmOpts o = *P.opts;
+    gmax = s_misc[1];
+    for (int p = 0; p < S; ++p)
+      if (!P.cam_fixed[p / 6]) gmax = fmax(gmax, fabs(gs[p]));
+    converged = gmax <= o.gradient_tolerance;
+    if (!converged) {
+      const double radius = cn->radius;
+      if (tid < S) {
+        const int p = tid;
+        if (P.cam_fixed[p / 6]) {
+          for (int q = 0; q < S; ++q) { A[p][q] = 0.0; A[q][p] = 0.0; }
+        }
+      }
+      __syncthreads();
+      if (tid < S) {
+        const int p = tid;
+        if (P.cam_fixed[p / 6]) { A[p][p] = 1.0; b[p] = 0.0; }
+        else A[p][p] += clampd(hd[p], o.min_lm_diagonal, o.max_lm_diagonal) / radius;
+      }
+      if (tid == 0) s_ok = s_misc[0] > 0.0 ? 0 : 1;
+      __syncthreads();
+      // right-looking Cholesky, lower triangle in place
+      for (int j = 0; j < S; ++j) {
+        if (tid == 0) {
+          const double d = A[j][j];
+          if (!(d > 0.0) || !isfinite(d)) s_ok = 0;
+          A[j][j] = sqrt(d);
+        }
+        __syncthreads();
+        const double inv = 1.0 / A[j][j];
+        if (tid > j && tid < S) A[tid][j] *= inv;
+        __syncthreads();
+        for (int e = tid; e < (S - j - 1) * (S - j - 1); e += 256) {
+          const int i = j + 1 + e / (S - j - 1), k = j + 1 + e % (S - j - 1);
+          if (k <= i) A[i][k] -= A[i][j] * A[k][j];
+        }
+        __syncthreads();
+      }
+      // forward / backward substitution (column oriented)
+      for (int j = 0; j < S; ++j) {
+        if (tid == 0) b[j] /= A[j][j];
+        __syncthreads();
+        if (tid > j && tid < S) b[tid] -= A[tid][j] * b[j];
+        __syncthreads();
+      }
+      for (int j = S - 1; j >= 0; --j) {
+        if (tid == 0) b[j] /= A[j][j];
+        __syncthreads();
+        if (tid < j) b[tid] -= A[j][tid] * b[j];
+        __syncthreads();
+      }
+      if (tid < S && !isfinite(b[tid])) s_ok = 0;
+      __syncthreads();
+      step_ok = s_ok != 0;
+      if (tid < S) P.ds[tid] = -b[tid];
+    }
+  }
+  // ---- camera candidates / records
+  const int dst = phase == 0 ? cur : (cur ^ 1);
+  double step2 = 0.0, xn2 = 0.0;
+  if (tid < P.C && (phase == 0 || step_ok)) {
+    const int c = tid;
+    const double* pc = P.cam + ((size_t)cur * P.C + c) * 8;
+    double q[4] = {pc[0], pc[1], pc[2], pc[3]}, t[3] = {pc[4], pc[5], pc[6]};
+    double dc[6] = {0, 0, 0, 0, 0, 0};
+    if (phase != 0) {
+      if (!P.cam_fixed[c]) {
+        for (int i = 0; i < 6; ++i) dc[i] = -b[c * 6 + i] * P.ss[c * 6 + i];
+        double qn[4];
+        quat_plus(q, dc, qn);
+        for (int i = 0; i < 4; ++i) { const double d = qn[i] - q[i]; step2 += d * d; q[i] = qn[i]; }
+        for (int i = 0; i < 3; ++i) { const double tn = t[i] + dc[3 + i]; const double d = tn - t[i]; step2 += d * d; t[i] = tn; }
+        xn2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + t[0] * t[0] + t[1] * t[1] + t[2] * t[2];
+      }
+      double* pd = P.cam + ((size_t)dst * P.C + c) * 8;
+      for (int i = 0; i < 4; ++i) pd[i] = q[i];
+      for (int i = 0; i < 3; ++i) pd[4 + i] = t[i];
+    }
+    double R[9];
+    quat_to_R(q, R);
+    double* rec = P.camrec + c * 32;
+    for (int i = 0; i < 9; ++i) rec[i] = R[i];
+    for (int i = 0; i < 3; ++i) rec[9 + i] = t[i];
+    for (int i = 0; i < 6; ++i) rec[12 + i] = dc[i];
+  }
+  const double st = block_sum256(step2, s4);
+  const double xs = block_sum256(xn2, s4);
+  if (tid == 0) {
+    LmCtl c = *cn;
+    if (phase != 0) {
+      c.gmax = gmax;
+      if (c.log_len > 0 && c.log_len <= P.log_cap && P.log[c.log_len - 1].accepted)
+        P.log[c.log_len - 1].gradient_max_norm = gmax;
+      if (converged) { c.done = 1; c.term = CC_CONVERGENCE_GRADIENT; }
+      else {
+        c.step_valid = step_ok ? 1 : 0;
+        c.cand_pending = 1;
+        P.shared_stats[0] = st;
+        P.shared_stats[1] = xs;
+      }
+    }
+    *P.ctl = c;
+    *P.ctl_next = c;
+  }
+}
+
+// per-observation robustified cost at the accepted point (extrinsics_calibrator.cpp:219-225)
+__global__ void k_rig_obs_cost(RigDev P, int cur, double* out /*sorted order*/) {
+  const int64_t g = blockIdx.x;
+  const int f = P.gframe[g], c = P.gcam[g];
+  const double* pc = P.cam + ((size_t)cur * P.C + c) * 8;
+  const double* pf = P.pose + ((size_t)cur * P.F + f) * 8;
+  double Rc[9], Rf[9];
+  quat_to_R(pc, Rc);
+  quat_to_R(pf, Rf);
+  const float2* uv2 = reinterpret_cast<const float2*>(P.uv);
+  for (int64_t idx = P.goff[g] + threadIdx.x; idx < P.goff[g + 1]; idx += blockDim.x) {
+    const float2 m = uv2[idx];
+    const int64_t w = P.widx[idx];
+    RigObs o;
+    rig_common(Rf, pf + 4, Rc, pc + 4, (double)P.wxyz[w * 3], (double)P.wxyz[w * 3 + 1], (double)P.wxyz[w * 3 + 2],
+               (double)m.x, (double)m.y, o);
+    double rho, sr;
+    huber(P.huber_a, o.ru * o.ru + o.rv * o.rv, rho, sr);
+    out[idx] = 0.5 * rho;
+  }
+}
+
+}  // namespace cc
+
+// =============================================================================================
+// host side
+// =============================================================================================
+struct cc_rig {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  cc::RigDev d{};
+  int64_t C = 0, F = 0, N = 0, NG = 0, P = 0;
+  std::vector<int64_t> perm;  // sorted position -> caller's observation index
+  std::vector<void*> allocs;
+  double* init_cam = nullptr;
+  double* init_pose = nullptr;
+  double* d_cost = nullptr;
+  bool have_state = false;
+  cc::LmCtl* h_ctl = nullptr;
+  hipGraphExec_t graph[2] = {nullptr, nullptr};
+  int graph_iters = 0;
+};
+
+namespace cc {
+
+template <class T>
+static int dev_alloc(cc_rig* h, T** p, size_t n) {
+  CC_HIP(hipMalloc(p, std::max<size_t>(n, 1) * sizeof(T)));
+  h->allocs.push_back(*p);
+  return 0;
+}
+template <class T>
+static int dev_upload(cc_rig* h, const T** p, const std::vector<T>& v) {
+  T* q = nullptr;
+  if (int rc = dev_alloc(h, &q, v.size())) return rc;
+  if (!v.empty()) CC_HIP(hipMemcpy(q, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *p = q;
+  return 0;
+}
+
+static void rig_drop_graphs(cc_rig* h) {
+  for (auto& g : h->graph)
+    if (g) { hipGraphExecDestroy(g); g = nullptr; }
+}
+
+static void rig_enqueue_round(cc_rig* h) {
+  const RigDev& d = h->d;
+  hipLaunchKernelGGL(k_rig_solve, dim3(1), dim3(256), 0, h->stream, d);
+  hipLaunchKernelGGL(k_rig_update, dim3((unsigned)((h->F + 15) / 16)), dim3(256), 0, h->stream, d);
+  hipLaunchKernelGGL(k_rig_sweep, dim3((unsigned)h->NG), dim3(kRigThreads), kRigSweepLdsBytes, h->stream, d);
+  hipLaunchKernelGGL(k_rig_init, dim3(1), dim3(256), 0, h->stream, d);
+  hipLaunchKernelGGL(k_rig_decide_elim, dim3(d.nblk), dim3(256), 0, h->stream, d);
+}
+
+static int rig_write_ctl(cc_rig* h, const LmCtl& c) {
+  CC_HIP(hipMemcpyAsync(h->d.ctl, &c, sizeof(c), hipMemcpyHostToDevice, h->stream));
+  CC_HIP(hipMemcpyAsync(h->d.ctl_next, &c, sizeof(c), hipMemcpyHostToDevice, h->stream));
+  return 0;
+}
+static int rig_read_ctl(cc_rig* h, LmCtl* c) {
+  CC_HIP(hipMemcpyAsync(h->h_ctl, h->d.ctl_next, sizeof(LmCtl), hipMemcpyDeviceToHost, h->stream));
+  CC_HIP(hipStreamSynchronize(h->stream));
+  *c = *h->h_ctl;
+  return 0;
+}
+
+}  // namespace cc
+
+extern "C" {
+
+int cc_rig_create(int32_t device, int64_t C, int64_t F, int64_t n_world, const int64_t* off,
+                  const uint32_t* obs_cam, const uint64_t* obs_world, const float* obs_uv,
+                  const float* world_xyz, const uint8_t* cam_frozen, double huber_a, cc_rig** out) {
+  using namespace cc;
+  if (!out || !off || C < 1 || F < 1 || n_world < 0) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: bad arguments");
+  if (C > kRigMaxCams) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: at most %d cameras", kRigMaxCams);
+  if (off[0] != 0) return fail(CC_ERR_BAD_ARGUMENT, "obs_frame_offsets[0] must be 0");
+  const int64_t N = off[F];
+  for (int64_t f = 0; f < F; ++f)
+    if (off[f + 1] < off[f]) return fail(CC_ERR_BAD_ARGUMENT, "obs_frame_offsets must be non-decreasing");
+  if (N > 0 && (!obs_cam || !obs_world || !obs_uv || !world_xyz)) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: NULL arrays");
+  for (int64_t k = 0; k < N; ++k) {
+    if (obs_cam[k] >= (uint32_t)C) return fail(CC_ERR_BAD_ARGUMENT, "observation %lld: camera id out of range", (long long)k);
+    if (obs_world[k] >= (uint64_t)n_world) return fail(CC_ERR_BAD_ARGUMENT, "observation %lld: world point id out of range", (long long)k);
+  }
+  if (int rc = select_device(device)) return rc;
+  cc_rig* h = new cc_rig();
+  h->device = device; h->C = C; h->F = F; h->N = N; h->P = n_world;
+  // ---- regroup: within each frame, stable sort by camera -> (frame, camera) groups
+  h->perm.resize((size_t)N);
+  std::vector<int64_t> goff{0}, fgoff((size_t)F + 1, 0);
+  std::vector<int32_t> gframe, gcam;
+  std::vector<uint8_t> seen((size_t)C, 0);
+  {
+    int64_t pos = 0;
+    for (int64_t f = 0; f < F; ++f) {
+      std::vector<int64_t> idx((size_t)(off[f + 1] - off[f]));
+      std::iota(idx.begin(), idx.end(), off[f]);
+      std::stable_sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) { return obs_cam[a] < obs_cam[b]; });
+      for (size_t i = 0; i < idx.size(); ++i) {
+        if (i == 0 || obs_cam[idx[i]] != obs_cam[idx[i - 1]]) {
+          if (i != 0) goff.push_back(pos);
+          gframe.push_back((int32_t)f);
+          gcam.push_back((int32_t)obs_cam[idx[i]]);
+          seen[obs_cam[idx[i]]] = 1;
+        }
+        h->perm[(size_t)pos++] = idx[i];
+      }
+      if (!idx.empty()) goff.push_back(pos);
+      fgoff[(size_t)f + 1] = (int64_t)gframe.size();
+    }
+  }
+  const int64_t NG = (int64_t)gframe.size();
+  h->NG = NG;
+  if (NG == 0) { delete h; return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: no observations"); }
+  std::vector<float> uv((size_t)N * 2);
+  std::vector<int32_t> widx((size_t)N);
+  for (int64_t i = 0; i < N; ++i) {
+    const int64_t k = h->perm[(size_t)i];
+    uv[2 * i] = obs_uv[2 * k]; uv[2 * i + 1] = obs_uv[2 * k + 1];
+    widx[(size_t)i] = (int32_t)obs_world[k];
+  }
+  std::vector<int32_t> cam_goff((size_t)C + 1, 0), cam_glist((size_t)NG);
+  for (int64_t g = 0; g < NG; ++g) cam_goff[(size_t)gcam[g] + 1]++;
+  for (int64_t c = 0; c < C; ++c) cam_goff[c + 1] += cam_goff[c];
+  {
+    std::vector<int32_t> fill(cam_goff.begin(), cam_goff.end() - 1);
+    for (int64_t g = 0; g < NG; ++g) cam_glist[(size_t)fill[gcam[g]]++] = (int32_t)g;
+  }
+  std::vector<uint8_t> fixed((size_t)C);
+  for (int64_t c = 0; c < C; ++c) fixed[c] = ((cam_frozen && cam_frozen[c]) || !seen[c]) ? 1 : 0;
+  const int S = (int)(6 * C);
+  std::vector<uint8_t> pp, pq;
+  for (int p = 0; p < S; ++p) for (int q = p; q < S; ++q) { pp.push_back((uint8_t)p); pq.push_back((uint8_t)q); }
+
+  CC_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  RigDev& d = h->d;
+  d.F = F; d.N = N; d.NG = NG; d.C = (int32_t)C; d.S = S; d.SW = S + 1; d.NP = S * (S + 1) / 2;
+  d.pc_b = d.NP; d.pc_hd = d.NP + S; d.pc_fail = d.NP + 2 * S; d.pc_gs = d.pc_fail + 1; d.pc_gmax = d.pc_gs + S; d.PC = d.pc_gmax + 1;
+  d.nblk = (int)std::min<int64_t>(kRigMaxElimBlocks, F);
+  d.huber_a = huber_a;
+  if (d.PC > 256 * kRigOwn) { delete h; return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: too many cameras"); }
+  { const float* p; if (int rc = dev_upload(h, &p, uv)) return rc; d.uv = p; }
+  if (int rc = dev_upload(h, &d.widx, widx)) return rc;
+  { std::vector<float> w(world_xyz, world_xyz + (size_t)n_world * 3); if (int rc = dev_upload(h, &d.wxyz, w)) return rc; }
+  if (int rc = dev_upload(h, &d.goff, goff)) return rc;
+  if (int rc = dev_upload(h, &d.gframe, gframe)) return rc;
+  if (int rc = dev_upload(h, &d.gcam, gcam)) return rc;
+  if (int rc = dev_upload(h, &d.fgoff, fgoff)) return rc;
+  if (int rc = dev_upload(h, &d.cam_goff, cam_goff)) return rc;
+  if (int rc = dev_upload(h, &d.cam_glist, cam_glist)) return rc;
+  if (int rc = dev_upload(h, &d.cam_fixed, fixed)) return rc;
+  if (int rc = dev_upload(h, &d.pair_p, pp)) return rc;
+  if (int rc = dev_upload(h, &d.pair_q, pq)) return rc;
+  if (int rc = dev_alloc(h, &d.cam, (size_t)2 * C * 8)) return rc;
+  if (int rc = dev_alloc(h, &d.pose, (size_t)2 * F * 8)) return rc;
+  if (int rc = dev_alloc(h, &d.camrec, (size_t)C * 32)) return rc;
+  if (int rc = dev_alloc(h, &d.frec, (size_t)F * 32)) return rc;
+  if (int rc = dev_alloc(h, &d.gblocks, (size_t)2 * NG * 256)) return rc;
+  if (int rc = dev_alloc(h, &d.gstats, (size_t)NG * 2)) return rc;
+  if (int rc = dev_alloc(h, &d.fstats, (size_t)F * 2)) return rc;
+  if (int rc = dev_alloc(h, &d.ghd0, (size_t)NG * 8)) return rc;
+  if (int rc = dev_alloc(h, &d.sp, (size_t)F * 8)) return rc;
+  if (int rc = dev_alloc(h, &d.ss, (size_t)64)) return rc;
+  if (int rc = dev_alloc(h, &d.ds, (size_t)64)) return rc;
+  if (int rc = dev_alloc(h, &d.Y, (size_t)F * 6 * d.SW)) return rc;
+  if (int rc = dev_alloc(h, &d.partial, (size_t)d.nblk * d.PC)) return rc;
+  if (int rc = dev_alloc(h, &d.shared_stats, (size_t)4)) return rc;
+  if (int rc = dev_alloc(h, &d.ctl, (size_t)1)) return rc;
+  if (int rc = dev_alloc(h, &d.ctl_next, (size_t)1)) return rc;
+  if (int rc = dev_alloc(h, &d.opts, (size_t)1)) return rc;
+  d.log_cap = 4096;
+  if (int rc = dev_alloc(h, &d.log, (size_t)d.log_cap)) return rc;
+  if (int rc = dev_alloc(h, &h->init_cam, (size_t)C * 8)) return rc;
+  if (int rc = dev_alloc(h, &h->init_pose, (size_t)F * 8)) return rc;
+  if (int rc = dev_alloc(h, &h->d_cost, (size_t)N)) return rc;
+  CC_HIP(hipMemset(d.cam, 0, (size_t)2 * C * 8 * sizeof(double)));
+  CC_HIP(hipMemset(d.pose, 0, (size_t)2 * F * 8 * sizeof(double)));
+  CC_HIP(hipMemset(d.sp, 0, (size_t)F * 8 * sizeof(double)));
+  CC_HIP(hipMemset(d.ss, 0, 64 * sizeof(double)));
+  CC_HIP(hipMemset(d.ds, 0, 64 * sizeof(double)));
+  CC_HIP(hipMemset(d.Y, 0, (size_t)F * 6 * d.SW * sizeof(double)));
+  CC_HIP(hipMemset(d.gstats, 0, (size_t)NG * 2 * sizeof(double)));
+  CC_HIP(hipMemset(d.fstats, 0, (size_t)F * 2 * sizeof(double)));
+  CC_HIP(hipMemset(d.ghd0, 0, (size_t)NG * 8 * sizeof(double)));
+  CC_HIP(hipMemset(d.frec, 0, (size_t)F * 32 * sizeof(double)));
+  CC_HIP(hipMemset(d.camrec, 0, (size_t)C * 32 * sizeof(double)));
+  CC_HIP(hipMemset(d.partial, 0, (size_t)d.nblk * d.PC * sizeof(double)));
+  CC_HIP(hipMemset(d.shared_stats, 0, 4 * sizeof(double)));
+  CC_HIP(hipMemset(d.ctl, 0, sizeof(LmCtl)));
+  CC_HIP(hipMemset(d.ctl_next, 0, sizeof(LmCtl)));
+  CC_HIP(hipHostMalloc(&h->h_ctl, sizeof(LmCtl), hipHostMallocDefault));
+  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_sweep), hipFuncAttributeMaxDynamicSharedMemorySize, kRigSweepLdsBytes));
+  *out = h;
+  return CC_OK;
+}
+
+void cc_rig_destroy(cc_rig* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  cc::rig_drop_graphs(h);
+  for (void* p : h->allocs) hipFree(p);
+  if (h->h_ctl) hipHostFree(h->h_ctl);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int cc_rig_set_state(cc_rig* h, const double* cam_q, const double* cam_t, const double* frame_q, const double* frame_t) {
+  using namespace cc;
+  if (!h || !cam_q || !cam_t || !frame_q || !frame_t) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_set_state: NULL argument");
+  CC_HIP(hipSetDevice(h->device));
+  std::vector<double> cam((size_t)h->C * 8, 0.0), pose((size_t)h->F * 8, 0.0);
+  for (int64_t c = 0; c < h->C; ++c) {
+    for (int i = 0; i < 4; ++i) cam[c * 8 + i] = cam_q[c * 4 + i];
+    for (int i = 0; i < 3; ++i) cam[c * 8 + 4 + i] = cam_t[c * 3 + i];
+  }
+  for (int64_t f = 0; f < h->F; ++f) {
+    for (int i = 0; i < 4; ++i) pose[f * 8 + i] = frame_q[f * 4 + i];
+    for (int i = 0; i < 3; ++i) pose[f * 8 + 4 + i] = frame_t[f * 3 + i];
+  }
+  CC_HIP(hipStreamSynchronize(h->stream));
+  CC_HIP(hipMemcpy(h->init_cam, cam.data(), cam.size() * sizeof(double), hipMemcpyHostToDevice));
+  CC_HIP(hipMemcpy(h->init_pose, pose.data(), pose.size() * sizeof(double), hipMemcpyHostToDevice));
+  h->have_state = true;
+  return cc_rig_reset(h);
+}
+
+int cc_rig_reset(cc_rig* h) {
+  using namespace cc;
+  if (!h || !h->have_state) return fail(CC_ERR_STATE, "cc_rig_reset: no state set");
+  CC_HIP(hipSetDevice(h->device));
+  LmCtl c{};
+  if (int rc = rig_write_ctl(h, c)) return rc;
+  CC_HIP(hipMemcpyAsync(h->d.cam, h->init_cam, (size_t)h->C * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  CC_HIP(hipMemcpyAsync(h->d.pose, h->init_pose, (size_t)h->F * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  return CC_OK;
+}
+
+int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
+  using namespace cc;
+  if (!h || !h->have_state) return fail(CC_ERR_STATE, "cc_rig_solve: no state set");
+  const auto t0 = std::chrono::steady_clock::now();
+  cc_options o;
+  if (opt) o = *opt; else { cc_options_init(&o); o.max_iterations = 1000; }  // extrinsics_calibrator.cpp:211
+  if (o.check_interval < 1) o.check_interval = 1;
+  if (o.max_iterations > h->d.log_cap - 1) o.max_iterations = h->d.log_cap - 1;
+  const bool use_graph = o.use_graph != 0;
+  CC_HIP(hipSetDevice(h->device));
+  {
+    LmCtl st;
+    if (int rc = rig_read_ctl(h, &st)) return rc;
+    if (st.cur & 1) {
+      CC_HIP(hipMemcpyAsync(h->d.cam, h->d.cam + (size_t)h->C * 8, (size_t)h->C * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+      CC_HIP(hipMemcpyAsync(h->d.pose, h->d.pose + (size_t)h->F * 8, (size_t)h->F * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    }
+    LmOpts lo;
+    opts_from_public(o, &lo);
+    CC_HIP(hipMemcpyAsync(h->d.opts, &lo, sizeof(lo), hipMemcpyHostToDevice, h->stream));
+    LmCtl c{};
+    if (int rc = rig_write_ctl(h, c)) return rc;
+  }
+  if (use_graph && (!h->graph[0] || h->graph_iters != o.check_interval)) {
+    rig_drop_graphs(h);
+    for (int gi = 0; gi < 2; ++gi) {
+      hipGraph_t g = nullptr;
+      CC_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+      const int n = o.check_interval + (gi == 0 ? 1 : 0);
+      for (int i = 0; i < n; ++i) rig_enqueue_round(h);
+      CC_HIP(hipStreamEndCapture(h->stream, &g));
+      CC_HIP(hipGraphInstantiate(&h->graph[gi], g, nullptr, nullptr, 0));
+      hipGraphDestroy(g);
+    }
+    h->graph_iters = o.check_interval;
+  }
+  int launched = 0;
+  LmCtl st;
+  for (int chunk = 0;; ++chunk) {
+    const int n = o.check_interval + (chunk == 0 ? 1 : 0);
+    if (use_graph) {
+      CC_HIP(hipGraphLaunch(h->graph[chunk == 0 ? 0 : 1], h->stream));
+    } else {
+      for (int i = 0; i < n; ++i) rig_enqueue_round(h);
+      CC_HIP(hipGetLastError());
+    }
+    launched += n;
+    if (int rc = rig_read_ctl(h, &st)) return rc;
+    if (st.done) break;
+    if (launched > o.max_iterations + 2 * o.check_interval + 2)
+      return fail(CC_ERR_STATE, "rig LM loop did not terminate (iter=%d)", st.iter);
+  }
+  if (summary) {
+    cc_iteration* user_log = summary->log;
+    const int cap = summary->log_capacity;
+    summary->iterations = st.iter;
+    summary->successful_steps = st.n_success;
+    summary->termination = st.term;
+    summary->initial_cost = st.initial_cost;
+    summary->final_cost = st.x_cost;
+    summary->sweeps = st.sweeps;
+    const int n = user_log ? std::min(std::min(st.log_len, cap), h->d.log_cap) : 0;
+    summary->log_len = n;
+    if (n > 0) CC_HIP(hipMemcpy(user_log, h->d.log, (size_t)n * sizeof(cc_iteration), hipMemcpyDeviceToHost));
+    for (int i = 0; i < CC_K_COUNT; ++i) { summary->kernel_ms[i] = 0.0; summary->kernel_launches[i] = 0; }
+    summary->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  return CC_OK;
+}
+
+int cc_rig_get_state(cc_rig* h, double* cam_q, double* cam_t, double* frame_q, double* frame_t, double* obs_cost) {
+  using namespace cc;
+  if (!h) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_get_state: NULL handle");
+  CC_HIP(hipSetDevice(h->device));
+  LmCtl c;
+  if (int rc = rig_read_ctl(h, &c)) return rc;
+  const int cur = c.cur & 1;
+  if (cam_q || cam_t) {
+    std::vector<double> cam((size_t)h->C * 8);
+    CC_HIP(hipMemcpy(cam.data(), h->d.cam + (size_t)cur * h->C * 8, cam.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int64_t k = 0; k < h->C; ++k) {
+      if (cam_q) for (int i = 0; i < 4; ++i) cam_q[k * 4 + i] = cam[k * 8 + i];
+      if (cam_t) for (int i = 0; i < 3; ++i) cam_t[k * 3 + i] = cam[k * 8 + 4 + i];
+    }
+  }
+  if (frame_q || frame_t) {
+    std::vector<double> pose((size_t)h->F * 8);
+    CC_HIP(hipMemcpy(pose.data(), h->d.pose + (size_t)cur * h->F * 8, pose.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int64_t f = 0; f < h->F; ++f) {
+      if (frame_q) for (int i = 0; i < 4; ++i) frame_q[f * 4 + i] = pose[f * 8 + i];
+      if (frame_t) for (int i = 0; i < 3; ++i) frame_t[f * 3 + i] = pose[f * 8 + 4 + i];
+    }
+  }
+  if (obs_cost && h->N > 0) {
+    hipLaunchKernelGGL(k_rig_obs_cost, dim3((unsigned)h->NG), dim3(256), 0, h->stream, h->d, cur, h->d_cost);
+    CC_HIP(hipGetLastError());
+    std::vector<double> sorted((size_t)h->N);
+    CC_HIP(hipMemcpyAsync(sorted.data(), h->d_cost, sorted.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    CC_HIP(hipStreamSynchronize(h->stream));
+    for (int64_t i = 0; i < h->N; ++i) obs_cost[h->perm[(size_t)i]] = sorted[(size_t)i];
+  }
+  return CC_OK;
+}
+
+int cc_rig_eval(cc_rig* h, double* cost) {
+  using namespace cc;
+  if (!h || !h->have_state || !cost) return fail(CC_ERR_STATE, "cc_rig_eval: no state set");
+  std::vector<double> oc((size_t)h->N);
+  if (int rc = cc_rig_get_state(h, nullptr, nullptr, nullptr, nullptr, oc.data())) return rc;
+  double c = 0.0;
+  for (double v : oc) c += v;
+  *cost = c;
+  return CC_OK;
+}
+
+// Debug/test aid (not declared in the public header): copies a named device buffer to the host.
+int cc_rig_debug_fetch(cc_rig* h, const char* name, double* out, int64_t n) {
+  using namespace cc;
+  if (!h || !name || !out) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_debug_fetch: bad arguments");
+  CC_HIP(hipSetDevice(h->device));
+  CC_HIP(hipStreamSynchronize(h->stream));
+  const std::string k(name);
+  const double* src = nullptr;
+  const RigDev& d = h->d;
+  if (k == "ss") src = d.ss; else if (k == "sp") src = d.sp; else if (k == "ds") src = d.ds;
+  else if (k == "Y") src = d.Y; else if (k == "partial") src = d.partial; else if (k == "gblocks") src = d.gblocks;
+  else if (k == "camrec") src = d.camrec; else if (k == "frec") src = d.frec; else if (k == "gstats") src = d.gstats;
+  else if (k == "fstats") src = d.fstats; else if (k == "shared_stats") src = d.shared_stats; else if (k == "cam") src = d.cam; else if (k == "pose") src = d.pose;
+  else return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_debug_fetch: unknown buffer %s", name);
+  CC_HIP(hipMemcpy(out, src, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  return CC_OK;
+}
+
+int cc_rig_optimize(const cc_options* opt, int32_t device, int64_t C, int64_t F, int64_t n_world,
+                    const int64_t* off, const uint32_t* obs_cam, const uint64_t* obs_world,
+                    const float* obs_uv, const float* world_xyz, double* cam_q, double* cam_t,
+                    const uint8_t* cam_frozen, double* frame_q, double* frame_t, double huber_a,
+                    double* obs_cost, cc_summary* summary) {
+  cc_rig* h = nullptr;
+  int rc = cc_rig_create(device, C, F, n_world, off, obs_cam, obs_world, obs_uv, world_xyz, cam_frozen, huber_a, &h);
+  if (rc) return rc;
+  rc = cc_rig_set_state(h, cam_q, cam_t, frame_q, frame_t);
+  if (!rc) rc = cc_rig_solve(h, opt, summary);
+  if (!rc) rc = cc_rig_get_state(h, cam_q, cam_t, frame_q, frame_t, obs_cost);
+  cc_rig_destroy(h);
+  return rc;
+}
+
+}  // extern "C"

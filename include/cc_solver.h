@@ -156,6 +156,41 @@ int cc_partition_frames(int64_t n_frames, const int64_t* frame_offsets, int32_t 
                         int64_t* first_frame);
 
 /* ---------------------------------------------------------------------------------------------
+ * Rig problem (ExtrinsicsCalibrator::Optimize, extrinsics_calibrator.cpp:86-257): one pose per
+ * camera (camera_T_rig, shared) and one per observation frame (rig_T_world); world points are
+ * constant; residuals in normalised image coordinates with ceres::HuberLoss(huber_a).
+ * Observations are grouped by frame: frame f owns [obs_frame_offsets[f], obs_frame_offsets[f+1]).
+ * obs_world indexes world_xyz (3 floats per point). cam_frozen[c] != 0 keeps camera c constant;
+ * cameras / frames without observations are left untouched (they never enter the problem).
+ * n_cams <= 10.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct cc_rig cc_rig;
+
+int cc_rig_create(int32_t device, int64_t n_cams, int64_t n_frames, int64_t n_world,
+                  const int64_t* obs_frame_offsets, const uint32_t* obs_cam,
+                  const uint64_t* obs_world, const float* obs_uv, const float* world_xyz,
+                  const uint8_t* cam_frozen, double huber_a, cc_rig** out);
+void cc_rig_destroy(cc_rig* h);
+int cc_rig_set_state(cc_rig* h, const double* cam_q, const double* cam_t, const double* frame_q,
+                     const double* frame_t);
+int cc_rig_reset(cc_rig* h);
+int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary);
+/* Any output may be NULL. obs_cost[k] = 1/2 rho(|r_k|^2) at the current point, in the caller's
+ * observation order (extrinsics_calibrator.cpp:219-225). */
+int cc_rig_get_state(cc_rig* h, double* cam_q, double* cam_t, double* frame_q, double* frame_t,
+                     double* obs_cost);
+/* Total robustified cost at the current point (one sweep). */
+int cc_rig_eval(cc_rig* h, double* cost);
+
+/* One-shot: the call ExtrinsicsCalibrator::Optimize makes in place of
+ * extrinsics_calibrator.cpp:92-225. opt == NULL -> cc_options_init with max_iterations = 1000. */
+int cc_rig_optimize(const cc_options* opt, int32_t device, int64_t n_cams, int64_t n_frames,
+                    int64_t n_world, const int64_t* obs_frame_offsets, const uint32_t* obs_cam,
+                    const uint64_t* obs_world, const float* obs_uv, const float* world_xyz,
+                    double* cam_q, double* cam_t, const uint8_t* cam_frozen, double* frame_q,
+                    double* frame_t, double huber_a, double* obs_cost, cc_summary* summary);
+
+/* ---------------------------------------------------------------------------------------------
  * Point kernels of the Calibrator surface.
  * ------------------------------------------------------------------------------------------- */
 /* Calibrator::Distort (calibrator.cpp:157-166): normalised -> pixel coordinates, float arithmetic

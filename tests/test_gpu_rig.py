@@ -1,0 +1,97 @@
+"""Parity of the HIP rig path (cc_rig_*, through the C ABI) against the CPU oracle.
+Scenario: src/test_extrinsics_calibrator.cpp:48-134 at several sizes. Tolerances: costs 1e-9
+relative with identical accept/reject sequence; converged camera/frame translations 1e-9,
+quaternions 1e-9; per-observation costs 1e-9 relative (+1e-18 absolute)."""
+import numpy as np
+import pytest
+
+from camera_calibrator_amd import capi
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+TIGHT = dict(function_tolerance=1e-15, gradient_tolerance=1e-13, parameter_tolerance=1e-14, max_iterations=200)
+
+
+def _inputs(sc):
+    cq, ct = po.affine_to_qt(sc["cam_T"])
+    fq, ft = po.affine_to_qt(sc["frame_T"])
+    return cq, ct, fq, ft
+
+
+def _both(sc, n_cams, huber_a=capi.HUBER_A, frozen=None, **kw):
+    cq, ct, fq, ft = _inputs(sc)
+    frozen = sc["cam_frozen"] if frozen is None else frozen
+    args = (n_cams, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"], sc["world_xyz"], cq, ct, frozen, fq, ft)
+    g = capi.rig_optimize(*args, huber_a=huber_a, options=capi.default_options(max_iterations=1000, **kw))
+    o = po.rig_solve(*args, huber_a=huber_a, options=po.default_options(max_iterations=1000, **kw))
+    return g, o
+
+
+def _assert_same(g, o, atol=1e-9):
+    assert g[5]["iterations"] == o[5]["iterations"] and g[5]["termination"] == o[5]["termination"]
+    assert [l["accepted"] for l in g[5]["log"]] == [l["accepted"] for l in o[5]["log"]]
+    assert np.allclose([l["cost"] for l in g[5]["log"]], [l["cost"] for l in o[5]["log"]], rtol=1e-9)
+    for k in range(4):
+        assert np.abs(g[k] - o[k]).max() < atol
+    assert np.allclose(g[4], o[4], rtol=1e-9, atol=1e-18)
+    assert np.isclose(g[5]["final_cost"], o[5]["final_cost"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("cams,frames,pts", [(2, 50, 4), (2, 1000, 4), (4, 40, 30), (3, 20, 300), (8, 25, 70)])
+def test_rig_default_options_match_oracle(cams, frames, pts):
+    sc = po.rig_scenario(cams, frames, pts)
+    g, o = _both(sc, cams)
+    _assert_same(g, o)
+    assert np.array_equal(g[0][0], o[0][0]) and np.array_equal(g[1][0], o[1][0])   # frozen camera untouched
+
+
+def test_rig_converged_minimiser_and_golden():
+    import os
+    gld = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rig_2x50x4.npz"))
+    g = capi.rig_optimize(2, gld["frame_offsets"], gld["obs_cam"], gld["obs_world"], gld["obs_uv"], gld["world_xyz"],
+                          gld["cam_q0"], gld["cam_t0"], gld["cam_frozen"], gld["frame_q0"], gld["frame_t0"],
+                          options=capi.default_options(max_iterations=1000, function_tolerance=1e-15,
+                                                       gradient_tolerance=1e-13, parameter_tolerance=1e-14))
+    assert np.isclose(g[5]["final_cost"], float(gld["final_cost"]), rtol=1e-10)
+    assert np.abs(g[1] - gld["cam_t"]).max() < 1e-9 and np.abs(g[0] - gld["cam_q"]).max() < 1e-9
+    assert np.abs(g[3] - gld["frame_t"]).max() < 1e-8
+    assert np.allclose(g[4], gld["obs_cost"], rtol=1e-7, atol=1e-16)
+    # float write-back of the camera transform (extrinsics_calibrator.cpp:228-256)
+    assert np.abs(po.qt_to_affine(g[0], g[1]) - gld["cam_T_out"]).max() <= 1.2e-7
+
+
+def test_rig_huber_off_equals_l2():
+    sc = po.rig_scenario(2, 30, 4)
+    g, o = _both(sc, 2, huber_a=1e6)
+    _assert_same(g, o)
+
+
+def test_rig_ragged_visibility_unobserved_camera_and_empty_frame():
+    sc = po.rig_scenario(3, 20, 6)
+    rng = np.random.default_rng(0)
+    keep = (sc["obs_cam"] != 2) & (rng.uniform(size=len(sc["obs_cam"])) > 0.3)   # camera 2 sees nothing; random drop-outs
+    off0 = sc["frame_offsets"]
+    keep[off0[7]:off0[8]] = False                                               # frame 7 has no observation
+    counts = [np.count_nonzero(keep[off0[f]:off0[f + 1]]) for f in range(20)]
+    sc2 = dict(sc, obs_cam=sc["obs_cam"][keep], obs_world=sc["obs_world"][keep], obs_uv=sc["obs_uv"][keep],
+               frame_offsets=np.concatenate([[0], np.cumsum(counts)]).astype(np.int64))
+    g, o = _both(sc2, 3)
+    _assert_same(g, o)
+    cq, ct, fq, ft = _inputs(sc)
+    assert np.array_equal(g[0][2], cq[2]) and np.array_equal(g[2][7], fq[7]) and np.array_equal(g[3][7], ft[7])
+
+
+def test_rig_handle_api_reset_and_determinism():
+    sc = po.rig_scenario(2, 60, 4)
+    cq, ct, fq, ft = _inputs(sc)
+    prob = capi.RigProblem(2, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"], sc["world_xyz"], sc["cam_frozen"])
+    prob.set_state(cq, ct, fq, ft)
+    c0 = prob.eval()
+    s1 = prob.solve(); r1 = prob.get_state()
+    prob.reset()
+    assert prob.eval() == c0
+    s2 = prob.solve(); r2 = prob.get_state()
+    prob.close()
+    assert s1["final_cost"] == s2["final_cost"] and all(np.array_equal(a, b) for a, b in zip(r1, r2))
+    assert np.isclose(s1["initial_cost"], c0, rtol=1e-12) and np.isclose(r1[4].sum(), s1["final_cost"], rtol=1e-12)
