@@ -1,0 +1,248 @@
+// extrinsics_calibrator.cpp -- ExtrinsicsCalibrator on top of the C ABI (include/cc_solver.h).
+#include "extrinsics_calibrator.hh"
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <fstream>
+#include <functional>
+#include <limits>
+#include <sstream>
+#include <stdexcept>
+
+#include "../../include/cc_solver.h"
+#include "geometry.hh"
+#include "json_min.hh"
+
+namespace calibrator {
+
+// ---- id bookkeeping (reference: extrinsics_calibrator.cpp:9-49) -------------------------------
+
+size_t ExtrinsicsCalibrator::AddCameraTRig(const Eigen::Affine3f& camera_T_rig, const bool freeze) {
+  const size_t id = camera_T_rigs_.size();
+  camera_T_rigs_.push_back(camera_T_rig);
+  if (freeze) frozen_camera_T_rigs_.insert(id);
+  return id;
+}
+
+Eigen::Affine3f ExtrinsicsCalibrator::GetCameraTRig(const size_t id) const { return camera_T_rigs_[id]; }
+
+size_t ExtrinsicsCalibrator::AddObservationFrame(const Eigen::Affine3f& rig_T_world) {
+  observation_frames_.emplace_back(rig_T_world);
+  return observation_frames_.size() - 1;
+}
+
+Eigen::Affine3f ExtrinsicsCalibrator::GetObservationFrame(const size_t id) const { return observation_frames_[id].rig_T_world; }
+
+size_t ExtrinsicsCalibrator::AddWorldPoint(const size_t frame_id, const Point3D& world_point) {
+  ObservationFrame& frame = observation_frames_[frame_id];
+  world_point_infos_.push_back(WorldPointInfo{frame_id, frame.world_points.size()});
+  frame.world_points.push_back(world_point);
+  return world_point_infos_.size() - 1;
+}
+
+void ExtrinsicsCalibrator::AddObservation(const size_t camera_id, const size_t world_point_id, const Point2D& image_point) {
+  const WorldPointInfo& info = world_point_infos_[world_point_id];
+  ObservationFrame::Observation obs;
+  obs.camera_id = camera_id;
+  obs.world_point_idx = info.world_point_idx;
+  obs.world_point_id = world_point_id;
+  obs.image_point = image_point;
+  obs.cost = std::numeric_limits<double>::quiet_NaN();  // "not evaluated yet"
+  observation_frames_[info.observation_frame_id].observations.push_back(obs);  // stored with the point's frame
+}
+
+void ExtrinsicsCalibrator::GetObservation(size_t frame_id, size_t k, size_t* camera_id, size_t* world_point_idx,
+                                          size_t* world_point_id, Point2D* image_point, double* cost) const {
+  const auto& o = observation_frames_[frame_id].observations[k];
+  if (camera_id) *camera_id = o.camera_id;
+  if (world_point_idx) *world_point_idx = o.world_point_idx;
+  if (world_point_id) *world_point_id = o.world_point_id;
+  if (image_point) *image_point = o.image_point;
+  if (cost) *cost = o.cost;
+}
+
+// ---- the solve -----------------------------------------------------------------------------------
+
+void ExtrinsicsCalibrator::Optimize() {
+  const size_t C = camera_T_rigs_.size(), F = observation_frames_.size(), Pn = world_point_infos_.size();
+  // fp64 parameter arrays exactly as the reference fills them (extrinsics_calibrator.cpp:116-137)
+  std::vector<double> cam_q(4 * C), cam_t(3 * C), frame_q(4 * F), frame_t(3 * F);
+  for (size_t i = 0; i < C; ++i) AffineToQuaternionTranslation(camera_T_rigs_[i], &cam_q[4 * i], &cam_t[3 * i]);
+  for (size_t i = 0; i < F; ++i) AffineToQuaternionTranslation(observation_frames_[i].rig_T_world, &frame_q[4 * i], &frame_t[3 * i]);
+  std::vector<float> world(3 * Pn);
+  for (size_t i = 0; i < Pn; ++i) {
+    const WorldPointInfo& info = world_point_infos_[i];
+    const Point3D& p = observation_frames_[info.observation_frame_id].world_points[info.world_point_idx];
+    world[3 * i] = p.x(); world[3 * i + 1] = p.y(); world[3 * i + 2] = p.z();
+  }
+  std::vector<int64_t> offsets(F + 1, 0);
+  for (size_t f = 0; f < F; ++f) offsets[f + 1] = offsets[f] + (int64_t)observation_frames_[f].observations.size();
+  const size_t N = (size_t)offsets[F];
+  std::vector<uint32_t> obs_cam(N);
+  std::vector<uint64_t> obs_world(N);
+  std::vector<float> obs_uv(2 * N);
+  for (size_t f = 0, k = 0; f < F; ++f)
+    for (const auto& o : observation_frames_[f].observations) {
+      obs_cam[k] = (uint32_t)o.camera_id;
+      obs_world[k] = (uint64_t)o.world_point_id;
+      obs_uv[2 * k] = o.image_point.x();
+      obs_uv[2 * k + 1] = o.image_point.y();
+      ++k;
+    }
+  std::vector<uint8_t> frozen(C, 0);
+  for (size_t id : frozen_camera_T_rigs_) if (id < C) frozen[id] = 1;
+  std::vector<double> cost(N, 0.0);
+
+  cc_options options;
+  cc_options_init(&options);
+  options.max_iterations = 1000;  // extrinsics_calibrator.cpp:211
+  std::vector<cc_iteration> log(1001);
+  cc_summary summary{};
+  summary.log = log.data();
+  summary.log_capacity = (int32_t)log.size();
+  const double huber_a = 3.0f / 500.0f;  // extrinsics_calibrator.cpp:176 (float literal, as in the reference)
+  last_status_ = 0;
+  if (N > 0 && C > 0 && F > 0) {
+    last_status_ = cc_rig_optimize(&options, device_, (int64_t)C, (int64_t)F, (int64_t)Pn, offsets.data(), obs_cam.data(),
+                                   obs_world.data(), obs_uv.data(), world.data(), cam_q.data(), cam_t.data(), frozen.data(),
+                                   frame_q.data(), frame_t.data(), huber_a, cost.data(), &summary);
+    if (last_status_ == CC_ERR_NO_DEVICE || last_status_ == CC_ERR_HIP || last_status_ == CC_ERR_BAD_ARGUMENT)
+      throw std::runtime_error(std::string("ExtrinsicsCalibrator::Optimize: ") + cc_last_error());  // no silent CPU path
+  }
+  last_iterations_ = summary.iterations;
+  last_final_cost_ = summary.final_cost;
+  if (verbose_) {  // the reference lets Ceres print its per-iteration table (extrinsics_calibrator.cpp:212-213)
+    std::printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n");
+    std::printf("%4d %.6e    0.00e+00\n", 0, summary.initial_cost);
+    for (int i = 0; i < summary.log_len; ++i)
+      std::printf("%4d %.6e %11.2e %10.2e %10.2e %9.2e %9.2e\n", i + 1, log[i].cost, log[i].cost_change, log[i].gradient_max_norm,
+                  log[i].step_norm, log[i].relative_decrease, log[i].radius);
+  }
+  // per-observation robustified cost (extrinsics_calibrator.cpp:219-225)
+  for (size_t f = 0, k = 0; f < F; ++f)
+    for (auto& o : observation_frames_[f].observations) o.cost = cost[k++];
+  // poses back through float (extrinsics_calibrator.cpp:228-256)
+  for (size_t i = 0; i < C; ++i) camera_T_rigs_[i] = QuaternionTranslationToAffine(&cam_q[4 * i], &cam_t[3 * i]);
+  for (size_t i = 0; i < F; ++i) observation_frames_[i].rig_T_world = QuaternionTranslationToAffine(&frame_q[4 * i], &frame_t[3 * i]);
+}
+
+// ---- JSON wire format (reference: extrinsics_calibrator.cpp:268-413) -----------------------------
+
+namespace {
+jsonmin::Value transform_to_json(const Eigen::Affine3f& T) {
+  jsonmin::Value a = jsonmin::Value::array();
+  for (int i = 0; i < 16; ++i) a.arr.push_back(jsonmin::Value::number(T.matrix()(i)));  // column-major (.reshaped())
+  return a;
+}
+Eigen::Affine3f transform_from_json(const jsonmin::Value& a) {
+  Eigen::Matrix4f M;
+  for (size_t i = 0; i < a.size() && i < 16; ++i) M(static_cast<int>(i)) = (float)a.at(i).as_number();
+  return Eigen::Affine3f(M);
+}
+}  // namespace
+
+void ExtrinsicsCalibrator::Serialize(const std::string& fname) const {
+  using jsonmin::Value;
+  Value root = Value::object();
+  Value cams = Value::array();
+  for (size_t i = 0; i < camera_T_rigs_.size(); ++i) {
+    Value c = Value::object();
+    c.obj["frozen"] = Value::boolean(frozen_camera_T_rigs_.count(i) != 0);
+    c.obj["camera_T_rig"] = transform_to_json(camera_T_rigs_[i]);
+    cams.arr.push_back(c);
+  }
+  Value wps = Value::array();
+  for (const WorldPointInfo& info : world_point_infos_) {
+    Value w = Value::object();
+    w.obj["frame_id"] = Value::integer(info.observation_frame_id);
+    const Point3D& p = observation_frames_[info.observation_frame_id].world_points[info.world_point_idx];
+    Value v = Value::array();
+    for (int i = 0; i < 3; ++i) v.arr.push_back(Value::number(p(i)));
+    w.obj["world_point"] = v;
+    wps.arr.push_back(w);
+  }
+  Value frames = Value::array();
+  for (const ObservationFrame& frame : observation_frames_) {
+    Value f = Value::object();
+    f.obj["rig_T_world"] = transform_to_json(frame.rig_T_world);
+    Value obs = Value::array();
+    for (const auto& o : frame.observations) {
+      Value e = Value::object();
+      e.obj["camera_id"] = Value::integer(o.camera_id);
+      e.obj["world_point_id"] = Value::integer(o.world_point_id);
+      Value ip = Value::array();
+      ip.arr.push_back(Value::number(o.image_point.x()));
+      ip.arr.push_back(Value::number(o.image_point.y()));
+      e.obj["image_point"] = ip;
+      e.obj["cost"] = Value::number(o.cost);  // NaN -> null
+      obs.arr.push_back(e);
+    }
+    f.obj["observations"] = obs;
+    frames.arr.push_back(f);
+  }
+  root.obj["camera_T_rigs"] = cams;
+  root.obj["world_points"] = wps;
+  root.obj["observation_frames"] = frames;
+  std::string text;
+  jsonmin::dump(root, text);
+  std::ofstream out(fname.c_str());
+  out << text;
+}
+
+void ExtrinsicsCalibrator::Parse(const std::string& fname) {
+  // Like the reference (extrinsics_calibrator.cpp:348-351) the camera list is NOT cleared: parsing
+  // into a calibrator that already holds cameras appends the parsed ones behind them.
+  frozen_camera_T_rigs_.clear();
+  world_point_infos_.clear();
+  observation_frames_.clear();
+  std::ifstream in(fname.c_str());
+  if (!in) throw std::runtime_error("ExtrinsicsCalibrator::Parse: cannot open " + fname);
+  std::stringstream ss;
+  ss << in.rdbuf();
+  const std::string text = ss.str();
+  const jsonmin::Value root = jsonmin::Parser(text).parse();
+
+  const jsonmin::Value& cams = root.at("camera_T_rigs");
+  for (size_t i = 0; i < cams.size(); ++i)
+    AddCameraTRig(transform_from_json(cams.at(i).at("camera_T_rig")), cams.at(i).at("frozen").as_bool());
+  const jsonmin::Value& frames = root.at("observation_frames");
+  for (size_t i = 0; i < frames.size(); ++i) AddObservationFrame(transform_from_json(frames.at(i).at("rig_T_world")));
+  const jsonmin::Value& wps = root.at("world_points");
+  for (size_t i = 0; i < wps.size(); ++i) {
+    const jsonmin::Value& v = wps.at(i).at("world_point");
+    AddWorldPoint((size_t)wps.at(i).at("frame_id").as_number(),
+                  Point3D((float)v.at(0).as_number(), (float)v.at(1).as_number(), (float)v.at(2).as_number()));
+  }
+  for (size_t i = 0; i < frames.size(); ++i) {
+    const jsonmin::Value& obs = frames.at(i).at("observations");
+    for (size_t k = 0; k < obs.size(); ++k) {
+      const jsonmin::Value& ip = obs.at(k).at("image_point");
+      AddObservation((size_t)obs.at(k).at("camera_id").as_number(), (size_t)obs.at(k).at("world_point_id").as_number(),
+                     Point2D((float)ip.at(0).as_number(), (float)ip.at(1).as_number()));  // cost is ignored (-> NaN)
+    }
+  }
+}
+
+// ---- frame removal with id renumbering (reference: extrinsics_calibrator.cpp:415-452) -------------
+
+void ExtrinsicsCalibrator::RemoveObservationFrame(const size_t observation_frame_id) {
+  const size_t removed_points = observation_frames_[observation_frame_id].world_points.size();
+  observation_frames_.erase(observation_frames_.begin() + (std::ptrdiff_t)observation_frame_id);
+  // world point ids of all later frames slide down by the removed frame's point count
+  for (size_t f = observation_frame_id; f < observation_frames_.size(); ++f)
+    for (auto& o : observation_frames_[f].observations) o.world_point_id -= removed_points;
+  world_point_infos_.erase(std::remove_if(world_point_infos_.begin(), world_point_infos_.end(),
+                                          [=](const WorldPointInfo& w) { return w.observation_frame_id == observation_frame_id; }),
+                           world_point_infos_.end());
+  for (WorldPointInfo& w : world_point_infos_)
+    if (w.observation_frame_id >= observation_frame_id) --w.observation_frame_id;
+}
+
+void ExtrinsicsCalibrator::RemoveObservationFrames(const std::vector<size_t> observation_frame_ids) {
+  std::vector<size_t> ids = observation_frame_ids;
+  std::sort(ids.begin(), ids.end(), std::greater<size_t>());  // highest first: earlier ids stay valid
+  for (size_t id : ids) RemoveObservationFrame(id);
+}
+
+}  // namespace calibrator

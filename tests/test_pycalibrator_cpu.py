@@ -1,0 +1,177 @@
+"""Host side of the class surface (pycalibrator, built from camera_calibrator_amd/csrc): id
+bookkeeping and JSON against the pure-Python restatement of the reference, geometry free functions
+against the oracle and the reference's own geometry tests. No GPU needed."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "camera_calibrator_amd"))
+pc = pytest.importorskip("pycalibrator")
+
+from oracle import pyoracle as po  # noqa: E402
+from oracle.py_bookkeeping import Bookkeeping  # noqa: E402
+
+
+def _T(rng):
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = po.fix_rotation_matrix(rng.normal(size=(3, 3)).astype(np.float32))
+    T[:3, 3] = rng.normal(size=3)
+    return T
+
+
+def _build(rng, n_cams=3, n_frames=5, interleave=False):
+    e, b = pc.ExtrinsicsCalibrator(), Bookkeeping()
+    e.SetVerbose(False)
+    for c in range(n_cams):
+        T = _T(rng)
+        assert e.AddCameraTRig(T, freeze=(c == 0)) == b.add_camera(T, c == 0)
+    for f in range(n_frames):
+        T = _T(rng)
+        assert e.AddObservationFrame(T) == b.add_frame(T)
+    order = [(f, k) for f in range(n_frames) for k in range(2 + f % 3)]
+    if interleave:
+        rng.shuffle(order)
+    wids = []
+    for f, _ in order:
+        p = rng.normal(size=3).astype(np.float32)
+        w = e.AddWorldPoint(f, p)
+        assert w == b.add_world_point(f, p)
+        wids.append(w)
+    for w in wids:
+        for c in range(n_cams):
+            if rng.uniform() < 0.7:
+                uv = rng.normal(size=2).astype(np.float32)
+                e.AddObservation(c, w, uv)
+                b.add_observation(c, w, uv)
+    return e, b
+
+
+def _same(e, b):
+    assert e.NumCameras() == len(b.camera_T_rigs) and e.NumObservationFrames() == len(b.frames)
+    assert e.NumWorldPoints() == len(b.world_point_infos)
+    for i, T in enumerate(b.camera_T_rigs):
+        assert np.array_equal(e.GetCameraTRig(i), T) and e.IsCameraFrozen(i) == (i in b.frozen)
+    for f, fr in enumerate(b.frames):
+        assert np.array_equal(e.GetObservationFrame(f), fr["rig_T_world"])
+        assert e.NumObservations(f) == len(fr["observations"])
+        for k, o in enumerate(fr["observations"]):
+            cam, idx, wid, uv, cost = e.GetObservation(f, k)
+            assert (cam, idx, wid) == (o["camera_id"], o["world_point_idx"], o["world_point_id"])
+            assert np.array_equal(uv, o["image_point"]) and np.isnan(cost)
+
+
+@pytest.mark.parametrize("interleave", [False, True])
+def test_bookkeeping_matches_reference_semantics(interleave, tmp_path):
+    rng = np.random.default_rng(0)
+    e, b = _build(rng, interleave=interleave)
+    _same(e, b)
+    # JSON text identical to an nlohmann-style dump of the same state
+    fn = str(tmp_path / "a.json")
+    e.Serialize(fn)
+    assert json.loads(open(fn).read()) == b.to_json_obj()
+    assert open(fn).read() == b.dumps()
+    # removal with renumbering (including the reference's size_t wrap-around when ids interleave)
+    e.RemoveObservationFrame(1); b.remove_frame(1)
+    _same(e, b)
+    e.RemoveObservationFrames([0, 2]); b.remove_frames([0, 2])
+    _same(e, b)
+
+
+def test_parse_round_trip_and_camera_quirk(tmp_path):
+    rng = np.random.default_rng(1)
+    e, b = _build(rng)
+    fn = str(tmp_path / "s.json")
+    e.Serialize(fn)
+    fresh = pc.ExtrinsicsCalibrator()
+    fresh.Parse(fn)
+    _same(fresh, b)
+    fn2 = str(tmp_path / "s2.json")
+    fresh.Serialize(fn2)
+    assert open(fn).read() == open(fn2).read()
+    # Parse does not clear the camera list (extrinsics_calibrator.cpp:348-351): parsing into the
+    # same object doubles the cameras, the frozen flags are re-derived for the appended ids.
+    n = e.NumCameras()
+    e.Parse(fn)
+    assert e.NumCameras() == 2 * n and e.NumObservationFrames() == len(b.frames)
+    assert not e.IsCameraFrozen(0) and e.IsCameraFrozen(n)
+
+
+def test_affine_caster_reads_top_3x4_only():
+    e = pc.ExtrinsicsCalibrator()
+    T = np.arange(16, dtype=np.float32).reshape(4, 4)
+    e.AddCameraTRig(T)
+    out = e.GetCameraTRig(0)
+    assert np.array_equal(out[:3], T[:3]) and np.array_equal(out[3], [0, 0, 0, 1])   # binds.cpp:21-31
+
+
+def test_calibrator_defaults_and_setters():
+    c = pc.Calibrator(1600, 1000)
+    assert np.array_equal(c.GetK(), np.eye(3, dtype=np.float32)) and np.array_equal(c.GetDistortion(), np.zeros(5, np.float32))
+    c.SetK(po.FIXTURE_K); c.SetDistortion(po.FIXTURE_DIST)
+    assert np.array_equal(c.GetK(), po.FIXTURE_K) and np.array_equal(c.GetDistortion(), po.FIXTURE_DIST)
+    with pytest.raises(RuntimeError):
+        c.EstimateOpenCv([], [])
+
+
+# ---- geometry (src/test_geometry.cpp) ---------------------------------------------------------
+
+def test_plane_helpers():   # test_geometry.cpp:12-64,124-161
+    rng = np.random.default_rng(2)
+    for _ in range(20):
+        p = rng.uniform(-1, 1, size=(3, 3)).astype(np.float32)
+        plane = pc.EstimatePlaneFinite(p[0], p[1], p[2])
+        for q in p:
+            assert abs(float(plane[:3] @ q + plane[3])) < 2e-5
+        n = pc.PlaneNormal(plane)
+        assert abs(np.linalg.norm(n) - 1) < 1e-6
+        assert abs(float(n @ (p[1] - p[0]))) < 2e-5 and abs(float(n @ (p[2] - p[0]))) < 2e-5
+        x = rng.uniform(-1, 1, size=3).astype(np.float32)
+        proj = pc.ProjectToPlane(plane, x)
+        assert abs(float(plane[:3] @ proj + plane[3])) < 1e-5
+        d = rng.uniform(-1, 1, size=3).astype(np.float32)
+        proj2 = pc.ProjectToPlane(plane, x, d)
+        assert abs(float(plane[:3] @ proj2 + plane[3])) < 1e-4
+        assert np.linalg.norm(np.cross(proj2 - x, d)) < 1e-4 * max(1.0, np.linalg.norm(proj2 - x))
+
+
+def test_rotation_helpers():   # test_geometry.cpp:66-93,163-170
+    rng = np.random.default_rng(3)
+    for _ in range(100):
+        R = pc.FixRotationMatrix(rng.uniform(-1, 1, size=(3, 3)).astype(np.float32)).astype(np.float64)
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-5)
+    plane = pc.EstimatePlaneFinite(*rng.uniform(-1, 1, size=(3, 3)).astype(np.float32))
+    R = pc.RotationMatrixFromPlane(plane).astype(np.float64)
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-5) and np.allclose(R[2], pc.PlaneNormal(plane), atol=1e-6)
+
+
+def test_estimate_homography_recovers_h():   # test_geometry.cpp:172-194
+    rng = np.random.default_rng(4)
+    H = rng.uniform(-1, 1, size=(3, 3)).astype(np.float32)
+    p1 = rng.uniform(-1, 1, size=(10, 2)).astype(np.float32)
+    ph = np.concatenate([p1, np.ones((10, 1), np.float32)], 1) @ H.T
+    p2 = (ph[:, :2] / ph[:, 2:3]).astype(np.float32)
+    He = pc.EstimateHomography(p1, p2)
+    He = He / He[2, 2] * H[2, 2]
+    assert np.abs(He - H).max() < 1e-4 * max(1.0, np.abs(H).max() / abs(H[2, 2]))
+
+
+def test_zhang_pieces_match_oracle():
+    off, uv, xyz = po.make_intrinsics_problem(6, 50)
+    Hs = []
+    for f in range(6):
+        Ho = po.estimate_homography(xyz[off[f]:off[f + 1]], uv[off[f]:off[f + 1]])
+        Hp = pc.EstimateHomography(xyz[off[f]:off[f + 1], :2], uv[off[f]:off[f + 1]])
+        s = np.sign(Ho[2, 2] * Hp[2, 2])
+        assert np.abs(Ho - s * Hp).max() < 1e-5 * np.abs(Ho).max()
+        Hs.append(Hp)
+    Kp = pc.EstimateKFromHomographies(Hs)
+    Ko = po.estimate_k_from_homographies(np.array(Hs))
+    assert np.allclose(Kp, Ko, rtol=1e-5)
+    Ki = np.linalg.inv(Kp.astype(np.float64)).astype(np.float32)
+    Rp, tp = pc.RecoverExtrinsics(Ki, Hs[0])
+    Ro, to = po.recover_extrinsics(Ki, Hs[0])
+    assert np.allclose(Rp, Ro, atol=1e-5) and np.allclose(tp, to, atol=1e-5)
