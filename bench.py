@@ -107,7 +107,8 @@ def main():
         done, solves, last = 0, 0, None
         while done < k:
             prob.reset()
-            o = capi.default_options(max_iterations=min(opts.max_iterations, k - done))
+            remaining = k - done
+            o = opts if remaining >= opts.max_iterations else capi.default_options(max_iterations=remaining)
             s = prob.solve(o, log_capacity=0)
             if s["iterations"] <= 0:
                 raise RuntimeError(f"solve made no progress: {s}")

@@ -4,6 +4,7 @@
 #include <dlfcn.h>
 
 #include <cstring>
+#include <string>
 
 #include "cc_common.hpp"
 
@@ -24,9 +25,25 @@ Api g_api;
 
 int load_api() {
   if (g_api.lib) return CC_OK;
-  void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-  if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  // RCCL must match the HIP runtime this process actually runs on: a Python process that imported
+  // torch runs on torch's bundled libamdhip64/librccl, a plain C++ process on /opt/rocm's. Look for
+  // librccl next to the libamdhip64 that provides hipGetDeviceCount, then fall back to the soname.
+  void* lib = nullptr;
+  Dl_info info;
+  if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+    std::string dir(info.dli_fname);
+    const size_t slash = dir.rfind('/');
+    if (slash != std::string::npos) {
+      dir.resize(slash);
+      for (const char* name : {"/librccl.so.1", "/librccl.so"}) {
+        lib = dlopen((dir + name).c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (lib) break;
+      }
+    }
+  }
+  if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
   if (!lib) return fail(CC_ERR_COMM, "cannot load librccl: %s", dlerror());
   g_api.GetUniqueId = reinterpret_cast<decltype(g_api.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
   g_api.CommInitRank = reinterpret_cast<decltype(g_api.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));

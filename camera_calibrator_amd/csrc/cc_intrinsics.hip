@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstring>
 #include <vector>
 
 namespace cc {
@@ -140,52 +141,69 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P) {
   double* sm = s_stage + 4 * kStageDoublesPerWave;              // [256] prologue scratch
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t f = blockIdx.x;
+  // ---- one global round trip gathers every input of the prologue; nothing in it depends on the
+  // control block (both buffers of the ping-pong state are fetched, the right one is picked later)
+  // sm[0..59] Y, [60..66] pose buf 0, [67..73] pose buf 1, [74..82] intr buf 0, [83..91] intr buf 1,
+  // [92..100] ds (scaled), [101..109] ss, [110..115] sp
+  // sm[120..134] unscaled step (9 shared, 6 pose); sm[136..144] R; [145..147] t; [148..156] intr_cand
+  // sm[158] step^2 (pose part), sm[159] |x_cand|^2 (pose part); sm[160..169] pose/intr of `cur`
   const LmCtl* ctl = P.ctl;
-  if (ctl->done) return;
-  const int phase = ctl->phase;
-  if (phase != 0 && !ctl->step_valid) return;
-  const int cur = ctl->cur, dst = phase == 0 ? cur : (cur ^ 1);
-
-  // ---- prologue: candidate point of this frame. One global round trip gathers every input.
-  // sm[0..59] Y, [60..66] pose, [67..75] intr, [76..84] ds (scaled), [85..93] ss, [94..99] sp
-  // sm[100..114] unscaled step (9 shared, 6 pose); sm[116..124] R; [125..127] t; [128..136] intr_cand
-  // sm[138] step^2 (pose part), sm[139] |x_cand|^2 (pose part)
-  double g_old = 0.0;
-  if (tid < 100) {
+  const int done = ctl->done, phase = ctl->phase, step_valid = ctl->step_valid, cur = ctl->cur;
+  const int64_t s0 = P.off[f], s1 = P.off[f + 1];
+  if (tid < 116) {
     double v;
-    if (tid < 60) v = phase != 0 ? P.Y[f * kYStride + tid] : 0.0;
-    else if (tid < 67) v = P.pose[((size_t)cur * P.F + f) * 8 + (tid - 60)];
-    else if (tid < 76) v = P.intr[cur * 16 + (tid - 67)];
-    else if (tid < 85) v = phase != 0 ? P.ds[tid - 76] : 0.0;
-    else if (tid < 94) v = phase != 0 ? P.ss[tid - 85] : 0.0;
-    else v = phase != 0 ? P.sp[f * 8 + (tid - 94)] : 0.0;
+    if (tid < 60) v = P.Y[f * kYStride + tid];
+    else if (tid < 67) v = P.pose[(size_t)f * 8 + (tid - 60)];
+    else if (tid < 74) v = P.pose[((size_t)P.F + f) * 8 + (tid - 67)];
+    else if (tid < 83) v = P.intr[tid - 74];
+    else if (tid < 92) v = P.intr[16 + (tid - 83)];
+    else if (tid < 101) v = P.ds[tid - 92];
+    else if (tid < 110) v = P.ss[tid - 101];
+    else v = P.sp[f * 8 + (tid - 110)];
     sm[tid] = v;
   }
-  if (phase != 0) g_old = P.blocks[((size_t)cur * P.F + f) * 256 + tid];
+  const double g_old0 = P.blocks[(size_t)f * 256 + tid];
+  const double g_old1 = P.blocks[((size_t)P.F + f) * 256 + tid];
+  if (done) return;
+  if (phase != 0 && !step_valid) return;
+  const int dst = phase == 0 ? cur : (cur ^ 1);
+  const double g_old = cur ? g_old1 : g_old0;
+  // first pass of observations: issued now, consumed after the prologue
+  const float2* uv2 = reinterpret_cast<const float2*>(P.uv);
+  const int npass = (int)((s1 - s0 + kSweepThreads - 1) / kSweepThreads);
+  float2 nm = make_float2(0.f, 0.f);
+  float nX0 = 0.f, nX1 = 0.f, nX2 = 1.f;
+  if (npass > 0) {
+    const int64_t idx = s0 + tid;
+    const int64_t ic = idx < s1 ? idx : s0;
+    nm = uv2[ic];
+    nX0 = P.xyz[ic * 3]; nX1 = P.xyz[ic * 3 + 1]; nX2 = P.xyz[ic * 3 + 2];
+  }
   __syncthreads();
+  const int pose_o = cur ? 67 : 60, intr_o = cur ? 83 : 74;
   if (tid < 6) {
     const double* Yr = sm + tid * 10;
     double a = Yr[9];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) a += Yr[j] * sm[76 + j];
-    sm[109 + tid] = -a * sm[94 + tid];
+    for (int j = 0; j < 9; ++j) a += Yr[j] * sm[92 + j];
+    sm[129 + tid] = phase != 0 ? -a * sm[110 + tid] : 0.0;
   } else if (tid >= 8 && tid < 17) {
     const int j = tid - 8;
-    const double d = (P.mask & (1u << j)) ? 0.0 : sm[76 + j] * sm[85 + j];
-    sm[100 + j] = d;
-    const double kc = sm[67 + j] + d;
-    sm[128 + j] = kc;
+    const double d = (phase == 0 || (P.mask & (1u << j))) ? 0.0 : sm[92 + j] * sm[101 + j];
+    sm[120 + j] = d;
+    const double kc = sm[intr_o + j] + d;
+    sm[148 + j] = kc;
     if (f == 0 && phase != 0) P.intr[dst * 16 + j] = kc;
   }
   __syncthreads();
   if (tid == 0) {
     double q[4], t[3], dp[6];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) q[i] = sm[60 + i];
+    for (int i = 0; i < 4; ++i) q[i] = sm[pose_o + i];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) t[i] = sm[64 + i];
+    for (int i = 0; i < 3; ++i) t[i] = sm[pose_o + 4 + i];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) dp[i] = sm[109 + i];
+    for (int i = 0; i < 6; ++i) dp[i] = sm[129 + i];
     double step2 = 0.0;
     if (phase != 0) {
       double qn[4];
@@ -203,11 +221,11 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P) {
     double R[9];
     quat_to_R(q, R);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) sm[116 + i] = R[i];
+    for (int i = 0; i < 9; ++i) sm[136 + i] = R[i];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) sm[125 + i] = t[i];
-    sm[138] = step2;
-    sm[139] = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + t[0] * t[0] + t[1] * t[1] + t[2] * t[2];
+    for (int i = 0; i < 3; ++i) sm[145 + i] = t[i];
+    sm[158] = step2;
+    sm[159] = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + t[0] * t[0] + t[1] * t[1] + t[2] * t[2];
   }
   __syncthreads();
 
@@ -216,30 +234,33 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P) {
   double qterm = 0.0;
   if (phase != 0) {
     const int a = tid >> 4, b = tid & 15;
-    if (a < 15) qterm = b < 15 ? 0.5 * sm[100 + a] * g_old * sm[100 + b] : sm[100 + a] * g_old;
+    if (a < 15) qterm = b < 15 ? 0.5 * sm[120 + a] * g_old * sm[120 + b] : sm[120 + a] * g_old;
   }
 
   double R[9], tt[3], kk[9];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) R[i] = rfl(sm[116 + i]);
+  for (int i = 0; i < 9; ++i) R[i] = rfl(sm[136 + i]);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) tt[i] = rfl(sm[125 + i]);
+  for (int i = 0; i < 3; ++i) tt[i] = rfl(sm[145 + i]);
 #pragma unroll
-  for (int i = 0; i < 9; ++i) kk[i] = rfl(sm[128 + i]);
+  for (int i = 0; i < 9; ++i) kk[i] = rfl(sm[148 + i]);
   const uint32_t mask = P.mask;
 
-  // ---- main loop: 64 observations per wave per pass, no workgroup barrier -------------------
-  const int64_t s0 = P.off[f], s1 = P.off[f + 1];
-  const int npass = (int)((s1 - s0 + kSweepThreads - 1) / kSweepThreads);
+  // ---- main loop: 64 observations per wave per pass, no workgroup barrier; the next pass's
+  // observations are fetched while the current one is processed
   double* stage = s_stage + wave * kStageDoublesPerWave;
-  const float2* uv2 = reinterpret_cast<const float2*>(P.uv);
   d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
   for (int p = 0; p < npass; ++p) {
     const int64_t idx = s0 + (int64_t)p * kSweepThreads + tid;
     const bool valid = idx < s1;  // only the last pass of a frame has idle lanes
-    const int64_t ic = valid ? idx : s0;
-    const float2 m = uv2[ic];
-    const float X0 = P.xyz[ic * 3], X1 = P.xyz[ic * 3 + 1], X2 = P.xyz[ic * 3 + 2];
+    const float2 m = nm;
+    const float X0 = nX0, X1 = nX1, X2 = nX2;
+    if (p + 1 < npass) {
+      const int64_t nidx = idx + kSweepThreads;
+      const int64_t ic = nidx < s1 ? nidx : s0;
+      nm = uv2[ic];
+      nX0 = P.xyz[ic * 3]; nX1 = P.xyz[ic * 3 + 1]; nX2 = P.xyz[ic * 3 + 2];
+    }
     ObsCommon oc;
     obs_common(kk, R, tt, (double)X0, (double)X1, (double)X2, oc);
     double v[16];
@@ -269,7 +290,7 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) s_blk[wave * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc0[r] + acc1[r];
   const double qw = wave_sum(qterm);
-  if (lane == 0) sm[140 + wave] = qw;
+  if (lane == 0) sm[170 + wave] = qw;
   __syncthreads();
   const double g = (s_blk[tid] + s_blk[256 + tid]) + (s_blk[512 + tid] + s_blk[768 + tid]);
   P.blocks[((size_t)dst * P.F + f) * 256 + tid] = g;
@@ -279,9 +300,9 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P) {
   if (tid == 0) {
     double* st = P.stats + f * kStatsCols;
     st[ST_COST] = 0.5 * G[255];
-    st[ST_QMODEL] = (sm[140] + sm[141]) + (sm[142] + sm[143]);
-    st[ST_STEP2] = sm[138];
-    st[ST_XNORM2] = sm[139];
+    st[ST_QMODEL] = (sm[170] + sm[171]) + (sm[172] + sm[173]);
+    st[ST_STEP2] = sm[158];
+    st[ST_XNORM2] = sm[159];
   }
   if (phase == 0) {
     if (tid < 6) P.sp[f * 8 + tid] = P.opts->jacobi_scaling ? 1.0 / (1.0 + sqrt(G[(9 + tid) * 17])) : 1.0;
@@ -674,6 +695,17 @@ __global__ __launch_bounds__(kSolveThreads) void k_intr_solve(IntrDev P, int nbl
   *P.ctl_next = c;
 }
 
+// restores the initial point into buffer 0 and clears both control blocks (one launch per restart)
+__global__ __launch_bounds__(256) void k_intr_reset(IntrDev P, const double* init_intr, const double* init_pose) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < P.F * 8) P.pose[i] = init_pose[i];
+  if (i < 16) P.intr[i] = init_intr[i];
+  if (i < (int64_t)(sizeof(LmCtl) / sizeof(double))) {
+    reinterpret_cast<double*>(P.ctl)[i] = 0.0;
+    reinterpret_cast<double*>(P.ctl_next)[i] = 0.0;
+  }
+}
+
 }  // namespace cc
 
 // =============================================================================================
@@ -699,6 +731,10 @@ struct cc_intrinsics {
   double* init_pose = nullptr;  // [F][8]
   bool have_state = false;
   cc::LmCtl* h_ctl = nullptr;  // pinned
+  cc::LmOpts* h_opts = nullptr;  // pinned staging of the options
+  cc::LmOpts cached_opts{};     // what the device currently holds
+  bool opts_valid = false;
+  bool ctl_fresh = false;       // device control blocks are zeroed and the point sits in buffer 0
   hipGraphExec_t graph[2] = {nullptr, nullptr};  // [0]: 1 + check_interval triples, [1]: check_interval triples
   int graph_iters = 0;
   cc::Comm* comm = nullptr;
@@ -825,6 +861,7 @@ int cc_intrinsics_create(int32_t device, int64_t F, const int64_t* off, const fl
   CC_HIP(hipMemset(d.ctl, 0, sizeof(LmCtl)));
   CC_HIP(hipMemset(d.ctl_next, 0, sizeof(LmCtl)));
   CC_HIP(hipHostMalloc(&h->h_ctl, sizeof(LmCtl), hipHostMallocDefault));
+  CC_HIP(hipHostMalloc(&h->h_opts, sizeof(LmOpts), hipHostMallocDefault));
   h->elim_blocks = (int)std::min<int64_t>(kElimMaxBlocks, (F + 15) / 16);
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_intr_sweep),
                              hipFuncAttributeMaxDynamicSharedMemorySize, kSweepLdsBytes));
@@ -845,6 +882,7 @@ void cc_intrinsics_destroy(cc_intrinsics* h) {
   hipFree(d.ctl); hipFree(d.ctl_next); hipFree(d.opts); hipFree(d.log);
   hipFree(h->init_intr); hipFree(h->init_pose);
   if (h->h_ctl) hipHostFree(h->h_ctl);
+  if (h->h_opts) hipHostFree(h->h_opts);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
@@ -874,11 +912,10 @@ int cc_intrinsics_reset(cc_intrinsics* h) {
   using namespace cc;
   if (!h || !h->have_state) return fail(CC_ERR_STATE, "cc_intrinsics_reset: no state set");
   CC_HIP(hipSetDevice(h->device));
-  LmCtl c{};
-  if (int rc = write_ctl(h, c)) return rc;
-  // current point lives in buffer 0
-  CC_HIP(hipMemcpyAsync(h->d.intr, h->init_intr, 16 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-  CC_HIP(hipMemcpyAsync(h->d.pose, h->init_pose, (size_t)h->F * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  const unsigned blocks = (unsigned)((h->F * 8 + 255) / 256);
+  hipLaunchKernelGGL(k_intr_reset, dim3(blocks), dim3(256), 0, h->stream, h->d, h->init_intr, h->init_pose);
+  CC_HIP(hipGetLastError());
+  h->ctl_fresh = true;
   return CC_OK;
 }
 
@@ -908,6 +945,7 @@ int cc_intrinsics_eval(cc_intrinsics* h, double* blocks, double* cost) {
   // evaluate at the accepted point without disturbing it: a phase-0 sweep writes into buffer `cur`
   LmCtl st;
   if (int rc = read_ctl(h, &st)) return rc;
+  h->ctl_fresh = false;
   LmCtl ev{};
   ev.cur = st.cur & 1;
   CC_HIP(hipMemcpyAsync(h->d.ctl, &ev, sizeof(ev), hipMemcpyHostToDevice, h->stream));
@@ -939,19 +977,28 @@ int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* sum
   const bool profile = o.profile_kernels != 0;
   const bool use_graph = o.use_graph && !profile && !h->comm;
   CC_HIP(hipSetDevice(h->device));
-  // continue from the accepted point of the previous run: move it to buffer 0, fresh control block
-  {
+  if (!h->ctl_fresh) {
+    // continue from the accepted point of the previous run: move it to buffer 0, fresh control block
     LmCtl st;
     if (int rc = read_ctl(h, &st)) return rc;
     if (st.cur & 1) {
       CC_HIP(hipMemcpyAsync(h->d.intr, h->d.intr + 16, 16 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
       CC_HIP(hipMemcpyAsync(h->d.pose, h->d.pose + (size_t)h->F * 8, (size_t)h->F * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     }
-    LmOpts lo;
-    opts_from_public(o, &lo);
-    CC_HIP(hipMemcpyAsync(h->d.opts, &lo, sizeof(lo), hipMemcpyHostToDevice, h->stream));
     LmCtl c{};
     if (int rc = write_ctl(h, c)) return rc;
+  }
+  h->ctl_fresh = false;
+  {
+    LmOpts lo;
+    opts_from_public(o, &lo);
+    if (!h->opts_valid || std::memcmp(&lo, &h->cached_opts, sizeof(lo)) != 0) {
+      CC_HIP(hipStreamSynchronize(h->stream));  // the pinned staging buffer may still be in flight
+      *h->h_opts = lo;
+      CC_HIP(hipMemcpyAsync(h->d.opts, h->h_opts, sizeof(lo), hipMemcpyHostToDevice, h->stream));
+      h->cached_opts = lo;
+      h->opts_valid = true;
+    }
   }
   for (auto e : h->events) hipEventDestroy(e);
   h->events.clear();

@@ -161,3 +161,20 @@ def test_full_size_c3_properties_and_parity():
     assert block_rel_err(blk1, blk_or) < 1e-12
     truth = np.array([1000, 1000, 800, 500], dtype=np.float64)
     assert np.all(np.abs(ig[:4] - truth) / truth < 1e-3)
+
+
+def test_rccl_path_with_a_single_rank_communicator():
+    """The N>1 launch sequence (local reduce -> ncclAllReduce -> consume, no graph) exercised with a
+    1-rank RCCL communicator: must reproduce the single-GPU solve."""
+    import torch  # noqa: F401  (the process-wide librccl the library binds to)
+    case = intrinsics_case(20, 88)
+    prob = capi.IntrinsicsProblem(case["off"], case["uv"], case["xyz"])
+    prob.set_state(case["intr0"], case["q0"], case["t0"])
+    s0 = prob.solve(); i0, q0, t0 = prob.get_state()
+    prob.comm_init(capi.comm_get_unique_id(), 0, 1)
+    prob.reset()
+    s1 = prob.solve(); i1, q1, t1 = prob.get_state()
+    prob.close()
+    assert s1["iterations"] == s0["iterations"] and s1["termination"] == s0["termination"]
+    assert np.allclose([l["cost"] for l in s1["log"]], [l["cost"] for l in s0["log"]], rtol=1e-12)
+    assert np.allclose(i1, i0, rtol=1e-12, atol=1e-14) and np.allclose(q1, q0, atol=1e-13)
