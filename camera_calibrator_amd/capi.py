@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcc_hip.so")
+LIB_PATH = os.environ.get("CC_LIB_PATH", os.path.join(_HERE, "libcc_hip.so"))
 
 K_NAMES = ["sweep", "decide", "elim", "solve", "allreduce"]
 TERMINATION = {0: "NO_CONVERGENCE", 1: "GRADIENT", 2: "PARAMETER", 3: "FUNCTION",

@@ -25,6 +25,10 @@ __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOM
 // the ds_write_b128 groups (8 consecutive lanes) and the ds_read_b64 operand reads (two 32-lane
 // halves, each two consecutive rows) are both bank-conflict free.
 __device__ __forceinline__ void stage_row(double* stage, int lane, const double* v) {
+#if defined(CC_ABLATE) && CC_ABLATE == 2
+  asm volatile("" ::"v"(v[0] + v[5] + v[9] + v[12] + v[15]));
+  return;
+#endif
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     d2 val;
@@ -37,6 +41,10 @@ __device__ __forceinline__ void stage_row(double* stage, int lane, const double*
 // 16 MFMAs over the 64 staged rows: MFMA m consumes rows 4m..4m+3; lane l supplies component
 // (l & 15) of row 4m + (l >> 4) as both the A[i][k] and the B[k][j] operand of the Gram product.
 __device__ __forceinline__ void gram_rows(const double* stage, int lane, d4& acc0, d4& acc1) {
+#if defined(CC_ABLATE) && CC_ABLATE == 1
+  asm volatile("" ::"v"(stage[lane]));
+  return;
+#endif
   const int c = lane & 15, sub = lane >> 4;
 #pragma unroll
   for (int m = 0; m < 16; m += 2) {

@@ -21,6 +21,10 @@
 #include "cc_common.hpp"
 #include "cc_device.hpp"
 
+#ifndef CC_ABLATE
+#define CC_ABLATE 0  // timing-only experiments (scripts/ablate_sweep.sh); 0 = product build
+#endif
+
 #include <algorithm>
 #include <chrono>
 #include <cstring>
@@ -261,6 +265,9 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P) {
       nm = uv2[ic];
       nX0 = P.xyz[ic * 3]; nX1 = P.xyz[ic * 3 + 1]; nX2 = P.xyz[ic * 3 + 2];
     }
+#if CC_ABLATE == 3
+    if (p >= 0) continue;
+#endif
     ObsCommon oc;
     obs_common(kk, R, tt, (double)X0, (double)X1, (double)X2, oc);
     double v[16];
@@ -1072,7 +1079,7 @@ int cc_intrinsics_profile_sweep(cc_intrinsics* h, int32_t n, double* avg_ms) {
   CC_HIP(hipSetDevice(h->device));
   LmCtl st;
   if (int rc = read_ctl(h, &st)) return rc;
-  if (st.phase != 1 || st.iter < 1) return fail(CC_ERR_STATE, "cc_intrinsics_profile_sweep: run cc_intrinsics_solve first");
+  if (st.phase != 1) return fail(CC_ERR_STATE, "cc_intrinsics_profile_sweep: run cc_intrinsics_solve first");
   LmCtl run = st;
   run.done = 0; run.step_valid = 1;
   CC_HIP(hipMemcpyAsync(h->d.ctl, &run, sizeof(run), hipMemcpyHostToDevice, h->stream));
