@@ -634,7 +634,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_intr_solve(IntrDev P, int nbl
       c.term = CC_CONVERGENCE_GRADIENT;
     } else {
       bool ok = !(V[PC_FAIL] > 0.0);
-      double A[45], b[9];
+      double A[45], b[9], inv[9];
       {
         int idx = 0;
 #pragma unroll
@@ -658,21 +658,21 @@ __global__ __launch_bounds__(kSolveThreads) void k_intr_solve(IntrDev P, int nbl
           A[tri(j, j)] = 1.0;
           b[j] = 0.0;
         }
+      // Cholesky with reciprocal square roots; the substitutions multiply by 1 / L_jj
 #pragma unroll
       for (int j = 0; j < 9; ++j) {
         double d = A[tri(j, j)];
 #pragma unroll
         for (int k = 0; k < j; ++k) d -= A[tri(j, k)] * A[tri(j, k)];
         ok = ok && (d > 0.0) && isfinite(d);
-        d = sqrt(d);
-        A[tri(j, j)] = d;
-        const double inv = 1.0 / d;
+        const double r = rsqrt(d);
+        inv[j] = r;
 #pragma unroll
         for (int i = j + 1; i < 9; ++i) {
           double a = A[tri(i, j)];
 #pragma unroll
           for (int k = 0; k < j; ++k) a -= A[tri(i, k)] * A[tri(j, k)];
-          A[tri(i, j)] = a * inv;
+          A[tri(i, j)] = a * r;
         }
       }
 #pragma unroll
@@ -680,14 +680,14 @@ __global__ __launch_bounds__(kSolveThreads) void k_intr_solve(IntrDev P, int nbl
         double a = b[i];
 #pragma unroll
         for (int k = 0; k < i; ++k) a -= A[tri(i, k)] * b[k];
-        b[i] = a / A[tri(i, i)];
+        b[i] = a * inv[i];
       }
 #pragma unroll
       for (int i = 8; i >= 0; --i) {
         double a = b[i];
 #pragma unroll
         for (int k = i + 1; k < 9; ++k) a -= A[tri(k, i)] * b[k];
-        b[i] = a / A[tri(i, i)];
+        b[i] = a * inv[i];
       }
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
