@@ -28,7 +28,7 @@ constexpr int kRigMaxS = 6 * kRigMaxCams;
 constexpr int kRigThreads = 256;
 constexpr int kRigOwn = 8;  // partial-row columns owned per thread of the elim kernel (PC <= 2048)
 constexpr int kRigSweepLdsBytes = (4 * kStageDoublesPerWave + 256) * 8;
-constexpr int kRigMaxElimBlocks = 128;
+constexpr int kRigMaxElimBlocks = 512;
 
 struct RigDev {
   int64_t F, N, NG;
@@ -60,6 +60,7 @@ struct RigDev {
   double* ds;       // [64] scaled shared step
   double* Y;        // [F][6*SW]
   double* partial;  // [nblk][PC]
+  double* vec;      // [PC] column sums of the partial rows (k_rig_reduce)
   double* shared_stats;  // [4] step^2 and |x|^2 of the shared block (candidate)
   LmCtl* ctl;
   LmCtl* ctl_next;
@@ -543,6 +544,45 @@ __global__ __launch_bounds__(256) void k_rig_decide_elim(RigDev P) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// reduce: column sums (max for the last column) of the elimination partial rows, 16 columns per
+// block, 16 row groups per column, 16 loads in flight per thread. Deterministic.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rig_reduce(RigDev P) {
+  __shared__ double s_r[16][16];
+  const LmCtl* cn = P.ctl_next;
+  if (cn->done || cn->phase == 0) return;
+  const int tid = threadIdx.x, c = tid & 15, grp = tid >> 4;  // 16 columns x 16 row groups per block
+  const int o = blockIdx.x * 16 + c;
+  const bool is_max = o == P.pc_gmax;
+  double a = 0.0;
+  if (o < P.PC) {
+    for (int r0 = grp; r0 < P.nblk; r0 += 256) {
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = r0 + 16 * u < P.nblk ? P.partial[(size_t)(r0 + 16 * u) * P.PC + o] : 0.0;
+      if (is_max) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a = fmax(a, v[u]);
+      } else {
+        a += (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
+             (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+      }
+    }
+  }
+  s_r[grp][c] = a;
+  __syncthreads();
+  if (tid < 16 && o < P.PC) {
+    double r = 0.0;
+    if (is_max) { for (int g2 = 0; g2 < 16; ++g2) r = fmax(r, s_r[g2][c]); }
+    else {
+      r = (((s_r[0][c] + s_r[1][c]) + (s_r[2][c] + s_r[3][c])) + ((s_r[4][c] + s_r[5][c]) + (s_r[6][c] + s_r[7][c]))) +
+          (((s_r[8][c] + s_r[9][c]) + (s_r[10][c] + s_r[11][c])) + ((s_r[12][c] + s_r[13][c]) + (s_r[14][c] + s_r[15][c])));
+    }
+    P.vec[o] = r;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // solve (one block of 256): reduce the partial rows, dense Cholesky of the reduced system in
 // LDS, gradient test, camera candidates. In phase 0 it only prepares the camera records.
 // ---------------------------------------------------------------------------------------------
@@ -551,10 +591,13 @@ __global__ __launch_bounds__(256) void k_rig_solve(RigDev P) {
   __shared__ double b[kRigMaxS];
   __shared__ double hd[kRigMaxS];
   __shared__ double gs[kRigMaxS];
+  __shared__ double s_inv[kRigMaxS];
   __shared__ double s_misc[4];  // fail, gmax
   __shared__ int s_ok;
   __shared__ double s4[4];
+  __shared__ unsigned char s_fixed[kRigMaxCams];
   const int tid = threadIdx.x;
+  if (tid < P.C) s_fixed[tid] = P.cam_fixed[tid];
   const LmCtl* cn = P.ctl_next;
   const int done = cn->done, phase = cn->phase, cur = cn->cur;
   const int S = P.S;
@@ -565,20 +608,9 @@ __global__ __launch_bounds__(256) void k_rig_solve(RigDev P) {
   bool step_ok = false, converged = false;
   double gmax = 0.0;
   if (phase != 0) {
-    // ---- reduce partial rows: column o handled by thread o % 256
+    // ---- reduced column sums from k_rig_reduce
     for (int o = tid; o < P.PC; o += 256) {
-      double a = 0.0;
-      if (o == P.pc_gmax) { for (int r = 0; r < P.nblk; ++r) a = fmax(a, P.partial[(size_t)r * P.PC + o]); }
-      else {
-        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        int r = 0;
-        for (; r + 3 < P.nblk; r += 4) {
-          a0 += P.partial[(size_t)r * P.PC + o]; a1 += P.partial[(size_t)(r + 1) * P.PC + o];
-          a2 += P.partial[(size_t)(r + 2) * P.PC + o]; a3 += P.partial[(size_t)(r + 3) * P.PC + o];
-        }
-        for (; r < P.nblk; ++r) a0 += P.partial[(size_t)r * P.PC + o];
-        a = (a0 + a1) + (a2 + a3);
-      }
+      const double a = P.vec[o];
       if (o < P.NP) { const int p = P.pair_p[o], q = P.pair_q[o]; A[p][q] = a; A[q][p] = a; }
       else if (o < P.pc_hd) b[o - P.pc_b] = a;
       else if (o < P.pc_fail) hd[o - P.pc_hd] = a;
@@ -590,54 +622,60 @@ __global__ __launch_bounds__(256) void k_rig_solve(RigDev P) {
     const LmOpts o = *P.opts;
     gmax = s_misc[1];
     for (int p = 0; p < S; ++p)
-      if (!P.cam_fixed[p / 6]) gmax = fmax(gmax, fabs(gs[p]));
+      if (!s_fixed[p / 6]) gmax = fmax(gmax, fabs(gs[p]));
     converged = gmax <= o.gradient_tolerance;
     if (!converged) {
       const double radius = cn->radius;
       if (tid < S) {
         const int p = tid;
-        if (P.cam_fixed[p / 6]) {
+        if (s_fixed[p / 6]) {
           for (int q = 0; q < S; ++q) { A[p][q] = 0.0; A[q][p] = 0.0; }
         }
       }
       __syncthreads();
       if (tid < S) {
         const int p = tid;
-        if (P.cam_fixed[p / 6]) { A[p][p] = 1.0; b[p] = 0.0; }
+        if (s_fixed[p / 6]) { A[p][p] = 1.0; b[p] = 0.0; }
         else A[p][p] += clampd(hd[p], o.min_lm_diagonal, o.max_lm_diagonal) / radius;
       }
       if (tid == 0) s_ok = s_misc[0] > 0.0 ? 0 : 1;
       __syncthreads();
-      // right-looking Cholesky, lower triangle in place
+      // right-looking Cholesky, lower triangle in place, ONE barrier per step: every thread derives
+      // 1/sqrt(pivot) itself, the trailing update uses the unscaled column times inv^2, and the
+      // scaled column is written in the same step by the threads that own it.
+      const int ti = tid >> 4, tk = tid & 15;  // 16 x 16 thread tile over the trailing block
       for (int j = 0; j < S; ++j) {
-        if (tid == 0) {
-          const double d = A[j][j];
-          if (!(d > 0.0) || !isfinite(d)) s_ok = 0;
-          A[j][j] = sqrt(d);
+        const double d = A[j][j];
+        if (tid == 0 && (!(d > 0.0) || !isfinite(d))) s_ok = 0;
+        const double inv = rsqrt(d), inv2 = inv * inv;
+        for (int i = j + 1 + ti; i < S; i += 16) {
+          const double aij = A[i][j] * inv2;
+          for (int k = j + 1 + tk; k <= i; k += 16) A[i][k] -= aij * A[k][j];
         }
         __syncthreads();
-        const double inv = 1.0 / A[j][j];
         if (tid > j && tid < S) A[tid][j] *= inv;
-        __syncthreads();
-        for (int e = tid; e < (S - j - 1) * (S - j - 1); e += 256) {
-          const int i = j + 1 + e / (S - j - 1), k = j + 1 + e % (S - j - 1);
-          if (k <= i) A[i][k] -= A[i][j] * A[k][j];
+        if (tid == j) { A[j][j] = d * inv; s_inv[j] = inv; }
+        // (column j is read again only by the substitutions, after the final barrier)
+      }
+      __syncthreads();
+      // forward / backward substitution on one wave: lane i owns b[i]; the pivot row value is
+      // broadcast with a lane read, no barrier needed (S <= 60 <= 64)
+      if (tid < 64) {
+        const int i = tid;
+        double bi = i < S ? b[i] : 0.0;
+        for (int j = 0; j < S; ++j) {
+          const double yj = __shfl(bi, j, 64) * s_inv[j];
+          if (i == j) bi = yj;
+          else if (i > j && i < S) bi -= A[i][j] * yj;
         }
-        __syncthreads();
+        for (int j = S - 1; j >= 0; --j) {
+          const double xj = __shfl(bi, j, 64) * s_inv[j];
+          if (i == j) bi = xj;
+          else if (i < j) bi -= A[j][i] * xj;
+        }
+        if (i < S) b[i] = bi;
       }
-      // forward / backward substitution (column oriented)
-      for (int j = 0; j < S; ++j) {
-        if (tid == 0) b[j] /= A[j][j];
-        __syncthreads();
-        if (tid > j && tid < S) b[tid] -= A[tid][j] * b[j];
-        __syncthreads();
-      }
-      for (int j = S - 1; j >= 0; --j) {
-        if (tid == 0) b[j] /= A[j][j];
-        __syncthreads();
-        if (tid < j) b[tid] -= A[j][tid] * b[j];
-        __syncthreads();
-      }
+      __syncthreads();
       if (tid < S && !isfinite(b[tid])) s_ok = 0;
       __syncthreads();
       step_ok = s_ok != 0;
@@ -653,7 +691,7 @@ __global__ __launch_bounds__(256) void k_rig_solve(RigDev P) {
     double q[4] = {pc[0], pc[1], pc[2], pc[3]}, t[3] = {pc[4], pc[5], pc[6]};
     double dc[6] = {0, 0, 0, 0, 0, 0};
     if (phase != 0) {
-      if (!P.cam_fixed[c]) {
+      if (!s_fixed[c]) {
         for (int i = 0; i < 6; ++i) dc[i] = -b[c * 6 + i] * P.ss[c * 6 + i];
         double qn[4];
         quat_plus(q, dc, qn);
@@ -760,6 +798,7 @@ static void rig_drop_graphs(cc_rig* h) {
 
 static void rig_enqueue_round(cc_rig* h) {
   const RigDev& d = h->d;
+  hipLaunchKernelGGL(k_rig_reduce, dim3((unsigned)((d.PC + 15) / 16)), dim3(256), 0, h->stream, d);
   hipLaunchKernelGGL(k_rig_solve, dim3(1), dim3(256), 0, h->stream, d);
   hipLaunchKernelGGL(k_rig_update, dim3((unsigned)((h->F + 15) / 16)), dim3(256), 0, h->stream, d);
   hipLaunchKernelGGL(k_rig_sweep, dim3((unsigned)h->NG), dim3(kRigThreads), kRigSweepLdsBytes, h->stream, d);
@@ -880,6 +919,7 @@ int cc_rig_create(int32_t device, int64_t C, int64_t F, int64_t n_world, const i
   if (int rc = dev_alloc(h, &d.ds, (size_t)64)) return rc;
   if (int rc = dev_alloc(h, &d.Y, (size_t)F * 6 * d.SW)) return rc;
   if (int rc = dev_alloc(h, &d.partial, (size_t)d.nblk * d.PC)) return rc;
+  if (int rc = dev_alloc(h, &d.vec, (size_t)d.PC)) return rc;
   if (int rc = dev_alloc(h, &d.shared_stats, (size_t)4)) return rc;
   if (int rc = dev_alloc(h, &d.ctl, (size_t)1)) return rc;
   if (int rc = dev_alloc(h, &d.ctl_next, (size_t)1)) return rc;
@@ -901,6 +941,7 @@ int cc_rig_create(int32_t device, int64_t C, int64_t F, int64_t n_world, const i
   CC_HIP(hipMemset(d.frec, 0, (size_t)F * 32 * sizeof(double)));
   CC_HIP(hipMemset(d.camrec, 0, (size_t)C * 32 * sizeof(double)));
   CC_HIP(hipMemset(d.partial, 0, (size_t)d.nblk * d.PC * sizeof(double)));
+  CC_HIP(hipMemset(d.vec, 0, (size_t)d.PC * sizeof(double)));
   CC_HIP(hipMemset(d.shared_stats, 0, 4 * sizeof(double)));
   CC_HIP(hipMemset(d.ctl, 0, sizeof(LmCtl)));
   CC_HIP(hipMemset(d.ctl_next, 0, sizeof(LmCtl)));
