@@ -81,7 +81,7 @@ EXPORTED_SYMBOLS = [
     "cc_intrinsics_solve", "cc_intrinsics_profile_sweep", "cc_intrinsics_optimize", "cc_comm_get_unique_id",
     "cc_intrinsics_comm_init", "cc_partition_frames", "cc_distort", "cc_undistort",
     "cc_rig_create", "cc_rig_destroy", "cc_rig_set_state", "cc_rig_reset", "cc_rig_solve",
-    "cc_rig_get_state", "cc_rig_eval", "cc_rig_optimize",
+    "cc_rig_get_state", "cc_rig_eval", "cc_rig_optimize", "cc_zhang_init",
 ]
 
 _lib = None
@@ -332,6 +332,21 @@ def rig_optimize(n_cams, frame_offsets, obs_cam, obs_world, obs_uv, world_xyz, c
                                  _p(frame_q, C.c_double), _p(frame_t, C.c_double), C.c_double(huber_a),
                                  _p(cost, C.c_double), C.byref(s)))
     return cam_q, cam_t, frame_q, frame_t, cost, _summary_dict(s, log)
+
+
+def zhang_init(frame_offsets, uv, xyz, device=0, want_homographies=False):
+    """cc_zhang_init: returns (K 3x3 float32, q [F,4] float32, t [F,3] float32[, H [F,3,3]])."""
+    off = np.ascontiguousarray(frame_offsets, dtype=np.int64)
+    F = len(off) - 1
+    uv, xyz = _f32(uv), _f32(xyz)
+    K = np.zeros(9, dtype=np.float32)
+    q = np.zeros((F, 4), dtype=np.float32)
+    t = np.zeros((F, 3), dtype=np.float32)
+    H = np.zeros((F, 3, 3), dtype=np.float32)
+    _check(lib().cc_zhang_init(C.c_int32(device), C.c_int64(F), _p(off, C.c_int64), _p(uv, C.c_float),
+                               _p(xyz, C.c_float), _p(K, C.c_float), _p(q, C.c_float), _p(t, C.c_float),
+                               _p(H, C.c_float) if want_homographies else None))
+    return (K.reshape(3, 3), q, t, H) if want_homographies else (K.reshape(3, 3), q, t)
 
 
 def distort(K, dist, xy, device=0):

@@ -25,25 +25,28 @@ void Calibrator::EstimateOpenCv(const std::vector<Points2D>&, const std::vector<
 
 void Calibrator::Estimate(const std::vector<Points2D>& in_img_points, const std::vector<Points3D>& in_world_points) {
   assert(in_img_points.size() == in_world_points.size());
-  std::vector<Matrix3> homographies;
-  homographies.reserve(in_img_points.size());
-  for (size_t i = 0; i < in_img_points.size(); ++i)
-    homographies.push_back(EstimateHomography(in_world_points[i], in_img_points[i]));
-  K_ = EstimateKFromHomographies(homographies);
-  const Matrix3 K_inv = Inverse3x3(K_);
+  const size_t n_img = in_img_points.size();
+  // Zhang initialisation on the device (cc_zhang_init): homographies -> K -> poses
+  std::vector<int64_t> offsets(n_img + 1, 0);
+  for (size_t i = 0; i < n_img; ++i) offsets[i + 1] = offsets[i] + (int64_t)in_img_points[i].size();
+  std::vector<float> uv((size_t)offsets[n_img] * 2), xyz((size_t)offsets[n_img] * 3);
+  for (size_t i = 0; i < n_img; ++i) {
+    size_t k = (size_t)offsets[i];
+    for (size_t j = 0; j < in_img_points[i].size(); ++j, ++k) {
+      uv[2 * k] = in_img_points[i][j].x(); uv[2 * k + 1] = in_img_points[i][j].y();
+      xyz[3 * k] = in_world_points[i][j].x(); xyz[3 * k + 1] = in_world_points[i][j].y(); xyz[3 * k + 2] = in_world_points[i][j].z();
+    }
+  }
+  float K9[9];
+  std::vector<float> q(4 * n_img), t(3 * n_img);
+  const int rc = cc_zhang_init(device_, (int64_t)n_img, offsets.data(), uv.data(), xyz.data(), K9, q.data(), t.data(), nullptr);
+  if (rc != 0) throw std::runtime_error(std::string("Calibrator::Estimate: ") + cc_last_error());
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) K_(r, c) = K9[r * 3 + c];
   std::vector<Quaternion> qs;
   std::vector<Point3D> ts;
-  for (const Matrix3& H : homographies) {
-    auto [R, t] = RecoverExtrinsics(K_inv, H);
-    if (t.z() < 0.0f) {
-      // The DLT null vector has an arbitrary sign; -H is the same homography but yields the pose
-      // mirrored behind the camera (identical projections). Keep the board in front of the camera.
-      Matrix3 Hn;
-      for (int i = 0; i < 9; ++i) Hn(i) = -H(i);
-      std::tie(R, t) = RecoverExtrinsics(K_inv, Hn);
-    }
-    qs.push_back(QuaternionFromRotationMatrix(R));
-    ts.push_back(t);
+  for (size_t i = 0; i < n_img; ++i) {
+    qs.emplace_back(q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]);
+    ts.emplace_back(t[3 * i], t[3 * i + 1], t[3 * i + 2]);
   }
   Optimize(in_img_points, in_world_points, qs, ts);
 }

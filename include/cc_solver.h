@@ -191,6 +191,17 @@ int cc_rig_optimize(const cc_options* opt, int32_t device, int64_t n_cams, int64
                     double* frame_t, double huber_a, double* obs_cost, cc_summary* summary);
 
 /* ---------------------------------------------------------------------------------------------
+ * Zhang's closed-form initialisation on the device: what Calibrator::Estimate does before calling
+ * Optimize (calibrator.cpp:47-66): per-frame DLT homography from (world x,y) -> image
+ * (geometry.cpp:70-105), K from the homographies (geometry.cpp:123-177), per-frame pose
+ * (geometry.cpp:179-203) as a float quaternion w x y z and translation. Needs >= 3 frames with
+ * >= 4 points each. Outputs K9 (row-major 3x3); q_wxyz [4F], t_xyz [3F], homographies [9F] may be
+ * NULL. The DLT null vector's sign is fixed so that the board lies in front of the camera.
+ * ------------------------------------------------------------------------------------------- */
+int cc_zhang_init(int32_t device, int64_t n_frames, const int64_t* frame_offsets, const float* uv,
+                  const float* xyz, float* K9, float* q_wxyz, float* t_xyz, float* homographies);
+
+/* ---------------------------------------------------------------------------------------------
  * Point kernels of the Calibrator surface.
  * ------------------------------------------------------------------------------------------- */
 /* Calibrator::Distort (calibrator.cpp:157-166): normalised -> pixel coordinates, float arithmetic

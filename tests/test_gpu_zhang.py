@@ -1,0 +1,53 @@
+"""Zhang initialisation on the device (cc_zhang_init) against the oracle's SVD-based restatement of
+geometry.cpp:70-203 / calibrator.cpp:47-66. Tolerances: homographies (normalised, sign-aligned)
+1e-5 relative -- float32 storage, and 1e-4 is what the reference's own test allows
+(test_geometry.cpp:172-194); K 1e-5 relative; poses 2e-5 absolute (float32 outputs)."""
+import numpy as np
+import pytest
+
+from camera_calibrator_amd import capi
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("frames,pts", [(3, 4), (5, 100), (20, 88), (12, [4, 9, 64, 65, 300, 5, 257, 128, 77, 500, 31, 1000])])
+def test_zhang_init_matches_oracle(frames, pts):
+    off, uv, xyz = po.make_intrinsics_problem(frames, pts)
+    Kg, qg, tg, Hg = capi.zhang_init(off, uv, xyz, want_homographies=True)
+    Ko, qo, to = po.zhang_init(off, uv, xyz)
+    for f in range(frames):
+        Ho = po.estimate_homography(xyz[off[f]:off[f + 1]], uv[off[f]:off[f + 1]])
+        a, b = Hg[f] / np.linalg.norm(Hg[f]), Ho / np.linalg.norm(Ho)
+        if np.sum(a * b) < 0:
+            b = -b
+        assert np.abs(a - b).max() < 1e-5
+    if frames == 3 and pts == 4:
+        return  # K from 3 noisy 4-point homographies is ill-conditioned: only H is compared
+    assert np.allclose(Kg, Ko, rtol=1e-5, atol=1e-6)
+    assert np.all(tg[:, 2] > 0)
+    sign = np.sign(np.sum(qg * qo, axis=1, keepdims=True))
+    assert np.abs(qg - sign * qo).max() < 2e-5 and np.abs(tg - to).max() < 2e-5
+
+
+def test_zhang_init_feeds_the_solver_to_the_same_minimum():
+    from tests.helpers import TIGHT
+    off, uv, xyz = po.make_intrinsics_problem(20, 88)
+    Kg, qg, tg = capi.zhang_init(off, uv, xyz)
+    intr0 = np.array([Kg[0, 0], Kg[1, 1], Kg[0, 2], Kg[1, 2], 0, 0, 0, 0, 0], dtype=np.float64)
+    ig, _, _, sg = capi.intrinsics_optimize(off, uv, xyz, intr0, qg.astype(np.float64), tg.astype(np.float64),
+                                            options=capi.default_options(**TIGHT))
+    Ko, qo, to = po.zhang_init(off, uv, xyz)
+    intr1 = np.array([Ko[0, 0], Ko[1, 1], Ko[0, 2], Ko[1, 2], 0, 0, 0, 0, 0], dtype=np.float64)
+    io, _, _, so = po.intrinsics_solve(off, uv, xyz, intr1, qo.astype(np.float64), to.astype(np.float64),
+                                       options=po.default_options(**TIGHT))
+    assert np.all(np.abs(ig[:4] - io[:4]) <= 1e-9 * np.abs(io[:4])) and np.all(np.abs(ig[4:] - io[4:]) <= 1e-9)
+
+
+def test_zhang_init_rejects_bad_input():
+    off, uv, xyz = po.make_intrinsics_problem(2, 10)
+    with pytest.raises(capi.CcError):
+        capi.zhang_init(off, uv, xyz)          # needs >= 3 frames (geometry.cpp:126)
+    off, uv, xyz = po.make_intrinsics_problem(3, [10, 3, 10])
+    with pytest.raises(capi.CcError):
+        capi.zhang_init(off, uv, xyz)          # a homography needs >= 4 points
