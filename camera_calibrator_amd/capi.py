@@ -81,7 +81,7 @@ EXPORTED_SYMBOLS = [
     "cc_intrinsics_solve", "cc_intrinsics_profile_sweep", "cc_intrinsics_optimize", "cc_comm_get_unique_id",
     "cc_intrinsics_comm_init", "cc_partition_frames", "cc_distort", "cc_undistort",
     "cc_rig_create", "cc_rig_destroy", "cc_rig_set_state", "cc_rig_reset", "cc_rig_solve",
-    "cc_rig_get_state", "cc_rig_eval", "cc_rig_optimize", "cc_zhang_init",
+    "cc_rig_get_state", "cc_rig_eval", "cc_rig_optimize", "cc_rig_comm_init", "cc_zhang_init",
 ]
 
 _lib = None
@@ -306,6 +306,10 @@ class RigProblem:
         c = C.c_double()
         _check(lib().cc_rig_eval(self._h, C.byref(c)))
         return c.value
+
+    def comm_init(self, unique_id, rank, nranks):
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        _check(lib().cc_rig_comm_init(self._h, buf, C.c_int32(rank), C.c_int32(nranks)))
 
 
 def rig_optimize(n_cams, frame_offsets, obs_cam, obs_world, obs_uv, world_xyz, cam_q, cam_t, cam_frozen,

@@ -60,7 +60,9 @@ struct RigDev {
   double* ds;       // [64] scaled shared step
   double* Y;        // [F][6*SW]
   double* partial;  // [nblk][PC]
-  double* vec;      // [PC] column sums of the partial rows (k_rig_reduce)
+  double* vec;      // [PC + 32] column sums of the partial rows (k_rig_reduce) + one max-gradient slot per rank
+  double* vec_stats;  // [4 + 6C] globally reduced sweep statistics (multi-GPU only)
+  int32_t comm, rank, nranks;  // comm != 0: statistics / partial sums pass through an all-reduce
   double* shared_stats;  // [4] step^2 and |x|^2 of the shared block (candidate)
   LmCtl* ctl;
   LmCtl* ctl_next;
@@ -312,6 +314,36 @@ __device__ __forceinline__ void rig_reduce_stats(const RigDev& P, bool want, dou
 }
 
 // ---------------------------------------------------------------------------------------------
+// stats (multi-GPU only, one block): local sums of the sweep statistics -> vec_stats, which is then
+// all-reduced. [0..3] cost, model term, step^2, |x|^2; in phase 0 also [4 + 6c + i] = sum of
+// diag(H_cc) of camera c (Jacobi scaling of the shared block).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rig_stats(RigDev P) {
+  __shared__ double s4[4];
+  __shared__ double s_out[4];
+  const LmCtl* ctl = P.ctl;
+  if (ctl->done) return;
+  const int tid = threadIdx.x, phase = ctl->phase;
+  const bool need = phase == 0 || (ctl->cand_pending && ctl->step_valid);
+  rig_reduce_stats(P, need, s4, s_out);
+  if (tid < 4) P.vec_stats[tid] = need ? s_out[tid] : 0.0;
+  for (int c = 0; c < P.C; ++c) {
+    double h[6] = {0, 0, 0, 0, 0, 0};
+    if (phase == 0)
+      for (int k = P.cam_goff[c] + tid; k < P.cam_goff[c + 1]; k += 256) {
+        const int g = P.cam_glist[k];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) h[i] += P.ghd0[(size_t)g * 8 + i];
+      }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const double s = block_sum256(h[i], s4);
+      if (tid == 0) P.vec_stats[4 + c * 6 + i] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // init (one block, first evaluation only): Jacobi scale of the shared block, trust-region state
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rig_init(RigDev P) {
@@ -321,19 +353,24 @@ __global__ __launch_bounds__(256) void k_rig_init(RigDev P) {
   const LmCtl* ctl = P.ctl;
   if (ctl->done || ctl->phase != 0) return;
   const int tid = threadIdx.x;
-  rig_reduce_stats(P, true, s4, s_out);
   const bool jac = P.opts->jacobi_scaling != 0;
-  for (int c = 0; c < P.C; ++c) {
-    double h[6] = {0, 0, 0, 0, 0, 0};
-    for (int k = P.cam_goff[c] + tid; k < P.cam_goff[c + 1]; k += 256) {
-      const int g = P.cam_glist[k];
+  if (P.comm) {
+    if (tid < 4) s_out[tid] = P.vec_stats[tid];
+    if (tid < P.S) s_ss[tid] = jac ? 1.0 / (1.0 + sqrt(P.vec_stats[4 + tid])) : 1.0;
+  } else {
+    rig_reduce_stats(P, true, s4, s_out);
+    for (int c = 0; c < P.C; ++c) {
+      double h[6] = {0, 0, 0, 0, 0, 0};
+      for (int k = P.cam_goff[c] + tid; k < P.cam_goff[c + 1]; k += 256) {
+        const int g = P.cam_glist[k];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) h[i] += P.ghd0[(size_t)g * 8 + i];
-    }
+        for (int i = 0; i < 6; ++i) h[i] += P.ghd0[(size_t)g * 8 + i];
+      }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const double s = block_sum256(h[i], s4);
-      if (tid == 0) s_ss[c * 6 + i] = jac ? 1.0 / (1.0 + sqrt(s)) : 1.0;
+      for (int i = 0; i < 6; ++i) {
+        const double s = block_sum256(h[i], s4);
+        if (tid == 0) s_ss[c * 6 + i] = jac ? 1.0 / (1.0 + sqrt(s)) : 1.0;
+      }
     }
   }
   __syncthreads();
@@ -372,7 +409,12 @@ __global__ __launch_bounds__(256) void k_rig_decide_elim(RigDev P) {
   const LmCtl* ctl = P.ctl;
   if (ctl->done || ctl->phase == 0) return;
   const bool pending = ctl->cand_pending != 0;
-  rig_reduce_stats(P, pending && ctl->step_valid, s4, s_tot);
+  if (P.comm) {
+    if (tid < 4) s_tot[tid] = P.vec_stats[tid];
+    __syncthreads();
+  } else {
+    rig_reduce_stats(P, pending && ctl->step_valid, s4, s_tot);
+  }
   if (tid == 0) {
     LmCtl c = *ctl;
     const LmOpts o = *P.opts;
@@ -578,6 +620,7 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P) {
       r = (((s_r[0][c] + s_r[1][c]) + (s_r[2][c] + s_r[3][c])) + ((s_r[4][c] + s_r[5][c]) + (s_r[6][c] + s_r[7][c]))) +
           (((s_r[8][c] + s_r[9][c]) + (s_r[10][c] + s_r[11][c])) + ((s_r[12][c] + s_r[13][c]) + (s_r[14][c] + s_r[15][c])));
     }
+    if (is_max) { P.vec[P.PC + P.rank] = r; r = 0.0; }  // a sum all-reduce then carries the max
     P.vec[o] = r;
   }
 }
@@ -620,7 +663,8 @@ __global__ __launch_bounds__(256) void k_rig_solve(RigDev P) {
     }
     __syncthreads();
     const LmOpts o = *P.opts;
-    gmax = s_misc[1];
+    gmax = 0.0;
+    for (int r = 0; r < P.nranks && r < 32; ++r) gmax = fmax(gmax, P.vec[P.PC + r]);
     for (int p = 0; p < S; ++p)
       if (!s_fixed[p / 6]) gmax = fmax(gmax, fabs(gs[p]));
     converged = gmax <= o.gradient_tolerance;
@@ -758,6 +802,13 @@ __global__ void k_rig_obs_cost(RigDev P, int cur, double* out /*sorted order*/) 
 // =============================================================================================
 // host side
 // =============================================================================================
+namespace cc {
+struct Comm;
+int comm_create(const uint8_t id[128], int rank, int nranks, Comm** out);
+void comm_destroy(Comm* c);
+int comm_allreduce_sum(Comm* c, double* buf, int n, hipStream_t stream);
+}  // namespace cc
+
 struct cc_rig {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -772,6 +823,9 @@ struct cc_rig {
   cc::LmCtl* h_ctl = nullptr;
   hipGraphExec_t graph[2] = {nullptr, nullptr};
   int graph_iters = 0;
+  cc::Comm* comm = nullptr;
+  uint8_t* d_cam_fixed = nullptr;          // same memory as d.cam_fixed
+  std::vector<uint8_t> frozen, seen;       // host copies (user freeze flags, locally observed cameras)
 };
 
 namespace cc {
@@ -796,14 +850,20 @@ static void rig_drop_graphs(cc_rig* h) {
     if (g) { hipGraphExecDestroy(g); g = nullptr; }
 }
 
-static void rig_enqueue_round(cc_rig* h) {
+static int rig_enqueue_round(cc_rig* h) {
   const RigDev& d = h->d;
   hipLaunchKernelGGL(k_rig_reduce, dim3((unsigned)((d.PC + 15) / 16)), dim3(256), 0, h->stream, d);
+  if (h->comm) if (int rc = comm_allreduce_sum(h->comm, d.vec, d.PC + 32, h->stream)) return rc;
   hipLaunchKernelGGL(k_rig_solve, dim3(1), dim3(256), 0, h->stream, d);
   hipLaunchKernelGGL(k_rig_update, dim3((unsigned)((h->F + 15) / 16)), dim3(256), 0, h->stream, d);
   hipLaunchKernelGGL(k_rig_sweep, dim3((unsigned)h->NG), dim3(kRigThreads), kRigSweepLdsBytes, h->stream, d);
+  if (h->comm) {
+    hipLaunchKernelGGL(k_rig_stats, dim3(1), dim3(256), 0, h->stream, d);
+    if (int rc = comm_allreduce_sum(h->comm, d.vec_stats, 4 + d.S, h->stream)) return rc;
+  }
   hipLaunchKernelGGL(k_rig_init, dim3(1), dim3(256), 0, h->stream, d);
   hipLaunchKernelGGL(k_rig_decide_elim, dim3(d.nblk), dim3(256), 0, h->stream, d);
+  return 0;
 }
 
 static int rig_write_ctl(cc_rig* h, const LmCtl& c) {
@@ -893,6 +953,10 @@ int cc_rig_create(int32_t device, int64_t C, int64_t F, int64_t n_world, const i
   d.pc_b = d.NP; d.pc_hd = d.NP + S; d.pc_fail = d.NP + 2 * S; d.pc_gs = d.pc_fail + 1; d.pc_gmax = d.pc_gs + S; d.PC = d.pc_gmax + 1;
   d.nblk = (int)std::min<int64_t>(kRigMaxElimBlocks, F);
   d.huber_a = huber_a;
+  d.comm = 0; d.rank = 0; d.nranks = 1;
+  h->frozen.assign((size_t)C, 0);
+  if (cam_frozen) for (int64_t c = 0; c < C; ++c) h->frozen[(size_t)c] = cam_frozen[c] ? 1 : 0;
+  h->seen = seen;
   if (d.PC > 256 * kRigOwn) { delete h; return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: too many cameras"); }
   { const float* p; if (int rc = dev_upload(h, &p, uv)) return rc; d.uv = p; }
   if (int rc = dev_upload(h, &d.widx, widx)) return rc;
@@ -904,6 +968,7 @@ int cc_rig_create(int32_t device, int64_t C, int64_t F, int64_t n_world, const i
   if (int rc = dev_upload(h, &d.cam_goff, cam_goff)) return rc;
   if (int rc = dev_upload(h, &d.cam_glist, cam_glist)) return rc;
   if (int rc = dev_upload(h, &d.cam_fixed, fixed)) return rc;
+  h->d_cam_fixed = const_cast<uint8_t*>(d.cam_fixed);
   if (int rc = dev_upload(h, &d.pair_p, pp)) return rc;
   if (int rc = dev_upload(h, &d.pair_q, pq)) return rc;
   if (int rc = dev_alloc(h, &d.cam, (size_t)2 * C * 8)) return rc;
@@ -919,7 +984,8 @@ int cc_rig_create(int32_t device, int64_t C, int64_t F, int64_t n_world, const i
   if (int rc = dev_alloc(h, &d.ds, (size_t)64)) return rc;
   if (int rc = dev_alloc(h, &d.Y, (size_t)F * 6 * d.SW)) return rc;
   if (int rc = dev_alloc(h, &d.partial, (size_t)d.nblk * d.PC)) return rc;
-  if (int rc = dev_alloc(h, &d.vec, (size_t)d.PC)) return rc;
+  if (int rc = dev_alloc(h, &d.vec, (size_t)d.PC + 32)) return rc;
+  if (int rc = dev_alloc(h, &d.vec_stats, (size_t)4 + kRigMaxS)) return rc;
   if (int rc = dev_alloc(h, &d.shared_stats, (size_t)4)) return rc;
   if (int rc = dev_alloc(h, &d.ctl, (size_t)1)) return rc;
   if (int rc = dev_alloc(h, &d.ctl_next, (size_t)1)) return rc;
@@ -941,7 +1007,8 @@ int cc_rig_create(int32_t device, int64_t C, int64_t F, int64_t n_world, const i
   CC_HIP(hipMemset(d.frec, 0, (size_t)F * 32 * sizeof(double)));
   CC_HIP(hipMemset(d.camrec, 0, (size_t)C * 32 * sizeof(double)));
   CC_HIP(hipMemset(d.partial, 0, (size_t)d.nblk * d.PC * sizeof(double)));
-  CC_HIP(hipMemset(d.vec, 0, (size_t)d.PC * sizeof(double)));
+  CC_HIP(hipMemset(d.vec, 0, ((size_t)d.PC + 32) * sizeof(double)));
+  CC_HIP(hipMemset(d.vec_stats, 0, ((size_t)4 + kRigMaxS) * sizeof(double)));
   CC_HIP(hipMemset(d.shared_stats, 0, 4 * sizeof(double)));
   CC_HIP(hipMemset(d.ctl, 0, sizeof(LmCtl)));
   CC_HIP(hipMemset(d.ctl_next, 0, sizeof(LmCtl)));
@@ -956,6 +1023,7 @@ void cc_rig_destroy(cc_rig* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   cc::rig_drop_graphs(h);
+  if (h->comm) cc::comm_destroy(h->comm);
   for (void* p : h->allocs) hipFree(p);
   if (h->h_ctl) hipHostFree(h->h_ctl);
   if (h->stream) hipStreamDestroy(h->stream);
@@ -1001,7 +1069,7 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
   if (opt) o = *opt; else { cc_options_init(&o); o.max_iterations = 1000; }  // extrinsics_calibrator.cpp:211
   if (o.check_interval < 1) o.check_interval = 1;
   if (o.max_iterations > h->d.log_cap - 1) o.max_iterations = h->d.log_cap - 1;
-  const bool use_graph = o.use_graph != 0;
+  const bool use_graph = o.use_graph != 0 && !h->comm;
   CC_HIP(hipSetDevice(h->device));
   {
     LmCtl st;
@@ -1036,7 +1104,8 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
     if (use_graph) {
       CC_HIP(hipGraphLaunch(h->graph[chunk == 0 ? 0 : 1], h->stream));
     } else {
-      for (int i = 0; i < n; ++i) rig_enqueue_round(h);
+      for (int i = 0; i < n; ++i)
+        if (int rc = rig_enqueue_round(h)) return rc;
       CC_HIP(hipGetLastError());
     }
     launched += n;
@@ -1105,6 +1174,28 @@ int cc_rig_eval(cc_rig* h, double* cost) {
   double c = 0.0;
   for (double v : oc) c += v;
   *cost = c;
+  return CC_OK;
+}
+
+int cc_rig_comm_init(cc_rig* h, const uint8_t id[128], int32_t rank, int32_t nranks) {
+  using namespace cc;
+  if (!h || !id || rank < 0 || nranks < 1 || rank >= nranks || nranks > 32)
+    return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_comm_init: bad arguments (nranks must be 1..32)");
+  CC_HIP(hipSetDevice(h->device));
+  if (h->comm) { comm_destroy(h->comm); h->comm = nullptr; }
+  rig_drop_graphs(h);
+  if (int rc = comm_create(id, rank, nranks, &h->comm)) return rc;
+  h->d.comm = 1; h->d.rank = rank; h->d.nranks = nranks;
+  // a camera is part of the problem if ANY rank observes it: sum the per-rank "seen" flags
+  std::vector<double> flags((size_t)4 + kRigMaxS, 0.0);
+  for (int64_t c = 0; c < h->C; ++c) flags[(size_t)c] = h->seen[(size_t)c] ? 1.0 : 0.0;
+  CC_HIP(hipMemcpyAsync(h->d.vec_stats, flags.data(), flags.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (int rc = comm_allreduce_sum(h->comm, h->d.vec_stats, (int)h->C, h->stream)) return rc;
+  CC_HIP(hipMemcpyAsync(flags.data(), h->d.vec_stats, flags.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  CC_HIP(hipStreamSynchronize(h->stream));
+  std::vector<uint8_t> fixed((size_t)h->C);
+  for (int64_t c = 0; c < h->C; ++c) fixed[(size_t)c] = (h->frozen[(size_t)c] || !(flags[(size_t)c] > 0.0)) ? 1 : 0;
+  CC_HIP(hipMemcpy(h->d_cam_fixed, fixed.data(), fixed.size(), hipMemcpyHostToDevice));
   return CC_OK;
 }
 

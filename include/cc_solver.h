@@ -179,8 +179,13 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary);
  * observation order (extrinsics_calibrator.cpp:219-225). */
 int cc_rig_get_state(cc_rig* h, double* cam_q, double* cam_t, double* frame_q, double* frame_t,
                      double* obs_cost);
-/* Total robustified cost at the current point (one sweep). */
+/* Total robustified cost at the current point (one sweep; this rank's observations only). */
 int cc_rig_eval(cc_rig* h, double* cost);
+/* Multi-GPU: each rank creates its handle with a contiguous shard of frames (cc_partition_frames on
+ * obs_frame_offsets) and ALL cameras / world points; then attaches as for the intrinsics problem.
+ * Per LM iteration: one all-reduce of the reduced (6C)x(6C) system (PC + 32 doubles) and one of
+ * 4 + 6C statistics. */
+int cc_rig_comm_init(cc_rig* h, const uint8_t id[128], int32_t rank, int32_t nranks);
 
 /* One-shot: the call ExtrinsicsCalibrator::Optimize makes in place of
  * extrinsics_calibrator.cpp:92-225. opt == NULL -> cc_options_init with max_iterations = 1000. */

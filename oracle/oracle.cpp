@@ -910,11 +910,11 @@ void oc_rig_residual(const double* q_rw, const double* t_rw, const double* q_cr,
   rig_eval(Rf, t_rw, Rc, t_cr, X, uv[0], uv[1], res, reinterpret_cast<double(*)[12]>(J));
 }
 
-int oc_rig_solve(const oc_options* opt, int64_t C, int64_t F, int64_t n_world, const int64_t* off,
-                 const uint32_t* ocam, const uint64_t* oworld, const float* ouv, const float* wxyz,
-                 double* cam_q, double* cam_t, const uint8_t* cam_frozen, double* frame_q,
-                 double* frame_t, double huber_a, double* obs_cost, oc_summary* summary) {
-  (void)n_world;
+static int rig_solve_impl(const oc_options* opt, int64_t C, int64_t F, const int64_t* off,
+                          const uint32_t* ocam, const uint64_t* oworld, const float* ouv, const float* wxyz,
+                          double* cam_q, double* cam_t, const uint8_t* cam_frozen, const uint8_t* cam_seen_global,
+                          double* frame_q, double* frame_t, double huber_a, double* obs_cost, oc_summary* summary,
+                          oc_allreduce_fn ar, void* ctx) {
   oc_options o;
   if (opt) o = *opt; else { oc_options_init(&o); o.max_iterations = 1000; }
   RigProblem P;
@@ -927,6 +927,7 @@ int oc_rig_solve(const oc_options* opt, int64_t C, int64_t F, int64_t n_world, c
   P.frame_active.assign(F, 0);
   for (int64_t f = 0; f < F; ++f)
     for (int64_t k = off[f]; k < off[f + 1]; ++k) { cam_seen[ocam[k]] = 1; P.frame_active[f] = 1; }
+  if (cam_seen_global) for (int64_t c = 0; c < C; ++c) cam_seen[c] = cam_seen_global[c];
   P.cam_fixed.resize(C);
   P.shared_fixed.resize(6 * C);
   P.shared_amb_active.resize(7 * C);
@@ -940,7 +941,7 @@ int oc_rig_solve(const oc_options* opt, int64_t C, int64_t F, int64_t n_world, c
     for (int i = 0; i < 4; ++i) shared[c * 7 + i] = cam_q[c * 4 + i];
     for (int i = 0; i < 3; ++i) shared[c * 7 + 4 + i] = cam_t[c * 3 + i];
   }
-  const int rc = run_lm(P, o, shared.data(), frame_q, frame_t, summary, nullptr, nullptr);
+  const int rc = run_lm(P, o, shared.data(), frame_q, frame_t, summary, ar, ctx);
   for (int64_t c = 0; c < C; ++c) {
     for (int i = 0; i < 4; ++i) cam_q[c * 4 + i] = shared[c * 7 + i];
     for (int i = 0; i < 3; ++i) cam_t[c * 3 + i] = shared[c * 7 + 4 + i];
@@ -950,6 +951,25 @@ int oc_rig_solve(const oc_options* opt, int64_t C, int64_t F, int64_t n_world, c
     P.eval(shared.data(), frame_q, frame_t, nullptr);
   }
   return rc;
+}
+
+int oc_rig_solve(const oc_options* opt, int64_t C, int64_t F, int64_t n_world, const int64_t* off,
+                 const uint32_t* ocam, const uint64_t* oworld, const float* ouv, const float* wxyz,
+                 double* cam_q, double* cam_t, const uint8_t* cam_frozen, double* frame_q,
+                 double* frame_t, double huber_a, double* obs_cost, oc_summary* summary) {
+  (void)n_world;
+  return rig_solve_impl(opt, C, F, off, ocam, oworld, ouv, wxyz, cam_q, cam_t, cam_frozen, nullptr, frame_q, frame_t,
+                        huber_a, obs_cost, summary, nullptr, nullptr);
+}
+
+int oc_rig_solve_sharded(const oc_options* opt, int64_t C, int64_t F, int64_t n_world, const int64_t* off,
+                         const uint32_t* ocam, const uint64_t* oworld, const float* ouv, const float* wxyz,
+                         double* cam_q, double* cam_t, const uint8_t* cam_frozen, const uint8_t* cam_seen_global,
+                         double* frame_q, double* frame_t, double huber_a, double* obs_cost, oc_summary* summary,
+                         oc_allreduce_fn ar, void* ctx) {
+  (void)n_world;
+  return rig_solve_impl(opt, C, F, off, ocam, oworld, ouv, wxyz, cam_q, cam_t, cam_frozen, cam_seen_global, frame_q,
+                        frame_t, huber_a, obs_cost, summary, ar, ctx);
 }
 
 // ---- Zhang initialisation ----------------------------------------------------------------

@@ -126,6 +126,15 @@ int oc_rig_solve(const oc_options* opt, int64_t n_cams, int64_t n_frames, int64_
                  double* cam_q, double* cam_t, const uint8_t* cam_frozen, double* frame_q,
                  double* frame_t, double huber_a, double* obs_cost, oc_summary* summary);
 
+/* Sharded variant (world_size>1 CPU tests): the rank owns frames [0,n_frames) of its shard with their
+ * observations; cameras and world points are replicated. */
+int oc_rig_solve_sharded(const oc_options* opt, int64_t n_cams, int64_t n_frames, int64_t n_world,
+                         const int64_t* obs_frame_offsets, const uint32_t* obs_cam,
+                         const uint64_t* obs_world, const float* obs_uv, const float* world_xyz,
+                         double* cam_q, double* cam_t, const uint8_t* cam_frozen, const uint8_t* cam_seen_global,
+                         double* frame_q, double* frame_t, double huber_a, double* obs_cost,
+                         oc_summary* summary, oc_allreduce_fn allreduce, void* ctx);
+
 /* ---- Zhang initialisation (src/geometry.cpp:70-203, src/calibrator.cpp:47-68) ---- */
 void oc_estimate_homography(int64_t n, const float* p1, int32_t stride1, const float* p2,
                             int32_t stride2, float* H9);

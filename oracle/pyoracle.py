@@ -189,7 +189,8 @@ def intrinsics_solve(offsets, uv, xyz, intr, q, t, const_mask=0, options=None, l
 
 
 def rig_solve(n_cams, frame_offsets, obs_cam, obs_world, obs_uv, world_xyz, cam_q, cam_t,
-              cam_frozen, frame_q, frame_t, huber_a=None, options=None, log_capacity=2048):
+              cam_frozen, frame_q, frame_t, huber_a=None, options=None, log_capacity=2048,
+              allreduce=None, cam_seen_global=None):
     offs = np.ascontiguousarray(frame_offsets, dtype=np.int64)
     F = len(offs) - 1
     obs_cam = np.ascontiguousarray(obs_cam, dtype=np.uint32)
@@ -204,13 +205,23 @@ def rig_solve(n_cams, frame_offsets, obs_cam, obs_world, obs_uv, world_xyz, cam_
     s, log = _summary(log_capacity)
     n_obs = len(obs_cam)
     cost = np.zeros(n_obs)
-    rc = lib().oc_rig_solve(C.byref(opt), C.c_int64(n_cams), C.c_int64(F),
-                            C.c_int64(len(world_xyz) // 3 if world_xyz.ndim == 1 else world_xyz.shape[0]),
-                            _p(offs, C.c_int64), _p(obs_cam, C.c_uint32), _p(obs_world, C.c_uint64),
-                            _p(obs_uv, C.c_float), _p(world_xyz, C.c_float), _p(cam_q, C.c_double),
-                            _p(cam_t, C.c_double), _p(frozen, C.c_uint8), _p(frame_q, C.c_double),
-                            _p(frame_t, C.c_double), C.c_double(huber_a), _p(cost, C.c_double),
-                            C.byref(s))
+    n_world = C.c_int64(len(world_xyz) // 3 if world_xyz.ndim == 1 else world_xyz.shape[0])
+    if allreduce is None:
+        rc = lib().oc_rig_solve(C.byref(opt), C.c_int64(n_cams), C.c_int64(F), n_world,
+                                _p(offs, C.c_int64), _p(obs_cam, C.c_uint32), _p(obs_world, C.c_uint64),
+                                _p(obs_uv, C.c_float), _p(world_xyz, C.c_float), _p(cam_q, C.c_double),
+                                _p(cam_t, C.c_double), _p(frozen, C.c_uint8), _p(frame_q, C.c_double),
+                                _p(frame_t, C.c_double), C.c_double(huber_a), _p(cost, C.c_double),
+                                C.byref(s))
+    else:
+        cb = ALLREDUCE_FN(allreduce)
+        seen = np.ascontiguousarray(cam_seen_global, dtype=np.uint8)
+        rc = lib().oc_rig_solve_sharded(C.byref(opt), C.c_int64(n_cams), C.c_int64(F), n_world,
+                                        _p(offs, C.c_int64), _p(obs_cam, C.c_uint32), _p(obs_world, C.c_uint64),
+                                        _p(obs_uv, C.c_float), _p(world_xyz, C.c_float), _p(cam_q, C.c_double),
+                                        _p(cam_t, C.c_double), _p(frozen, C.c_uint8), _p(seen, C.c_uint8),
+                                        _p(frame_q, C.c_double), _p(frame_t, C.c_double), C.c_double(huber_a),
+                                        _p(cost, C.c_double), C.byref(s), cb, None)
     assert rc == 0
     return cam_q, cam_t, frame_q, frame_t, cost, summary_to_dict(s, log)
 

@@ -95,3 +95,21 @@ def test_rig_handle_api_reset_and_determinism():
     prob.close()
     assert s1["final_cost"] == s2["final_cost"] and all(np.array_equal(a, b) for a, b in zip(r1, r2))
     assert np.isclose(s1["initial_cost"], c0, rtol=1e-12) and np.isclose(r1[4].sum(), s1["final_cost"], rtol=1e-12)
+
+
+def test_rig_rccl_path_with_a_single_rank_communicator():
+    """The multi-GPU launch sequence of the rig path (reduce -> all-reduce -> solve ... stats -> all-reduce
+    -> init/decide) with a 1-rank RCCL communicator must reproduce the single-GPU solve."""
+    sc = po.rig_scenario(3, 40, 6)
+    cq, ct, fq, ft = _inputs(sc)
+    prob = capi.RigProblem(3, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"], sc["world_xyz"], sc["cam_frozen"])
+    prob.set_state(cq, ct, fq, ft)
+    s0 = prob.solve(); r0 = prob.get_state()
+    prob.comm_init(capi.comm_get_unique_id(), 0, 1)
+    prob.reset()
+    s1 = prob.solve(); r1 = prob.get_state()
+    prob.close()
+    assert s1["iterations"] == s0["iterations"] and s1["termination"] == s0["termination"]
+    assert np.allclose([l["cost"] for l in s1["log"]], [l["cost"] for l in s0["log"]], rtol=1e-12)
+    for a, b in zip(r0, r1):
+        assert np.allclose(a, b, rtol=1e-12, atol=1e-14)
