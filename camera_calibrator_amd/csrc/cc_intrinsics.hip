@@ -808,7 +808,13 @@ static int read_ctl(cc_intrinsics* h, LmCtl* c) {
 
 }  // namespace cc
 
+namespace cc {
+int intr_create_impl(cc_intrinsics* h, const int64_t* off, const float* uv, const float* xyz);
+}
+
 extern "C" {
+
+void cc_intrinsics_destroy(cc_intrinsics* h);
 
 int cc_intrinsics_create(int32_t device, int64_t F, const int64_t* off, const float* uv,
                          const float* xyz, cc_intrinsics** out) {
@@ -822,6 +828,20 @@ int cc_intrinsics_create(int32_t device, int64_t F, const int64_t* off, const fl
   if (int rc = select_device(device)) return rc;
   cc_intrinsics* h = new cc_intrinsics();
   h->device = device; h->F = F; h->N = N;
+  const int rc_init = cc::intr_create_impl(h, off, uv, xyz);
+  if (rc_init != CC_OK) {  // release whatever was allocated before the failure
+    cc_intrinsics_destroy(h);
+    return rc_init;
+  }
+  *out = h;
+  return CC_OK;
+}
+
+}  // extern "C"
+
+namespace cc {
+int intr_create_impl(cc_intrinsics* h, const int64_t* off, const float* uv, const float* xyz) {
+  const int64_t F = h->F, N = h->N;
   CC_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   IntrDev& d = h->d;
   d.F = F; d.N = N; d.rank = 0; d.nranks = 1; d.mask = 0;
@@ -872,9 +892,11 @@ int cc_intrinsics_create(int32_t device, int64_t F, const int64_t* off, const fl
   h->elim_blocks = (int)std::min<int64_t>(kElimMaxBlocks, (F + 15) / 16);
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_intr_sweep),
                              hipFuncAttributeMaxDynamicSharedMemorySize, kSweepLdsBytes));
-  *out = h;
   return CC_OK;
 }
+}  // namespace cc
+
+extern "C" {
 
 void cc_intrinsics_destroy(cc_intrinsics* h) {
   if (!h) return;

@@ -97,6 +97,10 @@ static int run_points(int device, const float* K, const float* dist, int64_t n, 
   P.k1 = dist[0]; P.k2 = dist[1]; P.p1 = dist[2]; P.p2 = dist[3]; P.k3 = dist[4];
   inv3f(K, P.Ki);
   float2 *din = nullptr, *dout = nullptr;
+  struct Release {
+    float2 **a, **b;
+    ~Release() { hipFree(*a); hipFree(*b); }
+  } release{&din, &dout};
   CC_HIP(hipMalloc(&din, (size_t)n * sizeof(float2)));
   CC_HIP(hipMalloc(&dout, (size_t)n * sizeof(float2)));
   CC_HIP(hipMemcpy(din, in, (size_t)n * sizeof(float2), hipMemcpyHostToDevice));
@@ -106,8 +110,6 @@ static int run_points(int device, const float* K, const float* dist, int64_t n, 
   else hipLaunchKernelGGL(k_distort, dim3(blocks), dim3(threads), 0, 0, P, n, din, dout);
   CC_HIP(hipGetLastError());
   CC_HIP(hipMemcpy(out, dout, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost));
-  hipFree(din);
-  hipFree(dout);
   return CC_OK;
 }
 

@@ -880,6 +880,16 @@ static int rig_read_ctl(cc_rig* h, LmCtl* c) {
 
 }  // namespace cc
 
+extern "C" void cc_rig_destroy(cc_rig* h);
+
+namespace cc {
+struct RigCreateGuard {  // releases a half-built handle on every early return
+  cc_rig* h;
+  bool ok = false;
+  ~RigCreateGuard() { if (!ok) cc_rig_destroy(h); }
+};
+}  // namespace cc
+
 extern "C" {
 
 int cc_rig_create(int32_t device, int64_t C, int64_t F, int64_t n_world, const int64_t* off,
@@ -899,6 +909,7 @@ int cc_rig_create(int32_t device, int64_t C, int64_t F, int64_t n_world, const i
   }
   if (int rc = select_device(device)) return rc;
   cc_rig* h = new cc_rig();
+  RigCreateGuard guard{h};
   h->device = device; h->C = C; h->F = F; h->N = N; h->P = n_world;
   // ---- regroup: within each frame, stable sort by camera -> (frame, camera) groups
   h->perm.resize((size_t)N);
@@ -926,7 +937,7 @@ int cc_rig_create(int32_t device, int64_t C, int64_t F, int64_t n_world, const i
   }
   const int64_t NG = (int64_t)gframe.size();
   h->NG = NG;
-  if (NG == 0) { delete h; return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: no observations"); }
+  if (NG == 0) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: no observations");
   std::vector<float> uv((size_t)N * 2);
   std::vector<int32_t> widx((size_t)N);
   for (int64_t i = 0; i < N; ++i) {
@@ -957,7 +968,7 @@ int cc_rig_create(int32_t device, int64_t C, int64_t F, int64_t n_world, const i
   h->frozen.assign((size_t)C, 0);
   if (cam_frozen) for (int64_t c = 0; c < C; ++c) h->frozen[(size_t)c] = cam_frozen[c] ? 1 : 0;
   h->seen = seen;
-  if (d.PC > 256 * kRigOwn) { delete h; return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: too many cameras"); }
+  if (d.PC > 256 * kRigOwn) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: too many cameras");
   { const float* p; if (int rc = dev_upload(h, &p, uv)) return rc; d.uv = p; }
   if (int rc = dev_upload(h, &d.widx, widx)) return rc;
   { std::vector<float> w(world_xyz, world_xyz + (size_t)n_world * 3); if (int rc = dev_upload(h, &d.wxyz, w)) return rc; }
@@ -1014,6 +1025,7 @@ int cc_rig_create(int32_t device, int64_t C, int64_t F, int64_t n_world, const i
   CC_HIP(hipMemset(d.ctl_next, 0, sizeof(LmCtl)));
   CC_HIP(hipHostMalloc(&h->h_ctl, sizeof(LmCtl), hipHostMallocDefault));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_sweep), hipFuncAttributeMaxDynamicSharedMemorySize, kRigSweepLdsBytes));
+  guard.ok = true;
   *out = h;
   return CC_OK;
 }

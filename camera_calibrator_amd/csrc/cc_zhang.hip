@@ -312,6 +312,10 @@ extern "C" int cc_zhang_init(int32_t device, int64_t F, const int64_t* off, cons
   float *duv = nullptr, *dxyz = nullptr, *dH = nullptr, *dK = nullptr, *dq = nullptr, *dt = nullptr;
   int64_t* doff = nullptr;
   double* dgram = nullptr;
+  struct Release {  // frees the scratch buffers on every exit path
+    float **a, **b, **c, **d, **e, **f; int64_t** g; double** h;
+    ~Release() { hipFree(*a); hipFree(*b); hipFree(*c); hipFree(*d); hipFree(*e); hipFree(*f); hipFree(*g); hipFree(*h); }
+  } release{&duv, &dxyz, &dH, &dK, &dq, &dt, &doff, &dgram};
   CC_HIP(hipMalloc(&duv, (size_t)N * 2 * sizeof(float)));
   CC_HIP(hipMalloc(&dxyz, (size_t)N * 3 * sizeof(float)));
   CC_HIP(hipMalloc(&doff, (size_t)(F + 1) * sizeof(int64_t)));
@@ -332,6 +336,5 @@ extern "C" int cc_zhang_init(int32_t device, int64_t F, const int64_t* off, cons
   if (q_wxyz) CC_HIP(hipMemcpy(q_wxyz, dq, (size_t)F * 4 * sizeof(float), hipMemcpyDeviceToHost));
   if (t_xyz) CC_HIP(hipMemcpy(t_xyz, dt, (size_t)F * 3 * sizeof(float), hipMemcpyDeviceToHost));
   if (homographies) CC_HIP(hipMemcpy(homographies, dH, (size_t)F * 9 * sizeof(float), hipMemcpyDeviceToHost));
-  hipFree(duv); hipFree(dxyz); hipFree(doff); hipFree(dgram); hipFree(dH); hipFree(dK); hipFree(dq); hipFree(dt);
   return CC_OK;
 }
