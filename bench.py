@@ -79,12 +79,13 @@ def main():
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     from camera_calibrator_amd import capi
-    from oracle import pyoracle as po  # synthetic-input generator + cpu_baseline leg only
 
-    # ---- synthetic input: data_generator.cpp restatement, test_calibrator.cpp fixture constants ----
+    # ---- synthetic input: the product's DataGenerator harness (include/cc_harness.h, the reference's
+    # data_generator.cpp without OpenCV) with the test_calibrator.cpp fixture constants; initial state
+    # from the device Zhang initialisation (cc_zhang_init = Calibrator::Estimate before Optimize)
     F_total = args.frames * world
-    off, uv, xyz = po.make_intrinsics_problem(F_total, args.points)
-    K0, q0, t0 = po.zhang_init(off, uv, xyz)  # Calibrator::Estimate's initialisation (calibrator.cpp:47-66)
+    off, uv, xyz = capi.make_intrinsics_problem(F_total, args.points)
+    K0, q0, t0 = capi.zhang_init(off, uv, xyz, device=local_rank)
     intr0 = np.array([K0[0, 0], K0[1, 1], K0[0, 2], K0[1, 2], 0, 0, 0, 0, 0], dtype=np.float64)
     q0 = q0.astype(np.float64)
     t0 = t0.astype(np.float64)
@@ -202,6 +203,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
+            from oracle import pyoracle as po  # the ONLY use of oracle/ in this file: the cpu_baseline leg
             # CPU baseline: the oracle (a "port": exact-Schur fp64 restatement, analytic Jacobians),
             # same arrays, same options, 1 thread like the reference (Ceres num_threads default 1).
             oo = po.default_options()

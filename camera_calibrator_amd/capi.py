@@ -83,6 +83,11 @@ EXPORTED_SYMBOLS = [
     "cc_rig_create", "cc_rig_destroy", "cc_rig_set_state", "cc_rig_reset", "cc_rig_solve",
     "cc_rig_get_state", "cc_rig_eval", "cc_rig_optimize", "cc_rig_comm_init", "cc_zhang_init",
 ]
+# every symbol include/cc_harness.h declares (synthetic-input harness, host code)
+HARNESS_SYMBOLS = [
+    "cc_generator_create", "cc_generator_destroy", "cc_generator_set_k", "cc_generator_set_distortion",
+    "cc_generator_set_noise", "cc_generator_planar", "cc_generator_points",
+]
 
 _lib = None
 
@@ -96,6 +101,9 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.cc_last_error.restype = C.c_char_p
         _lib.cc_version.restype = C.c_char_p
+        _lib.cc_generator_create.restype = C.c_void_p
+        _lib.cc_generator_planar.restype = C.c_int64
+        _lib.cc_generator_points.restype = C.c_int64
     return _lib
 
 
@@ -367,3 +375,51 @@ def undistort(K, dist, uv, device=0):
     _check(lib().cc_undistort(C.c_int32(device), _p(_f32(K), C.c_float), _p(_f32(dist), C.c_float),
                               C.c_int64(uv.size // 2), _p(uv, C.c_float), _p(out, C.c_float)))
     return out
+
+
+# ---- synthetic-input harness (include/cc_harness.h): the reference's DataGenerator without OpenCV ----
+# fixture constants of src/test_calibrator.cpp:11-21
+FIXTURE_W, FIXTURE_H = 1600, 1000
+FIXTURE_K = np.array([[1000, 0, 800], [0, 1000, 500], [0, 0, 1]], dtype=np.float32)
+FIXTURE_DIST = np.array([-4.0e-2, 5e-4, 1.0e-3, 2.0e-5, -3e-4], dtype=np.float32)
+FIXTURE_NOISE = 0.5
+
+
+class Generator:
+    def __init__(self, width=FIXTURE_W, height=FIXTURE_H, K=FIXTURE_K, dist=FIXTURE_DIST, noise=FIXTURE_NOISE):
+        self._g = C.c_void_p(lib().cc_generator_create(C.c_int32(width), C.c_int32(height)))
+        lib().cc_generator_set_k(self._g, _p(_f32(K), C.c_float))
+        lib().cc_generator_set_distortion(self._g, _p(_f32(dist), C.c_float))
+        lib().cc_generator_set_noise(self._g, C.c_float(noise))
+
+    def __del__(self):
+        if getattr(self, "_g", None):
+            lib().cc_generator_destroy(self._g)
+            self._g = None
+
+    def planar(self, num_p=100):
+        uv = np.zeros((num_p, 2), dtype=np.float32)
+        xyz = np.zeros((num_p, 3), dtype=np.float32)
+        n = lib().cc_generator_planar(self._g, C.c_int32(num_p), _p(uv, C.c_float), _p(xyz, C.c_float))
+        assert n == num_p
+        return uv, xyz
+
+    def points(self, num_p=100):
+        uv = np.zeros((num_p, 2), dtype=np.float32)
+        xyz = np.zeros((num_p, 3), dtype=np.float32)
+        n = lib().cc_generator_points(self._g, C.c_int32(num_p), _p(uv, C.c_float), _p(xyz, C.c_float))
+        assert n == num_p
+        return uv, xyz
+
+
+def make_intrinsics_problem(n_frames, pts_per_frame, **gen_kw):
+    """One GetDistortedPointsPlanar call per frame (src/test_calibrator.cpp:52-60); pts_per_frame may be ragged."""
+    g = Generator(**gen_kw)
+    counts = [pts_per_frame] * n_frames if np.isscalar(pts_per_frame) else list(pts_per_frame)
+    uvs, xyzs = [], []
+    for m in counts:
+        uv, xyz = g.planar(int(m))
+        uvs.append(uv)
+        xyzs.append(xyz)
+    offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    return offsets, np.concatenate(uvs), np.concatenate(xyzs)

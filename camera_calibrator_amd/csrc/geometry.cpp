@@ -117,14 +117,24 @@ Point3D PlaneNormal(const Plane& plane) {
 Matrix3 RotationMatrixFromPlane(const Plane& plane, const Point3D& new_normal) {
   if (!(std::fabs(new_normal.x()) < 1e-5f && std::fabs(new_normal.y()) < 1e-5f && std::fabs(new_normal.z() - 1.0f) < 1e-5f))
     std::cerr << "Warning: RotationMatrixFromPlane with new_normal other than UnitZ not tested" << std::endl;
+  // float arithmetic throughout, as Eigen's Vector3f cross()/normalized() in geometry.cpp:29-36
+  auto unitf = [](float x, float y, float z, float* o) {
+    const float zz = x * x + y * y + z * z;
+    if (zz > 0.0f) { const float n = std::sqrt(zz); o[0] = x / n; o[1] = y / n; o[2] = z / n; } else { o[0] = x; o[1] = y; o[2] = z; }
+  };
+  auto crossf = [](const float* a, const float* b, float* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+  };
   const Point3D nf = PlaneNormal(plane);
-  const V3 n{nf.x(), nf.y(), nf.z()};
-  const V3 v1 = unit(cross(n, unit(V3{new_normal.x(), new_normal.y(), new_normal.z()})));
-  const V3 v2 = unit(cross(n, v1));
+  const float n[3] = {nf.x(), nf.y(), nf.z()};
+  float nn[3], c1[3], v1[3], c2[3], v2[3];
+  unitf(new_normal.x(), new_normal.y(), new_normal.z(), nn);
+  crossf(n, nn, c1);
+  unitf(c1[0], c1[1], c1[2], v1);
+  crossf(n, v1, c2);
+  unitf(c2[0], c2[1], c2[2], v2);
   Matrix3 R;
-  R(0, 0) = (float)v1.x; R(0, 1) = (float)v1.y; R(0, 2) = (float)v1.z;
-  R(1, 0) = (float)v2.x; R(1, 1) = (float)v2.y; R(1, 2) = (float)v2.z;
-  R(2, 0) = (float)n.x;  R(2, 1) = (float)n.y;  R(2, 2) = (float)n.z;
+  for (int c = 0; c < 3; ++c) { R(0, c) = v1[c]; R(1, c) = v2[c]; R(2, c) = n[c]; }
   return R;
 }
 

@@ -12,8 +12,8 @@ from camera_calibrator_amd import capi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "cc_solver.h")).read()
+def _declared_symbols(header="cc_solver.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(cc_[a-z0-9_]+)\s*\(", text)))
 
@@ -25,6 +25,25 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, missing
     assert sorted(capi.EXPORTED_SYMBOLS) == declared
+    harness = _declared_symbols("cc_harness.h")
+    assert sorted(capi.HARNESS_SYMBOLS) == harness and all(hasattr(lib, s) for s in harness)
+    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["cc_harness.h", "cc_solver.h"]
+
+
+def test_product_generator_is_bit_identical_to_the_oracle_generator():
+    """The harness DataGenerator (camera_calibrator_amd/csrc/data_generator.cpp) and the oracle's
+    restatement (oracle/oracle.cpp) are two independent codes of src/data_generator.cpp."""
+    from oracle import pyoracle as po
+    for frames, pts in [(5, 100), (7, [8, 64, 65, 300, 5, 257, 128])]:
+        a = capi.make_intrinsics_problem(frames, pts)
+        b = po.make_intrinsics_problem(frames, pts)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    g1, g2 = capi.Generator(), po.Generator()
+    u1, x1 = g1.points(50)
+    u2, x2 = g2.points(50)
+    assert np.array_equal(u1, u2) and np.array_equal(x1, x2)
+    z = capi.Generator(noise=0.0).planar(20)
+    assert np.all(z[1][:, 2] == 0)
 
 
 def test_option_defaults_match_reference_call_site():
