@@ -632,6 +632,10 @@ __global__ __launch_bounds__(kSolveThreads) void k_intr_solve(IntrDev P, int nbl
     if (gmax <= o.gradient_tolerance) {
       c.done = 1;
       c.term = CC_CONVERGENCE_GRADIENT;
+    } else if (c.iter == 0 && c.radius < o.min_radius) {
+      // the loop-top radius test of the very first iteration (later ones are made by lm_decide)
+      c.done = 1;
+      c.term = CC_MIN_RADIUS;
     } else {
       bool ok = !(V[PC_FAIL] > 0.0);
       double A[45], b[9], inv[9];

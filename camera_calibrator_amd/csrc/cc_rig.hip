@@ -649,6 +649,7 @@ __global__ __launch_bounds__(256) void k_rig_solve(RigDev P) {
     return;
   }
   bool step_ok = false, converged = false;
+  int early_term = CC_CONVERGENCE_GRADIENT;
   double gmax = 0.0;
   if (phase != 0) {
     // ---- reduced column sums from k_rig_reduce
@@ -668,6 +669,8 @@ __global__ __launch_bounds__(256) void k_rig_solve(RigDev P) {
     for (int p = 0; p < S; ++p)
       if (!s_fixed[p / 6]) gmax = fmax(gmax, fabs(gs[p]));
     converged = gmax <= o.gradient_tolerance;
+    // the loop-top radius test of the very first iteration (later ones are made by lm_decide)
+    if (!converged && cn->iter == 0 && cn->radius < o.min_radius) { converged = true; early_term = CC_MIN_RADIUS; }
     if (!converged) {
       const double radius = cn->radius;
       if (tid < S) {
@@ -762,7 +765,7 @@ __global__ __launch_bounds__(256) void k_rig_solve(RigDev P) {
       c.gmax = gmax;
       if (c.log_len > 0 && c.log_len <= P.log_cap && P.log[c.log_len - 1].accepted)
         P.log[c.log_len - 1].gradient_max_norm = gmax;
-      if (converged) { c.done = 1; c.term = CC_CONVERGENCE_GRADIENT; }
+      if (converged) { c.done = 1; c.term = early_term; }
       else {
         c.step_valid = step_ok ? 1 : 0;
         c.cand_pending = 1;
