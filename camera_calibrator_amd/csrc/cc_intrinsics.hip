@@ -408,6 +408,9 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P) {
   const int phase = ctl->phase;
   const bool pending = ctl->cand_pending != 0;
   const bool need = phase == 0 || (pending && ctl->step_valid);
+#if CC_ABLATE_D == 1
+  if (ctl->gmax == 1e30) return;  // marker set by cc_intrinsics_profile_kernel
+#endif
   if (MODE == 0) {
     reduce_frame_stats(P, need, phase == 0, s_w, s_tot);
   } else {
@@ -440,6 +443,9 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P) {
     s_ctl = c;
     if (blockIdx.x == 0) *P.ctl_next = c;
   }
+#if CC_ABLATE_D == 2
+  if (ctl->gmax == 1e30) return;  // marker set by cc_intrinsics_profile_kernel
+#endif
   if (phase != 0 && tid < 9) s_ss[tid] = P.ss[tid];
   if (tid == 32) {
     int o = 0;
@@ -448,16 +454,52 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P) {
   }
   __syncthreads();
   if (s_ctl.done) return;
+#if CC_ABLATE_D == 3
+  if (ctl->gmax == 1e30) return;  // marker set by cc_intrinsics_profile_kernel
+#endif
   const int cur = s_ctl.cur;
-  const double radius = s_ctl.radius;
+  const double inv_radius = 1.0 / s_ctl.radius;
   const double mn = P.opts->min_lm_diagonal, mx = P.opts->max_lm_diagonal;
 
-  double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // slots l*5 + r
+  // Output slots l*5 + r of this lane: what they read is the same for every frame, so the source
+  // index, the scales and the Z columns live in registers and the loads go out with the Cholesky's.
+  int gi[5], zj[5], zk[5];
+  double sa[5], sb[5];
+  bool use_z[5];
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const int o = l * 5 + r;
+    gi[r] = 0; zj[r] = 0; zk[r] = 0; sa[r] = 0.0; sb[r] = 0.0; use_z[r] = false;
+    if (o < 45) {
+      const int j = pj[o], k = pk[o];
+      gi[r] = j * 16 + k; zj[r] = j; zk[r] = k; sa[r] = s_ss[j]; sb[r] = s_ss[k]; use_z[r] = true;
+    } else if (o < 54) {
+      const int j = o - 45;
+      gi[r] = j * 16 + 15; zj[r] = j; zk[r] = 9; sa[r] = s_ss[j]; sb[r] = 1.0; use_z[r] = true;
+    } else if (o < 63) {
+      const int j = o - 54;
+      gi[r] = j * 17; sa[r] = s_ss[j] * s_ss[j]; sb[r] = 1.0;
+    } else if (o >= PC_GS && o < PC_GS + 9) {
+      gi[r] = (o - PC_GS) * 16 + 15; sa[r] = 1.0; sb[r] = 1.0;
+    }  // PC_FAIL, PC_GMAXP and the padding columns: 0 here, the two live ones are filled in below
+  }
+  const int l6 = l < 6 ? l : l - 6 < 6 ? l - 6 : l - 12;
+  double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  double gacc = 0.0, facc = 0.0;
   for (int64_t base = (int64_t)blockIdx.x * 16; base < P.F; base += (int64_t)gridDim.x * 16) {
     const int64_t f = base + g;
     const bool valid = f < P.F;
     const double* G = P.blocks + ((size_t)cur * P.F + (valid ? f : 0)) * 256;
     double fail = 0.0;
+    double gv[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) gv[r] = G[gi[r]];
+    const double gp = fabs(G[(9 + l6) * 16 + 15]);
+    // column l (< 10) of [H_ps | g_p], loaded with everything else in one round trip
+    const int col = l < 9 ? l : 15;
+    double w[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) w[i] = G[(9 + i) * 16 + col];
     if (valid) {
       double s[6], L[21];
 #pragma unroll
@@ -467,8 +509,9 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P) {
 #pragma unroll
         for (int j = 0; j <= i; ++j) L[tri(i, j)] = s[i] * G[(9 + i) * 16 + 9 + j] * s[j];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) L[tri(i, i)] += clampd(L[tri(i, i)], mn, mx) / radius;
-      // in-place Cholesky (lower), fully unrolled so L stays in registers (redundant per lane)
+      for (int i = 0; i < 6; ++i) L[tri(i, i)] += clampd(L[tri(i, i)], mn, mx) * inv_radius;
+      // in-place Cholesky (lower), fully unrolled so L stays in registers (redundant per lane);
+      // one rsqrt per pivot: L_jj = d * rsqrt(d), 1 / L_jj = rsqrt(d)
       bool ok = true;
       double Li[6];  // 1 / L_jj
 #pragma unroll
@@ -477,9 +520,8 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P) {
 #pragma unroll
         for (int k = 0; k < j; ++k) d -= L[tri(j, k)] * L[tri(j, k)];
         ok = ok && (d > 0.0) && isfinite(d);
-        d = sqrt(d);
-        L[tri(j, j)] = d;
-        const double inv = 1.0 / d;
+        const double inv = rsqrt(d);
+        L[tri(j, j)] = d * inv;
         Li[j] = inv;
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
@@ -490,14 +532,16 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P) {
         }
       }
       if (!ok) fail = 1.0;
+#if CC_ABLATE_D == 4
+      if (L[20] != 123.0 && ctl->gmax == 1e30) return;
+#endif
       if (l < 10) {
-        // column l of [H_ps | g_p]: z = L^-1 w (for the Schur sums), y = L^-T z (for the back-substitution)
-        const int col = l < 9 ? l : 15;
+        // z = L^-1 w (for the Schur sums), y = L^-T z (for the back-substitution)
         const double sc = l < 9 ? s_ss[l] : 1.0;
         double z[6], y[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-          double a = s[i] * G[(9 + i) * 16 + col] * sc;
+          double a = s[i] * w[i] * sc;
 #pragma unroll
           for (int k = 0; k < i; ++k) a -= L[tri(i, k)] * z[k];
           z[i] = a * Li[i];
@@ -517,38 +561,31 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P) {
       }
     }
     __syncthreads();
+#if CC_ABLATE_D == 5
+    if (ctl->gmax == 1e30) return;
+#endif
     if (valid) {
 #pragma unroll
       for (int r = 0; r < 5; ++r) {
-        const int o = l * 5 + r;
-        double a = 0.0;
-        if (o < 45) {
-          const int j = pj[o], k = pk[o];
-          a = s_ss[j] * G[j * 16 + k] * s_ss[k];
+        double zz = 0.0;
 #pragma unroll
-          for (int i = 0; i < 6; ++i) a -= Zs[g][i * 10 + j] * Zs[g][i * 10 + k];
-        } else if (o < 54) {
-          const int j = o - 45;
-          a = s_ss[j] * G[j * 16 + 15];
-#pragma unroll
-          for (int i = 0; i < 6; ++i) a -= Zs[g][i * 10 + j] * Zs[g][i * 10 + 9];
-        } else if (o < 63) {
-          const int j = o - 54;
-          a = s_ss[j] * s_ss[j] * G[j * 17];
-        } else if (o == PC_FAIL) {
-          a = fail;
-        } else if (o < PC_GS + 9) {
-          a = G[(o - PC_GS) * 16 + 15];
-        } else if (o == PC_GMAXP) {
-          for (int i = 0; i < 6; ++i) a = fmax(a, fabs(G[(9 + i) * 16 + 15]));
-        }
-        if (o == PC_GMAXP) acc[r] = fmax(acc[r], a); else acc[r] += a;
+        for (int i = 0; i < 6; ++i) zz += Zs[g][i * 10 + zj[r]] * Zs[g][i * 10 + zk[r]];
+        acc[r] += sa[r] * gv[r] * sb[r] - (use_z[r] ? zz : 0.0);
       }
+      gacc = fmax(gacc, gp);
+      facc += fail;
     }
     __syncthreads();
   }
+#if CC_ABLATE_D == 6
+  if (ctl->gmax == 1e30) { if (acc[0] + acc[1] + acc[2] + acc[3] + acc[4] + gacc + facc == 123.0) P.partial[tid] = 0; return; }
+#endif
 #pragma unroll
-  for (int r = 0; r < 5; ++r) red[g][l * 5 + r] = acc[r];
+  for (int r = 0; r < 5; ++r)
+    if (l * 5 + r != PC_FAIL && l * 5 + r != PC_GMAXP) red[g][l * 5 + r] = acc[r];
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) gacc = fmax(gacc, __shfl_xor(gacc, o, 64));
+  if (l == 0) { red[g][PC_FAIL] = facc; red[g][PC_GMAXP] = gacc; }
   __syncthreads();
   if (tid < kPartialCols) {
     double a = 0.0;
@@ -1124,6 +1161,54 @@ int cc_intrinsics_profile_sweep(cc_intrinsics* h, int32_t n, double* avg_ms) {
   hipEventDestroy(e1);
   *avg_ms = (double)ms / n;
   CC_HIP(hipMemcpy(h->d.ctl, &st, sizeof(st), hipMemcpyHostToDevice));
+  return CC_OK;
+}
+
+// developer aid (not declared in cc_solver.h): time one kernel of the iteration in isolation, replayed
+// n times from the state the last solve left behind. which: 1 = decide_elim, 2 = solve.
+int cc_intrinsics_profile_kernel(cc_intrinsics* h, int32_t which, int32_t n, double* avg_ms) {
+  using namespace cc;
+  if (!h || n < 1 || !avg_ms || which < 1 || which > 2) return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_profile_kernel: bad arguments");
+  CC_HIP(hipSetDevice(h->device));
+  LmCtl st;
+  if (int rc = read_ctl(h, &st)) return rc;
+  if (st.phase != 1) return fail(CC_ERR_STATE, "cc_intrinsics_profile_kernel: run cc_intrinsics_solve first");
+  LmCtl run = st;
+  run.done = 0; run.step_valid = 1; run.cand_pending = 1; run.log_len = 1; run.iter = 1;
+  run.gmax = 1e30;
+  // keep every launch on the full path: tolerances off, the candidate looks like a clear improvement
+  run.x_cost = run.current_cost = run.reference_cost = run.candidate_cost = run.minimum_cost = 2.0 * st.x_cost + 1.0;
+  LmOpts lo = h->cached_opts;
+  lo.function_tolerance = lo.parameter_tolerance = lo.gradient_tolerance = -1.0;
+  lo.max_iterations = 1 << 30;
+  CC_HIP(hipMemcpy(h->d.opts, &lo, sizeof(lo), hipMemcpyHostToDevice));
+  h->opts_valid = false;  // the next solve uploads its own again
+  CC_HIP(hipMemcpyAsync(h->d.ctl, &run, sizeof(run), hipMemcpyHostToDevice, h->stream));
+  CC_HIP(hipMemcpyAsync(h->d.ctl_next, &run, sizeof(run), hipMemcpyHostToDevice, h->stream));
+  hipEvent_t e0, e1;
+  CC_HIP(hipEventCreate(&e0));
+  CC_HIP(hipEventCreate(&e1));
+  auto launch = [&]() {
+    if (which == 1) {
+      hipLaunchKernelGGL(k_intr_decide_elim<0>, dim3(h->elim_blocks), dim3(256), 0, h->stream, h->d);
+    } else {
+      hipLaunchKernelGGL(k_intr_solve<0>, dim3(1), dim3(kSolveThreads), 0, h->stream, h->d, h->elim_blocks);
+      hipMemcpyAsync(h->d.ctl_next, &run, sizeof(run), hipMemcpyHostToDevice, h->stream);
+    }
+  };
+  launch();
+  CC_HIP(hipEventRecord(e0, h->stream));
+  for (int i = 0; i < n; ++i) launch();
+  CC_HIP(hipEventRecord(e1, h->stream));
+  CC_HIP(hipGetLastError());
+  CC_HIP(hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  CC_HIP(hipEventElapsedTime(&ms, e0, e1));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  *avg_ms = (double)ms / n;
+  CC_HIP(hipMemcpy(h->d.ctl, &st, sizeof(st), hipMemcpyHostToDevice));
+  CC_HIP(hipMemcpy(h->d.ctl_next, &st, sizeof(st), hipMemcpyHostToDevice));
   return CC_OK;
 }
 
