@@ -609,37 +609,39 @@ __global__ __launch_bounds__(kSolveThreads) void k_intr_solve(IntrDev P, int nbl
   __shared__ double s_part[8][kPartialCols];
   const int tid = threadIdx.x;
   const LmCtl* cn = P.ctl_next;
+  if (MODE != 2) {
+    // thread -> (column, row group): all rows of the partials are fetched in one round trip, issued
+    // before anything is known about the control block (the buffer always exists)
+    const int col = tid % kPartialCols, grp = tid / kPartialCols;
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int b = grp + 8 * u;
+      v[u] = b < nblk ? P.partial[b * kPartialCols + col] : 0.0;
+    }
+    const bool act = !cn->done && cn->phase != 0;
+    double a = 0.0;
+    if (act) {
+      if (col == PC_GMAXP) a = fmax(fmax(fmax(v[0], v[1]), fmax(v[2], v[3])), fmax(fmax(v[4], v[5]), fmax(v[6], v[7])));
+      else a = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    s_part[grp][col] = a;
+    if (tid >= kPartialCols && tid < kVecSolve) sv[tid] = 0.0;  // rank slots; ours is written below
+  }
   const int done = cn->done, phase = cn->phase;
   const bool active = !done && phase != 0;
   if (MODE != 2) {
-    if (tid < kVecSolve) sv[tid] = 0.0;
     __syncthreads();
-    {
-      // thread -> (column, row group): all rows of the partials are fetched in one round trip
-      const int col = tid % kPartialCols, grp = tid / kPartialCols;
+    if (tid < kPartialCols) {
       double a = 0.0;
-      if (active) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int b = grp + 8 * u;
-          v[u] = b < nblk ? P.partial[b * kPartialCols + col] : 0.0;
-        }
-        if (col == PC_GMAXP) a = fmax(fmax(fmax(v[0], v[1]), fmax(v[2], v[3])), fmax(fmax(v[4], v[5]), fmax(v[6], v[7])));
-        else a = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-      }
-      s_part[grp][col] = a;
-    }
-    __syncthreads();
-    if (active && tid < kPartialCols) {
-      double a;
       if (tid == PC_GMAXP) {
-        a = 0.0;
-        for (int g2 = 0; g2 < 8; ++g2) a = fmax(a, s_part[g2][tid]);
+        if (active) for (int g2 = 0; g2 < 8; ++g2) a = fmax(a, s_part[g2][tid]);
         sv[kPartialCols + P.rank] = a;
+        sv[tid] = 0.0;
       } else {
-        a = ((s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid])) +
-            ((s_part[4][tid] + s_part[5][tid]) + (s_part[6][tid] + s_part[7][tid]));
+        if (active)
+          a = ((s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid])) +
+              ((s_part[4][tid] + s_part[5][tid]) + (s_part[6][tid] + s_part[7][tid]));
         sv[tid] = a;
       }
     }
@@ -812,9 +814,12 @@ static void launch_sweep(cc_intrinsics* h, bool profile) {
   hipLaunchKernelGGL(k_intr_sweep, dim3((unsigned)h->F), dim3(kSweepThreads), kSweepLdsBytes, h->stream, h->d);
 }
 
-// one triple: solve -> sweep -> decide+elim (the very first triple of a solve is the initial evaluation)
-static int enqueue_triple(cc_intrinsics* h, bool profile) {
-  if (h->comm) {
+// one triple: solve -> sweep -> decide+elim. The very first triple of a solve is the initial
+// evaluation: both control blocks are zero there and the solve step would only copy one onto the
+// other, so it (and its all-reduce) is left out.
+static int enqueue_triple(cc_intrinsics* h, bool profile, bool initial = false) {
+  if (initial) {
+  } else if (h->comm) {
     { Probe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_intr_solve<1>, dim3(1), dim3(kSolveThreads), 0, h->stream, h->d, h->elim_blocks); }
     { Probe p(h, CC_K_ALLREDUCE, profile); if (int rc = comm_allreduce_sum(h->comm, h->d.vec_solve, kVecSolve, h->stream)) return rc; }
     { Probe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_intr_solve<2>, dim3(1), dim3(kSolveThreads), 0, h->stream, h->d, h->elim_blocks); }
@@ -1080,7 +1085,7 @@ int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* sum
       hipGraph_t g = nullptr;
       CC_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
       const int n = o.check_interval + (gi == 0 ? 1 : 0);
-      for (int i = 0; i < n; ++i) enqueue_triple(h, false);
+      for (int i = 0; i < n; ++i) enqueue_triple(h, false, gi == 0 && i == 0);
       CC_HIP(hipStreamEndCapture(h->stream, &g));
       CC_HIP(hipGraphInstantiate(&h->graph[gi], g, nullptr, nullptr, 0));
       hipGraphDestroy(g);
@@ -1097,7 +1102,7 @@ int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* sum
       CC_HIP(hipGraphLaunch(h->graph[chunk == 0 ? 0 : 1], h->stream));
     } else {
       for (int i = 0; i < n; ++i)
-        if (int rc = enqueue_triple(h, profile)) return rc;
+        if (int rc = enqueue_triple(h, profile, chunk == 0 && i == 0)) return rc;
       CC_HIP(hipGetLastError());
     }
     launched += n;
