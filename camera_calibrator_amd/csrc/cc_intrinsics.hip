@@ -345,24 +345,29 @@ __device__ __forceinline__ void reduce_frame_stats(const IntrDev& P, bool want_s
   // combine the 16 row groups of a wave that share a column (lane bits 2..5)
 #pragma unroll
   for (int o = 4; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
-  double h = 0.0;
+  // hd0 (initial round only): thread t -> column pair t & 7 (16-byte loads), row group t >> 3 of 32;
+  // 16 loads in flight per thread, one round trip per 512 frames
+  double h0 = 0.0, h1 = 0.0;
   if (want_hd) {
-    // hd0: thread t -> column t & 15, row group t >> 4 (16 groups)
-    const int col = tid & 15;
-    for (int64_t fb = tid >> 4; fb < P.F; fb += 8 * 16) {
-      double v[8];
+    const int cp = tid & 7;
+    const d2* hd2 = reinterpret_cast<const d2*>(P.hd0);
+    for (int64_t fb = tid >> 3; fb < P.F; fb += 16 * 32) {
+      d2 v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int64_t f = fb + u * 16;
-        v[u] = f < P.F ? P.hd0[f * 16 + col] : 0.0;
+      for (int u = 0; u < 16; ++u) {
+        const int64_t f = fb + u * 32;
+        v[u] = f < P.F ? hd2[f * 8 + cp] : d2{0.0, 0.0};
       }
-      h += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      h0 += (((v[0].x + v[1].x) + (v[2].x + v[3].x)) + ((v[4].x + v[5].x) + (v[6].x + v[7].x))) +
+            (((v[8].x + v[9].x) + (v[10].x + v[11].x)) + ((v[12].x + v[13].x) + (v[14].x + v[15].x)));
+      h1 += (((v[0].y + v[1].y) + (v[2].y + v[3].y)) + ((v[4].y + v[5].y) + (v[6].y + v[7].y))) +
+            (((v[8].y + v[9].y) + (v[10].y + v[11].y)) + ((v[12].y + v[13].y) + (v[14].y + v[15].y)));
     }
   }
 #pragma unroll
-  for (int o = 16; o < 64; o <<= 1) h += __shfl_xor(h, o, 64);
+  for (int o = 8; o < 64; o <<= 1) { h0 += __shfl_xor(h0, o, 64); h1 += __shfl_xor(h1, o, 64); }
   if (lane < 4) s_w[wave * 16 + lane] = a;
-  if (lane < 9) s_w[64 + wave * 16 + lane] = h;
+  if (lane < 8) { s_w[64 + wave * 16 + 2 * lane] = h0; s_w[64 + wave * 16 + 2 * lane + 1] = h1; }
   __syncthreads();
   if (tid < 4) out[tid] = (s_w[tid] + s_w[16 + tid]) + (s_w[32 + tid] + s_w[48 + tid]);
   else if (tid >= 4 && tid < 13) {
