@@ -61,6 +61,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "CC_BENCH_DEVICE" in os.environ:   # rehearsal on a one-GPU box: every rank on the same device
+        local_rank = int(os.environ["CC_BENCH_DEVICE"])
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
@@ -93,12 +95,59 @@ def main():
     f0, f1 = int(first[rank]), int(first[rank + 1])
     o0, o1 = int(off[f0]), int(off[f1])
     my_off = off[f0:f1 + 1] - off[f0]
-    prob = capi.IntrinsicsProblem(my_off, uv[o0:o1], xyz[o0:o1], device=local_rank)
-    prob.set_state(intr0, q0[f0:f1], t0[f0:f1])
+    def make_problem():
+        p = capi.IntrinsicsProblem(my_off, uv[o0:o1], xyz[o0:o1], device=local_rank)
+        p.set_state(intr0, q0[f0:f1], t0[f0:f1])
+        return p
+
+    def all_ok(flag):
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(flag))
+        return all(flags)
+
+    prob = make_problem()
+    exchange = "none"
     if world > 1:
-        uid = [capi.comm_get_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        prob.comm_init(uid[0], rank, world)
+        # The two per-iteration reductions are <= 1 KB: within a node they go through mailboxes in peer
+        # HBM (cc_intrinsics_exchange_*, stores over xGMI, graph-captured); RCCL all-reduce is the
+        # fallback (and the only choice beyond 8 ranks). CC_EXCHANGE=mailbox|rccl forces one.
+        want = os.environ.get("CC_EXCHANGE", "auto")
+        if want in ("auto", "mailbox") and world <= 8:
+            try:
+                mine = (True, prob.exchange_export())
+            except capi.CcError as e:
+                mine = (False, str(e).encode())
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine)
+            ok = all(g[0] for g in gathered)
+            if ok:
+                try:
+                    prob.exchange_attach(rank, [g[1] for g in gathered])
+                except capi.CcError as e:
+                    ok = False
+                    print(f"[bench rank {rank}] mailbox attach failed: {e}", file=sys.stderr)
+            ok = all_ok(ok)
+            if ok:
+                try:  # one complete solve proves that every peer's posts arrive
+                    prob.reset()
+                    prob.solve(capi.default_options(), log_capacity=0)
+                except capi.CcError as e:
+                    ok = False
+                    print(f"[bench rank {rank}] mailbox exchange failed: {e}", file=sys.stderr)
+                ok = all_ok(ok)
+            if ok:
+                exchange = "mailbox"
+            elif want == "mailbox":
+                raise SystemExit("CC_EXCHANGE=mailbox but the mailbox exchange is not usable here")
+            else:
+                dist.barrier()
+                prob.close()
+                prob = make_problem()
+        if exchange == "none":
+            uid = [capi.comm_get_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            prob.comm_init(uid[0], rank, world)
+            exchange = "rccl"
 
     n_obs_total = int(off[-1])
     opts = capi.default_options()
@@ -174,7 +223,7 @@ def main():
                             f"{args.points} pts per GPU, radial-tangential distortion, Zhang init, "
                             f"reference solver options (calibrator.cpp:314-321)",
                 "frames_total": F_total, "points_per_frame": args.points,
-                "observations_total": n_obs_total, "parallelism": f"frame-sharded x{world}",
+                "observations_total": n_obs_total, "parallelism": f"frame-sharded x{world}", "exchange": exchange,
             },
             "lm_iterations_per_sec": it_per_s,
             "solves_in_timed_region": solves,
@@ -227,6 +276,8 @@ def main():
                               "value": 2.0 * n_obs_total * sm["iterations"] / sm["seconds"]},
             }
             result["speedup_vs_cpu_1thread"] = res_per_s / cpu_res
+    if dist is not None:
+        dist.barrier()          # no rank frees a mailbox / communicator a peer may still use
     prob.close()
     if dist is not None:
         dist.barrier()

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("CC_LIB_PATH", os.path.join(_HERE, "libcc_hip.so"))
 
 K_NAMES = ["sweep", "decide", "elim", "solve", "allreduce"]
 TERMINATION = {0: "NO_CONVERGENCE", 1: "GRADIENT", 2: "PARAMETER", 3: "FUNCTION",
-               4: "FAILURE_INVALID_STEPS", 5: "MIN_RADIUS"}
+               4: "FAILURE_INVALID_STEPS", 5: "MIN_RADIUS", 6: "FAILURE_EXCHANGE"}
 
 
 class CcError(RuntimeError):
@@ -79,7 +79,7 @@ EXPORTED_SYMBOLS = [
     "cc_intrinsics_create", "cc_intrinsics_destroy", "cc_intrinsics_set_state",
     "cc_intrinsics_reset", "cc_intrinsics_get_state", "cc_intrinsics_eval",
     "cc_intrinsics_solve", "cc_intrinsics_profile_sweep", "cc_intrinsics_optimize", "cc_comm_get_unique_id",
-    "cc_intrinsics_comm_init", "cc_partition_frames", "cc_distort", "cc_undistort",
+    "cc_intrinsics_comm_init", "cc_intrinsics_exchange_export", "cc_intrinsics_exchange_attach", "cc_partition_frames", "cc_distort", "cc_undistort",
     "cc_rig_create", "cc_rig_destroy", "cc_rig_set_state", "cc_rig_reset", "cc_rig_solve",
     "cc_rig_get_state", "cc_rig_eval", "cc_rig_optimize", "cc_rig_comm_init", "cc_zhang_init",
 ]
@@ -225,6 +225,19 @@ class IntrinsicsProblem:
     def comm_init(self, unique_id, rank, nranks):
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
         _check(lib().cc_intrinsics_comm_init(self._h, buf, C.c_int32(rank), C.c_int32(nranks)))
+
+    def exchange_export(self):
+        """Allocate this rank's mailbox; returns the 64-byte IPC handle to all-gather."""
+        buf = (C.c_uint8 * 64)()
+        _check(lib().cc_intrinsics_exchange_export(self._h, buf))
+        return bytes(buf)
+
+    def exchange_attach(self, rank, handles):
+        """handles: every rank's 64-byte handle, in rank order."""
+        blob = b"".join(bytes(x) for x in handles)
+        assert len(blob) == 64 * len(handles)
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+        _check(lib().cc_intrinsics_exchange_attach(self._h, C.c_int32(rank), C.c_int32(len(handles)), buf))
 
 
 def comm_get_unique_id():

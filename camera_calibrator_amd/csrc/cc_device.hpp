@@ -57,4 +57,76 @@ __device__ __forceinline__ void gram_rows(const double* stage, int lane, d4& acc
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// Mailbox exchange between the ranks of one node (one process per GPU). Every rank owns a mailbox in
+// its own HBM (uncached, exported with hipIpcGetMemHandle); peers map it and STORE their partial
+// sums into it over xGMI, then raise a flag; the owner only ever reads local memory. This replaces
+// a library all-reduce for the two tiny (<= 1 KB) latency-bound reductions of an LM iteration and
+// keeps the whole iteration inside one captured graph.
+//   slot(kind, parity, rank): 128 doubles = 127 payload + 1 flag word holding the epoch
+//   kind 0: elimination sums (solve), kind 1: sweep statistics (decide); parity = epoch & 1
+// A rank posts epoch e+2 of a kind only after it finished e+1, which needs every peer's e+1 post,
+// which a peer makes only after it has read all of epoch e: two parities are enough.
+// ---------------------------------------------------------------------------------------------
+constexpr int kP2pMaxRanks = 8;
+constexpr int kP2pSlot = 128;
+constexpr int kP2pFlag = 127;
+constexpr int kP2pDoubles = 2 * 2 * kP2pMaxRanks * kP2pSlot;
+constexpr long long kP2pTimeoutTicks = 200000000LL;  // 2 s of the 100 MHz wall clock
+
+struct P2pDev {
+  double* box[kP2pMaxRanks];   // box[r]: rank r's mailbox as mapped here (box[rank] is local)
+  unsigned long long* seq;     // [2] last completed epoch per kind (device memory of this rank)
+  int32_t on;
+  int32_t pad;
+};
+
+__device__ __forceinline__ int p2p_slot(int kind, unsigned long long epoch, int rank) {
+  return ((kind * 2 + (int)(epoch & 1ull)) * kP2pMaxRanks + rank) * kP2pSlot;
+}
+
+// all threads of the block call; src (LDS or registers spilled to LDS) holds n <= 127 doubles
+__device__ inline void p2p_post(const P2pDev& X, int kind, unsigned long long epoch, int rank, int nranks,
+                                const double* src, int n) {
+  const int off = p2p_slot(kind, epoch, rank);
+  for (int idx = threadIdx.x; idx < n * nranks; idx += blockDim.x) {
+    const int r = idx / n, i = idx - r * n;
+    __hip_atomic_store(X.box[r] + off + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __threadfence_system();
+  __syncthreads();
+  if ((int)threadIdx.x < nranks)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(X.box[threadIdx.x] + off + kP2pFlag), epoch,
+                       __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// all threads of the block call; returns false when a peer did not show up in time (s_ok: one LDS int)
+__device__ inline bool p2p_wait(const P2pDev& X, int kind, unsigned long long epoch, int rank, int nranks, int* s_ok) {
+  if (threadIdx.x == 0) *s_ok = 1;
+  __syncthreads();
+  if ((int)threadIdx.x < nranks) {
+    const unsigned long long* flag =
+        reinterpret_cast<const unsigned long long*>(X.box[rank] + p2p_slot(kind, epoch, threadIdx.x) + kP2pFlag);
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
+      if (wall_clock64() - t0 > kP2pTimeoutTicks) { *s_ok = 0; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+  return *s_ok != 0;
+}
+
+// payload word i of every rank's slot, summed in rank order (identical on all ranks)
+__device__ __forceinline__ double p2p_sum(const P2pDev& X, int kind, unsigned long long epoch, int rank, int nranks, int i) {
+  double v[kP2pMaxRanks];
+#pragma unroll
+  for (int r = 0; r < kP2pMaxRanks; ++r)
+    v[r] = r < nranks ? __hip_atomic_load(X.box[rank] + p2p_slot(kind, epoch, r) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
+  double a = v[0];
+#pragma unroll
+  for (int r = 1; r < kP2pMaxRanks; ++r) a += v[r];
+  return a;
+}
+
 }  // namespace cc

@@ -68,6 +68,7 @@ struct IntrDev {
   int32_t log_cap;
   uint32_t mask;
   int32_t rank, nranks;
+  P2pDev x;           // mailbox exchange (cc_device.hpp); x.on == 0 on a single GPU / with RCCL
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -377,7 +378,9 @@ __device__ __forceinline__ void reduce_frame_stats(const IntrDev& P, bool want_s
   __syncthreads();
 }
 
-// multi-GPU only: local reduction -> vec_decide, which is then all-reduced
+// multi-GPU only: local reduction -> vec_decide (then all-reduced by RCCL), or, with the mailbox
+// exchange, posted straight into every rank's mailbox (kind 1); decide_elim<3> waits for it.
+template <bool P2P>
 __global__ __launch_bounds__(256) void k_intr_stats_reduce(IntrDev P) {
   __shared__ double s_w[128];
   __shared__ double s_out[16];
@@ -386,7 +389,16 @@ __global__ __launch_bounds__(256) void k_intr_stats_reduce(IntrDev P) {
   const int phase = ctl->phase;
   const bool need = phase == 0 || (ctl->cand_pending && ctl->step_valid);
   reduce_frame_stats(P, need, phase == 0, s_w, s_out);
-  if (threadIdx.x < 16) P.vec_decide[threadIdx.x] = (need && threadIdx.x < 13) ? s_out[threadIdx.x] : 0.0;
+  if (P2P) {
+    if (!need) return;
+    if (threadIdx.x >= 13 && threadIdx.x < 16) s_out[threadIdx.x] = 0.0;
+    __syncthreads();
+    const unsigned long long epoch = P.x.seq[1] + 1ull;
+    p2p_post(P.x, 1, epoch, P.rank, P.nranks, s_out, 16);
+    if (threadIdx.x == 0) P.x.seq[1] = epoch;
+  } else {
+    if (threadIdx.x < 16) P.vec_decide[threadIdx.x] = (need && threadIdx.x < 13) ? s_out[threadIdx.x] : 0.0;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -396,7 +408,8 @@ __global__ __launch_bounds__(256) void k_intr_stats_reduce(IntrDev P) {
 // Output row per block (80 columns): [0..44] upper triangle of the reduced 9x9 system (row-major
 // pairs j<=k), [45..53] reduced rhs, [54..62] diag of the scaled H_ss, [63] Cholesky failures,
 // [64..72] unscaled shared gradient, [73] max |pose gradient| (max-combined), rest 0.
-// MODE 0: reduce stats inline (single GPU); MODE 2: stats come all-reduced in vec_decide.
+// MODE 0: reduce stats inline (single GPU); MODE 2: stats come all-reduced in vec_decide;
+// MODE 3: stats are summed from the mailbox slots the ranks posted (kind 1).
 // ---------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P) {
@@ -416,8 +429,19 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P) {
 #if CC_ABLATE_D == 1
   if (ctl->gmax == 1e30) return;  // marker set by cc_intrinsics_profile_kernel
 #endif
+  bool exchange_ok = true;
   if (MODE == 0) {
     reduce_frame_stats(P, need, phase == 0, s_w, s_tot);
+  } else if (MODE == 3) {
+    __shared__ int s_ok;
+    if (need) {
+      const unsigned long long epoch = P.x.seq[1];  // bumped by k_intr_stats_reduce<true> of this round
+      exchange_ok = p2p_wait(P.x, 1, epoch, P.rank, P.nranks, &s_ok);
+      if (tid < 16) s_tot[tid] = exchange_ok ? p2p_sum(P.x, 1, epoch, P.rank, P.nranks, tid) : 0.0;
+    } else if (tid < 16) {
+      s_tot[tid] = 0.0;
+    }
+    __syncthreads();
   } else {
     if (tid < 16) s_tot[tid] = P.vec_decide[tid];
     __syncthreads();
@@ -445,6 +469,7 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P) {
       }
       lm_decide(c, o, log, P.log_cap, s_tot[ST_COST], s_tot[ST_QMODEL], step2, xn2);
     }
+    if (!exchange_ok) { c.done = 1; c.term = CC_FAILURE_EXCHANGE; }
     s_ctl = c;
     if (blockIdx.x == 0) *P.ctl_next = c;
   }
@@ -603,7 +628,8 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P) {
 // ---------------------------------------------------------------------------------------------
 // solve (one block): reduce the elimination partials, add the LM diagonal, 9x9 Cholesky in
 // registers, gradient-tolerance test of the accepted point; publishes the control block for the
-// sweep. MODE 0: reduce + solve; 1: reduce only (-> vec_solve, then all-reduced); 2: solve only.
+// sweep. MODE 0: reduce + solve; 1: reduce only (-> vec_solve, then all-reduced); 2: solve only;
+// 3: reduce + mailbox exchange with the other ranks + solve.
 // vec_solve: [0..79] column sums (col 73 unused), [80 + rank] this rank's max |pose gradient|.
 // ---------------------------------------------------------------------------------------------
 constexpr int kSolveThreads = 8 * kPartialCols;
@@ -614,6 +640,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_intr_solve(IntrDev P, int nbl
   __shared__ double s_part[8][kPartialCols];
   const int tid = threadIdx.x;
   const LmCtl* cn = P.ctl_next;
+  bool exchange_ok = true;
   if (MODE != 2) {
     // thread -> (column, row group): all rows of the partials are fetched in one round trip, issued
     // before anything is known about the control block (the buffer always exists)
@@ -655,13 +682,28 @@ __global__ __launch_bounds__(kSolveThreads) void k_intr_solve(IntrDev P, int nbl
       if (tid < kVecSolve) P.vec_solve[tid] = sv[tid];
       return;
     }
+    if (MODE == 3 && active) {
+      // mailbox all-reduce of the 112 sums (kind 0): post, wait for every rank, add in rank order
+      __shared__ int s_ok;
+      const unsigned long long epoch = P.x.seq[0] + 1ull;
+      p2p_post(P.x, 0, epoch, P.rank, P.nranks, sv, kVecSolve);
+      exchange_ok = p2p_wait(P.x, 0, epoch, P.rank, P.nranks, &s_ok);
+      const double a = (exchange_ok && tid < kVecSolve) ? p2p_sum(P.x, 0, epoch, P.rank, P.nranks, tid) : 0.0;
+      __syncthreads();
+      if (tid < kVecSolve) sv[tid] = a;
+      if (tid == 0) P.x.seq[0] = epoch;
+      __syncthreads();
+    }
   } else {
     if (tid < kVecSolve) sv[tid] = P.vec_solve[tid];
     __syncthreads();
   }
   if (tid != 0) return;
   LmCtl c = *cn;
-  if (active) {
+  if (!exchange_ok) {
+    c.done = 1;
+    c.term = CC_FAILURE_EXCHANGE;
+  } else if (active) {
     const LmOpts o = *P.opts;
     const double* V = sv;
     // gradient of the accepted point: max-norm over the tangent coordinates
@@ -793,6 +835,10 @@ struct cc_intrinsics {
   hipGraphExec_t graph[2] = {nullptr, nullptr};  // [0]: 1 + check_interval triples, [1]: check_interval triples
   int graph_iters = 0;
   cc::Comm* comm = nullptr;
+  // mailbox exchange (cc_intrinsics_exchange_export / _attach): our mailbox and the peers' mappings
+  double* box_local = nullptr;
+  double* box_peer[cc::kP2pMaxRanks] = {};
+  bool exchange = false;
   std::vector<hipEvent_t> events;
   std::vector<int> event_kind;
 };
@@ -802,6 +848,15 @@ namespace cc {
 static void drop_graphs(cc_intrinsics* h) {
   for (auto& g : h->graph)
     if (g) { hipGraphExecDestroy(g); g = nullptr; }
+}
+
+static void exchange_release(cc_intrinsics* h) {
+  for (int r = 0; r < kP2pMaxRanks; ++r)
+    if (h->box_peer[r] && h->box_peer[r] != h->box_local) { hipIpcCloseMemHandle(h->box_peer[r]); h->box_peer[r] = nullptr; }
+  if (h->box_local) { hipFree(h->box_local); h->box_local = nullptr; }
+  if (h->d.x.seq) { hipFree(h->d.x.seq); }
+  h->d.x = P2pDev{};
+  h->exchange = false;
 }
 
 struct Probe {  // optional hipEvent bracket around one launch
@@ -823,6 +878,14 @@ static void launch_sweep(cc_intrinsics* h, bool profile) {
 // evaluation: both control blocks are zero there and the solve step would only copy one onto the
 // other, so it (and its all-reduce) is left out.
 static int enqueue_triple(cc_intrinsics* h, bool profile, bool initial = false) {
+  if (h->exchange) {
+    // mailbox exchange inside the kernels: no library call, so the chain stays graph-capturable
+    if (!initial) { Probe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_intr_solve<3>, dim3(1), dim3(kSolveThreads), 0, h->stream, h->d, h->elim_blocks); }
+    launch_sweep(h, profile);
+    { Probe p(h, CC_K_DECIDE, profile); hipLaunchKernelGGL(k_intr_stats_reduce<true>, dim3(1), dim3(256), 0, h->stream, h->d); }
+    { Probe p(h, CC_K_ELIM, profile); hipLaunchKernelGGL(k_intr_decide_elim<3>, dim3(h->elim_blocks), dim3(256), 0, h->stream, h->d); }
+    return 0;
+  }
   if (initial) {
   } else if (h->comm) {
     { Probe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_intr_solve<1>, dim3(1), dim3(kSolveThreads), 0, h->stream, h->d, h->elim_blocks); }
@@ -834,7 +897,7 @@ static int enqueue_triple(cc_intrinsics* h, bool profile, bool initial = false) 
   }
   launch_sweep(h, profile);
   if (h->comm) {
-    { Probe p(h, CC_K_DECIDE, profile); hipLaunchKernelGGL(k_intr_stats_reduce, dim3(1), dim3(256), 0, h->stream, h->d); }
+    { Probe p(h, CC_K_DECIDE, profile); hipLaunchKernelGGL(k_intr_stats_reduce<false>, dim3(1), dim3(256), 0, h->stream, h->d); }
     { Probe p(h, CC_K_ALLREDUCE, profile); if (int rc = comm_allreduce_sum(h->comm, h->d.vec_decide, 16, h->stream)) return rc; }
     { Probe p(h, CC_K_ELIM, profile); hipLaunchKernelGGL(k_intr_decide_elim<2>, dim3(h->elim_blocks), dim3(256), 0, h->stream, h->d); }
   } else {
@@ -885,6 +948,55 @@ int cc_intrinsics_create(int32_t device, int64_t F, const int64_t* off, const fl
     return rc_init;
   }
   *out = h;
+  return CC_OK;
+}
+
+int cc_intrinsics_exchange_export(cc_intrinsics* h, uint8_t handle[64]) {
+  using namespace cc;
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size is part of the C ABI");
+  if (!h || !handle) return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_exchange_export: NULL argument");
+  CC_HIP(hipSetDevice(h->device));
+  CC_HIP(hipStreamSynchronize(h->stream));
+  drop_graphs(h);
+  exchange_release(h);
+  CC_HIP(hipExtMallocWithFlags((void**)&h->box_local, kP2pDoubles * sizeof(double), hipDeviceMallocUncached));
+  CC_HIP(hipMemset(h->box_local, 0, kP2pDoubles * sizeof(double)));
+  CC_HIP(hipMalloc(&h->d.x.seq, 2 * sizeof(unsigned long long)));
+  CC_HIP(hipMemset(h->d.x.seq, 0, 2 * sizeof(unsigned long long)));
+  CC_HIP(hipDeviceSynchronize());
+  hipIpcMemHandle_t hnd;
+  CC_HIP(hipIpcGetMemHandle(&hnd, h->box_local));
+  std::memcpy(handle, &hnd, 64);
+  return CC_OK;
+}
+
+int cc_intrinsics_exchange_attach(cc_intrinsics* h, int32_t rank, int32_t nranks, const uint8_t* handles) {
+  using namespace cc;
+  if (!h || !handles || rank < 0 || nranks < 1 || rank >= nranks || nranks > kP2pMaxRanks)
+    return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_exchange_attach: bad arguments (nranks must be 1..%d)", kP2pMaxRanks);
+  if (!h->box_local) return fail(CC_ERR_STATE, "cc_intrinsics_exchange_attach: call cc_intrinsics_exchange_export first");
+  if (h->comm) return fail(CC_ERR_STATE, "cc_intrinsics_exchange_attach: an RCCL communicator is already attached");
+  CC_HIP(hipSetDevice(h->device));
+  drop_graphs(h);
+  for (int r = 0; r < nranks; ++r) {
+    if (r == rank) { h->box_peer[r] = h->box_local; continue; }
+    hipIpcMemHandle_t hnd;
+    std::memcpy(&hnd, handles + (size_t)r * 64, 64);
+    void* p = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&p, hnd, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      for (int q = 0; q < r; ++q)
+        if (q != rank && h->box_peer[q]) { hipIpcCloseMemHandle(h->box_peer[q]); h->box_peer[q] = nullptr; }
+      return fail(CC_ERR_COMM, "hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e));
+    }
+    h->box_peer[r] = static_cast<double*>(p);
+  }
+  for (int r = 0; r < kP2pMaxRanks; ++r) h->d.x.box[r] = r < nranks ? h->box_peer[r] : nullptr;
+  h->d.x.on = 1;
+  h->d.rank = rank;
+  h->d.nranks = nranks;
+  h->exchange = true;
   return CC_OK;
 }
 
@@ -955,6 +1067,7 @@ void cc_intrinsics_destroy(cc_intrinsics* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   cc::drop_graphs(h);
   if (h->comm) cc::comm_destroy(h->comm);
+  cc::exchange_release(h);
   cc::IntrDev& d = h->d;
   hipFree((void*)d.uv); hipFree((void*)d.xyz); hipFree((void*)d.off);
   hipFree(d.intr); hipFree(d.pose); hipFree(d.blocks); hipFree(d.stats); hipFree(d.hd0); hipFree(d.sp);
@@ -1112,6 +1225,8 @@ int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* sum
     }
     launched += n;
     if (int rc = read_ctl(h, &st)) return rc;
+    if (st.done && st.term == CC_FAILURE_EXCHANGE)
+      return fail(CC_ERR_COMM, "mailbox exchange timed out: a peer rank did not post within 2 s (iteration %d)", st.iter);
     if (st.done) break;
     if (launched > o.max_iterations + 2 * o.check_interval + 2)
       return fail(CC_ERR_STATE, "LM loop did not terminate (iter=%d)", st.iter);

@@ -41,7 +41,8 @@ enum {
   CC_CONVERGENCE_PARAMETER = 2,
   CC_CONVERGENCE_FUNCTION = 3,
   CC_FAILURE_INVALID_STEPS = 4,
-  CC_MIN_RADIUS = 5
+  CC_MIN_RADIUS = 5,
+  CC_FAILURE_EXCHANGE = 6      /* multi-GPU mailbox exchange timed out (solve returns CC_ERR_COMM) */
 };
 
 /* Solver options.  cc_options_init() sets the Ceres 2.x defaults overlaid with what the
@@ -149,6 +150,19 @@ int cc_intrinsics_optimize(const cc_options* opt, int32_t device, int64_t n_fram
  * reduced shared-parameter blocks (64 doubles after elimination, 64 after the sweep). */
 int cc_comm_get_unique_id(uint8_t id[128]);
 int cc_intrinsics_comm_init(cc_intrinsics* h, const uint8_t id[128], int32_t rank, int32_t nranks);
+
+/* Multi-GPU within one node, without a collective library in the loop (preferred for <= 8 ranks):
+ * the two reductions of an iteration are <= 1 KB and purely latency-bound, so every rank STORES its
+ * partial sums straight into a mailbox in each peer's HBM over xGMI and the consumer kernels wait
+ * on flags in their own memory (cc_device.hpp). The iteration stays three/four kernels inside one
+ * captured graph. Protocol: every rank calls _export (allocates the mailbox, returns its 64-byte
+ * hipIpcMemHandle), the caller all-gathers the handles over its control plane (rank order), every
+ * rank calls _attach with all nranks*64 bytes. All ranks must then call cc_intrinsics_solve /
+ * cc_intrinsics_reset the same number of times with the same options. A peer that does not show
+ * up within 2 s makes the solve return CC_ERR_COMM (termination CC_FAILURE_EXCHANGE) instead of
+ * hanging. Keep the handle alive until every rank has finished its last solve. */
+int cc_intrinsics_exchange_export(cc_intrinsics* h, uint8_t handle[64]);
+int cc_intrinsics_exchange_attach(cc_intrinsics* h, int32_t rank, int32_t nranks, const uint8_t* handles);
 
 /* Contiguous frame partition balanced by observation count (host logic, no GPU needed).
  * first_frame has nranks+1 entries; rank r owns frames [first_frame[r], first_frame[r+1]). */

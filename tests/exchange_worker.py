@@ -1,0 +1,54 @@
+"""One rank of a multi-process run of the mailbox exchange (started by test_gpu_exchange.py; not a test
+module). All ranks share GPU 0 on the one-GPU test box: the exchange only needs IPC-mapped device memory
+and concurrently running kernels, which processes sharing a GPU also provide."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    rank, world, port, frames, pts, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    from camera_calibrator_amd import capi
+
+    off, uv, xyz = capi.make_intrinsics_problem(frames, pts)
+    K0, q0, t0 = capi.zhang_init(off, uv, xyz)
+    intr0 = np.array([K0[0, 0], K0[1, 1], K0[0, 2], K0[1, 2], 0, 0, 0, 0, 0], dtype=np.float64)
+    q0, t0 = q0.astype(np.float64), t0.astype(np.float64)
+    first = capi.partition_frames(off, world)
+    f0, f1 = int(first[rank]), int(first[rank + 1])
+    o0, o1 = int(off[f0]), int(off[f1])
+    prob = capi.IntrinsicsProblem(off[f0:f1 + 1] - off[f0], uv[o0:o1], xyz[o0:o1])
+    prob.set_state(intr0, q0[f0:f1], t0[f0:f1])
+    handles = [None] * world
+    dist.all_gather_object(handles, prob.exchange_export())
+    prob.exchange_attach(rank, handles)
+    res = {}
+    for name, kw in (("default", {}), ("nograph", dict(use_graph=0)),
+                     ("tight", dict(function_tolerance=1e-15, gradient_tolerance=1e-13, parameter_tolerance=1e-14, max_iterations=40))):
+        prob.reset()
+        s = prob.solve(capi.default_options(**kw))
+        intr, q, t = prob.get_state()
+        res[name + "_intr"] = intr
+        res[name + "_q"] = q
+        res[name + "_t"] = t
+        res[name + "_cost"] = np.array([l["cost"] for l in s["log"]])
+        res[name + "_acc"] = np.array([l["accepted"] for l in s["log"]])
+        res[name + "_term"] = np.array([s["termination_code"] if "termination_code" in s else -1, s["iterations"]])
+        res[name + "_termname"] = np.array(s["termination"])
+    dist.barrier()            # nobody frees a mailbox a peer may still be writing to
+    prob.close()
+    np.savez(out, f0=f0, f1=f1, **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,105 @@
+"""The multi-GPU mailbox exchange (cc_intrinsics_exchange_*), exercised with several processes that share
+the test box's single GPU: same kernels, same IPC mapping, same flags as across xGMI. Every rank must
+reach bit-identical shared intrinsics, and the sharded solution must match the single-process HIP solve
+(costs 1e-9 relative, identical accept sequence)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from camera_calibrator_amd import capi
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_ranks(world, frames, pts, tmp_path):
+    port = _free_port()
+    procs, outs = [], []
+    for r in range(world):
+        out = str(tmp_path / f"rank{r}.npz")
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "exchange_worker.py"), str(r), str(world),
+                                       str(port), str(frames), str(pts), out],
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=240)
+            logs.append(o)
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        raise
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"
+    return [np.load(o) for o in outs]
+
+
+@pytest.mark.parametrize("world,frames,pts", [(2, 40, 60), (3, 50, 33), (4, 128, 100)])
+def test_sharded_solve_over_the_mailbox_exchange(world, frames, pts, tmp_path):
+    ranks = _run_ranks(world, frames, pts, tmp_path)
+    off, uv, xyz = capi.make_intrinsics_problem(frames, pts)
+    K0, q0, t0 = capi.zhang_init(off, uv, xyz)
+    intr0 = np.array([K0[0, 0], K0[1, 1], K0[0, 2], K0[1, 2], 0, 0, 0, 0, 0], dtype=np.float64)
+    for name, kw in (("default", {}), ("nograph", dict(use_graph=0)),
+                     ("tight", dict(function_tolerance=1e-15, gradient_tolerance=1e-13, parameter_tolerance=1e-14, max_iterations=40))):
+        ref = capi.intrinsics_optimize(off, uv, xyz, intr0, q0.astype(np.float64), t0.astype(np.float64),
+                                       options=capi.default_options(**kw))
+        for r in ranks:
+            assert np.array_equal(r[name + "_intr"], ranks[0][name + "_intr"])            # every rank: same bits
+            assert np.array_equal(r[name + "_cost"], ranks[0][name + "_cost"])
+            f0, f1 = int(r["f0"]), int(r["f1"])
+            # a different summation order (per-rank partial sums): fx fy px py to 1e-9 relative, the
+            # weakly determined distortion coefficients and the poses to 1e-8 absolute
+            assert np.allclose(r[name + "_intr"][:4], ref[0][:4], rtol=1e-9)
+            assert np.allclose(r[name + "_intr"][4:], ref[0][4:], atol=1e-8)
+            assert np.allclose(r[name + "_q"], ref[1][f0:f1], atol=1e-8)
+            assert np.allclose(r[name + "_t"], ref[2][f0:f1], atol=1e-8)
+            if name == "tight":
+                # at the rounding floor the last iterations (and the reason for stopping) are noise
+                assert np.isclose(r[name + "_cost"][-1], ref[3]["final_cost"], rtol=1e-12)
+                continue
+            assert str(r[name + "_termname"]) == ref[3]["termination"], (name, str(r[name + "_termname"]))
+            assert int(r[name + "_term"][1]) == ref[3]["iterations"]
+            assert list(r[name + "_acc"]) == [l["accepted"] for l in ref[3]["log"]]
+            assert np.allclose(r[name + "_cost"], [l["cost"] for l in ref[3]["log"]], rtol=1e-9)
+        assert np.array_equal(ranks[0]["default_intr"], ranks[0]["nograph_intr"])         # graph replay == plain launches
+
+
+def test_exchange_argument_checks():
+    off, uv, xyz = capi.make_intrinsics_problem(4, 10)
+    p = capi.IntrinsicsProblem(off, uv, xyz)
+    with pytest.raises(capi.CcError, match="export first"):
+        p.exchange_attach(0, [b"\0" * 64])
+    h = p.exchange_export()
+    assert len(h) == 64
+    with pytest.raises(capi.CcError, match="bad arguments"):
+        p.exchange_attach(0, [h] * 9)
+    p.exchange_attach(0, [h])                      # a single rank is a valid (degenerate) exchange
+    p.close()
+
+
+def test_single_rank_exchange_equals_plain_solve():
+    off, uv, xyz = capi.make_intrinsics_problem(20, 50)
+    K0, q0, t0 = capi.zhang_init(off, uv, xyz)
+    intr0 = np.array([K0[0, 0], K0[1, 1], K0[0, 2], K0[1, 2], 0, 0, 0, 0, 0], dtype=np.float64)
+    ref = capi.intrinsics_optimize(off, uv, xyz, intr0, q0.astype(np.float64), t0.astype(np.float64))
+    p = capi.IntrinsicsProblem(off, uv, xyz)
+    p.set_state(intr0, q0.astype(np.float64), t0.astype(np.float64))
+    p.exchange_attach(0, [p.exchange_export()])
+    s = p.solve()
+    intr, _, _ = p.get_state()
+    p.close()
+    assert s["iterations"] == ref[3]["iterations"] and s["termination"] == ref[3]["termination"]
+    assert np.allclose(intr, ref[0], rtol=1e-12, atol=1e-14)
