@@ -60,72 +60,85 @@ __device__ __forceinline__ void gram_rows(const double* stage, int lane, d4& acc
 // ---------------------------------------------------------------------------------------------
 // Mailbox exchange between the ranks of one node (one process per GPU). Every rank owns a mailbox in
 // its own HBM (uncached, exported with hipIpcGetMemHandle); peers map it and STORE their partial
-// sums into it over xGMI, then raise a flag; the owner only ever reads local memory. This replaces
-// a library all-reduce for the two tiny (<= 1 KB) latency-bound reductions of an LM iteration and
-// keeps the whole iteration inside one captured graph.
-//   slot(kind, parity, rank): 128 doubles = 127 payload + 1 flag word holding the epoch
+// sums into it over xGMI; the owner only ever reads local memory. This replaces a library
+// all-reduce for the two tiny (<= 1 KB) latency-bound reductions of an LM iteration and keeps the
+// whole iteration inside one captured graph.
+//   slot(kind, parity, rank): 256 self-validating 8-byte words; payload double i travels as
+//   word 2i = {epoch32 : lo32(v)} and word 2i+1 = {epoch32 : hi32(v)}. An aligned 8-byte store is
+//   single-copy atomic, so a word either carries the expected epoch and its data or it does not:
+//   no fence, no separate flag, one store round trip + one load round trip per exchange.
 //   kind 0: elimination sums (solve), kind 1: sweep statistics (decide); parity = epoch & 1
 // A rank posts epoch e+2 of a kind only after it finished e+1, which needs every peer's e+1 post,
 // which a peer makes only after it has read all of epoch e: two parities are enough.
 // ---------------------------------------------------------------------------------------------
 constexpr int kP2pMaxRanks = 8;
-constexpr int kP2pSlot = 128;
-constexpr int kP2pFlag = 127;
-constexpr int kP2pDoubles = 2 * 2 * kP2pMaxRanks * kP2pSlot;
-constexpr long long kP2pTimeoutTicks = 200000000LL;  // 2 s of the 100 MHz wall clock
+constexpr int kP2pSlotWords = 256;                 // up to 128 doubles per slot
+constexpr int kP2pWords = 2 * 2 * kP2pMaxRanks * kP2pSlotWords;
+constexpr long long kP2pTimeoutTicks = 1000000000LL;  // 10 s of the 100 MHz wall clock
 
 struct P2pDev {
-  double* box[kP2pMaxRanks];   // box[r]: rank r's mailbox as mapped here (box[rank] is local)
-  unsigned long long* seq;     // [2] last completed epoch per kind (device memory of this rank)
+  unsigned long long* box[kP2pMaxRanks];   // box[r]: rank r's mailbox as mapped here (box[rank] is local)
+  unsigned long long* seq;                 // [2] last epoch per kind (device memory of this rank)
   int32_t on;
   int32_t pad;
 };
 
 __device__ __forceinline__ int p2p_slot(int kind, unsigned long long epoch, int rank) {
-  return ((kind * 2 + (int)(epoch & 1ull)) * kP2pMaxRanks + rank) * kP2pSlot;
+  return ((kind * 2 + (int)(epoch & 1ull)) * kP2pMaxRanks + rank) * kP2pSlotWords;
 }
 
-// all threads of the block call; src (LDS or registers spilled to LDS) holds n <= 127 doubles
+// all threads of the block call; src (LDS) holds n <= 128 doubles. No barrier inside.
 __device__ inline void p2p_post(const P2pDev& X, int kind, unsigned long long epoch, int rank, int nranks,
                                 const double* src, int n) {
   const int off = p2p_slot(kind, epoch, rank);
-  for (int idx = threadIdx.x; idx < n * nranks; idx += blockDim.x) {
-    const int r = idx / n, i = idx - r * n;
-    __hip_atomic_store(X.box[r] + off + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const unsigned long long tag = (epoch & 0xffffffffull) << 32;
+  const int words = 2 * n;
+  for (int idx = threadIdx.x; idx < words * nranks; idx += blockDim.x) {
+    const int r = idx / words, w = idx - r * words;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(src[w >> 1]);
+    const unsigned long long half = (w & 1) ? (bits >> 32) : (bits & 0xffffffffull);
+    __hip_atomic_store(X.box[r] + off + w, tag | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  __threadfence_system();
-  __syncthreads();
-  if ((int)threadIdx.x < nranks)
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(X.box[threadIdx.x] + off + kP2pFlag), epoch,
-                       __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// all threads of the block call; returns false when a peer did not show up in time (s_ok: one LDS int)
-__device__ inline bool p2p_wait(const P2pDev& X, int kind, unsigned long long epoch, int rank, int nranks, int* s_ok) {
+// Thread i < n returns payload i of every rank's slot summed in rank order (identical on all ranks);
+// all threads of the block call. *s_ok (one LDS int) ends 0 when a peer's words did not arrive in
+// time; the return value is then meaningless. Contains two barriers.
+__device__ inline double p2p_collect(const P2pDev& X, int kind, unsigned long long epoch, int rank, int nranks,
+                                     int n, int* s_ok) {
   if (threadIdx.x == 0) *s_ok = 1;
   __syncthreads();
-  if ((int)threadIdx.x < nranks) {
-    const unsigned long long* flag =
-        reinterpret_cast<const unsigned long long*>(X.box[rank] + p2p_slot(kind, epoch, threadIdx.x) + kP2pFlag);
+  double a = 0.0;
+  if ((int)threadIdx.x < n) {
+    const unsigned long long tag = epoch & 0xffffffffull;
+    const unsigned long long* base = X.box[rank] + 2 * threadIdx.x;
     const long long t0 = wall_clock64();
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
+    unsigned long long lo[kP2pMaxRanks], hi[kP2pMaxRanks];
+    for (;;) {
+      bool all = true;
+#pragma unroll
+      for (int r = 0; r < kP2pMaxRanks; ++r) {
+        if (r < nranks) {
+          const unsigned long long* p = base + p2p_slot(kind, epoch, r);
+          lo[r] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          hi[r] = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < kP2pMaxRanks; ++r)
+        if (r < nranks) all = all && (lo[r] >> 32) == tag && (hi[r] >> 32) == tag;
+      if (all) break;
       if (wall_clock64() - t0 > kP2pTimeoutTicks) { *s_ok = 0; break; }
       __builtin_amdgcn_s_sleep(1);
     }
+#pragma unroll
+    for (int r = 0; r < kP2pMaxRanks; ++r)
+      if (r < nranks) {
+        const double v = __longlong_as_double((long long)((hi[r] << 32) | (lo[r] & 0xffffffffull)));
+        a = r == 0 ? v : a + v;
+      }
   }
   __syncthreads();
-  return *s_ok != 0;
-}
-
-// payload word i of every rank's slot, summed in rank order (identical on all ranks)
-__device__ __forceinline__ double p2p_sum(const P2pDev& X, int kind, unsigned long long epoch, int rank, int nranks, int i) {
-  double v[kP2pMaxRanks];
-#pragma unroll
-  for (int r = 0; r < kP2pMaxRanks; ++r)
-    v[r] = r < nranks ? __hip_atomic_load(X.box[rank] + p2p_slot(kind, epoch, r) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
-  double a = v[0];
-#pragma unroll
-  for (int r = 1; r < kP2pMaxRanks; ++r) a += v[r];
   return a;
 }
 

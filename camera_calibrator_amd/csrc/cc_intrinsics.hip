@@ -171,6 +171,9 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P) {
   const double g_old1 = P.blocks[((size_t)P.F + f) * 256 + tid];
   if (done) return;
   if (phase != 0 && !step_valid) return;
+  // mailbox exchange: this round's statistics will be exchanged by decide_elim<3> (which evaluates the
+  // same predicate); advance their epoch here so that it cannot change while that kernel reads it
+  if (P.x.on && f == 0 && tid == 0) P.x.seq[1] += 1ull;
   const int dst = phase == 0 ? cur : (cur ^ 1);
   const double g_old = cur ? g_old1 : g_old0;
   // first pass of observations: issued now, consumed after the prologue
@@ -378,9 +381,7 @@ __device__ __forceinline__ void reduce_frame_stats(const IntrDev& P, bool want_s
   __syncthreads();
 }
 
-// multi-GPU only: local reduction -> vec_decide (then all-reduced by RCCL), or, with the mailbox
-// exchange, posted straight into every rank's mailbox (kind 1); decide_elim<3> waits for it.
-template <bool P2P>
+// RCCL path only: local reduction -> vec_decide, which is then all-reduced
 __global__ __launch_bounds__(256) void k_intr_stats_reduce(IntrDev P) {
   __shared__ double s_w[128];
   __shared__ double s_out[16];
@@ -389,16 +390,7 @@ __global__ __launch_bounds__(256) void k_intr_stats_reduce(IntrDev P) {
   const int phase = ctl->phase;
   const bool need = phase == 0 || (ctl->cand_pending && ctl->step_valid);
   reduce_frame_stats(P, need, phase == 0, s_w, s_out);
-  if (P2P) {
-    if (!need) return;
-    if (threadIdx.x >= 13 && threadIdx.x < 16) s_out[threadIdx.x] = 0.0;
-    __syncthreads();
-    const unsigned long long epoch = P.x.seq[1] + 1ull;
-    p2p_post(P.x, 1, epoch, P.rank, P.nranks, s_out, 16);
-    if (threadIdx.x == 0) P.x.seq[1] = epoch;
-  } else {
-    if (threadIdx.x < 16) P.vec_decide[threadIdx.x] = (need && threadIdx.x < 13) ? s_out[threadIdx.x] : 0.0;
-  }
+  if (threadIdx.x < 16) P.vec_decide[threadIdx.x] = (need && threadIdx.x < 13) ? s_out[threadIdx.x] : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -433,11 +425,21 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P) {
   if (MODE == 0) {
     reduce_frame_stats(P, need, phase == 0, s_w, s_tot);
   } else if (MODE == 3) {
+    // mailbox exchange (kind 1): block 0 reduces this rank's statistics and posts them into every
+    // rank's mailbox (its own included); all blocks then poll the local words and add the slots
+    // in rank order. The epoch was advanced by this round's sweep, so it is stable while we run.
     __shared__ int s_ok;
     if (need) {
-      const unsigned long long epoch = P.x.seq[1];  // bumped by k_intr_stats_reduce<true> of this round
-      exchange_ok = p2p_wait(P.x, 1, epoch, P.rank, P.nranks, &s_ok);
-      if (tid < 16) s_tot[tid] = exchange_ok ? p2p_sum(P.x, 1, epoch, P.rank, P.nranks, tid) : 0.0;
+      const unsigned long long epoch = P.x.seq[1];
+      if (blockIdx.x == 0) {
+        if (tid >= 13 && tid < 16) s_tot[tid] = 0.0;
+        reduce_frame_stats(P, true, phase == 0, s_w, s_tot);
+        p2p_post(P.x, 1, epoch, P.rank, P.nranks, s_tot, 16);
+        __syncthreads();
+      }
+      const double a = p2p_collect(P.x, 1, epoch, P.rank, P.nranks, 16, &s_ok);
+      exchange_ok = s_ok != 0;
+      if (tid < 16) s_tot[tid] = exchange_ok ? a : 0.0;
     } else if (tid < 16) {
       s_tot[tid] = 0.0;
     }
@@ -687,10 +689,9 @@ __global__ __launch_bounds__(kSolveThreads) void k_intr_solve(IntrDev P, int nbl
       __shared__ int s_ok;
       const unsigned long long epoch = P.x.seq[0] + 1ull;
       p2p_post(P.x, 0, epoch, P.rank, P.nranks, sv, kVecSolve);
-      exchange_ok = p2p_wait(P.x, 0, epoch, P.rank, P.nranks, &s_ok);
-      const double a = (exchange_ok && tid < kVecSolve) ? p2p_sum(P.x, 0, epoch, P.rank, P.nranks, tid) : 0.0;
-      __syncthreads();
-      if (tid < kVecSolve) sv[tid] = a;
+      const double a = p2p_collect(P.x, 0, epoch, P.rank, P.nranks, kVecSolve, &s_ok);
+      exchange_ok = s_ok != 0;
+      if (tid < kVecSolve) sv[tid] = exchange_ok ? a : 0.0;
       if (tid == 0) P.x.seq[0] = epoch;
       __syncthreads();
     }
@@ -836,8 +837,8 @@ struct cc_intrinsics {
   int graph_iters = 0;
   cc::Comm* comm = nullptr;
   // mailbox exchange (cc_intrinsics_exchange_export / _attach): our mailbox and the peers' mappings
-  double* box_local = nullptr;
-  double* box_peer[cc::kP2pMaxRanks] = {};
+  unsigned long long* box_local = nullptr;
+  unsigned long long* box_peer[cc::kP2pMaxRanks] = {};
   bool exchange = false;
   std::vector<hipEvent_t> events;
   std::vector<int> event_kind;
@@ -882,7 +883,6 @@ static int enqueue_triple(cc_intrinsics* h, bool profile, bool initial = false) 
     // mailbox exchange inside the kernels: no library call, so the chain stays graph-capturable
     if (!initial) { Probe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_intr_solve<3>, dim3(1), dim3(kSolveThreads), 0, h->stream, h->d, h->elim_blocks); }
     launch_sweep(h, profile);
-    { Probe p(h, CC_K_DECIDE, profile); hipLaunchKernelGGL(k_intr_stats_reduce<true>, dim3(1), dim3(256), 0, h->stream, h->d); }
     { Probe p(h, CC_K_ELIM, profile); hipLaunchKernelGGL(k_intr_decide_elim<3>, dim3(h->elim_blocks), dim3(256), 0, h->stream, h->d); }
     return 0;
   }
@@ -897,7 +897,7 @@ static int enqueue_triple(cc_intrinsics* h, bool profile, bool initial = false) 
   }
   launch_sweep(h, profile);
   if (h->comm) {
-    { Probe p(h, CC_K_DECIDE, profile); hipLaunchKernelGGL(k_intr_stats_reduce<false>, dim3(1), dim3(256), 0, h->stream, h->d); }
+    { Probe p(h, CC_K_DECIDE, profile); hipLaunchKernelGGL(k_intr_stats_reduce, dim3(1), dim3(256), 0, h->stream, h->d); }
     { Probe p(h, CC_K_ALLREDUCE, profile); if (int rc = comm_allreduce_sum(h->comm, h->d.vec_decide, 16, h->stream)) return rc; }
     { Probe p(h, CC_K_ELIM, profile); hipLaunchKernelGGL(k_intr_decide_elim<2>, dim3(h->elim_blocks), dim3(256), 0, h->stream, h->d); }
   } else {
@@ -959,8 +959,8 @@ int cc_intrinsics_exchange_export(cc_intrinsics* h, uint8_t handle[64]) {
   CC_HIP(hipStreamSynchronize(h->stream));
   drop_graphs(h);
   exchange_release(h);
-  CC_HIP(hipExtMallocWithFlags((void**)&h->box_local, kP2pDoubles * sizeof(double), hipDeviceMallocUncached));
-  CC_HIP(hipMemset(h->box_local, 0, kP2pDoubles * sizeof(double)));
+  CC_HIP(hipExtMallocWithFlags((void**)&h->box_local, kP2pWords * sizeof(unsigned long long), hipDeviceMallocUncached));
+  CC_HIP(hipMemset(h->box_local, 0, kP2pWords * sizeof(unsigned long long)));
   CC_HIP(hipMalloc(&h->d.x.seq, 2 * sizeof(unsigned long long)));
   CC_HIP(hipMemset(h->d.x.seq, 0, 2 * sizeof(unsigned long long)));
   CC_HIP(hipDeviceSynchronize());
@@ -990,7 +990,7 @@ int cc_intrinsics_exchange_attach(cc_intrinsics* h, int32_t rank, int32_t nranks
         if (q != rank && h->box_peer[q]) { hipIpcCloseMemHandle(h->box_peer[q]); h->box_peer[q] = nullptr; }
       return fail(CC_ERR_COMM, "hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e));
     }
-    h->box_peer[r] = static_cast<double*>(p);
+    h->box_peer[r] = static_cast<unsigned long long*>(p);
   }
   for (int r = 0; r < kP2pMaxRanks; ++r) h->d.x.box[r] = r < nranks ? h->box_peer[r] : nullptr;
   h->d.x.on = 1;
@@ -1226,7 +1226,7 @@ int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* sum
     launched += n;
     if (int rc = read_ctl(h, &st)) return rc;
     if (st.done && st.term == CC_FAILURE_EXCHANGE)
-      return fail(CC_ERR_COMM, "mailbox exchange timed out: a peer rank did not post within 2 s (iteration %d)", st.iter);
+      return fail(CC_ERR_COMM, "mailbox exchange timed out: a peer rank did not post within 10 s (iteration %d)", st.iter);
     if (st.done) break;
     if (launched > o.max_iterations + 2 * o.check_interval + 2)
       return fail(CC_ERR_STATE, "LM loop did not terminate (iter=%d)", st.iter);

@@ -159,7 +159,7 @@ int cc_intrinsics_comm_init(cc_intrinsics* h, const uint8_t id[128], int32_t ran
  * hipIpcMemHandle), the caller all-gathers the handles over its control plane (rank order), every
  * rank calls _attach with all nranks*64 bytes. All ranks must then call cc_intrinsics_solve /
  * cc_intrinsics_reset the same number of times with the same options. A peer that does not show
- * up within 2 s makes the solve return CC_ERR_COMM (termination CC_FAILURE_EXCHANGE) instead of
+ * up within 10 s makes the solve return CC_ERR_COMM (termination CC_FAILURE_EXCHANGE) instead of
  * hanging. Keep the handle alive until every rank has finished its last solve. */
 int cc_intrinsics_exchange_export(cc_intrinsics* h, uint8_t handle[64]);
 int cc_intrinsics_exchange_attach(cc_intrinsics* h, int32_t rank, int32_t nranks, const uint8_t* handles);
