@@ -139,7 +139,7 @@ __device__ __forceinline__ void row_v(const double* k, const ObsCommon& c, doubl
 // ---------------------------------------------------------------------------------------------
 // sweep: one workgroup (4 waves) per frame
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P) {
+__global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int in_solve) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* s_stage = reinterpret_cast<double*>(smem_raw);       // [4][1024]
   double* s_blk = s_stage;                                      // [2048] cross-wave reduce + block copy (after the loop)
@@ -172,8 +172,9 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P) {
   if (done) return;
   if (phase != 0 && !step_valid) return;
   // mailbox exchange: this round's statistics will be exchanged by decide_elim<3> (which evaluates the
-  // same predicate); advance their epoch here so that it cannot change while that kernel reads it
-  if (P.x.on && f == 0 && tid == 0) P.x.seq[1] += 1ull;
+  // same predicate); advance their epoch here so that it cannot change while that kernel reads it.
+  // Only sweeps that belong to a solve count (cc_intrinsics_eval / profile_sweep are rank-local).
+  if (P.x.on && in_solve && f == 0 && tid == 0) P.x.seq[1] += 1ull;
   const int dst = phase == 0 ? cur : (cur ^ 1);
   const double g_old = cur ? g_old1 : g_old0;
   // first pass of observations: issued now, consumed after the prologue
@@ -870,9 +871,9 @@ struct Probe {  // optional hipEvent bracket around one launch
   }
 };
 
-static void launch_sweep(cc_intrinsics* h, bool profile) {
+static void launch_sweep(cc_intrinsics* h, bool profile, bool in_solve = false) {
   Probe p(h, CC_K_SWEEP, profile);
-  hipLaunchKernelGGL(k_intr_sweep, dim3((unsigned)h->F), dim3(kSweepThreads), kSweepLdsBytes, h->stream, h->d);
+  hipLaunchKernelGGL(k_intr_sweep, dim3((unsigned)h->F), dim3(kSweepThreads), kSweepLdsBytes, h->stream, h->d, in_solve ? 1 : 0);
 }
 
 // one triple: solve -> sweep -> decide+elim. The very first triple of a solve is the initial
@@ -882,7 +883,7 @@ static int enqueue_triple(cc_intrinsics* h, bool profile, bool initial = false) 
   if (h->exchange) {
     // mailbox exchange inside the kernels: no library call, so the chain stays graph-capturable
     if (!initial) { Probe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_intr_solve<3>, dim3(1), dim3(kSolveThreads), 0, h->stream, h->d, h->elim_blocks); }
-    launch_sweep(h, profile);
+    launch_sweep(h, profile, true);
     { Probe p(h, CC_K_ELIM, profile); hipLaunchKernelGGL(k_intr_decide_elim<3>, dim3(h->elim_blocks), dim3(256), 0, h->stream, h->d); }
     return 0;
   }
@@ -895,7 +896,7 @@ static int enqueue_triple(cc_intrinsics* h, bool profile, bool initial = false) 
     Probe p(h, CC_K_SOLVE, profile);
     hipLaunchKernelGGL(k_intr_solve<0>, dim3(1), dim3(kSolveThreads), 0, h->stream, h->d, h->elim_blocks);
   }
-  launch_sweep(h, profile);
+  launch_sweep(h, profile, true);
   if (h->comm) {
     { Probe p(h, CC_K_DECIDE, profile); hipLaunchKernelGGL(k_intr_stats_reduce, dim3(1), dim3(256), 0, h->stream, h->d); }
     { Probe p(h, CC_K_ALLREDUCE, profile); if (int rc = comm_allreduce_sum(h->comm, h->d.vec_decide, 16, h->stream)) return rc; }

@@ -31,6 +31,7 @@ def main():
     dist.all_gather_object(handles, prob.exchange_export())
     prob.exchange_attach(rank, handles)
     res = {}
+    local_cost = []
     for name, kw in (("default", {}), ("nograph", dict(use_graph=0)),
                      ("tight", dict(function_tolerance=1e-15, gradient_tolerance=1e-13, parameter_tolerance=1e-14, max_iterations=40))):
         prob.reset()
@@ -43,6 +44,9 @@ def main():
         res[name + "_acc"] = np.array([l["accepted"] for l in s["log"]])
         res[name + "_term"] = np.array([s["termination_code"] if "termination_code" in s else -1, s["iterations"]])
         res[name + "_termname"] = np.array(s["termination"])
+        if rank == world - 1:      # rank-local calls between solves must not disturb the exchange epochs
+            local_cost.append(prob.eval(want_blocks=False)[1])
+            prob.profile_sweep(3)
     dist.barrier()            # nobody frees a mailbox a peer may still be writing to
     prob.close()
     np.savez(out, f0=f0, f1=f1, **res)
