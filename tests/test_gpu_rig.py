@@ -113,3 +113,48 @@ def test_rig_rccl_path_with_a_single_rank_communicator():
     assert np.allclose([l["cost"] for l in s1["log"]], [l["cost"] for l in s0["log"]], rtol=1e-12)
     for a, b in zip(r0, r1):
         assert np.allclose(a, b, rtol=1e-12, atol=1e-14)
+
+
+def test_rig_c4_full_size_matches_oracle():
+    """BASELINE.json configs[3] (4 cameras x 400 frames x 300 points, 480k observations) against the
+    oracle: same trajectory, same minimiser (the oracle needs ~2 s for it)."""
+    sc = po.rig_scenario(4, 400, 300)
+    g, o = _both(sc, 4)
+    _assert_same(g, o)
+
+
+def test_rig_c5_full_size_against_the_committed_oracle_result_and_properties():
+    """BASELINE.json configs[4] (8 cameras x 2000 frames x 500 points, 8M observations). The oracle needs
+    a minute for it, so its answer is a committed fixture (tests/golden/make_rig_c5.py): same trajectory,
+    same minimiser. Plus size-independent properties: the frozen camera is untouched, the per-observation
+    costs add up to the reported cost, a second solve from the solution is a fixed point.
+    (With the reference's tolerances this scenario stops at cost 450.27 with only camera 1 back at the
+    planted rig; the oracle does exactly the same.)"""
+    import os
+    gld = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rig_c5_oracle.npz"))
+    C_ = int(gld["cams"])
+    sc = po.rig_scenario(C_, int(gld["frames"]), int(gld["pts"]))
+    cq, ct, fq, ft = _inputs(sc)
+    prob = capi.RigProblem(C_, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"], sc["world_xyz"], sc["cam_frozen"])
+    prob.set_state(cq, ct, fq, ft)
+    s1 = prob.solve(capi.default_options(max_iterations=1000))
+    r1 = prob.get_state()
+    assert s1["termination"] == str(gld["termination"]) and s1["iterations"] == int(gld["iterations"])
+    assert [l["accepted"] for l in s1["log"]] == list(gld["accepted"])
+    assert np.allclose([l["cost"] for l in s1["log"]], gld["costs"], rtol=1e-9)
+    assert np.isclose(s1["initial_cost"], float(gld["initial_cost"]), rtol=1e-10)
+    assert np.isclose(s1["final_cost"], float(gld["final_cost"]), rtol=1e-10)
+    assert np.abs(r1[0] - gld["cam_q"]).max() < 1e-9 and np.abs(r1[1] - gld["cam_t"]).max() < 1e-9
+    pick = gld["frame_pick"]
+    assert np.abs(r1[2][pick] - gld["frame_q"]).max() < 1e-9 and np.abs(r1[3][pick] - gld["frame_t"]).max() < 1e-9
+    assert np.allclose(r1[4][:64], gld["obs_cost_head"], rtol=1e-7, atol=1e-14)
+    assert np.isclose(r1[4].sum(), float(gld["obs_cost_sum"]), rtol=1e-10)
+    # properties
+    assert np.array_equal(r1[0][0], cq[0]) and np.array_equal(r1[1][0], ct[0])
+    assert np.isclose(r1[4].sum(), s1["final_cost"], rtol=1e-10) and r1[4].shape == (8_000_000,)
+    prob.set_state(r1[0], r1[1], r1[2], r1[3])
+    s2 = prob.solve(capi.default_options(max_iterations=1000))
+    r2 = prob.get_state()
+    prob.close()
+    assert s2["iterations"] <= 2 and s2["final_cost"] <= s1["final_cost"] * (1 + 1e-9)
+    assert np.abs(r2[1] - r1[1]).max() < 1e-6
