@@ -145,6 +145,20 @@ __global__ __launch_bounds__(kRigThreads, 4) void k_rig_sweep(RigDev P) {
   const int cur = ctl->cur, dst = phase == 0 ? cur : (cur ^ 1);
   const int f = P.gframe[g], c = P.gcam[g];
   const bool fixed = P.cam_fixed[c] != 0;
+  // observations are fetched one pass ahead: pixel + world index, then the gathered world point (two
+  // dependent round trips); the first pass is issued here, under the prologue
+  const int64_t s0 = P.goff[g], s1 = P.goff[g + 1];
+  const int npass = (int)((s1 - s0 + kRigThreads - 1) / kRigThreads);
+  const float2* uv2 = reinterpret_cast<const float2*>(P.uv);
+  float2 nm = make_float2(0.f, 0.f);
+  float nX0 = 0.f, nX1 = 0.f, nX2 = 1.f;
+  if (npass > 0) {
+    const int64_t idx = s0 + tid;
+    const int64_t ic = idx < s1 ? idx : s0;
+    nm = uv2[ic];
+    const int64_t w = P.widx[ic];
+    nX0 = P.wxyz[w * 3]; nX1 = P.wxyz[w * 3 + 1]; nX2 = P.wxyz[w * 3 + 2];
+  }
   // sm[0..31] camera record, sm[32..63] frame record
   if (tid < 32) sm[tid] = P.camrec[c * 32 + tid];
   else if (tid < 64) sm[tid] = P.frec[(size_t)f * 32 + (tid - 32)];
@@ -172,19 +186,21 @@ __global__ __launch_bounds__(kRigThreads, 4) void k_rig_sweep(RigDev P) {
   for (int i = 0; i < 3; ++i) { tc[i] = rfl(sm[9 + i]); tf[i] = rfl(sm[32 + 9 + i]); }
   const double ha = P.huber_a;
 
-  const int64_t s0 = P.goff[g], s1 = P.goff[g + 1];
-  const int npass = (int)((s1 - s0 + kRigThreads - 1) / kRigThreads);
   double* stage = s_stage + wave * kStageDoublesPerWave;
-  const float2* uv2 = reinterpret_cast<const float2*>(P.uv);
   d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
   double cost = 0.0;
   for (int p = 0; p < npass; ++p) {
     const int64_t idx = s0 + (int64_t)p * kRigThreads + tid;
     const bool valid = idx < s1;
-    const int64_t ic = valid ? idx : s0;
-    const float2 m = uv2[ic];
-    const int64_t w = P.widx[ic];
-    const float X0 = P.wxyz[w * 3], X1 = P.wxyz[w * 3 + 1], X2 = P.wxyz[w * 3 + 2];
+    const float2 m = nm;
+    const float X0 = nX0, X1 = nX1, X2 = nX2;
+    if (p + 1 < npass) {
+      const int64_t idn = idx + kRigThreads;
+      const int64_t ic = idn < s1 ? idn : s0;
+      nm = uv2[ic];
+      const int64_t w = P.widx[ic];
+      nX0 = P.wxyz[w * 3]; nX1 = P.wxyz[w * 3 + 1]; nX2 = P.wxyz[w * 3 + 2];
+    }
     RigObs o;
     rig_common(Rf, tf, Rc, tc, (double)X0, (double)X1, (double)X2, (double)m.x, (double)m.y, o);
     double rho, sr;
@@ -853,10 +869,15 @@ static void rig_drop_graphs(cc_rig* h) {
     if (g) { hipGraphExecDestroy(g); g = nullptr; }
 }
 
-static int rig_enqueue_round(cc_rig* h) {
+// One round: reduce -> solve -> update -> sweep -> decide+elim. The very first round of a solve is the
+// initial evaluation: there is nothing to reduce yet (k_rig_reduce would return at once), and only
+// that round needs k_rig_init (Jacobi scale of the shared block, trust-region state).
+static int rig_enqueue_round(cc_rig* h, bool initial) {
   const RigDev& d = h->d;
-  hipLaunchKernelGGL(k_rig_reduce, dim3((unsigned)((d.PC + 15) / 16)), dim3(256), 0, h->stream, d);
-  if (h->comm) if (int rc = comm_allreduce_sum(h->comm, d.vec, d.PC + 32, h->stream)) return rc;
+  if (!initial) {
+    hipLaunchKernelGGL(k_rig_reduce, dim3((unsigned)((d.PC + 15) / 16)), dim3(256), 0, h->stream, d);
+    if (h->comm) if (int rc = comm_allreduce_sum(h->comm, d.vec, d.PC + 32, h->stream)) return rc;
+  }
   hipLaunchKernelGGL(k_rig_solve, dim3(1), dim3(256), 0, h->stream, d);
   hipLaunchKernelGGL(k_rig_update, dim3((unsigned)((h->F + 15) / 16)), dim3(256), 0, h->stream, d);
   hipLaunchKernelGGL(k_rig_sweep, dim3((unsigned)h->NG), dim3(kRigThreads), kRigSweepLdsBytes, h->stream, d);
@@ -864,7 +885,7 @@ static int rig_enqueue_round(cc_rig* h) {
     hipLaunchKernelGGL(k_rig_stats, dim3(1), dim3(256), 0, h->stream, d);
     if (int rc = comm_allreduce_sum(h->comm, d.vec_stats, 4 + d.S, h->stream)) return rc;
   }
-  hipLaunchKernelGGL(k_rig_init, dim3(1), dim3(256), 0, h->stream, d);
+  if (initial) hipLaunchKernelGGL(k_rig_init, dim3(1), dim3(256), 0, h->stream, d);
   hipLaunchKernelGGL(k_rig_decide_elim, dim3(d.nblk), dim3(256), 0, h->stream, d);
   return 0;
 }
@@ -1105,7 +1126,7 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
       hipGraph_t g = nullptr;
       CC_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
       const int n = o.check_interval + (gi == 0 ? 1 : 0);
-      for (int i = 0; i < n; ++i) rig_enqueue_round(h);
+      for (int i = 0; i < n; ++i) rig_enqueue_round(h, gi == 0 && i == 0);
       CC_HIP(hipStreamEndCapture(h->stream, &g));
       CC_HIP(hipGraphInstantiate(&h->graph[gi], g, nullptr, nullptr, 0));
       hipGraphDestroy(g);
@@ -1120,7 +1141,7 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
       CC_HIP(hipGraphLaunch(h->graph[chunk == 0 ? 0 : 1], h->stream));
     } else {
       for (int i = 0; i < n; ++i)
-        if (int rc = rig_enqueue_round(h)) return rc;
+        if (int rc = rig_enqueue_round(h, chunk == 0 && i == 0)) return rc;
       CC_HIP(hipGetLastError());
     }
     launched += n;
