@@ -642,21 +642,30 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// solve (one block of 256): reduce the partial rows, dense Cholesky of the reduced system in
-// LDS, gradient test, camera candidates. In phase 0 it only prepares the camera records.
+// solve (one block of 256): dense Cholesky of the reduced (6C)x(6C) system in LDS (all four waves,
+// one barrier per column), then wave 0 alone: substitutions with lane i owning b[i] (cross-lane
+// values through v_readlane, no barrier), gradient test, camera candidates. In phase 0 it only
+// prepares the camera records. Tried and dropped (C4, S = 24): a single-wave factorisation (33 us vs
+// 20: the read-modify-write chain through LDS has nothing to hide behind) and a register-tiled one
+// with only the pivot column crossing threads through LDS (23 us).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_d(double x, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
 __global__ __launch_bounds__(256) void k_rig_solve(RigDev P) {
   __shared__ double A[kRigMaxS][kRigMaxS + 1];
-  __shared__ double b[kRigMaxS];
-  __shared__ double hd[kRigMaxS];
-  __shared__ double gs[kRigMaxS];
-  __shared__ double s_inv[kRigMaxS];
-  __shared__ double s_misc[4];  // fail, gmax
+  __shared__ double s_inv[64];
   __shared__ int s_ok;
-  __shared__ double s4[4];
-  __shared__ unsigned char s_fixed[kRigMaxCams];
-  const int tid = threadIdx.x;
-  if (tid < P.C) s_fixed[tid] = P.cam_fixed[tid];
+  const int tid = threadIdx.x, lane = tid & 63, i = tid;
   const LmCtl* cn = P.ctl_next;
   const int done = cn->done, phase = cn->phase, cur = cn->cur;
   const int S = P.S;
@@ -664,45 +673,44 @@ __global__ __launch_bounds__(256) void k_rig_solve(RigDev P) {
     if (tid == 0) *P.ctl = *cn;
     return;
   }
+  const bool my_cam_fixed = lane < P.C && P.cam_fixed[lane] != 0;
+  const unsigned long long fixed_mask = __ballot(my_cam_fixed);  // bit c: camera c is held constant (every wave)
+  const bool row = tid < S;                                       // rows live in wave 0 (S <= 60)
+  const bool row_fixed = row && ((fixed_mask >> (i / 6)) & 1ull);
   bool step_ok = false, converged = false;
   int early_term = CC_CONVERGENCE_GRADIENT;
   double gmax = 0.0;
+  double bi = 0.0;
   if (phase != 0) {
-    // ---- reduced column sums from k_rig_reduce
-    for (int o = tid; o < P.PC; o += 256) {
-      const double a = P.vec[o];
-      if (o < P.NP) { const int p = P.pair_p[o], q = P.pair_q[o]; A[p][q] = a; A[q][p] = a; }
-      else if (o < P.pc_hd) b[o - P.pc_b] = a;
-      else if (o < P.pc_fail) hd[o - P.pc_hd] = a;
-      else if (o == P.pc_fail) s_misc[0] = a;
-      else if (o < P.pc_gmax) gs[o - P.pc_gs] = a;
-      else s_misc[1] = a;
+    // ---- reduced sums from k_rig_reduce: packed upper triangle -> lower triangle in LDS; rows and
+    // columns of constant cameras become identity. Everything is issued in one round trip.
+    const double b_in = row ? P.vec[P.pc_b + i] : 0.0;
+    const double hd_i = row ? P.vec[P.pc_hd + i] : 0.0;
+    const double gs_i = row ? P.vec[P.pc_gs + i] : 0.0;
+    const double fail = P.vec[P.pc_fail];
+    const double gm_r = (tid < P.nranks && tid < 32) ? P.vec[P.PC + tid] : 0.0;
+    const LmOpts o = *P.opts;
+    const double radius = cn->radius;
+    for (int idx = tid; idx < P.NP; idx += 256) {
+      const int p = P.pair_p[idx], q = P.pair_q[idx];  // p <= q
+      double a = P.vec[idx];
+      if (((fixed_mask >> (p / 6)) | (fixed_mask >> (q / 6))) & 1ull) a = p == q ? 1.0 : 0.0;
+      else if (p == q) a += clampd(P.vec[P.pc_hd + p], o.min_lm_diagonal, o.max_lm_diagonal) / radius;
+      A[q][p] = a;
+    }
+    if (tid == 0) s_ok = fail > 0.0 ? 0 : 1;
+    // gradient test (wave 0 holds the rows; the other waves compute the same uniform answer from LDS)
+    __shared__ double s_g;
+    if (tid < 64) {
+      const double g = wave_max(fmax(gm_r, (row && !row_fixed) ? fabs(gs_i) : 0.0));
+      if (tid == 0) s_g = g;
     }
     __syncthreads();
-    const LmOpts o = *P.opts;
-    gmax = 0.0;
-    for (int r = 0; r < P.nranks && r < 32; ++r) gmax = fmax(gmax, P.vec[P.PC + r]);
-    for (int p = 0; p < S; ++p)
-      if (!s_fixed[p / 6]) gmax = fmax(gmax, fabs(gs[p]));
+    gmax = s_g;
     converged = gmax <= o.gradient_tolerance;
     // the loop-top radius test of the very first iteration (later ones are made by lm_decide)
-    if (!converged && cn->iter == 0 && cn->radius < o.min_radius) { converged = true; early_term = CC_MIN_RADIUS; }
+    if (!converged && cn->iter == 0 && radius < o.min_radius) { converged = true; early_term = CC_MIN_RADIUS; }
     if (!converged) {
-      const double radius = cn->radius;
-      if (tid < S) {
-        const int p = tid;
-        if (s_fixed[p / 6]) {
-          for (int q = 0; q < S; ++q) { A[p][q] = 0.0; A[q][p] = 0.0; }
-        }
-      }
-      __syncthreads();
-      if (tid < S) {
-        const int p = tid;
-        if (s_fixed[p / 6]) { A[p][p] = 1.0; b[p] = 0.0; }
-        else A[p][p] += clampd(hd[p], o.min_lm_diagonal, o.max_lm_diagonal) / radius;
-      }
-      if (tid == 0) s_ok = s_misc[0] > 0.0 ? 0 : 1;
-      __syncthreads();
       // right-looking Cholesky, lower triangle in place, ONE barrier per step: every thread derives
       // 1/sqrt(pivot) itself, the trailing update uses the unscaled column times inv^2, and the
       // scaled column is written in the same step by the threads that own it.
@@ -711,9 +719,9 @@ __global__ __launch_bounds__(256) void k_rig_solve(RigDev P) {
         const double d = A[j][j];
         if (tid == 0 && (!(d > 0.0) || !isfinite(d))) s_ok = 0;
         const double inv = rsqrt(d), inv2 = inv * inv;
-        for (int i = j + 1 + ti; i < S; i += 16) {
-          const double aij = A[i][j] * inv2;
-          for (int k = j + 1 + tk; k <= i; k += 16) A[i][k] -= aij * A[k][j];
+        for (int r = j + 1 + ti; r < S; r += 16) {
+          const double arj = A[r][j] * inv2;
+          for (int k = j + 1 + tk; k <= r; k += 16) A[r][k] -= arj * A[k][j];
         }
         __syncthreads();
         if (tid > j && tid < S) A[tid][j] *= inv;
@@ -721,61 +729,60 @@ __global__ __launch_bounds__(256) void k_rig_solve(RigDev P) {
         // (column j is read again only by the substitutions, after the final barrier)
       }
       __syncthreads();
-      // forward / backward substitution on one wave: lane i owns b[i]; the pivot row value is
-      // broadcast with a lane read, no barrier needed (S <= 60 <= 64)
       if (tid < 64) {
-        const int i = tid;
-        double bi = i < S ? b[i] : 0.0;
+        // forward / backward substitution on wave 0: lane i owns b[i]
+        const double inv_own = row ? s_inv[i] : 0.0;
+        bi = row_fixed ? 0.0 : b_in;
         for (int j = 0; j < S; ++j) {
-          const double yj = __shfl(bi, j, 64) * s_inv[j];
+          const double yj = readlane_d(bi, j) * readlane_d(inv_own, j);
           if (i == j) bi = yj;
-          else if (i > j && i < S) bi -= A[i][j] * yj;
+          else if (row && i > j) bi -= A[i][j] * yj;
         }
         for (int j = S - 1; j >= 0; --j) {
-          const double xj = __shfl(bi, j, 64) * s_inv[j];
+          const double xj = readlane_d(bi, j) * readlane_d(inv_own, j);
           if (i == j) bi = xj;
           else if (i < j) bi -= A[j][i] * xj;
         }
-        if (i < S) b[i] = bi;
+        step_ok = s_ok != 0 && __all(!row || isfinite(bi));
+        if (row) P.ds[i] = -bi;
       }
-      __syncthreads();
-      if (tid < S && !isfinite(b[tid])) s_ok = 0;
-      __syncthreads();
-      step_ok = s_ok != 0;
-      if (tid < S) P.ds[tid] = -b[tid];
     }
   }
-  // ---- camera candidates / records
+  if (tid >= 64) return;
+  // ---- wave 0: camera candidates / records: lane c < C gathers its six step components from lanes 6c..6c+5
   const int dst = phase == 0 ? cur : (cur ^ 1);
   double step2 = 0.0, xn2 = 0.0;
-  if (tid < P.C && (phase == 0 || step_ok)) {
-    const int c = tid;
+  double dcv[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) dcv[k] = __shfl(bi, (lane < P.C ? lane : 0) * 6 + k, 64);
+  if (lane < P.C && (phase == 0 || step_ok)) {
+    const int c = lane;
     const double* pc = P.cam + ((size_t)cur * P.C + c) * 8;
     double q[4] = {pc[0], pc[1], pc[2], pc[3]}, t[3] = {pc[4], pc[5], pc[6]};
     double dc[6] = {0, 0, 0, 0, 0, 0};
     if (phase != 0) {
-      if (!s_fixed[c]) {
-        for (int i = 0; i < 6; ++i) dc[i] = -b[c * 6 + i] * P.ss[c * 6 + i];
+      if (!my_cam_fixed) {
+        for (int k = 0; k < 6; ++k) dc[k] = -dcv[k] * P.ss[c * 6 + k];
         double qn[4];
         quat_plus(q, dc, qn);
-        for (int i = 0; i < 4; ++i) { const double d = qn[i] - q[i]; step2 += d * d; q[i] = qn[i]; }
-        for (int i = 0; i < 3; ++i) { const double tn = t[i] + dc[3 + i]; const double d = tn - t[i]; step2 += d * d; t[i] = tn; }
+        for (int k = 0; k < 4; ++k) { const double d = qn[k] - q[k]; step2 += d * d; q[k] = qn[k]; }
+        for (int k = 0; k < 3; ++k) { const double tn = t[k] + dc[3 + k]; const double d = tn - t[k]; step2 += d * d; t[k] = tn; }
         xn2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + t[0] * t[0] + t[1] * t[1] + t[2] * t[2];
       }
       double* pd = P.cam + ((size_t)dst * P.C + c) * 8;
-      for (int i = 0; i < 4; ++i) pd[i] = q[i];
-      for (int i = 0; i < 3; ++i) pd[4 + i] = t[i];
+      for (int k = 0; k < 4; ++k) pd[k] = q[k];
+      for (int k = 0; k < 3; ++k) pd[4 + k] = t[k];
     }
     double R[9];
     quat_to_R(q, R);
     double* rec = P.camrec + c * 32;
-    for (int i = 0; i < 9; ++i) rec[i] = R[i];
-    for (int i = 0; i < 3; ++i) rec[9 + i] = t[i];
-    for (int i = 0; i < 6; ++i) rec[12 + i] = dc[i];
+    for (int k = 0; k < 9; ++k) rec[k] = R[k];
+    for (int k = 0; k < 3; ++k) rec[9 + k] = t[k];
+    for (int k = 0; k < 6; ++k) rec[12 + k] = dc[k];
   }
-  const double st = block_sum256(step2, s4);
-  const double xs = block_sum256(xn2, s4);
-  if (tid == 0) {
+  const double st = wave_sum(step2);
+  const double xs = wave_sum(xn2);
+  if (lane == 0) {
     LmCtl c = *cn;
     if (phase != 0) {
       c.gmax = gmax;
