@@ -172,7 +172,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # un-timed: one complete solve for reporting time-to-converge
+    # outside the timed region: one complete solve for reporting time-to-converge (the solve before it
+    # pays for the one-off graph capture)
+    prob.reset()
+    prob.solve(opts, log_capacity=0)
+    barrier()
     prob.reset()
     t_c0 = time.perf_counter()
     conv = prob.solve(opts, log_capacity=0)

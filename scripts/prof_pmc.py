@@ -5,10 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch  # noqa: F401  (loads the ROCm runtime first, as bench.py does)
 from camera_calibrator_amd import capi
-from oracle import pyoracle as po
 
-off, uv, xyz = po.make_intrinsics_problem(1000, 500)
-K0, q0, t0 = po.zhang_init(off, uv, xyz)
+off, uv, xyz = capi.make_intrinsics_problem(1000, 500)
+K0, q0, t0 = capi.zhang_init(off, uv, xyz)
 intr0 = np.array([K0[0, 0], K0[1, 1], K0[0, 2], K0[1, 2], 0, 0, 0, 0, 0], dtype=np.float64)
 prob = capi.IntrinsicsProblem(off, uv, xyz)
 prob.set_state(intr0, q0.astype(np.float64), t0.astype(np.float64))
