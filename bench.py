@@ -128,13 +128,25 @@ def main():
                     print(f"[bench rank {rank}] mailbox attach failed: {e}", file=sys.stderr)
             ok = all_ok(ok)
             if ok:
-                try:  # one complete solve proves that every peer's posts arrive
+                try:  # one complete solve proves that every peer's posts arrive ...
                     prob.reset()
-                    prob.solve(capi.default_options(), log_capacity=0)
+                    chk = prob.solve(capi.default_options(), log_capacity=0)
+                    intr_chk, _, _ = prob.get_state()
+                    local_cost, _ = prob.eval(want_blocks=False)
                 except capi.CcError as e:
                     ok = False
+                    chk, intr_chk, local_cost = None, None, float("nan")
                     print(f"[bench rank {rank}] mailbox exchange failed: {e}", file=sys.stderr)
                 ok = all_ok(ok)
+                if ok:  # ... and that the exchanged sums are right: same bits everywhere, cost = sum of shards
+                    parts = [None] * world
+                    dist.all_gather_object(parts, (intr_chk.tobytes(), chk["final_cost"], local_cost))
+                    same = all(p[0] == parts[0][0] and p[1] == parts[0][1] for p in parts)
+                    total = sum(p[2] for p in parts)
+                    ok = same and abs(total - chk["final_cost"]) <= 1e-9 * abs(total)
+                    if not ok and rank == 0:
+                        print(f"[bench] mailbox exchange gave inconsistent results (same={same}, "
+                              f"sum of shard costs {total!r} vs {chk['final_cost']!r})", file=sys.stderr)
             if ok:
                 exchange = "mailbox"
             elif want == "mailbox":
