@@ -81,7 +81,7 @@ EXPORTED_SYMBOLS = [
     "cc_intrinsics_solve", "cc_intrinsics_profile_sweep", "cc_intrinsics_optimize", "cc_comm_get_unique_id",
     "cc_intrinsics_comm_init", "cc_intrinsics_exchange_export", "cc_intrinsics_exchange_attach", "cc_partition_frames", "cc_distort", "cc_undistort",
     "cc_rig_create", "cc_rig_destroy", "cc_rig_set_state", "cc_rig_reset", "cc_rig_solve",
-    "cc_rig_get_state", "cc_rig_eval", "cc_rig_optimize", "cc_rig_comm_init", "cc_zhang_init",
+    "cc_rig_get_state", "cc_rig_eval", "cc_rig_optimize", "cc_rig_comm_init", "cc_rig_exchange_export", "cc_rig_exchange_attach", "cc_zhang_init",
 ]
 # every symbol include/cc_harness.h declares (synthetic-input harness, host code)
 HARNESS_SYMBOLS = [
@@ -331,6 +331,17 @@ class RigProblem:
     def comm_init(self, unique_id, rank, nranks):
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
         _check(lib().cc_rig_comm_init(self._h, buf, C.c_int32(rank), C.c_int32(nranks)))
+
+    def exchange_export(self):
+        buf = (C.c_uint8 * 64)()
+        _check(lib().cc_rig_exchange_export(self._h, buf))
+        return bytes(buf)
+
+    def exchange_attach(self, rank, handles):
+        """Collective: every rank calls it with all handles in rank order."""
+        blob = b"".join(bytes(x) for x in handles)
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+        _check(lib().cc_rig_exchange_attach(self._h, C.c_int32(rank), C.c_int32(len(handles)), buf))
 
 
 def rig_optimize(n_cams, frame_offsets, obs_cam, obs_world, obs_uv, world_xyz, cam_q, cam_t, cam_frozen,

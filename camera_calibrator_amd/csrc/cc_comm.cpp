@@ -93,8 +93,65 @@ int comm_allreduce_sum(Comm* c, double* buf, int n, hipStream_t stream) {
   return CC_OK;
 }
 
-}  // namespace cc
+// ---------------------------------------------------------------------------------------------
+// Mailbox exchange, host side: one uncached device allocation per rank, exported through hipIpc and
+// mapped by every peer of the node (layout and protocol: cc_device.hpp).
+// ---------------------------------------------------------------------------------------------
+void mailbox_release(Mailbox* m) {
+  for (int r = 0; r < kP2pMaxRanks; ++r) {
+    if (m->peer[r] && m->peer[r] != m->local) hipIpcCloseMemHandle(m->peer[r]);
+    m->peer[r] = nullptr;
+  }
+  if (m->local) { hipFree(m->local); m->local = nullptr; }
+  if (m->seq) { hipFree(m->seq); m->seq = nullptr; }
+  m->sw[0] = m->sw[1] = 0;
+}
 
+int mailbox_export(Mailbox* m, int doubles_kind0, int doubles_kind1, uint8_t handle[64]) {
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size is part of the C ABI");
+  mailbox_release(m);
+  m->sw[0] = (2 * doubles_kind0 + 63) / 64 * 64;
+  m->sw[1] = (2 * doubles_kind1 + 63) / 64 * 64;
+  const size_t words = (size_t)2 * kP2pMaxRanks * ((size_t)m->sw[0] + m->sw[1]);
+  CC_HIP(hipExtMallocWithFlags((void**)&m->local, words * sizeof(unsigned long long), hipDeviceMallocUncached));
+  CC_HIP(hipMemset(m->local, 0, words * sizeof(unsigned long long)));
+  CC_HIP(hipMalloc(&m->seq, 2 * sizeof(unsigned long long)));
+  CC_HIP(hipMemset(m->seq, 0, 2 * sizeof(unsigned long long)));
+  CC_HIP(hipDeviceSynchronize());
+  hipIpcMemHandle_t hnd;
+  CC_HIP(hipIpcGetMemHandle(&hnd, m->local));
+  std::memcpy(handle, &hnd, 64);
+  return CC_OK;
+}
+
+int mailbox_attach(Mailbox* m, int rank, int nranks, const uint8_t* handles, P2pDev* out) {
+  if (!m->local) return fail(CC_ERR_STATE, "exchange attach: export the mailbox first");
+  for (int r = 0; r < nranks; ++r) {
+    if (r == rank) { m->peer[r] = m->local; continue; }
+    hipIpcMemHandle_t hnd;
+    std::memcpy(&hnd, handles + (size_t)r * 64, 64);
+    void* p = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&p, hnd, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      for (int q = 0; q < r; ++q) {
+        if (q != rank && m->peer[q]) hipIpcCloseMemHandle(m->peer[q]);
+        m->peer[q] = nullptr;
+      }
+      return fail(CC_ERR_COMM, "hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e));
+    }
+    m->peer[r] = static_cast<unsigned long long*>(p);
+  }
+  *out = P2pDev{};
+  for (int r = 0; r < kP2pMaxRanks; ++r) out->box[r] = r < nranks ? m->peer[r] : nullptr;
+  out->seq = m->seq;
+  out->sw[0] = m->sw[0];
+  out->sw[1] = m->sw[1];
+  out->on = 1;
+  return CC_OK;
+}
+
+}  // namespace cc
 extern "C" int cc_comm_get_unique_id(uint8_t id[128]) {
   using namespace cc;
   if (!id) return fail(CC_ERR_BAD_ARGUMENT, "cc_comm_get_unique_id: NULL");

@@ -29,6 +29,30 @@ int fail(int code, const char* fmt, ...);
 int select_device(int device);
 
 // ---------------------------------------------------------------------------------------------
+// Mailbox exchange between the ranks of one node (device side: cc_device.hpp; host side: cc_comm.cpp)
+// ---------------------------------------------------------------------------------------------
+constexpr int kP2pMaxRanks = 8;
+constexpr long long kP2pTimeoutTicks = 1000000000LL;  // 10 s of the 100 MHz wall clock
+
+struct P2pDev {
+  unsigned long long* box[kP2pMaxRanks];   // box[r]: rank r's mailbox as mapped here (box[rank] is local)
+  unsigned long long* seq;                 // [2] last epoch per kind (device memory of this rank)
+  int32_t sw[2];                           // words per slot of kind 0 / kind 1 (two words per double)
+  int32_t on;
+  int32_t pad;
+};
+
+struct Mailbox {  // host-side owner of one rank's mailbox and of its mappings of the peers' mailboxes
+  unsigned long long* local = nullptr;
+  unsigned long long* peer[kP2pMaxRanks] = {};
+  unsigned long long* seq = nullptr;
+  int sw[2] = {0, 0};
+};
+int mailbox_export(Mailbox* m, int doubles_kind0, int doubles_kind1, uint8_t handle[64]);
+int mailbox_attach(Mailbox* m, int rank, int nranks, const uint8_t* handles, P2pDev* out);
+void mailbox_release(Mailbox* m);
+
+// ---------------------------------------------------------------------------------------------
 // Device-resident LM state machine.  All control decisions (step acceptance, radius update,
 // convergence tests) are taken on the device by a single thread of the `decide` kernel, so an
 // LM iteration is a fixed sequence of kernel launches that can be enqueued ahead / replayed

@@ -63,7 +63,8 @@ __device__ __forceinline__ void gram_rows(const double* stage, int lane, d4& acc
 // sums into it over xGMI; the owner only ever reads local memory. This replaces a library
 // all-reduce for the two tiny (<= 1 KB) latency-bound reductions of an LM iteration and keeps the
 // whole iteration inside one captured graph.
-//   slot(kind, parity, rank): 256 self-validating 8-byte words; payload double i travels as
+//   slot(kind, parity, rank): self-validating 8-byte words (two per payload double; the slot sizes
+//   of the two kinds are chosen by the problem type); payload double i travels as
 //   word 2i = {epoch32 : lo32(v)} and word 2i+1 = {epoch32 : hi32(v)}. An aligned 8-byte store is
 //   single-copy atomic, so a word either carries the expected epoch and its data or it does not:
 //   no fence, no separate flag, one store round trip + one load round trip per exchange.
@@ -71,26 +72,19 @@ __device__ __forceinline__ void gram_rows(const double* stage, int lane, d4& acc
 // A rank posts epoch e+2 of a kind only after it finished e+1, which needs every peer's e+1 post,
 // which a peer makes only after it has read all of epoch e: two parities are enough.
 // ---------------------------------------------------------------------------------------------
-constexpr int kP2pMaxRanks = 8;
-constexpr int kP2pSlotWords = 256;                 // up to 128 doubles per slot
-constexpr int kP2pWords = 2 * 2 * kP2pMaxRanks * kP2pSlotWords;
-constexpr long long kP2pTimeoutTicks = 1000000000LL;  // 10 s of the 100 MHz wall clock
+// (P2pDev, kP2pMaxRanks and the host-side mailbox management live in cc_common.hpp / cc_comm.cpp)
 
-struct P2pDev {
-  unsigned long long* box[kP2pMaxRanks];   // box[r]: rank r's mailbox as mapped here (box[rank] is local)
-  unsigned long long* seq;                 // [2] last epoch per kind (device memory of this rank)
-  int32_t on;
-  int32_t pad;
-};
-
-__device__ __forceinline__ int p2p_slot(int kind, unsigned long long epoch, int rank) {
-  return ((kind * 2 + (int)(epoch & 1ull)) * kP2pMaxRanks + rank) * kP2pSlotWords;
+// word offset of slot (kind, parity, rank); kind 0 slots hold X.sw[0] words, kind 1 slots X.sw[1]
+__device__ __forceinline__ int p2p_slot(const P2pDev& X, int kind, unsigned long long epoch, int rank) {
+  const int base = kind == 0 ? 0 : 2 * kP2pMaxRanks * X.sw[0];
+  return base + ((int)(epoch & 1ull) * kP2pMaxRanks + rank) * X.sw[kind];
 }
 
-// all threads of the block call; src (LDS) holds n <= 128 doubles. No barrier inside.
+// all threads of the block call; src holds payload doubles [first, first + n) of this rank's slot.
+// No barrier inside.
 __device__ inline void p2p_post(const P2pDev& X, int kind, unsigned long long epoch, int rank, int nranks,
-                                const double* src, int n) {
-  const int off = p2p_slot(kind, epoch, rank);
+                                const double* src, int n, int first = 0) {
+  const int off = p2p_slot(X, kind, epoch, rank) + 2 * first;
   const unsigned long long tag = (epoch & 0xffffffffull) << 32;
   const int words = 2 * n;
   for (int idx = threadIdx.x; idx < words * nranks; idx += blockDim.x) {
@@ -101,6 +95,39 @@ __device__ inline void p2p_post(const P2pDev& X, int kind, unsigned long long ep
   }
 }
 
+// payload i of every rank's slot, added in rank order; *ok is cleared when the words do not show up
+__device__ __forceinline__ double p2p_poll_sum(const P2pDev& X, int kind, unsigned long long epoch, int rank, int nranks,
+                                               int i, long long t0, int* s_ok) {
+  const unsigned long long tag = epoch & 0xffffffffull;
+  const unsigned long long* base = X.box[rank] + 2 * i;
+  unsigned long long lo[kP2pMaxRanks], hi[kP2pMaxRanks];
+  for (;;) {
+    bool all = true;
+#pragma unroll
+    for (int r = 0; r < kP2pMaxRanks; ++r) {
+      if (r < nranks) {
+        const unsigned long long* p = base + p2p_slot(X, kind, epoch, r);
+        lo[r] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        hi[r] = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kP2pMaxRanks; ++r)
+      if (r < nranks) all = all && (lo[r] >> 32) == tag && (hi[r] >> 32) == tag;
+    if (all) break;
+    if (wall_clock64() - t0 > kP2pTimeoutTicks) { *s_ok = 0; break; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  double a = 0.0;
+#pragma unroll
+  for (int r = 0; r < kP2pMaxRanks; ++r)
+    if (r < nranks) {
+      const double v = __longlong_as_double((long long)((hi[r] << 32) | (lo[r] & 0xffffffffull)));
+      a = r == 0 ? v : a + v;
+    }
+  return a;
+}
+
 // Thread i < n returns payload i of every rank's slot summed in rank order (identical on all ranks);
 // all threads of the block call. *s_ok (one LDS int) ends 0 when a peer's words did not arrive in
 // time; the return value is then meaningless. Contains two barriers.
@@ -109,37 +136,19 @@ __device__ inline double p2p_collect(const P2pDev& X, int kind, unsigned long lo
   if (threadIdx.x == 0) *s_ok = 1;
   __syncthreads();
   double a = 0.0;
-  if ((int)threadIdx.x < n) {
-    const unsigned long long tag = epoch & 0xffffffffull;
-    const unsigned long long* base = X.box[rank] + 2 * threadIdx.x;
-    const long long t0 = wall_clock64();
-    unsigned long long lo[kP2pMaxRanks], hi[kP2pMaxRanks];
-    for (;;) {
-      bool all = true;
-#pragma unroll
-      for (int r = 0; r < kP2pMaxRanks; ++r) {
-        if (r < nranks) {
-          const unsigned long long* p = base + p2p_slot(kind, epoch, r);
-          lo[r] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          hi[r] = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < kP2pMaxRanks; ++r)
-        if (r < nranks) all = all && (lo[r] >> 32) == tag && (hi[r] >> 32) == tag;
-      if (all) break;
-      if (wall_clock64() - t0 > kP2pTimeoutTicks) { *s_ok = 0; break; }
-      __builtin_amdgcn_s_sleep(1);
-    }
-#pragma unroll
-    for (int r = 0; r < kP2pMaxRanks; ++r)
-      if (r < nranks) {
-        const double v = __longlong_as_double((long long)((hi[r] << 32) | (lo[r] & 0xffffffffull)));
-        a = r == 0 ? v : a + v;
-      }
-  }
+  if ((int)threadIdx.x < n) a = p2p_poll_sum(X, kind, epoch, rank, nranks, threadIdx.x, wall_clock64(), s_ok);
   __syncthreads();
   return a;
+}
+
+// Same for n > blockDim.x payload words: the rank-ordered sums are written to dst[0..n) (global or LDS).
+__device__ inline void p2p_collect_to(const P2pDev& X, int kind, unsigned long long epoch, int rank, int nranks,
+                                      int n, double* dst, int* s_ok) {
+  if (threadIdx.x == 0) *s_ok = 1;
+  __syncthreads();
+  const long long t0 = wall_clock64();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = p2p_poll_sum(X, kind, epoch, rank, nranks, i, t0, s_ok);
+  __syncthreads();
 }
 
 }  // namespace cc

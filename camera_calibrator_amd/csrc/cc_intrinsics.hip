@@ -838,8 +838,7 @@ struct cc_intrinsics {
   int graph_iters = 0;
   cc::Comm* comm = nullptr;
   // mailbox exchange (cc_intrinsics_exchange_export / _attach): our mailbox and the peers' mappings
-  unsigned long long* box_local = nullptr;
-  unsigned long long* box_peer[cc::kP2pMaxRanks] = {};
+  cc::Mailbox mailbox;
   bool exchange = false;
   std::vector<hipEvent_t> events;
   std::vector<int> event_kind;
@@ -853,10 +852,7 @@ static void drop_graphs(cc_intrinsics* h) {
 }
 
 static void exchange_release(cc_intrinsics* h) {
-  for (int r = 0; r < kP2pMaxRanks; ++r)
-    if (h->box_peer[r] && h->box_peer[r] != h->box_local) { hipIpcCloseMemHandle(h->box_peer[r]); h->box_peer[r] = nullptr; }
-  if (h->box_local) { hipFree(h->box_local); h->box_local = nullptr; }
-  if (h->d.x.seq) { hipFree(h->d.x.seq); }
+  mailbox_release(&h->mailbox);
   h->d.x = P2pDev{};
   h->exchange = false;
 }
@@ -954,47 +950,23 @@ int cc_intrinsics_create(int32_t device, int64_t F, const int64_t* off, const fl
 
 int cc_intrinsics_exchange_export(cc_intrinsics* h, uint8_t handle[64]) {
   using namespace cc;
-  static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size is part of the C ABI");
   if (!h || !handle) return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_exchange_export: NULL argument");
   CC_HIP(hipSetDevice(h->device));
   CC_HIP(hipStreamSynchronize(h->stream));
   drop_graphs(h);
   exchange_release(h);
-  CC_HIP(hipExtMallocWithFlags((void**)&h->box_local, kP2pWords * sizeof(unsigned long long), hipDeviceMallocUncached));
-  CC_HIP(hipMemset(h->box_local, 0, kP2pWords * sizeof(unsigned long long)));
-  CC_HIP(hipMalloc(&h->d.x.seq, 2 * sizeof(unsigned long long)));
-  CC_HIP(hipMemset(h->d.x.seq, 0, 2 * sizeof(unsigned long long)));
-  CC_HIP(hipDeviceSynchronize());
-  hipIpcMemHandle_t hnd;
-  CC_HIP(hipIpcGetMemHandle(&hnd, h->box_local));
-  std::memcpy(handle, &hnd, 64);
-  return CC_OK;
+  return mailbox_export(&h->mailbox, kVecSolve, 16, handle);
 }
 
 int cc_intrinsics_exchange_attach(cc_intrinsics* h, int32_t rank, int32_t nranks, const uint8_t* handles) {
   using namespace cc;
   if (!h || !handles || rank < 0 || nranks < 1 || rank >= nranks || nranks > kP2pMaxRanks)
     return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_exchange_attach: bad arguments (nranks must be 1..%d)", kP2pMaxRanks);
-  if (!h->box_local) return fail(CC_ERR_STATE, "cc_intrinsics_exchange_attach: call cc_intrinsics_exchange_export first");
+  if (!h->mailbox.local) return fail(CC_ERR_STATE, "cc_intrinsics_exchange_attach: call cc_intrinsics_exchange_export first");
   if (h->comm) return fail(CC_ERR_STATE, "cc_intrinsics_exchange_attach: an RCCL communicator is already attached");
   CC_HIP(hipSetDevice(h->device));
   drop_graphs(h);
-  for (int r = 0; r < nranks; ++r) {
-    if (r == rank) { h->box_peer[r] = h->box_local; continue; }
-    hipIpcMemHandle_t hnd;
-    std::memcpy(&hnd, handles + (size_t)r * 64, 64);
-    void* p = nullptr;
-    const hipError_t e = hipIpcOpenMemHandle(&p, hnd, hipIpcMemLazyEnablePeerAccess);
-    if (e != hipSuccess) {
-      (void)hipGetLastError();
-      for (int q = 0; q < r; ++q)
-        if (q != rank && h->box_peer[q]) { hipIpcCloseMemHandle(h->box_peer[q]); h->box_peer[q] = nullptr; }
-      return fail(CC_ERR_COMM, "hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e));
-    }
-    h->box_peer[r] = static_cast<unsigned long long*>(p);
-  }
-  for (int r = 0; r < kP2pMaxRanks; ++r) h->d.x.box[r] = r < nranks ? h->box_peer[r] : nullptr;
-  h->d.x.on = 1;
+  if (int rc = mailbox_attach(&h->mailbox, rank, nranks, handles, &h->d.x)) return rc;
   h->d.rank = rank;
   h->d.nranks = nranks;
   h->exchange = true;

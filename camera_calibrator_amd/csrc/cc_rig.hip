@@ -63,6 +63,7 @@ struct RigDev {
   double* vec;      // [PC + 32] column sums of the partial rows (k_rig_reduce) + one max-gradient slot per rank
   double* vec_stats;  // [4 + 6C] globally reduced sweep statistics (multi-GPU only)
   int32_t comm, rank, nranks;  // comm != 0: statistics / partial sums pass through an all-reduce
+  P2pDev x;                    // mailbox exchange (cc_device.hpp); x.on != 0 replaces the RCCL all-reduces
   double* shared_stats;  // [4] step^2 and |x|^2 of the shared block (candidate)
   LmCtl* ctl;
   LmCtl* ctl_next;
@@ -357,6 +358,42 @@ __global__ __launch_bounds__(256) void k_rig_stats(RigDev P) {
       if (tid == 0) P.vec_stats[4 + c * 6 + i] = s;
     }
   }
+  if (P.x.on) {
+    // mailbox exchange (kind 1): post the local statistics, wait for every rank's, write the sums back
+    // (k_rig_init / k_rig_decide_elim read vec_stats as they do after an all-reduce)
+    __shared__ double s_post[4 + kRigMaxS];
+    __shared__ int s_ok;
+    __syncthreads();
+    const int n = 4 + P.S;
+    if (tid < n) s_post[tid] = P.vec_stats[tid];
+    __syncthreads();
+    const unsigned long long epoch = P.x.seq[1] + 1ull;
+    p2p_post(P.x, 1, epoch, P.rank, P.nranks, s_post, n);
+    const double a = p2p_collect(P.x, 1, epoch, P.rank, P.nranks, n, &s_ok);
+    if (tid < n) P.vec_stats[tid] = a;
+    if (tid == 0) {
+      P.x.seq[1] = epoch;
+      if (s_ok == 0) {
+        LmCtl c = *ctl;
+        c.done = 1; c.term = CC_FAILURE_EXCHANGE;
+        *P.ctl = c; *P.ctl_next = c;
+      }
+    }
+  }
+}
+
+// one-off (attach time): sum of the per-rank "camera seen" flags through the mailboxes (kind 1)
+__global__ __launch_bounds__(64) void k_rig_flag_exchange(RigDev P, const double* in, double* out, int n, int* ok) {
+  __shared__ double s_post[64];
+  __shared__ int s_ok;
+  const int tid = threadIdx.x;
+  if (tid < n) s_post[tid] = in[tid];
+  __syncthreads();
+  const unsigned long long epoch = P.x.seq[1] + 1ull;
+  p2p_post(P.x, 1, epoch, P.rank, P.nranks, s_post, n);
+  const double a = p2p_collect(P.x, 1, epoch, P.rank, P.nranks, n, &s_ok);
+  if (tid < n) out[tid] = a;
+  if (tid == 0) { P.x.seq[1] = epoch; *ok = s_ok; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -607,6 +644,8 @@ __global__ __launch_bounds__(256) void k_rig_decide_elim(RigDev P) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P) {
   __shared__ double s_r[16][16];
+  __shared__ double s_post[48];
+  __shared__ double s_tail;
   const LmCtl* cn = P.ctl_next;
   if (cn->done || cn->phase == 0) return;
   const int tid = threadIdx.x, c = tid & 15, grp = tid >> 4;  // 16 columns x 16 row groups per block
@@ -636,8 +675,24 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P) {
       r = (((s_r[0][c] + s_r[1][c]) + (s_r[2][c] + s_r[3][c])) + ((s_r[4][c] + s_r[5][c]) + (s_r[6][c] + s_r[7][c]))) +
           (((s_r[8][c] + s_r[9][c]) + (s_r[10][c] + s_r[11][c])) + ((s_r[12][c] + s_r[13][c]) + (s_r[14][c] + s_r[15][c])));
     }
-    if (is_max) { P.vec[P.PC + P.rank] = r; r = 0.0; }  // a sum all-reduce then carries the max
+    if (is_max) { P.vec[P.PC + P.rank] = r; s_tail = r; r = 0.0; }  // a sum all-reduce then carries the max
     P.vec[o] = r;
+    s_post[c] = r;
+  }
+  if (P.x.on) {
+    // mailbox exchange (kind 0): every block posts its 16 column sums straight into all ranks'
+    // mailboxes; the block that owns the max column also posts the 32 per-rank max slots (ours set,
+    // the others zero). k_rig_solve collects. The epoch is stable here: only k_rig_solve advances it.
+    __syncthreads();
+    const unsigned long long epoch = P.x.seq[0] + 1ull;
+    const int first = blockIdx.x * 16;
+    const int ncol = P.PC - first < 16 ? P.PC - first : 16;
+    p2p_post(P.x, 0, epoch, P.rank, P.nranks, s_post, ncol, first);
+    if (first <= P.pc_gmax && P.pc_gmax < first + 16) {
+      if (tid < 32) s_post[16 + tid] = tid == P.rank ? s_tail : 0.0;
+      __syncthreads();
+      p2p_post(P.x, 0, epoch, P.rank, P.nranks, s_post + 16, 32, P.PC);
+    }
   }
 }
 
@@ -681,6 +736,22 @@ __global__ __launch_bounds__(256) void k_rig_solve(RigDev P) {
   int early_term = CC_CONVERGENCE_GRADIENT;
   double gmax = 0.0;
   double bi = 0.0;
+  if (phase != 0 && P.x.on) {
+    // mailbox exchange (kind 0): wait for every rank's column sums (posted by k_rig_reduce), add them
+    // in rank order into P.vec; everything below then reads the global sums like on one GPU
+    const unsigned long long epoch = P.x.seq[0] + 1ull;
+    p2p_collect_to(P.x, 0, epoch, P.rank, P.nranks, P.PC + 32, P.vec, &s_ok);
+    if (tid == 0) P.x.seq[0] = epoch;
+    if (s_ok == 0) {
+      if (tid == 0) {
+        LmCtl c = *cn;
+        c.done = 1; c.term = CC_FAILURE_EXCHANGE;
+        *P.ctl = c; *P.ctl_next = c;
+      }
+      return;
+    }
+    __syncthreads();
+  }
   if (phase != 0) {
     // ---- reduced sums from k_rig_reduce: packed upper triangle -> lower triangle in LDS; rows and
     // columns of constant cameras become identity. Everything is issued in one round trip.
@@ -850,6 +921,8 @@ struct cc_rig {
   hipGraphExec_t graph[2] = {nullptr, nullptr};
   int graph_iters = 0;
   cc::Comm* comm = nullptr;
+  cc::Mailbox mailbox;          // mailbox exchange (cc_rig_exchange_export / _attach)
+  bool exchange = false;
   uint8_t* d_cam_fixed = nullptr;          // same memory as d.cam_fixed
   std::vector<uint8_t> frozen, seen;       // host copies (user freeze flags, locally observed cameras)
 };
@@ -883,14 +956,14 @@ static int rig_enqueue_round(cc_rig* h, bool initial) {
   const RigDev& d = h->d;
   if (!initial) {
     hipLaunchKernelGGL(k_rig_reduce, dim3((unsigned)((d.PC + 15) / 16)), dim3(256), 0, h->stream, d);
-    if (h->comm) if (int rc = comm_allreduce_sum(h->comm, d.vec, d.PC + 32, h->stream)) return rc;
+    if (h->comm) if (int rc = comm_allreduce_sum(h->comm, d.vec, d.PC + 32, h->stream)) return rc;  // (mailbox: posted by the kernel)
   }
   hipLaunchKernelGGL(k_rig_solve, dim3(1), dim3(256), 0, h->stream, d);
   hipLaunchKernelGGL(k_rig_update, dim3((unsigned)((h->F + 15) / 16)), dim3(256), 0, h->stream, d);
   hipLaunchKernelGGL(k_rig_sweep, dim3((unsigned)h->NG), dim3(kRigThreads), kRigSweepLdsBytes, h->stream, d);
-  if (h->comm) {
+  if (h->comm || h->exchange) {
     hipLaunchKernelGGL(k_rig_stats, dim3(1), dim3(256), 0, h->stream, d);
-    if (int rc = comm_allreduce_sum(h->comm, d.vec_stats, 4 + d.S, h->stream)) return rc;
+    if (h->comm) if (int rc = comm_allreduce_sum(h->comm, d.vec_stats, 4 + d.S, h->stream)) return rc;
   }
   if (initial) hipLaunchKernelGGL(k_rig_init, dim3(1), dim3(256), 0, h->stream, d);
   hipLaunchKernelGGL(k_rig_decide_elim, dim3(d.nblk), dim3(256), 0, h->stream, d);
@@ -1067,6 +1140,7 @@ void cc_rig_destroy(cc_rig* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   cc::rig_drop_graphs(h);
   if (h->comm) cc::comm_destroy(h->comm);
+  cc::mailbox_release(&h->mailbox);
   for (void* p : h->allocs) hipFree(p);
   if (h->h_ctl) hipHostFree(h->h_ctl);
   if (h->stream) hipStreamDestroy(h->stream);
@@ -1153,6 +1227,8 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
     }
     launched += n;
     if (int rc = rig_read_ctl(h, &st)) return rc;
+    if (st.done && st.term == CC_FAILURE_EXCHANGE)
+      return fail(CC_ERR_COMM, "mailbox exchange timed out: a peer rank did not post within 10 s (iteration %d)", st.iter);
     if (st.done) break;
     if (launched > o.max_iterations + 2 * o.check_interval + 2)
       return fail(CC_ERR_STATE, "rig LM loop did not terminate (iter=%d)", st.iter);
@@ -1236,6 +1312,53 @@ int cc_rig_comm_init(cc_rig* h, const uint8_t id[128], int32_t rank, int32_t nra
   if (int rc = comm_allreduce_sum(h->comm, h->d.vec_stats, (int)h->C, h->stream)) return rc;
   CC_HIP(hipMemcpyAsync(flags.data(), h->d.vec_stats, flags.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   CC_HIP(hipStreamSynchronize(h->stream));
+  std::vector<uint8_t> fixed((size_t)h->C);
+  for (int64_t c = 0; c < h->C; ++c) fixed[(size_t)c] = (h->frozen[(size_t)c] || !(flags[(size_t)c] > 0.0)) ? 1 : 0;
+  CC_HIP(hipMemcpy(h->d_cam_fixed, fixed.data(), fixed.size(), hipMemcpyHostToDevice));
+  return CC_OK;
+}
+
+int cc_rig_exchange_export(cc_rig* h, uint8_t handle[64]) {
+  using namespace cc;
+  if (!h || !handle) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_exchange_export: NULL argument");
+  CC_HIP(hipSetDevice(h->device));
+  CC_HIP(hipStreamSynchronize(h->stream));
+  rig_drop_graphs(h);
+  mailbox_release(&h->mailbox);
+  h->d.x = P2pDev{};
+  h->exchange = false;
+  return mailbox_export(&h->mailbox, h->d.PC + 32, 4 + kRigMaxS, handle);
+}
+
+// collective: every rank must call it (the "camera seen" flags are summed through the mailboxes)
+int cc_rig_exchange_attach(cc_rig* h, int32_t rank, int32_t nranks, const uint8_t* handles) {
+  using namespace cc;
+  if (!h || !handles || rank < 0 || nranks < 1 || rank >= nranks || nranks > kP2pMaxRanks)
+    return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_exchange_attach: bad arguments (nranks must be 1..%d)", kP2pMaxRanks);
+  if (!h->mailbox.local) return fail(CC_ERR_STATE, "cc_rig_exchange_attach: call cc_rig_exchange_export first");
+  if (h->comm) return fail(CC_ERR_STATE, "cc_rig_exchange_attach: an RCCL communicator is already attached");
+  CC_HIP(hipSetDevice(h->device));
+  rig_drop_graphs(h);
+  if (int rc = mailbox_attach(&h->mailbox, rank, nranks, handles, &h->d.x)) return rc;
+  h->d.comm = 1; h->d.rank = rank; h->d.nranks = nranks;
+  h->exchange = true;
+  // a camera is part of the problem if ANY rank observes it: sum the per-rank "seen" flags
+  std::vector<double> flags(64, 0.0);
+  for (int64_t c = 0; c < h->C; ++c) flags[(size_t)c] = h->seen[(size_t)c] ? 1.0 : 0.0;
+  double* d_io = nullptr;
+  int* d_ok = nullptr;
+  CC_HIP(hipMalloc(&d_io, 128 * sizeof(double)));
+  CC_HIP(hipMalloc(&d_ok, sizeof(int)));
+  CC_HIP(hipMemcpyAsync(d_io, flags.data(), 64 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_rig_flag_exchange, dim3(1), dim3(64), 0, h->stream, h->d, d_io, d_io + 64, (int)h->C, d_ok);
+  int ok = 0;
+  hipError_t e1 = hipMemcpyAsync(flags.data(), d_io + 64, 64 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  hipError_t e2 = hipMemcpyAsync(&ok, d_ok, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+  hipError_t e3 = hipStreamSynchronize(h->stream);
+  hipFree(d_io);
+  hipFree(d_ok);
+  CC_HIP(e1); CC_HIP(e2); CC_HIP(e3);
+  if (!ok) return fail(CC_ERR_COMM, "cc_rig_exchange_attach: a peer rank did not attach within 10 s");
   std::vector<uint8_t> fixed((size_t)h->C);
   for (int64_t c = 0; c < h->C; ++c) fixed[(size_t)c] = (h->frozen[(size_t)c] || !(flags[(size_t)c] > 0.0)) ? 1 : 0;
   CC_HIP(hipMemcpy(h->d_cam_fixed, fixed.data(), fixed.size(), hipMemcpyHostToDevice));

@@ -200,6 +200,11 @@ int cc_rig_eval(cc_rig* h, double* cost);
  * Per LM iteration: one all-reduce of the reduced (6C)x(6C) system (PC + 32 doubles) and one of
  * 4 + 6C statistics. */
 int cc_rig_comm_init(cc_rig* h, const uint8_t id[128], int32_t rank, int32_t nranks);
+/* Mailbox exchange for the rig path (same protocol as cc_intrinsics_exchange_*; <= 8 ranks of one node).
+ * _attach is collective: every rank must call it (the per-rank "camera seen" flags are summed through
+ * the mailboxes, like cc_rig_comm_init does with an all-reduce). */
+int cc_rig_exchange_export(cc_rig* h, uint8_t handle[64]);
+int cc_rig_exchange_attach(cc_rig* h, int32_t rank, int32_t nranks, const uint8_t* handles);
 
 /* One-shot: the call ExtrinsicsCalibrator::Optimize makes in place of
  * extrinsics_calibrator.cpp:92-225. opt == NULL -> cc_options_init with max_iterations = 1000. */

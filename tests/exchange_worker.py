@@ -9,6 +9,40 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def rig_main(rank, world, frames, pts, out, dist, capi):
+    """argv[7] = "rig:<cams>": the rig path, camera 2 (if present) visible to rank 0's frames only."""
+    from oracle import pyoracle as po      # scenario generator only (test input)
+    cams = int(sys.argv[7].split(":")[1])
+    sc = po.rig_scenario(cams, frames, pts)
+    cq, ct = po.affine_to_qt(sc["cam_T"])
+    fq, ft = po.affine_to_qt(sc["frame_T"])
+    off = sc["frame_offsets"]
+    first = capi.partition_frames(off, world)
+    f0, f1 = int(first[rank]), int(first[rank + 1])
+    o0, o1 = int(off[f0]), int(off[f1])
+    prob = capi.RigProblem(cams, off[f0:f1 + 1] - o0, sc["obs_cam"][o0:o1], sc["obs_world"][o0:o1], sc["obs_uv"][o0:o1],
+                           sc["world_xyz"], sc["cam_frozen"])
+    prob.set_state(cq, ct, fq[f0:f1], ft[f0:f1])
+    handles = [None] * world
+    dist.all_gather_object(handles, prob.exchange_export())
+    prob.exchange_attach(rank, handles)
+    res = {}
+    for name, kw in (("default", dict(max_iterations=1000)), ("nograph", dict(max_iterations=1000, use_graph=0))):
+        prob.reset()
+        s = prob.solve(capi.default_options(**kw))
+        r = prob.get_state()
+        res[name + "_cam_q"], res[name + "_cam_t"], res[name + "_frame_q"], res[name + "_frame_t"], res[name + "_cost"] = r
+        res[name + "_costs"] = np.array([l["cost"] for l in s["log"]])
+        res[name + "_acc"] = np.array([l["accepted"] for l in s["log"]])
+        res[name + "_iters"] = np.array(s["iterations"])
+        res[name + "_termname"] = np.array(s["termination"])
+    dist.barrier()
+    prob.close()
+    np.savez(out, f0=f0, f1=f1, o0=o0, o1=o1, **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     rank, world, port, frames, pts, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
     import torch
@@ -17,6 +51,8 @@ def main():
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     from camera_calibrator_amd import capi
+    if len(sys.argv) > 7 and sys.argv[7].startswith("rig"):
+        return rig_main(rank, world, frames, pts, out, dist, capi)
 
     off, uv, xyz = capi.make_intrinsics_problem(frames, pts)
     K0, q0, t0 = capi.zhang_init(off, uv, xyz)

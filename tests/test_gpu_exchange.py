@@ -22,14 +22,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_ranks(world, frames, pts, tmp_path):
+def _run_ranks(world, frames, pts, tmp_path, extra=()):
     port = _free_port()
     procs, outs = [], []
     for r in range(world):
         out = str(tmp_path / f"rank{r}.npz")
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "exchange_worker.py"), str(r), str(world),
-                                       str(port), str(frames), str(pts), out],
+                                       str(port), str(frames), str(pts), out, *extra],
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
     try:
@@ -103,3 +103,28 @@ def test_single_rank_exchange_equals_plain_solve():
     p.close()
     assert s["iterations"] == ref[3]["iterations"] and s["termination"] == ref[3]["termination"]
     assert np.allclose(intr, ref[0], rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.parametrize("world,cams,frames,pts", [(2, 3, 30, 12), (3, 4, 45, 30), (2, 8, 40, 20)])
+def test_sharded_rig_solve_over_the_mailbox_exchange(world, cams, frames, pts, tmp_path):
+    from oracle import pyoracle as po
+    ranks = _run_ranks(world, frames, pts, tmp_path, extra=(f"rig:{cams}",))
+    sc = po.rig_scenario(cams, frames, pts)
+    cq, ct = po.affine_to_qt(sc["cam_T"])
+    fq, ft = po.affine_to_qt(sc["frame_T"])
+    ref = capi.rig_optimize(cams, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"], sc["world_xyz"],
+                            cq, ct, sc["cam_frozen"], fq, ft, options=capi.default_options(max_iterations=1000))
+    for name in ("default", "nograph"):
+        for r in ranks:
+            assert np.array_equal(r[name + "_cam_q"], ranks[0][name + "_cam_q"])          # every rank: same bits
+            assert np.array_equal(r[name + "_cam_t"], ranks[0][name + "_cam_t"])
+            assert np.array_equal(r[name + "_costs"], ranks[0][name + "_costs"])
+            assert str(r[name + "_termname"]) == ref[5]["termination"] and int(r[name + "_iters"]) == ref[5]["iterations"]
+            assert list(r[name + "_acc"]) == [l["accepted"] for l in ref[5]["log"]]
+            assert np.allclose(r[name + "_costs"], [l["cost"] for l in ref[5]["log"]], rtol=1e-9)
+            assert np.abs(r[name + "_cam_q"] - ref[0]).max() < 1e-9 and np.abs(r[name + "_cam_t"] - ref[1]).max() < 1e-9
+            f0, f1, o0, o1 = int(r["f0"]), int(r["f1"]), int(r["o0"]), int(r["o1"])
+            assert np.abs(r[name + "_frame_q"] - ref[2][f0:f1]).max() < 1e-8
+            assert np.abs(r[name + "_frame_t"] - ref[3][f0:f1]).max() < 1e-8
+            assert np.allclose(r[name + "_cost"], ref[4][o0:o1], rtol=1e-6, atol=1e-13)
+        assert np.array_equal(ranks[0]["default_cam_t"], ranks[0]["nograph_cam_t"])
