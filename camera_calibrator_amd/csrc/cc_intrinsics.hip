@@ -179,7 +179,10 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
   const double g_old = cur ? g_old1 : g_old0;
   // first pass of observations: issued now, consumed after the prologue
   const float2* uv2 = reinterpret_cast<const float2*>(P.uv);
-  const int npass = (int)((s1 - s0 + kSweepThreads - 1) / kSweepThreads);
+  // passes of THIS wave: a wave whose 64 slots of a pass all lie beyond the frame skips that pass
+  // (wave-uniform; the main loop holds no workgroup barrier)
+  const int64_t wrem = s1 - s0 - wave * 64;
+  const int npass = wrem > 0 ? (int)((wrem + kSweepThreads - 1) / kSweepThreads) : 0;
   float2 nm = make_float2(0.f, 0.f);
   float nX0 = 0.f, nX1 = 0.f, nX2 = 1.f;
   if (npass > 0) {

@@ -149,7 +149,10 @@ __global__ __launch_bounds__(kRigThreads, 4) void k_rig_sweep(RigDev P) {
   // observations are fetched one pass ahead: pixel + world index, then the gathered world point (two
   // dependent round trips); the first pass is issued here, under the prologue
   const int64_t s0 = P.goff[g], s1 = P.goff[g + 1];
-  const int npass = (int)((s1 - s0 + kRigThreads - 1) / kRigThreads);
+  // passes of THIS wave: a wave whose 64 slots of a pass all lie beyond the group skips that pass
+  // (wave-uniform; the main loop holds no workgroup barrier)
+  const int64_t wrem = s1 - s0 - (tid >> 6) * 64;
+  const int npass = wrem > 0 ? (int)((wrem + kRigThreads - 1) / kRigThreads) : 0;
   const float2* uv2 = reinterpret_cast<const float2*>(P.uv);
   float2 nm = make_float2(0.f, 0.f);
   float nX0 = 0.f, nX1 = 0.f, nX2 = 1.f;
