@@ -88,6 +88,10 @@ def main():
     F_total = args.frames * world
     off, uv, xyz = capi.make_intrinsics_problem(F_total, args.points)
     K0, q0, t0 = capi.zhang_init(off, uv, xyz, device=local_rank)
+    if dist is not None:   # every rank must start from the same bits: take rank 0's initial state
+        init = [(K0, q0, t0) if rank == 0 else None]
+        dist.broadcast_object_list(init, src=0)
+        K0, q0, t0 = init[0]
     intr0 = np.array([K0[0, 0], K0[1, 1], K0[0, 2], K0[1, 2], 0, 0, 0, 0, 0], dtype=np.float64)
     q0 = q0.astype(np.float64)
     t0 = t0.astype(np.float64)
