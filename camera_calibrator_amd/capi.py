@@ -81,7 +81,8 @@ EXPORTED_SYMBOLS = [
     "cc_intrinsics_solve", "cc_intrinsics_profile_sweep", "cc_intrinsics_optimize", "cc_comm_get_unique_id",
     "cc_intrinsics_comm_init", "cc_intrinsics_exchange_export", "cc_intrinsics_exchange_attach", "cc_partition_frames", "cc_distort", "cc_undistort",
     "cc_rig_create", "cc_rig_destroy", "cc_rig_set_state", "cc_rig_reset", "cc_rig_solve",
-    "cc_rig_get_state", "cc_rig_eval", "cc_rig_optimize", "cc_rig_comm_init", "cc_rig_exchange_export", "cc_rig_exchange_attach", "cc_zhang_init",
+    "cc_rig_get_state", "cc_rig_eval", "cc_rig_optimize", "cc_rig_comm_init", "cc_rig_exchange_export", "cc_rig_exchange_attach", "cc_rigk_create",
+    "cc_rigk_set_intrinsics", "cc_rigk_get_intrinsics", "cc_zhang_init",
 ]
 # every symbol include/cc_harness.h declares (synthetic-input harness, host code)
 HARNESS_SYMBOLS = [
@@ -272,15 +273,18 @@ class RigProblem:
     """Handle on a rig pose problem resident in HBM (cc_rig_*)."""
 
     def __init__(self, n_cams, frame_offsets, obs_cam, obs_world, obs_uv, world_xyz, cam_frozen,
-                 huber_a=HUBER_A, device=0):
+                 huber_a=HUBER_A, device=0, with_intrinsics=False):
+        """with_intrinsics=True: the extension cc_rigk_create (pixel observations, 9 shared intrinsics)."""
         self._h = C.c_void_p()
+        self.with_intrinsics = bool(with_intrinsics)
         off = np.ascontiguousarray(frame_offsets, dtype=np.int64)
         self.n_cams, self.n_frames, self.n_obs = int(n_cams), len(off) - 1, int(off[-1])
         obs_cam = np.ascontiguousarray(obs_cam, dtype=np.uint32)
         obs_world = np.ascontiguousarray(obs_world, dtype=np.uint64)
         obs_uv, world_xyz = _f32(obs_uv), _f32(world_xyz)
         frozen = np.ascontiguousarray(cam_frozen, dtype=np.uint8)
-        _check(lib().cc_rig_create(C.c_int32(device), C.c_int64(n_cams), C.c_int64(self.n_frames),
+        create = lib().cc_rigk_create if with_intrinsics else lib().cc_rig_create
+        _check(create(C.c_int32(device), C.c_int64(n_cams), C.c_int64(self.n_frames),
                                    C.c_int64(world_xyz.size // 3), _p(off, C.c_int64),
                                    _p(obs_cam, C.c_uint32), _p(obs_world, C.c_uint64),
                                    _p(obs_uv, C.c_float), _p(world_xyz, C.c_float),
@@ -302,6 +306,16 @@ class RigProblem:
         assert cam_q.size == 4 * self.n_cams and frame_q.size == 4 * self.n_frames
         _check(lib().cc_rig_set_state(self._h, _p(cam_q, C.c_double), _p(cam_t, C.c_double),
                                       _p(frame_q, C.c_double), _p(frame_t, C.c_double)))
+
+    def set_intrinsics(self, intr9, const_mask=0):
+        intr9 = _f64(intr9)
+        assert intr9.size == 9
+        _check(lib().cc_rigk_set_intrinsics(self._h, _p(intr9, C.c_double), C.c_uint32(const_mask)))
+
+    def get_intrinsics(self):
+        out = np.zeros(9)
+        _check(lib().cc_rigk_get_intrinsics(self._h, _p(out, C.c_double)))
+        return out
 
     def reset(self):
         _check(lib().cc_rig_reset(self._h))

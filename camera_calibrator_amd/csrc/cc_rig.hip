@@ -28,6 +28,8 @@ constexpr int kRigMaxS = 6 * kRigMaxCams;
 constexpr int kRigThreads = 256;
 constexpr int kRigOwn = 8;  // partial-row columns owned per thread of the elim kernel (PC <= 2048)
 constexpr int kRigSweepLdsBytes = (4 * kStageDoublesPerWave + 256) * 8;
+constexpr int kRigSweepLdsBytesK = (8 * kStageDoublesPerWave + 256) * 8;  // with intrinsics: two staged tiles per wave
+constexpr int kRigK = 9;  // shared intrinsics columns of the extension (0 in the reference's problem)
 constexpr int kRigMaxElimBlocks = 512;
 
 struct RigDev {
@@ -51,7 +53,7 @@ struct RigDev {
   double* pose;     // [2][F][8]
   double* camrec;   // [C][32] R(9) t(3) unscaled step(6)
   double* frec;     // [F][32] R(9) t(3) unscaled step(6)
-  double* gblocks;  // [2][NG][256]
+  double* gblocks;  // [2][NG][gstride]: 256 (poses only) or 3 x 256 (AA | AB | BB tiles, with intrinsics)
   double* gstats;   // [NG][2] cost, model term
   double* fstats;   // [F][2] step^2, |x|^2
   double* ghd0;     // [NG][8] diag of H_cc at the initial point
@@ -71,6 +73,13 @@ struct RigDev {
   cc_iteration* log;
   int32_t log_cap;
   double huber_a;
+  // EXTENSION: 9 intrinsics shared by all cameras, pixel observations. K = 0: off.
+  // Shared tangent = [cam 0 (6) ... cam C-1 (6) | k (9)], S = 6C + K, S6 = 6C.
+  int32_t K, S6, gstride;
+  uint32_t kmask;     // bit i: intrinsic i is held constant
+  double* intr;       // [2][16]
+  double* krec;       // [32]: candidate intrinsics [0..8], unscaled step [16..24]
+  double* ghdk;       // [NG][16] diag of the intrinsics block of each group at the initial point
 };
 
 // ceres::HuberLoss(a) + Corrector (rho'' <= 0): residual and Jacobian scaled by sqrt(rho')
@@ -129,14 +138,59 @@ __device__ __forceinline__ void rig_row(const RigObs& o, const double* Rc, doubl
   }
 }
 
+// EXTENSION: pixel model behind the rig chain. Given the normalised point (o.x, o.y, o.iz) it returns
+// the pixel residuals, B = d residual / d x_cam (what rig_row chains through both poses) and the two
+// rows of d residual / d k (DistortNormalized / DistortPixels, calibrator.cpp:70-95).
+struct RigKObs {
+  double ru, rv, Bu0, Bu1, Bu2, Bv0, Bv1, Bv2;
+  double ju[9], jv[9];
+};
+__device__ __forceinline__ void rigk_obs(const double* k, const RigObs& o, double u, double v, RigKObs& r) {
+  const double x = o.x, y = o.y, iz = o.iz;
+  const double fx = k[0], fy = k[1];
+  const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+  const double m = 1.0 + k[4] * r2 + k[5] * r4 + k[8] * r6;
+  const double xd = x * m + 2.0 * k[6] * x * y + k[7] * (r2 + 2.0 * x * x);
+  const double yd = y * m + 2.0 * k[7] * x * y + k[6] * (r2 + 2.0 * y * y);
+  r.ru = fx * xd + k[2] - u;
+  r.rv = fy * yd + k[3] - v;
+  r.ju[0] = xd; r.ju[1] = 0.0; r.ju[2] = 1.0; r.ju[3] = 0.0;
+  r.ju[4] = fx * x * r2; r.ju[5] = fx * x * r4; r.ju[6] = fx * 2.0 * x * y; r.ju[7] = fx * (r2 + 2.0 * x * x); r.ju[8] = fx * x * r6;
+  r.jv[0] = 0.0; r.jv[1] = yd; r.jv[2] = 0.0; r.jv[3] = 1.0;
+  r.jv[4] = fy * y * r2; r.jv[5] = fy * y * r4; r.jv[6] = fy * (r2 + 2.0 * y * y); r.jv[7] = fy * 2.0 * x * y; r.jv[8] = fy * y * r6;
+  const double mp = k[4] + 2.0 * k[5] * r2 + 3.0 * k[8] * r4;
+  const double dxx = m + 2.0 * mp * x * x + 2.0 * k[6] * y + 6.0 * k[7] * x;
+  const double dxy = 2.0 * mp * x * y + 2.0 * k[6] * x + 2.0 * k[7] * y;
+  const double dyy = m + 2.0 * mp * y * y + 2.0 * k[7] * x + 6.0 * k[6] * y;
+  r.Bu0 = fx * dxx * iz; r.Bu1 = fx * dxy * iz; r.Bu2 = -(fx * dxx * x + fx * dxy * y) * iz;
+  r.Bv0 = fy * dxy * iz; r.Bv1 = fy * dyy * iz; r.Bv2 = -(fy * dxy * x + fy * dyy * y) * iz;
+}
+
+// Gram tile between two staged 16-column halves of the same 64 rows: D[i][j] += sum_rows a[i] b[j]
+__device__ __forceinline__ void gram_rows_ab(const double* sa, const double* sb, int lane, d4& acc0, d4& acc1) {
+  const int c = lane & 15, sub = lane >> 4;
+#pragma unroll
+  for (int m = 0; m < 16; m += 2) {
+    const int r0 = 4 * m + sub, r1 = 4 * (m + 1) + sub;
+    const int o0 = r0 * 16 + (((c >> 1) ^ (r0 & 7)) << 1) + (c & 1), o1 = r1 * 16 + (((c >> 1) ^ (r1 & 7)) << 1) + (c & 1);
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[o0], sb[o0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[o1], sb[o1], acc1, 0, 0, 0);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
-// sweep: one workgroup per (frame, camera) group
+// sweep: one workgroup per (frame, camera) group. HK = false: the reference's problem (normalised
+// observations, poses only, one 16x16 Gram tile). HK = true (extension): pixel observations through 9
+// shared intrinsics; the row is [J_cam(6) J_frame(6) r 0 0 0 | J_k(9) 0...] and the group block has
+// three tiles: AA (as before), AB (first half x intrinsics), BB (intrinsics x intrinsics).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kRigThreads, 4) void k_rig_sweep(RigDev P) {
+template <bool HK>
+__global__ __launch_bounds__(kRigThreads, HK ? 2 : 4) void k_rig_sweep(RigDev P) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int kTiles = HK ? 2 : 1;
   double* s_stage = reinterpret_cast<double*>(smem_raw);
   double* s_blk = s_stage;
-  double* sm = s_stage + 4 * kStageDoublesPerWave;  // [256]
+  double* sm = s_stage + 4 * kTiles * kStageDoublesPerWave;  // [256]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t g = blockIdx.x;
   const LmCtl* ctl = P.ctl;
@@ -163,18 +217,24 @@ __global__ __launch_bounds__(kRigThreads, 4) void k_rig_sweep(RigDev P) {
     const int64_t w = P.widx[ic];
     nX0 = P.wxyz[w * 3]; nX1 = P.wxyz[w * 3 + 1]; nX2 = P.wxyz[w * 3 + 2];
   }
-  // sm[0..31] camera record, sm[32..63] frame record
+  // sm[0..31] camera record, sm[32..63] frame record, sm[64..95] intrinsics record (candidate, step)
   if (tid < 32) sm[tid] = P.camrec[c * 32 + tid];
   else if (tid < 64) sm[tid] = P.frec[(size_t)f * 32 + (tid - 32)];
-  double g_old = 0.0;
-  if (phase != 0) g_old = P.gblocks[((size_t)cur * P.NG + g) * 256 + tid];
+  else if (HK && tid < 96) sm[tid] = P.krec[tid - 64];
+  const size_t gs = (size_t)P.gstride;
+  double g_old = 0.0, g_ab = 0.0, g_bb = 0.0;
+  if (phase != 0) {
+    const double* old = P.gblocks + ((size_t)cur * P.NG + g) * gs;
+    g_old = old[tid];
+    if (HK) { g_ab = old[256 + tid]; g_bb = old[512 + tid]; }
+  }
   __syncthreads();
-  // model-cost term of the group: d = [dc(6) df(6)], q = d^T g + 1/2 d^T H d over the 12x12 block
+  // model-cost term of the group: d = [dc(6) df(6) (dk(9))], q = d^T g + 1/2 d^T H d over its block
   double qterm = 0.0;
   if (phase != 0) {
     const int a = tid >> 4, b = tid & 15;
+    const double da = a < 6 ? sm[12 + a] : (a < 12 ? sm[32 + 12 + (a - 6)] : 0.0);
     if (a < 12) {
-      const double da = a < 6 ? sm[12 + a] : sm[32 + 12 + (a - 6)];
       if (b < 12) {
         const double db = b < 6 ? sm[12 + b] : sm[32 + 12 + (b - 6)];
         qterm = 0.5 * da * g_old * db;
@@ -182,16 +242,25 @@ __global__ __launch_bounds__(kRigThreads, 4) void k_rig_sweep(RigDev P) {
         qterm = da * g_old;
       }
     }
+    if (HK) {
+      const double dkb = b < 9 ? sm[64 + 16 + b] : 0.0;
+      if (a < 12) qterm += da * g_ab * dkb;            // cross term, counted once (1/2 * 2)
+      else if (a == 12) qterm += g_ab * dkb;           // gradient with respect to the intrinsics
+      if (a < 9) qterm += 0.5 * sm[64 + 16 + a] * g_bb * dkb;
+    }
   }
-  double Rc[9], tc[3], Rf[9], tf[3];
+  double Rc[9], tc[3], Rf[9], tf[3], kk[9];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) { Rc[i] = rfl(sm[i]); Rf[i] = rfl(sm[32 + i]); }
+  for (int i = 0; i < 9; ++i) { Rc[i] = rfl(sm[i]); Rf[i] = rfl(sm[32 + i]); kk[i] = HK ? rfl(sm[64 + i]) : 0.0; }
 #pragma unroll
   for (int i = 0; i < 3; ++i) { tc[i] = rfl(sm[9 + i]); tf[i] = rfl(sm[32 + 9 + i]); }
   const double ha = P.huber_a;
+  const uint32_t kmask = P.kmask;
 
-  double* stage = s_stage + wave * kStageDoublesPerWave;
+  double* stage = s_stage + wave * kTiles * kStageDoublesPerWave;
+  double* stage_b = stage + kStageDoublesPerWave;
   d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+  d4 ab0 = {0.0, 0.0, 0.0, 0.0}, ab1 = {0.0, 0.0, 0.0, 0.0}, bb0 = {0.0, 0.0, 0.0, 0.0}, bb1 = {0.0, 0.0, 0.0, 0.0};
   double cost = 0.0;
   for (int p = 0; p < npass; ++p) {
     const int64_t idx = s0 + (int64_t)p * kRigThreads + tid;
@@ -207,37 +276,71 @@ __global__ __launch_bounds__(kRigThreads, 4) void k_rig_sweep(RigDev P) {
     }
     RigObs o;
     rig_common(Rf, tf, Rc, tc, (double)X0, (double)X1, (double)X2, (double)m.x, (double)m.y, o);
+    RigKObs ko;
+    double ru = o.ru, rv = o.rv;
+    double Bu0 = o.iz, Bu1 = 0.0, Bu2 = -o.x * o.iz, Bv0 = 0.0, Bv1 = o.iz, Bv2 = -o.y * o.iz;
+    if (HK) {
+      rigk_obs(kk, o, (double)m.x, (double)m.y, ko);
+      ru = ko.ru; rv = ko.rv;
+      Bu0 = ko.Bu0; Bu1 = ko.Bu1; Bu2 = ko.Bu2; Bv0 = ko.Bv0; Bv1 = ko.Bv1; Bv2 = ko.Bv2;
+    }
     double rho, sr;
-    huber(ha, o.ru * o.ru + o.rv * o.rv, rho, sr);
+    huber(ha, ru * ru + rv * rv, rho, sr);
     if (valid) cost += 0.5 * rho;
-    double v[16];
-    rig_row(o, Rc, o.iz, 0.0, -o.x * o.iz, o.ru, sr, fixed, v);
+    double v[16], vb[16];
+    rig_row(o, Rc, Bu0, Bu1, Bu2, ru, sr, fixed, v);
     if (!valid) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) v[k] = 0.0;
     }
     stage_row(stage, lane, v);
+    if (HK) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) vb[k] = (k < 9 && valid && !(kmask & (1u << k))) ? sr * ko.ju[k] : 0.0;
+      stage_row(stage_b, lane, vb);
+    }
     wave_lds_fence();
     gram_rows(stage, lane, acc0, acc1);
+    if (HK) { gram_rows_ab(stage, stage_b, lane, ab0, ab1); gram_rows(stage_b, lane, bb0, bb1); }
     wave_lds_fence();
-    rig_row(o, Rc, 0.0, o.iz, -o.y * o.iz, o.rv, sr, fixed, v);
+    rig_row(o, Rc, Bv0, Bv1, Bv2, rv, sr, fixed, v);
     if (!valid) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) v[k] = 0.0;
     }
     stage_row(stage, lane, v);
+    if (HK) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) vb[k] = (k < 9 && valid && !(kmask & (1u << k))) ? sr * ko.jv[k] : 0.0;
+      stage_row(stage_b, lane, vb);
+    }
     wave_lds_fence();
     gram_rows(stage, lane, acc0, acc1);
+    if (HK) { gram_rows_ab(stage, stage_b, lane, ab0, ab1); gram_rows(stage_b, lane, bb0, bb1); }
     wave_lds_fence();
   }
   __syncthreads();
+  const int slot = ((lane >> 4)) * 16 + (lane & 15);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) s_blk[wave * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc0[r] + acc1[r];
+  for (int r = 0; r < 4; ++r) {
+    s_blk[wave * 256 + slot + 64 * r] = acc0[r] + acc1[r];
+    if (HK) {
+      s_blk[1024 + wave * 256 + slot + 64 * r] = ab0[r] + ab1[r];
+      s_blk[2048 + wave * 256 + slot + 64 * r] = bb0[r] + bb1[r];
+    }
+  }
   const double qw = wave_sum(qterm), cw = wave_sum(cost);
   if (lane == 0) { sm[140 + wave] = qw; sm[144 + wave] = cw; }
   __syncthreads();
+  double* out = P.gblocks + ((size_t)dst * P.NG + g) * gs;
   const double gv = (s_blk[tid] + s_blk[256 + tid]) + (s_blk[512 + tid] + s_blk[768 + tid]);
-  P.gblocks[((size_t)dst * P.NG + g) * 256 + tid] = gv;
+  out[tid] = gv;
+  if (HK) {
+    out[256 + tid] = (s_blk[1024 + tid] + s_blk[1280 + tid]) + (s_blk[1536 + tid] + s_blk[1792 + tid]);
+    const double bv = (s_blk[2048 + tid] + s_blk[2304 + tid]) + (s_blk[2560 + tid] + s_blk[2816 + tid]);
+    out[512 + tid] = bv;
+    if (phase == 0 && (tid >> 4) < 9 && (tid & 15) == (tid >> 4)) P.ghdk[g * 16 + (tid >> 4)] = bv;  // diag of H_kk
+  }
   if (tid == 0) {
     P.gstats[g * 2] = (sm[144] + sm[145]) + (sm[146] + sm[147]);
     P.gstats[g * 2 + 1] = (sm[140] + sm[141]) + (sm[142] + sm[143]);
@@ -429,6 +532,15 @@ __global__ __launch_bounds__(256) void k_rig_init(RigDev P) {
       }
     }
   }
+  if (P.K && !P.comm) {
+    // extension: diagonal of the intrinsics block summed over all groups
+    for (int j = 0; j < P.K; ++j) {
+      double h = 0.0;
+      for (int64_t g = tid; g < P.NG; g += 256) h += P.ghdk[g * 16 + j];
+      const double sum = block_sum256(h, s4);
+      if (tid == 0) s_ss[P.S6 + j] = jac ? 1.0 / (1.0 + sqrt(sum)) : 1.0;
+    }
+  }
   __syncthreads();
   if (tid < P.S) P.ss[tid] = s_ss[tid];
   if (tid == 0) {
@@ -438,6 +550,7 @@ __global__ __launch_bounds__(256) void k_rig_init(RigDev P) {
     for (int cc2 = 0; cc2 < P.C; ++cc2)
       if (!P.cam_fixed[cc2])
         for (int i = 0; i < 7; ++i) { const double v = P.cam[((size_t)c.cur * P.C + cc2) * 8 + i]; xn2 += v * v; }
+    for (int j = 0; j < P.K; ++j) { const double v = P.intr[c.cur * 16 + j]; xn2 += v * v; }
     lm_init(c, o, s_out[0], sqrt(xn2));
     *P.ctl = c;
     *P.ctl_next = c;
@@ -451,8 +564,15 @@ __global__ __launch_bounds__(256) void k_rig_init(RigDev P) {
 // Partial row: [0..NP) upper triangle of the reduced (6C)x(6C) system, [pc_b..) rhs, [pc_hd..) diag of
 // the scaled H_ss, [pc_fail] Cholesky failures, [pc_gs..) unscaled shared gradient, [pc_gmax] max |g_frame|.
 // ---------------------------------------------------------------------------------------------
+template <bool HK>
 __global__ __launch_bounds__(256) void k_rig_decide_elim(RigDev P) {
   __shared__ double LG[kRigMaxCams][256];
+  // extension (P.K != 0): AB tiles of the frame's groups, and the frame's sums over its groups of the
+  // intrinsics x intrinsics tile, of the frame-pose x intrinsics rows and of the intrinsics gradient
+  __shared__ double LGB[kRigMaxCams][256];
+  __shared__ double s_BB[256];
+  __shared__ double s_B[6][16];
+  __shared__ double s_gk[16];
   __shared__ double Zl[6][kRigMaxS + 4];
   __shared__ double s_A[28];  // 21 packed H_ff entries + 6 g_f
   __shared__ double s_ss[kRigMaxS];
@@ -508,7 +628,16 @@ __global__ __launch_bounds__(256) void k_rig_decide_elim(RigDev P) {
     if (tid < kRigMaxCams) s_slot[tid] = -1;
     __syncthreads();
     if (tid < ng) { const int cam = P.gcam[g0 + tid]; s_cam[tid] = cam; s_slot[cam] = tid; }
-    for (int s = 0; s < ng; ++s) LG[s][tid] = P.gblocks[((size_t)cur * P.NG + g0 + s) * 256 + tid];
+    for (int s = 0; s < ng; ++s) LG[s][tid] = P.gblocks[((size_t)cur * P.NG + g0 + s) * P.gstride + tid];
+    if (HK) {
+      double bb = 0.0;
+      for (int s = 0; s < ng; ++s) {
+        const double* gb = P.gblocks + ((size_t)cur * P.NG + g0 + s) * P.gstride;
+        LGB[s][tid] = gb[256 + tid];
+        bb += gb[512 + tid];
+      }
+      s_BB[tid] = bb;
+    }
     __syncthreads();
     // frame block: A = sum over groups of H_ff (rows/cols 6..11), g_f = sum of column 12
     if (tid < 21 + 6) {
@@ -523,6 +652,15 @@ __global__ __launch_bounds__(256) void k_rig_decide_elim(RigDev P) {
         for (int s = 0; s < ng; ++s) a += LG[s][(6 + i) * 16 + 12];
       }
       s_A[tid] = a;
+    } else if (HK && tid >= 32 && tid < 32 + 54) {
+      const int i = (tid - 32) / 9, j = (tid - 32) - i * 9;
+      double a = 0.0;
+      for (int s = 0; s < ng; ++s) a += LGB[s][(6 + i) * 16 + j];
+      s_B[i][j] = a;
+    } else if (HK && tid >= 96 && tid < 96 + 9) {
+      double a = 0.0;
+      for (int s = 0; s < ng; ++s) a += LGB[s][12 * 16 + (tid - 96)];
+      s_gk[tid - 96] = a;
     }
     __syncthreads();
     double sf[6], L[21], Li[6];
@@ -564,10 +702,13 @@ __global__ __launch_bounds__(256) void k_rig_decide_elim(RigDev P) {
     if (tid < P.SW) {
       const int k = tid;
       double w[6];
-      if (k < P.S) {
+      if (k < P.S6) {
         const int cam = k / 6, a = k - cam * 6, slot = s_slot[cam];
 #pragma unroll
         for (int i = 0; i < 6; ++i) w[i] = slot >= 0 ? sf[i] * LG[slot][a * 16 + 6 + i] * s_ss[k] : 0.0;
+      } else if (HK && k < P.S) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[i] = sf[i] * s_B[i][k - P.S6] * s_ss[k];
       } else {
 #pragma unroll
         for (int i = 0; i < 6; ++i) w[i] = sf[i] * s_A[21 + i];
@@ -600,32 +741,43 @@ __global__ __launch_bounds__(256) void k_rig_decide_elim(RigDev P) {
       if (o >= P.PC) continue;
       double a = 0.0;
       if (o < P.NP) {
+        // pair (p, q), p <= q, of shared columns: camera columns exist in this frame only if the camera
+        // has a group here, intrinsics columns always do
         const int p = op[r], q = oq[r];
-        const int cp = p / 6, cq = q / 6;
-        const int sp_ = s_slot[cp], sq_ = s_slot[cq];
+        const bool pk = HK && p >= P.S6, qk = HK && q >= P.S6;
+        const int cp = pk ? 0 : p / 6, cq = qk ? 0 : q / 6;
+        const int sp_ = pk ? 0 : s_slot[cp], sq_ = qk ? 0 : s_slot[cq];
         if (sp_ >= 0 && sq_ >= 0) {
-          if (cp == cq) a = s_ss[p] * LG[sp_][(p - cp * 6) * 16 + (q - cq * 6)] * s_ss[q];
+          if (pk) a = s_ss[p] * s_BB[(p - P.S6) * 16 + (q - P.S6)] * s_ss[q];                 // k x k
+          else if (qk) a = s_ss[p] * LGB[sp_][(p - cp * 6) * 16 + (q - P.S6)] * s_ss[q];       // camera x k
+          else if (cp == cq) a = s_ss[p] * LG[sp_][(p - cp * 6) * 16 + (q - cq * 6)] * s_ss[q];
 #pragma unroll
           for (int i = 0; i < 6; ++i) a -= Zl[i][p] * Zl[i][q];
         }
         acc[r] += a;
       } else if (o < P.pc_hd) {
-        const int p = o - P.pc_b, cp = p / 6, sl = s_slot[cp];
+        const int p = o - P.pc_b;
+        const bool pk = HK && p >= P.S6;
+        const int cp = pk ? 0 : p / 6, sl = pk ? 0 : s_slot[cp];
         if (sl >= 0) {
-          a = s_ss[p] * LG[sl][(p - cp * 6) * 16 + 12];
+          a = pk ? s_ss[p] * s_gk[p - P.S6] : s_ss[p] * LG[sl][(p - cp * 6) * 16 + 12];
 #pragma unroll
           for (int i = 0; i < 6; ++i) a -= Zl[i][p] * Zl[i][P.S];
         }
         acc[r] += a;
       } else if (o < P.pc_fail) {
-        const int p = o - P.pc_hd, cp = p / 6, sl = s_slot[cp];
-        if (sl >= 0) a = s_ss[p] * s_ss[p] * LG[sl][(p - cp * 6) * 17];
+        const int p = o - P.pc_hd;
+        const bool pk = HK && p >= P.S6;
+        const int cp = pk ? 0 : p / 6, sl = pk ? 0 : s_slot[cp];
+        if (sl >= 0) a = pk ? s_ss[p] * s_ss[p] * s_BB[(p - P.S6) * 17] : s_ss[p] * s_ss[p] * LG[sl][(p - cp * 6) * 17];
         acc[r] += a;
       } else if (o == P.pc_fail) {
         acc[r] += ok ? 0.0 : 1.0;
       } else if (o < P.pc_gmax) {
-        const int p = o - P.pc_gs, cp = p / 6, sl = s_slot[cp];
-        if (sl >= 0) a = LG[sl][(p - cp * 6) * 16 + 12];
+        const int p = o - P.pc_gs;
+        const bool pk = HK && p >= P.S6;
+        const int cp = pk ? 0 : p / 6, sl = pk ? 0 : s_slot[cp];
+        if (sl >= 0) a = pk ? s_gk[p - P.S6] : LG[sl][(p - cp * 6) * 16 + 12];
         acc[r] += a;
       } else {
         for (int i = 0; i < 6; ++i) a = fmax(a, fabs(s_A[21 + i]));
@@ -734,7 +886,10 @@ __global__ __launch_bounds__(256) void k_rig_solve(RigDev P) {
   const bool my_cam_fixed = lane < P.C && P.cam_fixed[lane] != 0;
   const unsigned long long fixed_mask = __ballot(my_cam_fixed);  // bit c: camera c is held constant (every wave)
   const bool row = tid < S;                                       // rows live in wave 0 (S <= 60)
-  const bool row_fixed = row && ((fixed_mask >> (i / 6)) & 1ull);
+  // columns 0..S6-1 belong to cameras (6 each), S6..S-1 to the shared intrinsics (extension)
+  const int S6 = P.S6;
+  const uint32_t kmask = P.kmask;
+  const bool row_fixed = row && (i < S6 ? ((fixed_mask >> (i / 6)) & 1ull) != 0 : ((kmask >> (i - S6)) & 1u) != 0);
   bool step_ok = false, converged = false;
   int early_term = CC_CONVERGENCE_GRADIENT;
   double gmax = 0.0;
@@ -768,7 +923,9 @@ __global__ __launch_bounds__(256) void k_rig_solve(RigDev P) {
     for (int idx = tid; idx < P.NP; idx += 256) {
       const int p = P.pair_p[idx], q = P.pair_q[idx];  // p <= q
       double a = P.vec[idx];
-      if (((fixed_mask >> (p / 6)) | (fixed_mask >> (q / 6))) & 1ull) a = p == q ? 1.0 : 0.0;
+      const bool pf = p < S6 ? ((fixed_mask >> (p / 6)) & 1ull) != 0 : ((kmask >> (p - S6)) & 1u) != 0;
+      const bool qf = q < S6 ? ((fixed_mask >> (q / 6)) & 1ull) != 0 : ((kmask >> (q - S6)) & 1u) != 0;
+      if (pf || qf) a = p == q ? 1.0 : 0.0;
       else if (p == q) a += clampd(P.vec[P.pc_hd + p], o.min_lm_diagonal, o.max_lm_diagonal) / radius;
       A[q][p] = a;
     }
@@ -854,6 +1011,20 @@ __global__ __launch_bounds__(256) void k_rig_solve(RigDev P) {
     for (int k = 0; k < 3; ++k) rec[9 + k] = t[k];
     for (int k = 0; k < 6; ++k) rec[12 + k] = dc[k];
   }
+  if (P.K && lane >= S6 && lane < S6 + P.K) {
+    // extension: candidate intrinsics (lane S6 + j owns the step of intrinsic j); every intrinsic counts
+    // in |x| (cf. IntrinsicsProblem), frozen ones do not move
+    const int j = lane - S6;
+    const double kc = P.intr[cur * 16 + j];
+    double dk = 0.0;
+    if (phase != 0 && step_ok && !((kmask >> j) & 1u)) dk = -bi * P.ss[lane];
+    const double kn = kc + dk;
+    if (phase == 0 || step_ok) {
+      if (phase != 0) { P.intr[dst * 16 + j] = kn; step2 += dk * dk; xn2 = kn * kn; }
+      P.krec[j] = kn;
+      P.krec[16 + j] = dk;
+    }
+  }
   const double st = wave_sum(step2);
   const double xs = wave_sum(xn2);
   if (lane == 0) {
@@ -891,8 +1062,14 @@ __global__ void k_rig_obs_cost(RigDev P, int cur, double* out /*sorted order*/) 
     RigObs o;
     rig_common(Rf, pf + 4, Rc, pc + 4, (double)P.wxyz[w * 3], (double)P.wxyz[w * 3 + 1], (double)P.wxyz[w * 3 + 2],
                (double)m.x, (double)m.y, o);
+    double ru = o.ru, rv = o.rv;
+    if (P.K) {
+      RigKObs ko;
+      rigk_obs(P.intr + cur * 16, o, (double)m.x, (double)m.y, ko);
+      ru = ko.ru; rv = ko.rv;
+    }
     double rho, sr;
-    huber(P.huber_a, o.ru * o.ru + o.rv * o.rv, rho, sr);
+    huber(P.huber_a, ru * ru + rv * rv, rho, sr);
     out[idx] = 0.5 * rho;
   }
 }
@@ -925,6 +1102,8 @@ struct cc_rig {
   int graph_iters = 0;
   cc::Comm* comm = nullptr;
   cc::Mailbox mailbox;          // mailbox exchange (cc_rig_exchange_export / _attach)
+  double* init_intr = nullptr;  // [16] (extension)
+  bool have_intr = false;
   bool exchange = false;
   uint8_t* d_cam_fixed = nullptr;          // same memory as d.cam_fixed
   std::vector<uint8_t> frozen, seen;       // host copies (user freeze flags, locally observed cameras)
@@ -963,13 +1142,15 @@ static int rig_enqueue_round(cc_rig* h, bool initial) {
   }
   hipLaunchKernelGGL(k_rig_solve, dim3(1), dim3(256), 0, h->stream, d);
   hipLaunchKernelGGL(k_rig_update, dim3((unsigned)((h->F + 15) / 16)), dim3(256), 0, h->stream, d);
-  hipLaunchKernelGGL(k_rig_sweep, dim3((unsigned)h->NG), dim3(kRigThreads), kRigSweepLdsBytes, h->stream, d);
+  if (d.K) hipLaunchKernelGGL(k_rig_sweep<true>, dim3((unsigned)h->NG), dim3(kRigThreads), kRigSweepLdsBytesK, h->stream, d);
+  else hipLaunchKernelGGL(k_rig_sweep<false>, dim3((unsigned)h->NG), dim3(kRigThreads), kRigSweepLdsBytes, h->stream, d);
   if (h->comm || h->exchange) {
     hipLaunchKernelGGL(k_rig_stats, dim3(1), dim3(256), 0, h->stream, d);
     if (h->comm) if (int rc = comm_allreduce_sum(h->comm, d.vec_stats, 4 + d.S, h->stream)) return rc;
   }
   if (initial) hipLaunchKernelGGL(k_rig_init, dim3(1), dim3(256), 0, h->stream, d);
-  hipLaunchKernelGGL(k_rig_decide_elim, dim3(d.nblk), dim3(256), 0, h->stream, d);
+  if (d.K) hipLaunchKernelGGL(k_rig_decide_elim<true>, dim3(d.nblk), dim3(256), 0, h->stream, d);
+  else hipLaunchKernelGGL(k_rig_decide_elim<false>, dim3(d.nblk), dim3(256), 0, h->stream, d);
   return 0;
 }
 
@@ -999,12 +1180,13 @@ struct RigCreateGuard {  // releases a half-built handle on every early return
 
 extern "C" {
 
-int cc_rig_create(int32_t device, int64_t C, int64_t F, int64_t n_world, const int64_t* off,
-                  const uint32_t* obs_cam, const uint64_t* obs_world, const float* obs_uv,
-                  const float* world_xyz, const uint8_t* cam_frozen, double huber_a, cc_rig** out) {
+static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world, const int64_t* off,
+                           const uint32_t* obs_cam, const uint64_t* obs_world, const float* obs_uv,
+                           const float* world_xyz, const uint8_t* cam_frozen, double huber_a, int K, cc_rig** out) {
   using namespace cc;
   if (!out || !off || C < 1 || F < 1 || n_world < 0) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: bad arguments");
   if (C > kRigMaxCams) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: at most %d cameras", kRigMaxCams);
+  if (6 * C + K > kRigMaxS) return fail(CC_ERR_BAD_ARGUMENT, "cc_rigk_create: at most %d cameras with shared intrinsics", (kRigMaxS - K) / 6);
   if (off[0] != 0) return fail(CC_ERR_BAD_ARGUMENT, "obs_frame_offsets[0] must be 0");
   const int64_t N = off[F];
   for (int64_t f = 0; f < F; ++f)
@@ -1061,7 +1243,7 @@ int cc_rig_create(int32_t device, int64_t C, int64_t F, int64_t n_world, const i
   }
   std::vector<uint8_t> fixed((size_t)C);
   for (int64_t c = 0; c < C; ++c) fixed[c] = ((cam_frozen && cam_frozen[c]) || !seen[c]) ? 1 : 0;
-  const int S = (int)(6 * C);
+  const int S = (int)(6 * C) + K;
   std::vector<uint8_t> pp, pq;
   for (int p = 0; p < S; ++p) for (int q = p; q < S; ++q) { pp.push_back((uint8_t)p); pq.push_back((uint8_t)q); }
 
@@ -1070,8 +1252,9 @@ int cc_rig_create(int32_t device, int64_t C, int64_t F, int64_t n_world, const i
   d.F = F; d.N = N; d.NG = NG; d.C = (int32_t)C; d.S = S; d.SW = S + 1; d.NP = S * (S + 1) / 2;
   d.pc_b = d.NP; d.pc_hd = d.NP + S; d.pc_fail = d.NP + 2 * S; d.pc_gs = d.pc_fail + 1; d.pc_gmax = d.pc_gs + S; d.PC = d.pc_gmax + 1;
   d.nblk = (int)std::min<int64_t>(kRigMaxElimBlocks, F);
-  d.huber_a = huber_a;
+  d.huber_a = (K && !(huber_a > 0.0)) ? 1e300 : huber_a;   // extension: a <= 0 switches the loss off
   d.comm = 0; d.rank = 0; d.nranks = 1;
+  d.K = K; d.S6 = (int32_t)(6 * C); d.gstride = K ? 768 : 256; d.kmask = 0;
   h->frozen.assign((size_t)C, 0);
   if (cam_frozen) for (int64_t c = 0; c < C; ++c) h->frozen[(size_t)c] = cam_frozen[c] ? 1 : 0;
   h->seen = seen;
@@ -1093,7 +1276,15 @@ int cc_rig_create(int32_t device, int64_t C, int64_t F, int64_t n_world, const i
   if (int rc = dev_alloc(h, &d.pose, (size_t)2 * F * 8)) return rc;
   if (int rc = dev_alloc(h, &d.camrec, (size_t)C * 32)) return rc;
   if (int rc = dev_alloc(h, &d.frec, (size_t)F * 32)) return rc;
-  if (int rc = dev_alloc(h, &d.gblocks, (size_t)2 * NG * 256)) return rc;
+  if (int rc = dev_alloc(h, &d.gblocks, (size_t)2 * NG * d.gstride)) return rc;
+  if (int rc = dev_alloc(h, &d.intr, (size_t)32)) return rc;
+  if (int rc = dev_alloc(h, &d.krec, (size_t)32)) return rc;
+  if (int rc = dev_alloc(h, &d.ghdk, (size_t)(K ? NG * 16 : 16))) return rc;
+  if (int rc = dev_alloc(h, &h->init_intr, (size_t)16)) return rc;
+  CC_HIP(hipMemset(d.intr, 0, 32 * sizeof(double)));
+  CC_HIP(hipMemset(d.krec, 0, 32 * sizeof(double)));
+  CC_HIP(hipMemset(d.ghdk, 0, (size_t)(K ? NG * 16 : 16) * sizeof(double)));
+  CC_HIP(hipMemset(h->init_intr, 0, 16 * sizeof(double)));
   if (int rc = dev_alloc(h, &d.gstats, (size_t)NG * 2)) return rc;
   if (int rc = dev_alloc(h, &d.fstats, (size_t)F * 2)) return rc;
   if (int rc = dev_alloc(h, &d.ghd0, (size_t)NG * 8)) return rc;
@@ -1131,9 +1322,52 @@ int cc_rig_create(int32_t device, int64_t C, int64_t F, int64_t n_world, const i
   CC_HIP(hipMemset(d.ctl, 0, sizeof(LmCtl)));
   CC_HIP(hipMemset(d.ctl_next, 0, sizeof(LmCtl)));
   CC_HIP(hipHostMalloc(&h->h_ctl, sizeof(LmCtl), hipHostMallocDefault));
-  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_sweep), hipFuncAttributeMaxDynamicSharedMemorySize, kRigSweepLdsBytes));
+  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_sweep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kRigSweepLdsBytes));
+  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_sweep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kRigSweepLdsBytesK));
   guard.ok = true;
   *out = h;
+  return CC_OK;
+}
+
+int cc_rig_create(int32_t device, int64_t C, int64_t F, int64_t n_world, const int64_t* off,
+                  const uint32_t* obs_cam, const uint64_t* obs_world, const float* obs_uv,
+                  const float* world_xyz, const uint8_t* cam_frozen, double huber_a, cc_rig** out) {
+  return rig_create_impl(device, C, F, n_world, off, obs_cam, obs_world, obs_uv, world_xyz, cam_frozen, huber_a, 0, out);
+}
+
+// EXTENSION: the same handle with 9 intrinsics shared by all cameras; obs_uv in pixels
+int cc_rigk_create(int32_t device, int64_t C, int64_t F, int64_t n_world, const int64_t* off,
+                   const uint32_t* obs_cam, const uint64_t* obs_world, const float* obs_uv_pixels,
+                   const float* world_xyz, const uint8_t* cam_frozen, double huber_a, cc_rig** out) {
+  return rig_create_impl(device, C, F, n_world, off, obs_cam, obs_world, obs_uv_pixels, world_xyz, cam_frozen, huber_a,
+                         cc::kRigK, out);
+}
+
+int cc_rigk_set_intrinsics(cc_rig* h, const double* intr9, uint32_t const_mask) {
+  using namespace cc;
+  if (!h || !intr9) return fail(CC_ERR_BAD_ARGUMENT, "cc_rigk_set_intrinsics: NULL argument");
+  if (!h->d.K) return fail(CC_ERR_STATE, "cc_rigk_set_intrinsics: the handle was created without intrinsics (cc_rig_create)");
+  CC_HIP(hipSetDevice(h->device));
+  CC_HIP(hipStreamSynchronize(h->stream));
+  double k16[16] = {0};
+  for (int i = 0; i < 9; ++i) k16[i] = intr9[i];
+  CC_HIP(hipMemcpy(h->init_intr, k16, sizeof(k16), hipMemcpyHostToDevice));
+  if (h->d.kmask != (const_mask & 0x1ffu)) rig_drop_graphs(h);   // the mask is a kernel argument
+  h->d.kmask = const_mask & 0x1ffu;
+  h->have_intr = true;
+  return h->have_state ? cc_rig_reset(h) : CC_OK;
+}
+
+int cc_rigk_get_intrinsics(cc_rig* h, double* intr9) {
+  using namespace cc;
+  if (!h || !intr9) return fail(CC_ERR_BAD_ARGUMENT, "cc_rigk_get_intrinsics: NULL argument");
+  if (!h->d.K) return fail(CC_ERR_STATE, "cc_rigk_get_intrinsics: the handle was created without intrinsics");
+  CC_HIP(hipSetDevice(h->device));
+  LmCtl c;
+  if (int rc = rig_read_ctl(h, &c)) return rc;
+  double k16[16];
+  CC_HIP(hipMemcpy(k16, h->d.intr + (size_t)(c.cur & 1) * 16, sizeof(k16), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 9; ++i) intr9[i] = k16[i];
   return CC_OK;
 }
 
@@ -1178,12 +1412,15 @@ int cc_rig_reset(cc_rig* h) {
   if (int rc = rig_write_ctl(h, c)) return rc;
   CC_HIP(hipMemcpyAsync(h->d.cam, h->init_cam, (size_t)h->C * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   CC_HIP(hipMemcpyAsync(h->d.pose, h->init_pose, (size_t)h->F * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  if (h->d.K) CC_HIP(hipMemcpyAsync(h->d.intr, h->init_intr, 16 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   return CC_OK;
 }
 
 int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
   using namespace cc;
   if (!h || !h->have_state) return fail(CC_ERR_STATE, "cc_rig_solve: no state set");
+  if (h->d.K && !h->have_intr) return fail(CC_ERR_STATE, "cc_rig_solve: cc_rigk_set_intrinsics has not been called");
+  if (h->d.K && (h->comm || h->exchange)) return fail(CC_ERR_STATE, "cc_rig_solve: the intrinsics extension is single-GPU");
   const auto t0 = std::chrono::steady_clock::now();
   cc_options o;
   if (opt) o = *opt; else { cc_options_init(&o); o.max_iterations = 1000; }  // extrinsics_calibrator.cpp:211
@@ -1197,6 +1434,7 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
     if (st.cur & 1) {
       CC_HIP(hipMemcpyAsync(h->d.cam, h->d.cam + (size_t)h->C * 8, (size_t)h->C * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
       CC_HIP(hipMemcpyAsync(h->d.pose, h->d.pose + (size_t)h->F * 8, (size_t)h->F * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+      if (h->d.K) CC_HIP(hipMemcpyAsync(h->d.intr, h->d.intr + 16, 16 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     }
     LmOpts lo;
     opts_from_public(o, &lo);

@@ -206,6 +206,20 @@ int cc_rig_comm_init(cc_rig* h, const uint8_t id[128], int32_t rank, int32_t nra
 int cc_rig_exchange_export(cc_rig* h, uint8_t handle[64]);
 int cc_rig_exchange_attach(cc_rig* h, int32_t rank, int32_t nranks, const uint8_t* handles);
 
+/* EXTENSION (BASELINE.json configs[3]-[4] name it, nothing in the reference does it):
+ * the rig problem with 9 intrinsics (fx fy px py k1 k2 p1 p2 k3, calibrator.cpp:168-179) shared by all
+ * cameras and co-optimised with the poses. Observations are PIXELS: the residual is the composition of
+ * ReprojectionErrorExtrinsics (extrinsics_calibrator.cpp:51-84) and DistortNormalized/DistortPixels
+ * (calibrator.cpp:70-95). huber_a is in pixels, <= 0 switches the loss off. At most 8 cameras; single GPU.
+ * The handle is a cc_rig: set_state / reset / solve / get_state / eval / destroy are the cc_rig_* calls;
+ * cc_rigk_set_intrinsics must be called once before the first solve (const_mask bit i freezes intrinsic i). */
+int cc_rigk_create(int32_t device, int64_t n_cams, int64_t n_frames, int64_t n_world,
+                   const int64_t* obs_frame_offsets, const uint32_t* obs_cam, const uint64_t* obs_world,
+                   const float* obs_uv_pixels, const float* world_xyz, const uint8_t* cam_frozen,
+                   double huber_a, cc_rig** out);
+int cc_rigk_set_intrinsics(cc_rig* h, const double* intr9, uint32_t const_mask);
+int cc_rigk_get_intrinsics(cc_rig* h, double* intr9);
+
 /* One-shot: the call ExtrinsicsCalibrator::Optimize makes in place of
  * extrinsics_calibrator.cpp:92-225. opt == NULL -> cc_options_init with max_iterations = 1000. */
 int cc_rig_optimize(const cc_options* opt, int32_t device, int64_t n_cams, int64_t n_frames,

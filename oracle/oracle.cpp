@@ -156,6 +156,60 @@ inline void rig_eval(const double* Rf, const double* tf, const double* Rc, const
   }
 }
 
+// EXTENSION (no counterpart in the reference): the rig model composed with the
+// pixel model -- x_cam = R_c (R_f X + t_f) + t_c as in ReprojectionErrorExtrinsics
+// (extrinsics_calibrator.cpp:51-84), then DistortNormalized/DistortPixels with 9 intrinsics shared by
+// all cameras (calibrator.cpp:70-95); residual in pixels.
+// J rows: d res / d [cam rot(3), cam t(3), frame rot(3), frame t(3), k(9)].
+inline void rigk_eval(const double* k, const double* Rf, const double* tf, const double* Rc, const double* tc,
+                      const double* X, double u, double v, double* res, double (*J)[21]) {
+  const double b0 = Rf[0] * X[0] + Rf[1] * X[1] + Rf[2] * X[2];
+  const double b1 = Rf[3] * X[0] + Rf[4] * X[1] + Rf[5] * X[2];
+  const double b2 = Rf[6] * X[0] + Rf[7] * X[1] + Rf[8] * X[2];
+  const double r0 = b0 + tf[0], r1 = b1 + tf[1], r2_ = b2 + tf[2];  // X_rig
+  const double a0 = Rc[0] * r0 + Rc[1] * r1 + Rc[2] * r2_;
+  const double a1 = Rc[3] * r0 + Rc[4] * r1 + Rc[5] * r2_;
+  const double a2 = Rc[6] * r0 + Rc[7] * r1 + Rc[8] * r2_;
+  const double xc = a0 + tc[0], yc = a1 + tc[1], zc = a2 + tc[2];
+  const double iz = 1.0 / zc;
+  const double x = xc * iz, y = yc * iz;
+  const double fx = k[0], fy = k[1], px = k[2], py = k[3];
+  const double k1 = k[4], k2 = k[5], p1 = k[6], p2 = k[7], k3 = k[8];
+  const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+  const double m = 1.0 + k1 * r2 + k2 * r4 + k3 * r6;
+  const double xd = x * m + 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x);
+  const double yd = y * m + 2.0 * p2 * x * y + p1 * (r2 + 2.0 * y * y);
+  res[0] = fx * xd + px - u;
+  res[1] = fy * yd + py - v;
+  if (!J) return;
+  J[0][12] = xd; J[0][13] = 0;  J[0][14] = 1; J[0][15] = 0;
+  J[0][16] = fx * x * r2; J[0][17] = fx * x * r4; J[0][18] = fx * 2.0 * x * y;
+  J[0][19] = fx * (r2 + 2.0 * x * x); J[0][20] = fx * x * r6;
+  J[1][12] = 0;  J[1][13] = yd; J[1][14] = 0; J[1][15] = 1;
+  J[1][16] = fy * y * r2; J[1][17] = fy * y * r4; J[1][18] = fy * (r2 + 2.0 * y * y);
+  J[1][19] = fy * 2.0 * x * y; J[1][20] = fy * y * r6;
+  const double mp = k1 + 2.0 * k2 * r2 + 3.0 * k3 * r4;
+  const double dxx = m + 2.0 * mp * x * x + 2.0 * p1 * y + 6.0 * p2 * x;
+  const double dxy = 2.0 * mp * x * y + 2.0 * p1 * x + 2.0 * p2 * y;
+  const double dyy = m + 2.0 * mp * y * y + 2.0 * p2 * x + 6.0 * p1 * y;
+  double B[2][3];  // d res / d x_cam
+  B[0][0] = fx * dxx * iz; B[0][1] = fx * dxy * iz; B[0][2] = -(fx * dxx * x + fx * dxy * y) * iz;
+  B[1][0] = fy * dxy * iz; B[1][1] = fy * dyy * iz; B[1][2] = -(fy * dxy * x + fy * dyy * y) * iz;
+  for (int i = 0; i < 2; ++i) {
+    J[i][0] = 2.0 * (B[i][2] * a1 - B[i][1] * a2);
+    J[i][1] = 2.0 * (B[i][0] * a2 - B[i][2] * a0);
+    J[i][2] = 2.0 * (B[i][1] * a0 - B[i][0] * a1);
+    J[i][3] = B[i][0]; J[i][4] = B[i][1]; J[i][5] = B[i][2];
+    const double m0 = B[i][0] * Rc[0] + B[i][1] * Rc[3] + B[i][2] * Rc[6];
+    const double m1 = B[i][0] * Rc[1] + B[i][1] * Rc[4] + B[i][2] * Rc[7];
+    const double m2 = B[i][0] * Rc[2] + B[i][1] * Rc[5] + B[i][2] * Rc[8];
+    J[i][6] = 2.0 * (m2 * b1 - m1 * b2);
+    J[i][7] = 2.0 * (m0 * b2 - m2 * b0);
+    J[i][8] = 2.0 * (m1 * b0 - m0 * b1);
+    J[i][9] = m0; J[i][10] = m1; J[i][11] = m2;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Block-arrow LM (Ceres TrustRegionMinimizer + LevenbergMarquardtStrategy semantics,
 // exact Schur linear solve).  Shared block of tangent size S, F per-frame blocks of size 6.
@@ -665,6 +719,94 @@ struct RigProblem : ArrowProblem {
   }
 };
 
+// EXTENSION: rig poses + 9 shared intrinsics. Shared tangent = [cam 0 (6) ... cam C-1 (6) | k (9)],
+// ambient = [cam (7 each) | k (9)]; pixel observations; Huber on the pixel residual (a <= 0: off).
+struct RigKProblem : ArrowProblem {
+  int64_t C;
+  const int64_t* off;
+  const uint32_t* ocam;
+  const uint64_t* oworld;
+  const float* ouv;
+  const float* wxyz;
+  double huber_a;
+  uint32_t kmask;
+  std::vector<uint8_t> cam_fixed;
+  double* obs_cost = nullptr;
+
+  double eval(const double* shared, const double* fq, const double* ft, Blocks* B) override {
+    const int Sd = S;
+    const int K0 = (int)(6 * C);
+    const double* kk = shared + 7 * C;
+    const int nt = std::max(1, num_threads);
+    std::vector<double> Rc(C * 9);
+    for (int64_t c = 0; c < C; ++c) quat_to_R(&shared[c * 7], &Rc[c * 9]);
+    std::vector<double> cost_t(nt, 0.0);
+    std::vector<std::vector<double>> hs(nt);
+    if (B) { B->resize(F, Sd); for (auto& h : hs) h.assign((size_t)Sd * Sd + Sd, 0.0); }
+    parallel_frames(F, nt, [&](int64_t f0, int64_t f1, int tid) {
+      double c = 0;
+      for (int64_t f = f0; f < f1; ++f) {
+        double Rf[9];
+        quat_to_R(&fq[f * 4], Rf);
+        for (int64_t o = off[f]; o < off[f + 1]; ++o) {
+          const uint32_t cam = ocam[o];
+          const float* Xf = &wxyz[oworld[o] * 3];
+          const double X[3] = {Xf[0], Xf[1], Xf[2]};
+          double res[2], J[2][21];
+          rigk_eval(kk, Rf, &ft[f * 3], &Rc[cam * 9], &shared[cam * 7 + 4], X, ouv[o * 2], ouv[o * 2 + 1], res,
+                    B ? J : nullptr);
+          double rho = res[0] * res[0] + res[1] * res[1], sr = 1.0;
+          if (huber_a > 0.0) huber(huber_a, rho, &rho, &sr);
+          c += 0.5 * rho;
+          if (obs_cost) obs_cost[o] = 0.5 * rho;
+          if (!B) continue;
+          const bool fixed = cam_fixed[cam];
+          double* hss = hs[tid].data();
+          for (int r = 0; r < 2; ++r) {
+            // the row restricted to the shared block: 6 camera columns + 9 intrinsics columns
+            double vs[15], vf[6];
+            int col[15];
+            for (int i = 0; i < 6; ++i) { vs[i] = fixed ? 0.0 : sr * J[r][i]; col[i] = (int)cam * 6 + i; vf[i] = sr * J[r][6 + i]; }
+            for (int i = 0; i < 9; ++i) { vs[6 + i] = (kmask & (1u << i)) ? 0.0 : sr * J[r][12 + i]; col[6 + i] = K0 + i; }
+            const double rr = sr * res[r];
+            for (int i = 0; i < 6; ++i) {
+              for (int j = 0; j < 6; ++j) B->Hpp[f * 36 + i * 6 + j] += vf[i] * vf[j];
+              for (int j = 0; j < 15; ++j) B->Hps[(f * 6 + i) * Sd + col[j]] += vf[i] * vs[j];
+              B->gp[f * 6 + i] += vf[i] * rr;
+            }
+            for (int i = 0; i < 15; ++i) {
+              for (int j = 0; j < 15; ++j) hss[(size_t)col[i] * Sd + col[j]] += vs[i] * vs[j];
+              hss[(size_t)Sd * Sd + col[i]] += vs[i] * rr;
+            }
+          }
+        }
+      }
+      cost_t[tid] = c;
+    });
+    double cost = 0;
+    for (int t = 0; t < nt; ++t) {
+      cost += cost_t[t];
+      if (B) {
+        for (size_t i = 0; i < (size_t)Sd * Sd; ++i) B->Hss[i] += hs[t][i];
+        for (int i = 0; i < Sd; ++i) B->gs[i] += hs[t][(size_t)Sd * Sd + i];
+      }
+    }
+    return cost;
+  }
+  void plus_shared(const double* shared, const double* delta, double* out) override {
+    for (int64_t c = 0; c < C; ++c) {
+      if (cam_fixed[c]) {
+        for (int i = 0; i < 7; ++i) out[c * 7 + i] = shared[c * 7 + i];
+        continue;
+      }
+      quat_plus(&shared[c * 7], &delta[c * 6], &out[c * 7]);
+      for (int i = 0; i < 3; ++i) out[c * 7 + 4 + i] = shared[c * 7 + 4 + i] + delta[c * 6 + 3 + i];
+    }
+    for (int i = 0; i < 9; ++i)
+      out[7 * C + i] = shared[7 * C + i] + ((kmask & (1u << i)) ? 0.0 : delta[6 * C + i]);
+  }
+};
+
 // ------------------------------------------------------------------------------------------
 // float helpers restating Eigen-typed code of the reference
 // ------------------------------------------------------------------------------------------
@@ -970,6 +1112,59 @@ int oc_rig_solve_sharded(const oc_options* opt, int64_t C, int64_t F, int64_t n_
   (void)n_world;
   return rig_solve_impl(opt, C, F, off, ocam, oworld, ouv, wxyz, cam_q, cam_t, cam_frozen, cam_seen_global, frame_q,
                         frame_t, huber_a, obs_cost, summary, ar, ctx);
+}
+
+// EXTENSION: rig poses + shared intrinsics on pixel observations (see RigKProblem)
+void oc_rigk_residual(const double* k, const double* q_rw, const double* t_rw, const double* q_cr, const double* t_cr,
+                      const double* X, const double* uv, double* res, double* J) {
+  double Rf[9], Rc[9];
+  quat_to_R(q_rw, Rf);
+  quat_to_R(q_cr, Rc);
+  rigk_eval(k, Rf, t_rw, Rc, t_cr, X, uv[0], uv[1], res, reinterpret_cast<double(*)[21]>(J));
+}
+
+int oc_rigk_solve(const oc_options* opt, int64_t C, int64_t F, int64_t n_world, const int64_t* off,
+                  const uint32_t* ocam, const uint64_t* oworld, const float* ouv, const float* wxyz,
+                  double* intr, uint32_t kmask, double* cam_q, double* cam_t, const uint8_t* cam_frozen,
+                  double* frame_q, double* frame_t, double huber_a, double* obs_cost, oc_summary* summary) {
+  (void)n_world;
+  oc_options o;
+  if (opt) o = *opt; else { oc_options_init(&o); o.max_iterations = 1000; }
+  RigKProblem P;
+  P.C = C; P.F = F; P.S = (int)(6 * C + 9); P.S_amb = (int)(7 * C + 9);
+  P.off = off; P.ocam = ocam; P.oworld = oworld; P.ouv = ouv; P.wxyz = wxyz;
+  P.huber_a = huber_a; P.kmask = kmask;
+  P.num_threads = o.num_threads;
+  std::vector<uint8_t> cam_seen(C, 0);
+  P.frame_active.assign(F, 0);
+  for (int64_t f = 0; f < F; ++f)
+    for (int64_t k = off[f]; k < off[f + 1]; ++k) { cam_seen[ocam[k]] = 1; P.frame_active[f] = 1; }
+  P.cam_fixed.resize(C);
+  P.shared_fixed.assign(6 * C + 9, 0);
+  P.shared_amb_active.assign(7 * C + 9, 1);
+  for (int64_t c = 0; c < C; ++c) {
+    P.cam_fixed[c] = (cam_frozen && cam_frozen[c]) || !cam_seen[c];
+    for (int i = 0; i < 6; ++i) P.shared_fixed[c * 6 + i] = P.cam_fixed[c];
+    for (int i = 0; i < 7; ++i) P.shared_amb_active[c * 7 + i] = !P.cam_fixed[c];
+  }
+  for (int i = 0; i < 9; ++i) P.shared_fixed[6 * C + i] = (kmask >> i) & 1;
+  std::vector<double> shared(7 * C + 9);
+  for (int64_t c = 0; c < C; ++c) {
+    for (int i = 0; i < 4; ++i) shared[c * 7 + i] = cam_q[c * 4 + i];
+    for (int i = 0; i < 3; ++i) shared[c * 7 + 4 + i] = cam_t[c * 3 + i];
+  }
+  for (int i = 0; i < 9; ++i) shared[7 * C + i] = intr[i];
+  const int rc = run_lm(P, o, shared.data(), frame_q, frame_t, summary, nullptr, nullptr);
+  for (int64_t c = 0; c < C; ++c) {
+    for (int i = 0; i < 4; ++i) cam_q[c * 4 + i] = shared[c * 7 + i];
+    for (int i = 0; i < 3; ++i) cam_t[c * 3 + i] = shared[c * 7 + 4 + i];
+  }
+  for (int i = 0; i < 9; ++i) intr[i] = shared[7 * C + i];
+  if (obs_cost) {
+    P.obs_cost = obs_cost;
+    P.eval(shared.data(), frame_q, frame_t, nullptr);
+  }
+  return rc;
 }
 
 // ---- Zhang initialisation ----------------------------------------------------------------

@@ -135,6 +135,18 @@ int oc_rig_solve_sharded(const oc_options* opt, int64_t n_cams, int64_t n_frames
                          double* frame_q, double* frame_t, double huber_a, double* obs_cost,
                          oc_summary* summary, oc_allreduce_fn allreduce, void* ctx);
 
+/* ---- EXTENSION (nothing in the reference does this): rig poses + 9 intrinsics
+ * shared by all cameras, pixel observations = the two functors composed (extrinsics_calibrator.cpp:51-84
+ * then calibrator.cpp:70-95). J is 2x21 row-major: camera rot(3) t(3), frame rot(3) t(3), k(9).
+ * huber_a <= 0 switches the loss off; kmask bit i freezes intrinsic i (fx fy px py k1 k2 p1 p2 k3). ---- */
+void oc_rigk_residual(const double* intr9, const double* q_rw, const double* t_rw, const double* q_cr,
+                      const double* t_cr, const double* X, const double* uv, double* res, double* J);
+int oc_rigk_solve(const oc_options* opt, int64_t n_cams, int64_t n_frames, int64_t n_world,
+                  const int64_t* obs_frame_offsets, const uint32_t* obs_cam, const uint64_t* obs_world,
+                  const float* obs_uv_pixels, const float* world_xyz, double* intr9, uint32_t kmask,
+                  double* cam_q, double* cam_t, const uint8_t* cam_frozen, double* frame_q, double* frame_t,
+                  double huber_a, double* obs_cost, oc_summary* summary);
+
 /* ---- Zhang initialisation (src/geometry.cpp:70-203, src/calibrator.cpp:47-68) ---- */
 void oc_estimate_homography(int64_t n, const float* p1, int32_t stride1, const float* p2,
                             int32_t stride2, float* H9);

@@ -154,6 +154,44 @@ def rig_residual(q_rw, t_rw, q_cr, t_cr, X, uv, want_jacobian=True):
     return res, J
 
 
+def rigk_residual(intr, q_rw, t_rw, q_cr, t_cr, X, uv, want_jacobian=True):
+    """EXTENSION: rig model composed with the pixel model; J is 2x21 (cam 6, frame 6, intrinsics 9)."""
+    res = np.zeros(2)
+    J = np.zeros((2, 21)) if want_jacobian else None
+    lib().oc_rigk_residual(_p(_f64(intr), C.c_double), _p(_f64(q_rw), C.c_double), _p(_f64(t_rw), C.c_double),
+                           _p(_f64(q_cr), C.c_double), _p(_f64(t_cr), C.c_double),
+                           _p(_f64(X), C.c_double), _p(_f64(uv), C.c_double), _p(res, C.c_double),
+                           _p(J, C.c_double) if J is not None else None)
+    return res, J
+
+
+def rigk_solve(n_cams, frame_offsets, obs_cam, obs_world, obs_uv_pixels, world_xyz, intr, cam_q, cam_t,
+               cam_frozen, frame_q, frame_t, const_mask=0, huber_a=0.0, options=None, log_capacity=2048):
+    """EXTENSION: rig poses + shared intrinsics. Returns (intr, cam_q, cam_t, frame_q, frame_t, obs_cost, summary)."""
+    offs = np.ascontiguousarray(frame_offsets, dtype=np.int64)
+    F = len(offs) - 1
+    obs_cam = np.ascontiguousarray(obs_cam, dtype=np.uint32)
+    obs_world = np.ascontiguousarray(obs_world, dtype=np.uint64)
+    obs_uv, world_xyz = _f32(obs_uv_pixels), _f32(world_xyz)
+    intr = _f64(intr).copy()
+    cam_q, cam_t = _f64(cam_q).copy(), _f64(cam_t).copy()
+    frame_q, frame_t = _f64(frame_q).copy(), _f64(frame_t).copy()
+    frozen = np.ascontiguousarray(cam_frozen, dtype=np.uint8)
+    opt = options if options is not None else default_options(max_iterations=1000)
+    s, log = _summary(log_capacity)
+    cost = np.zeros(len(obs_cam))
+    n_world = C.c_int64(len(world_xyz) // 3 if world_xyz.ndim == 1 else world_xyz.shape[0])
+    rc = lib().oc_rigk_solve(C.byref(opt), C.c_int64(n_cams), C.c_int64(F), n_world, _p(offs, C.c_int64),
+                             _p(obs_cam, C.c_uint32), _p(obs_world, C.c_uint64), _p(obs_uv, C.c_float),
+                             _p(world_xyz, C.c_float), _p(intr, C.c_double), C.c_uint32(const_mask),
+                             _p(cam_q, C.c_double), _p(cam_t, C.c_double), _p(frozen, C.c_uint8),
+                             _p(frame_q, C.c_double), _p(frame_t, C.c_double), C.c_double(huber_a),
+                             _p(cost, C.c_double), C.byref(s))
+    if rc != 0:
+        raise RuntimeError(f"oc_rigk_solve failed: {rc}")
+    return intr, cam_q, cam_t, frame_q, frame_t, cost, summary_to_dict(s, log)
+
+
 def intrinsics_blocks(offsets, uv, xyz, intr, q, t, const_mask=0, want_blocks=True, num_threads=1):
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
     F = len(offsets) - 1

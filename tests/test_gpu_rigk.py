@@ -1,0 +1,72 @@
+"""EXTENSION: rig poses + 9 shared intrinsics on pixel observations (cc_rigk_*).
+Nothing in the reference does this; the checker is the oracle's own restatement of the composed model
+(oracle.cpp RigKProblem), itself validated on the CPU in tests/test_oracle_rigk.py."""
+import numpy as np
+import pytest
+
+from camera_calibrator_amd import capi
+from oracle import pyoracle as po
+from tests.helpers import RIGK_INTR_TRUE, rigk_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(k, const_mask=0, huber_a=0.0, **kw):
+    prob = capi.RigProblem(k["cams"], k["frame_offsets"], k["obs_cam"], k["obs_world"], k["obs_uv_pix"], k["world_xyz"],
+                           k["cam_frozen"], huber_a=huber_a, with_intrinsics=True)
+    prob.set_intrinsics(k["intr0"], const_mask)
+    prob.set_state(k["cam_q0"], k["cam_t0"], k["frame_q0"], k["frame_t0"])
+    s = prob.solve(capi.default_options(max_iterations=200, **kw))
+    g = (prob.get_intrinsics(),) + tuple(prob.get_state()) + (s,)
+    prob.close()
+    o = po.rigk_solve(k["cams"], k["frame_offsets"], k["obs_cam"], k["obs_world"], k["obs_uv_pix"], k["world_xyz"], k["intr0"],
+                      k["cam_q0"], k["cam_t0"], k["cam_frozen"], k["frame_q0"], k["frame_t0"], const_mask=const_mask,
+                      huber_a=huber_a, options=po.default_options(max_iterations=200, **kw))
+    return g, o
+
+
+def _assert_same(g, o):
+    sg, so = g[6], o[6]
+    assert sg["termination"] == so["termination"] and sg["iterations"] == so["iterations"]
+    assert [l["accepted"] for l in sg["log"]] == [l["accepted"] for l in so["log"]]
+    assert np.allclose([l["cost"] for l in sg["log"]], [l["cost"] for l in so["log"]], rtol=1e-9)
+    assert np.allclose(g[0][:4], o[0][:4], rtol=1e-9) and np.allclose(g[0][4:], o[0][4:], atol=1e-8)
+    for a in range(1, 5):
+        assert np.abs(g[a] - o[a]).max() < 1e-8
+    assert np.allclose(g[5], o[5], rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("cams,frames,pts", [(2, 50, 8), (4, 60, 30), (3, 20, 300), (8, 25, 70), (1, 40, 20)])
+def test_rigk_matches_oracle(cams, frames, pts):
+    g, o = _both(rigk_case(cams, frames, pts))
+    _assert_same(g, o)
+
+
+def test_rigk_frozen_intrinsics_and_huber():
+    k = rigk_case(3, 40, 25)
+    mask = (1 << 8) | (1 << 5)                       # k3 and k2 held constant (cf. cam_calibration.py:308)
+    g, o = _both(k, const_mask=mask, huber_a=1.0)
+    _assert_same(g, o)
+    assert g[0][8] == k["intr0"][8] and g[0][5] == k["intr0"][5]
+
+
+def test_rigk_recovers_the_planted_camera_and_rig():
+    k = rigk_case(4, 120, 40)
+    g, _ = _both(k)
+    assert np.abs(g[0][:2] / RIGK_INTR_TRUE[:2] - 1).max() < 5e-3 and np.abs(g[0][2:4] - RIGK_INTR_TRUE[2:4]).max() < 5.0
+    assert np.abs(g[2] - k["cam_t_true"]).max() < 0.2 * np.abs(k["cam_t0"] - k["cam_t_true"]).max()
+    assert np.array_equal(g[1][0], k["cam_q0"][0]) and np.array_equal(g[2][0], k["cam_t0"][0])   # frozen camera
+
+
+def test_rigk_needs_its_intrinsics_and_a_plain_handle_refuses_them():
+    k = rigk_case(2, 10, 6)
+    prob = capi.RigProblem(2, k["frame_offsets"], k["obs_cam"], k["obs_world"], k["obs_uv_pix"], k["world_xyz"],
+                           k["cam_frozen"], with_intrinsics=True)
+    prob.set_state(k["cam_q0"], k["cam_t0"], k["frame_q0"], k["frame_t0"])
+    with pytest.raises(capi.CcError, match="set_intrinsics"):
+        prob.solve()
+    prob.close()
+    plain = capi.RigProblem(2, k["frame_offsets"], k["obs_cam"], k["obs_world"], k["obs_uv_pix"], k["world_xyz"], k["cam_frozen"])
+    with pytest.raises(capi.CcError, match="without intrinsics"):
+        plain.set_intrinsics(k["intr0"])
+    plain.close()

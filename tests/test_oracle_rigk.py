@@ -1,0 +1,113 @@
+"""CPU validation of the oracle's EXTENSION model: rig poses + 9 shared intrinsics on
+pixel observations. The reference has no such code, so the oracle is checked against itself and against
+independent numerics: finite differences through the manifold Plus, consistency with the two functors it
+composes, recovery of a planted rig and camera, frozen coordinates, and scipy's least_squares."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests.helpers import RIGK_INTR_TRUE, quat_plus, rigk_case
+
+
+def _rand_state(rng):
+    qf = rng.normal(size=4); qf /= np.linalg.norm(qf)
+    qc = np.array([1.0, 0.02, -0.01, 0.03]); qc /= np.linalg.norm(qc)
+    X = rng.uniform(-0.2, 0.2, size=3)
+    tf = np.array([0.05, -0.03, 0.9]) + rng.uniform(-0.1, 0.1, size=3)
+    return qf * np.array([1, 0.05, 0.05, 0.05]) / np.linalg.norm(qf * np.array([1, 0.05, 0.05, 0.05])), tf, qc, np.array([0.02, -0.01, 0.01]), X
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_jacobian_matches_central_differences_through_plus(seed):
+    rng = np.random.default_rng(seed)
+    qf, tf, qc, tc, X = _rand_state(rng)
+    intr = RIGK_INTR_TRUE * (1 + 0.01 * rng.normal(size=9))
+    _, J = po.rigk_residual(intr, qf, tf, qc, tc, X, [0, 0])
+
+    def f(d):
+        return po.rigk_residual(intr + d[12:], quat_plus(qf, d[6:9]), tf + d[9:12], quat_plus(qc, d[0:3]), tc + d[3:6], X,
+                                [0, 0], want_jacobian=False)[0]
+    Jn = np.zeros((2, 21))
+    for j in range(21):
+        h = 1e-6 * max(1.0, abs(intr[j - 12])) if j >= 12 else 1e-6
+        d = np.zeros(21); d[j] = h
+        Jn[:, j] = (f(d) - f(-d)) / (2 * h)
+    assert np.abs(J - Jn).max() <= 2e-8 * np.abs(J).max()
+
+
+def test_composition_of_the_two_reference_functors():
+    """pixel residual = DistortPixels(normalised point of the rig functor); with an identity frame the
+    intrinsics columns equal those of the single-camera functor."""
+    rng = np.random.default_rng(3)
+    qf, tf, qc, tc, X = _rand_state(rng)
+    res_n, _ = po.rig_residual(qf, tf, qc, tc, X, [0, 0], want_jacobian=False)       # normalised coordinates
+    K = np.array([[RIGK_INTR_TRUE[0], 0, RIGK_INTR_TRUE[2]], [0, RIGK_INTR_TRUE[1], RIGK_INTR_TRUE[3]], [0, 0, 1]])
+    pix = po.distort(K.astype(np.float32), RIGK_INTR_TRUE[4:].astype(np.float32), res_n.astype(np.float32)[None, :])[0]
+    res_k, Jk = po.rigk_residual(RIGK_INTR_TRUE, qf, tf, qc, tc, X, [0, 0])
+    assert np.allclose(res_k, pix, rtol=2e-6, atol=1e-3)                              # float32 Distort vs double
+    res_i, Ji = po.intrinsics_residual(RIGK_INTR_TRUE, qc, tc, _rig_point(qf, tf, X), [0, 0])
+    assert np.allclose(res_k, res_i, rtol=1e-12) and np.allclose(Jk[:, 12:], Ji[:, :9], rtol=1e-12)
+    assert np.allclose(Jk[:, 0:6], Ji[:, 9:15], rtol=1e-12)                           # camera pose columns
+
+
+def _rig_point(qf, tf, X):
+    from tests.helpers import _quat_to_R
+    return _quat_to_R(qf) @ X + tf
+
+
+def _solve(k, **kw):
+    return po.rigk_solve(k["cams"], k["frame_offsets"], k["obs_cam"], k["obs_world"], k["obs_uv_pix"], k["world_xyz"], k["intr0"],
+                         k["cam_q0"], k["cam_t0"], k["cam_frozen"], k["frame_q0"], k["frame_t0"], **kw)
+
+
+def test_recovers_the_planted_rig_and_camera():
+    k = rigk_case(4, 120, 40)
+    r = _solve(k)
+    assert r[6]["termination"] in ("FUNCTION", "PARAMETER", "GRADIENT") and r[6]["final_cost"] < 1e-2 * r[6]["initial_cost"]
+    assert np.abs(r[0][:2] / RIGK_INTR_TRUE[:2] - 1).max() < 5e-3
+    assert np.abs(r[2] - k["cam_t_true"]).max() < 0.2 * np.abs(k["cam_t0"] - k["cam_t_true"]).max()
+    assert np.array_equal(r[1][0], k["cam_q0"][0]) and np.array_equal(r[2][0], k["cam_t0"][0])
+    assert np.isclose(r[5].sum(), r[6]["final_cost"], rtol=1e-10)
+
+
+def test_frozen_intrinsics_do_not_move_and_huber_only_lowers_the_cost():
+    k = rigk_case(3, 40, 25)
+    mask = (1 << 8) | (1 << 5) | (1 << 2)
+    r = _solve(k, const_mask=mask)
+    for j in (8, 5, 2):
+        assert r[0][j] == k["intr0"][j]
+    rh = _solve(k, const_mask=mask, huber_a=1.0)
+    assert rh[6]["final_cost"] <= r[6]["final_cost"]
+
+
+def test_minimiser_agrees_with_scipy_least_squares():
+    from scipy.optimize import least_squares
+    k = rigk_case(2, 12, 10, pixel_noise=0.3)
+    mask = 0b111100000                                                               # distortion frozen: well posed
+    r = _solve(k, const_mask=mask, options=po.default_options(max_iterations=200, function_tolerance=1e-15,
+                                                              gradient_tolerance=1e-13, parameter_tolerance=1e-14))
+    F, C_ = 12, 2
+    q_c, t_c, q_f, t_f = r[1].copy(), r[2].copy(), r[3].copy(), r[4].copy()
+
+    def unpack(x):
+        intr = r[0].copy(); intr[:4] = x[:4]
+        cq, ct = q_c.copy(), t_c.copy()
+        cq[1] = quat_plus(q_c[1], x[4:7]); ct[1] = t_c[1] + x[7:10]
+        fq = np.array([quat_plus(q_f[f], x[10 + 6 * f:13 + 6 * f]) for f in range(F)])
+        ft = t_f + x[10:].reshape(F, 6)[:, 3:]
+        return intr, cq, ct, fq, ft
+
+    def fun(x):
+        intr, cq, ct, fq, ft = unpack(x)
+        out = []
+        off = k["frame_offsets"]
+        for f in range(F):
+            for o in range(off[f], off[f + 1]):
+                c = k["obs_cam"][o]
+                out.append(po.rigk_residual(intr, fq[f], ft[f], cq[c], ct[c], k["world_xyz"][k["obs_world"][o]],
+                                            k["obs_uv_pix"][o], want_jacobian=False)[0])
+        return np.concatenate(out)
+    x0 = np.concatenate([r[0][:4], np.zeros(6 + 6 * F)])
+    sol = least_squares(fun, x0, method="lm", xtol=1e-15, ftol=1e-15, gtol=1e-15)
+    assert np.isclose(0.5 * np.sum(sol.fun ** 2), r[6]["final_cost"], rtol=1e-9)       # already at the minimum
+    assert np.abs(sol.x[:4] - r[0][:4]).max() < 1e-5 * 1000 and np.abs(sol.x[4:]).max() < 1e-6
