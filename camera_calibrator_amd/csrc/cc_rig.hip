@@ -13,6 +13,11 @@
 //   sweep  : per group, residuals + Jacobian rows + Huber scaling -> Gram block, cost, model term
 //   init   : (first evaluation only) Jacobi scaling of the shared block, trust-region state
 //   decide+elim : trust-region decision; per frame 6x6 Cholesky and Schur complement partials
+//   reduce : column sums of the elimination partials (and, multi-GPU, their posting to the mailboxes)
+//
+// EXTENSION (cc_rigk_*, SURVEY 8f rank 4, no counterpart in the reference): the same kernels, templated
+// where it matters, with 9 intrinsics shared by all cameras appended to the shared block and pixel
+// observations (see k_rig_sweep<true>).
 #include <algorithm>
 #include <chrono>
 #include <numeric>
@@ -914,7 +919,6 @@ __global__ __launch_bounds__(256) void k_rig_solve(RigDev P) {
     // ---- reduced sums from k_rig_reduce: packed upper triangle -> lower triangle in LDS; rows and
     // columns of constant cameras become identity. Everything is issued in one round trip.
     const double b_in = row ? P.vec[P.pc_b + i] : 0.0;
-    const double hd_i = row ? P.vec[P.pc_hd + i] : 0.0;
     const double gs_i = row ? P.vec[P.pc_gs + i] : 0.0;
     const double fail = P.vec[P.pc_fail];
     const double gm_r = (tid < P.nranks && tid < 32) ? P.vec[P.PC + tid] : 0.0;
