@@ -47,6 +47,18 @@ def load_traffic():
         return None
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask and cgroup CPU quota, not the node's count."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -283,7 +295,7 @@ def main():
                 its += so["iterations"]
                 secs += so["seconds"]
                 n_solves += 1
-            cores = os.cpu_count() or 1
+            cores = usable_cores()
             om = po.default_options(num_threads=cores)
             _, _, _, sm = po.intrinsics_solve(off, uv, xyz, intr0, q0, t0, options=om, log_capacity=0)
             cpu_res = 2.0 * n_obs_total * its / secs
