@@ -469,6 +469,13 @@ __global__ __launch_bounds__(256) void k_rig_stats(RigDev P) {
       if (tid == 0) P.vec_stats[4 + c * 6 + i] = s;
     }
   }
+  for (int j = 0; j < P.K; ++j) {   // extension: diagonal of the intrinsics block (Jacobi scaling)
+    double hk = 0.0;
+    if (phase == 0)
+      for (int64_t g = tid; g < P.NG; g += 256) hk += P.ghdk[g * 16 + j];
+    const double sum = block_sum256(hk, s4);
+    if (tid == 0) P.vec_stats[4 + P.S6 + j] = sum;
+  }
   if (P.x.on) {
     // mailbox exchange (kind 1): post the local statistics, wait for every rank's, write the sums back
     // (k_rig_init / k_rig_decide_elim read vec_stats as they do after an all-reduce)
@@ -1424,7 +1431,6 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
   using namespace cc;
   if (!h || !h->have_state) return fail(CC_ERR_STATE, "cc_rig_solve: no state set");
   if (h->d.K && !h->have_intr) return fail(CC_ERR_STATE, "cc_rig_solve: cc_rigk_set_intrinsics has not been called");
-  if (h->d.K && (h->comm || h->exchange)) return fail(CC_ERR_STATE, "cc_rig_solve: the intrinsics extension is single-GPU");
   const auto t0 = std::chrono::steady_clock::now();
   cc_options o;
   if (opt) o = *opt; else { cc_options_init(&o); o.max_iterations = 1000; }  // extrinsics_calibrator.cpp:211

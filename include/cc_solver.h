@@ -210,7 +210,8 @@ int cc_rig_exchange_attach(cc_rig* h, int32_t rank, int32_t nranks, const uint8_
  * the rig problem with 9 intrinsics (fx fy px py k1 k2 p1 p2 k3, calibrator.cpp:168-179) shared by all
  * cameras and co-optimised with the poses. Observations are PIXELS: the residual is the composition of
  * ReprojectionErrorExtrinsics (extrinsics_calibrator.cpp:51-84) and DistortNormalized/DistortPixels
- * (calibrator.cpp:70-95). huber_a is in pixels, <= 0 switches the loss off. At most 8 cameras; single GPU.
+ * (calibrator.cpp:70-95). huber_a is in pixels, <= 0 switches the loss off. At most 8 cameras. Multi-GPU
+ * through cc_rig_exchange_* / cc_rig_comm_init like the plain rig problem (intrinsics replicated).
  * The handle is a cc_rig: set_state / reset / solve / get_state / eval / destroy are the cc_rig_* calls;
  * cc_rigk_set_intrinsics must be called once before the first solve (const_mask bit i freezes intrinsic i). */
 int cc_rigk_create(int32_t device, int64_t n_cams, int64_t n_frames, int64_t n_world,

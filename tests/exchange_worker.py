@@ -10,18 +10,28 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def rig_main(rank, world, frames, pts, out, dist, capi):
-    """argv[7] = "rig:<cams>": the rig path, camera 2 (if present) visible to rank 0's frames only."""
+    """argv[7] = "rig:<cams>" (the reference's rig problem) or "rigk:<cams>" (extension: + shared intrinsics)."""
     from oracle import pyoracle as po      # scenario generator only (test input)
+    with_k = sys.argv[7].startswith("rigk")
     cams = int(sys.argv[7].split(":")[1])
-    sc = po.rig_scenario(cams, frames, pts)
-    cq, ct = po.affine_to_qt(sc["cam_T"])
-    fq, ft = po.affine_to_qt(sc["frame_T"])
+    if with_k:
+        from tests.helpers import rigk_case
+        k = rigk_case(cams, frames, pts)
+        sc = dict(frame_offsets=k["frame_offsets"], obs_cam=k["obs_cam"], obs_world=k["obs_world"], obs_uv=k["obs_uv_pix"],
+                  world_xyz=k["world_xyz"], cam_frozen=k["cam_frozen"])
+        cq, ct, fq, ft = k["cam_q0"], k["cam_t0"], k["frame_q0"], k["frame_t0"]
+    else:
+        sc = po.rig_scenario(cams, frames, pts)
+        cq, ct = po.affine_to_qt(sc["cam_T"])
+        fq, ft = po.affine_to_qt(sc["frame_T"])
     off = sc["frame_offsets"]
     first = capi.partition_frames(off, world)
     f0, f1 = int(first[rank]), int(first[rank + 1])
     o0, o1 = int(off[f0]), int(off[f1])
     prob = capi.RigProblem(cams, off[f0:f1 + 1] - o0, sc["obs_cam"][o0:o1], sc["obs_world"][o0:o1], sc["obs_uv"][o0:o1],
-                           sc["world_xyz"], sc["cam_frozen"])
+                           sc["world_xyz"], sc["cam_frozen"], **(dict(huber_a=0.0, with_intrinsics=True) if with_k else {}))
+    if with_k:
+        prob.set_intrinsics(k["intr0"], 1 << 8)
     prob.set_state(cq, ct, fq[f0:f1], ft[f0:f1])
     handles = [None] * world
     dist.all_gather_object(handles, prob.exchange_export())
@@ -36,6 +46,8 @@ def rig_main(rank, world, frames, pts, out, dist, capi):
         res[name + "_acc"] = np.array([l["accepted"] for l in s["log"]])
         res[name + "_iters"] = np.array(s["iterations"])
         res[name + "_termname"] = np.array(s["termination"])
+        if with_k:
+            res[name + "_intr"] = prob.get_intrinsics()
     dist.barrier()
     prob.close()
     np.savez(out, f0=f0, f1=f1, o0=o0, o1=o1, **res)

@@ -128,3 +128,28 @@ def test_sharded_rig_solve_over_the_mailbox_exchange(world, cams, frames, pts, t
             assert np.abs(r[name + "_frame_t"] - ref[3][f0:f1]).max() < 1e-8
             assert np.allclose(r[name + "_cost"], ref[4][o0:o1], rtol=1e-6, atol=1e-13)
         assert np.array_equal(ranks[0]["default_cam_t"], ranks[0]["nograph_cam_t"])
+
+
+@pytest.mark.parametrize("world,cams,frames,pts", [(2, 3, 30, 20), (3, 6, 45, 12)])
+def test_sharded_rig_with_intrinsics_over_the_mailbox_exchange(world, cams, frames, pts, tmp_path):
+    """The extension (cc_rigk_*) sharded over ranks: intrinsics replicated, bit-identical on every rank."""
+    from tests.helpers import rigk_case
+    ranks = _run_ranks(world, frames, pts, tmp_path, extra=(f"rigk:{cams}",))
+    k = rigk_case(cams, frames, pts)
+    prob = capi.RigProblem(cams, k["frame_offsets"], k["obs_cam"], k["obs_world"], k["obs_uv_pix"], k["world_xyz"], k["cam_frozen"],
+                           huber_a=0.0, with_intrinsics=True)
+    prob.set_intrinsics(k["intr0"], 1 << 8)
+    prob.set_state(k["cam_q0"], k["cam_t0"], k["frame_q0"], k["frame_t0"])
+    s = prob.solve(capi.default_options(max_iterations=1000))
+    intr = prob.get_intrinsics()
+    ref = prob.get_state()
+    prob.close()
+    for name in ("default", "nograph"):
+        for r in ranks:
+            assert np.array_equal(r[name + "_intr"], ranks[0][name + "_intr"]) and np.array_equal(r[name + "_cam_t"], ranks[0][name + "_cam_t"])
+            assert str(r[name + "_termname"]) == s["termination"] and int(r[name + "_iters"]) == s["iterations"]
+            assert np.allclose(r[name + "_costs"], [l["cost"] for l in s["log"]], rtol=1e-9)
+            assert np.allclose(r[name + "_intr"][:4], intr[:4], rtol=1e-9) and np.allclose(r[name + "_intr"][4:], intr[4:], atol=1e-8)
+            assert np.abs(r[name + "_cam_t"] - ref[1]).max() < 1e-8
+            f0, f1 = int(r["f0"]), int(r["f1"])
+            assert np.abs(r[name + "_frame_t"] - ref[3][f0:f1]).max() < 1e-7
