@@ -217,10 +217,23 @@ __device__ inline void quat_to_R(const double* q, double* R) {
 
 // ceres::QuaternionManifold::Plus (calibrator.cpp:298)
 __device__ inline void quat_plus(const double* x, const double* d, double* out) {
-  const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-  if (nd == 0.0) { out[0] = x[0]; out[1] = x[1]; out[2] = x[2]; out[3] = x[3]; return; }
-  const double s = sin(nd) / nd;
-  const double a0 = cos(nd), a1 = s * d[0], a2 = s * d[1], a3 = s * d[2];
+  const double n2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  if (n2 == 0.0) { out[0] = x[0]; out[1] = x[1]; out[2] = x[2]; out[3] = x[3]; return; }
+  double s, a0;
+  if (n2 < 0.0625) {
+    // LM steps are small rotations: cos(n) and sin(n)/n as even power series in n^2, truncated below
+    // 1 ulp for n < 0.25 (next terms n^20/20! ~ 4e-31 and n^18/19! ~ 1e-28); ~20 FMAs on the
+    // single-lane critical path of the sweep prologue instead of two libm calls and a square root
+    a0 = 1.0 + n2 * (-1.0 / 2 + n2 * (1.0 / 24 + n2 * (-1.0 / 720 + n2 * (1.0 / 40320 + n2 * (-1.0 / 3628800 +
+         n2 * (1.0 / 479001600 + n2 * (-1.0 / 87178291200.0 + n2 * (1.0 / 20922789888000.0))))))));
+    s = 1.0 + n2 * (-1.0 / 6 + n2 * (1.0 / 120 + n2 * (-1.0 / 5040 + n2 * (1.0 / 362880 + n2 * (-1.0 / 39916800 +
+        n2 * (1.0 / 6227020800.0 + n2 * (-1.0 / 1307674368000.0 + n2 * (1.0 / 355687428096000.0))))))));
+  } else {
+    const double nd = sqrt(n2);
+    s = sin(nd) / nd;
+    a0 = cos(nd);
+  }
+  const double a1 = s * d[0], a2 = s * d[1], a3 = s * d[2];
   out[0] = a0 * x[0] - a1 * x[1] - a2 * x[2] - a3 * x[3];
   out[1] = a0 * x[1] + a1 * x[0] + a2 * x[3] - a3 * x[2];
   out[2] = a0 * x[2] - a1 * x[3] + a2 * x[0] + a3 * x[1];
