@@ -210,6 +210,14 @@ def main():
     conv = prob.solve(opts, log_capacity=0)
     conv_ms = (time.perf_counter() - t_c0) * 1e3
     intr_final, _, _ = prob.get_state()
+    # also outside the timed region (single GPU only): the one-shot C-ABI call a drop-in caller makes,
+    # i.e. allocation + host->device upload of this rank's observations + solve + read-back
+    e2e_ms = None
+    if world == 1:
+        capi.intrinsics_optimize(my_off, uv[o0:o1], xyz[o0:o1], intr0, q0[f0:f1], t0[f0:f1], options=opts, log_capacity=0)
+        t_e = time.perf_counter()
+        capi.intrinsics_optimize(my_off, uv[o0:o1], xyz[o0:o1], intr0, q0[f0:f1], t0[f0:f1], options=opts, log_capacity=0)
+        e2e_ms = (time.perf_counter() - t_e) * 1e3
 
     run_steps(args.warmup)
     barrier()
@@ -261,6 +269,8 @@ def main():
             "solves_in_timed_region": solves,
             "iterations_per_solve": conv["iterations"],
             "time_to_converge_ms": conv_ms,
+            "observations_per_sec": n_obs_total * args.steps / elapsed,
+            "one_shot_ms_including_upload": e2e_ms,
             "converged": {"termination": conv["termination"], "final_cost": conv["final_cost"],
                           "intrinsics": [float(x) for x in intr_final]},
             "roofline": {
