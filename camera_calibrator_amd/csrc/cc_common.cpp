@@ -2,6 +2,7 @@
 #include "cc_common.hpp"
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 namespace cc {
@@ -22,16 +23,70 @@ int fail(int code, const char* fmt, ...) {
 }
 
 int select_device(int device) {
+  static std::mutex mu;
+  static std::vector<char> is_gfx950;   // per device: 0 unknown, 1 yes (the property query is slow)
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
     return fail(CC_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
   if (device < 0 || device >= n) return fail(CC_ERR_BAD_ARGUMENT, "device %d out of range (0..%d)", device, n - 1);
-  hipDeviceProp_t prop;
-  CC_HIP(hipGetDeviceProperties(&prop, device));
-  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
-    return fail(CC_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+  bool known;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if ((int)is_gfx950.size() < n) is_gfx950.resize((size_t)n, 0);
+    known = is_gfx950[(size_t)device] != 0;
+  }
+  if (!known) {
+    hipDeviceProp_t prop;
+    CC_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+      return fail(CC_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    std::lock_guard<std::mutex> lk(mu);
+    is_gfx950[(size_t)device] = 1;
+  }
   CC_HIP(hipSetDevice(device));
   return CC_OK;
+}
+
+namespace {
+std::mutex g_cache_mu;
+std::vector<void*> g_pinned_free;
+std::vector<std::vector<hipStream_t>> g_stream_free;   // per device
+}  // namespace
+
+void* pinned_block_get() {
+  {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    if (!g_pinned_free.empty()) { void* p = g_pinned_free.back(); g_pinned_free.pop_back(); return p; }
+  }
+  void* p = nullptr;
+  if (hipHostMalloc(&p, 512, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+
+void pinned_block_put(void* p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(g_cache_mu);
+  g_pinned_free.push_back(p);
+}
+
+int stream_get(int device, hipStream_t* out) {
+  {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    if ((int)g_stream_free.size() > device && !g_stream_free[(size_t)device].empty()) {
+      *out = g_stream_free[(size_t)device].back();
+      g_stream_free[(size_t)device].pop_back();
+      return CC_OK;
+    }
+  }
+  CC_HIP(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+  return CC_OK;
+}
+
+void stream_put(int device, hipStream_t s) {
+  if (!s) return;
+  std::lock_guard<std::mutex> lk(g_cache_mu);
+  if ((int)g_stream_free.size() <= device) g_stream_free.resize((size_t)device + 1);
+  g_stream_free[(size_t)device].push_back(s);   // idle (the owner synchronised it) and reusable
 }
 
 }  // namespace cc

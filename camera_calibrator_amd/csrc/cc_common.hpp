@@ -28,6 +28,15 @@ int fail(int code, const char* fmt, ...);
 
 int select_device(int device);
 
+// Small per-process caches of resources that are slow to create and destroy (hipHostMalloc/hipHostFree
+// ~0.2-0.4 ms, streams ~0.1 ms): a one-shot solve should not pay for them every time. Pinned blocks
+// are 512 bytes (control block / options staging); streams are per device. Thread-safe; entries live
+// until the process ends.
+void* pinned_block_get();
+void pinned_block_put(void* p);
+int stream_get(int device, hipStream_t* out);
+void stream_put(int device, hipStream_t s);
+
 // ---------------------------------------------------------------------------------------------
 // Mailbox exchange between the ranks of one node (device side: cc_device.hpp; host side: cc_comm.cpp)
 // ---------------------------------------------------------------------------------------------

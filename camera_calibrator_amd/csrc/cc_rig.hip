@@ -1258,7 +1258,7 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   std::vector<uint8_t> pp, pq;
   for (int p = 0; p < S; ++p) for (int q = p; q < S; ++q) { pp.push_back((uint8_t)p); pq.push_back((uint8_t)q); }
 
-  CC_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  if (int rc = stream_get(device, &h->stream)) return rc;
   RigDev& d = h->d;
   d.F = F; d.N = N; d.NG = NG; d.C = (int32_t)C; d.S = S; d.SW = S + 1; d.NP = S * (S + 1) / 2;
   d.pc_b = d.NP; d.pc_hd = d.NP + S; d.pc_fail = d.NP + 2 * S; d.pc_gs = d.pc_fail + 1; d.pc_gmax = d.pc_gs + S; d.PC = d.pc_gmax + 1;
@@ -1332,7 +1332,8 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   CC_HIP(hipMemset(d.shared_stats, 0, 4 * sizeof(double)));
   CC_HIP(hipMemset(d.ctl, 0, sizeof(LmCtl)));
   CC_HIP(hipMemset(d.ctl_next, 0, sizeof(LmCtl)));
-  CC_HIP(hipHostMalloc(&h->h_ctl, sizeof(LmCtl), hipHostMallocDefault));
+  h->h_ctl = reinterpret_cast<LmCtl*>(pinned_block_get());
+  if (!h->h_ctl) return fail(CC_ERR_HIP, "hipHostMalloc failed");
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_sweep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kRigSweepLdsBytes));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_sweep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kRigSweepLdsBytesK));
   guard.ok = true;
@@ -1390,8 +1391,8 @@ void cc_rig_destroy(cc_rig* h) {
   if (h->comm) cc::comm_destroy(h->comm);
   cc::mailbox_release(&h->mailbox);
   for (void* p : h->allocs) hipFree(p);
-  if (h->h_ctl) hipHostFree(h->h_ctl);
-  if (h->stream) hipStreamDestroy(h->stream);
+  cc::pinned_block_put(h->h_ctl);
+  cc::stream_put(h->device, h->stream);   // synchronised above
   delete h;
 }
 
@@ -1643,7 +1644,10 @@ int cc_rig_optimize(const cc_options* opt, int32_t device, int64_t C, int64_t F,
   int rc = cc_rig_create(device, C, F, n_world, off, obs_cam, obs_world, obs_uv, world_xyz, cam_frozen, huber_a, &h);
   if (rc) return rc;
   rc = cc_rig_set_state(h, cam_q, cam_t, frame_q, frame_t);
-  if (!rc) rc = cc_rig_solve(h, opt, summary);
+  cc_options o;
+  if (opt) o = *opt; else { cc_options_init(&o); o.max_iterations = 1000; }  // extrinsics_calibrator.cpp:211
+  o.use_graph = 0;   // one solve per handle: capturing and instantiating a graph cannot pay off
+  if (!rc) rc = cc_rig_solve(h, &o, summary);
   if (!rc) rc = cc_rig_get_state(h, cam_q, cam_t, frame_q, frame_t, obs_cost);
   cc_rig_destroy(h);
   return rc;
