@@ -1103,7 +1103,9 @@ struct cc_rig {
   cc::RigDev d{};
   int64_t C = 0, F = 0, N = 0, NG = 0, P = 0;
   std::vector<int64_t> perm;  // sorted position -> caller's observation index
-  std::vector<void*> allocs;
+  std::vector<void*> allocs;    // the chunks dev_alloc carves buffers from
+  char* chunk_cur = nullptr;
+  size_t chunk_left = 0;
   double* init_cam = nullptr;
   double* init_pose = nullptr;
   double* d_cost = nullptr;
@@ -1122,10 +1124,22 @@ struct cc_rig {
 
 namespace cc {
 
+// Device buffers of a handle are carved out of a few large chunks (bump allocation, 256-byte aligned):
+// a one-shot caller pays for a handful of hipMalloc / hipFree calls instead of forty.
 template <class T>
 static int dev_alloc(cc_rig* h, T** p, size_t n) {
-  CC_HIP(hipMalloc(p, std::max<size_t>(n, 1) * sizeof(T)));
-  h->allocs.push_back(*p);
+  const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
+  if (h->chunk_left < bytes) {
+    const size_t sz = std::max<size_t>(bytes, (size_t)16 << 20);
+    void* c = nullptr;
+    CC_HIP(hipMalloc(&c, sz));
+    h->allocs.push_back(c);
+    h->chunk_cur = static_cast<char*>(c);
+    h->chunk_left = sz;
+  }
+  *p = reinterpret_cast<T*>(h->chunk_cur);
+  h->chunk_cur += bytes;
+  h->chunk_left -= bytes;
   return 0;
 }
 template <class T>
@@ -1217,21 +1231,23 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   std::vector<int32_t> gframe, gcam;
   std::vector<uint8_t> seen((size_t)C, 0);
   {
+    // counting sort by camera inside each frame (stable: observation order is kept within a group)
     int64_t pos = 0;
+    std::vector<int64_t> cnt((size_t)C), start((size_t)C);
     for (int64_t f = 0; f < F; ++f) {
-      std::vector<int64_t> idx((size_t)(off[f + 1] - off[f]));
-      std::iota(idx.begin(), idx.end(), off[f]);
-      std::stable_sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) { return obs_cam[a] < obs_cam[b]; });
-      for (size_t i = 0; i < idx.size(); ++i) {
-        if (i == 0 || obs_cam[idx[i]] != obs_cam[idx[i - 1]]) {
-          if (i != 0) goff.push_back(pos);
+      std::fill(cnt.begin(), cnt.end(), 0);
+      for (int64_t k = off[f]; k < off[f + 1]; ++k) cnt[obs_cam[k]]++;
+      for (int64_t c = 0; c < C; ++c) {
+        start[(size_t)c] = pos;
+        if (cnt[(size_t)c] > 0) {
           gframe.push_back((int32_t)f);
-          gcam.push_back((int32_t)obs_cam[idx[i]]);
-          seen[obs_cam[idx[i]]] = 1;
+          gcam.push_back((int32_t)c);
+          seen[(size_t)c] = 1;
+          pos += cnt[(size_t)c];
+          goff.push_back(pos);
         }
-        h->perm[(size_t)pos++] = idx[i];
       }
-      if (!idx.empty()) goff.push_back(pos);
+      for (int64_t k = off[f]; k < off[f + 1]; ++k) h->perm[(size_t)start[obs_cam[k]]++] = k;
       fgoff[(size_t)f + 1] = (int64_t)gframe.size();
     }
   }
@@ -1272,7 +1288,12 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   if (d.PC > 256 * kRigOwn) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: too many cameras");
   { const float* p; if (int rc = dev_upload(h, &p, uv)) return rc; d.uv = p; }
   if (int rc = dev_upload(h, &d.widx, widx)) return rc;
-  { std::vector<float> w(world_xyz, world_xyz + (size_t)n_world * 3); if (int rc = dev_upload(h, &d.wxyz, w)) return rc; }
+  {
+    float* w = nullptr;
+    if (int rc = dev_alloc(h, &w, (size_t)n_world * 3)) return rc;
+    if (n_world > 0) CC_HIP(hipMemcpy(w, world_xyz, (size_t)n_world * 3 * sizeof(float), hipMemcpyHostToDevice));
+    d.wxyz = w;
+  }
   if (int rc = dev_upload(h, &d.goff, goff)) return rc;
   if (int rc = dev_upload(h, &d.gframe, gframe)) return rc;
   if (int rc = dev_upload(h, &d.gcam, gcam)) return rc;
