@@ -309,21 +309,27 @@ extern "C" int cc_zhang_init(int32_t device, int64_t F, const int64_t* off, cons
   const int64_t N = off[F];
   if (!uv || !xyz) return fail(CC_ERR_BAD_ARGUMENT, "cc_zhang_init: NULL arrays");
   if (int rc = select_device(device)) return rc;
-  float *duv = nullptr, *dxyz = nullptr, *dH = nullptr, *dK = nullptr, *dq = nullptr, *dt = nullptr;
-  int64_t* doff = nullptr;
-  double* dgram = nullptr;
-  struct Release {  // frees the scratch buffers on every exit path
-    float **a, **b, **c, **d, **e, **f; int64_t** g; double** h;
-    ~Release() { hipFree(*a); hipFree(*b); hipFree(*c); hipFree(*d); hipFree(*e); hipFree(*f); hipFree(*g); hipFree(*h); }
-  } release{&duv, &dxyz, &dH, &dK, &dq, &dt, &doff, &dgram};
-  CC_HIP(hipMalloc(&duv, (size_t)N * 2 * sizeof(float)));
-  CC_HIP(hipMalloc(&dxyz, (size_t)N * 3 * sizeof(float)));
-  CC_HIP(hipMalloc(&doff, (size_t)(F + 1) * sizeof(int64_t)));
-  CC_HIP(hipMalloc(&dgram, (size_t)F * 256 * sizeof(double)));
-  CC_HIP(hipMalloc(&dH, (size_t)F * 9 * sizeof(float)));
-  CC_HIP(hipMalloc(&dK, 9 * sizeof(float)));
-  CC_HIP(hipMalloc(&dq, (size_t)F * 4 * sizeof(float)));
-  CC_HIP(hipMalloc(&dt, (size_t)F * 3 * sizeof(float)));
+  // one scratch arena (one hipMalloc / hipFree per call), 256-byte aligned pieces
+  size_t cursor = 0;
+  auto take = [&](size_t bytes) { const size_t at = cursor; cursor += (bytes + 255) & ~(size_t)255; return at; };
+  const size_t o_uv = take((size_t)N * 2 * sizeof(float)), o_xyz = take((size_t)N * 3 * sizeof(float));
+  const size_t o_off = take((size_t)(F + 1) * sizeof(int64_t)), o_gram = take((size_t)F * 256 * sizeof(double));
+  const size_t o_H = take((size_t)F * 9 * sizeof(float)), o_K = take(9 * sizeof(float));
+  const size_t o_q = take((size_t)F * 4 * sizeof(float)), o_t = take((size_t)F * 3 * sizeof(float));
+  char* arena = nullptr;
+  struct Release {  // frees the scratch arena on every exit path
+    char** p;
+    ~Release() { if (*p) hipFree(*p); }
+  } release{&arena};
+  CC_HIP(hipMalloc(&arena, cursor));
+  float* duv = reinterpret_cast<float*>(arena + o_uv);
+  float* dxyz = reinterpret_cast<float*>(arena + o_xyz);
+  int64_t* doff = reinterpret_cast<int64_t*>(arena + o_off);
+  double* dgram = reinterpret_cast<double*>(arena + o_gram);
+  float* dH = reinterpret_cast<float*>(arena + o_H);
+  float* dK = reinterpret_cast<float*>(arena + o_K);
+  float* dq = reinterpret_cast<float*>(arena + o_q);
+  float* dt = reinterpret_cast<float*>(arena + o_t);
   CC_HIP(hipMemcpy(duv, uv, (size_t)N * 2 * sizeof(float), hipMemcpyHostToDevice));
   CC_HIP(hipMemcpy(dxyz, xyz, (size_t)N * 3 * sizeof(float), hipMemcpyHostToDevice));
   CC_HIP(hipMemcpy(doff, off, (size_t)(F + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
