@@ -18,3 +18,16 @@ except Exception:  # pragma: no cover
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_sessionstart(session):
+    """The native pieces are git-ignored build products: if a fresh checkout runs the tests before
+    __graft_entry__.build(), build them now (hipcc cross-compiles gfx950 without a GPU)."""
+    need = [os.path.join(ROOT, "camera_calibrator_amd", "libcc_hip.so"), os.path.join(ROOT, "oracle", "liboracle.so"),
+            os.path.join(ROOT, "tests", "cpp", "test_dropin")]
+    import glob
+    have_pyb = bool(glob.glob(os.path.join(ROOT, "camera_calibrator_amd", "pycalibrator*.so")))
+    if all(os.path.exists(p) for p in need) and have_pyb:
+        return
+    import __graft_entry__
+    __graft_entry__.build()
