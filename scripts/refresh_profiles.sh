@@ -27,5 +27,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rigtrace -- python3
 cd $R
 cp $(find $OUT/rigtrace -name "*kernel_stats.csv" | head -1) $OUT/rig_kernel_stats.csv
 python scripts/time_comm1.py 2>&1 | grep -E "graph|mailbox|rccl 1|sweep" > $OUT/exchange_1rank.txt
+python scripts/bench_rigk.py > $OUT/rigk_bench.jsonl
+python scripts/bench_estimate.py > $OUT/estimate_bench.json
+bash scripts/pmc_compute.sh > /dev/null 2>&1 && (head -1 gpurun_out/pmc2/compute_summary.csv; grep "k_intr_" gpurun_out/pmc2/compute_summary.csv) > $OUT/pmc_compute.csv
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/rigtrace
 ls -la $OUT
