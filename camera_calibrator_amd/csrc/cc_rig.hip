@@ -949,6 +949,9 @@ __global__ __launch_bounds__(256) void k_rig_solve(RigDev P) {
     }
     __syncthreads();
     gmax = s_g;
+#if CC_ABLATE_RS == 1
+    return;
+#endif
     converged = gmax <= o.gradient_tolerance;
     // the loop-top radius test of the very first iteration (later ones are made by lm_decide)
     if (!converged && cn->iter == 0 && radius < o.min_radius) { converged = true; early_term = CC_MIN_RADIUS; }
@@ -971,25 +974,51 @@ __global__ __launch_bounds__(256) void k_rig_solve(RigDev P) {
         // (column j is read again only by the substitutions, after the final barrier)
       }
       __syncthreads();
+#if CC_ABLATE_RS == 2
+      return;
+#endif
       if (tid < 64) {
         // forward / backward substitution on wave 0: lane i owns b[i]
         const double inv_own = row ? s_inv[i] : 0.0;
         bi = row_fixed ? 0.0 : b_in;
-        for (int j = 0; j < S; ++j) {
-          const double yj = readlane_d(bi, j) * readlane_d(inv_own, j);
-          if (i == j) bi = yj;
-          else if (row && i > j) bi -= A[i][j] * yj;
+        // the factor entries a lane needs do not depend on the running solution: fetch them eight
+        // steps ahead so that only the lane reads and the FMA sit on the dependent chain
+        for (int j0 = 0; j0 < S; j0 += 8) {
+          double a[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) a[u] = (row && j0 + u < S && i > j0 + u) ? A[i][j0 + u] : 0.0;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u;
+            if (j < S) {
+              const double yj = readlane_d(bi, j) * readlane_d(inv_own, j);
+              if (i == j) bi = yj;
+              else bi -= a[u] * yj;
+            }
+          }
         }
-        for (int j = S - 1; j >= 0; --j) {
-          const double xj = readlane_d(bi, j) * readlane_d(inv_own, j);
-          if (i == j) bi = xj;
-          else if (i < j) bi -= A[j][i] * xj;
+        for (int j0 = S - 1; j0 >= 0; j0 -= 8) {
+          double a[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) a[u] = (j0 - u >= 0 && i < j0 - u) ? A[j0 - u][i] : 0.0;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int j = j0 - u;
+            if (j >= 0) {
+              const double xj = readlane_d(bi, j) * readlane_d(inv_own, j);
+              if (i == j) bi = xj;
+              else bi -= a[u] * xj;
+            }
+          }
         }
         step_ok = s_ok != 0 && __all(!row || isfinite(bi));
         if (row) P.ds[i] = -bi;
       }
     }
   }
+#if CC_ABLATE_RS == 3
+  if (phase != 0) return;
+#endif
   if (tid >= 64) return;
   // ---- wave 0: camera candidates / records: lane c < C gathers its six step components from lanes 6c..6c+5
   const int dst = phase == 0 ? cur : (cur ^ 1);

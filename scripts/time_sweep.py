@@ -2,10 +2,9 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from camera_calibrator_amd import capi
-from oracle import pyoracle as po
 F, M = int(os.environ.get("F", 1000)), int(os.environ.get("M", 500))
-off, uv, xyz = po.make_intrinsics_problem(F, M)
-K0, q0, t0 = po.zhang_init(off, uv, xyz)
+off, uv, xyz = capi.make_intrinsics_problem(F, M)
+K0, q0, t0 = capi.zhang_init(off, uv, xyz)
 intr0 = np.array([K0[0, 0], K0[1, 1], K0[0, 2], K0[1, 2], 0, 0, 0, 0, 0], dtype=np.float64)
 prob = capi.IntrinsicsProblem(off, uv, xyz)
 prob.set_state(intr0, q0.astype(np.float64), t0.astype(np.float64))
