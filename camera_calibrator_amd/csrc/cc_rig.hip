@@ -1590,6 +1590,7 @@ int cc_rig_get_state(cc_rig* h, double* cam_q, double* cam_t, double* frame_q, d
 int cc_rig_eval(cc_rig* h, double* cost) {
   using namespace cc;
   if (!h || !h->have_state || !cost) return fail(CC_ERR_STATE, "cc_rig_eval: no state set");
+  if (h->d.K && !h->have_intr) return fail(CC_ERR_STATE, "cc_rig_eval: cc_rigk_set_intrinsics has not been called");
   std::vector<double> oc((size_t)h->N);
   if (int rc = cc_rig_get_state(h, nullptr, nullptr, nullptr, nullptr, oc.data())) return rc;
   double c = 0.0;
