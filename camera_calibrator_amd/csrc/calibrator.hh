@@ -13,56 +13,54 @@ namespace calibrator {
 
 class Calibrator {
  public:
-  Calibrator(const int img_width, const int img_height);
+  Calibrator(const int image_width, const int image_height);
 
-  /// OpenCV's cv::calibrateCamera wrapper of the reference (calibrator.cpp:16-45). OpenCV is not
-  /// part of this build: throws std::runtime_error.
-  void EstimateOpenCv(const std::vector<Points2D>& in_img_points,
-                      const std::vector<Points3D>& in_world_points);
+  // ---- the model: K (fx, fy, px, py; zero skew) and the distortion k1 k2 p1 p2 k3 ---------------
+  Matrix3 GetK() const { return camera_matrix_; }
+  void SetK(const Matrix3& K) { camera_matrix_ = K; }
+  DynamicVector GetDistortion() const { return distortion_; }
+  void SetDistortion(const DynamicVector& dist) { distortion_ = dist; }
+  /// Keep distortion coefficient `coefficient` (0..4 = k1 k2 p1 p2 k3) at its current value in Optimize.
+  void ForceDistortionToConstant(const int coefficient);
 
-  /// Zhang initialisation (homographies -> K -> poses) followed by Optimize (calibrator.cpp:47-68).
-  void Estimate(const std::vector<Points2D>& in_img_points,
-                const std::vector<Points3D>& in_world_points);
+  // ---- estimation ---------------------------------------------------------------------------------
+  /// Closed-form start (homography per view -> K -> board poses) followed by Optimize
+  /// (reference: calibrator.cpp:47-68). The closed form runs on the GPU too (cc_zhang_init).
+  void Estimate(const std::vector<Points2D>& pixels_per_view, const std::vector<Points3D>& board_points_per_view);
+  /// The reference's cv::calibrateCamera wrapper (calibrator.cpp:16-45). OpenCV is not part of this
+  /// build: the method exists for source compatibility and throws std::runtime_error.
+  void EstimateOpenCv(const std::vector<Points2D>& pixels_per_view, const std::vector<Points3D>& board_points_per_view);
+  /// Reprojection-error bundle adjustment over the 9 intrinsics and one pose per view, starting from
+  /// the given poses (reference: calibrator.cpp:221-336). Updates K and the distortion; like the
+  /// reference it leaves qs / ts as they were.
+  void Optimize(const std::vector<Points2D>& pixels_per_view, const std::vector<Points3D>& board_points_per_view,
+                std::vector<Quaternion>& qs, std::vector<Point3D>& ts);
 
-  /// Reprojection-error bundle adjustment over the 9 intrinsics and one pose per image
-  /// (calibrator.cpp:221-336). K and the distortion are updated; like the reference, the refined
-  /// poses are not written back to qs / ts.
-  void Optimize(const std::vector<Points2D>& in_img_points,
-                const std::vector<Points3D>& in_world_points, std::vector<Quaternion>& qs,
-                std::vector<Point3D>& ts);
+  // ---- mapping points through the model ------------------------------------------------------------
+  /// pixels -> undistorted normalised coordinates (reference: calibrator.cpp:118-155)
+  Points2D Undistort(const Points2D& pixels);
+  /// normalised coordinates -> distorted pixels (reference: calibrator.cpp:157-166)
+  Points2D Distort(const Points2D& normalised);
 
-  Matrix3 GetK() const { return K_; }
-  DynamicVector GetDistortion() const { return dist_; }
-  void SetK(const Matrix3& K) { K_ = K; }
-  void SetDistortion(const DynamicVector& dist) { dist_ = dist; }
-
-  /// Freeze distortion coefficient `distortion_idx` (order k1 k2 p1 p2 k3) during Optimize.
-  void ForceDistortionToConstant(const int distortion_idx);
-
-  /// Pixel coordinates -> undistorted normalised coordinates (calibrator.cpp:118-155).
-  Points2D Undistort(const Points2D& img_points);
-  /// Normalised coordinates -> distorted pixel coordinates (calibrator.cpp:157-166).
-  Points2D Distort(const Points2D& normalized_points);
-
-  // ---- additions of this build (not in the reference) ----
-  /// GPU used by Optimize / Distort / Undistort (default 0).
+  // ---- additions of this build (not in the reference) ----------------------------------------------
+  /// GPU used by Optimize / Estimate / Distort / Undistort (default 0).
   void SetDevice(int device) { device_ = device; }
-  /// Status of the last Optimize: 0 or a negative cc_status; the reference has no error channel
+  /// Status of the last Optimize: 0 or a negative cc_status. The reference has no error channel
   /// (ceres' summary is discarded), so Optimize itself never throws on solver failure.
   int LastStatus() const { return last_status_; }
   int LastIterations() const { return last_iterations_; }
   double LastFinalCost() const { return last_final_cost_; }
 
  private:
-  int width_;
-  int height_;
+  int image_w_;
+  int image_h_;
   int device_{0};
   int last_status_{0};
   int last_iterations_{0};
   double last_final_cost_{0.0};
-  Matrix3 K_{Matrix3::Identity()};
-  DynamicVector dist_{DynamicVector::Zero(5)};
-  std::set<int> constant_intrinsics_;
+  Matrix3 camera_matrix_{Matrix3::Identity()};
+  DynamicVector distortion_{DynamicVector::Zero(5)};
+  std::set<int> frozen_intrinsics_;
 };
 
 }  // namespace calibrator

@@ -22,69 +22,75 @@ inline Point3D scaled_unit(const Point3D& p, float s) {  // p.normalize(); p *= 
 }
 }  // namespace
 
-DataGenerator::DataGenerator(int img_width, int img_height)
-    : width_(img_width), height_(img_height), rand_w_(0.0f, img_width - 1.0f), rand_h_(0.0f, img_height - 1.0f),
-      rand_dist_(min_distance_, max_distance_), rand_pixel_(-noise_in_pixels_, noise_in_pixels_) {}
+namespace {
+using Camera = DataGenerator::Camera;
+using Draws = DataGenerator::Draws;
 
-void DataGenerator::SetK(const Matrix3& K) { K_ = K; }
-void DataGenerator::SetDistortion(const DynamicVector& dist) { dist_ = dist; }
-void DataGenerator::SetNoiseInPixels(const float noise) {
-  noise_in_pixels_ = noise;
-  rand_pixel_ = std::uniform_real_distribution<float>(-noise_in_pixels_, noise_in_pixels_);
-}
-
-// data_generator.cpp:10-32
-bool DataGenerator::ProjectAndDistort(const Point3D& p, Point2D* out) {
+// pixel of a camera-frame point through the distortion model, plus noise; false when the noisy pixel
+// leaves the image (data_generator.cpp:10-32; the two noise draws happen before the test)
+bool project_noisy(const Camera& cam, Draws& rnd, const Point3D& p, Point2D* out) {
   const double x = (double)p.x() / (double)p.z(), y = (double)p.y() / (double)p.z();
-  const double k1 = dist_(0), k2 = dist_(1), p1 = dist_(2), p2 = dist_(3), k3 = dist_(4);
+  const double k1 = cam.dist(0), k2 = cam.dist(1), p1 = cam.dist(2), p2 = cam.dist(3), k3 = cam.dist(4);
   const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
   const double cdist = 1 + k1 * r2 + k2 * r4 + k3 * r6;
   const double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
   const double xd = x * cdist + p1 * a1 + p2 * a2, yd = y * cdist + p1 * a3 + p2 * a1;
-  const float u = (float)(xd * (double)K_(0, 0) + (double)K_(0, 2));
-  const float v = (float)(yd * (double)K_(1, 1) + (double)K_(1, 2));
-  const float ud = u + rand_pixel_(gen_);
-  const float vd = v + rand_pixel_(gen_);
-  if (ud < 0.0f || ud >= width_ - 1 || vd < 0.0f || vd >= height_ - 1) return false;
+  const float u = (float)(xd * (double)cam.K(0, 0) + (double)cam.K(0, 2));
+  const float v = (float)(yd * (double)cam.K(1, 1) + (double)cam.K(1, 2));
+  const float ud = u + rnd.pixel_noise(rnd.engine);
+  const float vd = v + rnd.pixel_noise(rnd.engine);
+  if (ud < 0.0f || ud >= cam.width - 1 || vd < 0.0f || vd >= cam.height - 1) return false;
   *out = Point2D(ud, vd);
   return true;
 }
 
-// data_generator.cpp:126-146
-Point3D DataGenerator::GetRandomPixel() {
-  const float u = rand_w_(gen_);
-  const float v = rand_h_(gen_);
-  return Point3D(u, v, 1.0f);
-}
-Point3D DataGenerator::GetRandom3DPointVisibleToCamera(const Matrix3& K_inv) {
-  const Point3D ray = mul(K_inv, GetRandomPixel());
-  const float depth = rand_dist_(gen_);  // drawn after the pixel
+// a point on the viewing ray of a uniformly drawn pixel, at a uniformly drawn distance
+// (data_generator.cpp:126-146: u, v, then the distance)
+Point3D frustum_point(Draws& rnd, const Matrix3& K_inv) {
+  const float u = rnd.u(rnd.engine);
+  const float v = rnd.v(rnd.engine);
+  const Point3D ray = mul(K_inv, Point3D(u, v, 1.0f));
+  const float depth = rnd.depth(rnd.engine);
   return scaled_unit(ray, depth);
 }
 
-// data_generator.cpp:52-75
-Plane DataGenerator::GetRandomPlane(const Matrix3& K_inv) {
+// plane through three image corners pushed out to random distances (data_generator.cpp:52-75)
+Plane corner_plane(const Camera& cam, Draws& rnd, const Matrix3& K_inv) {
   Point3D corner(0.0f, 0.0f, 1.0f);
-  const Point3D p1 = scaled_unit(mul(K_inv, corner), rand_dist_(gen_));
-  corner.x() = static_cast<float>(width_ - 1);
-  const Point3D p2 = scaled_unit(mul(K_inv, corner), rand_dist_(gen_));
-  corner.y() = static_cast<float>(height_ - 1);
-  const Point3D p3 = scaled_unit(mul(K_inv, corner), rand_dist_(gen_));
-  return EstimatePlaneFinite(p1, p2, p3);
+  const Point3D a = scaled_unit(mul(K_inv, corner), rnd.depth(rnd.engine));
+  corner.x() = static_cast<float>(cam.width - 1);
+  const Point3D b = scaled_unit(mul(K_inv, corner), rnd.depth(rnd.engine));
+  corner.y() = static_cast<float>(cam.height - 1);
+  const Point3D c = scaled_unit(mul(K_inv, corner), rnd.depth(rnd.engine));
+  return EstimatePlaneFinite(a, b, c);
+}
+}  // namespace
+
+DataGenerator::DataGenerator(int img_width, int img_height) {
+  cam_.width = img_width;
+  cam_.height = img_height;
+  rnd_.u = std::uniform_real_distribution<float>(0.0f, img_width - 1.0f);
+  rnd_.v = std::uniform_real_distribution<float>(0.0f, img_height - 1.0f);
+}
+
+void DataGenerator::SetK(const Matrix3& K) { cam_.K = K; }
+void DataGenerator::SetDistortion(const DynamicVector& dist) { cam_.dist = dist; }
+void DataGenerator::SetNoiseInPixels(const float noise) {
+  rnd_.pixel_noise = std::uniform_real_distribution<float>(-noise, noise);
 }
 
 // data_generator.cpp:77-124
 GeneratedData DataGenerator::GetDistortedPointsPlanar(const int num_p) {
   GeneratedData out;
-  const Matrix3 K_inv = Inverse3x3(K_);  // pseudo-inverse of an invertible K
-  const Plane plane = GetRandomPlane(K_inv);
+  const Matrix3 K_inv = Inverse3x3(cam_.K);  // pseudo-inverse of an invertible K
+  const Plane plane = corner_plane(cam_, rnd_, K_inv);
   const Matrix3 R = RotationMatrixFromPlane(plane);
   while ((int)out.image.size() < num_p) {
-    const Point3D p = GetRandom3DPointVisibleToCamera(K_inv);
+    const Point3D p = frustum_point(rnd_, K_inv);
     const Point3D on_plane = ProjectToPlane(plane, p, p);
     const Point3D rotated = mul(R, on_plane);
     Point2D px;
-    if (!ProjectAndDistort(on_plane, &px)) { ++rejected_; continue; }
+    if (!project_noisy(cam_, rnd_, on_plane, &px)) { ++rejected_; continue; }
     out.world.emplace_back(rotated.x(), rotated.y(), 0.0f);
     out.image.push_back(px);
   }
@@ -94,11 +100,11 @@ GeneratedData DataGenerator::GetDistortedPointsPlanar(const int num_p) {
 // data_generator.cpp:148-184
 GeneratedData DataGenerator::GetDistortedPoints(const int num_p) {
   GeneratedData out;
-  const Matrix3 K_inv = Inverse3x3(K_);
+  const Matrix3 K_inv = Inverse3x3(cam_.K);
   while ((int)out.image.size() < num_p) {
-    const Point3D p = GetRandom3DPointVisibleToCamera(K_inv);
+    const Point3D p = frustum_point(rnd_, K_inv);
     Point2D px;
-    if (!ProjectAndDistort(p, &px)) { ++rejected_; continue; }
+    if (!project_noisy(cam_, rnd_, p, &px)) { ++rejected_; continue; }
     out.world.push_back(p);
     out.image.push_back(px);
   }

@@ -19,80 +19,80 @@ namespace calibrator {
 // ---- id bookkeeping (reference: extrinsics_calibrator.cpp:9-49) -------------------------------
 
 size_t ExtrinsicsCalibrator::AddCameraTRig(const Eigen::Affine3f& camera_T_rig, const bool freeze) {
-  const size_t id = camera_T_rigs_.size();
-  camera_T_rigs_.push_back(camera_T_rig);
-  if (freeze) frozen_camera_T_rigs_.insert(id);
+  const size_t id = cameras_.size();
+  cameras_.push_back(camera_T_rig);
+  if (freeze) frozen_.insert(id);
   return id;
 }
 
-Eigen::Affine3f ExtrinsicsCalibrator::GetCameraTRig(const size_t id) const { return camera_T_rigs_[id]; }
+Eigen::Affine3f ExtrinsicsCalibrator::GetCameraTRig(const size_t id) const { return cameras_[id]; }
 
-size_t ExtrinsicsCalibrator::AddObservationFrame(const Eigen::Affine3f& rig_T_world) {
-  observation_frames_.emplace_back(rig_T_world);
-  return observation_frames_.size() - 1;
+size_t ExtrinsicsCalibrator::AddObservationFrame(const Eigen::Affine3f& pose) {
+  frames_.emplace_back(pose);
+  return frames_.size() - 1;
 }
 
-Eigen::Affine3f ExtrinsicsCalibrator::GetObservationFrame(const size_t id) const { return observation_frames_[id].rig_T_world; }
+Eigen::Affine3f ExtrinsicsCalibrator::GetObservationFrame(const size_t id) const { return frames_[id].pose; }
 
 size_t ExtrinsicsCalibrator::AddWorldPoint(const size_t frame_id, const Point3D& world_point) {
-  ObservationFrame& frame = observation_frames_[frame_id];
-  world_point_infos_.push_back(WorldPointInfo{frame_id, frame.world_points.size()});
-  frame.world_points.push_back(world_point);
-  return world_point_infos_.size() - 1;
+  Frame& frame = frames_[frame_id];
+  point_refs_.push_back(PointRef{frame_id, frame.points.size()});
+  frame.points.push_back(world_point);
+  return point_refs_.size() - 1;
 }
 
-void ExtrinsicsCalibrator::AddObservation(const size_t camera_id, const size_t world_point_id, const Point2D& image_point) {
-  const WorldPointInfo& info = world_point_infos_[world_point_id];
-  ObservationFrame::Observation obs;
-  obs.camera_id = camera_id;
-  obs.world_point_idx = info.world_point_idx;
-  obs.world_point_id = world_point_id;
-  obs.image_point = image_point;
-  obs.cost = std::numeric_limits<double>::quiet_NaN();  // "not evaluated yet"
-  observation_frames_[info.observation_frame_id].observations.push_back(obs);  // stored with the point's frame
+void ExtrinsicsCalibrator::AddObservation(const size_t camera, const size_t point_global, const Point2D& normalised) {
+  const PointRef& info = point_refs_[point_global];
+  Frame::Sighting obs;
+  obs.camera = camera;
+  obs.point_in_frame = info.point_in_frame;
+  obs.point_global = point_global;
+  obs.normalised = normalised;
+  obs.half_rho = std::numeric_limits<double>::quiet_NaN();  // "not evaluated yet"
+  frames_[info.frame].sightings.push_back(obs);  // stored with the point's frame
 }
 
-void ExtrinsicsCalibrator::GetObservation(size_t frame_id, size_t k, size_t* camera_id, size_t* world_point_idx,
-                                          size_t* world_point_id, Point2D* image_point, double* cost) const {
-  const auto& o = observation_frames_[frame_id].observations[k];
-  if (camera_id) *camera_id = o.camera_id;
-  if (world_point_idx) *world_point_idx = o.world_point_idx;
-  if (world_point_id) *world_point_id = o.world_point_id;
-  if (image_point) *image_point = o.image_point;
-  if (cost) *cost = o.cost;
+void ExtrinsicsCalibrator::GetObservation(size_t frame_id, size_t k, size_t* camera, size_t* point_in_frame,
+                                          size_t* point_global, Point2D* normalised, double* half_rho) const {
+  const auto& o = frames_[frame_id].sightings[k];
+  if (camera) *camera = o.camera;
+  if (point_in_frame) *point_in_frame = o.point_in_frame;
+  if (point_global) *point_global = o.point_global;
+  if (normalised) *normalised = o.normalised;
+  if (half_rho) *half_rho = o.half_rho;
 }
 
 // ---- the solve -----------------------------------------------------------------------------------
 
 void ExtrinsicsCalibrator::Optimize() {
-  const size_t C = camera_T_rigs_.size(), F = observation_frames_.size(), Pn = world_point_infos_.size();
+  const size_t C = cameras_.size(), F = frames_.size(), Pn = point_refs_.size();
   // fp64 parameter arrays exactly as the reference fills them (extrinsics_calibrator.cpp:116-137)
   std::vector<double> cam_q(4 * C), cam_t(3 * C), frame_q(4 * F), frame_t(3 * F);
-  for (size_t i = 0; i < C; ++i) AffineToQuaternionTranslation(camera_T_rigs_[i], &cam_q[4 * i], &cam_t[3 * i]);
-  for (size_t i = 0; i < F; ++i) AffineToQuaternionTranslation(observation_frames_[i].rig_T_world, &frame_q[4 * i], &frame_t[3 * i]);
+  for (size_t i = 0; i < C; ++i) AffineToQuaternionTranslation(cameras_[i], &cam_q[4 * i], &cam_t[3 * i]);
+  for (size_t i = 0; i < F; ++i) AffineToQuaternionTranslation(frames_[i].pose, &frame_q[4 * i], &frame_t[3 * i]);
   std::vector<float> world(3 * Pn);
   for (size_t i = 0; i < Pn; ++i) {
-    const WorldPointInfo& info = world_point_infos_[i];
-    const Point3D& p = observation_frames_[info.observation_frame_id].world_points[info.world_point_idx];
+    const PointRef& info = point_refs_[i];
+    const Point3D& p = frames_[info.frame].points[info.point_in_frame];
     world[3 * i] = p.x(); world[3 * i + 1] = p.y(); world[3 * i + 2] = p.z();
   }
   std::vector<int64_t> offsets(F + 1, 0);
-  for (size_t f = 0; f < F; ++f) offsets[f + 1] = offsets[f] + (int64_t)observation_frames_[f].observations.size();
+  for (size_t f = 0; f < F; ++f) offsets[f + 1] = offsets[f] + (int64_t)frames_[f].sightings.size();
   const size_t N = (size_t)offsets[F];
   std::vector<uint32_t> obs_cam(N);
   std::vector<uint64_t> obs_world(N);
   std::vector<float> obs_uv(2 * N);
   for (size_t f = 0, k = 0; f < F; ++f)
-    for (const auto& o : observation_frames_[f].observations) {
-      obs_cam[k] = (uint32_t)o.camera_id;
-      obs_world[k] = (uint64_t)o.world_point_id;
-      obs_uv[2 * k] = o.image_point.x();
-      obs_uv[2 * k + 1] = o.image_point.y();
+    for (const auto& o : frames_[f].sightings) {
+      obs_cam[k] = (uint32_t)o.camera;
+      obs_world[k] = (uint64_t)o.point_global;
+      obs_uv[2 * k] = o.normalised.x();
+      obs_uv[2 * k + 1] = o.normalised.y();
       ++k;
     }
   std::vector<uint8_t> frozen(C, 0);
-  for (size_t id : frozen_camera_T_rigs_) if (id < C) frozen[id] = 1;
-  std::vector<double> cost(N, 0.0);
+  for (size_t id : frozen_) if (id < C) frozen[id] = 1;
+  std::vector<double> half_rho(N, 0.0);
 
   cc_options options;
   cc_options_init(&options);
@@ -106,7 +106,7 @@ void ExtrinsicsCalibrator::Optimize() {
   if (N > 0 && C > 0 && F > 0) {
     last_status_ = cc_rig_optimize(&options, device_, (int64_t)C, (int64_t)F, (int64_t)Pn, offsets.data(), obs_cam.data(),
                                    obs_world.data(), obs_uv.data(), world.data(), cam_q.data(), cam_t.data(), frozen.data(),
-                                   frame_q.data(), frame_t.data(), huber_a, cost.data(), &summary);
+                                   frame_q.data(), frame_t.data(), huber_a, half_rho.data(), &summary);
     if (last_status_ == CC_ERR_NO_DEVICE || last_status_ == CC_ERR_HIP || last_status_ == CC_ERR_BAD_ARGUMENT)
       throw std::runtime_error(std::string("ExtrinsicsCalibrator::Optimize: ") + cc_last_error());  // no silent CPU path
   }
@@ -119,12 +119,12 @@ void ExtrinsicsCalibrator::Optimize() {
       std::printf("%4d %.6e %11.2e %10.2e %10.2e %9.2e %9.2e\n", i + 1, log[i].cost, log[i].cost_change, log[i].gradient_max_norm,
                   log[i].step_norm, log[i].relative_decrease, log[i].radius);
   }
-  // per-observation robustified cost (extrinsics_calibrator.cpp:219-225)
+  // per-observation robustified half_rho (extrinsics_calibrator.cpp:219-225)
   for (size_t f = 0, k = 0; f < F; ++f)
-    for (auto& o : observation_frames_[f].observations) o.cost = cost[k++];
+    for (auto& o : frames_[f].sightings) o.half_rho = half_rho[k++];
   // poses back through float (extrinsics_calibrator.cpp:228-256)
-  for (size_t i = 0; i < C; ++i) camera_T_rigs_[i] = QuaternionTranslationToAffine(&cam_q[4 * i], &cam_t[3 * i]);
-  for (size_t i = 0; i < F; ++i) observation_frames_[i].rig_T_world = QuaternionTranslationToAffine(&frame_q[4 * i], &frame_t[3 * i]);
+  for (size_t i = 0; i < C; ++i) cameras_[i] = QuaternionTranslationToAffine(&cam_q[4 * i], &cam_t[3 * i]);
+  for (size_t i = 0; i < F; ++i) frames_[i].pose = QuaternionTranslationToAffine(&frame_q[4 * i], &frame_t[3 * i]);
 }
 
 // ---- JSON wire format (reference: extrinsics_calibrator.cpp:268-413) -----------------------------
@@ -146,36 +146,36 @@ void ExtrinsicsCalibrator::Serialize(const std::string& fname) const {
   using jsonmin::Value;
   Value root = Value::object();
   Value cams = Value::array();
-  for (size_t i = 0; i < camera_T_rigs_.size(); ++i) {
+  for (size_t i = 0; i < cameras_.size(); ++i) {
     Value c = Value::object();
-    c.obj["frozen"] = Value::boolean(frozen_camera_T_rigs_.count(i) != 0);
-    c.obj["camera_T_rig"] = transform_to_json(camera_T_rigs_[i]);
+    c.obj["frozen"] = Value::boolean(frozen_.count(i) != 0);
+    c.obj["camera_T_rig"] = transform_to_json(cameras_[i]);
     cams.arr.push_back(c);
   }
   Value wps = Value::array();
-  for (const WorldPointInfo& info : world_point_infos_) {
+  for (const PointRef& info : point_refs_) {
     Value w = Value::object();
-    w.obj["frame_id"] = Value::integer(info.observation_frame_id);
-    const Point3D& p = observation_frames_[info.observation_frame_id].world_points[info.world_point_idx];
+    w.obj["frame_id"] = Value::integer(info.frame);
+    const Point3D& p = frames_[info.frame].points[info.point_in_frame];
     Value v = Value::array();
     for (int i = 0; i < 3; ++i) v.arr.push_back(Value::number(p(i)));
     w.obj["world_point"] = v;
     wps.arr.push_back(w);
   }
   Value frames = Value::array();
-  for (const ObservationFrame& frame : observation_frames_) {
+  for (const Frame& frame : frames_) {
     Value f = Value::object();
-    f.obj["rig_T_world"] = transform_to_json(frame.rig_T_world);
+    f.obj["rig_T_world"] = transform_to_json(frame.pose);
     Value obs = Value::array();
-    for (const auto& o : frame.observations) {
+    for (const auto& o : frame.sightings) {
       Value e = Value::object();
-      e.obj["camera_id"] = Value::integer(o.camera_id);
-      e.obj["world_point_id"] = Value::integer(o.world_point_id);
+      e.obj["camera_id"] = Value::integer(o.camera);
+      e.obj["world_point_id"] = Value::integer(o.point_global);
       Value ip = Value::array();
-      ip.arr.push_back(Value::number(o.image_point.x()));
-      ip.arr.push_back(Value::number(o.image_point.y()));
+      ip.arr.push_back(Value::number(o.normalised.x()));
+      ip.arr.push_back(Value::number(o.normalised.y()));
       e.obj["image_point"] = ip;
-      e.obj["cost"] = Value::number(o.cost);  // NaN -> null
+      e.obj["cost"] = Value::number(o.half_rho);  // NaN -> null
       obs.arr.push_back(e);
     }
     f.obj["observations"] = obs;
@@ -193,9 +193,9 @@ void ExtrinsicsCalibrator::Serialize(const std::string& fname) const {
 void ExtrinsicsCalibrator::Parse(const std::string& fname) {
   // Like the reference (extrinsics_calibrator.cpp:348-351) the camera list is NOT cleared: parsing
   // into a calibrator that already holds cameras appends the parsed ones behind them.
-  frozen_camera_T_rigs_.clear();
-  world_point_infos_.clear();
-  observation_frames_.clear();
+  frozen_.clear();
+  point_refs_.clear();
+  frames_.clear();
   std::ifstream in(fname.c_str());
   if (!in) throw std::runtime_error("ExtrinsicsCalibrator::Parse: cannot open " + fname);
   std::stringstream ss;
@@ -219,24 +219,24 @@ void ExtrinsicsCalibrator::Parse(const std::string& fname) {
     for (size_t k = 0; k < obs.size(); ++k) {
       const jsonmin::Value& ip = obs.at(k).at("image_point");
       AddObservation((size_t)obs.at(k).at("camera_id").as_number(), (size_t)obs.at(k).at("world_point_id").as_number(),
-                     Point2D((float)ip.at(0).as_number(), (float)ip.at(1).as_number()));  // cost is ignored (-> NaN)
+                     Point2D((float)ip.at(0).as_number(), (float)ip.at(1).as_number()));  // half_rho is ignored (-> NaN)
     }
   }
 }
 
 // ---- frame removal with id renumbering (reference: extrinsics_calibrator.cpp:415-452) -------------
 
-void ExtrinsicsCalibrator::RemoveObservationFrame(const size_t observation_frame_id) {
-  const size_t removed_points = observation_frames_[observation_frame_id].world_points.size();
-  observation_frames_.erase(observation_frames_.begin() + (std::ptrdiff_t)observation_frame_id);
+void ExtrinsicsCalibrator::RemoveObservationFrame(const size_t frame) {
+  const size_t removed_points = frames_[frame].points.size();
+  frames_.erase(frames_.begin() + (std::ptrdiff_t)frame);
   // world point ids of all later frames slide down by the removed frame's point count
-  for (size_t f = observation_frame_id; f < observation_frames_.size(); ++f)
-    for (auto& o : observation_frames_[f].observations) o.world_point_id -= removed_points;
-  world_point_infos_.erase(std::remove_if(world_point_infos_.begin(), world_point_infos_.end(),
-                                          [=](const WorldPointInfo& w) { return w.observation_frame_id == observation_frame_id; }),
-                           world_point_infos_.end());
-  for (WorldPointInfo& w : world_point_infos_)
-    if (w.observation_frame_id >= observation_frame_id) --w.observation_frame_id;
+  for (size_t f = frame; f < frames_.size(); ++f)
+    for (auto& o : frames_[f].sightings) o.point_global -= removed_points;
+  point_refs_.erase(std::remove_if(point_refs_.begin(), point_refs_.end(),
+                                          [=](const PointRef& w) { return w.frame == frame; }),
+                           point_refs_.end());
+  for (PointRef& w : point_refs_)
+    if (w.frame >= frame) --w.frame;
 }
 
 void ExtrinsicsCalibrator::RemoveObservationFrames(const std::vector<size_t> observation_frame_ids) {

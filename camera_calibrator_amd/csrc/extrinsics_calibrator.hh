@@ -16,15 +16,15 @@ class ExtrinsicsCalibrator {
   size_t AddCameraTRig(const Eigen::Affine3f& camera_T_rig, const bool freeze = false);
   Eigen::Affine3f GetCameraTRig(const size_t id) const;
 
-  /// Registers the initial rig pose (rig_T_world) of a new observation frame. Returns the frame id.
-  size_t AddObservationFrame(const Eigen::Affine3f& rig_T_world);
+  /// Registers the initial rig pose (pose) of a new observation frame. Returns the frame id.
+  size_t AddObservationFrame(const Eigen::Affine3f& pose);
   Eigen::Affine3f GetObservationFrame(const size_t id) const;
 
   /// Adds a world point to a frame. Returns the (global) world point id.
   size_t AddWorldPoint(const size_t frame_id, const Point3D& world_point);
 
   /// Adds an observation of a world point, in normalised (undistorted) image coordinates.
-  void AddObservation(const size_t camera_id, const size_t world_point_id, const Point2D& image_point);
+  void AddObservation(const size_t camera, const size_t point_global, const Point2D& normalised);
 
   /// Huber-robustified reprojection-error bundle adjustment over all non-frozen camera poses and
   /// all frame poses (extrinsics_calibrator.cpp:86-257). Updates the stored transforms and the
@@ -34,7 +34,7 @@ class ExtrinsicsCalibrator {
   void Serialize(const std::string& fname) const;
   void Parse(const std::string& fname);
 
-  void RemoveObservationFrame(const size_t observation_frame_id);
+  void RemoveObservationFrame(const size_t frame);
   void RemoveObservationFrames(const std::vector<size_t> observation_frame_ids);
 
   // ---- additions of this build (not in the reference) ----
@@ -44,38 +44,38 @@ class ExtrinsicsCalibrator {
   int LastIterations() const { return last_iterations_; }
   double LastFinalCost() const { return last_final_cost_; }
   /// Bookkeeping introspection used by the tests (ids are what the reference's private members hold).
-  size_t NumCameras() const { return camera_T_rigs_.size(); }
-  size_t NumObservationFrames() const { return observation_frames_.size(); }
-  size_t NumWorldPoints() const { return world_point_infos_.size(); }
-  bool IsCameraFrozen(size_t id) const { return frozen_camera_T_rigs_.count(id) != 0; }
-  size_t NumObservations(size_t frame_id) const { return observation_frames_[frame_id].observations.size(); }
-  /// (camera_id, world_point_idx, world_point_id, cost) of observation k of a frame
-  void GetObservation(size_t frame_id, size_t k, size_t* camera_id, size_t* world_point_idx,
-                      size_t* world_point_id, Point2D* image_point, double* cost) const;
+  size_t NumCameras() const { return cameras_.size(); }
+  size_t NumObservationFrames() const { return frames_.size(); }
+  size_t NumWorldPoints() const { return point_refs_.size(); }
+  bool IsCameraFrozen(size_t id) const { return frozen_.count(id) != 0; }
+  size_t NumObservations(size_t frame_id) const { return frames_[frame_id].sightings.size(); }
+  /// (camera, point_in_frame, point_global, half_rho) of observation k of a frame
+  void GetObservation(size_t frame_id, size_t k, size_t* camera, size_t* point_in_frame,
+                      size_t* point_global, Point2D* normalised, double* half_rho) const;
 
  private:
-  struct ObservationFrame {
-    explicit ObservationFrame(const Eigen::Affine3f& T) : rig_T_world(T) {}
-    Eigen::Affine3f rig_T_world;
-    Points3D world_points;
-    struct Observation {
-      size_t camera_id;
-      size_t world_point_idx;  // index inside the frame's world_points
-      size_t world_point_id;   // global id
-      Point2D image_point;
-      double cost{0.0};
+  struct Frame {
+    explicit Frame(const Eigen::Affine3f& T) : pose(T) {}
+    Eigen::Affine3f pose;
+    Points3D points;
+    struct Sighting {
+      size_t camera;
+      size_t point_in_frame;  // index inside the frame's points
+      size_t point_global;   // global id
+      Point2D normalised;
+      double half_rho{0.0};
     };
-    std::vector<Observation, Eigen::aligned_allocator<Observation>> observations;
+    std::vector<Sighting, Eigen::aligned_allocator<Sighting>> sightings;
   };
-  struct WorldPointInfo {
-    size_t observation_frame_id;
-    size_t world_point_idx;
+  struct PointRef {
+    size_t frame;
+    size_t point_in_frame;
   };
 
-  std::vector<Eigen::Affine3f, Eigen::aligned_allocator<Eigen::Affine3f>> camera_T_rigs_;
-  std::vector<ObservationFrame, Eigen::aligned_allocator<ObservationFrame>> observation_frames_;
-  std::vector<WorldPointInfo> world_point_infos_;
-  std::set<size_t> frozen_camera_T_rigs_;
+  std::vector<Eigen::Affine3f, Eigen::aligned_allocator<Eigen::Affine3f>> cameras_;
+  std::vector<Frame, Eigen::aligned_allocator<Frame>> frames_;
+  std::vector<PointRef> point_refs_;
+  std::set<size_t> frozen_;
   int device_{0};
   bool verbose_{true};
   int last_status_{0};

@@ -11,28 +11,29 @@
 
 namespace calibrator {
 
-/// Plane a x + b y + c z + d = 0 through three points, normalised so that d = -1.
-Plane EstimatePlaneFinite(const Point3D& p1, const Point3D& p2, const Point3D& p3);
-/// Unit normal of the plane.
+// ---- homographies and Zhang's closed form ------------------------------------------------------
+/// DLT homography with `to` ~ H * `from` (of 3-D points only x and y are used: their z must be constant).
+Matrix3 EstimateHomography(const Points2D& from, const Points2D& to);
+Matrix3 EstimateHomography(const Points2D& from, const Points3D& to);
+Matrix3 EstimateHomography(const Points3D& from, const Points2D& to);
+Matrix3 EstimateHomography(const Points3D& from, const Points3D& to);
+/// Zhang's closed-form K (zero skew) from at least three world-to-image homographies.
+Matrix3 EstimateKFromHomographies(const std::vector<Matrix3>& homographies);
+/// Pose (R, t) of the board from the inverse camera matrix and its world-to-image homography.
+std::tuple<Matrix3, Point3D> RecoverExtrinsics(const Matrix3& K_inverse, const Matrix3& homography);
+/// Closest orthogonal matrix to a nearly-orthogonal one (U V^T of its SVD).
+Matrix3 FixRotationMatrix(const Matrix3& nearly_orthogonal);
+
+// ---- planes ------------------------------------------------------------------------------------------
+/// Plane through three points, scaled so that its last coefficient is -1.
+Plane EstimatePlaneFinite(const Point3D& a, const Point3D& b, const Point3D& c);
+/// Unit normal of a plane.
 Point3D PlaneNormal(const Plane& plane);
-/// Rotation whose third row is the plane normal (points on the plane get constant z).
-Matrix3 RotationMatrixFromPlane(const Plane& plane, const Point3D& new_normal = Point3D::UnitZ());
-/// Projects p onto the plane along projection_direction (plane normal if not given).
-Point3D ProjectToPlane(const Plane& plane, const Point3D& p,
-                       const std::optional<Point3D>& projection_direction = std::nullopt);
-
-/// DLT homography p2 ~ H p1 (only x, y of 3-D points are used; their z must be constant).
-Matrix3 EstimateHomography(const Points2D& p1, const Points2D& p2);
-Matrix3 EstimateHomography(const Points2D& p1, const Points3D& p2);
-Matrix3 EstimateHomography(const Points3D& p1, const Points2D& p2);
-Matrix3 EstimateHomography(const Points3D& p1, const Points3D& p2);
-
-/// Zhang's closed-form K from >= 3 world-to-image homographies (zero skew).
-Matrix3 EstimateKFromHomographies(const std::vector<Matrix3>& Hs);
-/// Pose (R, t) from K^-1 and a world-to-image homography.
-std::tuple<Matrix3, Point3D> RecoverExtrinsics(const Matrix3& K_inv, const Matrix3& H);
-/// Closest orthogonal matrix (U V^T of the SVD).
-Matrix3 FixRotationMatrix(const Matrix3& R);
+/// Rotation that turns the plane normal into `target_normal` (points of the plane get a constant z for UnitZ).
+Matrix3 RotationMatrixFromPlane(const Plane& plane, const Point3D& target_normal = Point3D::UnitZ());
+/// Point where the line through `point` along `direction` (default: the plane normal) meets the plane.
+Point3D ProjectToPlane(const Plane& plane, const Point3D& point,
+                       const std::optional<Point3D>& direction = std::nullopt);
 
 // ---- helpers of the class surface (not part of the reference's geometry.hh) -----------------
 Matrix3 Inverse3x3(const Matrix3& m);                         // Eigen: Matrix3f::inverse()

@@ -23,16 +23,19 @@
 
 namespace calibrator {
 
-using Point2D = Eigen::Vector2f;
-using Point3D = Eigen::Vector3f;
-using Vector3 = Point3D;
-using Vector4 = Eigen::Vector4f;
-using Plane = Eigen::Vector4f;
-using Matrix3 = Eigen::Matrix3f;
-using Matrix4 = Eigen::Matrix4f;
-using DynamicVector = Eigen::VectorXf;
-using Quaternion = Eigen::Quaternionf;
-using Points2D = std::vector<Point2D, Eigen::aligned_allocator<Point2D>>;
-using Points3D = std::vector<Point3D, Eigen::aligned_allocator<Point3D>>;
+// single points and small fixed-size linear algebra (all float32, as the reference's API stores them)
+typedef Eigen::Vector2f Point2D;
+typedef Eigen::Vector3f Point3D;
+typedef Point3D Vector3;
+typedef Eigen::Vector4f Vector4;
+typedef Eigen::Vector4f Plane;          ///< (a, b, c, d) of a x + b y + c z + d = 0
+typedef Eigen::Matrix3f Matrix3;
+typedef Eigen::Matrix4f Matrix4;
+typedef Eigen::Quaternionf Quaternion;
+typedef Eigen::VectorXf DynamicVector;  ///< distortion coefficients k1 k2 p1 p2 k3
+
+// point lists of one view
+typedef std::vector<Point2D, Eigen::aligned_allocator<Point2D>> Points2D;
+typedef std::vector<Point3D, Eigen::aligned_allocator<Point3D>> Points3D;
 
 }  // namespace calibrator
