@@ -87,7 +87,7 @@ EXPORTED_SYMBOLS = [
 # every symbol include/cc_harness.h declares (synthetic-input harness, host code)
 HARNESS_SYMBOLS = [
     "cc_generator_create", "cc_generator_destroy", "cc_generator_set_k", "cc_generator_set_distortion",
-    "cc_generator_set_noise", "cc_generator_planar", "cc_generator_points",
+    "cc_generator_set_noise", "cc_generator_planar", "cc_generator_points", "cc_rig_scenario", "cc_affine_to_qt",
 ]
 
 _lib = None
@@ -461,3 +461,32 @@ def make_intrinsics_problem(n_frames, pts_per_frame, **gen_kw):
         xyzs.append(xyz)
     offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
     return offsets, np.concatenate(uvs), np.concatenate(xyzs)
+
+
+def rig_scenario(n_cams, n_frames, pts_per_frame, seed=0):
+    """cc_rig_scenario: the reference's rig test scenario (test_extrinsics_calibrator.cpp:48-134) at any size."""
+    C_, F, M = int(n_cams), int(n_frames), int(pts_per_frame)
+    cam_T = np.zeros((C_, 16), dtype=np.float32)
+    cam_T_true = np.zeros((C_, 16), dtype=np.float32)
+    frame_T = np.zeros((F, 16), dtype=np.float32)
+    world = np.zeros((F * M, 3), dtype=np.float32)
+    n = F * M * C_
+    obs_cam = np.zeros(n, dtype=np.uint32)
+    obs_world = np.zeros(n, dtype=np.uint64)
+    obs_uv = np.zeros((n, 2), dtype=np.float32)
+    lib().cc_rig_scenario(C.c_int32(C_), C.c_int32(F), C.c_int32(M), C.c_uint32(seed), _p(cam_T, C.c_float),
+                          _p(cam_T_true, C.c_float), _p(frame_T, C.c_float), _p(world, C.c_float),
+                          _p(obs_cam, C.c_uint32), _p(obs_world, C.c_uint64), _p(obs_uv, C.c_float))
+    return dict(cam_T=cam_T, cam_T_true=cam_T_true, frame_T=frame_T, world_xyz=world, obs_cam=obs_cam,
+                obs_world=obs_world, obs_uv=obs_uv, frame_offsets=(np.arange(F + 1) * M * C_).astype(np.int64),
+                cam_frozen=np.array([1] + [0] * (C_ - 1), dtype=np.uint8))
+
+
+def affine_to_qt(T16):
+    """cc_affine_to_qt on every row: (q [n,4] w x y z, t [n,3]) in fp64."""
+    T16 = _f32(T16).reshape(-1, 16)
+    q = np.zeros((T16.shape[0], 4))
+    t = np.zeros((T16.shape[0], 3))
+    for i in range(T16.shape[0]):
+        lib().cc_affine_to_qt(_p(T16[i], C.c_float), _p(q[i], C.c_double), _p(t[i], C.c_double))
+    return q, t

@@ -110,13 +110,14 @@ __host__ inline void opts_from_public(const cc_options& o, LmOpts* d) {
 
 #if defined(__HIPCC__)
 
-__device__ inline void lm_log(LmCtl& st, cc_iteration* log, int cap, double cost, double cc_,
+// One log record per LM iteration. lm_decide fills `e` (when the caller passes one); the caller stores it at
+// log[st.log_len - 1] (after the gradient of an accepted point is known: solve step).
+__device__ inline void lm_log(LmCtl& st, cc_iteration* e, double cost, double cc_,
                               double mcc, double rd, double sn, int acc, int valid) {
-  if (log && st.log_len < cap) {
-    cc_iteration& it = log[st.log_len];
-    it.cost = cost; it.cost_change = cc_; it.model_cost_change = mcc; it.relative_decrease = rd;
-    it.gradient_max_norm = st.gmax; it.step_norm = sn; it.radius = st.radius; it.accepted = acc;
-    it.valid = valid;
+  if (e) {
+    e->cost = cost; e->cost_change = cc_; e->model_cost_change = mcc; e->relative_decrease = rd;
+    e->gradient_max_norm = st.gmax; e->step_norm = sn; e->radius = st.radius; e->accepted = acc;
+    e->valid = valid;
   }
   st.log_len++;
 }
@@ -135,8 +136,8 @@ __device__ inline void lm_init(LmCtl& st, const LmOpts& o, double cost, double x
 
 // One LM iteration's decision. Inputs are the globally reduced quantities of the candidate point.
 // An accepted candidate flips st.cur. The gradient-tolerance test of the new point is made by the
-// next solve kernel, which owns the reduced gradient (it also patches the log entry's gradient).
-__device__ inline void lm_decide(LmCtl& st, const LmOpts& o, cc_iteration* log, int log_cap,
+// solve step, which owns the reduced gradient (lm_finalize; it also completes the log record).
+__device__ inline void lm_decide(LmCtl& st, const LmOpts& o, cc_iteration* e,
                                  double cand_cost, double q_model, double step2, double xnorm2_cand) {
   st.iter++;
   if (st.step_valid) st.sweeps++;
@@ -147,7 +148,7 @@ __device__ inline void lm_decide(LmCtl& st, const LmOpts& o, cc_iteration* log, 
     st.n_invalid++;
     st.radius /= st.decrease_factor;
     st.decrease_factor *= 2.0;
-    lm_log(st, log, log_cap, st.x_cost, 0.0, mcc, 0.0, 0.0, 0, 0);
+    lm_log(st, e, st.x_cost, 0.0, mcc, 0.0, 0.0, 0, 0);
     if (st.n_invalid >= o.max_consecutive_invalid_steps) { st.done = 1; st.term = CC_FAILURE_INVALID_STEPS; }
   } else {
     st.n_invalid = 0;
@@ -156,10 +157,10 @@ __device__ inline void lm_decide(LmCtl& st, const LmOpts& o, cc_iteration* log, 
     const double cost_change = st.x_cost - cand_cost;
     if (step_norm <= o.parameter_tolerance * (st.x_norm + o.parameter_tolerance)) {
       st.done = 1; st.term = CC_CONVERGENCE_PARAMETER;
-      lm_log(st, log, log_cap, st.x_cost, cost_change, mcc, 0.0, step_norm, 0, 1);
+      lm_log(st, e, st.x_cost, cost_change, mcc, 0.0, step_norm, 0, 1);
     } else if (fabs(cost_change) <= o.function_tolerance * st.x_cost) {
       st.done = 1; st.term = CC_CONVERGENCE_FUNCTION;
-      lm_log(st, log, log_cap, st.x_cost, cost_change, mcc, 0.0, step_norm, 0, 1);
+      lm_log(st, e, st.x_cost, cost_change, mcc, 0.0, step_norm, 0, 1);
     } else {
       // TrustRegionStepEvaluator::StepQuality
       double quality;
@@ -191,20 +192,30 @@ __device__ inline void lm_decide(LmCtl& st, const LmOpts& o, cc_iteration* log, 
         const int maxn = o.use_nonmonotonic_steps ? o.max_consecutive_nonmonotonic_steps : 0;
         if (st.num_nonmono == maxn) { st.reference_cost = st.candidate_cost; st.acc_ref = st.acc_cand; }
         st.n_success++;
-        lm_log(st, log, log_cap, st.x_cost, cost_change, mcc, quality, step_norm, 1, 1);
+        lm_log(st, e, st.x_cost, cost_change, mcc, quality, step_norm, 1, 1);
       } else {
         st.radius /= st.decrease_factor;
         st.decrease_factor *= 2.0;
-        lm_log(st, log, log_cap, st.x_cost, cost_change, mcc, quality, step_norm, 0, 1);
+        lm_log(st, e, st.x_cost, cost_change, mcc, quality, step_norm, 0, 1);
       }
     }
   }
-  if (!st.done) {
-    if (st.iter >= o.max_iterations) { st.done = 1; st.term = CC_NO_CONVERGENCE; }
-    else if (st.radius < o.min_radius) { st.done = 1; st.term = CC_MIN_RADIUS; }
-  }
+  // TrustRegionMinimizer::FinalizeIterationAndCheckIfMinimizerCanContinue tests max iterations, then the
+  // gradient tolerance, then the minimum radius: the first is made here, the other two by the solve step
+  // (lm_finalize), which owns the gradient of the accepted point.
+  if (!st.done && st.iter >= o.max_iterations) { st.done = 1; st.term = CC_NO_CONVERGENCE; }
   st.step_valid = 0;
   st.cand_pending = 0;
+}
+
+// Second half of FinalizeIterationAndCheckIfMinimizerCanContinue, run by the solve step once the gradient
+// max-norm of the accepted point is known: gradient tolerance, then minimum trust-region radius. Returns
+// true when the minimiser goes on (the caller then computes the next step).
+__device__ inline bool lm_finalize(LmCtl& st, const LmOpts& o, double gmax) {
+  st.gmax = gmax;
+  if (gmax <= o.gradient_tolerance) { st.done = 1; st.term = CC_CONVERGENCE_GRADIENT; return false; }
+  if (st.radius < o.min_radius) { st.done = 1; st.term = CC_MIN_RADIUS; return false; }
+  return true;
 }
 
 // ---- small device math -------------------------------------------------------------------

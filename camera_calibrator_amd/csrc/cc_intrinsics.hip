@@ -1,18 +1,19 @@
 // cc_intrinsics.hip -- single-camera intrinsics bundle adjustment on MI355X (gfx950).
 //
 // Replaces the ceres::Problem/ceres::Solve block of Calibrator::Optimize
-// (/root/reference/src/calibrator.cpp:236-324). Four kernels per LM iteration:
+// (/root/reference/src/calibrator.cpp:236-324). Two kernels per LM iteration (single GPU / mailbox exchange;
+// the RCCL route keeps the solve step in a kernel of its own around the all-reduce):
 //
-//   elim   : per frame, damped 6x6 pose block -> Cholesky, Z = L^-1 [H_ps | g_p]; partial sums of
-//            the reduced (Schur) 9x9 system over frames.
-//   solve  : reduce the partials, add the LM diagonal, 9x9 Cholesky solve -> scaled shared step.
+//   decide+elim+solve : reduce the per-frame statistics, Ceres trust-region logic; per frame, damped 6x6
+//            pose block -> Cholesky, Z = L^-1 [H_ps | g_p]; partial sums of the reduced (Schur) 9x9
+//            system over frames; the LAST block to finish reduces the partials, adds the LM diagonal and
+//            solves the 9x9 system -> scaled shared step, gradient / radius tests, control block.
 //   sweep  : one workgroup per frame. Prologue back-substitutes the frame's pose step, forms the
 //            candidate point (QuaternionManifold::Plus) and the frame's model-cost term; the main
 //            loop evaluates pinhole + radial-tangential projection and the analytic 2x15 Jacobian
 //            per observation (one lane = one observation), stages [J r] rows through LDS and
 //            contracts them with v_mfma_f64_16x16x4_f64 into the frame's 16x16 Gram block
 //            G_f = sum_rows [J r]^T [J r]  (= H_ss,f H_sp,f g_s,f / H_pp,f g_p,f / 2 cost_f).
-//   decide : reduce the per-frame statistics, Ceres trust-region logic on one thread.
 //
 // HBM layout (per handle): uv float2[N], xyz float[3N] exactly as the API hands them over
 // (20 B / observation, read once per sweep, coalesced: lane i of a wave reads observation
@@ -61,8 +62,11 @@ struct IntrDev {
   double* vec_decide; // [16]  reduced sweep statistics (all-reduced across ranks)
   double* ds;         // [16] scaled shared step
   double* ss;         // [16] Jacobi scale of the shared block
-  LmCtl* ctl;         // read by sweep / decide_elim, written by solve
-  LmCtl* ctl_next;    // written by decide_elim (block 0) and solve; polled by the host
+  LmCtl* ctl;         // read by sweep / decide_elim, written by the solve step
+  LmCtl* ctl_next;    // written by the solve step (RCCL route: also by block 0 of decide_elim); read by the host
+  unsigned* arrive;   // [1] blocks of decide_elim that have stored their partial row (last-block-done)
+  unsigned long long* pub_seq;   // [1] device: chunks published so far
+  unsigned long long* host_pub;  // pinned host memory: [0] sequence word, [2..19] copy of the control block
   LmOpts* opts;
   cc_iteration* log;
   int32_t log_cap;
@@ -398,27 +402,133 @@ __global__ __launch_bounds__(256) void k_intr_stats_reduce(IntrDev P) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// decide + elim.  Every block reduces the (small) per-frame statistics itself and takes the same
-// trust-region decision on a register copy of the control block; block 0 publishes it. Then the
-// block eliminates the pose blocks of its frames: 16 lanes per frame.
+// Solve step (one thread): gradient / radius tests of the accepted point (lm_finalize), then the reduced
+// 9x9 system. V: the kVecSolve reduced sums (LDS); c: the control block after the decision; e: this
+// iteration's log record (NULL when there is none). Writes the scaled shared step P.ds.
+// V layout: [0..79] column sums (col 73 unused), [80 + rank] each rank's max |pose gradient|.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void intr_solve_step(const IntrDev& P, const double* V, LmCtl& c, cc_iteration* e) {
+  const LmOpts o = *P.opts;
+  // gradient of the accepted point: max-norm over the tangent coordinates
+  double gmax = 0.0;
+  for (int r = 0; r < P.nranks && r < 32; ++r) gmax = fmax(gmax, V[kPartialCols + r]);
+#pragma unroll
+  for (int j = 0; j < 9; ++j)
+    if (!(P.mask & (1u << j))) gmax = fmax(gmax, fabs(V[PC_GS + j]));
+  if (e && e->accepted) e->gradient_max_norm = gmax;
+  if (!lm_finalize(c, o, gmax)) return;
+  bool ok = !(V[PC_FAIL] > 0.0);
+  double A[45], b[9], inv[9];
+  {
+    int idx = 0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+      for (int k = j; k < 9; ++k) { A[tri(k, j)] = V[idx]; ++idx; }
+  }
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    A[tri(j, j)] += clampd(V[PC_HDIAG + j], o.min_lm_diagonal, o.max_lm_diagonal) / c.radius;
+    b[j] = V[PC_B + j];
+  }
+#pragma unroll
+  for (int j = 0; j < 9; ++j)
+    if (P.mask & (1u << j)) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        if (k < j) A[tri(j, k)] = 0.0;
+        if (k > j) A[tri(k, j)] = 0.0;
+      }
+      A[tri(j, j)] = 1.0;
+      b[j] = 0.0;
+    }
+  // Cholesky with reciprocal square roots; the substitutions multiply by 1 / L_jj
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    double d = A[tri(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= A[tri(j, k)] * A[tri(j, k)];
+    ok = ok && (d > 0.0) && isfinite(d);
+    const double r = rsqrt(d);
+    inv[j] = r;
+#pragma unroll
+    for (int i = j + 1; i < 9; ++i) {
+      double a = A[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) a -= A[tri(i, k)] * A[tri(j, k)];
+      A[tri(i, j)] = a * r;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    double a = b[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) a -= A[tri(i, k)] * b[k];
+    b[i] = a * inv[i];
+  }
+#pragma unroll
+  for (int i = 8; i >= 0; --i) {
+    double a = b[i];
+#pragma unroll
+    for (int k = i + 1; k < 9; ++k) a -= A[tri(k, i)] * b[k];
+    b[i] = a * inv[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    P.ds[i] = -b[i];
+    ok = ok && isfinite(b[i]);
+  }
+  c.step_valid = ok ? 1 : 0;
+  c.cand_pending = 1;
+}
+
+// Hands the control block to the host without a copy engine in the way: payload words first, then the
+// sequence word the host spins on (system-scope stores into pinned host memory; one thread).
+__device__ __forceinline__ void publish_to_host(const IntrDev& P, const LmCtl& c) {
+  if (!P.host_pub) return;
+  const unsigned long long* w = reinterpret_cast<const unsigned long long*>(&c);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(LmCtl) / 8); ++i)
+    __hip_atomic_store(P.host_pub + 2 + i, w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const unsigned long long seq = *P.pub_seq + 1ull;
+  *P.pub_seq = seq;
+  __hip_atomic_store(P.host_pub, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ---------------------------------------------------------------------------------------------
+// decide + elim (+ solve).  Every block reduces the (small) per-frame statistics itself and takes the
+// same trust-region decision on a register copy of the control block. Then the block eliminates the
+// pose blocks of its frames: 16 lanes per frame.
 // Output row per block (80 columns): [0..44] upper triangle of the reduced 9x9 system (row-major
 // pairs j<=k), [45..53] reduced rhs, [54..62] diag of the scaled H_ss, [63] Cholesky failures,
 // [64..72] unscaled shared gradient, [73] max |pose gradient| (max-combined), rest 0.
-// MODE 0: reduce stats inline (single GPU); MODE 2: stats come all-reduced in vec_decide;
-// MODE 3: stats are summed from the mailbox slots the ranks posted (kind 1).
+// MODE 0 (single GPU) and MODE 3 (mailbox exchange): the row is stored write-through, the block arrives on
+// a counter, and the LAST block to arrive sums the rows (sc1 loads: no fence needed, MI355X guide, valid
+// hand-off forms), [MODE 3: exchanges the sums with the other ranks,] runs the solve step and publishes
+// the control block: nobody else writes it, and everybody has read it before the last arrival.
+// MODE 2 (RCCL): statistics come all-reduced in vec_decide; block 0 publishes the decision and the solve
+// step runs in k_intr_solve<1> -> all-reduce -> k_intr_solve<2>.
+// publish != 0: last kernel of a host chunk -> also hand the control block to the host (pinned memory).
 // ---------------------------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P) {
+__global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish) {
   __shared__ double Zs[16][64];
   __shared__ double red[16][kPartialCols];
   __shared__ double s_w[128];
   __shared__ double s_tot[16];
   __shared__ double s_ss[16];
   __shared__ LmCtl s_ctl;
+  __shared__ cc_iteration s_log;
+  __shared__ int s_logged;
+  __shared__ int s_last;
   __shared__ unsigned char pj[48], pk[48];
+  constexpr bool kFused = MODE != 2;
   const int tid = threadIdx.x, g = tid >> 4, l = tid & 15;
   const LmCtl* ctl = P.ctl;
-  if (ctl->done) return;
+  if (ctl->done) {
+    if (publish && blockIdx.x == 0 && tid == 0) publish_to_host(P, *ctl);
+    return;
+  }
   const int phase = ctl->phase;
   const bool pending = ctl->cand_pending != 0;
   const bool need = phase == 0 || (pending && ctl->step_valid);
@@ -455,7 +565,7 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P) {
   if (tid == 0) {
     LmCtl c = *ctl;
     const LmOpts o = *P.opts;
-    cc_iteration* log = blockIdx.x == 0 ? P.log : nullptr;
+    const int len0 = c.log_len;
     if (phase == 0) {
       const double* k = P.intr + c.cur * 16;
       double xn2 = s_tot[ST_XNORM2];
@@ -473,11 +583,15 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P) {
         const double* k0 = P.intr + c.cur * 16;
         for (int i = 0; i < 9; ++i) { const double d = kc[i] - k0[i]; step2 += d * d; xn2 += kc[i] * kc[i]; }
       }
-      lm_decide(c, o, log, P.log_cap, s_tot[ST_COST], s_tot[ST_QMODEL], step2, xn2);
+      lm_decide(c, o, &s_log, s_tot[ST_COST], s_tot[ST_QMODEL], step2, xn2);
     }
     if (!exchange_ok) { c.done = 1; c.term = CC_FAILURE_EXCHANGE; }
     s_ctl = c;
-    if (blockIdx.x == 0) *P.ctl_next = c;
+    s_logged = c.log_len != len0;
+    if (!kFused && blockIdx.x == 0) {
+      if (s_logged && c.log_len <= P.log_cap) P.log[c.log_len - 1] = s_log;
+      *P.ctl_next = c;
+    }
   }
 #if CC_ABLATE_D == 2
   if (ctl->gmax == 1e30) return;  // marker set by cc_intrinsics_profile_kernel
@@ -489,10 +603,12 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P) {
       for (int k = j; k < 9; ++k) { pj[o] = (unsigned char)j; pk[o] = (unsigned char)k; ++o; }
   }
   __syncthreads();
-  if (s_ctl.done) return;
+  const bool stop = s_ctl.done != 0;   // the same answer in every block
+  if (stop && !kFused) return;
 #if CC_ABLATE_D == 3
   if (ctl->gmax == 1e30) return;  // marker set by cc_intrinsics_profile_kernel
 #endif
+  if (!stop) {
   const int cur = s_ctl.cur;
   const double inv_radius = 1.0 / s_ctl.radius;
   const double mn = P.opts->min_lm_diagonal, mx = P.opts->max_lm_diagonal;
@@ -627,29 +743,104 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P) {
     double a = 0.0;
     if (tid == PC_GMAXP) { for (int g2 = 0; g2 < 16; ++g2) a = fmax(a, red[g2][tid]); }
     else { for (int g2 = 0; g2 < 16; ++g2) a += red[g2][tid]; }
-    P.partial[blockIdx.x * kPartialCols + tid] = a;
+    if (kFused)   // write-through: the last block reads these words with sc1 loads
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(P.partial) + blockIdx.x * kPartialCols + tid,
+                         (unsigned long long)__double_as_longlong(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      P.partial[blockIdx.x * kPartialCols + tid] = a;
   }
+  }  // !stop
+  if (!kFused) return;
+
+  // ---- last-block-done: every storing wave drains its stores, the block arrives, the last one goes on
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(P.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = prev + 1u == gridDim.x;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (tid == 0) __hip_atomic_store(P.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+  double* sv = &red[0][0];            // [kVecSolve] reduced sums (the staging rows are no longer needed)
+  double* s_part = &red[2][0];        // [3][kPartialCols]
+  if (!stop) {
+    const bool active = true;
+    {
+      // thread -> (column, row group of 3): all rows in one round trip, sc1 loads
+      const int col = tid % kPartialCols, grp = tid / kPartialCols;
+      const int nblk = (int)gridDim.x;
+      if (grp < 3) {
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(P.partial) + col;
+        double v[22];
+#pragma unroll
+        for (int u = 0; u < 22; ++u) {
+          const int b = grp + 3 * u;
+          v[u] = b < nblk ? __longlong_as_double((long long)__hip_atomic_load(src + b * kPartialCols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
+        }
+        double a = 0.0;
+        if (col == PC_GMAXP) {
+#pragma unroll
+          for (int u = 0; u < 22; ++u) a = fmax(a, v[u]);
+        } else {
+#pragma unroll
+          for (int u = 0; u < 22; ++u) a += v[u];
+        }
+        s_part[grp * kPartialCols + col] = a;
+      }
+    }
+    __syncthreads();
+    if (tid < kVecSolve) {   // sv = red[0..1] and s_part = red[2..4] do not overlap
+      double a = 0.0;
+      if (tid < kPartialCols) {
+        if (tid != PC_GMAXP) a = (s_part[tid] + s_part[kPartialCols + tid]) + s_part[2 * kPartialCols + tid];
+      } else if (tid == kPartialCols + P.rank) {
+        a = fmax(fmax(s_part[PC_GMAXP], s_part[kPartialCols + PC_GMAXP]), s_part[2 * kPartialCols + PC_GMAXP]);
+      }
+      sv[tid] = a;
+    }
+    __syncthreads();
+    if (MODE == 3 && active) {
+      // mailbox all-reduce of the 112 sums (kind 0): post, wait for every rank, add in rank order
+      __shared__ int s_ok2;
+      const unsigned long long epoch = P.x.seq[0] + 1ull;
+      p2p_post(P.x, 0, epoch, P.rank, P.nranks, sv, kVecSolve);
+      const double a = p2p_collect(P.x, 0, epoch, P.rank, P.nranks, kVecSolve, &s_ok2);
+      exchange_ok = s_ok2 != 0;
+      if (tid < kVecSolve) sv[tid] = exchange_ok ? a : 0.0;
+      if (tid == 0) P.x.seq[0] = epoch;
+      __syncthreads();
+    }
+  }
+  if (tid != 0) return;
+  LmCtl c = s_ctl;
+  cc_iteration* e = s_logged ? &s_log : nullptr;
+  if (!exchange_ok) { c.done = 1; c.term = CC_FAILURE_EXCHANGE; }
+  else if (!stop) intr_solve_step(P, sv, c, e);
+  if (publish == 2) return;   // timing replay (cc_intrinsics_profile_kernel): the state stays as it is
+  if (e && c.log_len <= P.log_cap) P.log[c.log_len - 1] = *e;
+  *P.ctl = c;
+  *P.ctl_next = c;
+  if (publish) publish_to_host(P, c);
 }
 
 // ---------------------------------------------------------------------------------------------
-// solve (one block): reduce the elimination partials, add the LM diagonal, 9x9 Cholesky in
-// registers, gradient-tolerance test of the accepted point; publishes the control block for the
-// sweep. MODE 0: reduce + solve; 1: reduce only (-> vec_solve, then all-reduced); 2: solve only;
-// 3: reduce + mailbox exchange with the other ranks + solve.
+// RCCL route only. MODE 1: reduce the elimination partials of this rank -> vec_solve (then all-reduced);
+// MODE 2: the solve step on the all-reduced sums; publishes the control block for the sweep.
 // vec_solve: [0..79] column sums (col 73 unused), [80 + rank] this rank's max |pose gradient|.
 // ---------------------------------------------------------------------------------------------
 constexpr int kSolveThreads = 8 * kPartialCols;
 
 template <int MODE>
-__global__ __launch_bounds__(kSolveThreads) void k_intr_solve(IntrDev P, int nblk) {
+__global__ __launch_bounds__(kSolveThreads) void k_intr_solve(IntrDev P, int nblk, int publish) {
+  static_assert(MODE == 1 || MODE == 2, "single-GPU and mailbox solves are fused into k_intr_decide_elim");
   __shared__ double sv[kVecSolve];
   __shared__ double s_part[8][kPartialCols];
   const int tid = threadIdx.x;
   const LmCtl* cn = P.ctl_next;
-  bool exchange_ok = true;
-  if (MODE != 2) {
-    // thread -> (column, row group): all rows of the partials are fetched in one round trip, issued
-    // before anything is known about the control block (the buffer always exists)
+  const bool active = !cn->done && cn->phase != 0;
+  if (MODE == 1) {
+    // thread -> (column, row group): all rows of the partials are fetched in one round trip
     const int col = tid % kPartialCols, grp = tid / kPartialCols;
     double v[8];
 #pragma unroll
@@ -657,147 +848,50 @@ __global__ __launch_bounds__(kSolveThreads) void k_intr_solve(IntrDev P, int nbl
       const int b = grp + 8 * u;
       v[u] = b < nblk ? P.partial[b * kPartialCols + col] : 0.0;
     }
-    const bool act = !cn->done && cn->phase != 0;
     double a = 0.0;
-    if (act) {
+    if (active) {
       if (col == PC_GMAXP) a = fmax(fmax(fmax(v[0], v[1]), fmax(v[2], v[3])), fmax(fmax(v[4], v[5]), fmax(v[6], v[7])));
       else a = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     }
     s_part[grp][col] = a;
     if (tid >= kPartialCols && tid < kVecSolve) sv[tid] = 0.0;  // rank slots; ours is written below
-  }
-  const int done = cn->done, phase = cn->phase;
-  const bool active = !done && phase != 0;
-  if (MODE != 2) {
     __syncthreads();
     if (tid < kPartialCols) {
-      double a = 0.0;
+      double a2 = 0.0;
       if (tid == PC_GMAXP) {
-        if (active) for (int g2 = 0; g2 < 8; ++g2) a = fmax(a, s_part[g2][tid]);
-        sv[kPartialCols + P.rank] = a;
+        if (active) for (int g2 = 0; g2 < 8; ++g2) a2 = fmax(a2, s_part[g2][tid]);
+        sv[kPartialCols + P.rank] = a2;
         sv[tid] = 0.0;
       } else {
         if (active)
-          a = ((s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid])) +
-              ((s_part[4][tid] + s_part[5][tid]) + (s_part[6][tid] + s_part[7][tid]));
-        sv[tid] = a;
+          a2 = ((s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid])) +
+               ((s_part[4][tid] + s_part[5][tid]) + (s_part[6][tid] + s_part[7][tid]));
+        sv[tid] = a2;
       }
     }
     __syncthreads();
-    if (MODE == 1) {
-      if (tid < kVecSolve) P.vec_solve[tid] = sv[tid];
-      return;
-    }
-    if (MODE == 3 && active) {
-      // mailbox all-reduce of the 112 sums (kind 0): post, wait for every rank, add in rank order
-      __shared__ int s_ok;
-      const unsigned long long epoch = P.x.seq[0] + 1ull;
-      p2p_post(P.x, 0, epoch, P.rank, P.nranks, sv, kVecSolve);
-      const double a = p2p_collect(P.x, 0, epoch, P.rank, P.nranks, kVecSolve, &s_ok);
-      exchange_ok = s_ok != 0;
-      if (tid < kVecSolve) sv[tid] = exchange_ok ? a : 0.0;
-      if (tid == 0) P.x.seq[0] = epoch;
-      __syncthreads();
-    }
-  } else {
-    if (tid < kVecSolve) sv[tid] = P.vec_solve[tid];
-    __syncthreads();
+    if (tid < kVecSolve) P.vec_solve[tid] = sv[tid];
+    return;
   }
+  if (tid < kVecSolve) sv[tid] = P.vec_solve[tid];
+  __syncthreads();
   if (tid != 0) return;
   LmCtl c = *cn;
-  if (!exchange_ok) {
-    c.done = 1;
-    c.term = CC_FAILURE_EXCHANGE;
-  } else if (active) {
-    const LmOpts o = *P.opts;
-    const double* V = sv;
-    // gradient of the accepted point: max-norm over the tangent coordinates
-    double gmax = 0.0;
-    for (int r = 0; r < P.nranks && r < 32; ++r) gmax = fmax(gmax, V[kPartialCols + r]);
-#pragma unroll
-    for (int j = 0; j < 9; ++j)
-      if (!(P.mask & (1u << j))) gmax = fmax(gmax, fabs(V[PC_GS + j]));
-    c.gmax = gmax;
-    if (c.log_len > 0 && c.log_len <= P.log_cap && P.log[c.log_len - 1].accepted)
-      P.log[c.log_len - 1].gradient_max_norm = gmax;
-    if (gmax <= o.gradient_tolerance) {
-      c.done = 1;
-      c.term = CC_CONVERGENCE_GRADIENT;
-    } else if (c.iter == 0 && c.radius < o.min_radius) {
-      // the loop-top radius test of the very first iteration (later ones are made by lm_decide)
-      c.done = 1;
-      c.term = CC_MIN_RADIUS;
-    } else {
-      bool ok = !(V[PC_FAIL] > 0.0);
-      double A[45], b[9], inv[9];
-      {
-        int idx = 0;
-#pragma unroll
-        for (int j = 0; j < 9; ++j)
-#pragma unroll
-          for (int k = j; k < 9; ++k) { A[tri(k, j)] = V[idx]; ++idx; }
-      }
-#pragma unroll
-      for (int j = 0; j < 9; ++j) {
-        A[tri(j, j)] += clampd(V[PC_HDIAG + j], o.min_lm_diagonal, o.max_lm_diagonal) / c.radius;
-        b[j] = V[PC_B + j];
-      }
-#pragma unroll
-      for (int j = 0; j < 9; ++j)
-        if (P.mask & (1u << j)) {
-#pragma unroll
-          for (int k = 0; k < 9; ++k) {
-            if (k < j) A[tri(j, k)] = 0.0;
-            if (k > j) A[tri(k, j)] = 0.0;
-          }
-          A[tri(j, j)] = 1.0;
-          b[j] = 0.0;
-        }
-      // Cholesky with reciprocal square roots; the substitutions multiply by 1 / L_jj
-#pragma unroll
-      for (int j = 0; j < 9; ++j) {
-        double d = A[tri(j, j)];
-#pragma unroll
-        for (int k = 0; k < j; ++k) d -= A[tri(j, k)] * A[tri(j, k)];
-        ok = ok && (d > 0.0) && isfinite(d);
-        const double r = rsqrt(d);
-        inv[j] = r;
-#pragma unroll
-        for (int i = j + 1; i < 9; ++i) {
-          double a = A[tri(i, j)];
-#pragma unroll
-          for (int k = 0; k < j; ++k) a -= A[tri(i, k)] * A[tri(j, k)];
-          A[tri(i, j)] = a * r;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 9; ++i) {
-        double a = b[i];
-#pragma unroll
-        for (int k = 0; k < i; ++k) a -= A[tri(i, k)] * b[k];
-        b[i] = a * inv[i];
-      }
-#pragma unroll
-      for (int i = 8; i >= 0; --i) {
-        double a = b[i];
-#pragma unroll
-        for (int k = i + 1; k < 9; ++k) a -= A[tri(k, i)] * b[k];
-        b[i] = a * inv[i];
-      }
-#pragma unroll
-      for (int i = 0; i < 9; ++i) {
-        P.ds[i] = -b[i];
-        ok = ok && isfinite(b[i]);
-      }
-      c.step_valid = ok ? 1 : 0;
-      c.cand_pending = 1;
-    }
+  if (active) {
+    // the log record of this iteration was stored by decide_elim<2>; complete it in place
+    cc_iteration* e = (c.log_len > 0 && c.log_len <= P.log_cap) ? &P.log[c.log_len - 1] : nullptr;
+    cc_iteration rec;
+    if (e) rec = *e;
+    intr_solve_step(P, sv, c, e ? &rec : nullptr);
+    if (e && rec.accepted) e->gradient_max_norm = rec.gradient_max_norm;
   }
   *P.ctl = c;
   *P.ctl_next = c;
+  if (publish) publish_to_host(P, c);
 }
 
-// restores the initial point into buffer 0 and clears both control blocks (one launch per restart)
+// restores the initial point into buffer 0 and clears the control blocks and the arrival counter (first
+// node of a solve-from-the-initial-state graph, or one launch per restart)
 __global__ __launch_bounds__(256) void k_intr_reset(IntrDev P, const double* init_intr, const double* init_pose) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < P.F * 8) P.pose[i] = init_pose[i];
@@ -806,6 +900,7 @@ __global__ __launch_bounds__(256) void k_intr_reset(IntrDev P, const double* ini
     reinterpret_cast<double*>(P.ctl)[i] = 0.0;
     reinterpret_cast<double*>(P.ctl_next)[i] = 0.0;
   }
+  if (i == 0) *P.arrive = 0u;
 }
 
 }  // namespace cc
@@ -833,13 +928,19 @@ struct cc_intrinsics {
   double* init_intr = nullptr;  // [16]
   double* init_pose = nullptr;  // [F][8]
   bool have_state = false;
-  void* pinned = nullptr;      // cached 512-byte pinned block: h_ctl | h_opts
+  void* pinned = nullptr;      // cached 512-byte pinned block: host_pub (160 B) | h_ctl | h_opts
+  volatile unsigned long long* host_pub = nullptr;  // [0] sequence word written by the device, [2..19] control block
+  unsigned long long pub_count = 0;                 // chunks published so far (what the sequence word will read next: + 1)
   cc::LmCtl* h_ctl = nullptr;  // pinned
   cc::LmOpts* h_opts = nullptr;  // pinned staging of the options
   cc::LmOpts cached_opts{};     // what the device currently holds
   bool opts_valid = false;
-  bool ctl_fresh = false;       // device control blocks are zeroed and the point sits in buffer 0
-  hipGraphExec_t graph[2] = {nullptr, nullptr};  // [0]: 1 + check_interval triples, [1]: check_interval triples
+  bool ctl_fresh = false;       // the next solve starts from the point of the last set_state
+  bool reset_pending = false;   // ... and the device buffers have not been restored yet (lazy: the restart is the
+                                // first node of the solve's graph, cc_intrinsics_reset costs no launch of its own)
+  // [0]: restart + initial evaluation + check_interval iterations, [1]: check_interval iterations,
+  // [2]: initial evaluation + check_interval iterations (continuing from the accepted point of the last solve)
+  hipGraphExec_t graph[3] = {nullptr, nullptr, nullptr};
   int graph_iters = 0;
   cc::Comm* comm = nullptr;
   // mailbox exchange (cc_intrinsics_exchange_export / _attach): our mailbox and the peers' mappings
@@ -877,35 +978,33 @@ static void launch_sweep(cc_intrinsics* h, bool profile, bool in_solve = false) 
   hipLaunchKernelGGL(k_intr_sweep, dim3((unsigned)h->F), dim3(kSweepThreads), kSweepLdsBytes, h->stream, h->d, in_solve ? 1 : 0);
 }
 
-// one triple: solve -> sweep -> decide+elim. The very first triple of a solve is the initial
-// evaluation: both control blocks are zero there and the solve step would only copy one onto the
-// other, so it (and its all-reduce) is left out.
-static int enqueue_triple(cc_intrinsics* h, bool profile, bool initial = false) {
-  if (h->exchange) {
-    // mailbox exchange inside the kernels: no library call, so the chain stays graph-capturable
-    if (!initial) { Probe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_intr_solve<3>, dim3(1), dim3(kSolveThreads), 0, h->stream, h->d, h->elim_blocks); }
-    launch_sweep(h, profile, true);
-    { Probe p(h, CC_K_ELIM, profile); hipLaunchKernelGGL(k_intr_decide_elim<3>, dim3(h->elim_blocks), dim3(256), 0, h->stream, h->d); }
-    return 0;
-  }
-  if (initial) {
-  } else if (h->comm) {
-    { Probe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_intr_solve<1>, dim3(1), dim3(kSolveThreads), 0, h->stream, h->d, h->elim_blocks); }
-    { Probe p(h, CC_K_ALLREDUCE, profile); if (int rc = comm_allreduce_sum(h->comm, h->d.vec_solve, kVecSolve, h->stream)) return rc; }
-    { Probe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_intr_solve<2>, dim3(1), dim3(kSolveThreads), 0, h->stream, h->d, h->elim_blocks); }
-  } else {
-    Probe p(h, CC_K_SOLVE, profile);
-    hipLaunchKernelGGL(k_intr_solve<0>, dim3(1), dim3(kSolveThreads), 0, h->stream, h->d, h->elim_blocks);
-  }
-  launch_sweep(h, profile, true);
+static void launch_reset(cc_intrinsics* h) {
+  const unsigned blocks = (unsigned)((h->F * 8 + 255) / 256);
+  hipLaunchKernelGGL(k_intr_reset, dim3(blocks), dim3(256), 0, h->stream, h->d, h->init_intr, h->init_pose);
+}
+
+// One round = sweep -> decide + elim + solve step (two kernels; the very first round of a solve is the initial
+// evaluation, same launches). RCCL route: the solve step is a pair of kernels around the all-reduce of the
+// reduced sums at the head of the round (left out of the initial round: nothing to solve yet).
+// publish: last round of a host chunk -> its final kernel hands the control block to the host.
+static int enqueue_round(cc_intrinsics* h, bool profile, bool initial, bool publish) {
+  const int pub = publish ? 1 : 0;
   if (h->comm) {
+    if (!initial) {
+      { Probe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_intr_solve<1>, dim3(1), dim3(kSolveThreads), 0, h->stream, h->d, h->elim_blocks, 0); }
+      { Probe p(h, CC_K_ALLREDUCE, profile); if (int rc = comm_allreduce_sum(h->comm, h->d.vec_solve, kVecSolve, h->stream)) return rc; }
+      { Probe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_intr_solve<2>, dim3(1), dim3(kSolveThreads), 0, h->stream, h->d, h->elim_blocks, 0); }
+    }
+    launch_sweep(h, profile, true);
     { Probe p(h, CC_K_DECIDE, profile); hipLaunchKernelGGL(k_intr_stats_reduce, dim3(1), dim3(256), 0, h->stream, h->d); }
     { Probe p(h, CC_K_ALLREDUCE, profile); if (int rc = comm_allreduce_sum(h->comm, h->d.vec_decide, 16, h->stream)) return rc; }
-    { Probe p(h, CC_K_ELIM, profile); hipLaunchKernelGGL(k_intr_decide_elim<2>, dim3(h->elim_blocks), dim3(256), 0, h->stream, h->d); }
-  } else {
-    Probe p(h, CC_K_ELIM, profile);
-    hipLaunchKernelGGL(k_intr_decide_elim<0>, dim3(h->elim_blocks), dim3(256), 0, h->stream, h->d);
+    { Probe p(h, CC_K_ELIM, profile); hipLaunchKernelGGL(k_intr_decide_elim<2>, dim3(h->elim_blocks), dim3(256), 0, h->stream, h->d, 0); }
+    return 0;
   }
+  launch_sweep(h, profile, true);
+  Probe p(h, CC_K_ELIM, profile);
+  if (h->exchange) hipLaunchKernelGGL(k_intr_decide_elim<3>, dim3(h->elim_blocks), dim3(256), 0, h->stream, h->d, pub);
+  else hipLaunchKernelGGL(k_intr_decide_elim<0>, dim3(h->elim_blocks), dim3(256), 0, h->stream, h->d, pub);
   return 0;
 }
 
@@ -915,10 +1014,41 @@ static int write_ctl(cc_intrinsics* h, const LmCtl& c) {
   return 0;
 }
 
+// restores the point of the last set_state on the device if that is still owed (see reset_pending)
+static int flush_reset(cc_intrinsics* h) {
+  if (!h->reset_pending) return 0;
+  launch_reset(h);
+  CC_HIP(hipGetLastError());
+  h->reset_pending = false;
+  return 0;
+}
+
 static int read_ctl(cc_intrinsics* h, LmCtl* c) {
+  if (int rc = flush_reset(h)) return rc;
   CC_HIP(hipMemcpyAsync(h->h_ctl, h->d.ctl_next, sizeof(LmCtl), hipMemcpyDeviceToHost, h->stream));
   CC_HIP(hipStreamSynchronize(h->stream));
   *c = *h->h_ctl;
+  return 0;
+}
+
+// Waits for the chunk just enqueued: spins on the sequence word its last kernel stores into pinned host memory
+// (no copy engine, no stream synchronisation on the way), then takes the control block from next to it. A
+// stream that has gone idle without the word showing up (a kernel fault, a stale counter) falls back to a copy.
+static int wait_published(cc_intrinsics* h, LmCtl* c) {
+  const unsigned long long want = ++h->pub_count;
+  for (unsigned spins = 0;; ++spins) {
+    if (__atomic_load_n(const_cast<const unsigned long long*>(h->host_pub), __ATOMIC_ACQUIRE) == want) break;
+    if ((spins & 0xfffu) == 0xfffu) {
+      const hipError_t q = hipStreamQuery(h->stream);
+      if (q == hipSuccess) {
+        if (__atomic_load_n(const_cast<const unsigned long long*>(h->host_pub), __ATOMIC_ACQUIRE) == want) break;
+        h->pub_count = __atomic_load_n(const_cast<const unsigned long long*>(h->host_pub), __ATOMIC_ACQUIRE);
+        return read_ctl(h, c);
+      }
+      if (q != hipErrorNotReady) return fail(CC_ERR_HIP, "stream failed while waiting for the solver: %s", hipGetErrorString(q));
+    }
+  }
+  std::memcpy(c, const_cast<const unsigned long long*>(h->host_pub) + 2, sizeof(LmCtl));
   return 0;
 }
 
@@ -1006,6 +1136,7 @@ int intr_create_impl(cc_intrinsics* h, const int64_t* off, const float* uv, cons
   const size_t o_ss = take(16 * sizeof(double));
   const size_t o_ctl = take(sizeof(LmCtl));
   const size_t o_ctln = take(sizeof(LmCtl));
+  const size_t o_sync = take(64);                     // arrival counter (+0), published-chunk counter (+8)
   const size_t o_opts = take(sizeof(LmOpts));
   const size_t o_iintr = take(16 * sizeof(double));
   const size_t o_ipose = take((size_t)F * 8 * sizeof(double));
@@ -1041,15 +1172,25 @@ int intr_create_impl(cc_intrinsics* h, const int64_t* off, const float* uv, cons
   d.ss = reinterpret_cast<double*>(base + o_ss);
   d.ctl = reinterpret_cast<LmCtl*>(base + o_ctl);
   d.ctl_next = reinterpret_cast<LmCtl*>(base + o_ctln);
+  d.arrive = reinterpret_cast<unsigned*>(base + o_sync);
+  d.pub_seq = reinterpret_cast<unsigned long long*>(base + o_sync + 8);
   d.opts = reinterpret_cast<LmOpts*>(base + o_opts);
   d.log = reinterpret_cast<cc_iteration*>(base + o_log);
   h->init_intr = reinterpret_cast<double*>(base + o_iintr);
   h->init_pose = reinterpret_cast<double*>(base + o_ipose);
-  static_assert(sizeof(LmCtl) <= 256 && sizeof(LmOpts) <= 256, "one cached 512-byte pinned block holds both");
+  static_assert(16 + sizeof(LmCtl) <= 192 && sizeof(LmCtl) <= 160 && sizeof(LmOpts) <= 160, "one cached 512-byte pinned block holds all three");
   h->pinned = pinned_block_get();
   if (!h->pinned) return fail(CC_ERR_HIP, "hipHostMalloc failed");
-  h->h_ctl = reinterpret_cast<LmCtl*>(h->pinned);
-  h->h_opts = reinterpret_cast<LmOpts*>(static_cast<char*>(h->pinned) + 256);
+  h->host_pub = reinterpret_cast<volatile unsigned long long*>(h->pinned);
+  h->h_ctl = reinterpret_cast<LmCtl*>(static_cast<char*>(h->pinned) + 192);
+  h->h_opts = reinterpret_cast<LmOpts*>(static_cast<char*>(h->pinned) + 352);
+  h->host_pub[0] = 0ull;     // a recycled block may carry an old sequence number; the device counter starts at 0
+  h->pub_count = 0;
+  {
+    void* dev_view = nullptr;
+    CC_HIP(hipHostGetDevicePointer(&dev_view, h->pinned, 0));
+    d.host_pub = reinterpret_cast<unsigned long long*>(dev_view);
+  }
   h->elim_blocks = (int)std::min<int64_t>(kElimMaxBlocks, (F + 15) / 16);
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_intr_sweep),
                              hipFuncAttributeMaxDynamicSharedMemorySize, kSweepLdsBytes));
@@ -1096,11 +1237,10 @@ int cc_intrinsics_set_state(cc_intrinsics* h, const double* intr9, uint32_t mask
 int cc_intrinsics_reset(cc_intrinsics* h) {
   using namespace cc;
   if (!h || !h->have_state) return fail(CC_ERR_STATE, "cc_intrinsics_reset: no state set");
-  CC_HIP(hipSetDevice(h->device));
-  const unsigned blocks = (unsigned)((h->F * 8 + 255) / 256);
-  hipLaunchKernelGGL(k_intr_reset, dim3(blocks), dim3(256), 0, h->stream, h->d, h->init_intr, h->init_pose);
-  CC_HIP(hipGetLastError());
+  // lazy: the restore kernel is the first node of the next solve's graph (or is launched by whoever reads the
+  // device state first), so a restart costs neither a launch of its own nor a host round trip
   h->ctl_fresh = true;
+  h->reset_pending = true;
   return CC_OK;
 }
 
@@ -1151,6 +1291,33 @@ int cc_intrinsics_eval(cc_intrinsics* h, double* blocks, double* cost) {
   return CC_OK;
 }
 
+}  // extern "C"
+
+namespace cc {
+// Captures `rounds` rounds (optionally behind the restore kernel) into an executable graph. On any failure the
+// stream is taken out of capture mode again and nothing is kept (a stream left capturing would poison the
+// process-wide stream cache it returns to).
+static int capture_chunk(cc_intrinsics* h, bool with_reset, bool initial, int rounds, hipGraphExec_t* out) {
+  hipGraph_t g = nullptr;
+  CC_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+  int rc = 0;
+  if (with_reset) launch_reset(h);
+  for (int i = 0; i < rounds && !rc; ++i) rc = enqueue_round(h, false, initial && i == 0, i == rounds - 1);
+  const hipError_t e_end = hipStreamEndCapture(h->stream, &g);
+  if (rc || e_end != hipSuccess) {
+    if (g) hipGraphDestroy(g);
+    (void)hipGetLastError();
+    return rc ? rc : fail(CC_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e_end));
+  }
+  const hipError_t e_inst = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
+  hipGraphDestroy(g);
+  if (e_inst != hipSuccess) { *out = nullptr; return fail(CC_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e_inst)); }
+  return 0;
+}
+}  // namespace cc
+
+extern "C" {
+
 int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* summary) {
   using namespace cc;
   if (!h || !h->have_state) return fail(CC_ERR_STATE, "cc_intrinsics_solve: no state set");
@@ -1161,8 +1328,10 @@ int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* sum
   if (o.max_iterations > h->d.log_cap - 1) o.max_iterations = h->d.log_cap - 1;
   const bool profile = o.profile_kernels != 0;
   const bool use_graph = o.use_graph && !profile && !h->comm;
+  const bool host_word = !h->comm;   // fused routes hand the control block over through pinned memory
   CC_HIP(hipSetDevice(h->device));
-  if (!h->ctl_fresh) {
+  const bool from_initial = h->ctl_fresh;
+  if (!from_initial) {
     // continue from the accepted point of the previous run: move it to buffer 0, fresh control block
     LmCtl st;
     if (int rc = read_ctl(h, &st)) return rc;
@@ -1172,6 +1341,7 @@ int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* sum
     }
     LmCtl c{};
     if (int rc = write_ctl(h, c)) return rc;
+    CC_HIP(hipMemsetAsync(h->d.arrive, 0, sizeof(unsigned), h->stream));   // (a failed solve may have left arrivals behind)
   }
   h->ctl_fresh = false;
   {
@@ -1189,34 +1359,33 @@ int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* sum
   h->events.clear();
   h->event_kind.clear();
 
-  if (use_graph && (!h->graph[0] || h->graph_iters != o.check_interval)) {
-    drop_graphs(h);
-    for (int gi = 0; gi < 2; ++gi) {
-      hipGraph_t g = nullptr;
-      CC_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-      const int n = o.check_interval + (gi == 0 ? 1 : 0);
-      for (int i = 0; i < n; ++i) enqueue_triple(h, false, gi == 0 && i == 0);
-      CC_HIP(hipStreamEndCapture(h->stream, &g));
-      CC_HIP(hipGraphInstantiate(&h->graph[gi], g, nullptr, nullptr, 0));
-      hipGraphDestroy(g);
-    }
-    h->graph_iters = o.check_interval;
-  }
+  if (use_graph && h->graph_iters != o.check_interval) { drop_graphs(h); h->graph_iters = o.check_interval; }
+  auto graph_for = [&](int which) -> int {   // 0: restart + initial + n, 1: n, 2: initial + n
+    if (h->graph[which]) return 0;
+    const int rounds = o.check_interval + (which == 1 ? 0 : 1);
+    const int rc = capture_chunk(h, which == 0, which != 1, rounds, &h->graph[which]);
+    if (rc) drop_graphs(h);
+    return rc;
+  };
 
-  // The first chunk holds the initial evaluation plus check_interval iterations.
+  // The first chunk holds the (restart and the) initial evaluation plus check_interval iterations.
   int launched = 0;
   LmCtl st;
   for (int chunk = 0;; ++chunk) {
     const int n = o.check_interval + (chunk == 0 ? 1 : 0);
     if (use_graph) {
-      CC_HIP(hipGraphLaunch(h->graph[chunk == 0 ? 0 : 1], h->stream));
+      const int which = chunk > 0 ? 1 : (h->reset_pending ? 0 : 2);
+      if (int rc = graph_for(which)) return rc;
+      CC_HIP(hipGraphLaunch(h->graph[which], h->stream));
+      h->reset_pending = false;
     } else {
+      if (int rc = flush_reset(h)) return rc;
       for (int i = 0; i < n; ++i)
-        if (int rc = enqueue_triple(h, profile, chunk == 0 && i == 0)) return rc;
+        if (int rc = enqueue_round(h, profile, chunk == 0 && i == 0, i == n - 1)) return rc;
       CC_HIP(hipGetLastError());
     }
     launched += n;
-    if (int rc = read_ctl(h, &st)) return rc;
+    if (int rc = host_word ? wait_published(h, &st) : read_ctl(h, &st)) return rc;
     if (st.done && st.term == CC_FAILURE_EXCHANGE)
       return fail(CC_ERR_COMM, "mailbox exchange timed out: a peer rank did not post within 10 s (iteration %d)", st.iter);
     if (st.done) break;
@@ -1281,11 +1450,13 @@ int cc_intrinsics_profile_sweep(cc_intrinsics* h, int32_t n, double* avg_ms) {
   return CC_OK;
 }
 
-// developer aid (not declared in cc_solver.h): time one kernel of the iteration in isolation, replayed
-// n times from the state the last solve left behind. which: 1 = decide_elim, 2 = solve.
+// developer aid (not declared in cc_solver.h): time the decide + elim + solve kernel in isolation, replayed
+// n times from the state the last solve left behind (which must be 1; the solve step no longer has a kernel
+// of its own on a single GPU).
 int cc_intrinsics_profile_kernel(cc_intrinsics* h, int32_t which, int32_t n, double* avg_ms) {
   using namespace cc;
-  if (!h || n < 1 || !avg_ms || which < 1 || which > 2) return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_profile_kernel: bad arguments");
+  if (!h || n < 1 || !avg_ms || which != 1) return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_profile_kernel: bad arguments");
+  if (h->comm || h->exchange) return fail(CC_ERR_STATE, "cc_intrinsics_profile_kernel: single-GPU handles only");
   CC_HIP(hipSetDevice(h->device));
   LmCtl st;
   if (int rc = read_ctl(h, &st)) return rc;
@@ -1305,14 +1476,7 @@ int cc_intrinsics_profile_kernel(cc_intrinsics* h, int32_t which, int32_t n, dou
   hipEvent_t e0, e1;
   CC_HIP(hipEventCreate(&e0));
   CC_HIP(hipEventCreate(&e1));
-  auto launch = [&]() {
-    if (which == 1) {
-      hipLaunchKernelGGL(k_intr_decide_elim<0>, dim3(h->elim_blocks), dim3(256), 0, h->stream, h->d);
-    } else {
-      hipLaunchKernelGGL(k_intr_solve<0>, dim3(1), dim3(kSolveThreads), 0, h->stream, h->d, h->elim_blocks);
-      hipMemcpyAsync(h->d.ctl_next, &run, sizeof(run), hipMemcpyHostToDevice, h->stream);
-    }
-  };
+  auto launch = [&]() { hipLaunchKernelGGL(k_intr_decide_elim<0>, dim3(h->elim_blocks), dim3(256), 0, h->stream, h->d, 2); };
   launch();
   CC_HIP(hipEventRecord(e0, h->stream));
   for (int i = 0; i < n; ++i) launch();

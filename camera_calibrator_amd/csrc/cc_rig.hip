@@ -609,7 +609,10 @@ __global__ __launch_bounds__(256) void k_rig_decide_elim(RigDev P) {
     if (pending) {
       double step2 = s_tot[2], xn2 = s_tot[3];
       if (c.step_valid) { step2 += P.shared_stats[0]; xn2 += P.shared_stats[1]; }
-      lm_decide(c, o, blockIdx.x == 0 ? P.log : nullptr, P.log_cap, s_tot[0], s_tot[1], step2, xn2);
+      cc_iteration rec;
+      const int len0 = c.log_len;
+      lm_decide(c, o, &rec, s_tot[0], s_tot[1], step2, xn2);
+      if (blockIdx.x == 0 && c.log_len != len0 && c.log_len <= P.log_cap) P.log[c.log_len - 1] = rec;
     }
     s_ctl = c;
     if (blockIdx.x == 0) *P.ctl_next = c;
@@ -952,9 +955,10 @@ __global__ __launch_bounds__(256) void k_rig_solve(RigDev P) {
 #if CC_ABLATE_RS == 1
     return;
 #endif
+    // second half of FinalizeIterationAndCheckIfMinimizerCanContinue (cf. lm_finalize): gradient tolerance, then
+    // minimum trust-region radius
     converged = gmax <= o.gradient_tolerance;
-    // the loop-top radius test of the very first iteration (later ones are made by lm_decide)
-    if (!converged && cn->iter == 0 && radius < o.min_radius) { converged = true; early_term = CC_MIN_RADIUS; }
+    if (!converged && radius < o.min_radius) { converged = true; early_term = CC_MIN_RADIUS; }
     if (!converged) {
       // right-looking Cholesky, lower triangle in place, ONE barrier per step: every thread derives
       // 1/sqrt(pivot) itself, the trailing update uses the unscaled column times inv^2, and the

@@ -498,7 +498,9 @@ int run_lm(ArrowProblem& P, const oc_options& o, double* shared, double* fq, dou
       ev.accepted(cand_cost, mcc);
       ++n_success;
       log(x_cost, cost_change, mcc, quality, step_norm, 1, 1);
-      if (gmax <= o.gradient_tolerance) { term = OC_CONVERGENCE_GRADIENT; break; }
+      // TrustRegionMinimizer::FinalizeIterationAndCheckIfMinimizerCanContinue: max iterations is tested before
+      // the gradient tolerance, the minimum radius after it (top of the loop)
+      if (iters < o.max_iterations && gmax <= o.gradient_tolerance) { term = OC_CONVERGENCE_GRADIENT; break; }
     } else {
       radius /= decrease_factor;
       decrease_factor *= 2.0;

@@ -78,18 +78,42 @@ def build(force=False):
 
 
 _lib = None
+_FAST_PATH = os.path.join(_HERE, "liboracle_fast.so")
+
+
+def _declare(l):
+    l.oc_intrinsics_blocks.restype = C.c_double
+    l.oc_generator_create.restype = C.c_void_p
+    l.oc_generator_planar.restype = C.c_int64
+    l.oc_generator_points.restype = C.c_int64
+    return l
 
 
 def lib():
     global _lib
     if _lib is None:
         build()
-        _lib = C.CDLL(_LIB_PATH)
-        _lib.oc_intrinsics_blocks.restype = C.c_double
-        _lib.oc_generator_create.restype = C.c_void_p
-        _lib.oc_generator_planar.restype = C.c_int64
-        _lib.oc_generator_points.restype = C.c_int64
+        _lib = _declare(C.CDLL(_LIB_PATH))
     return _lib
+
+
+def use_fast_build():
+    """TIMING ONLY (bench.py's cpu_baseline leg): rebuild the oracle on THIS host with -O3 -march=native
+     as liboracle_fast.so and route every call of this module through it from now on. Parity
+    tests never call this: their library is the -ffp-contract=off build. Returns (flags, cpu model name)."""
+    global _lib
+    subprocess.check_call(["make", "-s", "-B", "-C", _HERE, "liboracle_fast.so"])
+    _lib = _declare(C.CDLL(_FAST_PATH))
+    flags = subprocess.check_output(["make", "-s", "-C", _HERE, "--eval", "pf: ; @echo $(CXX) $(FASTFLAGS)", "pf"]).decode().strip()
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return flags, model
 
 
 def _p(a, t):

@@ -46,6 +46,20 @@ def test_product_generator_is_bit_identical_to_the_oracle_generator():
     assert np.all(z[1][:, 2] == 0)
 
 
+def test_product_rig_scenario_is_bit_identical_to_the_oracle_scenario():
+    """cc_rig_scenario (camera_calibrator_amd/csrc/rig_scenario.cpp) and the oracle's oc_rig_scenario are two
+    independent codes of test_extrinsics_calibrator.cpp:9-134; likewise the Affine3f -> (q, t) conversion."""
+    from oracle import pyoracle as po
+    for cams, frames, pts in [(2, 30, 4), (5, 9, 33)]:
+        a, b = capi.rig_scenario(cams, frames, pts), po.rig_scenario(cams, frames, pts)
+        assert sorted(a) == sorted(b) and all(np.array_equal(a[k], b[k]) for k in a)
+        for key in ("cam_T", "frame_T"):
+            qa, ta = capi.affine_to_qt(a[key])
+            qb, tb = po.affine_to_qt(b[key])
+            assert np.array_equal(qa, qb) and np.array_equal(ta, tb)
+    assert not np.array_equal(capi.rig_scenario(2, 3, 4, seed=1)["obs_uv"], capi.rig_scenario(2, 3, 4)["obs_uv"])
+
+
 def test_option_defaults_match_reference_call_site():
     o = capi.default_options()
     assert (o.max_iterations, o.use_nonmonotonic_steps) == (100, 1)          # calibrator.cpp:315,319

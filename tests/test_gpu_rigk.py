@@ -70,3 +70,48 @@ def test_rigk_needs_its_intrinsics_and_a_plain_handle_refuses_them():
     with pytest.raises(capi.CcError, match="without intrinsics"):
         plain.set_intrinsics(k["intr0"])
     plain.close()
+
+
+def test_rigk_c4_full_size_matches_oracle():
+    """BASELINE.json configs[3] WITH shared intrinsics: 4 cameras x 400 frames x 300 points, 480k PIXEL observations.
+    Live against the oracle (~1 s): same trajectory, same minimiser."""
+    g, o = _both(rigk_case(4, 400, 300))
+    _assert_same(g, o)
+    assert g[6]["iterations"] >= 3
+
+
+def test_rigk_c5_full_size_against_the_committed_oracle_result_and_properties():
+    """BASELINE.json configs[4] WITH shared intrinsics: 8 cameras x 2000 frames x 500 points, 8M pixel observations.
+    The oracle's answer is a committed fixture (tests/golden/make_rigk_c5.py): same trajectory, same intrinsics,
+    camera poses, a subset of the frame poses and per-observation costs. Plus size-independent properties: the
+    frozen camera is untouched, the per-observation costs add up to the reported cost, a second solve from the
+    solution is (nearly) a fixed point."""
+    import os
+    gld = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rigk_c5_oracle.npz"))
+    k = rigk_case(int(gld["cams"]), int(gld["frames"]), int(gld["pts"]))
+    prob = capi.RigProblem(k["cams"], k["frame_offsets"], k["obs_cam"], k["obs_world"], k["obs_uv_pix"], k["world_xyz"],
+                           k["cam_frozen"], huber_a=0.0, with_intrinsics=True)
+    prob.set_intrinsics(k["intr0"], 0)
+    prob.set_state(k["cam_q0"], k["cam_t0"], k["frame_q0"], k["frame_t0"])
+    s1 = prob.solve(capi.default_options(max_iterations=200))
+    intr = prob.get_intrinsics()
+    r1 = prob.get_state()
+    assert s1["termination"] == str(gld["termination"]) and s1["iterations"] == int(gld["iterations"])
+    assert [l["accepted"] for l in s1["log"]] == list(gld["accepted"])
+    assert np.allclose([l["cost"] for l in s1["log"]], gld["costs"], rtol=1e-9)
+    assert np.isclose(s1["initial_cost"], float(gld["initial_cost"]), rtol=1e-10)
+    assert np.isclose(s1["final_cost"], float(gld["final_cost"]), rtol=1e-10)
+    assert np.allclose(intr[:4], gld["intr"][:4], rtol=1e-9) and np.allclose(intr[4:], gld["intr"][4:], atol=1e-8)
+    assert np.abs(r1[0] - gld["cam_q"]).max() < 1e-8 and np.abs(r1[1] - gld["cam_t"]).max() < 1e-8
+    pick = gld["frame_pick"]
+    assert np.abs(r1[2][pick] - gld["frame_q"]).max() < 1e-8 and np.abs(r1[3][pick] - gld["frame_t"]).max() < 1e-8
+    assert np.allclose(r1[4][:64], gld["obs_cost_head"], rtol=1e-6, atol=1e-12)
+    assert np.isclose(r1[4].sum(), float(gld["obs_cost_sum"]), rtol=1e-9)
+    # properties
+    assert np.array_equal(r1[0][0], k["cam_q0"][0]) and np.array_equal(r1[1][0], k["cam_t0"][0])
+    assert np.isclose(r1[4].sum(), s1["final_cost"], rtol=1e-9) and r1[4].shape == (8_000_000,)
+    prob.set_intrinsics(intr, 0)
+    prob.set_state(r1[0], r1[1], r1[2], r1[3])
+    s2 = prob.solve(capi.default_options(max_iterations=200))
+    prob.close()
+    assert s2["iterations"] <= 2 and s2["final_cost"] <= s1["final_cost"] * (1 + 1e-9)
