@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CC_LIB_PATH", os.path.join(_HERE, "libcc_hip.so"))
 
-K_NAMES = ["sweep", "decide", "elim", "solve", "allreduce"]
+K_NAMES = ["sweep", "decide", "elim", "solve", "allreduce", "update", "reduce"]
 TERMINATION = {0: "NO_CONVERGENCE", 1: "GRADIENT", 2: "PARAMETER", 3: "FUNCTION",
                4: "FAILURE_INVALID_STEPS", 5: "MIN_RADIUS", 6: "FAILURE_EXCHANGE"}
 
@@ -82,7 +82,8 @@ EXPORTED_SYMBOLS = [
     "cc_intrinsics_comm_init", "cc_intrinsics_exchange_export", "cc_intrinsics_exchange_attach", "cc_partition_frames", "cc_distort", "cc_undistort",
     "cc_rig_create", "cc_rig_destroy", "cc_rig_set_state", "cc_rig_reset", "cc_rig_solve",
     "cc_rig_get_state", "cc_rig_eval", "cc_rig_optimize", "cc_rig_comm_init", "cc_rig_exchange_export", "cc_rig_exchange_attach", "cc_rigk_create",
-    "cc_rigk_set_intrinsics", "cc_rigk_get_intrinsics", "cc_zhang_init",
+    "cc_rigk_set_intrinsics", "cc_rigk_get_intrinsics", "cc_rigk_create_per_camera", "cc_rigk_set_camera_intrinsics",
+    "cc_rigk_get_camera_intrinsics", "cc_zhang_init",
 ]
 # every symbol include/cc_harness.h declares (synthetic-input harness, host code)
 HARNESS_SYMBOLS = [
@@ -274,16 +275,18 @@ class RigProblem:
 
     def __init__(self, n_cams, frame_offsets, obs_cam, obs_world, obs_uv, world_xyz, cam_frozen,
                  huber_a=HUBER_A, device=0, with_intrinsics=False):
-        """with_intrinsics=True: the extension cc_rigk_create (pixel observations, 9 shared intrinsics)."""
+        """with_intrinsics=True: the extension cc_rigk_create (pixel observations, 9 shared intrinsics);
+        with_intrinsics="per_camera": cc_rigk_create_per_camera (one set of 9 per camera)."""
         self._h = C.c_void_p()
         self.with_intrinsics = bool(with_intrinsics)
+        self.per_camera = with_intrinsics == "per_camera"
         off = np.ascontiguousarray(frame_offsets, dtype=np.int64)
         self.n_cams, self.n_frames, self.n_obs = int(n_cams), len(off) - 1, int(off[-1])
         obs_cam = np.ascontiguousarray(obs_cam, dtype=np.uint32)
         obs_world = np.ascontiguousarray(obs_world, dtype=np.uint64)
         obs_uv, world_xyz = _f32(obs_uv), _f32(world_xyz)
         frozen = np.ascontiguousarray(cam_frozen, dtype=np.uint8)
-        create = lib().cc_rigk_create if with_intrinsics else lib().cc_rig_create
+        create = (lib().cc_rigk_create_per_camera if self.per_camera else lib().cc_rigk_create) if with_intrinsics else lib().cc_rig_create
         _check(create(C.c_int32(device), C.c_int64(n_cams), C.c_int64(self.n_frames),
                                    C.c_int64(world_xyz.size // 3), _p(off, C.c_int64),
                                    _p(obs_cam, C.c_uint32), _p(obs_world, C.c_uint64),
@@ -315,6 +318,19 @@ class RigProblem:
     def get_intrinsics(self):
         out = np.zeros(9)
         _check(lib().cc_rigk_get_intrinsics(self._h, _p(out, C.c_double)))
+        return out
+
+    def set_camera_intrinsics(self, camera, intr9, const_mask=0):
+        intr9 = _f64(intr9)
+        assert intr9.size == 9
+        _check(lib().cc_rigk_set_camera_intrinsics(self._h, C.c_int64(camera), _p(intr9, C.c_double), C.c_uint32(const_mask)))
+
+    def get_camera_intrinsics(self, camera=None):
+        """One camera's set, or (camera=None) an [n_cams, 9] array of all of them."""
+        if camera is None:
+            return np.stack([self.get_camera_intrinsics(c) for c in range(self.n_cams)])
+        out = np.zeros(9)
+        _check(lib().cc_rigk_get_camera_intrinsics(self._h, C.c_int64(camera), _p(out, C.c_double)))
         return out
 
     def reset(self):

@@ -7,19 +7,27 @@
 //
 // Observations are regrouped on the host into (frame, camera) groups; one workgroup sweeps one
 // group and produces its 16x16 Gram block of [J_cam(6) J_frame(6) r 0 0 0] rows with the same
-// LDS-staged v_mfma_f64_16x16x4_f64 contraction as the intrinsics problem. Per LM iteration:
-//   solve  : reduce elimination partials, dense (6C)x(6C) Cholesky in LDS, camera candidates
-//   update : per frame, back-substitute the pose step, candidate pose (QuaternionManifold::Plus)
+// LDS-staged v_mfma_f64_16x16x4_f64 contraction as the intrinsics problem. Only cameras that are
+// observed AND not frozen own columns of the reduced system (any number of frozen / unobserved cameras
+// costs nothing, cf. the Parse-keeps-cameras quirk of extrinsics_calibrator.cpp:348-351). Per LM iteration:
 //   sweep  : per group, residuals + Jacobian rows + Huber scaling -> Gram block, cost, model term
 //   init   : (first evaluation only) Jacobi scaling of the shared block, trust-region state
-//   decide+elim : trust-region decision; per frame 6x6 Cholesky and Schur complement partials
-//   reduce : column sums of the elimination partials (and, multi-GPU, their posting to the mailboxes)
+//   elim   : trust-region decision; one wave per frame: 6x6 Cholesky of the frame block,
+//            Z = L^-1 [H_fs | g_f] staged in LDS, Y = L^-T Z for the back-substitution; the Schur
+//            products Z^T Z of four frames at a time are accumulated on the matrix cores
+//            (v_mfma_f64_16x16x4_f64 over 16-column tiles of the shared block); per-camera sums of the
+//            shared-block entries ("direct" sums); one partial row per block
+//   reduce+solve : column sums of the partial rows; the LAST block to finish assembles the reduced
+//            system in LDS, dense Cholesky, substitutions, gradient / radius tests, camera (and
+//            intrinsics) candidates, control block
+//   update : per frame, back-substitute the pose step, candidate pose (QuaternionManifold::Plus)
 //
 // EXTENSION (cc_rigk_*, SURVEY 8f rank 4, no counterpart in the reference): the same kernels, templated
-// where it matters, with 9 intrinsics shared by all cameras appended to the shared block and pixel
-// observations (see k_rig_sweep<true>).
+// where it matters, with 9 intrinsics appended to the shared block -- one set shared by all cameras or one
+// set per camera -- and pixel observations (see k_rig_sweep<true>).
 #include <algorithm>
 #include <chrono>
+#include <cstring>
 #include <numeric>
 #include <vector>
 
@@ -28,19 +36,28 @@
 
 namespace cc {
 
-constexpr int kRigMaxCams = 10;
-constexpr int kRigMaxS = 6 * kRigMaxCams;
+constexpr int kRigMaxS = 127;   // shared tangent coordinates: S + 1 (right-hand side) <= 128 = 8 column tiles of 16
 constexpr int kRigThreads = 256;
-constexpr int kRigOwn = 8;  // partial-row columns owned per thread of the elim kernel (PC <= 2048)
 constexpr int kRigSweepLdsBytes = (4 * kStageDoublesPerWave + 256) * 8;
 constexpr int kRigSweepLdsBytesK = (8 * kStageDoublesPerWave + 256) * 8;  // with intrinsics: two staged tiles per wave
-constexpr int kRigK = 9;  // shared intrinsics columns of the extension (0 in the reference's problem)
-constexpr int kRigMaxElimBlocks = 512;
+constexpr int kRigK = 9;              // intrinsics per set (extension)
+constexpr int kRigMaxElimBlocks = 256;
+constexpr int kRigDirectPerLane = 24; // direct-sum accumulators per lane in the elim kernel (ND <= 1536)
+constexpr int kRigTilesPerWave = 9;   // 36 upper tiles of an 8 x 8 tile grid over 4 waves
+constexpr int kDE0 = 27, kDEK = 135;  // direct entries per observed camera (poses only / with intrinsics)
+
+enum { RIG_K_NONE = 0, RIG_K_SHARED = 1, RIG_K_PER_CAMERA = 2 };
 
 struct RigDev {
   int64_t F, N, NG;
-  int32_t C, S, SW, NP, PC;  // cameras, 6C, 6C+1, S(S+1)/2, partial-row columns
-  int32_t pc_b, pc_hd, pc_fail, pc_gs, pc_gmax;
+  int32_t C;            // cameras as the caller numbers them
+  int32_t CO;           // observed cameras (own groups and direct sums)
+  int32_t CK;           // intrinsics sets: 0, 1 (shared) or C (per camera)
+  int32_t S, SW;        // shared tangent size; SW = S + 1 (right-hand-side column)
+  int32_t T, nT, ZS;    // 16-column tiles over SW, upper tile pairs T(T+1)/2, staged Z row stride (doubles)
+  int32_t DE, ND;       // direct entries per observed camera, CO * DE
+  int32_t PC;           // partial-row length: nT * 256 + ND + 2
+  int32_t pc_dir, pc_fail, pc_gmax;
   int32_t nblk;
   const float* uv;        // [N] float2, (frame, camera)-sorted
   const int32_t* widx;    // [N] world point index
@@ -51,9 +68,18 @@ struct RigDev {
   const int64_t* fgoff;   // [F+1] group range of each frame
   const int32_t* cam_goff;   // [C+1]
   const int32_t* cam_glist;  // [NG] groups of each camera
-  const uint8_t* cam_fixed;  // [C] frozen or unobserved
-  const uint8_t* pair_p;     // [NP] (p,q), p <= q, row-major upper triangle
-  const uint8_t* pair_q;
+  const uint8_t* cam_fixed;  // [C] pose held constant (frozen, or unobserved by every rank)
+  const int32_t* pcol;       // [C] first shared column of the camera's pose, -1: constant
+  const int32_t* kcol;       // [C] first shared column of the camera's intrinsics, -1: none
+  const int32_t* kset;       // [C] intrinsics set of the camera (0 when shared)
+  const int32_t* kscol;      // [max(CK,1)] first shared column of intrinsics set s, -1: not in the problem
+  const int32_t* obs_cam;    // [CO] camera id of observed camera j
+  const int32_t* fslot;      // [F][CO] group of (frame, observed camera j), -1: the camera does not see the frame
+  const int32_t* colinfo;    // [SW] (observed camera j << 8) | (kind << 4) | component; kind 0 pose, 1 own intrinsics,
+                             //      2 intrinsics shared by all cameras, 3 right-hand side
+  const int16_t* dmap;       // [DE] offset of direct entry e inside a group block
+  const uint8_t* tile_i;     // [nT] tile pairs (ti <= tj), row-major upper triangle
+  const uint8_t* tile_j;
   double* cam;      // [2][C][8] q(4) t(3)
   double* pose;     // [2][F][8]
   double* camrec;   // [C][32] R(9) t(3) unscaled step(6)
@@ -63,13 +89,13 @@ struct RigDev {
   double* fstats;   // [F][2] step^2, |x|^2
   double* ghd0;     // [NG][8] diag of H_cc at the initial point
   double* sp;       // [F][8]
-  double* ss;       // [64]
-  double* ds;       // [64] scaled shared step
+  double* ss;       // [128]
+  double* ds;       // [128] scaled shared step
   double* Y;        // [F][6*SW]
   double* partial;  // [nblk][PC]
-  double* vec;      // [PC + 32] column sums of the partial rows (k_rig_reduce) + one max-gradient slot per rank
-  double* vec_stats;  // [4 + 6C] globally reduced sweep statistics (multi-GPU only)
-  int32_t comm, rank, nranks;  // comm != 0: statistics / partial sums pass through an all-reduce
+  double* vec;      // [PC + 32] column sums of the partial rows + one max-gradient slot per rank
+  double* vec_stats;  // [4 + S] globally reduced sweep statistics (multi-GPU only)
+  int32_t comm, rank, nranks;  // comm != 0: statistics / partial sums pass through an exchange
   P2pDev x;                    // mailbox exchange (cc_device.hpp); x.on != 0 replaces the RCCL all-reduces
   double* shared_stats;  // [4] step^2 and |x|^2 of the shared block (candidate)
   LmCtl* ctl;
@@ -77,15 +103,21 @@ struct RigDev {
   LmOpts* opts;
   cc_iteration* log;
   int32_t log_cap;
+  unsigned* arrive;      // [1] blocks of k_rig_reduce that have stored their sums (last-block-done)
   double huber_a;
-  // EXTENSION: 9 intrinsics shared by all cameras, pixel observations. K = 0: off.
-  // Shared tangent = [cam 0 (6) ... cam C-1 (6) | k (9)], S = 6C + K, S6 = 6C.
-  int32_t K, S6, gstride;
-  uint32_t kmask;     // bit i: intrinsic i is held constant
-  double* intr;       // [2][16]
-  double* krec;       // [32]: candidate intrinsics [0..8], unscaled step [16..24]
+  // EXTENSION: intrinsics in the shared block, pixel observations. kmode 0: off.
+  int32_t kmode, gstride;
+  const uint32_t* kmask;  // [max(CK,1)] bit i: intrinsic i of the set is held constant
+  double* intr;       // [2][max(CK,1)][16]
+  double* krec;       // [max(CK,1)][32]: candidate intrinsics [0..8], unscaled step [16..24]
   double* ghdk;       // [NG][16] diag of the intrinsics block of each group at the initial point
 };
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
 
 // ceres::HuberLoss(a) + Corrector (rho'' <= 0): residual and Jacobian scaled by sqrt(rho')
 __device__ __forceinline__ void huber(double a, double s, double& rho, double& sr) {
@@ -185,8 +217,8 @@ __device__ __forceinline__ void gram_rows_ab(const double* sa, const double* sb,
 
 // ---------------------------------------------------------------------------------------------
 // sweep: one workgroup per (frame, camera) group. HK = false: the reference's problem (normalised
-// observations, poses only, one 16x16 Gram tile). HK = true (extension): pixel observations through 9
-// shared intrinsics; the row is [J_cam(6) J_frame(6) r 0 0 0 | J_k(9) 0...] and the group block has
+// observations, poses only, one 16x16 Gram tile). HK = true (extension): pixel observations through the
+// camera's 9 intrinsics (its own set or the one shared by all cameras); the row is [J_cam(6) J_frame(6) r 0 0 0 | J_k(9) 0...] and the group block has
 // three tiles: AA (as before), AB (first half x intrinsics), BB (intrinsics x intrinsics).
 // ---------------------------------------------------------------------------------------------
 template <bool HK>
@@ -205,6 +237,7 @@ __global__ __launch_bounds__(kRigThreads, HK ? 2 : 4) void k_rig_sweep(RigDev P)
   const int cur = ctl->cur, dst = phase == 0 ? cur : (cur ^ 1);
   const int f = P.gframe[g], c = P.gcam[g];
   const bool fixed = P.cam_fixed[c] != 0;
+  const int ks = HK ? P.kset[c] : 0;
   // observations are fetched one pass ahead: pixel + world index, then the gathered world point (two
   // dependent round trips); the first pass is issued here, under the prologue
   const int64_t s0 = P.goff[g], s1 = P.goff[g + 1];
@@ -225,7 +258,7 @@ __global__ __launch_bounds__(kRigThreads, HK ? 2 : 4) void k_rig_sweep(RigDev P)
   // sm[0..31] camera record, sm[32..63] frame record, sm[64..95] intrinsics record (candidate, step)
   if (tid < 32) sm[tid] = P.camrec[c * 32 + tid];
   else if (tid < 64) sm[tid] = P.frec[(size_t)f * 32 + (tid - 32)];
-  else if (HK && tid < 96) sm[tid] = P.krec[tid - 64];
+  else if (HK && tid < 96) sm[tid] = P.krec[ks * 32 + (tid - 64)];
   const size_t gs = (size_t)P.gstride;
   double g_old = 0.0, g_ab = 0.0, g_bb = 0.0;
   if (phase != 0) {
@@ -260,7 +293,7 @@ __global__ __launch_bounds__(kRigThreads, HK ? 2 : 4) void k_rig_sweep(RigDev P)
 #pragma unroll
   for (int i = 0; i < 3; ++i) { tc[i] = rfl(sm[9 + i]); tf[i] = rfl(sm[32 + 9 + i]); }
   const double ha = P.huber_a;
-  const uint32_t kmask = P.kmask;
+  const uint32_t kmask = HK ? P.kmask[ks] : 0u;
 
   double* stage = s_stage + wave * kTiles * kStageDoublesPerWave;
   double* stage_b = stage + kStageDoublesPerWave;
@@ -425,61 +458,68 @@ __device__ __forceinline__ double block_sum256(double v, double* s4) {
   return (s4[0] + s4[1]) + (s4[2] + s4[3]);
 }
 
-// column sums of gstats[NG][2] and fstats[F][2] -> out[0..3] = cost, q, step2, xnorm2 (all threads)
-__device__ __forceinline__ void rig_reduce_stats(const RigDev& P, bool want, double* s4, double* out) {
-  const int tid = threadIdx.x;
+// column sums of gstats[NG][2] and fstats[F][2] -> out[0..3] = cost, q, step2, xnorm2 (all threads after return)
+__device__ __forceinline__ void rig_reduce_stats(const RigDev& P, bool want, double* s16, double* out) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double a[4] = {0, 0, 0, 0};
   if (want) {
-    for (int64_t i = tid; i < P.NG; i += 256) { a[0] += P.gstats[i * 2]; a[1] += P.gstats[i * 2 + 1]; }
-    for (int64_t i = tid; i < P.F; i += 256) { a[2] += P.fstats[i * 2]; a[3] += P.fstats[i * 2 + 1]; }
+    const d2* gs2 = reinterpret_cast<const d2*>(P.gstats);
+    const d2* fs2 = reinterpret_cast<const d2*>(P.fstats);
+    for (int64_t i = tid; i < P.NG; i += 256) { const d2 v = gs2[i]; a[0] += v.x; a[1] += v.y; }
+    for (int64_t i = tid; i < P.F; i += 256) { const d2 v = fs2[i]; a[2] += v.x; a[3] += v.y; }
   }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const double s = block_sum256(a[k], s4);
-    if (tid == 0) out[k] = s;
+  for (int k = 0; k < 4; ++k) a[k] = wave_sum(a[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s16[wave * 4 + k] = a[k];
   }
   __syncthreads();
+  if (tid < 4) out[tid] = (s16[tid] + s16[4 + tid]) + (s16[8 + tid] + s16[12 + tid]);
+  __syncthreads();
+}
+
+// Sum over this rank's groups of the diagonal entry of shared column k at the initial point (Jacobi scaling of
+// the shared block). All 256 threads call; the result is valid for thread 0.
+__device__ __forceinline__ double rig_column_diag_sum(const RigDev& P, int k, double* s4) {
+  const int info = P.colinfo[k], kind = (info >> 4) & 15, comp = info & 15, co = info >> 8;
+  const int tid = threadIdx.x;
+  double h = 0.0;
+  if (kind == 2) {
+    for (int64_t g = tid; g < P.NG; g += 256) h += P.ghdk[g * 16 + comp];
+  } else {
+    const int c = P.obs_cam[co];
+    for (int i = P.cam_goff[c] + tid; i < P.cam_goff[c + 1]; i += 256) {
+      const int g = P.cam_glist[i];
+      h += kind == 0 ? P.ghd0[(size_t)g * 8 + comp] : P.ghdk[(size_t)g * 16 + comp];
+    }
+  }
+  return block_sum256(h, s4);
 }
 
 // ---------------------------------------------------------------------------------------------
 // stats (multi-GPU only, one block): local sums of the sweep statistics -> vec_stats, which is then
-// all-reduced. [0..3] cost, model term, step^2, |x|^2; in phase 0 also [4 + 6c + i] = sum of
-// diag(H_cc) of camera c (Jacobi scaling of the shared block).
+// exchanged. [0..3] cost, model term, step^2, |x|^2; in phase 0 also [4 + k] = diagonal sum of shared
+// column k over this rank's groups (Jacobi scaling of the shared block).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rig_stats(RigDev P) {
   __shared__ double s4[4];
+  __shared__ double s16[16];
   __shared__ double s_out[4];
   const LmCtl* ctl = P.ctl;
   if (ctl->done) return;
   const int tid = threadIdx.x, phase = ctl->phase;
   const bool need = phase == 0 || (ctl->cand_pending && ctl->step_valid);
-  rig_reduce_stats(P, need, s4, s_out);
+  rig_reduce_stats(P, need, s16, s_out);
   if (tid < 4) P.vec_stats[tid] = need ? s_out[tid] : 0.0;
-  for (int c = 0; c < P.C; ++c) {
-    double h[6] = {0, 0, 0, 0, 0, 0};
-    if (phase == 0)
-      for (int k = P.cam_goff[c] + tid; k < P.cam_goff[c + 1]; k += 256) {
-        const int g = P.cam_glist[k];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) h[i] += P.ghd0[(size_t)g * 8 + i];
-      }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const double s = block_sum256(h[i], s4);
-      if (tid == 0) P.vec_stats[4 + c * 6 + i] = s;
-    }
-  }
-  for (int j = 0; j < P.K; ++j) {   // extension: diagonal of the intrinsics block (Jacobi scaling)
-    double hk = 0.0;
-    if (phase == 0)
-      for (int64_t g = tid; g < P.NG; g += 256) hk += P.ghdk[g * 16 + j];
-    const double sum = block_sum256(hk, s4);
-    if (tid == 0) P.vec_stats[4 + P.S6 + j] = sum;
+  for (int k = 0; k < P.S; ++k) {
+    const double s = phase == 0 ? rig_column_diag_sum(P, k, s4) : 0.0;
+    if (tid == 0) P.vec_stats[4 + k] = s;
   }
   if (P.x.on) {
     // mailbox exchange (kind 1): post the local statistics, wait for every rank's, write the sums back
-    // (k_rig_init / k_rig_decide_elim read vec_stats as they do after an all-reduce)
-    __shared__ double s_post[4 + kRigMaxS];
+    // (k_rig_init / k_rig_elim read vec_stats as they do after an all-reduce)
+    __shared__ double s_post[4 + kRigMaxS + 1];
     __shared__ int s_ok;
     __syncthreads();
     const int n = 4 + P.S;
@@ -501,8 +541,8 @@ __global__ __launch_bounds__(256) void k_rig_stats(RigDev P) {
 }
 
 // one-off (attach time): sum of the per-rank "camera seen" flags through the mailboxes (kind 1)
-__global__ __launch_bounds__(64) void k_rig_flag_exchange(RigDev P, const double* in, double* out, int n, int* ok) {
-  __shared__ double s_post[64];
+__global__ __launch_bounds__(128) void k_rig_flag_exchange(RigDev P, const double* in, double* out, int n, int* ok) {
+  __shared__ double s_post[128];
   __shared__ int s_ok;
   const int tid = threadIdx.x;
   if (tid < n) s_post[tid] = in[tid];
@@ -519,8 +559,9 @@ __global__ __launch_bounds__(64) void k_rig_flag_exchange(RigDev P, const double
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rig_init(RigDev P) {
   __shared__ double s4[4];
+  __shared__ double s16[16];
   __shared__ double s_out[4];
-  __shared__ double s_ss[kRigMaxS];
+  __shared__ double s_ss[kRigMaxS + 1];
   const LmCtl* ctl = P.ctl;
   if (ctl->done || ctl->phase != 0) return;
   const int tid = threadIdx.x;
@@ -529,28 +570,10 @@ __global__ __launch_bounds__(256) void k_rig_init(RigDev P) {
     if (tid < 4) s_out[tid] = P.vec_stats[tid];
     if (tid < P.S) s_ss[tid] = jac ? 1.0 / (1.0 + sqrt(P.vec_stats[4 + tid])) : 1.0;
   } else {
-    rig_reduce_stats(P, true, s4, s_out);
-    for (int c = 0; c < P.C; ++c) {
-      double h[6] = {0, 0, 0, 0, 0, 0};
-      for (int k = P.cam_goff[c] + tid; k < P.cam_goff[c + 1]; k += 256) {
-        const int g = P.cam_glist[k];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) h[i] += P.ghd0[(size_t)g * 8 + i];
-      }
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const double s = block_sum256(h[i], s4);
-        if (tid == 0) s_ss[c * 6 + i] = jac ? 1.0 / (1.0 + sqrt(s)) : 1.0;
-      }
-    }
-  }
-  if (P.K && !P.comm) {
-    // extension: diagonal of the intrinsics block summed over all groups
-    for (int j = 0; j < P.K; ++j) {
-      double h = 0.0;
-      for (int64_t g = tid; g < P.NG; g += 256) h += P.ghdk[g * 16 + j];
-      const double sum = block_sum256(h, s4);
-      if (tid == 0) s_ss[P.S6 + j] = jac ? 1.0 / (1.0 + sqrt(sum)) : 1.0;
+    rig_reduce_stats(P, true, s16, s_out);
+    for (int k = 0; k < P.S; ++k) {
+      const double s = rig_column_diag_sum(P, k, s4);
+      if (tid == 0) s_ss[k] = jac ? 1.0 / (1.0 + sqrt(s)) : 1.0;
     }
   }
   __syncthreads();
@@ -562,7 +585,9 @@ __global__ __launch_bounds__(256) void k_rig_init(RigDev P) {
     for (int cc2 = 0; cc2 < P.C; ++cc2)
       if (!P.cam_fixed[cc2])
         for (int i = 0; i < 7; ++i) { const double v = P.cam[((size_t)c.cur * P.C + cc2) * 8 + i]; xn2 += v * v; }
-    for (int j = 0; j < P.K; ++j) { const double v = P.intr[c.cur * 16 + j]; xn2 += v * v; }
+    for (int s = 0; s < P.CK; ++s)   // every intrinsic of a set that is in the problem counts in |x|
+      if (P.kscol[s] >= 0)
+        for (int j = 0; j < kRigK; ++j) { const double v = P.intr[((size_t)c.cur * P.CK + s) * 16 + j]; xn2 += v * v; }
     lm_init(c, o, s_out[0], sqrt(xn2));
     *P.ctl = c;
     *P.ctl_next = c;
@@ -570,30 +595,28 @@ __global__ __launch_bounds__(256) void k_rig_init(RigDev P) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// decide + elim. All 256 threads of a block work on one frame at a time; the block loops over its
-// frames. Each thread owns up to kRigOwn columns of the partial row and accumulates them in
-// registers across frames (no atomics, deterministic).
-// Partial row: [0..NP) upper triangle of the reduced (6C)x(6C) system, [pc_b..) rhs, [pc_hd..) diag of
-// the scaled H_ss, [pc_fail] Cholesky failures, [pc_gs..) unscaled shared gradient, [pc_gmax] max |g_frame|.
+// elim: trust-region decision (every block, same answer; block 0 publishes it), then the elimination of the
+// frame poses. One WAVE per frame, four frames per block iteration:
+//   lanes 0..26 sum the frame block A = sum_groups H_ff (21 entries) and g_f (6) over the frame's groups;
+//   every lane factors the damped 6x6 block in registers; lane k owns shared column k (and k + 64):
+//   w = column of [H_fs | g_f] (scaled), z = L^-1 w -> staged in LDS, y = L^-T z -> Y (back-substitution);
+//   the wave also adds its frame's entries of the shared diagonal blocks into per-lane accumulators;
+//   then the four waves contract the 24 staged rows of Z on the matrix cores: tile pair (ti <= tj) of
+//   the (SW x SW) product Z^T Z goes to wave (index mod 4), 6 k-steps of v_mfma_f64_16x16x4_f64.
+// Partial row of a block: [nT tiles x 256 | ND direct sums | Cholesky failures | max |g_frame|].
 // ---------------------------------------------------------------------------------------------
 template <bool HK>
-__global__ __launch_bounds__(256) void k_rig_decide_elim(RigDev P) {
-  __shared__ double LG[kRigMaxCams][256];
-  // extension (P.K != 0): AB tiles of the frame's groups, and the frame's sums over its groups of the
-  // intrinsics x intrinsics tile, of the frame-pose x intrinsics rows and of the intrinsics gradient
-  __shared__ double LGB[kRigMaxCams][256];
-  __shared__ double s_BB[256];
-  __shared__ double s_B[6][16];
-  __shared__ double s_gk[16];
-  __shared__ double Zl[6][kRigMaxS + 4];
-  __shared__ double s_A[28];  // 21 packed H_ff entries + 6 g_f
-  __shared__ double s_ss[kRigMaxS];
-  __shared__ double s4[4];
+__global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* s_Z = reinterpret_cast<double*>(smem_raw);         // [24][ZS] staged Z rows of the four frames
+  double* s_A = s_Z + 24 * P.ZS;                             // [4][32] frame block broadcast, per wave
+  double* s_red = s_A + 4 * 32;                              // [4][1024] cross-wave reduction scratch
+  __shared__ double s_ss[kRigMaxS + 1];
+  __shared__ double s16[16];
   __shared__ double s_tot[4];
-  __shared__ int s_slot[kRigMaxCams];   // camera -> slot of its group in this frame (-1: absent)
-  __shared__ int s_cam[kRigMaxCams];    // slot -> camera
+  __shared__ double s_fg[8];
   __shared__ LmCtl s_ctl;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const LmCtl* ctl = P.ctl;
   if (ctl->done || ctl->phase == 0) return;
   const bool pending = ctl->cand_pending != 0;
@@ -601,7 +624,7 @@ __global__ __launch_bounds__(256) void k_rig_decide_elim(RigDev P) {
     if (tid < 4) s_tot[tid] = P.vec_stats[tid];
     __syncthreads();
   } else {
-    rig_reduce_stats(P, pending && ctl->step_valid, s4, s_tot);
+    rig_reduce_stats(P, pending && ctl->step_valid, s16, s_tot);
   }
   if (tid == 0) {
     LmCtl c = *ctl;
@@ -618,206 +641,574 @@ __global__ __launch_bounds__(256) void k_rig_decide_elim(RigDev P) {
     if (blockIdx.x == 0) *P.ctl_next = c;
   }
   if (tid < P.S) s_ss[tid] = P.ss[tid];
+  for (int i = tid; i < 24 * P.ZS; i += 256) s_Z[i] = 0.0;   // padding columns stay zero
   __syncthreads();
   if (s_ctl.done) return;
   const int cur = s_ctl.cur;
-  const double radius = s_ctl.radius;
+  const double inv_radius = 1.0 / s_ctl.radius;
   const double mn = P.opts->min_lm_diagonal, mx = P.opts->max_lm_diagonal;
+  const bool first_elim = ctl->phase == 1 && s_ctl.iter == 0 && !pending;   // Jacobi scale of the frame blocks
+  const bool jac = P.opts->jacobi_scaling != 0;
+  const int SW = P.SW, S = P.S, CO = P.CO, ZS = P.ZS;
+  const size_t gs = (size_t)P.gstride;
+  const double* blocks = P.gblocks + (size_t)cur * P.NG * gs;
 
-  // static description of the columns this thread owns
-  int op[kRigOwn], oq[kRigOwn];
-#pragma unroll
-  for (int r = 0; r < kRigOwn; ++r) {
-    const int o = tid + 256 * r;
-    op[r] = -1; oq[r] = -1;
-    if (o < P.NP) { op[r] = P.pair_p[o]; oq[r] = P.pair_q[o]; }
+  // ---- static (frame-independent) description of what this lane owns
+  // frame-block entry of lane e < 27 (offset inside a group's AA tile); lanes holding a diagonal entry also
+  // store the frame's Jacobi scale in the first elimination
+  int a_off = 0, sp_i = -1;
+  if (lane < 21) {
+    int i = 0;
+    while (tri(i + 1, 0) <= lane) ++i;
+    const int j = lane - tri(i, 0);
+    a_off = (6 + i) * 16 + 6 + j;
+    if (i == j) sp_i = i;
+  } else if (lane < 27) {
+    a_off = (6 + (lane - 21)) * 16 + 12;
   }
-  double acc[kRigOwn];
+  // shared columns of this lane: k = lane and lane + 64
+  int c_kind[2], c_co[2], c_comp[2];
+  double c_ss[2];
 #pragma unroll
-  for (int r = 0; r < kRigOwn; ++r) acc[r] = 0.0;
+  for (int h = 0; h < 2; ++h) {
+    const int k = lane + 64 * h;
+    c_kind[h] = -1; c_co[h] = 0; c_comp[h] = 0; c_ss[h] = 0.0;
+    if (k < SW) {
+      const int info = P.colinfo[k];
+      c_kind[h] = (info >> 4) & 15; c_co[h] = info >> 8; c_comp[h] = info & 15;
+      c_ss[h] = k < S ? s_ss[k] : 1.0;
+    }
+  }
+  // direct-sum entries of this lane: e = lane + 64 r -> (observed camera, offset inside the group block)
+  int d_co[kRigDirectPerLane], d_off[kRigDirectPerLane];
+  double dacc[kRigDirectPerLane];
+#pragma unroll
+  for (int r = 0; r < kRigDirectPerLane; ++r) {
+    const int e = lane + 64 * r;
+    d_co[r] = -1; d_off[r] = 0; dacc[r] = 0.0;
+    if (e < P.ND) { d_co[r] = e / P.DE; d_off[r] = P.dmap[e - d_co[r] * P.DE]; }
+  }
+  d4 acc[kRigTilesPerWave];
+#pragma unroll
+  for (int u = 0; u < kRigTilesPerWave; ++u) acc[u] = d4{0.0, 0.0, 0.0, 0.0};
+  double gmax = 0.0, nfail = 0.0;
+  double* As = s_A + wave * 32;
 
-  for (int64_t f = blockIdx.x; f < P.F; f += gridDim.x) {
-    const int64_t g0 = P.fgoff[f];
-    const int ng = (int)(P.fgoff[f + 1] - g0);
-    if (ng == 0) continue;  // uniform across the block
-    if (tid < kRigMaxCams) s_slot[tid] = -1;
-    __syncthreads();
-    if (tid < ng) { const int cam = P.gcam[g0 + tid]; s_cam[tid] = cam; s_slot[cam] = tid; }
-    for (int s = 0; s < ng; ++s) LG[s][tid] = P.gblocks[((size_t)cur * P.NG + g0 + s) * P.gstride + tid];
-    if (HK) {
-      double bb = 0.0;
-      for (int s = 0; s < ng; ++s) {
-        const double* gb = P.gblocks + ((size_t)cur * P.NG + g0 + s) * P.gstride;
-        LGB[s][tid] = gb[256 + tid];
-        bb += gb[512 + tid];
-      }
-      s_BB[tid] = bb;
-    }
-    __syncthreads();
-    // frame block: A = sum over groups of H_ff (rows/cols 6..11), g_f = sum of column 12
-    if (tid < 21 + 6) {
-      double a = 0.0;
-      if (tid < 21) {
-        int i = 0;
-        while (tri(i + 1, 0) <= tid) ++i;
-        const int j = tid - tri(i, 0);
-        for (int s = 0; s < ng; ++s) a += LG[s][(6 + i) * 16 + 6 + j];
-      } else {
-        const int i = tid - 21;
-        for (int s = 0; s < ng; ++s) a += LG[s][(6 + i) * 16 + 12];
-      }
-      s_A[tid] = a;
-    } else if (HK && tid >= 32 && tid < 32 + 54) {
-      const int i = (tid - 32) / 9, j = (tid - 32) - i * 9;
-      double a = 0.0;
-      for (int s = 0; s < ng; ++s) a += LGB[s][(6 + i) * 16 + j];
-      s_B[i][j] = a;
-    } else if (HK && tid >= 96 && tid < 96 + 9) {
-      double a = 0.0;
-      for (int s = 0; s < ng; ++s) a += LGB[s][12 * 16 + (tid - 96)];
-      s_gk[tid - 96] = a;
-    }
-    __syncthreads();
-    double sf[6], L[21], Li[6];
-    if (ctl->phase == 1 && s_ctl.iter == 0 && !pending) {
-      // first elimination after the initial evaluation: Jacobi scale of this frame's pose block
+  for (int64_t fb = (int64_t)blockIdx.x * 4; fb < P.F; fb += (int64_t)gridDim.x * 4) {
+    const int64_t f = fb + wave;
+    const bool live = f < P.F && P.fgoff[f + 1] > P.fgoff[f];   // wave-uniform
+    if (live) {
+      // group of (frame, observed camera j) on lane j
+      const int gj = lane < CO ? P.fslot[f * CO + lane] : -1;
+      // ---- loads: frame block entries (lanes < 27, summed over the groups), column data, direct entries
+      double a_e = 0.0;
+      for (int j0 = 0; j0 < CO; j0 += 8) {
+        double v[8];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) sf[i] = P.opts->jacobi_scaling ? 1.0 / (1.0 + sqrt(s_A[tri(i, i)])) : 1.0;
-      if (tid < 6) P.sp[f * 8 + tid] = sf[tid];
+        for (int u = 0; u < 8; ++u) {
+          const int g = j0 + u < CO ? __builtin_amdgcn_readlane(gj, j0 + u) : -1;
+          v[u] = (g >= 0 && lane < 27) ? blocks[(size_t)g * gs + a_off] : 0.0;
+        }
+        a_e += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      }
+      double w[2][6];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[h][i] = 0.0;
+        const int gsel = __shfl(gj, c_co[h], 64);
+        if ((c_kind[h] == 0 || c_kind[h] == 1) && gsel >= 0) {
+          const double* G = blocks + (size_t)gsel * gs;
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+            w[h][i] = c_kind[h] == 0 ? G[c_comp[h] * 16 + 6 + i] : G[256 + (6 + i) * 16 + c_comp[h]];
+        }
+      }
+      if (HK && P.kmode == RIG_K_SHARED) {
+        // columns of the intrinsics shared by all cameras: sum of the frame's groups
+        for (int j = 0; j < CO; ++j) {
+          const int g = __builtin_amdgcn_readlane(gj, j);
+          if (g < 0) continue;
+          const double* G = blocks + (size_t)g * gs + 256;
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            if (c_kind[h] == 2) {
+#pragma unroll
+              for (int i = 0; i < 6; ++i) w[h][i] += G[(6 + i) * 16 + c_comp[h]];
+            }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < kRigDirectPerLane; ++r) {
+        const int g = __shfl(gj, d_co[r] < 0 ? 0 : d_co[r], 64);
+        if (d_co[r] >= 0 && g >= 0) dacc[r] += blocks[(size_t)g * gs + d_off[r]];
+      }
+      double sf[6];
+      if (!first_elim) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) sf[i] = P.sp[f * 8 + i];
+      }
+      // ---- broadcast the frame block
+      if (lane < 27) As[lane] = a_e;
+      wave_lds_fence();
+      double A[27];
+#pragma unroll
+      for (int i = 0; i < 27; ++i) A[i] = As[i];
+      wave_lds_fence();
+      if (first_elim) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) sf[i] = jac ? 1.0 / (1.0 + sqrt(A[tri(i, i)])) : 1.0;
+        if (sp_i >= 0) P.sp[f * 8 + sp_i] = jac ? 1.0 / (1.0 + sqrt(a_e)) : 1.0;
+      }
+      double L[21], Li[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) L[tri(i, j)] = sf[i] * A[tri(i, j)] * sf[j];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) L[tri(i, i)] += clampd(L[tri(i, i)], mn, mx) * inv_radius;
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        double d = L[tri(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= L[tri(j, k)] * L[tri(j, k)];
+        ok = ok && (d > 0.0) && isfinite(d);
+        const double inv = rsqrt(d);
+        L[tri(j, j)] = d * inv;
+        Li[j] = inv;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+          double a = L[tri(i, j)];
+#pragma unroll
+          for (int k = 0; k < j; ++k) a -= L[tri(i, k)] * L[tri(j, k)];
+          L[tri(i, j)] = a * inv;
+        }
+      }
+      if (!ok) nfail += 1.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) gmax = fmax(gmax, fabs(A[21 + i]));
+      // ---- columns: z = L^-1 w, y = L^-T z
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = lane + 64 * h;
+        if (k < SW) {
+          double z[6], y[6];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            double a = c_kind[h] == 3 ? sf[i] * A[21 + i] : sf[i] * w[h][i] * c_ss[h];
+#pragma unroll
+            for (int kk = 0; kk < i; ++kk) a -= L[tri(i, kk)] * z[kk];
+            z[i] = a * Li[i];
+          }
+#pragma unroll
+          for (int i = 5; i >= 0; --i) {
+            double a = z[i];
+#pragma unroll
+            for (int kk = i + 1; kk < 6; ++kk) a -= L[tri(kk, i)] * y[kk];
+            y[i] = a * Li[i];
+          }
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            s_Z[(wave * 6 + i) * ZS + k] = z[i];
+            P.Y[((size_t)f * 6 + i) * SW + k] = y[i];
+          }
+        }
+      }
     } else {
+      for (int k = lane; k < SW; k += 64)
 #pragma unroll
-      for (int i = 0; i < 6; ++i) sf[i] = P.sp[f * 8 + i];
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int j = 0; j <= i; ++j) L[tri(i, j)] = sf[i] * s_A[tri(i, j)] * sf[j];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) L[tri(i, i)] += clampd(L[tri(i, i)], mn, mx) / radius;
-    bool ok = true;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      double d = L[tri(j, j)];
-#pragma unroll
-      for (int k = 0; k < j; ++k) d -= L[tri(j, k)] * L[tri(j, k)];
-      ok = ok && (d > 0.0) && isfinite(d);
-      d = sqrt(d);
-      L[tri(j, j)] = d;
-      const double inv = 1.0 / d;
-      Li[j] = inv;
-#pragma unroll
-      for (int i = j + 1; i < 6; ++i) {
-        double a = L[tri(i, j)];
-#pragma unroll
-        for (int k = 0; k < j; ++k) a -= L[tri(i, k)] * L[tri(j, k)];
-        L[tri(i, j)] = a * inv;
-      }
-    }
-    // columns of [H_fs | g_f]: column k < S belongs to camera k/6 (zero if absent), column S is g_f
-    if (tid < P.SW) {
-      const int k = tid;
-      double w[6];
-      if (k < P.S6) {
-        const int cam = k / 6, a = k - cam * 6, slot = s_slot[cam];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) w[i] = slot >= 0 ? sf[i] * LG[slot][a * 16 + 6 + i] * s_ss[k] : 0.0;
-      } else if (HK && k < P.S) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) w[i] = sf[i] * s_B[i][k - P.S6] * s_ss[k];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) w[i] = sf[i] * s_A[21 + i];
-      }
-      double z[6], y[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        double a = w[i];
-#pragma unroll
-        for (int kk = 0; kk < i; ++kk) a -= L[tri(i, kk)] * z[kk];
-        z[i] = a * Li[i];
-      }
-#pragma unroll
-      for (int i = 5; i >= 0; --i) {
-        double a = z[i];
-#pragma unroll
-        for (int kk = i + 1; kk < 6; ++kk) a -= L[tri(kk, i)] * y[kk];
-        y[i] = a * Li[i];
-      }
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        Zl[i][k] = z[i];
-        P.Y[((size_t)f * 6 + i) * P.SW + k] = y[i];
-      }
+        for (int i = 0; i < 6; ++i) s_Z[(wave * 6 + i) * ZS + k] = 0.0;
     }
     __syncthreads();
+    // ---- Schur products of the four staged frames on the matrix cores
 #pragma unroll
-    for (int r = 0; r < kRigOwn; ++r) {
-      const int o = tid + 256 * r;
-      if (o >= P.PC) continue;
-      double a = 0.0;
-      if (o < P.NP) {
-        // pair (p, q), p <= q, of shared columns: camera columns exist in this frame only if the camera
-        // has a group here, intrinsics columns always do
-        const int p = op[r], q = oq[r];
-        const bool pk = HK && p >= P.S6, qk = HK && q >= P.S6;
-        const int cp = pk ? 0 : p / 6, cq = qk ? 0 : q / 6;
-        const int sp_ = pk ? 0 : s_slot[cp], sq_ = qk ? 0 : s_slot[cq];
-        if (sp_ >= 0 && sq_ >= 0) {
-          if (pk) a = s_ss[p] * s_BB[(p - P.S6) * 16 + (q - P.S6)] * s_ss[q];                 // k x k
-          else if (qk) a = s_ss[p] * LGB[sp_][(p - cp * 6) * 16 + (q - P.S6)] * s_ss[q];       // camera x k
-          else if (cp == cq) a = s_ss[p] * LG[sp_][(p - cp * 6) * 16 + (q - cq * 6)] * s_ss[q];
+    for (int u = 0; u < kRigTilesPerWave; ++u) {
+      const int idx = 4 * u + wave;
+      if (idx < P.nT) {
+        const int ti = P.tile_i[idx], tj = P.tile_j[idx];
+        const int col = lane & 15, sub = lane >> 4;
 #pragma unroll
-          for (int i = 0; i < 6; ++i) a -= Zl[i][p] * Zl[i][q];
+        for (int ksx = 0; ksx < 6; ++ksx) {
+          const double* row = s_Z + (4 * ksx + sub) * ZS;
+          const double a = row[16 * ti + col], b = row[16 * tj + col];
+          acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[u], 0, 0, 0);
         }
-        acc[r] += a;
-      } else if (o < P.pc_hd) {
-        const int p = o - P.pc_b;
-        const bool pk = HK && p >= P.S6;
-        const int cp = pk ? 0 : p / 6, sl = pk ? 0 : s_slot[cp];
-        if (sl >= 0) {
-          a = pk ? s_ss[p] * s_gk[p - P.S6] : s_ss[p] * LG[sl][(p - cp * 6) * 16 + 12];
-#pragma unroll
-          for (int i = 0; i < 6; ++i) a -= Zl[i][p] * Zl[i][P.S];
-        }
-        acc[r] += a;
-      } else if (o < P.pc_fail) {
-        const int p = o - P.pc_hd;
-        const bool pk = HK && p >= P.S6;
-        const int cp = pk ? 0 : p / 6, sl = pk ? 0 : s_slot[cp];
-        if (sl >= 0) a = pk ? s_ss[p] * s_ss[p] * s_BB[(p - P.S6) * 17] : s_ss[p] * s_ss[p] * LG[sl][(p - cp * 6) * 17];
-        acc[r] += a;
-      } else if (o == P.pc_fail) {
-        acc[r] += ok ? 0.0 : 1.0;
-      } else if (o < P.pc_gmax) {
-        const int p = o - P.pc_gs;
-        const bool pk = HK && p >= P.S6;
-        const int cp = pk ? 0 : p / 6, sl = pk ? 0 : s_slot[cp];
-        if (sl >= 0) a = pk ? s_gk[p - P.S6] : LG[sl][(p - cp * 6) * 16 + 12];
-        acc[r] += a;
-      } else {
-        for (int i = 0; i < 6; ++i) a = fmax(a, fabs(s_A[21 + i]));
-        acc[r] = fmax(acc[r], a);
       }
     }
     __syncthreads();
   }
+
+  // ---- one partial row per block
+  double* prow = P.partial + (size_t)blockIdx.x * P.PC;
+  // tiles: each belongs to exactly one wave. C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-  for (int r = 0; r < kRigOwn; ++r) {
-    const int o = tid + 256 * r;
-    if (o < P.PC) P.partial[(size_t)blockIdx.x * P.PC + o] = acc[r];
+  for (int u = 0; u < kRigTilesPerWave; ++u) {
+    const int idx = 4 * u + wave;
+    if (idx < P.nT) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) prow[(size_t)idx * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[u][r];
+    }
+  }
+  // direct sums: four waves each hold partial sums of the same entries
+#pragma unroll
+  for (int r0 = 0; r0 < kRigDirectPerLane; r0 += 16) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (r0 + r < kRigDirectPerLane) s_red[wave * 1024 + r * 64 + lane] = dacc[r0 + r];
+    __syncthreads();
+    for (int i = tid; i < 1024; i += 256) {
+      const int e = r0 * 64 + i;
+      if (e < P.ND) prow[P.pc_dir + e] = (s_red[i] + s_red[1024 + i]) + (s_red[2048 + i] + s_red[3072 + i]);
+    }
+  }
+  gmax = wave_max(gmax);
+  if (lane == 0) { s_fg[wave] = gmax; s_fg[4 + wave] = nfail; }
+  __syncthreads();
+  if (tid == 0) {
+    prow[P.pc_fail] = (s_fg[4] + s_fg[5]) + (s_fg[6] + s_fg[7]);
+    prow[P.pc_gmax] = fmax(fmax(s_fg[0], s_fg[1]), fmax(s_fg[2], s_fg[3]));
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// reduce: column sums (max for the last column) of the elimination partial rows, 16 columns per
-// block, 16 row groups per column, 16 loads in flight per thread. Deterministic.
+// The solve step, run by ONE block of 256 threads on the reduced sums (vec: [nT tiles | direct | fail | 0],
+// then one max-gradient slot per rank): assembles the damped reduced system in LDS (lower triangle), dense
+// Cholesky (all four waves, one barrier per column), then wave 0 alone: substitutions with lane i owning
+// b[i] and b[i + 64] (cross-lane values through v_readlane, no barrier), gradient / radius tests
+// (lm_finalize order), camera and intrinsics candidates, control block.
+// SRC: where a reduced value comes from. 0: plain loads of P.vec (after an all-reduce, RCCL route);
+// 1: write-through stores of the reduce blocks, read with sc1 loads (last-block-done, single GPU);
+// 2: the ranks' mailbox slots, polled and added in rank order (last-block-done, mailbox exchange).
+// Tried and dropped in round 1 (S = 24): a single-wave factorisation through LDS (33 us vs 20) and a
+// register-tiled one with only the pivot column crossing threads through LDS (23 us).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_d(double x, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ void untri(int idx, int& i, int& j) {  // packed lower index -> (i >= j)
+  i = 0;
+  while (tri(i + 1, 0) <= idx) ++i;
+  j = idx - tri(i, 0);
+}
+
+struct RigVal {   // reader of reduced value e
+  const RigDev& P; unsigned long long epoch; long long t0; int* s_ok;
+  template <int SRC>
+  __device__ __forceinline__ double get(int e) const {
+    if (SRC == 0) return P.vec[e];
+    if (SRC == 1)
+      return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(P.vec) + e,
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return p2p_poll_sum(P.x, 0, epoch, P.rank, P.nranks, e, t0, s_ok);
+  }
+};
+
+// writes the camera / intrinsics records the sweep reads, from the current parameters plus (step_ok) the step
+// x (LDS, scaled shared step with the sign of b: the step is -x * ss). Returns this thread's share of
+// (step^2, |x_cand|^2) of the shared block. All 256 threads call.
+__device__ __forceinline__ void rig_candidates(const RigDev& P, const double* x, bool have_step, int cur, int dst,
+                                               double& step2, double& xn2) {
+  const int tid = threadIdx.x;
+  step2 = 0.0; xn2 = 0.0;
+  for (int c = tid; c < P.C; c += 256) {
+    const double* pc = P.cam + ((size_t)cur * P.C + c) * 8;
+    double q[4] = {pc[0], pc[1], pc[2], pc[3]}, t[3] = {pc[4], pc[5], pc[6]};
+    double dc[6] = {0, 0, 0, 0, 0, 0};
+    const int p0 = P.pcol[c];
+    if (have_step) {
+      if (p0 >= 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dc[k] = -x[p0 + k] * P.ss[p0 + k];
+        double qn[4];
+        quat_plus(q, dc, qn);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const double d = qn[k] - q[k]; step2 += d * d; q[k] = qn[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const double tn = t[k] + dc[3 + k]; const double d = tn - t[k]; step2 += d * d; t[k] = tn; }
+        xn2 += q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + t[0] * t[0] + t[1] * t[1] + t[2] * t[2];
+      }
+      double* pd = P.cam + ((size_t)dst * P.C + c) * 8;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pd[k] = q[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pd[4 + k] = t[k];
+    }
+    double R[9];
+    quat_to_R(q, R);
+    double* rec = P.camrec + c * 32;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) rec[k] = R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rec[9 + k] = t[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) rec[12 + k] = dc[k];
+  }
+  // extension: candidate intrinsics, thread (set, j). Every intrinsic of a set that is in the problem counts in
+  // |x| (cf. IntrinsicsProblem), frozen ones do not move.
+  for (int i = tid; i < P.CK * kRigK; i += 256) {
+    const int s = i / kRigK, j = i - s * kRigK;
+    const int k0 = P.kscol[s];
+    const double kc = P.intr[((size_t)cur * P.CK + s) * 16 + j];
+    double dk = 0.0;
+    if (have_step && k0 >= 0 && !((P.kmask[s] >> j) & 1u)) dk = -x[k0 + j] * P.ss[k0 + j];
+    const double kn = kc + dk;
+    if (have_step) {
+      P.intr[((size_t)dst * P.CK + s) * 16 + j] = kn;
+      if (k0 >= 0) { step2 += dk * dk; xn2 += kn * kn; }
+    }
+    P.krec[s * 32 + j] = kn;
+    P.krec[s * 32 + 16 + j] = dk;
+  }
+}
+
+template <int SRC>
+__device__ void rig_solve_block(const RigDev& P, double* smem) {
+  const int S = P.S, LD = S + 1;
+  double* A = smem;                       // [S][LD] lower triangle of the reduced system
+  double* s_b = A + (size_t)S * LD;       // [128] right-hand side, then the solution x
+  double* s_gs = s_b + 128;               // [128] unscaled shared gradient
+  double* s_hd = s_gs + 128;              // [128] diagonal of the scaled H_ss
+  double* s_inv = s_hd + 128;             // [128] 1 / L_jj
+  __shared__ int s_ok, s_cholok, s_stepok, s_go;
+  __shared__ double s_g;
+  __shared__ double s4[4];
+  __shared__ LmCtl s_c;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const LmCtl* cn = P.ctl_next;
+  const int cur = cn->cur, dst = cur ^ 1;
+  const double radius = cn->radius;
+  const LmOpts o = *P.opts;
+  RigVal val{P, SRC == 2 ? P.x.seq[0] + 1ull : 0ull, wall_clock64(), &s_ok};
+  if (tid == 0) { s_ok = 1; s_cholok = 1; s_stepok = 0; s_go = 0; }
+  for (int i = tid; i < S * LD; i += 256) A[i] = 0.0;
+  if (tid < 128) { s_b[tid] = 0.0; s_gs[tid] = 0.0; s_hd[tid] = 0.0; s_inv[tid] = 0.0; }
+  __syncthreads();
+  // ---- 1. per-camera sums of the shared-block entries -> scaled H_ss (lower triangle), unscaled gradient.
+  // An intrinsics set shared by several cameras is summed by the first of them, in camera order.
+  for (int e = tid; e < P.ND; e += 256) {
+    const int co = e / P.DE, idx = e - co * P.DE;
+    const int c = P.obs_cam[co];
+    const int p0 = P.pcol[c], k0 = P.kcol[c];
+    if (idx < 27) {
+      if (p0 < 0) continue;
+      const double v = val.get<SRC>(P.pc_dir + e);
+      if (idx < 21) {
+        int i, j;
+        untri(idx, i, j);
+        A[(size_t)(p0 + i) * LD + p0 + j] = P.ss[p0 + i] * v * P.ss[p0 + j];
+      } else {
+        s_gs[p0 + idx - 21] = v;
+      }
+    } else if (idx < 81) {
+      if (p0 < 0 || k0 < 0) continue;
+      const int t = idx - 27, i = t / 9, j = t - i * 9;   // H_ck[i][j]; intrinsics columns follow all pose columns
+      const double v = val.get<SRC>(P.pc_dir + e);
+      A[(size_t)(k0 + j) * LD + p0 + i] = P.ss[k0 + j] * v * P.ss[p0 + i];
+    } else {
+      if (k0 < 0) continue;
+      bool first = true;
+      for (int co2 = 0; co2 < co; ++co2) first = first && P.kcol[P.obs_cam[co2]] != k0;
+      if (!first) continue;
+      double v = 0.0;
+      for (int co2 = co; co2 < P.CO; ++co2)
+        if (P.kcol[P.obs_cam[co2]] == k0) v += val.get<SRC>(P.pc_dir + co2 * P.DE + idx);
+      if (idx < 126) {
+        int i, j;
+        untri(idx - 81, i, j);
+        A[(size_t)(k0 + i) * LD + k0 + j] = P.ss[k0 + i] * v * P.ss[k0 + j];
+      } else {
+        s_gs[k0 + idx - 126] = v;
+      }
+    }
+  }
+  const double fail = val.get<SRC>(P.pc_fail);
+  const double gm_r = (tid < P.nranks && tid < 32) ? val.get<SRC>(P.PC + tid) : 0.0;
+  __syncthreads();
+  if (tid < S) s_hd[tid] = A[(size_t)tid * LD + tid];
+  // ---- 2. minus the Schur products Z^T Z (upper tile pairs; element (r, c) of pair (ti, tj) is (p, q), p <= q)
+  for (int i = tid; i < P.nT * 256; i += 256) {
+    const int t = i >> 8, r = (i >> 4) & 15, c = i & 15;
+    const int p = 16 * P.tile_i[t] + r, q = 16 * P.tile_j[t] + c;
+    if (p > q || p >= S || q > S) continue;
+    const double v = val.get<SRC>(i);
+    if (q < S) A[(size_t)q * LD + p] -= v;
+    else s_b[p] = -v;
+  }
+  __syncthreads();
+  // ---- 3. right-hand side, LM diagonal, constant coordinates (held intrinsics) become identity rows
+  bool pinned = false;
+  if (tid < S) {
+    const int info = P.colinfo[tid], kind = (info >> 4) & 15, comp = info & 15;
+    if (kind == 1) pinned = (P.kmask[P.kset[P.obs_cam[info >> 8]]] >> comp) & 1u;
+    else if (kind == 2) pinned = (P.kmask[0] >> comp) & 1u;
+    s_b[tid] = pinned ? 0.0 : s_b[tid] + P.ss[tid] * s_gs[tid];
+  }
+  __syncthreads();
+  if (tid < S) {
+    if (pinned) {
+      for (int k = 0; k < tid; ++k) A[(size_t)tid * LD + k] = 0.0;
+      for (int k = tid + 1; k < S; ++k) A[(size_t)k * LD + tid] = 0.0;
+      A[(size_t)tid * LD + tid] = 1.0;
+    } else {
+      A[(size_t)tid * LD + tid] += clampd(s_hd[tid], o.min_lm_diagonal, o.max_lm_diagonal) / radius;
+    }
+  }
+  // gradient of the accepted point: max-norm over the tangent coordinates (frames: per-rank slots)
+  {
+    double g = gm_r;
+    if (tid < S && !pinned) g = fmax(g, fabs(s_gs[tid]));
+    g = wave_max(g);
+    if (lane == 0) s4[tid >> 6] = g;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    LmCtl c = *cn;
+    const double gmax = fmax(fmax(s4[0], s4[1]), fmax(s4[2], s4[3]));
+    if (c.log_len > 0 && c.log_len <= P.log_cap && P.log[c.log_len - 1].accepted) P.log[c.log_len - 1].gradient_max_norm = gmax;
+    if (s_ok == 0) { c.done = 1; c.term = CC_FAILURE_EXCHANGE; }
+    else if (lm_finalize(c, o, gmax)) s_go = 1;
+    if (fail > 0.0) s_cholok = 0;
+    s_c = c;
+    s_g = gmax;
+  }
+  __syncthreads();
+  if (s_go) {
+    // right-looking Cholesky, lower triangle in place, ONE barrier per step: every thread derives
+    // 1/sqrt(pivot) itself, the trailing update uses the unscaled column times inv^2, and the
+    // scaled column is written in the same step by the threads that own it.
+    const int ti = tid >> 4, tk = tid & 15;  // 16 x 16 thread tile over the trailing block
+    for (int j = 0; j < S; ++j) {
+      const double d = A[(size_t)j * LD + j];
+      if (tid == 0 && (!(d > 0.0) || !isfinite(d))) s_cholok = 0;
+      const double inv = rsqrt(d), inv2 = inv * inv;
+      for (int r = j + 1 + ti; r < S; r += 16) {
+        const double arj = A[(size_t)r * LD + j] * inv2;
+        for (int k = j + 1 + tk; k <= r; k += 16) A[(size_t)r * LD + k] -= arj * A[(size_t)k * LD + j];
+      }
+      __syncthreads();
+      for (int r = tid; r < S; r += 256)
+        if (r > j) A[(size_t)r * LD + j] *= inv;
+      if (tid == 0) { A[(size_t)j * LD + j] = d * inv; s_inv[j] = inv; }
+      // (column j is read again only by the substitutions, after the final barrier)
+    }
+    __syncthreads();
+    if (tid < 64) {
+      // forward / backward substitution on wave 0: lane i owns rows i and i + 64
+      const int i0 = lane, i1 = lane + 64;
+      double b0 = i0 < S ? s_b[i0] : 0.0, b1 = i1 < S ? s_b[i1] : 0.0;
+      const double v0 = i0 < S ? s_inv[i0] : 0.0, v1 = i1 < S ? s_inv[i1] : 0.0;
+      // the factor entries a lane needs do not depend on the running solution: fetch them eight
+      // steps ahead so that only the lane reads and the FMA sit on the dependent chain
+      for (int j0 = 0; j0 < S; j0 += 8) {
+        double a0[8], a1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + u;
+          a0[u] = (j < S && i0 > j && i0 < S) ? A[(size_t)i0 * LD + j] : 0.0;
+          a1[u] = (j < S && i1 > j && i1 < S) ? A[(size_t)i1 * LD + j] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + u;
+          if (j < S) {
+            const double yj = j < 64 ? readlane_d(b0, j) * readlane_d(v0, j) : readlane_d(b1, j - 64) * readlane_d(v1, j - 64);
+            if (i0 == j) b0 = yj; else b0 -= a0[u] * yj;
+            if (i1 == j) b1 = yj; else b1 -= a1[u] * yj;
+          }
+        }
+      }
+      for (int j0 = S - 1; j0 >= 0; j0 -= 8) {
+        double a0[8], a1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 - u;
+          a0[u] = (j >= 0 && i0 < j) ? A[(size_t)j * LD + i0] : 0.0;
+          a1[u] = (j >= 0 && i1 < j) ? A[(size_t)j * LD + i1] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 - u;
+          if (j >= 0) {
+            const double xj = j < 64 ? readlane_d(b0, j) * readlane_d(v0, j) : readlane_d(b1, j - 64) * readlane_d(v1, j - 64);
+            if (i0 == j) b0 = xj; else b0 -= a0[u] * xj;
+            if (i1 == j) b1 = xj; else b1 -= a1[u] * xj;
+          }
+        }
+      }
+      const bool fin = (i0 >= S || isfinite(b0)) && (i1 >= S || isfinite(b1));
+      const bool step_ok = s_cholok != 0 && __all(fin);
+      if (i0 < S) { s_b[i0] = b0; P.ds[i0] = -b0; }
+      if (i1 < S) { s_b[i1] = b1; P.ds[i1] = -b1; }
+      if (lane == 0) s_stepok = step_ok ? 1 : 0;
+    }
+    __syncthreads();
+  }
+  // ---- camera / intrinsics candidates and records (nothing moves unless a valid step exists)
+  double st2 = 0.0, xs2 = 0.0;
+  const bool have_step = s_go != 0 && s_stepok != 0;
+  if (have_step) rig_candidates(P, s_b, true, cur, dst, st2, xs2);
+  const double st = block_sum256(st2, s4);
+  const double xs = block_sum256(xs2, s4);
+  if (tid == 0) {
+    LmCtl c = s_c;
+    if (s_go) {
+      c.step_valid = have_step ? 1 : 0;
+      c.cand_pending = 1;
+      P.shared_stats[0] = st;
+      P.shared_stats[1] = xs;
+    }
+    if (SRC == 2) P.x.seq[0] = val.epoch;
+    *P.ctl = c;
+    *P.ctl_next = c;
+  }
+}
+
+// RCCL route: the solve step as a kernel of its own (after the all-reduce of P.vec)
+__global__ __launch_bounds__(256) void k_rig_solve(RigDev P) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const LmCtl* cn = P.ctl_next;
+  if (cn->done) {
+    if (threadIdx.x == 0) *P.ctl = *cn;
+    return;
+  }
+  if (cn->phase == 0) return;
+  rig_solve_block<0>(P, reinterpret_cast<double*>(smem_raw));
+}
+
+// first launch of a solve: camera / intrinsics records of the starting point (what the first sweep reads)
+__global__ __launch_bounds__(256) void k_rig_records(RigDev P) {
+  const LmCtl* ctl = P.ctl;
+  if (ctl->done || ctl->phase != 0) return;
+  double a, b;
+  rig_candidates(P, nullptr, false, ctl->cur, ctl->cur, a, b);
+}
+
+// ---------------------------------------------------------------------------------------------
+// reduce (+ solve): column sums (max for the last column) of the elimination partial rows, 16 columns per
+// block, 16 row groups per column, 16 loads in flight per thread. Deterministic.
+// MODE 0 (single GPU): the sums are stored write-through, the block arrives on a counter and the LAST block
+// to arrive runs the solve step on them (sc1 loads, no fence: MI355X guide, valid hand-off forms).
+// MODE 3 (mailbox exchange): every block posts its 16 sums straight into all ranks' mailboxes; the last block
+// to arrive collects them in rank order inside the solve step. MODE 2 (RCCL): sums -> P.vec, nothing else.
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
 __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   __shared__ double s_r[16][16];
   __shared__ double s_post[48];
   __shared__ double s_tail;
+  __shared__ int s_last;
   const LmCtl* cn = P.ctl_next;
-  if (cn->done || cn->phase == 0) return;
+  if (cn->done) {
+    if (MODE != 2 && blockIdx.x == 0 && threadIdx.x == 0) *P.ctl = *cn;
+    return;
+  }
+  if (cn->phase == 0) return;
   const int tid = threadIdx.x, c = tid & 15, grp = tid >> 4;  // 16 columns x 16 row groups per block
   const int o = blockIdx.x * 16 + c;
   const bool is_max = o == P.pc_gmax;
@@ -845,14 +1236,20 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P) {
       r = (((s_r[0][c] + s_r[1][c]) + (s_r[2][c] + s_r[3][c])) + ((s_r[4][c] + s_r[5][c]) + (s_r[6][c] + s_r[7][c]))) +
           (((s_r[8][c] + s_r[9][c]) + (s_r[10][c] + s_r[11][c])) + ((s_r[12][c] + s_r[13][c]) + (s_r[14][c] + s_r[15][c])));
     }
-    if (is_max) { P.vec[P.PC + P.rank] = r; s_tail = r; r = 0.0; }  // a sum all-reduce then carries the max
-    P.vec[o] = r;
+    unsigned long long* vw = reinterpret_cast<unsigned long long*>(P.vec);
+    if (is_max) {   // the per-rank slot carries the max (a sum exchange then keeps it); the column itself is 0
+      if (MODE == 0) __hip_atomic_store(vw + P.PC + P.rank, (unsigned long long)__double_as_longlong(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else P.vec[P.PC + P.rank] = r;
+      s_tail = r;
+      r = 0.0;
+    }
+    if (MODE == 0) __hip_atomic_store(vw + o, (unsigned long long)__double_as_longlong(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else P.vec[o] = r;
     s_post[c] = r;
   }
-  if (P.x.on) {
-    // mailbox exchange (kind 0): every block posts its 16 column sums straight into all ranks'
-    // mailboxes; the block that owns the max column also posts the 32 per-rank max slots (ours set,
-    // the others zero). k_rig_solve collects. The epoch is stable here: only k_rig_solve advances it.
+  if (MODE == 3) {
+    // mailbox exchange (kind 0): the block that owns the max column also posts the 32 per-rank max slots
+    // (ours set, the others zero). The epoch is stable here: only the solve step advances it.
     __syncthreads();
     const unsigned long long epoch = P.x.seq[0] + 1ull;
     const int first = blockIdx.x * 16;
@@ -864,230 +1261,18 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P) {
       p2p_post(P.x, 0, epoch, P.rank, P.nranks, s_post + 16, 32, P.PC);
     }
   }
-}
-
-// ---------------------------------------------------------------------------------------------
-// solve (one block of 256): dense Cholesky of the reduced (6C)x(6C) system in LDS (all four waves,
-// one barrier per column), then wave 0 alone: substitutions with lane i owning b[i] (cross-lane
-// values through v_readlane, no barrier), gradient test, camera candidates. In phase 0 it only
-// prepares the camera records. Tried and dropped (C4, S = 24): a single-wave factorisation (33 us vs
-// 20: the read-modify-write chain through LDS has nothing to hide behind) and a register-tiled one
-// with only the pivot column crossing threads through LDS (23 us).
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double readlane_d(double x, int l) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
-  return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-  return v;
-}
-
-__global__ __launch_bounds__(256) void k_rig_solve(RigDev P) {
-  __shared__ double A[kRigMaxS][kRigMaxS + 1];
-  __shared__ double s_inv[64];
-  __shared__ int s_ok;
-  const int tid = threadIdx.x, lane = tid & 63, i = tid;
-  const LmCtl* cn = P.ctl_next;
-  const int done = cn->done, phase = cn->phase, cur = cn->cur;
-  const int S = P.S;
-  if (done) {
-    if (tid == 0) *P.ctl = *cn;
-    return;
+  if (MODE == 2) return;
+  // ---- last-block-done: every storing wave drains its stores, the block arrives, the last one solves
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(P.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = prev + 1u == gridDim.x;
   }
-  const bool my_cam_fixed = lane < P.C && P.cam_fixed[lane] != 0;
-  const unsigned long long fixed_mask = __ballot(my_cam_fixed);  // bit c: camera c is held constant (every wave)
-  const bool row = tid < S;                                       // rows live in wave 0 (S <= 60)
-  // columns 0..S6-1 belong to cameras (6 each), S6..S-1 to the shared intrinsics (extension)
-  const int S6 = P.S6;
-  const uint32_t kmask = P.kmask;
-  const bool row_fixed = row && (i < S6 ? ((fixed_mask >> (i / 6)) & 1ull) != 0 : ((kmask >> (i - S6)) & 1u) != 0);
-  bool step_ok = false, converged = false;
-  int early_term = CC_CONVERGENCE_GRADIENT;
-  double gmax = 0.0;
-  double bi = 0.0;
-  if (phase != 0 && P.x.on) {
-    // mailbox exchange (kind 0): wait for every rank's column sums (posted by k_rig_reduce), add them
-    // in rank order into P.vec; everything below then reads the global sums like on one GPU
-    const unsigned long long epoch = P.x.seq[0] + 1ull;
-    p2p_collect_to(P.x, 0, epoch, P.rank, P.nranks, P.PC + 32, P.vec, &s_ok);
-    if (tid == 0) P.x.seq[0] = epoch;
-    if (s_ok == 0) {
-      if (tid == 0) {
-        LmCtl c = *cn;
-        c.done = 1; c.term = CC_FAILURE_EXCHANGE;
-        *P.ctl = c; *P.ctl_next = c;
-      }
-      return;
-    }
-    __syncthreads();
-  }
-  if (phase != 0) {
-    // ---- reduced sums from k_rig_reduce: packed upper triangle -> lower triangle in LDS; rows and
-    // columns of constant cameras become identity. Everything is issued in one round trip.
-    const double b_in = row ? P.vec[P.pc_b + i] : 0.0;
-    const double gs_i = row ? P.vec[P.pc_gs + i] : 0.0;
-    const double fail = P.vec[P.pc_fail];
-    const double gm_r = (tid < P.nranks && tid < 32) ? P.vec[P.PC + tid] : 0.0;
-    const LmOpts o = *P.opts;
-    const double radius = cn->radius;
-    for (int idx = tid; idx < P.NP; idx += 256) {
-      const int p = P.pair_p[idx], q = P.pair_q[idx];  // p <= q
-      double a = P.vec[idx];
-      const bool pf = p < S6 ? ((fixed_mask >> (p / 6)) & 1ull) != 0 : ((kmask >> (p - S6)) & 1u) != 0;
-      const bool qf = q < S6 ? ((fixed_mask >> (q / 6)) & 1ull) != 0 : ((kmask >> (q - S6)) & 1u) != 0;
-      if (pf || qf) a = p == q ? 1.0 : 0.0;
-      else if (p == q) a += clampd(P.vec[P.pc_hd + p], o.min_lm_diagonal, o.max_lm_diagonal) / radius;
-      A[q][p] = a;
-    }
-    if (tid == 0) s_ok = fail > 0.0 ? 0 : 1;
-    // gradient test (wave 0 holds the rows; the other waves compute the same uniform answer from LDS)
-    __shared__ double s_g;
-    if (tid < 64) {
-      const double g = wave_max(fmax(gm_r, (row && !row_fixed) ? fabs(gs_i) : 0.0));
-      if (tid == 0) s_g = g;
-    }
-    __syncthreads();
-    gmax = s_g;
-#if CC_ABLATE_RS == 1
-    return;
-#endif
-    // second half of FinalizeIterationAndCheckIfMinimizerCanContinue (cf. lm_finalize): gradient tolerance, then
-    // minimum trust-region radius
-    converged = gmax <= o.gradient_tolerance;
-    if (!converged && radius < o.min_radius) { converged = true; early_term = CC_MIN_RADIUS; }
-    if (!converged) {
-      // right-looking Cholesky, lower triangle in place, ONE barrier per step: every thread derives
-      // 1/sqrt(pivot) itself, the trailing update uses the unscaled column times inv^2, and the
-      // scaled column is written in the same step by the threads that own it.
-      const int ti = tid >> 4, tk = tid & 15;  // 16 x 16 thread tile over the trailing block
-      for (int j = 0; j < S; ++j) {
-        const double d = A[j][j];
-        if (tid == 0 && (!(d > 0.0) || !isfinite(d))) s_ok = 0;
-        const double inv = rsqrt(d), inv2 = inv * inv;
-        for (int r = j + 1 + ti; r < S; r += 16) {
-          const double arj = A[r][j] * inv2;
-          for (int k = j + 1 + tk; k <= r; k += 16) A[r][k] -= arj * A[k][j];
-        }
-        __syncthreads();
-        if (tid > j && tid < S) A[tid][j] *= inv;
-        if (tid == j) { A[j][j] = d * inv; s_inv[j] = inv; }
-        // (column j is read again only by the substitutions, after the final barrier)
-      }
-      __syncthreads();
-#if CC_ABLATE_RS == 2
-      return;
-#endif
-      if (tid < 64) {
-        // forward / backward substitution on wave 0: lane i owns b[i]
-        const double inv_own = row ? s_inv[i] : 0.0;
-        bi = row_fixed ? 0.0 : b_in;
-        // the factor entries a lane needs do not depend on the running solution: fetch them eight
-        // steps ahead so that only the lane reads and the FMA sit on the dependent chain
-        for (int j0 = 0; j0 < S; j0 += 8) {
-          double a[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) a[u] = (row && j0 + u < S && i > j0 + u) ? A[i][j0 + u] : 0.0;
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int j = j0 + u;
-            if (j < S) {
-              const double yj = readlane_d(bi, j) * readlane_d(inv_own, j);
-              if (i == j) bi = yj;
-              else bi -= a[u] * yj;
-            }
-          }
-        }
-        for (int j0 = S - 1; j0 >= 0; j0 -= 8) {
-          double a[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) a[u] = (j0 - u >= 0 && i < j0 - u) ? A[j0 - u][i] : 0.0;
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int j = j0 - u;
-            if (j >= 0) {
-              const double xj = readlane_d(bi, j) * readlane_d(inv_own, j);
-              if (i == j) bi = xj;
-              else bi -= a[u] * xj;
-            }
-          }
-        }
-        step_ok = s_ok != 0 && __all(!row || isfinite(bi));
-        if (row) P.ds[i] = -bi;
-      }
-    }
-  }
-#if CC_ABLATE_RS == 3
-  if (phase != 0) return;
-#endif
-  if (tid >= 64) return;
-  // ---- wave 0: camera candidates / records: lane c < C gathers its six step components from lanes 6c..6c+5
-  const int dst = phase == 0 ? cur : (cur ^ 1);
-  double step2 = 0.0, xn2 = 0.0;
-  double dcv[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) dcv[k] = __shfl(bi, (lane < P.C ? lane : 0) * 6 + k, 64);
-  if (lane < P.C && (phase == 0 || step_ok)) {
-    const int c = lane;
-    const double* pc = P.cam + ((size_t)cur * P.C + c) * 8;
-    double q[4] = {pc[0], pc[1], pc[2], pc[3]}, t[3] = {pc[4], pc[5], pc[6]};
-    double dc[6] = {0, 0, 0, 0, 0, 0};
-    if (phase != 0) {
-      if (!my_cam_fixed) {
-        for (int k = 0; k < 6; ++k) dc[k] = -dcv[k] * P.ss[c * 6 + k];
-        double qn[4];
-        quat_plus(q, dc, qn);
-        for (int k = 0; k < 4; ++k) { const double d = qn[k] - q[k]; step2 += d * d; q[k] = qn[k]; }
-        for (int k = 0; k < 3; ++k) { const double tn = t[k] + dc[3 + k]; const double d = tn - t[k]; step2 += d * d; t[k] = tn; }
-        xn2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + t[0] * t[0] + t[1] * t[1] + t[2] * t[2];
-      }
-      double* pd = P.cam + ((size_t)dst * P.C + c) * 8;
-      for (int k = 0; k < 4; ++k) pd[k] = q[k];
-      for (int k = 0; k < 3; ++k) pd[4 + k] = t[k];
-    }
-    double R[9];
-    quat_to_R(q, R);
-    double* rec = P.camrec + c * 32;
-    for (int k = 0; k < 9; ++k) rec[k] = R[k];
-    for (int k = 0; k < 3; ++k) rec[9 + k] = t[k];
-    for (int k = 0; k < 6; ++k) rec[12 + k] = dc[k];
-  }
-  if (P.K && lane >= S6 && lane < S6 + P.K) {
-    // extension: candidate intrinsics (lane S6 + j owns the step of intrinsic j); every intrinsic counts
-    // in |x| (cf. IntrinsicsProblem), frozen ones do not move
-    const int j = lane - S6;
-    const double kc = P.intr[cur * 16 + j];
-    double dk = 0.0;
-    if (phase != 0 && step_ok && !((kmask >> j) & 1u)) dk = -bi * P.ss[lane];
-    const double kn = kc + dk;
-    if (phase == 0 || step_ok) {
-      if (phase != 0) { P.intr[dst * 16 + j] = kn; step2 += dk * dk; xn2 = kn * kn; }
-      P.krec[j] = kn;
-      P.krec[16 + j] = dk;
-    }
-  }
-  const double st = wave_sum(step2);
-  const double xs = wave_sum(xn2);
-  if (lane == 0) {
-    LmCtl c = *cn;
-    if (phase != 0) {
-      c.gmax = gmax;
-      if (c.log_len > 0 && c.log_len <= P.log_cap && P.log[c.log_len - 1].accepted)
-        P.log[c.log_len - 1].gradient_max_norm = gmax;
-      if (converged) { c.done = 1; c.term = early_term; }
-      else {
-        c.step_valid = step_ok ? 1 : 0;
-        c.cand_pending = 1;
-        P.shared_stats[0] = st;
-        P.shared_stats[1] = xs;
-      }
-    }
-    *P.ctl = c;
-    *P.ctl_next = c;
-  }
+  __syncthreads();
+  if (!s_last) return;
+  if (tid == 0) __hip_atomic_store(P.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+  rig_solve_block<MODE == 0 ? 1 : 2>(P, reinterpret_cast<double*>(smem_raw));
 }
 
 // per-observation robustified cost at the accepted point (extrinsics_calibrator.cpp:219-225)
@@ -1100,6 +1285,7 @@ __global__ void k_rig_obs_cost(RigDev P, int cur, double* out /*sorted order*/) 
   quat_to_R(pc, Rc);
   quat_to_R(pf, Rf);
   const float2* uv2 = reinterpret_cast<const float2*>(P.uv);
+  const double* kk = P.kmode ? P.intr + ((size_t)cur * P.CK + P.kset[c]) * 16 : nullptr;
   for (int64_t idx = P.goff[g] + threadIdx.x; idx < P.goff[g + 1]; idx += blockDim.x) {
     const float2 m = uv2[idx];
     const int64_t w = P.widx[idx];
@@ -1107,9 +1293,9 @@ __global__ void k_rig_obs_cost(RigDev P, int cur, double* out /*sorted order*/) 
     rig_common(Rf, pf + 4, Rc, pc + 4, (double)P.wxyz[w * 3], (double)P.wxyz[w * 3 + 1], (double)P.wxyz[w * 3 + 2],
                (double)m.x, (double)m.y, o);
     double ru = o.ru, rv = o.rv;
-    if (P.K) {
+    if (kk) {
       RigKObs ko;
-      rigk_obs(P.intr + cur * 16, o, (double)m.x, (double)m.y, ko);
+      rigk_obs(kk, o, (double)m.x, (double)m.y, ko);
       ru = ko.ru; rv = ko.rv;
     }
     double rho, sr;
@@ -1135,6 +1321,7 @@ struct cc_rig {
   hipStream_t stream = nullptr;
   cc::RigDev d{};
   int64_t C = 0, F = 0, N = 0, NG = 0, P = 0;
+  int kmode = 0;
   std::vector<int64_t> perm;  // sorted position -> caller's observation index
   std::vector<void*> allocs;    // the chunks dev_alloc carves buffers from
   char* chunk_cur = nullptr;
@@ -1148,11 +1335,18 @@ struct cc_rig {
   int graph_iters = 0;
   cc::Comm* comm = nullptr;
   cc::Mailbox mailbox;          // mailbox exchange (cc_rig_exchange_export / _attach)
-  double* init_intr = nullptr;  // [16] (extension)
+  double* init_intr = nullptr;  // [max(CK,1)][16] (extension)
+  uint32_t* d_kmask = nullptr;  // same memory as d.kmask
   bool have_intr = false;
   bool exchange = false;
   uint8_t* d_cam_fixed = nullptr;          // same memory as d.cam_fixed
   std::vector<uint8_t> frozen, seen;       // host copies (user freeze flags, locally observed cameras)
+  std::vector<uint8_t> seen_any;           // cameras observed by any rank (what the column layout is built for)
+  std::vector<int32_t> gframe_h, gcam_h;   // host copies of the group tables (layout rebuilds)
+  std::vector<int64_t> fgoff_h;
+  size_t elim_lds = 0, solve_lds = 0;
+  std::vector<hipEvent_t> events;
+  std::vector<int> event_kind;
 };
 
 namespace cc {
@@ -1176,6 +1370,12 @@ static int dev_alloc(cc_rig* h, T** p, size_t n) {
   return 0;
 }
 template <class T>
+static int dev_zeroed(cc_rig* h, T** p, size_t n) {
+  if (int rc = dev_alloc(h, p, n)) return rc;
+  CC_HIP(hipMemset(*p, 0, std::max<size_t>(n, 1) * sizeof(T)));
+  return 0;
+}
+template <class T>
 static int dev_upload(cc_rig* h, const T** p, const std::vector<T>& v) {
   T* q = nullptr;
   if (int rc = dev_alloc(h, &q, v.size())) return rc;
@@ -1189,27 +1389,155 @@ static void rig_drop_graphs(cc_rig* h) {
     if (g) { hipGraphExecDestroy(g); g = nullptr; }
 }
 
-// One round: reduce -> solve -> update -> sweep -> decide+elim. The very first round of a solve is the
-// initial evaluation: there is nothing to reduce yet (k_rig_reduce would return at once), and only
-// that round needs k_rig_init (Jacobi scale of the shared block, trust-region state).
-static int rig_enqueue_round(cc_rig* h, bool initial) {
-  const RigDev& d = h->d;
-  if (!initial) {
-    hipLaunchKernelGGL(k_rig_reduce, dim3((unsigned)((d.PC + 15) / 16)), dim3(256), 0, h->stream, d);
-    if (h->comm) if (int rc = comm_allreduce_sum(h->comm, d.vec, d.PC + 32, h->stream)) return rc;  // (mailbox: posted by the kernel)
+struct RigProbe {  // optional hipEvent bracket around one launch
+  cc_rig* h; int kind; bool on; hipEvent_t e0 = nullptr, e1 = nullptr;
+  RigProbe(cc_rig* h_, int kind_, bool on_) : h(h_), kind(kind_), on(on_) {
+    if (on) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, h->stream); }
   }
-  hipLaunchKernelGGL(k_rig_solve, dim3(1), dim3(256), 0, h->stream, d);
-  hipLaunchKernelGGL(k_rig_update, dim3((unsigned)((h->F + 15) / 16)), dim3(256), 0, h->stream, d);
-  if (d.K) hipLaunchKernelGGL(k_rig_sweep<true>, dim3((unsigned)h->NG), dim3(kRigThreads), kRigSweepLdsBytesK, h->stream, d);
-  else hipLaunchKernelGGL(k_rig_sweep<false>, dim3((unsigned)h->NG), dim3(kRigThreads), kRigSweepLdsBytes, h->stream, d);
-  if (h->comm || h->exchange) {
-    hipLaunchKernelGGL(k_rig_stats, dim3(1), dim3(256), 0, h->stream, d);
-    if (h->comm) if (int rc = comm_allreduce_sum(h->comm, d.vec_stats, 4 + d.S, h->stream)) return rc;
+  ~RigProbe() {
+    if (on) { hipEventRecord(e1, h->stream); h->events.push_back(e0); h->events.push_back(e1); h->event_kind.push_back(kind); }
   }
-  if (initial) hipLaunchKernelGGL(k_rig_init, dim3(1), dim3(256), 0, h->stream, d);
-  if (d.K) hipLaunchKernelGGL(k_rig_decide_elim<true>, dim3(d.nblk), dim3(256), 0, h->stream, d);
-  else hipLaunchKernelGGL(k_rig_decide_elim<false>, dim3(d.nblk), dim3(256), 0, h->stream, d);
+};
+
+// Shared-block layout for the cameras in `seen_any` (observed by at least one rank): which camera owns which
+// columns, the tile grid of the Schur products, the direct-sum table -- and every buffer whose size depends on
+// them. Called by create (with the locally observed cameras) and again by the multi-GPU attach calls when
+// another rank observes a camera this one does not.
+static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
+  RigDev& d = h->d;
+  const int64_t C = h->C, F = h->F;
+  const int kmode = h->kmode;
+  h->seen_any = seen_any;
+  std::vector<int32_t> pcol((size_t)C, -1), kcol((size_t)C, -1), kset((size_t)C, 0), cobs((size_t)C, -1), obs_cam, colinfo;
+  std::vector<uint8_t> fixed((size_t)C, 1);
+  int S = 0;
+  for (int64_t c = 0; c < C; ++c)
+    if (seen_any[(size_t)c]) { cobs[(size_t)c] = (int32_t)obs_cam.size(); obs_cam.push_back((int32_t)c); }
+  for (int64_t c = 0; c < C; ++c)
+    if (seen_any[(size_t)c] && !h->frozen[(size_t)c]) {
+      pcol[(size_t)c] = S;
+      fixed[(size_t)c] = 0;
+      for (int a = 0; a < 6; ++a) colinfo.push_back((cobs[(size_t)c] << 8) | (0 << 4) | a);
+      S += 6;
+    }
+  const int CK = kmode == RIG_K_NONE ? 0 : (kmode == RIG_K_SHARED ? 1 : (int)C);
+  std::vector<int32_t> kscol((size_t)std::max(CK, 1), -1);
+  if (kmode == RIG_K_SHARED && !obs_cam.empty()) {
+    kscol[0] = S;
+    for (int64_t c = 0; c < C; ++c) if (seen_any[(size_t)c]) kcol[(size_t)c] = S;
+    for (int j = 0; j < kRigK; ++j) colinfo.push_back((0 << 8) | (2 << 4) | j);
+    S += kRigK;
+  } else if (kmode == RIG_K_PER_CAMERA) {
+    for (int64_t c = 0; c < C; ++c) {
+      kset[(size_t)c] = (int32_t)c;
+      if (!seen_any[(size_t)c]) continue;
+      kcol[(size_t)c] = S;
+      kscol[(size_t)c] = S;
+      for (int j = 0; j < kRigK; ++j) colinfo.push_back((cobs[(size_t)c] << 8) | (1 << 4) | j);
+      S += kRigK;
+    }
+  }
+  colinfo.push_back((0 << 8) | (3 << 4) | 0);   // right-hand side
+  const int CO = (int)obs_cam.size();
+  if (S > kRigMaxS)
+    return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: %d optimised shared coordinates (6 per observed non-frozen camera%s); at most %d",
+                S, kmode ? " + 9 per intrinsics set" : "", kRigMaxS);
+  if (CO > 64) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: %d observed cameras; at most 64", CO);
+  const int DE = kmode ? kDEK : kDE0;
+  if (CO * DE > 64 * kRigDirectPerLane)
+    return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: %d observed cameras%s; at most %d", CO, kmode ? " with intrinsics" : "", 64 * kRigDirectPerLane / DE);
+  d.C = (int32_t)C; d.CO = CO; d.CK = CK; d.S = S; d.SW = S + 1;
+  d.T = (d.SW + 15) / 16; d.nT = d.T * (d.T + 1) / 2; d.ZS = 16 * d.T + ((d.T & 1) ? 0 : 16);
+  d.DE = DE; d.ND = CO * DE;
+  d.pc_dir = d.nT * 256; d.pc_fail = d.pc_dir + d.ND; d.pc_gmax = d.pc_fail + 1; d.PC = d.pc_gmax + 1;
+  d.nblk = (int)std::max<int64_t>(1, std::min<int64_t>(kRigMaxElimBlocks, (F + 3) / 4));
+  std::vector<int16_t> dmap((size_t)DE);
+  for (int i = 0; i < 6; ++i) for (int j = 0; j <= i; ++j) dmap[(size_t)(i * (i + 1) / 2 + j)] = (int16_t)(i * 16 + j);
+  for (int i = 0; i < 6; ++i) dmap[(size_t)(21 + i)] = (int16_t)(i * 16 + 12);
+  if (kmode) {
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 9; ++j) dmap[(size_t)(27 + i * 9 + j)] = (int16_t)(256 + i * 16 + j);
+    for (int i = 0; i < 9; ++i) for (int j = 0; j <= i; ++j) dmap[(size_t)(81 + i * (i + 1) / 2 + j)] = (int16_t)(512 + i * 16 + j);
+    for (int j = 0; j < 9; ++j) dmap[(size_t)(126 + j)] = (int16_t)(256 + 12 * 16 + j);
+  }
+  std::vector<uint8_t> ti, tj;
+  for (int a = 0; a < d.T; ++a) for (int b = a; b < d.T; ++b) { ti.push_back((uint8_t)a); tj.push_back((uint8_t)b); }
+  std::vector<int32_t> fslot((size_t)F * std::max(CO, 1), -1);
+  for (int64_t g = 0; g < h->NG; ++g) fslot[(size_t)h->gframe_h[(size_t)g] * CO + cobs[(size_t)h->gcam_h[(size_t)g]]] = (int32_t)g;
+  if (int rc = dev_upload(h, &d.pcol, pcol)) return rc;
+  if (int rc = dev_upload(h, &d.kcol, kcol)) return rc;
+  if (int rc = dev_upload(h, &d.kset, kset)) return rc;
+  if (int rc = dev_upload(h, &d.kscol, kscol)) return rc;
+  if (int rc = dev_upload(h, &d.obs_cam, obs_cam)) return rc;
+  if (int rc = dev_upload(h, &d.colinfo, colinfo)) return rc;
+  if (int rc = dev_upload(h, &d.dmap, dmap)) return rc;
+  if (int rc = dev_upload(h, &d.tile_i, ti)) return rc;
+  if (int rc = dev_upload(h, &d.tile_j, tj)) return rc;
+  if (int rc = dev_upload(h, &d.fslot, fslot)) return rc;
+  if (!h->d_cam_fixed) { if (int rc = dev_alloc(h, &h->d_cam_fixed, (size_t)C)) return rc; d.cam_fixed = h->d_cam_fixed; }
+  CC_HIP(hipMemcpy(h->d_cam_fixed, fixed.data(), fixed.size(), hipMemcpyHostToDevice));
+  if (int rc = dev_zeroed(h, &d.Y, (size_t)F * 6 * d.SW)) return rc;
+  if (int rc = dev_zeroed(h, &d.partial, (size_t)d.nblk * d.PC)) return rc;
+  if (int rc = dev_zeroed(h, &d.vec, (size_t)d.PC + 32)) return rc;
+  if (int rc = dev_zeroed(h, &d.vec_stats, (size_t)4 + kRigMaxS + 1)) return rc;
+  h->elim_lds = ((size_t)24 * d.ZS + 4 * 32 + 4 * 1024) * sizeof(double);
+  h->solve_lds = ((size_t)S * (S + 1) + 4 * 128) * sizeof(double);
+  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
+  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
+  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_reduce<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
+  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_reduce<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
+  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
+  rig_drop_graphs(h);
   return 0;
+}
+
+// upper bounds of the exchanged vector sizes (every non-frozen camera observed): mailbox slots are allocated
+// before the ranks know which cameras the others see
+static void rig_exchange_bounds(const cc_rig* h, int* doubles_kind0, int* doubles_kind1) {
+  int S = 0, CO = (int)h->C;
+  for (int64_t c = 0; c < h->C; ++c) if (!h->frozen[(size_t)c]) S += 6;
+  if (h->kmode == RIG_K_SHARED) S += kRigK;
+  if (h->kmode == RIG_K_PER_CAMERA) S += kRigK * (int)h->C;
+  S = std::min(S, kRigMaxS);
+  CO = std::min(CO, 64);
+  const int T = (S + 1 + 15) / 16;
+  *doubles_kind0 = T * (T + 1) / 2 * 256 + CO * (h->kmode ? kDEK : kDE0) + 2 + 32;
+  *doubles_kind1 = std::max(4 + S, (int)std::min<int64_t>(h->C, 128));
+}
+
+// One round: sweep -> [statistics exchange] -> [init, first round only] -> decision + elimination ->
+// reduce + solve step -> pose update (what the next round's sweep evaluates). The first round of a solve is
+// the initial evaluation.
+static int rig_enqueue_round(cc_rig* h, bool initial, bool profile) {
+  const RigDev& d = h->d;
+  { RigProbe p(h, CC_K_SWEEP, profile);
+    if (d.kmode) hipLaunchKernelGGL(k_rig_sweep<true>, dim3((unsigned)h->NG), dim3(kRigThreads), kRigSweepLdsBytesK, h->stream, d);
+    else hipLaunchKernelGGL(k_rig_sweep<false>, dim3((unsigned)h->NG), dim3(kRigThreads), kRigSweepLdsBytes, h->stream, d); }
+  if (h->comm || h->exchange) {
+    { RigProbe p(h, CC_K_DECIDE, profile); hipLaunchKernelGGL(k_rig_stats, dim3(1), dim3(256), 0, h->stream, d); }
+    if (h->comm) { RigProbe p(h, CC_K_ALLREDUCE, profile); if (int rc = comm_allreduce_sum(h->comm, d.vec_stats, 4 + d.S, h->stream)) return rc; }
+  }
+  if (initial) { RigProbe p(h, CC_K_DECIDE, profile); hipLaunchKernelGGL(k_rig_init, dim3(1), dim3(256), 0, h->stream, d); }
+  { RigProbe p(h, CC_K_ELIM, profile);
+    if (d.kmode) hipLaunchKernelGGL(k_rig_elim<true>, dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d);
+    else hipLaunchKernelGGL(k_rig_elim<false>, dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d); }
+  const unsigned rblocks = (unsigned)((d.PC + 15) / 16);
+  if (h->comm) {
+    { RigProbe p(h, CC_K_REDUCE, profile); hipLaunchKernelGGL(k_rig_reduce<2>, dim3(rblocks), dim3(256), 0, h->stream, d); }
+    { RigProbe p(h, CC_K_ALLREDUCE, profile); if (int rc = comm_allreduce_sum(h->comm, d.vec, d.PC + 32, h->stream)) return rc; }
+    { RigProbe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_rig_solve, dim3(1), dim3(256), h->solve_lds, h->stream, d); }
+  } else {
+    RigProbe p(h, CC_K_SOLVE, profile);
+    if (h->exchange) hipLaunchKernelGGL(k_rig_reduce<3>, dim3(rblocks), dim3(256), h->solve_lds, h->stream, d);
+    else hipLaunchKernelGGL(k_rig_reduce<0>, dim3(rblocks), dim3(256), h->solve_lds, h->stream, d);
+  }
+  { RigProbe p(h, CC_K_UPDATE, profile); hipLaunchKernelGGL(k_rig_update, dim3((unsigned)((h->F + 15) / 16)), dim3(256), 0, h->stream, d); }
+  return 0;
+}
+
+// head of a solve: records of the starting point for the first sweep
+static void rig_enqueue_prep(cc_rig* h) {
+  hipLaunchKernelGGL(k_rig_records, dim3(1), dim3(256), 0, h->stream, h->d);
+  hipLaunchKernelGGL(k_rig_update, dim3((unsigned)((h->F + 15) / 16)), dim3(256), 0, h->stream, h->d);
 }
 
 static int rig_write_ctl(cc_rig* h, const LmCtl& c) {
@@ -1240,15 +1568,16 @@ extern "C" {
 
 static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world, const int64_t* off,
                            const uint32_t* obs_cam, const uint64_t* obs_world, const float* obs_uv,
-                           const float* world_xyz, const uint8_t* cam_frozen, double huber_a, int K, cc_rig** out) {
+                           const float* world_xyz, const uint8_t* cam_frozen, double huber_a, int kmode, cc_rig** out) {
   using namespace cc;
   if (!out || !off || C < 1 || F < 1 || n_world < 0) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: bad arguments");
-  if (C > kRigMaxCams) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: at most %d cameras", kRigMaxCams);
-  if (6 * C + K > kRigMaxS) return fail(CC_ERR_BAD_ARGUMENT, "cc_rigk_create: at most %d cameras with shared intrinsics", (kRigMaxS - K) / 6);
   if (off[0] != 0) return fail(CC_ERR_BAD_ARGUMENT, "obs_frame_offsets[0] must be 0");
   const int64_t N = off[F];
   for (int64_t f = 0; f < F; ++f)
     if (off[f + 1] < off[f]) return fail(CC_ERR_BAD_ARGUMENT, "obs_frame_offsets must be non-decreasing");
+  // device-side indices are 32-bit (world point, group, camera) and launch grids are unsigned
+  if (C > (1 << 20) || F >= INT32_MAX || n_world >= INT32_MAX || N >= ((int64_t)1 << 40))
+    return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: problem too large (cameras < 2^20, frames and world points < 2^31)");
   if (N > 0 && (!obs_cam || !obs_world || !obs_uv || !world_xyz)) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: NULL arrays");
   for (int64_t k = 0; k < N; ++k) {
     if (obs_cam[k] >= (uint32_t)C) return fail(CC_ERR_BAD_ARGUMENT, "observation %lld: camera id out of range", (long long)k);
@@ -1257,36 +1586,41 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   if (int rc = select_device(device)) return rc;
   cc_rig* h = new cc_rig();
   RigCreateGuard guard{h};
-  h->device = device; h->C = C; h->F = F; h->N = N; h->P = n_world;
+  h->device = device; h->C = C; h->F = F; h->N = N; h->P = n_world; h->kmode = kmode;
   // ---- regroup: within each frame, stable sort by camera -> (frame, camera) groups
   h->perm.resize((size_t)N);
-  std::vector<int64_t> goff{0}, fgoff((size_t)F + 1, 0);
-  std::vector<int32_t> gframe, gcam;
+  std::vector<int64_t> goff{0};
+  h->fgoff_h.assign((size_t)F + 1, 0);
+  std::vector<int32_t>& gframe = h->gframe_h;
+  std::vector<int32_t>& gcam = h->gcam_h;
   std::vector<uint8_t> seen((size_t)C, 0);
   {
-    // counting sort by camera inside each frame (stable: observation order is kept within a group)
+    // counting sort by camera inside each frame (stable: observation order is kept within a group); only the
+    // cameras that occur in the frame are visited, so thousands of idle cameras cost nothing
     int64_t pos = 0;
-    std::vector<int64_t> cnt((size_t)C), start((size_t)C);
+    std::vector<int64_t> cnt((size_t)C, 0), start((size_t)C, 0);
+    std::vector<uint32_t> present;
     for (int64_t f = 0; f < F; ++f) {
-      std::fill(cnt.begin(), cnt.end(), 0);
-      for (int64_t k = off[f]; k < off[f + 1]; ++k) cnt[obs_cam[k]]++;
-      for (int64_t c = 0; c < C; ++c) {
-        start[(size_t)c] = pos;
-        if (cnt[(size_t)c] > 0) {
-          gframe.push_back((int32_t)f);
-          gcam.push_back((int32_t)c);
-          seen[(size_t)c] = 1;
-          pos += cnt[(size_t)c];
-          goff.push_back(pos);
-        }
+      present.clear();
+      for (int64_t k = off[f]; k < off[f + 1]; ++k) if (cnt[obs_cam[k]]++ == 0) present.push_back(obs_cam[k]);
+      std::sort(present.begin(), present.end());
+      for (uint32_t c : present) {
+        start[c] = pos;
+        gframe.push_back((int32_t)f);
+        gcam.push_back((int32_t)c);
+        seen[c] = 1;
+        pos += cnt[c];
+        goff.push_back(pos);
       }
       for (int64_t k = off[f]; k < off[f + 1]; ++k) h->perm[(size_t)start[obs_cam[k]]++] = k;
-      fgoff[(size_t)f + 1] = (int64_t)gframe.size();
+      for (uint32_t c : present) cnt[c] = 0;
+      h->fgoff_h[(size_t)f + 1] = (int64_t)gframe.size();
     }
   }
   const int64_t NG = (int64_t)gframe.size();
   h->NG = NG;
   if (NG == 0) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: no observations");
+  if (NG >= INT32_MAX) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: too many (frame, camera) groups");
   std::vector<float> uv((size_t)N * 2);
   std::vector<int32_t> widx((size_t)N);
   for (int64_t i = 0; i < N; ++i) {
@@ -1301,24 +1635,16 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
     std::vector<int32_t> fill(cam_goff.begin(), cam_goff.end() - 1);
     for (int64_t g = 0; g < NG; ++g) cam_glist[(size_t)fill[gcam[g]]++] = (int32_t)g;
   }
-  std::vector<uint8_t> fixed((size_t)C);
-  for (int64_t c = 0; c < C; ++c) fixed[c] = ((cam_frozen && cam_frozen[c]) || !seen[c]) ? 1 : 0;
-  const int S = (int)(6 * C) + K;
-  std::vector<uint8_t> pp, pq;
-  for (int p = 0; p < S; ++p) for (int q = p; q < S; ++q) { pp.push_back((uint8_t)p); pq.push_back((uint8_t)q); }
-
-  if (int rc = stream_get(device, &h->stream)) return rc;
-  RigDev& d = h->d;
-  d.F = F; d.N = N; d.NG = NG; d.C = (int32_t)C; d.S = S; d.SW = S + 1; d.NP = S * (S + 1) / 2;
-  d.pc_b = d.NP; d.pc_hd = d.NP + S; d.pc_fail = d.NP + 2 * S; d.pc_gs = d.pc_fail + 1; d.pc_gmax = d.pc_gs + S; d.PC = d.pc_gmax + 1;
-  d.nblk = (int)std::min<int64_t>(kRigMaxElimBlocks, F);
-  d.huber_a = (K && !(huber_a > 0.0)) ? 1e300 : huber_a;   // extension: a <= 0 switches the loss off
-  d.comm = 0; d.rank = 0; d.nranks = 1;
-  d.K = K; d.S6 = (int32_t)(6 * C); d.gstride = K ? 768 : 256; d.kmask = 0;
   h->frozen.assign((size_t)C, 0);
   if (cam_frozen) for (int64_t c = 0; c < C; ++c) h->frozen[(size_t)c] = cam_frozen[c] ? 1 : 0;
   h->seen = seen;
-  if (d.PC > 256 * kRigOwn) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: too many cameras");
+
+  if (int rc = stream_get(device, &h->stream)) return rc;
+  RigDev& d = h->d;
+  d.F = F; d.N = N; d.NG = NG;
+  d.huber_a = (kmode && !(huber_a > 0.0)) ? 1e300 : huber_a;   // extension: a <= 0 switches the loss off
+  d.comm = 0; d.rank = 0; d.nranks = 1;
+  d.kmode = kmode; d.gstride = kmode ? 768 : 256;
   { const float* p; if (int rc = dev_upload(h, &p, uv)) return rc; d.uv = p; }
   if (int rc = dev_upload(h, &d.widx, widx)) return rc;
   {
@@ -1330,62 +1656,38 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   if (int rc = dev_upload(h, &d.goff, goff)) return rc;
   if (int rc = dev_upload(h, &d.gframe, gframe)) return rc;
   if (int rc = dev_upload(h, &d.gcam, gcam)) return rc;
-  if (int rc = dev_upload(h, &d.fgoff, fgoff)) return rc;
+  if (int rc = dev_upload(h, &d.fgoff, h->fgoff_h)) return rc;
   if (int rc = dev_upload(h, &d.cam_goff, cam_goff)) return rc;
   if (int rc = dev_upload(h, &d.cam_glist, cam_glist)) return rc;
-  if (int rc = dev_upload(h, &d.cam_fixed, fixed)) return rc;
-  h->d_cam_fixed = const_cast<uint8_t*>(d.cam_fixed);
-  if (int rc = dev_upload(h, &d.pair_p, pp)) return rc;
-  if (int rc = dev_upload(h, &d.pair_q, pq)) return rc;
-  if (int rc = dev_alloc(h, &d.cam, (size_t)2 * C * 8)) return rc;
-  if (int rc = dev_alloc(h, &d.pose, (size_t)2 * F * 8)) return rc;
-  if (int rc = dev_alloc(h, &d.camrec, (size_t)C * 32)) return rc;
-  if (int rc = dev_alloc(h, &d.frec, (size_t)F * 32)) return rc;
+  if (int rc = rig_layout(h, seen)) return rc;
+  const size_t CKn = (size_t)std::max(d.CK, 1);
+  if (int rc = dev_zeroed(h, &d.cam, (size_t)2 * C * 8)) return rc;
+  if (int rc = dev_zeroed(h, &d.pose, (size_t)2 * F * 8)) return rc;
+  if (int rc = dev_zeroed(h, &d.camrec, (size_t)C * 32)) return rc;
+  if (int rc = dev_zeroed(h, &d.frec, (size_t)F * 32)) return rc;
   if (int rc = dev_alloc(h, &d.gblocks, (size_t)2 * NG * d.gstride)) return rc;
-  if (int rc = dev_alloc(h, &d.intr, (size_t)32)) return rc;
-  if (int rc = dev_alloc(h, &d.krec, (size_t)32)) return rc;
-  if (int rc = dev_alloc(h, &d.ghdk, (size_t)(K ? NG * 16 : 16))) return rc;
-  if (int rc = dev_alloc(h, &h->init_intr, (size_t)16)) return rc;
-  CC_HIP(hipMemset(d.intr, 0, 32 * sizeof(double)));
-  CC_HIP(hipMemset(d.krec, 0, 32 * sizeof(double)));
-  CC_HIP(hipMemset(d.ghdk, 0, (size_t)(K ? NG * 16 : 16) * sizeof(double)));
-  CC_HIP(hipMemset(h->init_intr, 0, 16 * sizeof(double)));
-  if (int rc = dev_alloc(h, &d.gstats, (size_t)NG * 2)) return rc;
-  if (int rc = dev_alloc(h, &d.fstats, (size_t)F * 2)) return rc;
-  if (int rc = dev_alloc(h, &d.ghd0, (size_t)NG * 8)) return rc;
-  if (int rc = dev_alloc(h, &d.sp, (size_t)F * 8)) return rc;
-  if (int rc = dev_alloc(h, &d.ss, (size_t)64)) return rc;
-  if (int rc = dev_alloc(h, &d.ds, (size_t)64)) return rc;
-  if (int rc = dev_alloc(h, &d.Y, (size_t)F * 6 * d.SW)) return rc;
-  if (int rc = dev_alloc(h, &d.partial, (size_t)d.nblk * d.PC)) return rc;
-  if (int rc = dev_alloc(h, &d.vec, (size_t)d.PC + 32)) return rc;
-  if (int rc = dev_alloc(h, &d.vec_stats, (size_t)4 + kRigMaxS)) return rc;
-  if (int rc = dev_alloc(h, &d.shared_stats, (size_t)4)) return rc;
-  if (int rc = dev_alloc(h, &d.ctl, (size_t)1)) return rc;
-  if (int rc = dev_alloc(h, &d.ctl_next, (size_t)1)) return rc;
+  if (int rc = dev_zeroed(h, &d.intr, 2 * CKn * 16)) return rc;
+  if (int rc = dev_zeroed(h, &d.krec, CKn * 32)) return rc;
+  if (int rc = dev_zeroed(h, &d.ghdk, (size_t)(kmode ? NG * 16 : 16))) return rc;
+  if (int rc = dev_zeroed(h, &h->init_intr, CKn * 16)) return rc;
+  if (int rc = dev_zeroed(h, &h->d_kmask, CKn)) return rc;
+  d.kmask = h->d_kmask;
+  if (int rc = dev_zeroed(h, &d.gstats, (size_t)NG * 2)) return rc;
+  if (int rc = dev_zeroed(h, &d.fstats, (size_t)F * 2)) return rc;
+  if (int rc = dev_zeroed(h, &d.ghd0, (size_t)NG * 8)) return rc;
+  if (int rc = dev_zeroed(h, &d.sp, (size_t)F * 8)) return rc;
+  if (int rc = dev_zeroed(h, &d.ss, (size_t)128)) return rc;
+  if (int rc = dev_zeroed(h, &d.ds, (size_t)128)) return rc;
+  if (int rc = dev_zeroed(h, &d.shared_stats, (size_t)4)) return rc;
+  if (int rc = dev_zeroed(h, &d.ctl, (size_t)1)) return rc;
+  if (int rc = dev_zeroed(h, &d.ctl_next, (size_t)1)) return rc;
+  if (int rc = dev_zeroed(h, &d.arrive, (size_t)16)) return rc;
   if (int rc = dev_alloc(h, &d.opts, (size_t)1)) return rc;
   d.log_cap = 4096;
   if (int rc = dev_alloc(h, &d.log, (size_t)d.log_cap)) return rc;
   if (int rc = dev_alloc(h, &h->init_cam, (size_t)C * 8)) return rc;
   if (int rc = dev_alloc(h, &h->init_pose, (size_t)F * 8)) return rc;
   if (int rc = dev_alloc(h, &h->d_cost, (size_t)N)) return rc;
-  CC_HIP(hipMemset(d.cam, 0, (size_t)2 * C * 8 * sizeof(double)));
-  CC_HIP(hipMemset(d.pose, 0, (size_t)2 * F * 8 * sizeof(double)));
-  CC_HIP(hipMemset(d.sp, 0, (size_t)F * 8 * sizeof(double)));
-  CC_HIP(hipMemset(d.ss, 0, 64 * sizeof(double)));
-  CC_HIP(hipMemset(d.ds, 0, 64 * sizeof(double)));
-  CC_HIP(hipMemset(d.Y, 0, (size_t)F * 6 * d.SW * sizeof(double)));
-  CC_HIP(hipMemset(d.gstats, 0, (size_t)NG * 2 * sizeof(double)));
-  CC_HIP(hipMemset(d.fstats, 0, (size_t)F * 2 * sizeof(double)));
-  CC_HIP(hipMemset(d.ghd0, 0, (size_t)NG * 8 * sizeof(double)));
-  CC_HIP(hipMemset(d.frec, 0, (size_t)F * 32 * sizeof(double)));
-  CC_HIP(hipMemset(d.camrec, 0, (size_t)C * 32 * sizeof(double)));
-  CC_HIP(hipMemset(d.partial, 0, (size_t)d.nblk * d.PC * sizeof(double)));
-  CC_HIP(hipMemset(d.vec, 0, ((size_t)d.PC + 32) * sizeof(double)));
-  CC_HIP(hipMemset(d.vec_stats, 0, ((size_t)4 + kRigMaxS) * sizeof(double)));
-  CC_HIP(hipMemset(d.shared_stats, 0, 4 * sizeof(double)));
-  CC_HIP(hipMemset(d.ctl, 0, sizeof(LmCtl)));
-  CC_HIP(hipMemset(d.ctl_next, 0, sizeof(LmCtl)));
   h->h_ctl = reinterpret_cast<LmCtl*>(pinned_block_get());
   if (!h->h_ctl) return fail(CC_ERR_HIP, "hipHostMalloc failed");
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_sweep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kRigSweepLdsBytes));
@@ -1398,7 +1700,7 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
 int cc_rig_create(int32_t device, int64_t C, int64_t F, int64_t n_world, const int64_t* off,
                   const uint32_t* obs_cam, const uint64_t* obs_world, const float* obs_uv,
                   const float* world_xyz, const uint8_t* cam_frozen, double huber_a, cc_rig** out) {
-  return rig_create_impl(device, C, F, n_world, off, obs_cam, obs_world, obs_uv, world_xyz, cam_frozen, huber_a, 0, out);
+  return rig_create_impl(device, C, F, n_world, off, obs_cam, obs_world, obs_uv, world_xyz, cam_frozen, huber_a, cc::RIG_K_NONE, out);
 }
 
 // EXTENSION: the same handle with 9 intrinsics shared by all cameras; obs_uv in pixels
@@ -1406,47 +1708,74 @@ int cc_rigk_create(int32_t device, int64_t C, int64_t F, int64_t n_world, const 
                    const uint32_t* obs_cam, const uint64_t* obs_world, const float* obs_uv_pixels,
                    const float* world_xyz, const uint8_t* cam_frozen, double huber_a, cc_rig** out) {
   return rig_create_impl(device, C, F, n_world, off, obs_cam, obs_world, obs_uv_pixels, world_xyz, cam_frozen, huber_a,
-                         cc::kRigK, out);
+                         cc::RIG_K_SHARED, out);
 }
 
-int cc_rigk_set_intrinsics(cc_rig* h, const double* intr9, uint32_t const_mask) {
+// EXTENSION: one set of 9 intrinsics PER CAMERA (BASELINE.json configs[4]: "full intrinsics+extrinsics co-optimisation")
+int cc_rigk_create_per_camera(int32_t device, int64_t C, int64_t F, int64_t n_world, const int64_t* off,
+                              const uint32_t* obs_cam, const uint64_t* obs_world, const float* obs_uv_pixels,
+                              const float* world_xyz, const uint8_t* cam_frozen, double huber_a, cc_rig** out) {
+  return rig_create_impl(device, C, F, n_world, off, obs_cam, obs_world, obs_uv_pixels, world_xyz, cam_frozen, huber_a,
+                         cc::RIG_K_PER_CAMERA, out);
+}
+
+// camera < 0: every set (the one shared set, or all per-camera sets)
+static int rigk_set(cc_rig* h, int64_t camera, const double* intr9, uint32_t const_mask) {
   using namespace cc;
   if (!h || !intr9) return fail(CC_ERR_BAD_ARGUMENT, "cc_rigk_set_intrinsics: NULL argument");
-  if (!h->d.K) return fail(CC_ERR_STATE, "cc_rigk_set_intrinsics: the handle was created without intrinsics (cc_rig_create)");
+  if (!h->d.kmode) return fail(CC_ERR_STATE, "cc_rigk_set_intrinsics: the handle was created without intrinsics (cc_rig_create)");
+  const int CK = h->d.CK;
+  if (camera >= 0 && (h->d.kmode != RIG_K_PER_CAMERA || camera >= CK))
+    return fail(CC_ERR_BAD_ARGUMENT, "cc_rigk_set_camera_intrinsics: needs a per-camera handle and a camera id below %d", CK);
   CC_HIP(hipSetDevice(h->device));
   CC_HIP(hipStreamSynchronize(h->stream));
   double k16[16] = {0};
   for (int i = 0; i < 9; ++i) k16[i] = intr9[i];
-  CC_HIP(hipMemcpy(h->init_intr, k16, sizeof(k16), hipMemcpyHostToDevice));
-  if (h->d.kmask != (const_mask & 0x1ffu)) rig_drop_graphs(h);   // the mask is a kernel argument
-  h->d.kmask = const_mask & 0x1ffu;
+  const uint32_t m = const_mask & 0x1ffu;
+  for (int s = 0; s < CK; ++s) {
+    if (camera >= 0 && s != camera) continue;
+    CC_HIP(hipMemcpy(h->init_intr + (size_t)s * 16, k16, sizeof(k16), hipMemcpyHostToDevice));
+    CC_HIP(hipMemcpy(h->d_kmask + s, &m, sizeof(m), hipMemcpyHostToDevice));
+  }
   h->have_intr = true;
   return h->have_state ? cc_rig_reset(h) : CC_OK;
 }
 
-int cc_rigk_get_intrinsics(cc_rig* h, double* intr9) {
+int cc_rigk_set_intrinsics(cc_rig* h, const double* intr9, uint32_t const_mask) { return rigk_set(h, -1, intr9, const_mask); }
+int cc_rigk_set_camera_intrinsics(cc_rig* h, int64_t camera, const double* intr9, uint32_t const_mask) {
+  if (camera < 0) return cc::fail(CC_ERR_BAD_ARGUMENT, "cc_rigk_set_camera_intrinsics: negative camera id");
+  return rigk_set(h, camera, intr9, const_mask);
+}
+
+int cc_rigk_get_camera_intrinsics(cc_rig* h, int64_t camera, double* intr9) {
   using namespace cc;
   if (!h || !intr9) return fail(CC_ERR_BAD_ARGUMENT, "cc_rigk_get_intrinsics: NULL argument");
-  if (!h->d.K) return fail(CC_ERR_STATE, "cc_rigk_get_intrinsics: the handle was created without intrinsics");
+  if (!h->d.kmode) return fail(CC_ERR_STATE, "cc_rigk_get_intrinsics: the handle was created without intrinsics");
+  const int64_t s = h->d.kmode == RIG_K_SHARED ? 0 : camera;
+  if (s < 0 || s >= h->d.CK) return fail(CC_ERR_BAD_ARGUMENT, "cc_rigk_get_camera_intrinsics: camera id out of range");
   CC_HIP(hipSetDevice(h->device));
   LmCtl c;
   if (int rc = rig_read_ctl(h, &c)) return rc;
   double k16[16];
-  CC_HIP(hipMemcpy(k16, h->d.intr + (size_t)(c.cur & 1) * 16, sizeof(k16), hipMemcpyDeviceToHost));
+  CC_HIP(hipMemcpy(k16, h->d.intr + ((size_t)(c.cur & 1) * h->d.CK + (size_t)s) * 16, sizeof(k16), hipMemcpyDeviceToHost));
   for (int i = 0; i < 9; ++i) intr9[i] = k16[i];
   return CC_OK;
 }
+int cc_rigk_get_intrinsics(cc_rig* h, double* intr9) { return cc_rigk_get_camera_intrinsics(h, 0, intr9); }
 
 void cc_rig_destroy(cc_rig* h) {
   if (!h) return;
   hipSetDevice(h->device);
-  if (h->stream) hipStreamSynchronize(h->stream);
+  bool stream_ok = true;
+  if (h->stream) stream_ok = hipStreamSynchronize(h->stream) == hipSuccess;
   cc::rig_drop_graphs(h);
+  for (auto e : h->events) hipEventDestroy(e);
   if (h->comm) cc::comm_destroy(h->comm);
   cc::mailbox_release(&h->mailbox);
   for (void* p : h->allocs) hipFree(p);
   cc::pinned_block_put(h->h_ctl);
-  cc::stream_put(h->device, h->stream);   // synchronised above
+  if (stream_ok) cc::stream_put(h->device, h->stream);   // idle and reusable
+  else if (h->stream) hipStreamDestroy(h->stream);      // never hand a failed stream to the next handle
   delete h;
 }
 
@@ -1478,20 +1807,47 @@ int cc_rig_reset(cc_rig* h) {
   if (int rc = rig_write_ctl(h, c)) return rc;
   CC_HIP(hipMemcpyAsync(h->d.cam, h->init_cam, (size_t)h->C * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   CC_HIP(hipMemcpyAsync(h->d.pose, h->init_pose, (size_t)h->F * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-  if (h->d.K) CC_HIP(hipMemcpyAsync(h->d.intr, h->init_intr, 16 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  if (h->d.kmode) CC_HIP(hipMemcpyAsync(h->d.intr, h->init_intr, (size_t)h->d.CK * 16 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   return CC_OK;
 }
+
+}  // extern "C"
+
+namespace cc {
+// Captures the head of a solve (optional) and `rounds` rounds into an executable graph; on any failure the
+// stream is taken out of capture mode again and nothing is kept.
+static int rig_capture(cc_rig* h, bool first_chunk, int rounds, hipGraphExec_t* out) {
+  hipGraph_t g = nullptr;
+  CC_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+  int rc = 0;
+  if (first_chunk) rig_enqueue_prep(h);
+  for (int i = 0; i < rounds && !rc; ++i) rc = rig_enqueue_round(h, first_chunk && i == 0, false);
+  const hipError_t e_end = hipStreamEndCapture(h->stream, &g);
+  if (rc || e_end != hipSuccess) {
+    if (g) hipGraphDestroy(g);
+    (void)hipGetLastError();
+    return rc ? rc : fail(CC_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e_end));
+  }
+  const hipError_t e_inst = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
+  hipGraphDestroy(g);
+  if (e_inst != hipSuccess) { *out = nullptr; return fail(CC_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e_inst)); }
+  return 0;
+}
+}  // namespace cc
+
+extern "C" {
 
 int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
   using namespace cc;
   if (!h || !h->have_state) return fail(CC_ERR_STATE, "cc_rig_solve: no state set");
-  if (h->d.K && !h->have_intr) return fail(CC_ERR_STATE, "cc_rig_solve: cc_rigk_set_intrinsics has not been called");
+  if (h->d.kmode && !h->have_intr) return fail(CC_ERR_STATE, "cc_rig_solve: cc_rigk_set_intrinsics has not been called");
   const auto t0 = std::chrono::steady_clock::now();
   cc_options o;
   if (opt) o = *opt; else { cc_options_init(&o); o.max_iterations = 1000; }  // extrinsics_calibrator.cpp:211
   if (o.check_interval < 1) o.check_interval = 1;
   if (o.max_iterations > h->d.log_cap - 1) o.max_iterations = h->d.log_cap - 1;
-  const bool use_graph = o.use_graph != 0 && !h->comm;
+  const bool profile = o.profile_kernels != 0;
+  const bool use_graph = o.use_graph != 0 && !h->comm && !profile;
   CC_HIP(hipSetDevice(h->device));
   {
     LmCtl st;
@@ -1499,36 +1855,32 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
     if (st.cur & 1) {
       CC_HIP(hipMemcpyAsync(h->d.cam, h->d.cam + (size_t)h->C * 8, (size_t)h->C * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
       CC_HIP(hipMemcpyAsync(h->d.pose, h->d.pose + (size_t)h->F * 8, (size_t)h->F * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-      if (h->d.K) CC_HIP(hipMemcpyAsync(h->d.intr, h->d.intr + 16, 16 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+      if (h->d.kmode) CC_HIP(hipMemcpyAsync(h->d.intr, h->d.intr + (size_t)h->d.CK * 16, (size_t)h->d.CK * 16 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     }
     LmOpts lo;
     opts_from_public(o, &lo);
     CC_HIP(hipMemcpyAsync(h->d.opts, &lo, sizeof(lo), hipMemcpyHostToDevice, h->stream));
     LmCtl c{};
     if (int rc = rig_write_ctl(h, c)) return rc;
+    CC_HIP(hipMemsetAsync(h->d.arrive, 0, sizeof(unsigned), h->stream));
   }
-  if (use_graph && (!h->graph[0] || h->graph_iters != o.check_interval)) {
-    rig_drop_graphs(h);
-    for (int gi = 0; gi < 2; ++gi) {
-      hipGraph_t g = nullptr;
-      CC_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-      const int n = o.check_interval + (gi == 0 ? 1 : 0);
-      for (int i = 0; i < n; ++i) rig_enqueue_round(h, gi == 0 && i == 0);
-      CC_HIP(hipStreamEndCapture(h->stream, &g));
-      CC_HIP(hipGraphInstantiate(&h->graph[gi], g, nullptr, nullptr, 0));
-      hipGraphDestroy(g);
-    }
-    h->graph_iters = o.check_interval;
-  }
+  for (auto e : h->events) hipEventDestroy(e);
+  h->events.clear();
+  h->event_kind.clear();
+  if (use_graph && h->graph_iters != o.check_interval) { rig_drop_graphs(h); h->graph_iters = o.check_interval; }
   int launched = 0;
   LmCtl st;
   for (int chunk = 0;; ++chunk) {
     const int n = o.check_interval + (chunk == 0 ? 1 : 0);
     if (use_graph) {
-      CC_HIP(hipGraphLaunch(h->graph[chunk == 0 ? 0 : 1], h->stream));
+      const int which = chunk == 0 ? 0 : 1;
+      if (!h->graph[which])
+        if (int rc = rig_capture(h, which == 0, n, &h->graph[which])) { rig_drop_graphs(h); return rc; }
+      CC_HIP(hipGraphLaunch(h->graph[which], h->stream));
     } else {
+      if (chunk == 0) rig_enqueue_prep(h);
       for (int i = 0; i < n; ++i)
-        if (int rc = rig_enqueue_round(h, chunk == 0 && i == 0)) return rc;
+        if (int rc = rig_enqueue_round(h, chunk == 0 && i == 0, profile)) return rc;
       CC_HIP(hipGetLastError());
     }
     launched += n;
@@ -1552,8 +1904,20 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
     summary->log_len = n;
     if (n > 0) CC_HIP(hipMemcpy(user_log, h->d.log, (size_t)n * sizeof(cc_iteration), hipMemcpyDeviceToHost));
     for (int i = 0; i < CC_K_COUNT; ++i) { summary->kernel_ms[i] = 0.0; summary->kernel_launches[i] = 0; }
+    if (profile) {
+      for (size_t i = 0; i < h->event_kind.size(); ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->events[2 * i], h->events[2 * i + 1]) == hipSuccess) {
+          summary->kernel_ms[h->event_kind[i]] += ms;
+          summary->kernel_launches[h->event_kind[i]]++;
+        }
+      }
+    }
     summary->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
+  for (auto e : h->events) hipEventDestroy(e);
+  h->events.clear();
+  h->event_kind.clear();
   return CC_OK;
 }
 
@@ -1594,7 +1958,7 @@ int cc_rig_get_state(cc_rig* h, double* cam_q, double* cam_t, double* frame_q, d
 int cc_rig_eval(cc_rig* h, double* cost) {
   using namespace cc;
   if (!h || !h->have_state || !cost) return fail(CC_ERR_STATE, "cc_rig_eval: no state set");
-  if (h->d.K && !h->have_intr) return fail(CC_ERR_STATE, "cc_rig_eval: cc_rigk_set_intrinsics has not been called");
+  if (h->d.kmode && !h->have_intr) return fail(CC_ERR_STATE, "cc_rig_eval: cc_rigk_set_intrinsics has not been called");
   std::vector<double> oc((size_t)h->N);
   if (int rc = cc_rig_get_state(h, nullptr, nullptr, nullptr, nullptr, oc.data())) return rc;
   double c = 0.0;
@@ -1602,6 +1966,22 @@ int cc_rig_eval(cc_rig* h, double* cost) {
   *cost = c;
   return CC_OK;
 }
+
+}  // extern "C"
+
+namespace cc {
+// multi-GPU attach, common part: the column layout must be the same on every rank, so it is rebuilt for the
+// cameras that ANY rank observes (flags[c] > 0) when that differs from what this rank built at create time
+static int rig_adopt_global_cameras(cc_rig* h, const std::vector<double>& flags) {
+  std::vector<uint8_t> any((size_t)h->C);
+  for (int64_t c = 0; c < h->C; ++c) any[(size_t)c] = flags[(size_t)c] > 0.0 ? 1 : 0;
+  if (any == h->seen_any) return 0;
+  CC_HIP(hipStreamSynchronize(h->stream));
+  return rig_layout(h, any);
+}
+}  // namespace cc
+
+extern "C" {
 
 int cc_rig_comm_init(cc_rig* h, const uint8_t id[128], int32_t rank, int32_t nranks) {
   using namespace cc;
@@ -1613,16 +1993,18 @@ int cc_rig_comm_init(cc_rig* h, const uint8_t id[128], int32_t rank, int32_t nra
   if (int rc = comm_create(id, rank, nranks, &h->comm)) return rc;
   h->d.comm = 1; h->d.rank = rank; h->d.nranks = nranks;
   // a camera is part of the problem if ANY rank observes it: sum the per-rank "seen" flags
-  std::vector<double> flags((size_t)4 + kRigMaxS, 0.0);
+  std::vector<double> flags((size_t)h->C, 0.0);
   for (int64_t c = 0; c < h->C; ++c) flags[(size_t)c] = h->seen[(size_t)c] ? 1.0 : 0.0;
-  CC_HIP(hipMemcpyAsync(h->d.vec_stats, flags.data(), flags.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  if (int rc = comm_allreduce_sum(h->comm, h->d.vec_stats, (int)h->C, h->stream)) return rc;
-  CC_HIP(hipMemcpyAsync(flags.data(), h->d.vec_stats, flags.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  CC_HIP(hipStreamSynchronize(h->stream));
-  std::vector<uint8_t> fixed((size_t)h->C);
-  for (int64_t c = 0; c < h->C; ++c) fixed[(size_t)c] = (h->frozen[(size_t)c] || !(flags[(size_t)c] > 0.0)) ? 1 : 0;
-  CC_HIP(hipMemcpy(h->d_cam_fixed, fixed.data(), fixed.size(), hipMemcpyHostToDevice));
-  return CC_OK;
+  double* d_flags = nullptr;
+  CC_HIP(hipMalloc(&d_flags, flags.size() * sizeof(double)));
+  hipError_t e1 = hipMemcpyAsync(d_flags, flags.data(), flags.size() * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  int rc = e1 == hipSuccess ? comm_allreduce_sum(h->comm, d_flags, (int)h->C, h->stream) : 0;
+  hipError_t e2 = hipMemcpyAsync(flags.data(), d_flags, flags.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  hipError_t e3 = hipStreamSynchronize(h->stream);
+  hipFree(d_flags);
+  CC_HIP(e1); CC_HIP(e2); CC_HIP(e3);
+  if (rc) return rc;
+  return rig_adopt_global_cameras(h, flags);
 }
 
 int cc_rig_exchange_export(cc_rig* h, uint8_t handle[64]) {
@@ -1634,7 +2016,9 @@ int cc_rig_exchange_export(cc_rig* h, uint8_t handle[64]) {
   mailbox_release(&h->mailbox);
   h->d.x = P2pDev{};
   h->exchange = false;
-  return mailbox_export(&h->mailbox, h->d.PC + 32, 4 + kRigMaxS, handle);
+  int k0 = 0, k1 = 0;
+  rig_exchange_bounds(h, &k0, &k1);
+  return mailbox_export(&h->mailbox, k0, k1, handle);
 }
 
 // collective: every rank must call it (the "camera seen" flags are summed through the mailboxes)
@@ -1644,32 +2028,30 @@ int cc_rig_exchange_attach(cc_rig* h, int32_t rank, int32_t nranks, const uint8_
     return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_exchange_attach: bad arguments (nranks must be 1..%d)", kP2pMaxRanks);
   if (!h->mailbox.local) return fail(CC_ERR_STATE, "cc_rig_exchange_attach: call cc_rig_exchange_export first");
   if (h->comm) return fail(CC_ERR_STATE, "cc_rig_exchange_attach: an RCCL communicator is already attached");
+  if (h->C > 128) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_exchange_attach: at most 128 cameras with the mailbox exchange");
   CC_HIP(hipSetDevice(h->device));
   rig_drop_graphs(h);
   if (int rc = mailbox_attach(&h->mailbox, rank, nranks, handles, &h->d.x)) return rc;
   h->d.comm = 1; h->d.rank = rank; h->d.nranks = nranks;
   h->exchange = true;
   // a camera is part of the problem if ANY rank observes it: sum the per-rank "seen" flags
-  std::vector<double> flags(64, 0.0);
+  std::vector<double> flags(128, 0.0);
   for (int64_t c = 0; c < h->C; ++c) flags[(size_t)c] = h->seen[(size_t)c] ? 1.0 : 0.0;
   double* d_io = nullptr;
   int* d_ok = nullptr;
-  CC_HIP(hipMalloc(&d_io, 128 * sizeof(double)));
+  CC_HIP(hipMalloc(&d_io, 256 * sizeof(double)));
   CC_HIP(hipMalloc(&d_ok, sizeof(int)));
-  CC_HIP(hipMemcpyAsync(d_io, flags.data(), 64 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_rig_flag_exchange, dim3(1), dim3(64), 0, h->stream, h->d, d_io, d_io + 64, (int)h->C, d_ok);
+  CC_HIP(hipMemcpyAsync(d_io, flags.data(), 128 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_rig_flag_exchange, dim3(1), dim3(128), 0, h->stream, h->d, d_io, d_io + 128, (int)h->C, d_ok);
   int ok = 0;
-  hipError_t e1 = hipMemcpyAsync(flags.data(), d_io + 64, 64 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  hipError_t e1 = hipMemcpyAsync(flags.data(), d_io + 128, 128 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
   hipError_t e2 = hipMemcpyAsync(&ok, d_ok, sizeof(int), hipMemcpyDeviceToHost, h->stream);
   hipError_t e3 = hipStreamSynchronize(h->stream);
   hipFree(d_io);
   hipFree(d_ok);
   CC_HIP(e1); CC_HIP(e2); CC_HIP(e3);
   if (!ok) return fail(CC_ERR_COMM, "cc_rig_exchange_attach: a peer rank did not attach within 10 s");
-  std::vector<uint8_t> fixed((size_t)h->C);
-  for (int64_t c = 0; c < h->C; ++c) fixed[(size_t)c] = (h->frozen[(size_t)c] || !(flags[(size_t)c] > 0.0)) ? 1 : 0;
-  CC_HIP(hipMemcpy(h->d_cam_fixed, fixed.data(), fixed.size(), hipMemcpyHostToDevice));
-  return CC_OK;
+  return rig_adopt_global_cameras(h, flags);
 }
 
 // Debug/test aid (not declared in the public header): copies a named device buffer to the host.
@@ -1685,6 +2067,7 @@ int cc_rig_debug_fetch(cc_rig* h, const char* name, double* out, int64_t n) {
   else if (k == "Y") src = d.Y; else if (k == "partial") src = d.partial; else if (k == "gblocks") src = d.gblocks;
   else if (k == "camrec") src = d.camrec; else if (k == "frec") src = d.frec; else if (k == "gstats") src = d.gstats;
   else if (k == "fstats") src = d.fstats; else if (k == "shared_stats") src = d.shared_stats; else if (k == "cam") src = d.cam; else if (k == "pose") src = d.pose;
+  else if (k == "vec") src = d.vec;
   else return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_debug_fetch: unknown buffer %s", name);
   CC_HIP(hipMemcpy(out, src, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
   return CC_OK;

@@ -80,7 +80,7 @@ typedef struct cc_iteration {
   int32_t valid;
 } cc_iteration;
 
-enum { CC_K_SWEEP = 0, CC_K_DECIDE = 1, CC_K_ELIM = 2, CC_K_SOLVE = 3, CC_K_ALLREDUCE = 4, CC_K_COUNT = 8 };
+enum { CC_K_SWEEP = 0, CC_K_DECIDE = 1, CC_K_ELIM = 2, CC_K_SOLVE = 3, CC_K_ALLREDUCE = 4, CC_K_UPDATE = 5, CC_K_REDUCE = 6, CC_K_COUNT = 8 };
 
 typedef struct cc_summary {
   int32_t iterations;        /* LM iterations executed (accepted + rejected + invalid) */
@@ -176,7 +176,8 @@ int cc_partition_frames(int64_t n_frames, const int64_t* frame_offsets, int32_t 
  * Observations are grouped by frame: frame f owns [obs_frame_offsets[f], obs_frame_offsets[f+1]).
  * obs_world indexes world_xyz (3 floats per point). cam_frozen[c] != 0 keeps camera c constant;
  * cameras / frames without observations are left untouched (they never enter the problem).
- * n_cams <= 10.
+ * Any number of cameras: only cameras that are observed and not frozen own columns of the reduced system
+ * (6 each, at most 127 in all, i.e. 21 optimised cameras; at most 64 observed cameras).
  * ------------------------------------------------------------------------------------------- */
 typedef struct cc_rig cc_rig;
 
@@ -210,8 +211,9 @@ int cc_rig_exchange_attach(cc_rig* h, int32_t rank, int32_t nranks, const uint8_
  * the rig problem with 9 intrinsics (fx fy px py k1 k2 p1 p2 k3, calibrator.cpp:168-179) shared by all
  * cameras and co-optimised with the poses. Observations are PIXELS: the residual is the composition of
  * ReprojectionErrorExtrinsics (extrinsics_calibrator.cpp:51-84) and DistortNormalized/DistortPixels
- * (calibrator.cpp:70-95). huber_a is in pixels, <= 0 switches the loss off. At most 8 cameras. Multi-GPU
- * through cc_rig_exchange_* / cc_rig_comm_init like the plain rig problem (intrinsics replicated).
+ * (calibrator.cpp:70-95). huber_a is in pixels, <= 0 switches the loss off. 6 columns per optimised camera + 9
+ * must stay <= 127 and at most 11 cameras may be observed. Multi-GPU through cc_rig_exchange_* /
+ * cc_rig_comm_init like the plain rig problem (intrinsics replicated).
  * The handle is a cc_rig: set_state / reset / solve / get_state / eval / destroy are the cc_rig_* calls;
  * cc_rigk_set_intrinsics must be called once before the first solve (const_mask bit i freezes intrinsic i). */
 int cc_rigk_create(int32_t device, int64_t n_cams, int64_t n_frames, int64_t n_world,
@@ -220,6 +222,16 @@ int cc_rigk_create(int32_t device, int64_t n_cams, int64_t n_frames, int64_t n_w
                    double huber_a, cc_rig** out);
 int cc_rigk_set_intrinsics(cc_rig* h, const double* intr9, uint32_t const_mask);
 int cc_rigk_get_intrinsics(cc_rig* h, double* intr9);
+/* Same extension with one set of 9 intrinsics PER CAMERA (BASELINE.json configs[4]: "full intrinsics+extrinsics
+ * co-optimisation"): shared block = 6 per optimised camera + 9 per observed camera (<= 127: eight cameras).
+ * cc_rigk_set_intrinsics sets every camera's set at once, cc_rigk_set_camera_intrinsics one camera's (with its own
+ * constant mask, cf. Calibrator::ForceDistortionToConstant); cc_rigk_get_camera_intrinsics reads one set. */
+int cc_rigk_create_per_camera(int32_t device, int64_t n_cams, int64_t n_frames, int64_t n_world,
+                              const int64_t* obs_frame_offsets, const uint32_t* obs_cam, const uint64_t* obs_world,
+                              const float* obs_uv_pixels, const float* world_xyz, const uint8_t* cam_frozen,
+                              double huber_a, cc_rig** out);
+int cc_rigk_set_camera_intrinsics(cc_rig* h, int64_t camera, const double* intr9, uint32_t const_mask);
+int cc_rigk_get_camera_intrinsics(cc_rig* h, int64_t camera, double* intr9);
 
 /* One-shot: the call ExtrinsicsCalibrator::Optimize makes in place of
  * extrinsics_calibrator.cpp:92-225. opt == NULL -> cc_options_init with max_iterations = 1000. */

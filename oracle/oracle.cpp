@@ -721,9 +721,13 @@ struct RigProblem : ArrowProblem {
   }
 };
 
-// EXTENSION: rig poses + 9 shared intrinsics. Shared tangent = [cam 0 (6) ... cam C-1 (6) | k (9)],
-// ambient = [cam (7 each) | k (9)]; pixel observations; Huber on the pixel residual (a <= 0: off).
+// EXTENSION: rig poses + intrinsics, either 9 shared by all cameras (NK = 1) or 9 per camera (NK = C).
+// Shared tangent = [cam 0 (6) ... cam C-1 (6) | k set 0 (9) ... k set NK-1 (9)], ambient = [cam (7 each) | k sets];
+// pixel observations; Huber on the pixel residual (a <= 0: off).
 struct RigKProblem : ArrowProblem {
+  int64_t NK = 1;                   // intrinsics sets
+  std::vector<uint32_t> kmasks;     // NK: bit i = intrinsic i of the set is held constant
+  int64_t kset(uint32_t cam) const { return NK == 1 ? 0 : (int64_t)cam; }
   int64_t C;
   const int64_t* off;
   const uint32_t* ocam;
@@ -731,14 +735,12 @@ struct RigKProblem : ArrowProblem {
   const float* ouv;
   const float* wxyz;
   double huber_a;
-  uint32_t kmask;
   std::vector<uint8_t> cam_fixed;
   double* obs_cost = nullptr;
 
   double eval(const double* shared, const double* fq, const double* ft, Blocks* B) override {
     const int Sd = S;
     const int K0 = (int)(6 * C);
-    const double* kk = shared + 7 * C;
     const int nt = std::max(1, num_threads);
     std::vector<double> Rc(C * 9);
     for (int64_t c = 0; c < C; ++c) quat_to_R(&shared[c * 7], &Rc[c * 9]);
@@ -755,6 +757,9 @@ struct RigKProblem : ArrowProblem {
           const float* Xf = &wxyz[oworld[o] * 3];
           const double X[3] = {Xf[0], Xf[1], Xf[2]};
           double res[2], J[2][21];
+          const int64_t ks = kset(cam);
+          const double* kk = shared + 7 * C + 9 * ks;
+          const uint32_t kmask = kmasks[(size_t)ks];
           rigk_eval(kk, Rf, &ft[f * 3], &Rc[cam * 9], &shared[cam * 7 + 4], X, ouv[o * 2], ouv[o * 2 + 1], res,
                     B ? J : nullptr);
           double rho = res[0] * res[0] + res[1] * res[1], sr = 1.0;
@@ -769,7 +774,7 @@ struct RigKProblem : ArrowProblem {
             double vs[15], vf[6];
             int col[15];
             for (int i = 0; i < 6; ++i) { vs[i] = fixed ? 0.0 : sr * J[r][i]; col[i] = (int)cam * 6 + i; vf[i] = sr * J[r][6 + i]; }
-            for (int i = 0; i < 9; ++i) { vs[6 + i] = (kmask & (1u << i)) ? 0.0 : sr * J[r][12 + i]; col[6 + i] = K0 + i; }
+            for (int i = 0; i < 9; ++i) { vs[6 + i] = (kmask & (1u << i)) ? 0.0 : sr * J[r][12 + i]; col[6 + i] = K0 + (int)(9 * ks) + i; }
             const double rr = sr * res[r];
             for (int i = 0; i < 6; ++i) {
               for (int j = 0; j < 6; ++j) B->Hpp[f * 36 + i * 6 + j] += vf[i] * vf[j];
@@ -804,8 +809,9 @@ struct RigKProblem : ArrowProblem {
       quat_plus(&shared[c * 7], &delta[c * 6], &out[c * 7]);
       for (int i = 0; i < 3; ++i) out[c * 7 + 4 + i] = shared[c * 7 + 4 + i] + delta[c * 6 + 3 + i];
     }
-    for (int i = 0; i < 9; ++i)
-      out[7 * C + i] = shared[7 * C + i] + ((kmask & (1u << i)) ? 0.0 : delta[6 * C + i]);
+    for (int64_t ks = 0; ks < NK; ++ks)
+      for (int i = 0; i < 9; ++i)
+        out[7 * C + 9 * ks + i] = shared[7 * C + 9 * ks + i] + ((shared_fixed[6 * C + 9 * ks + i]) ? 0.0 : delta[6 * C + 9 * ks + i]);
   }
 };
 
@@ -1125,48 +1131,68 @@ void oc_rigk_residual(const double* k, const double* q_rw, const double* t_rw, c
   rigk_eval(k, Rf, t_rw, Rc, t_cr, X, uv[0], uv[1], res, reinterpret_cast<double(*)[21]>(J));
 }
 
-int oc_rigk_solve(const oc_options* opt, int64_t C, int64_t F, int64_t n_world, const int64_t* off,
-                  const uint32_t* ocam, const uint64_t* oworld, const float* ouv, const float* wxyz,
-                  double* intr, uint32_t kmask, double* cam_q, double* cam_t, const uint8_t* cam_frozen,
-                  double* frame_q, double* frame_t, double huber_a, double* obs_cost, oc_summary* summary) {
+// per_camera == 0: intr[9], kmask[1] (one set shared by all cameras); != 0: intr[C][9], kmask[C]. A set that no
+// observation uses is not part of the problem (its coordinates stay put and do not count in |x|).
+int oc_rigk_solve_sets(const oc_options* opt, int64_t C, int64_t F, int64_t n_world, const int64_t* off,
+                       const uint32_t* ocam, const uint64_t* oworld, const float* ouv, const float* wxyz,
+                       int32_t per_camera, double* intr, const uint32_t* kmask, double* cam_q, double* cam_t,
+                       const uint8_t* cam_frozen, double* frame_q, double* frame_t, double huber_a, double* obs_cost,
+                       oc_summary* summary) {
   (void)n_world;
   oc_options o;
   if (opt) o = *opt; else { oc_options_init(&o); o.max_iterations = 1000; }
   RigKProblem P;
-  P.C = C; P.F = F; P.S = (int)(6 * C + 9); P.S_amb = (int)(7 * C + 9);
+  const int64_t NK = per_camera ? C : 1;
+  P.NK = NK;
+  P.C = C; P.F = F; P.S = (int)(6 * C + 9 * NK); P.S_amb = (int)(7 * C + 9 * NK);
   P.off = off; P.ocam = ocam; P.oworld = oworld; P.ouv = ouv; P.wxyz = wxyz;
-  P.huber_a = huber_a; P.kmask = kmask;
+  P.huber_a = huber_a;
+  P.kmasks.assign(kmask, kmask + NK);
   P.num_threads = o.num_threads;
   std::vector<uint8_t> cam_seen(C, 0);
   P.frame_active.assign(F, 0);
   for (int64_t f = 0; f < F; ++f)
     for (int64_t k = off[f]; k < off[f + 1]; ++k) { cam_seen[ocam[k]] = 1; P.frame_active[f] = 1; }
   P.cam_fixed.resize(C);
-  P.shared_fixed.assign(6 * C + 9, 0);
-  P.shared_amb_active.assign(7 * C + 9, 1);
+  P.shared_fixed.assign(P.S, 0);
+  P.shared_amb_active.assign(P.S_amb, 1);
   for (int64_t c = 0; c < C; ++c) {
     P.cam_fixed[c] = (cam_frozen && cam_frozen[c]) || !cam_seen[c];
     for (int i = 0; i < 6; ++i) P.shared_fixed[c * 6 + i] = P.cam_fixed[c];
     for (int i = 0; i < 7; ++i) P.shared_amb_active[c * 7 + i] = !P.cam_fixed[c];
   }
-  for (int i = 0; i < 9; ++i) P.shared_fixed[6 * C + i] = (kmask >> i) & 1;
-  std::vector<double> shared(7 * C + 9);
+  for (int64_t ks = 0; ks < NK; ++ks) {
+    const bool used = per_camera ? cam_seen[ks] != 0 : true;
+    for (int i = 0; i < 9; ++i) {
+      P.shared_fixed[6 * C + 9 * ks + i] = !used || ((kmask[ks] >> i) & 1);
+      P.shared_amb_active[7 * C + 9 * ks + i] = used;
+    }
+  }
+  std::vector<double> shared(P.S_amb);
   for (int64_t c = 0; c < C; ++c) {
     for (int i = 0; i < 4; ++i) shared[c * 7 + i] = cam_q[c * 4 + i];
     for (int i = 0; i < 3; ++i) shared[c * 7 + 4 + i] = cam_t[c * 3 + i];
   }
-  for (int i = 0; i < 9; ++i) shared[7 * C + i] = intr[i];
+  for (int64_t i = 0; i < 9 * NK; ++i) shared[7 * C + i] = intr[i];
   const int rc = run_lm(P, o, shared.data(), frame_q, frame_t, summary, nullptr, nullptr);
   for (int64_t c = 0; c < C; ++c) {
     for (int i = 0; i < 4; ++i) cam_q[c * 4 + i] = shared[c * 7 + i];
     for (int i = 0; i < 3; ++i) cam_t[c * 3 + i] = shared[c * 7 + 4 + i];
   }
-  for (int i = 0; i < 9; ++i) intr[i] = shared[7 * C + i];
+  for (int64_t i = 0; i < 9 * NK; ++i) intr[i] = shared[7 * C + i];
   if (obs_cost) {
     P.obs_cost = obs_cost;
     P.eval(shared.data(), frame_q, frame_t, nullptr);
   }
   return rc;
+}
+
+int oc_rigk_solve(const oc_options* opt, int64_t C, int64_t F, int64_t n_world, const int64_t* off,
+                  const uint32_t* ocam, const uint64_t* oworld, const float* ouv, const float* wxyz,
+                  double* intr, uint32_t kmask, double* cam_q, double* cam_t, const uint8_t* cam_frozen,
+                  double* frame_q, double* frame_t, double huber_a, double* obs_cost, oc_summary* summary) {
+  return oc_rigk_solve_sets(opt, C, F, n_world, off, ocam, oworld, ouv, wxyz, 0, intr, &kmask, cam_q, cam_t, cam_frozen,
+                            frame_q, frame_t, huber_a, obs_cost, summary);
 }
 
 // ---- Zhang initialisation ----------------------------------------------------------------

@@ -146,6 +146,13 @@ int oc_rigk_solve(const oc_options* opt, int64_t n_cams, int64_t n_frames, int64
                   const float* obs_uv_pixels, const float* world_xyz, double* intr9, uint32_t kmask,
                   double* cam_q, double* cam_t, const uint8_t* cam_frozen, double* frame_q, double* frame_t,
                   double huber_a, double* obs_cost, oc_summary* summary);
+/* per_camera == 0: as oc_rigk_solve (intr[9], kmask[1]); != 0: one set of intrinsics per camera (intr[n_cams][9],
+ * kmask[n_cams]); a set no observation uses is not part of the problem. */
+int oc_rigk_solve_sets(const oc_options* opt, int64_t n_cams, int64_t n_frames, int64_t n_world,
+                       const int64_t* obs_frame_offsets, const uint32_t* obs_cam, const uint64_t* obs_world,
+                       const float* obs_uv_pixels, const float* world_xyz, int32_t per_camera, double* intr,
+                       const uint32_t* kmask, double* cam_q, double* cam_t, const uint8_t* cam_frozen,
+                       double* frame_q, double* frame_t, double huber_a, double* obs_cost, oc_summary* summary);
 
 /* ---- Zhang initialisation (src/geometry.cpp:70-203, src/calibrator.cpp:47-68) ---- */
 void oc_estimate_homography(int64_t n, const float* p1, int32_t stride1, const float* p2,

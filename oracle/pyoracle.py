@@ -216,6 +216,35 @@ def rigk_solve(n_cams, frame_offsets, obs_cam, obs_world, obs_uv_pixels, world_x
     return intr, cam_q, cam_t, frame_q, frame_t, cost, summary_to_dict(s, log)
 
 
+def rigk_solve_per_camera(n_cams, frame_offsets, obs_cam, obs_world, obs_uv_pixels, world_xyz, intr, cam_q, cam_t,
+                          cam_frozen, frame_q, frame_t, const_masks=None, huber_a=0.0, options=None, log_capacity=2048):
+    """EXTENSION: rig poses + one set of 9 intrinsics per camera (intr: [n_cams, 9], const_masks: [n_cams]).
+    Returns (intr [n_cams, 9], cam_q, cam_t, frame_q, frame_t, obs_cost, summary)."""
+    offs = np.ascontiguousarray(frame_offsets, dtype=np.int64)
+    F = len(offs) - 1
+    obs_cam = np.ascontiguousarray(obs_cam, dtype=np.uint32)
+    obs_world = np.ascontiguousarray(obs_world, dtype=np.uint64)
+    obs_uv, world_xyz = _f32(obs_uv_pixels), _f32(world_xyz)
+    intr = _f64(intr).reshape(n_cams, 9).copy()
+    masks = np.zeros(n_cams, dtype=np.uint32) if const_masks is None else np.ascontiguousarray(const_masks, dtype=np.uint32)
+    cam_q, cam_t = _f64(cam_q).copy(), _f64(cam_t).copy()
+    frame_q, frame_t = _f64(frame_q).copy(), _f64(frame_t).copy()
+    frozen = np.ascontiguousarray(cam_frozen, dtype=np.uint8)
+    opt = options if options is not None else default_options(max_iterations=1000)
+    s, log = _summary(log_capacity)
+    cost = np.zeros(len(obs_cam))
+    n_world = C.c_int64(len(world_xyz) // 3 if world_xyz.ndim == 1 else world_xyz.shape[0])
+    rc = lib().oc_rigk_solve_sets(C.byref(opt), C.c_int64(n_cams), C.c_int64(F), n_world, _p(offs, C.c_int64),
+                                  _p(obs_cam, C.c_uint32), _p(obs_world, C.c_uint64), _p(obs_uv, C.c_float),
+                                  _p(world_xyz, C.c_float), C.c_int32(1), _p(intr, C.c_double), _p(masks, C.c_uint32),
+                                  _p(cam_q, C.c_double), _p(cam_t, C.c_double), _p(frozen, C.c_uint8),
+                                  _p(frame_q, C.c_double), _p(frame_t, C.c_double), C.c_double(huber_a),
+                                  _p(cost, C.c_double), C.byref(s))
+    if rc != 0:
+        raise RuntimeError(f"oc_rigk_solve_sets failed: {rc}")
+    return intr, cam_q, cam_t, frame_q, frame_t, cost, summary_to_dict(s, log)
+
+
 def intrinsics_blocks(offsets, uv, xyz, intr, q, t, const_mask=0, want_blocks=True, num_threads=1):
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
     F = len(offsets) - 1

@@ -45,13 +45,15 @@ def _quat_to_R(q):
                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
 
 
-def rigk_case(cams, frames, pts, seed=0, pixel_noise=0.5):
+def rigk_case(cams, frames, pts, seed=0, pixel_noise=0.5, per_camera=False):
     """EXTENSION scenario: a rig of `cams` cameras (camera 0 = rig frame, frozen; the others
     offset by U(-0.03, 0.03) in x, y as in test_extrinsics_calibrator.cpp:60-69) watching, in every frame, `pts`
     world points of a +-0.2 cube from 0.6-1.2 m, every camera seeing every point; pixel observations through the
     fixture camera of test_calibrator.cpp:14-19 with U(-noise, noise) px. Initial state: cameras off by 5 mm /
     0.1 deg, frames by 20 mm / 1 deg (the magnitudes of test_extrinsics_calibrator.cpp:53-58), focal lengths
-    2 % off, principal point 5 px off, no distortion."""
+    2 % off, principal point 5 px off, no distortion.
+    per_camera=True: every camera has a camera of its own (focal lengths and principal point a few per cent /
+    pixels apart, distortion scaled), returned as intr_true [cams, 9]; intr0 is then [cams, 9] too."""
     rng = np.random.default_rng(seed)
     ident = np.array([1.0, 0, 0, 0])
 
@@ -72,7 +74,12 @@ def rigk_case(cams, frames, pts, seed=0, pixel_noise=0.5):
     frame_q0, frame_t0 = np.zeros((frames, 4)), np.zeros((frames, 3))
     world = np.zeros((frames * pts, 3), dtype=np.float32)
     obs_cam, obs_world, obs_uv = [], [], []
-    k = RIGK_INTR_TRUE
+    k_all = np.tile(RIGK_INTR_TRUE, (cams, 1))
+    if per_camera:
+        krng = np.random.default_rng(seed + 12345)   # its own stream: the rest of the scenario does not change
+        k_all[:, :2] *= 1 + krng.uniform(-0.03, 0.03, size=(cams, 2))
+        k_all[:, 2:4] += krng.uniform(-15, 15, size=(cams, 2))
+        k_all[:, 4:] *= krng.uniform(0.7, 1.3, size=(cams, 1))
     for f in range(frames):
         frame_q[f] = quat_plus(ident, small_rot(15.0))
         frame_t[f] = [rng.uniform(-0.1, 0.1), rng.uniform(-0.1, 0.1), rng.uniform(0.6, 1.2)]
@@ -83,6 +90,7 @@ def rigk_case(cams, frames, pts, seed=0, pixel_noise=0.5):
         world[f * pts:(f + 1) * pts] = (X + rng.uniform(-0.001, 0.001, size=(pts, 3))).astype(np.float32)
         Xr = X @ Rf.T + frame_t[f]
         for c in range(cams):
+            k = k_all[c]
             Xc = Xr @ _quat_to_R(cam_q[c]).T + cam_t[c]
             x, y = Xc[:, 0] / Xc[:, 2], Xc[:, 1] / Xc[:, 2]
             r2 = x * x + y * y
@@ -103,4 +111,6 @@ def rigk_case(cams, frames, pts, seed=0, pixel_noise=0.5):
                 obs_world=np.ascontiguousarray(ow), obs_uv_pix=np.ascontiguousarray(ou), world_xyz=world, cam_frozen=frozen,
                 cam_q_true=cam_q, cam_t_true=cam_t, frame_q_true=frame_q, frame_t_true=frame_t,
                 cam_q0=cam_q0, cam_t0=cam_t0, frame_q0=frame_q0, frame_t0=frame_t0,
-                intr0=np.array([1020.0, 980.0, 805.0, 495.0, 0, 0, 0, 0, 0], dtype=np.float64))
+                intr0=(np.tile(np.array([1020.0, 980.0, 805.0, 495.0, 0, 0, 0, 0, 0]), (cams, 1)) if per_camera
+                       else np.array([1020.0, 980.0, 805.0, 495.0, 0, 0, 0, 0, 0], dtype=np.float64)),
+                intr_true=k_all if per_camera else RIGK_INTR_TRUE)

@@ -87,6 +87,6 @@ def test_rig_malformed_arguments_are_refused():
     w_bad[0] = len(sc["world_xyz"])          # world point index out of range
     with pytest.raises(capi.CcError):
         capi.RigProblem(2, sc["frame_offsets"], sc["obs_cam"], w_bad, sc["obs_uv"], sc["world_xyz"], sc["cam_frozen"])
-    with pytest.raises(capi.CcError):
-        capi.RigProblem(11, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"], sc["world_xyz"],
-                        np.zeros(11, np.uint8))   # more cameras than the rig kernels are built for
+    # any number of cameras is fine as long as few enough are optimised (only observed, non-frozen ones own columns)
+    capi.RigProblem(11, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"], sc["world_xyz"],
+                    np.zeros(11, np.uint8)).close()

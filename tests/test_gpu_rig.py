@@ -158,3 +158,54 @@ def test_rig_c5_full_size_against_the_committed_oracle_result_and_properties():
     prob.close()
     assert s2["iterations"] <= 2 and s2["final_cost"] <= s1["final_cost"] * (1 + 1e-9)
     assert np.abs(r2[1] - r1[1]).max() < 1e-6
+
+
+def test_rig_many_cameras_only_optimised_ones_cost_columns():
+    """The reference takes any number of cameras (extrinsics_calibrator.cpp:9-17). Here only observed, non-frozen
+    cameras own columns: 16 observed cameras solve (90 shared coordinates), and so does the state the reference's
+    own test leaves behind -- Serialize -> Parse into the same object doubles the cameras (Parse does not clear
+    them, extrinsics_calibrator.cpp:348-351): ids C..2C-1 are unobserved duplicates, the copy of camera 0 frozen."""
+    sc = po.rig_scenario(16, 30, 12)
+    g, o = _both(sc, 16)
+    _assert_same(g, o)
+    sc = po.rig_scenario(6, 40, 10)
+    cq, ct, fq, ft = _inputs(sc)
+    cq2, ct2 = np.concatenate([cq, cq]), np.concatenate([ct, ct])
+    frozen2 = np.concatenate([sc["cam_frozen"], sc["cam_frozen"]])
+    args = (12, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"], sc["world_xyz"], cq2, ct2, frozen2, fq, ft)
+    g = capi.rig_optimize(*args, options=capi.default_options(max_iterations=1000))
+    o = po.rig_solve(*args, options=po.default_options(max_iterations=1000))
+    _assert_same(g, o)
+    assert np.array_equal(g[0][6:], cq) and np.array_equal(g[1][6:], ct)            # the duplicates never move
+    g6, _ = _both(sc, 6)
+    assert np.abs(g[1][:6] - g6[1]).max() < 1e-12 and g[5]["iterations"] == g6[5]["iterations"]
+    # 200 idle cameras around two live ones
+    sc = po.rig_scenario(2, 25, 8)
+    cq, ct, fq, ft = _inputs(sc)
+    pad_q, pad_t = np.tile([1.0, 0, 0, 0], (200, 1)), np.zeros((200, 3))
+    args = (202, sc["frame_offsets"], sc["obs_cam"] * np.uint32(201), sc["obs_world"], sc["obs_uv"], sc["world_xyz"],
+            np.concatenate([cq[:1], pad_q, cq[1:]]), np.concatenate([ct[:1], pad_t, ct[1:]]),
+            np.concatenate([[1], np.zeros(201, dtype=np.uint8)]).astype(np.uint8), fq, ft)
+    g = capi.rig_optimize(*args, options=capi.default_options(max_iterations=1000))
+    o = po.rig_solve(*args, options=po.default_options(max_iterations=1000))
+    _assert_same(g, o)
+
+
+def test_rig_too_many_optimised_cameras_is_an_error_not_a_wrong_answer():
+    sc = po.rig_scenario(23, 4, 3)     # 22 optimised cameras = 132 shared coordinates > 127
+    with pytest.raises(capi.CcError, match="at most 127"):
+        capi.RigProblem(23, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"], sc["world_xyz"], sc["cam_frozen"])
+
+
+def test_rig_kernel_profile_of_a_solve():
+    sc = po.rig_scenario(3, 40, 20)
+    cq, ct, fq, ft = _inputs(sc)
+    prob = capi.RigProblem(3, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"], sc["world_xyz"], sc["cam_frozen"])
+    prob.set_state(cq, ct, fq, ft)
+    s0 = prob.solve()
+    prob.reset()
+    s1 = prob.solve(capi.default_options(max_iterations=1000, profile_kernels=1))
+    prob.close()
+    assert s1["iterations"] == s0["iterations"] and s1["final_cost"] == s0["final_cost"]
+    # (launches of a chunk that follow the terminating iteration return at once but are still counted)
+    assert s1["kernel_launches"]["sweep"] >= s1["iterations"] + 1 and s1["kernel_ms"]["sweep"] > 0 and s1["kernel_ms"]["elim"] > 0

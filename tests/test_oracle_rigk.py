@@ -111,3 +111,49 @@ def test_minimiser_agrees_with_scipy_least_squares():
     sol = least_squares(fun, x0, method="lm", xtol=1e-15, ftol=1e-15, gtol=1e-15)
     assert np.isclose(0.5 * np.sum(sol.fun ** 2), r[6]["final_cost"], rtol=1e-9)       # already at the minimum
     assert np.abs(sol.x[:4] - r[0][:4]).max() < 1e-5 * 1000 and np.abs(sol.x[4:]).max() < 1e-6
+
+
+# ---- one set of intrinsics per camera (oc_rigk_solve_sets, per_camera = 1) ----
+
+def _solve_pc(k, **kw):
+    return po.rigk_solve_per_camera(k["cams"], k["frame_offsets"], k["obs_cam"], k["obs_world"], k["obs_uv_pix"], k["world_xyz"],
+                                    k["intr0"], k["cam_q0"], k["cam_t0"], k["cam_frozen"], k["frame_q0"], k["frame_t0"], **kw)
+
+
+def test_per_camera_intrinsics_recover_each_planted_camera():
+    k = rigk_case(3, 150, 40, per_camera=True)
+    r = _solve_pc(k, options=po.default_options(max_iterations=300))
+    assert r[6]["termination"] in ("FUNCTION", "PARAMETER", "GRADIENT") and r[6]["final_cost"] < 1e-2 * r[6]["initial_cost"]
+    assert r[0].shape == (3, 9)
+    assert np.abs(r[0][:, :2] / k["intr_true"][:, :2] - 1).max() < 5e-3
+    assert np.abs(r[0][:, 2:4] - k["intr_true"][:, 2:4]).max() < 5.0
+    # the cameras really differ, and the solver told them apart
+    assert np.abs(r[0][0, :2] - r[0][1, :2]).max() > 5.0
+    assert np.array_equal(r[1][0], k["cam_q0"][0]) and np.array_equal(r[2][0], k["cam_t0"][0])   # frozen pose, free intrinsics
+    assert np.isclose(r[5].sum(), r[6]["final_cost"], rtol=1e-10)
+
+
+def test_per_camera_problem_with_one_camera_is_the_shared_problem():
+    k = rigk_case(1, 40, 20)
+    a = _solve(k)
+    kp = dict(k, intr0=k["intr0"][None, :])
+    b = _solve_pc(kp)
+    assert a[6]["iterations"] == b[6]["iterations"] and np.allclose([l["cost"] for l in a[6]["log"]], [l["cost"] for l in b[6]["log"]], rtol=1e-13)
+    assert np.allclose(a[0], b[0][0], rtol=1e-12, atol=1e-14)
+
+
+def test_per_camera_masks_and_unused_sets():
+    k = rigk_case(3, 40, 25, per_camera=True)
+    masks = np.array([(1 << 8) | (1 << 5), 0, 1 << 8], dtype=np.uint32)
+    r = _solve_pc(k, const_masks=masks)
+    assert r[0][0, 8] == k["intr0"][0, 8] and r[0][0, 5] == k["intr0"][0, 5] and r[0][2, 8] == k["intr0"][2, 8]
+    assert r[0][1, 8] != k["intr0"][1, 8]
+    # a camera without observations: its pose and its intrinsics stay put and the others do not notice
+    keep = k["obs_cam"] != 2
+    offs = np.concatenate([[0], np.cumsum([keep[k["frame_offsets"][f]:k["frame_offsets"][f + 1]].sum() for f in range(40)])])
+    k2 = dict(k, frame_offsets=offs.astype(np.int64), obs_cam=k["obs_cam"][keep], obs_world=k["obs_world"][keep], obs_uv_pix=k["obs_uv_pix"][keep])
+    r2 = _solve_pc(k2)
+    assert np.array_equal(r2[0][2], k["intr0"][2]) and np.array_equal(r2[1][2], k["cam_q0"][2])
+    k3 = dict(k2, cams=2, intr0=k["intr0"][:2], cam_q0=k["cam_q0"][:2], cam_t0=k["cam_t0"][:2], cam_frozen=k["cam_frozen"][:2])
+    r3 = _solve_pc(k3)
+    assert np.allclose(r2[0][:2], r3[0], rtol=1e-12) and r2[6]["iterations"] == r3[6]["iterations"]
