@@ -11,8 +11,13 @@ converges is followed by another one from the same initial state until exactly K
 The per-solve initial Jacobian sweep and host polls are inside the timed region and are NOT
 counted as steps (conservative).
 
-For N>1 every rank owns 1000 frames x 500 points (weak scaling): the global problem has N*1000
-frames sharing one set of intrinsics; ranks all-reduce (RCCL) 2 x 64 doubles per LM iteration.
+For N>1 `value` is WEAK scaling: every rank owns 1000 frames x 500 points of one joint problem with N*1000
+frames sharing one set of intrinsics; per LM iteration the ranks exchange 112 + 16 doubles (mailboxes in peer
+HBM over xGMI, RCCL as the fallback).  The same line also carries `strong_scaling`: BASELINE.json configs[2]
+exactly as written, the FIXED 1000 x 500 problem split N ways.
+
+At N=1 the line additionally carries `configs` (BASELINE.json configs[3], configs[4]: the rig path at full
+size, poses only = the reference's problem, and with the shared-intrinsics extension) and `cpu_baseline`.
 """
 import argparse
 import json
@@ -30,6 +35,7 @@ PTS_PER_FRAME = 500
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # MI355X fp64 vector = matrix peak (AMD datasheet)
 FLOP_PER_OBS = 800.0       # ~0.8 kflop fp64 per observation and Jacobian sweep
+RIG_FLOP_PER_OBS = 750.0   # estimate in the same spirit: ~200 (two poses, projection, 2x12 Jacobian, Huber) + 544 (Gram)
 
 
 def algorithmic_bytes_sweep(n_obs, n_frames):
@@ -37,14 +43,25 @@ def algorithmic_bytes_sweep(n_obs, n_frames):
     return 20.0 * n_obs + 704.0 * n_frames
 
 
-def load_traffic():
-    """HBM bytes per sweep launch from the committed PMC profile (profiles/), or None."""
+def algorithmic_bytes_rig_sweep(n_obs, n_world, n_frames, n_cams):
+    # SURVEY.md 8(d), rig Jacobian sweep: 13 B per observation, 12 B per world point, per frame the pose (56 B) and
+    # the block outputs (6x6 symmetric 21 + gradient 6 + 6x6 coupling per non-reference camera) doubles:
+    # C4 8.1 MB, C5 120.6 MB
+    return 13.0 * n_obs + 12.0 * n_world + n_frames * (56.0 + 8.0 * (27.0 + 36.0 * (n_cams - 1)))
+
+
+def load_traffic(frames, points):
+    """HBM bytes per sweep launch from the committed PMC profile -- only when this run has the profiled shape."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get("sweep_hbm_bytes_per_launch")
+            t = json.load(f)
+        shape = t.get("shape", {})
+        if shape.get("frames") == frames and shape.get("points_per_frame") == points:
+            return t.get("sweep_hbm_bytes_per_launch")
     except Exception:
-        return None
+        pass
+    return None
 
 
 def usable_cores():
@@ -64,10 +81,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU")
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU (weak scaling)")
     ap.add_argument("--points", type=int, default=PTS_PER_FRAME)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the rig configurations (configs[3], configs[4])")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -94,111 +112,141 @@ def main():
 
     from camera_calibrator_amd import capi
 
-    # ---- synthetic input: the product's DataGenerator harness (include/cc_harness.h, the reference's
-    # data_generator.cpp without OpenCV) with the test_calibrator.cpp fixture constants; initial state
-    # from the device Zhang initialisation (cc_zhang_init = Calibrator::Estimate before Optimize)
-    F_total = args.frames * world
-    off, uv, xyz = capi.make_intrinsics_problem(F_total, args.points)
-    K0, q0, t0 = capi.zhang_init(off, uv, xyz, device=local_rank)
-    if dist is not None:   # every rank must start from the same bits: take rank 0's initial state
-        init = [(K0, q0, t0) if rank == 0 else None]
-        dist.broadcast_object_list(init, src=0)
-        K0, q0, t0 = init[0]
-    intr0 = np.array([K0[0, 0], K0[1, 1], K0[0, 2], K0[1, 2], 0, 0, 0, 0, 0], dtype=np.float64)
-    q0 = q0.astype(np.float64)
-    t0 = t0.astype(np.float64)
-    first = capi.partition_frames(off, world)
-    f0, f1 = int(first[rank]), int(first[rank + 1])
-    o0, o1 = int(off[f0]), int(off[f1])
-    my_off = off[f0:f1 + 1] - off[f0]
-    def make_problem():
-        p = capi.IntrinsicsProblem(my_off, uv[o0:o1], xyz[o0:o1], device=local_rank)
-        p.set_state(intr0, q0[f0:f1], t0[f0:f1])
-        return p
-
     def all_ok(flag):
         flags = [None] * world
         dist.all_gather_object(flags, bool(flag))
         return all(flags)
 
-    prob = make_problem()
-    exchange = "none"
-    if world > 1:
-        # The two per-iteration reductions are <= 1 KB: within a node they go through mailboxes in peer
-        # HBM (cc_intrinsics_exchange_*, stores over xGMI, graph-captured); RCCL all-reduce is the
-        # fallback (and the only choice beyond 8 ranks). CC_EXCHANGE=mailbox|rccl forces one.
-        want = os.environ.get("CC_EXCHANGE", "auto")
-        if want in ("auto", "mailbox") and world <= 8:
-            try:
-                mine = (True, prob.exchange_export())
-            except capi.CcError as e:
-                mine = (False, str(e).encode())
-            gathered = [None] * world
-            dist.all_gather_object(gathered, mine)
-            ok = all(g[0] for g in gathered)
-            if ok:
-                try:
-                    prob.exchange_attach(rank, [g[1] for g in gathered])
-                except capi.CcError as e:
-                    ok = False
-                    print(f"[bench rank {rank}] mailbox attach failed: {e}", file=sys.stderr)
-            ok = all_ok(ok)
-            if ok:
-                try:  # one complete solve proves that every peer's posts arrive ...
-                    prob.reset()
-                    chk = prob.solve(capi.default_options(), log_capacity=0)
-                    intr_chk, _, _ = prob.get_state()
-                    local_cost, _ = prob.eval(want_blocks=False)
-                except capi.CcError as e:
-                    ok = False
-                    chk, intr_chk, local_cost = None, None, float("nan")
-                    print(f"[bench rank {rank}] mailbox exchange failed: {e}", file=sys.stderr)
-                ok = all_ok(ok)
-                if ok:  # ... and that the exchanged sums are right: same bits everywhere, cost = sum of shards
-                    parts = [None] * world
-                    dist.all_gather_object(parts, (intr_chk.tobytes(), chk["final_cost"], local_cost))
-                    same = all(p[0] == parts[0][0] and p[1] == parts[0][1] for p in parts)
-                    total = sum(p[2] for p in parts)
-                    ok = same and abs(total - chk["final_cost"]) <= 1e-9 * abs(total)
-                    if not ok and rank == 0:
-                        print(f"[bench] mailbox exchange gave inconsistent results (same={same}, "
-                              f"sum of shard costs {total!r} vs {chk['final_cost']!r})", file=sys.stderr)
-            if ok:
-                exchange = "mailbox"
-            elif want == "mailbox":
-                raise SystemExit("CC_EXCHANGE=mailbox but the mailbox exchange is not usable here")
-            else:
-                dist.barrier()
-                prob.close()
-                prob = make_problem()
-        if exchange == "none":
-            uid = [capi.comm_get_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            prob.comm_init(uid[0], rank, world)
-            exchange = "rccl"
-
-    n_obs_total = int(off[-1])
-    opts = capi.default_options()
-
-    def run_steps(k):
-        """Run exactly k LM iterations as consecutive complete solves; returns per-solve stats."""
-        done, solves, last = 0, 0, None
-        while done < k:
-            prob.reset()
-            remaining = k - done
-            o = opts if remaining >= opts.max_iterations else capi.default_options(max_iterations=remaining)
-            s = prob.solve(o, log_capacity=0)
-            if s["iterations"] <= 0:
-                raise RuntimeError(f"solve made no progress: {s}")
-            done += s["iterations"]
-            solves += 1
-            last = s
-        return solves, last
-
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    opts = capi.default_options()
+
+    class Leg:
+        """One sharded intrinsics problem of F_total frames: this rank's handle, attached to its peers."""
+
+        def __init__(self, F_total):
+            # synthetic input: the product's DataGenerator harness (include/cc_harness.h, the reference's
+            # data_generator.cpp without OpenCV) with the test_calibrator.cpp fixture constants; initial state from
+            # the device Zhang initialisation (cc_zhang_init = Calibrator::Estimate before Optimize)
+            self.F_total = F_total
+            self.off, self.uv, self.xyz = capi.make_intrinsics_problem(F_total, args.points)
+            K0, q0, t0 = capi.zhang_init(self.off, self.uv, self.xyz, device=local_rank)
+            if dist is not None:   # every rank must start from the same bits: take rank 0's initial state
+                init = [(K0, q0, t0) if rank == 0 else None]
+                dist.broadcast_object_list(init, src=0)
+                K0, q0, t0 = init[0]
+            self.intr0 = np.array([K0[0, 0], K0[1, 1], K0[0, 2], K0[1, 2], 0, 0, 0, 0, 0], dtype=np.float64)
+            self.q0, self.t0 = q0.astype(np.float64), t0.astype(np.float64)
+            first = capi.partition_frames(self.off, world)
+            self.f0, self.f1 = int(first[rank]), int(first[rank + 1])
+            self.o0, self.o1 = int(self.off[self.f0]), int(self.off[self.f1])
+            self.my_off = self.off[self.f0:self.f1 + 1] - self.off[self.f0]
+            self.n_obs_total = int(self.off[-1])
+            self.prob = self._make()
+            self.exchange = "none"
+            if world > 1:
+                self._attach()
+
+        def _make(self):
+            p = capi.IntrinsicsProblem(self.my_off, self.uv[self.o0:self.o1], self.xyz[self.o0:self.o1], device=local_rank)
+            p.set_state(self.intr0, self.q0[self.f0:self.f1], self.t0[self.f0:self.f1])
+            return p
+
+        def _attach(self):
+            # The two per-iteration reductions are <= 1 KB: within a node they go through mailboxes in peer HBM
+            # (cc_intrinsics_exchange_*, stores over xGMI, graph-captured); RCCL all-reduce is the fallback (and the
+            # only choice beyond 8 ranks). CC_EXCHANGE=mailbox|rccl forces one.
+            prob = self.prob
+            want = os.environ.get("CC_EXCHANGE", "auto")
+            if want in ("auto", "mailbox") and world <= 8:
+                try:
+                    mine = (True, prob.exchange_export())
+                except capi.CcError as e:
+                    mine = (False, str(e).encode())
+                gathered = [None] * world
+                dist.all_gather_object(gathered, mine)
+                ok = all(g[0] for g in gathered)
+                if ok:
+                    try:
+                        prob.exchange_attach(rank, [g[1] for g in gathered])
+                    except capi.CcError as e:
+                        ok = False
+                        print(f"[bench rank {rank}] mailbox attach failed: {e}", file=sys.stderr)
+                ok = all_ok(ok)
+                if ok:
+                    try:  # one complete solve proves that every peer's posts arrive ...
+                        prob.reset()
+                        chk = prob.solve(capi.default_options(), log_capacity=0)
+                        intr_chk, _, _ = prob.get_state()
+                        local_cost, _ = prob.eval(want_blocks=False)
+                    except capi.CcError as e:
+                        ok = False
+                        chk, intr_chk, local_cost = None, None, float("nan")
+                        print(f"[bench rank {rank}] mailbox exchange failed: {e}", file=sys.stderr)
+                    ok = all_ok(ok)
+                    if ok:  # ... and that the exchanged sums are right: same bits everywhere, cost = sum of shards
+                        parts = [None] * world
+                        dist.all_gather_object(parts, (intr_chk.tobytes(), chk["final_cost"], local_cost))
+                        same = all(p[0] == parts[0][0] and p[1] == parts[0][1] for p in parts)
+                        total = sum(p[2] for p in parts)
+                        ok = same and abs(total - chk["final_cost"]) <= 1e-9 * abs(total)
+                        if not ok and rank == 0:
+                            print(f"[bench] mailbox exchange gave inconsistent results (same={same}, "
+                                  f"sum of shard costs {total!r} vs {chk['final_cost']!r})", file=sys.stderr)
+                if ok:
+                    self.exchange = "mailbox"
+                elif want == "mailbox":
+                    raise SystemExit("CC_EXCHANGE=mailbox but the mailbox exchange is not usable here")
+                else:
+                    dist.barrier()
+                    prob.close()
+                    self.prob = prob = self._make()
+            if self.exchange == "none":
+                uid = [capi.comm_get_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                prob.comm_init(uid[0], rank, world)
+                self.exchange = "rccl"
+
+        def run_steps(self, k):
+            """Run exactly k LM iterations as consecutive complete solves; returns (solves, last summary)."""
+            done, solves, last = 0, 0, None
+            while done < k:
+                self.prob.reset()
+                remaining = k - done
+                o = opts if remaining >= opts.max_iterations else capi.default_options(max_iterations=remaining)
+                s = self.prob.solve(o, log_capacity=0)
+                if s["iterations"] <= 0:
+                    raise RuntimeError(f"solve made no progress: {s}")
+                done += s["iterations"]
+                solves += 1
+                last = s
+            return solves, last
+
+        def timed(self, steps, warmup):
+            self.run_steps(warmup)
+            barrier()
+            t_start = time.perf_counter()
+            solves, _ = self.run_steps(steps)
+            barrier()
+            elapsed = time.perf_counter() - t_start
+            if dist is not None:
+                tt = torch.tensor([elapsed], dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                elapsed = float(tt.item())
+            return elapsed, solves
+
+        def close(self):
+            if dist is not None:
+                dist.barrier()          # no rank frees a mailbox / communicator a peer may still use
+            self.prob.close()
+            if dist is not None:
+                dist.barrier()
+
+    leg = Leg(args.frames * world)
+    prob = leg.prob
 
     # outside the timed region: one complete solve for reporting time-to-converge (the solve before it
     # pays for the one-off graph capture)
@@ -214,21 +262,22 @@ def main():
     # i.e. allocation + host->device upload of this rank's observations + solve + read-back
     e2e_ms = None
     if world == 1:
-        capi.intrinsics_optimize(my_off, uv[o0:o1], xyz[o0:o1], intr0, q0[f0:f1], t0[f0:f1], options=opts, log_capacity=0)
+        one_shot = lambda: capi.intrinsics_optimize(leg.my_off, leg.uv, leg.xyz, leg.intr0, leg.q0, leg.t0, options=opts, log_capacity=0)
+        one_shot()
         t_e = time.perf_counter()
-        capi.intrinsics_optimize(my_off, uv[o0:o1], xyz[o0:o1], intr0, q0[f0:f1], t0[f0:f1], options=opts, log_capacity=0)
+        one_shot()
         e2e_ms = (time.perf_counter() - t_e) * 1e3
 
-    run_steps(args.warmup)
-    barrier()
-    t_start = time.perf_counter()
-    solves, last = run_steps(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t_start
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed, solves = leg.timed(args.steps, args.warmup)
+
+    # spread over individually timed solves (outside the contract's timed region; guards a short --steps run)
+    per_iter_us = []
+    for _ in range(20):
+        prob.reset()
+        barrier()
+        t1 = time.perf_counter()
+        s = prob.solve(opts, log_capacity=0)
+        per_iter_us.append((time.perf_counter() - t1) * 1e6 / max(1, s["iterations"]))
 
     # ---- roofline of the dominant kernel (Jacobian sweep), HIP events on the solver's stream ----
     prob.reset()
@@ -236,13 +285,28 @@ def main():
     sweep_ms = prob.profile_sweep(100)
     prob.reset()
     prof = prob.solve(capi.default_options(profile_kernels=1), log_capacity=0)
-    my_obs, my_frames = o1 - o0, f1 - f0
+    my_obs, my_frames = leg.o1 - leg.o0, leg.f1 - leg.f0
     bytes_sweep = algorithmic_bytes_sweep(my_obs, my_frames)
     achieved_gbs = bytes_sweep / (sweep_ms * 1e-3) / 1e9
     fp64_tflops = FLOP_PER_OBS * my_obs / (sweep_ms * 1e-3) / 1e12
 
+    # ---- strong scaling: BASELINE.json configs[2] as written, the fixed 1000 x 500 problem split over the ranks
+    strong = None
+    if world > 1:
+        sleg = Leg(FRAMES_PER_GPU)
+        s_elapsed, s_solves = sleg.timed(args.steps, args.warmup)
+        s_sweep_ms = sleg.prob.profile_sweep(100)
+        strong = {
+            "workload": f"fixed {FRAMES_PER_GPU} frames x {args.points} pts split over {world} GPUs",
+            "value": 2.0 * sleg.n_obs_total * args.steps / s_elapsed, "unit": "residuals/s",
+            "ms_per_step": s_elapsed / args.steps * 1e3, "lm_iterations_per_sec": args.steps / s_elapsed,
+            "frames_per_gpu": sleg.f1 - sleg.f0, "exchange": sleg.exchange, "sweep_ms_rank0": s_sweep_ms,
+        }
+        sleg.close()
+
     result = None
     if rank == 0:
+        n_obs_total = leg.n_obs_total
         it_per_s = args.steps / elapsed
         res_per_s = 2.0 * n_obs_total * args.steps / elapsed
         result = {
@@ -262,8 +326,8 @@ def main():
                 "workload": f"BASELINE.json configs[2]: single-camera intrinsics, {args.frames} frames x "
                             f"{args.points} pts per GPU, radial-tangential distortion, Zhang init, "
                             f"reference solver options (calibrator.cpp:314-321)",
-                "frames_total": F_total, "points_per_frame": args.points,
-                "observations_total": n_obs_total, "parallelism": f"frame-sharded x{world}", "exchange": exchange,
+                "frames_total": leg.F_total, "points_per_frame": args.points,
+                "observations_total": n_obs_total, "parallelism": f"frame-sharded x{world}", "exchange": leg.exchange,
             },
             "lm_iterations_per_sec": it_per_s,
             "solves_in_timed_region": solves,
@@ -271,6 +335,8 @@ def main():
             "time_to_converge_ms": conv_ms,
             "observations_per_sec": n_obs_total * args.steps / elapsed,
             "one_shot_ms_including_upload": e2e_ms,
+            "per_solve_us_per_iteration": {"n_solves": len(per_iter_us), "median": float(np.median(per_iter_us)),
+                                           "min": float(np.min(per_iter_us)), "max": float(np.max(per_iter_us))},
             "converged": {"termination": conv["termination"], "final_cost": conv["final_cost"],
                           "intrinsics": [float(x) for x in intr_final]},
             "roofline": {
@@ -280,7 +346,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
-                "traffic": load_traffic(),
+                "traffic": load_traffic(my_frames, args.points),
                 "avg_launch_ms": sweep_ms,
                 "algorithmic_bytes_per_launch": bytes_sweep,
             },
@@ -293,39 +359,96 @@ def main():
                 for k in prof["kernel_ms"]
             },
         }
+        if strong is not None:
+            result["strong_scaling"] = strong
+        if world == 1 and not args.no_configs:
+            result["configs"] = rig_configs(capi, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             from oracle import pyoracle as po  # the ONLY use of oracle/ in this file: the cpu_baseline leg
-            # CPU baseline: the oracle (a "port": exact-Schur fp64 restatement, analytic Jacobians),
+            # CPU baseline: the oracle (a "port": exact-Schur fp64 restatement, analytic Jacobians), rebuilt on THIS
+            # host with -O3 -march=native (the parity tests keep their -ffp-contract=off build),
             # same arrays, same options, 1 thread like the reference (Ceres num_threads default 1).
+            flags, cpu_model = po.use_fast_build()
             oo = po.default_options()
             its, secs, n_solves = 0, 0.0, 0
             t_b = time.perf_counter()
             while time.perf_counter() - t_b < args.cpu_seconds:
-                _, _, _, so = po.intrinsics_solve(off, uv, xyz, intr0, q0, t0, options=oo, log_capacity=0)
+                _, _, _, so = po.intrinsics_solve(leg.off, leg.uv, leg.xyz, leg.intr0, leg.q0, leg.t0, options=oo, log_capacity=0)
                 its += so["iterations"]
                 secs += so["seconds"]
                 n_solves += 1
             cores = usable_cores()
             om = po.default_options(num_threads=cores)
-            _, _, _, sm = po.intrinsics_solve(off, uv, xyz, intr0, q0, t0, options=om, log_capacity=0)
+            _, _, _, sm = po.intrinsics_solve(leg.off, leg.uv, leg.xyz, leg.intr0, leg.q0, leg.t0, options=om, log_capacity=0)
             cpu_res = 2.0 * n_obs_total * its / secs
             result["cpu_baseline"] = {
                 "value": cpu_res, "unit": "residuals/s", "cores": 1, "kind": "port",
                 "sample": f"{n_solves} complete solves ({its} LM iterations, {secs:.1f} s) of the same "
-                          f"{F_total}x{args.points} problem by oracle/liboracle.so, 1 thread",
+                          f"{leg.F_total}x{args.points} problem by oracle/liboracle_fast.so ({flags}) on {cpu_model}, 1 thread",
                 "lm_iterations_per_sec": its / secs,
                 "all_cores": {"cores": cores, "lm_iterations_per_sec": sm["iterations"] / sm["seconds"],
                               "value": 2.0 * n_obs_total * sm["iterations"] / sm["seconds"]},
             }
             result["speedup_vs_cpu_1thread"] = res_per_s / cpu_res
+    leg.close()
     if dist is not None:
-        dist.barrier()          # no rank frees a mailbox / communicator a peer may still use
-    prob.close()
-    if dist is not None:
-        dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+
+
+def rig_configs(capi, device):
+    """BASELINE.json configs[3] and configs[4] on one GPU: the rig path at full size (scenario of the reference's own
+    rig test, include/cc_harness.h cc_rig_scenario), complete solves with the reference's options; per configuration
+    the per-iteration time, the iteration count, the dominant kernel and its roofline fractions."""
+    out = {}
+    for name, (C_, F, M) in (("rig_c4", (4, 400, 300)), ("rig_c5", (8, 2000, 500))):
+        sc = capi.rig_scenario(C_, F, M)
+        cq, ct = capi.affine_to_qt(sc["cam_T"])
+        fq, ft = capi.affine_to_qt(sc["frame_T"])
+        for variant in ("poses", "shared_intrinsics"):
+            if variant == "poses":
+                prob = capi.RigProblem(C_, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"], sc["world_xyz"],
+                                       sc["cam_frozen"], device=device)
+            else:
+                # extension: the same rig seen through the fixture camera (test_calibrator.cpp:14-19): pixel observations
+                px = (sc["obs_uv"].astype(np.float64) * 1000.0 + np.array([800.0, 500.0])).astype(np.float32)
+                prob = capi.RigProblem(C_, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], px, sc["world_xyz"],
+                                       sc["cam_frozen"], huber_a=0.0, device=device, with_intrinsics=True)
+                prob.set_intrinsics(np.array([1020.0, 980.0, 805.0, 495.0, 0, 0, 0, 0, 0]), 0)
+            prob.set_state(cq, ct, fq, ft)
+            o = capi.default_options(max_iterations=1000)
+            s = prob.solve(o, log_capacity=0)
+            ts = []
+            for _ in range(3):
+                prob.reset()
+                t0 = time.perf_counter()
+                s = prob.solve(o, log_capacity=0)
+                ts.append(time.perf_counter() - t0)
+            prob.reset()
+            p = prob.solve(capi.default_options(max_iterations=1000, profile_kernels=1), log_capacity=0)
+            prob.close()
+            n_obs, n_world = len(sc["obs_cam"]), len(sc["world_xyz"])
+            t_solve = float(np.median(ts))
+            # the profile counts every launch of a chunk; the ones after the terminating iteration return at once
+            per_launch = {k: (p["kernel_ms"][k] / p["kernel_launches"][k] if p["kernel_launches"][k] else None) for k in p["kernel_ms"]}
+            sweeps = s["iterations"] + 1
+            sweep_ms = p["kernel_ms"]["sweep"] / sweeps
+            ab = algorithmic_bytes_rig_sweep(n_obs, n_world, F, C_)
+            out[f"{name}_{variant}"] = {
+                "workload": f"rig {C_} cameras x {F} frames x {M} pts, {variant.replace('_', ' ')}"
+                            + (" (= ExtrinsicsCalibrator::Optimize)" if variant == "poses" else " (extension, pixel observations)"),
+                "observations": n_obs, "iterations": s["iterations"], "termination": s["termination"],
+                "solve_ms": t_solve * 1e3, "ms_per_iteration": t_solve * 1e3 / max(1, s["iterations"]),
+                "residuals_per_sec": 2.0 * n_obs * s["iterations"] / t_solve,
+                "dominant_kernel": "k_rig_sweep", "dominant_kernel_ms_per_launch": sweep_ms,
+                "dominant_kernel_hbm_frac": ab / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "dominant_kernel_fp64_frac": RIG_FLOP_PER_OBS * n_obs / (sweep_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                "algorithmic_bytes_per_launch": ab,
+                "kernel_ms_per_launch_eager": per_launch,
+                "final_cost": s["final_cost"],
+            }
+    return out
 
 
 if __name__ == "__main__":
