@@ -401,21 +401,26 @@ def rig_configs(capi, device):
     """BASELINE.json configs[3] and configs[4] on one GPU: the rig path at full size (scenario of the reference's own
     rig test, include/cc_harness.h cc_rig_scenario), complete solves with the reference's options; per configuration
     the per-iteration time, the iteration count, the dominant kernel and its roofline fractions."""
+    from camera_calibrator_amd import harness
     out = {}
     for name, (C_, F, M) in (("rig_c4", (4, 400, 300)), ("rig_c5", (8, 2000, 500))):
-        sc = capi.rig_scenario(C_, F, M)
-        cq, ct = capi.affine_to_qt(sc["cam_T"])
-        fq, ft = capi.affine_to_qt(sc["frame_T"])
         for variant in ("poses", "shared_intrinsics"):
             if variant == "poses":
+                sc = capi.rig_scenario(C_, F, M)
+                cq, ct = capi.affine_to_qt(sc["cam_T"])
+                fq, ft = capi.affine_to_qt(sc["frame_T"])
+                n_obs, n_world = len(sc["obs_cam"]), len(sc["world_xyz"])
                 prob = capi.RigProblem(C_, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"], sc["world_xyz"],
                                        sc["cam_frozen"], device=device)
             else:
-                # extension: the same rig seen through the fixture camera (test_calibrator.cpp:14-19): pixel observations
-                px = (sc["obs_uv"].astype(np.float64) * 1000.0 + np.array([800.0, 500.0])).astype(np.float32)
-                prob = capi.RigProblem(C_, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], px, sc["world_xyz"],
-                                       sc["cam_frozen"], huber_a=0.0, device=device, with_intrinsics=True)
-                prob.set_intrinsics(np.array([1020.0, 980.0, 805.0, 495.0, 0, 0, 0, 0, 0]), 0)
+                # extension: pixel observations of a rig through the fixture camera of test_calibrator.cpp:14-19
+                # (camera_calibrator_amd/harness.py, the scenario of the parity tests)
+                k = harness.rigk_case(C_, F, M)
+                cq, ct, fq, ft = k["cam_q0"], k["cam_t0"], k["frame_q0"], k["frame_t0"]
+                n_obs, n_world = len(k["obs_cam"]), len(k["world_xyz"])
+                prob = capi.RigProblem(C_, k["frame_offsets"], k["obs_cam"], k["obs_world"], k["obs_uv_pix"], k["world_xyz"],
+                                       k["cam_frozen"], huber_a=0.0, device=device, with_intrinsics=True)
+                prob.set_intrinsics(k["intr0"], 0)
             prob.set_state(cq, ct, fq, ft)
             o = capi.default_options(max_iterations=1000)
             s = prob.solve(o, log_capacity=0)
@@ -428,7 +433,6 @@ def rig_configs(capi, device):
             prob.reset()
             p = prob.solve(capi.default_options(max_iterations=1000, profile_kernels=1), log_capacity=0)
             prob.close()
-            n_obs, n_world = len(sc["obs_cam"]), len(sc["world_xyz"])
             t_solve = float(np.median(ts))
             # the profile counts every launch of a chunk; the ones after the terminating iteration return at once
             per_launch = {k: (p["kernel_ms"][k] / p["kernel_launches"][k] if p["kernel_launches"][k] else None) for k in p["kernel_ms"]}

@@ -83,7 +83,7 @@ EXPORTED_SYMBOLS = [
     "cc_rig_create", "cc_rig_destroy", "cc_rig_set_state", "cc_rig_reset", "cc_rig_solve",
     "cc_rig_get_state", "cc_rig_eval", "cc_rig_optimize", "cc_rig_comm_init", "cc_rig_exchange_export", "cc_rig_exchange_attach", "cc_rigk_create",
     "cc_rigk_set_intrinsics", "cc_rigk_get_intrinsics", "cc_rigk_create_per_camera", "cc_rigk_set_camera_intrinsics",
-    "cc_rigk_get_camera_intrinsics", "cc_zhang_init",
+    "cc_rigk_get_camera_intrinsics", "cc_zhang_init", "cc_intrinsics_optimize_multi", "cc_rig_optimize_multi",
 ]
 # every symbol include/cc_harness.h declares (synthetic-input harness, host code)
 HARNESS_SYMBOLS = [
@@ -249,8 +249,9 @@ def comm_get_unique_id():
 
 
 def intrinsics_optimize(frame_offsets, uv, xyz, intr, q, t, const_mask=0, options=None, device=0,
-                        log_capacity=1024):
-    """One-shot cc_intrinsics_optimize. Returns (intr, q, t, summary)."""
+                        log_capacity=1024, devices=None):
+    """One-shot cc_intrinsics_optimize (devices=[...]: cc_intrinsics_optimize_multi, one host thread driving several
+    devices). Returns (intr, q, t, summary)."""
     off = np.ascontiguousarray(frame_offsets, dtype=np.int64)
     F = len(off) - 1
     uv, xyz = _f32(uv), _f32(xyz)
@@ -260,6 +261,13 @@ def intrinsics_optimize(frame_offsets, uv, xyz, intr, q, t, const_mask=0, option
     s = Summary()
     s.log = C.cast(log, C.POINTER(Iteration))
     s.log_capacity = log_capacity
+    if devices is not None:
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        _check(lib().cc_intrinsics_optimize_multi(C.byref(opt), C.c_int32(len(devs)), _p(devs, C.c_int32), C.c_int64(F),
+                                                  _p(off, C.c_int64), _p(uv, C.c_float), _p(xyz, C.c_float),
+                                                  _p(intr, C.c_double), C.c_uint32(const_mask),
+                                                  _p(q, C.c_double), _p(t, C.c_double), C.byref(s)))
+        return intr, q, t, _summary_dict(s, log)
     _check(lib().cc_intrinsics_optimize(C.byref(opt), C.c_int32(device), C.c_int64(F),
                                         _p(off, C.c_int64), _p(uv, C.c_float), _p(xyz, C.c_float),
                                         _p(intr, C.c_double), C.c_uint32(const_mask),
@@ -375,8 +383,8 @@ class RigProblem:
 
 
 def rig_optimize(n_cams, frame_offsets, obs_cam, obs_world, obs_uv, world_xyz, cam_q, cam_t, cam_frozen,
-                 frame_q, frame_t, huber_a=HUBER_A, options=None, device=0, log_capacity=2048):
-    """One-shot cc_rig_optimize. Returns (cam_q, cam_t, frame_q, frame_t, obs_cost, summary)."""
+                 frame_q, frame_t, huber_a=HUBER_A, options=None, device=0, log_capacity=2048, devices=None):
+    """One-shot cc_rig_optimize (devices=[...]: cc_rig_optimize_multi). Returns (cam_q, cam_t, frame_q, frame_t, obs_cost, summary)."""
     off = np.ascontiguousarray(frame_offsets, dtype=np.int64)
     F = len(off) - 1
     obs_cam = np.ascontiguousarray(obs_cam, dtype=np.uint32)
@@ -391,6 +399,15 @@ def rig_optimize(n_cams, frame_offsets, obs_cam, obs_world, obs_uv, world_xyz, c
     s = Summary()
     s.log = C.cast(log, C.POINTER(Iteration))
     s.log_capacity = log_capacity
+    if devices is not None:
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        _check(lib().cc_rig_optimize_multi(C.byref(opt), C.c_int32(len(devs)), _p(devs, C.c_int32), C.c_int64(n_cams), C.c_int64(F),
+                                           C.c_int64(world_xyz.size // 3), _p(off, C.c_int64), _p(obs_cam, C.c_uint32),
+                                           _p(obs_world, C.c_uint64), _p(obs_uv, C.c_float), _p(world_xyz, C.c_float),
+                                           _p(cam_q, C.c_double), _p(cam_t, C.c_double), _p(frozen, C.c_uint8),
+                                           _p(frame_q, C.c_double), _p(frame_t, C.c_double), C.c_double(huber_a),
+                                           _p(cost, C.c_double), C.byref(s)))
+        return cam_q, cam_t, frame_q, frame_t, cost, _summary_dict(s, log)
     _check(lib().cc_rig_optimize(C.byref(opt), C.c_int32(device), C.c_int64(n_cams), C.c_int64(F),
                                  C.c_int64(world_xyz.size // 3), _p(off, C.c_int64), _p(obs_cam, C.c_uint32),
                                  _p(obs_world, C.c_uint64), _p(obs_uv, C.c_float), _p(world_xyz, C.c_float),

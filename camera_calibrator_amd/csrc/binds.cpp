@@ -146,6 +146,7 @@ PYBIND11_MODULE(pycalibrator, m) {
       .def("Distort", &Calibrator::Distort, py::arg("normalized_points"))
       // additions of this build
       .def("SetDevice", &Calibrator::SetDevice, py::arg("device"))
+      .def("SetDevices", &Calibrator::SetDevices, py::arg("devices"))
       .def("LastStatus", &Calibrator::LastStatus)
       .def("LastIterations", &Calibrator::LastIterations)
       .def("LastFinalCost", &Calibrator::LastFinalCost);
@@ -165,6 +166,7 @@ PYBIND11_MODULE(pycalibrator, m) {
       .def("RemoveObservationFrames", &ExtrinsicsCalibrator::RemoveObservationFrames, py::arg("observation_frame_ids"))
       // additions of this build
       .def("SetDevice", &ExtrinsicsCalibrator::SetDevice, py::arg("device"))
+      .def("SetDevices", &ExtrinsicsCalibrator::SetDevices, py::arg("devices"))
       .def("SetVerbose", &ExtrinsicsCalibrator::SetVerbose, py::arg("verbose"))
       .def("LastStatus", &ExtrinsicsCalibrator::LastStatus)
       .def("LastIterations", &ExtrinsicsCalibrator::LastIterations)

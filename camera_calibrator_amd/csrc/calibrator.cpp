@@ -85,12 +85,19 @@ void Calibrator::Optimize(const std::vector<Points2D>& pixels_per_view, const st
   cc_options options;
   cc_options_init(&options);  // non-monotonic steps, 100 iterations: calibrator.cpp:314-321
   cc_summary summary{};
-  last_status_ = n_img == 0 ? 0
-                            : cc_intrinsics_optimize(&options, device_, (int64_t)n_img, offsets.data(), uv.data(), xyz.data(),
-                                                     intr, frozen, q.data(), t.data(), &summary);
+  if (n_img == 0) {
+    last_status_ = 0;
+  } else if (devices_.size() > 1) {
+    std::vector<int32_t> devs(devices_.begin(), devices_.end());
+    last_status_ = cc_intrinsics_optimize_multi(&options, (int32_t)devs.size(), devs.data(), (int64_t)n_img, offsets.data(), uv.data(),
+                                                xyz.data(), intr, frozen, q.data(), t.data(), &summary);
+  } else {
+    last_status_ = cc_intrinsics_optimize(&options, device_, (int64_t)n_img, offsets.data(), uv.data(), xyz.data(),
+                                          intr, frozen, q.data(), t.data(), &summary);
+  }
   last_iterations_ = summary.iterations;
   last_final_cost_ = summary.final_cost;
-  if (last_status_ == CC_ERR_NO_DEVICE || last_status_ == CC_ERR_HIP)
+  if (last_status_ == CC_ERR_NO_DEVICE || last_status_ == CC_ERR_HIP || last_status_ == CC_ERR_COMM)
     throw std::runtime_error(std::string("Calibrator::Optimize: ") + cc_last_error());  // no silent CPU path
 
   camera_matrix_(0, 0) = static_cast<float>(intr[FX]);

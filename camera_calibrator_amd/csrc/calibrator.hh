@@ -44,7 +44,10 @@ class Calibrator {
 
   // ---- additions of this build (not in the reference) ----------------------------------------------
   /// GPU used by Optimize / Estimate / Distort / Undistort (default 0).
-  void SetDevice(int device) { device_ = device; }
+  void SetDevice(int device) { device_ = device; devices_.clear(); }
+  /// Several GPUs for Optimize (and the Optimize inside Estimate): the views are sharded over them and ONE host
+  /// thread drives all of them (cc_intrinsics_optimize_multi). The first one also serves the point kernels.
+  void SetDevices(const std::vector<int>& devices) { devices_ = devices; if (!devices.empty()) device_ = devices[0]; }
   /// Status of the last Optimize: 0 or a negative cc_status. The reference has no error channel
   /// (ceres' summary is discarded), so Optimize itself never throws on solver failure.
   int LastStatus() const { return last_status_; }
@@ -55,6 +58,7 @@ class Calibrator {
   int image_w_;
   int image_h_;
   int device_{0};
+  std::vector<int> devices_;
   int last_status_{0};
   int last_iterations_{0};
   double last_final_cost_{0.0};

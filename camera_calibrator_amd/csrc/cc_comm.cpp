@@ -99,16 +99,16 @@ int comm_allreduce_sum(Comm* c, double* buf, int n, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------
 void mailbox_release(Mailbox* m) {
   for (int r = 0; r < kP2pMaxRanks; ++r) {
-    if (m->peer[r] && m->peer[r] != m->local) hipIpcCloseMemHandle(m->peer[r]);
+    if (m->peer[r] && m->peer_ipc[r]) hipIpcCloseMemHandle(m->peer[r]);
     m->peer[r] = nullptr;
+    m->peer_ipc[r] = false;
   }
   if (m->local) { hipFree(m->local); m->local = nullptr; }
   if (m->seq) { hipFree(m->seq); m->seq = nullptr; }
   m->sw[0] = m->sw[1] = 0;
 }
 
-int mailbox_export(Mailbox* m, int doubles_kind0, int doubles_kind1, uint8_t handle[64]) {
-  static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size is part of the C ABI");
+int mailbox_alloc(Mailbox* m, int doubles_kind0, int doubles_kind1) {
   mailbox_release(m);
   m->sw[0] = (2 * doubles_kind0 + 63) / 64 * 64;
   m->sw[1] = (2 * doubles_kind1 + 63) / 64 * 64;
@@ -118,9 +118,42 @@ int mailbox_export(Mailbox* m, int doubles_kind0, int doubles_kind1, uint8_t han
   CC_HIP(hipMalloc(&m->seq, 2 * sizeof(unsigned long long)));
   CC_HIP(hipMemset(m->seq, 0, 2 * sizeof(unsigned long long)));
   CC_HIP(hipDeviceSynchronize());
+  return CC_OK;
+}
+
+int mailbox_export(Mailbox* m, int doubles_kind0, int doubles_kind1, uint8_t handle[64]) {
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size is part of the C ABI");
+  if (int rc = mailbox_alloc(m, doubles_kind0, doubles_kind1)) return rc;
   hipIpcMemHandle_t hnd;
   CC_HIP(hipIpcGetMemHandle(&hnd, m->local));
   std::memcpy(handle, &hnd, 64);
+  return CC_OK;
+}
+
+int mailbox_wire_local(Mailbox* m, int rank, int nranks, Mailbox* const* all, const int* devices, P2pDev* out) {
+  if (!m->local) return fail(CC_ERR_STATE, "exchange wiring: allocate the mailbox first");
+  CC_HIP(hipSetDevice(devices[rank]));
+  for (int r = 0; r < nranks; ++r) {
+    if (!all[r]->local || all[r]->sw[0] != m->sw[0] || all[r]->sw[1] != m->sw[1])
+      return fail(CC_ERR_STATE, "exchange wiring: rank %d has no mailbox of the same shape", r);
+    if (devices[r] != devices[rank]) {
+      int can = 0;
+      CC_HIP(hipDeviceCanAccessPeer(&can, devices[rank], devices[r]));
+      if (!can) return fail(CC_ERR_COMM, "device %d cannot access device %d directly", devices[rank], devices[r]);
+      const hipError_t e = hipDeviceEnablePeerAccess(devices[r], 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+        return fail(CC_ERR_HIP, "hipDeviceEnablePeerAccess(%d -> %d): %s", devices[rank], devices[r], hipGetErrorString(e));
+      (void)hipGetLastError();
+    }
+    m->peer[r] = all[r]->local;
+    m->peer_ipc[r] = false;
+  }
+  *out = P2pDev{};
+  for (int r = 0; r < kP2pMaxRanks; ++r) out->box[r] = r < nranks ? m->peer[r] : nullptr;
+  out->seq = m->seq;
+  out->sw[0] = m->sw[0];
+  out->sw[1] = m->sw[1];
+  out->on = 1;
   return CC_OK;
 }
 
@@ -135,12 +168,14 @@ int mailbox_attach(Mailbox* m, int rank, int nranks, const uint8_t* handles, P2p
     if (e != hipSuccess) {
       (void)hipGetLastError();
       for (int q = 0; q < r; ++q) {
-        if (q != rank && m->peer[q]) hipIpcCloseMemHandle(m->peer[q]);
+        if (m->peer_ipc[q] && m->peer[q]) hipIpcCloseMemHandle(m->peer[q]);
         m->peer[q] = nullptr;
+        m->peer_ipc[q] = false;
       }
       return fail(CC_ERR_COMM, "hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e));
     }
     m->peer[r] = static_cast<unsigned long long*>(p);
+    m->peer_ipc[r] = true;
   }
   *out = P2pDev{};
   for (int r = 0; r < kP2pMaxRanks; ++r) out->box[r] = r < nranks ? m->peer[r] : nullptr;

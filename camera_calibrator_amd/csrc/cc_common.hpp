@@ -54,11 +54,17 @@ struct P2pDev {
 struct Mailbox {  // host-side owner of one rank's mailbox and of its mappings of the peers' mailboxes
   unsigned long long* local = nullptr;
   unsigned long long* peer[kP2pMaxRanks] = {};
+  bool peer_ipc[kP2pMaxRanks] = {};        // peer[r] was opened with hipIpcOpenMemHandle (and must be closed)
   unsigned long long* seq = nullptr;
   int sw[2] = {0, 0};
 };
+int mailbox_alloc(Mailbox* m, int doubles_kind0, int doubles_kind1);   // on the current device
 int mailbox_export(Mailbox* m, int doubles_kind0, int doubles_kind1, uint8_t handle[64]);
 int mailbox_attach(Mailbox* m, int rank, int nranks, const uint8_t* handles, P2pDev* out);
+// Same wiring inside ONE process (one host thread driving several devices): the peers' mailboxes are used through
+// their own pointers; peer access between distinct devices is switched on. all[r] / devices[r]: rank r's mailbox
+// and device.
+int mailbox_wire_local(Mailbox* m, int rank, int nranks, Mailbox* const* all, const int* devices, P2pDev* out);
 void mailbox_release(Mailbox* m);
 
 // ---------------------------------------------------------------------------------------------

@@ -1316,22 +1316,29 @@ static int capture_chunk(cc_intrinsics* h, bool with_reset, bool initial, int ro
 }
 }  // namespace cc
 
-extern "C" {
-
-int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* summary) {
-  using namespace cc;
-  if (!h || !h->have_state) return fail(CC_ERR_STATE, "cc_intrinsics_solve: no state set");
-  const auto t0 = std::chrono::steady_clock::now();
+namespace cc {
+// A solve in phases, so that ONE host thread can drive several handles (devices) in lock step:
+// begin (state, options) -> { launch a chunk on every handle -> wait for every handle } ... -> finish.
+struct SolveRun {
   cc_options o;
-  if (opt) o = *opt; else cc_options_init(&o);
+  bool profile = false, use_graph = false, host_word = false;
+  int launched = 0;
+  LmCtl st{};
+  std::chrono::steady_clock::time_point t0;
+};
+
+static int solve_begin(cc_intrinsics* h, const cc_options* opt, SolveRun* r) {
+  r->t0 = std::chrono::steady_clock::now();
+  if (opt) r->o = *opt; else cc_options_init(&r->o);
+  cc_options& o = r->o;
   if (o.check_interval < 1) o.check_interval = 1;
   if (o.max_iterations > h->d.log_cap - 1) o.max_iterations = h->d.log_cap - 1;
-  const bool profile = o.profile_kernels != 0;
-  const bool use_graph = o.use_graph && !profile && !h->comm;
-  const bool host_word = !h->comm;   // fused routes hand the control block over through pinned memory
+  r->profile = o.profile_kernels != 0;
+  r->use_graph = o.use_graph && !r->profile && !h->comm;
+  r->host_word = !h->comm;   // fused routes hand the control block over through pinned memory
+  r->launched = 0;
   CC_HIP(hipSetDevice(h->device));
-  const bool from_initial = h->ctl_fresh;
-  if (!from_initial) {
+  if (!h->ctl_fresh) {
     // continue from the accepted point of the previous run: move it to buffer 0, fresh control block
     LmCtl st;
     if (int rc = read_ctl(h, &st)) return rc;
@@ -1344,54 +1351,58 @@ int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* sum
     CC_HIP(hipMemsetAsync(h->d.arrive, 0, sizeof(unsigned), h->stream));   // (a failed solve may have left arrivals behind)
   }
   h->ctl_fresh = false;
-  {
-    LmOpts lo;
-    opts_from_public(o, &lo);
-    if (!h->opts_valid || std::memcmp(&lo, &h->cached_opts, sizeof(lo)) != 0) {
-      CC_HIP(hipStreamSynchronize(h->stream));  // the pinned staging buffer may still be in flight
-      *h->h_opts = lo;
-      CC_HIP(hipMemcpyAsync(h->d.opts, h->h_opts, sizeof(lo), hipMemcpyHostToDevice, h->stream));
-      h->cached_opts = lo;
-      h->opts_valid = true;
-    }
+  LmOpts lo;
+  opts_from_public(o, &lo);
+  if (!h->opts_valid || std::memcmp(&lo, &h->cached_opts, sizeof(lo)) != 0) {
+    CC_HIP(hipStreamSynchronize(h->stream));  // the pinned staging buffer may still be in flight
+    *h->h_opts = lo;
+    CC_HIP(hipMemcpyAsync(h->d.opts, h->h_opts, sizeof(lo), hipMemcpyHostToDevice, h->stream));
+    h->cached_opts = lo;
+    h->opts_valid = true;
   }
   for (auto e : h->events) hipEventDestroy(e);
   h->events.clear();
   h->event_kind.clear();
+  if (r->use_graph && h->graph_iters != o.check_interval) { drop_graphs(h); h->graph_iters = o.check_interval; }
+  return 0;
+}
 
-  if (use_graph && h->graph_iters != o.check_interval) { drop_graphs(h); h->graph_iters = o.check_interval; }
-  auto graph_for = [&](int which) -> int {   // 0: restart + initial + n, 1: n, 2: initial + n
-    if (h->graph[which]) return 0;
-    const int rounds = o.check_interval + (which == 1 ? 0 : 1);
-    const int rc = capture_chunk(h, which == 0, which != 1, rounds, &h->graph[which]);
-    if (rc) drop_graphs(h);
-    return rc;
-  };
-
-  // The first chunk holds the (restart and the) initial evaluation plus check_interval iterations.
-  int launched = 0;
-  LmCtl st;
-  for (int chunk = 0;; ++chunk) {
-    const int n = o.check_interval + (chunk == 0 ? 1 : 0);
-    if (use_graph) {
-      const int which = chunk > 0 ? 1 : (h->reset_pending ? 0 : 2);
-      if (int rc = graph_for(which)) return rc;
-      CC_HIP(hipGraphLaunch(h->graph[which], h->stream));
-      h->reset_pending = false;
-    } else {
-      if (int rc = flush_reset(h)) return rc;
-      for (int i = 0; i < n; ++i)
-        if (int rc = enqueue_round(h, profile, chunk == 0 && i == 0, i == n - 1)) return rc;
-      CC_HIP(hipGetLastError());
+// The first chunk holds the (restart and the) initial evaluation plus check_interval iterations.
+static int solve_launch(cc_intrinsics* h, SolveRun* r, int chunk) {
+  const cc_options& o = r->o;
+  CC_HIP(hipSetDevice(h->device));
+  const int n = o.check_interval + (chunk == 0 ? 1 : 0);
+  if (r->use_graph) {
+    const int which = chunk > 0 ? 1 : (h->reset_pending ? 0 : 2);   // 0: restart + initial + n, 1: n, 2: initial + n
+    if (!h->graph[which]) {
+      const int rounds = o.check_interval + (which == 1 ? 0 : 1);
+      if (int rc = capture_chunk(h, which == 0, which != 1, rounds, &h->graph[which])) { drop_graphs(h); return rc; }
     }
-    launched += n;
-    if (int rc = host_word ? wait_published(h, &st) : read_ctl(h, &st)) return rc;
-    if (st.done && st.term == CC_FAILURE_EXCHANGE)
-      return fail(CC_ERR_COMM, "mailbox exchange timed out: a peer rank did not post within 10 s (iteration %d)", st.iter);
-    if (st.done) break;
-    if (launched > o.max_iterations + 2 * o.check_interval + 2)
-      return fail(CC_ERR_STATE, "LM loop did not terminate (iter=%d)", st.iter);
+    CC_HIP(hipGraphLaunch(h->graph[which], h->stream));
+    h->reset_pending = false;
+  } else {
+    if (int rc = flush_reset(h)) return rc;
+    for (int i = 0; i < n; ++i)
+      if (int rc = enqueue_round(h, r->profile, chunk == 0 && i == 0, i == n - 1)) return rc;
+    CC_HIP(hipGetLastError());
   }
+  r->launched += n;
+  return 0;
+}
+
+static int solve_wait(cc_intrinsics* h, SolveRun* r) {
+  CC_HIP(hipSetDevice(h->device));
+  if (int rc = r->host_word ? wait_published(h, &r->st) : read_ctl(h, &r->st)) return rc;
+  if (r->st.done && r->st.term == CC_FAILURE_EXCHANGE)
+    return fail(CC_ERR_COMM, "mailbox exchange timed out: a peer rank did not post within 10 s (iteration %d)", r->st.iter);
+  if (!r->st.done && r->launched > r->o.max_iterations + 2 * r->o.check_interval + 2)
+    return fail(CC_ERR_STATE, "LM loop did not terminate (iter=%d)", r->st.iter);
+  return 0;
+}
+
+static int solve_finish(cc_intrinsics* h, SolveRun* r, cc_summary* summary) {
+  const LmCtl& st = r->st;
+  CC_HIP(hipSetDevice(h->device));
   if (summary) {
     cc_iteration* user_log = summary->log;
     const int cap = summary->log_capacity;
@@ -1405,7 +1416,7 @@ int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* sum
     summary->log_len = n;
     if (n > 0) CC_HIP(hipMemcpy(user_log, h->d.log, (size_t)n * sizeof(cc_iteration), hipMemcpyDeviceToHost));
     for (int i = 0; i < CC_K_COUNT; ++i) { summary->kernel_ms[i] = 0.0; summary->kernel_launches[i] = 0; }
-    if (profile) {
+    if (r->profile) {
       for (size_t i = 0; i < h->event_kind.size(); ++i) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, h->events[2 * i], h->events[2 * i + 1]) == hipSuccess) {
@@ -1414,12 +1425,93 @@ int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* sum
         }
       }
     }
-    summary->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    summary->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - r->t0).count();
   }
   for (auto e : h->events) hipEventDestroy(e);
   h->events.clear();
   h->event_kind.clear();
   return CC_OK;
+}
+}  // namespace cc
+
+extern "C" {
+
+int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* summary) {
+  using namespace cc;
+  if (!h || !h->have_state) return fail(CC_ERR_STATE, "cc_intrinsics_solve: no state set");
+  SolveRun r;
+  if (int rc = solve_begin(h, opt, &r)) return rc;
+  for (int chunk = 0;; ++chunk) {
+    if (int rc = solve_launch(h, &r, chunk)) return rc;
+    if (int rc = solve_wait(h, &r)) return rc;
+    if (r.st.done) break;
+  }
+  return solve_finish(h, &r, summary);
+}
+
+// Multi-device solve driven by ONE host thread (SURVEY.md 8(b) thread model): the frames are split into contiguous
+// shards by observation count, one handle + stream per device, mailboxes wired inside the process (peer access, no
+// hipIpc), every device's chunk enqueued before any of them is waited for. A device id may appear several times
+// (several shards on one GPU: what the one-GPU test box does). Replaces calibrator.cpp:236-324 like
+// cc_intrinsics_optimize; every shard ends with bit-identical intrinsics.
+int cc_intrinsics_optimize_multi(const cc_options* opt, int32_t n_devices, const int32_t* devices, int64_t F,
+                                 const int64_t* off, const float* uv, const float* xyz, double* intr9, uint32_t mask,
+                                 double* q, double* t, cc_summary* summary) {
+  using namespace cc;
+  if (n_devices < 1 || !devices || n_devices > kP2pMaxRanks)
+    return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_optimize_multi: 1..%d devices", kP2pMaxRanks);
+  if (!off || F <= 0 || !intr9 || !q || !t) return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_optimize_multi: bad arguments");
+  const int n = (int)std::min<int64_t>(n_devices, F);      // never more shards than frames
+  if (n == 1) return cc_intrinsics_optimize(opt, devices[0], F, off, uv, xyz, intr9, mask, q, t, summary);
+  std::vector<int64_t> first((size_t)n + 1);
+  if (int rc = cc_partition_frames(F, off, n, first.data())) return rc;
+  std::vector<cc_intrinsics*> hs((size_t)n, nullptr);
+  auto cleanup = [&]() {
+    for (auto* h : hs) if (h) { hipSetDevice(h->device); hipStreamSynchronize(h->stream); }   // nobody frees a mailbox a peer still writes
+    for (auto* h : hs) cc_intrinsics_destroy(h);
+  };
+  int rc = 0;
+  for (int r = 0; r < n && !rc; ++r) {
+    const int64_t f0 = first[(size_t)r], f1 = first[(size_t)r + 1], o0 = off[f0];
+    std::vector<int64_t> so((size_t)(f1 - f0) + 1);
+    for (int64_t f = f0; f <= f1; ++f) so[(size_t)(f - f0)] = off[f] - o0;
+    rc = cc_intrinsics_create(devices[r], f1 - f0, so.data(), uv ? uv + 2 * o0 : nullptr, xyz ? xyz + 3 * o0 : nullptr, &hs[(size_t)r]);
+    if (!rc) rc = cc_intrinsics_set_state(hs[(size_t)r], intr9, mask, q + 4 * f0, t + 3 * f0);
+  }
+  if (!rc) {
+    std::vector<Mailbox*> boxes;
+    std::vector<int> devs;
+    for (auto* h : hs) { boxes.push_back(&h->mailbox); devs.push_back(h->device); }
+    for (int r = 0; r < n && !rc; ++r) { rc = hipSetDevice(hs[(size_t)r]->device) == hipSuccess ? mailbox_alloc(&hs[(size_t)r]->mailbox, kVecSolve, 16) : fail(CC_ERR_HIP, "hipSetDevice failed"); }
+    for (int r = 0; r < n && !rc; ++r) {
+      cc_intrinsics* h = hs[(size_t)r];
+      rc = mailbox_wire_local(&h->mailbox, r, n, boxes.data(), devs.data(), &h->d.x);
+      if (!rc) { h->d.rank = r; h->d.nranks = n; h->exchange = true; }
+    }
+  }
+  cc_options o;
+  if (opt) o = *opt; else cc_options_init(&o);
+  o.use_graph = 0;   // one solve per handle: capturing and instantiating a graph cannot pay off
+  std::vector<SolveRun> runs((size_t)n);
+  for (int r = 0; r < n && !rc; ++r) rc = solve_begin(hs[(size_t)r], &o, &runs[(size_t)r]);
+  for (int chunk = 0; !rc; ++chunk) {
+    for (int r = 0; r < n && !rc; ++r) rc = solve_launch(hs[(size_t)r], &runs[(size_t)r], chunk);
+    for (int r = 0; r < n && !rc; ++r) rc = solve_wait(hs[(size_t)r], &runs[(size_t)r]);
+    if (rc) break;
+    bool all_done = true, any_done = false;
+    for (auto& run : runs) { all_done = all_done && run.st.done; any_done = any_done || run.st.done; }
+    if (all_done) break;
+    if (any_done) rc = fail(CC_ERR_STATE, "cc_intrinsics_optimize_multi: the shards disagree about termination");
+  }
+  if (!rc) rc = solve_finish(hs[0], &runs[0], summary);
+  for (int r = 0; r < n && !rc; ++r) {
+    const int64_t f0 = first[(size_t)r];
+    rc = cc_intrinsics_get_state(hs[(size_t)r], r == 0 ? intr9 : nullptr, q + 4 * f0, t + 3 * f0);
+  }
+  const std::string err = rc ? last_error() : std::string();
+  cleanup();
+  if (rc) last_error() = err;
+  return rc;
 }
 
 int cc_intrinsics_profile_sweep(cc_intrinsics* h, int32_t n, double* avg_ms) {

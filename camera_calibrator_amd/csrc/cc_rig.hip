@@ -966,6 +966,42 @@ __device__ __forceinline__ void rig_candidates(const RigDev& P, const double* x,
   }
 }
 
+// Cholesky + forward substitution of an S x S system (S <= SMAX <= 64) on ONE wave, matrix rows in REGISTERS:
+// lane i keeps row i of the lower triangle (loaded from LDS, row stride LD); column j's pivot and multipliers
+// travel through v_readlane, so a column step is two scalar reads and one FMA per trailing column with no LDS
+// round trip and no barrier on the dependent chain (the LDS version below pays ~0.4 us per column for them).
+// Rows / columns S..SMAX-1 are identity. On return: L (lower) is back in LDS, b holds y = L^-1 b (lane i: y_i),
+// vinv lane j = 1 / L_jj, ok = every pivot positive and finite.
+template <int SMAX>
+__device__ __noinline__ void chol_wave(double* A, int S, int LD, double& b, double& vinv, int& ok_out) {
+  const int lane = threadIdx.x & 63;
+  double a[SMAX];
+#pragma unroll
+  for (int k = 0; k < SMAX; ++k) a[k] = (lane < S && k <= lane) ? A[(size_t)lane * LD + k] : (k == lane ? 1.0 : 0.0);
+  bool ok = true;
+  vinv = 0.0;
+#pragma unroll
+  for (int j = 0; j < SMAX; ++j) {
+    const double d = readlane_d(a[j], j);
+    ok = ok && (d > 0.0) && isfinite(d);
+    const double inv = rsqrt(d);
+    const double l = lane == j ? d * inv : a[j] * inv;
+    a[j] = l;
+    if (lane == j) vinv = inv;
+#pragma unroll
+    for (int k = j + 1; k < SMAX; ++k) a[k] -= l * readlane_d(l, k);
+    // the forward substitution rides along: y_j = b_j / L_jj, b_i -= L_ij y_j (i > j)
+    const double yj = readlane_d(b, j) * inv;
+    b = lane == j ? yj : (lane > j ? b - l * yj : b);
+  }
+  if (lane < S) {
+#pragma unroll
+    for (int k = 0; k < SMAX; ++k)
+      if (k <= lane) A[(size_t)lane * LD + k] = a[k];
+  }
+  ok_out = ok ? 1 : 0;
+}
+
 template <int SRC>
 __device__ void rig_solve_block(const RigDev& P, double* smem) {
   const int S = P.S, LD = S + 1;
@@ -975,7 +1011,6 @@ __device__ void rig_solve_block(const RigDev& P, double* smem) {
   double* s_hd = s_gs + 128;              // [128] diagonal of the scaled H_ss
   double* s_inv = s_hd + 128;             // [128] 1 / L_jj
   __shared__ int s_ok, s_cholok, s_stepok, s_go;
-  __shared__ double s_g;
   __shared__ double s4[4];
   __shared__ LmCtl s_c;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -988,56 +1023,93 @@ __device__ void rig_solve_block(const RigDev& P, double* smem) {
   for (int i = tid; i < S * LD; i += 256) A[i] = 0.0;
   if (tid < 128) { s_b[tid] = 0.0; s_gs[tid] = 0.0; s_hd[tid] = 0.0; s_inv[tid] = 0.0; }
   __syncthreads();
-  // ---- 1. per-camera sums of the shared-block entries -> scaled H_ss (lower triangle), unscaled gradient.
-  // An intrinsics set shared by several cameras is summed by the first of them, in camera order.
-  for (int e = tid; e < P.ND; e += 256) {
-    const int co = e / P.DE, idx = e - co * P.DE;
-    const int c = P.obs_cam[co];
-    const int p0 = P.pcol[c], k0 = P.kcol[c];
-    if (idx < 27) {
-      if (p0 < 0) continue;
-      const double v = val.get<SRC>(P.pc_dir + e);
-      if (idx < 21) {
-        int i, j;
-        untri(idx, i, j);
-        A[(size_t)(p0 + i) * LD + p0 + j] = P.ss[p0 + i] * v * P.ss[p0 + j];
+  // ---- 1. one pass over the reduced values (loads batched eight deep: one round trip per batch, not per value):
+  // per-camera sums of the shared-block entries -> scaled H_ss (lower triangle) and unscaled gradient, minus the
+  // Schur products Z^T Z. An element of A gets at most two contributions (one of each kind), added with LDS
+  // atomics onto zero: x + y is commutative, so the result does not depend on who comes first. An intrinsics
+  // set shared by several cameras is summed by the first of them, in camera order.
+  constexpr int NB = SRC == 2 ? 1 : 8;   // (a mailbox read is a polling loop of its own: no batching there)
+  const double fail = val.get<SRC>(P.pc_fail);
+  const double gm_r = (tid < P.nranks && tid < 32) ? val.get<SRC>(P.PC + tid) : 0.0;
+  for (int e0 = 0; e0 < P.ND; e0 += NB * 256) {
+    double v[NB];
+    int dst[NB];    // >= 0: element of A (scaled by sc); -1: nothing; <= -2: gradient entry -(dst + 2)
+    double sc[NB];
+    int hdp[NB];    // diagonal entry of the scaled H_ss
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int e = e0 + u * 256 + tid;
+      v[u] = 0.0; dst[u] = -1; sc[u] = 0.0; hdp[u] = -1;
+      if (e >= P.ND) continue;
+      const int co = e / P.DE, idx = e - co * P.DE;
+      const int c = P.obs_cam[co];
+      const int p0 = P.pcol[c], k0 = P.kcol[c];
+      if (idx < 27) {
+        if (p0 < 0) continue;
+        v[u] = val.get<SRC>(P.pc_dir + e);
+        if (idx < 21) {
+          int i, j;
+          untri(idx, i, j);
+          dst[u] = (p0 + i) * LD + p0 + j; sc[u] = P.ss[p0 + i] * P.ss[p0 + j];
+          if (i == j) hdp[u] = p0 + i;
+        } else {
+          dst[u] = -2 - (p0 + idx - 21);
+        }
+      } else if (idx < 81) {
+        if (p0 < 0 || k0 < 0) continue;
+        const int t = idx - 27, i = t / 9, j = t - i * 9;   // H_ck[i][j]; intrinsics columns follow all pose columns
+        v[u] = val.get<SRC>(P.pc_dir + e);
+        dst[u] = (k0 + j) * LD + p0 + i; sc[u] = P.ss[k0 + j] * P.ss[p0 + i];
       } else {
-        s_gs[p0 + idx - 21] = v;
+        if (k0 < 0) continue;
+        bool first = true;
+        for (int co2 = 0; co2 < co; ++co2) first = first && P.kcol[P.obs_cam[co2]] != k0;
+        if (!first) continue;
+        double acc = 0.0;
+        for (int co2 = co; co2 < P.CO; ++co2)
+          if (P.kcol[P.obs_cam[co2]] == k0) acc += val.get<SRC>(P.pc_dir + co2 * P.DE + idx);
+        v[u] = acc;
+        if (idx < 126) {
+          int i, j;
+          untri(idx - 81, i, j);
+          dst[u] = (k0 + i) * LD + k0 + j; sc[u] = P.ss[k0 + i] * P.ss[k0 + j];
+          if (i == j) hdp[u] = k0 + i;
+        } else {
+          dst[u] = -2 - (k0 + idx - 126);
+        }
       }
-    } else if (idx < 81) {
-      if (p0 < 0 || k0 < 0) continue;
-      const int t = idx - 27, i = t / 9, j = t - i * 9;   // H_ck[i][j]; intrinsics columns follow all pose columns
-      const double v = val.get<SRC>(P.pc_dir + e);
-      A[(size_t)(k0 + j) * LD + p0 + i] = P.ss[k0 + j] * v * P.ss[p0 + i];
-    } else {
-      if (k0 < 0) continue;
-      bool first = true;
-      for (int co2 = 0; co2 < co; ++co2) first = first && P.kcol[P.obs_cam[co2]] != k0;
-      if (!first) continue;
-      double v = 0.0;
-      for (int co2 = co; co2 < P.CO; ++co2)
-        if (P.kcol[P.obs_cam[co2]] == k0) v += val.get<SRC>(P.pc_dir + co2 * P.DE + idx);
-      if (idx < 126) {
-        int i, j;
-        untri(idx - 81, i, j);
-        A[(size_t)(k0 + i) * LD + k0 + j] = P.ss[k0 + i] * v * P.ss[k0 + j];
-      } else {
-        s_gs[k0 + idx - 126] = v;
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      if (dst[u] >= 0) {
+        const double x = sc[u] * v[u];
+        __hip_atomic_fetch_add(&A[dst[u]], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (hdp[u] >= 0) s_hd[hdp[u]] = x;
+      } else if (dst[u] <= -2) {
+        s_gs[-2 - dst[u]] = v[u];
       }
     }
   }
-  const double fail = val.get<SRC>(P.pc_fail);
-  const double gm_r = (tid < P.nranks && tid < 32) ? val.get<SRC>(P.PC + tid) : 0.0;
-  __syncthreads();
-  if (tid < S) s_hd[tid] = A[(size_t)tid * LD + tid];
-  // ---- 2. minus the Schur products Z^T Z (upper tile pairs; element (r, c) of pair (ti, tj) is (p, q), p <= q)
-  for (int i = tid; i < P.nT * 256; i += 256) {
-    const int t = i >> 8, r = (i >> 4) & 15, c = i & 15;
-    const int p = 16 * P.tile_i[t] + r, q = 16 * P.tile_j[t] + c;
-    if (p > q || p >= S || q > S) continue;
-    const double v = val.get<SRC>(i);
-    if (q < S) A[(size_t)q * LD + p] -= v;
-    else s_b[p] = -v;
+  // Schur products (upper tile pairs; element (r, c) of pair (ti, tj) is (p, q), p <= q; column S is the rhs)
+  for (int i0 = 0; i0 < P.nT * 256; i0 += NB * 256) {
+    double v[NB];
+    int dst[NB];   // >= 0: A element, <= -2: rhs entry
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int i = i0 + u * 256 + tid;
+      v[u] = 0.0; dst[u] = -1;
+      if (i >= P.nT * 256) continue;
+      const int t = i >> 8, r = (i >> 4) & 15, c = i & 15;
+      const int p = 16 * P.tile_i[t] + r, q = 16 * P.tile_j[t] + c;
+      if (p > q || p >= S || q > S) continue;
+      v[u] = val.get<SRC>(i);
+      dst[u] = q < S ? q * LD + p : -2 - p;
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      if (dst[u] >= 0) __hip_atomic_fetch_add(&A[dst[u]], -v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else if (dst[u] <= -2) s_b[-2 - dst[u]] = -v[u];
+    }
   }
   __syncthreads();
   // ---- 3. right-hand side, LM diagonal, constant coordinates (held intrinsics) become identity rows
@@ -1074,10 +1146,45 @@ __device__ void rig_solve_block(const RigDev& P, double* smem) {
     else if (lm_finalize(c, o, gmax)) s_go = 1;
     if (fail > 0.0) s_cholok = 0;
     s_c = c;
-    s_g = gmax;
   }
   __syncthreads();
-  if (s_go) {
+  if (s_go && S <= 64) {
+    // ---- factorisation and forward substitution in registers on wave 0, backward substitution from LDS
+    if (tid < 64) {
+      double b0 = lane < S ? s_b[lane] : 0.0, vinv = 0.0;
+      int ok = 0;
+      if (S <= 8) chol_wave<8>(A, S, LD, b0, vinv, ok);
+      else if (S <= 16) chol_wave<16>(A, S, LD, b0, vinv, ok);
+      else if (S <= 24) chol_wave<24>(A, S, LD, b0, vinv, ok);
+      else if (S <= 32) chol_wave<32>(A, S, LD, b0, vinv, ok);
+      else if (S <= 40) chol_wave<40>(A, S, LD, b0, vinv, ok);
+      else if (S <= 48) chol_wave<48>(A, S, LD, b0, vinv, ok);
+      else if (S <= 56) chol_wave<56>(A, S, LD, b0, vinv, ok);
+      else chol_wave<64>(A, S, LD, b0, vinv, ok);
+      wave_lds_fence();
+      const int i0 = lane;
+      for (int j0 = S - 1; j0 >= 0; j0 -= 8) {
+        double a0[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 - u;
+          a0[u] = (j >= 0 && i0 < j) ? A[(size_t)j * LD + i0] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 - u;
+          if (j >= 0) {
+            const double xj = readlane_d(b0, j) * readlane_d(vinv, j);
+            if (i0 == j) b0 = xj; else b0 -= a0[u] * xj;
+          }
+        }
+      }
+      const bool step_ok = s_cholok != 0 && ok != 0 && __all(i0 >= S || isfinite(b0));
+      if (i0 < S) { s_b[i0] = b0; P.ds[i0] = -b0; }
+      if (lane == 0) s_stepok = step_ok ? 1 : 0;
+    }
+    __syncthreads();
+  } else if (s_go) {
     // right-looking Cholesky, lower triangle in place, ONE barrier per step: every thread derives
     // 1/sqrt(pivot) itself, the trailing update uses the unscaled column times inv^2, and the
     // scaled column is written in the same step by the threads that own it.
@@ -1835,62 +1942,78 @@ static int rig_capture(cc_rig* h, bool first_chunk, int rounds, hipGraphExec_t* 
 }
 }  // namespace cc
 
-extern "C" {
-
-int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
-  using namespace cc;
-  if (!h || !h->have_state) return fail(CC_ERR_STATE, "cc_rig_solve: no state set");
-  if (h->d.kmode && !h->have_intr) return fail(CC_ERR_STATE, "cc_rig_solve: cc_rigk_set_intrinsics has not been called");
-  const auto t0 = std::chrono::steady_clock::now();
+namespace cc {
+// A solve in phases (cf. cc_intrinsics.hip): begin -> { launch a chunk -> wait } ... -> finish, so that one host
+// thread can drive several handles (devices) in lock step.
+struct RigRun {
   cc_options o;
-  if (opt) o = *opt; else { cc_options_init(&o); o.max_iterations = 1000; }  // extrinsics_calibrator.cpp:211
+  bool profile = false, use_graph = false;
+  int launched = 0;
+  LmCtl st{};
+  std::chrono::steady_clock::time_point t0;
+};
+
+static int rig_begin(cc_rig* h, const cc_options* opt, RigRun* r) {
+  r->t0 = std::chrono::steady_clock::now();
+  if (opt) r->o = *opt; else { cc_options_init(&r->o); r->o.max_iterations = 1000; }  // extrinsics_calibrator.cpp:211
+  cc_options& o = r->o;
   if (o.check_interval < 1) o.check_interval = 1;
   if (o.max_iterations > h->d.log_cap - 1) o.max_iterations = h->d.log_cap - 1;
-  const bool profile = o.profile_kernels != 0;
-  const bool use_graph = o.use_graph != 0 && !h->comm && !profile;
+  r->profile = o.profile_kernels != 0;
+  r->use_graph = o.use_graph != 0 && !h->comm && !r->profile;
+  r->launched = 0;
   CC_HIP(hipSetDevice(h->device));
-  {
-    LmCtl st;
-    if (int rc = rig_read_ctl(h, &st)) return rc;
-    if (st.cur & 1) {
-      CC_HIP(hipMemcpyAsync(h->d.cam, h->d.cam + (size_t)h->C * 8, (size_t)h->C * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-      CC_HIP(hipMemcpyAsync(h->d.pose, h->d.pose + (size_t)h->F * 8, (size_t)h->F * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-      if (h->d.kmode) CC_HIP(hipMemcpyAsync(h->d.intr, h->d.intr + (size_t)h->d.CK * 16, (size_t)h->d.CK * 16 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    }
-    LmOpts lo;
-    opts_from_public(o, &lo);
-    CC_HIP(hipMemcpyAsync(h->d.opts, &lo, sizeof(lo), hipMemcpyHostToDevice, h->stream));
-    LmCtl c{};
-    if (int rc = rig_write_ctl(h, c)) return rc;
-    CC_HIP(hipMemsetAsync(h->d.arrive, 0, sizeof(unsigned), h->stream));
+  LmCtl st;
+  if (int rc = rig_read_ctl(h, &st)) return rc;
+  if (st.cur & 1) {
+    CC_HIP(hipMemcpyAsync(h->d.cam, h->d.cam + (size_t)h->C * 8, (size_t)h->C * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    CC_HIP(hipMemcpyAsync(h->d.pose, h->d.pose + (size_t)h->F * 8, (size_t)h->F * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    if (h->d.kmode) CC_HIP(hipMemcpyAsync(h->d.intr, h->d.intr + (size_t)h->d.CK * 16, (size_t)h->d.CK * 16 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   }
+  LmOpts lo;
+  opts_from_public(o, &lo);
+  CC_HIP(hipMemcpyAsync(h->d.opts, &lo, sizeof(lo), hipMemcpyHostToDevice, h->stream));
+  LmCtl c{};
+  if (int rc = rig_write_ctl(h, c)) return rc;
+  CC_HIP(hipMemsetAsync(h->d.arrive, 0, sizeof(unsigned), h->stream));
   for (auto e : h->events) hipEventDestroy(e);
   h->events.clear();
   h->event_kind.clear();
-  if (use_graph && h->graph_iters != o.check_interval) { rig_drop_graphs(h); h->graph_iters = o.check_interval; }
-  int launched = 0;
-  LmCtl st;
-  for (int chunk = 0;; ++chunk) {
-    const int n = o.check_interval + (chunk == 0 ? 1 : 0);
-    if (use_graph) {
-      const int which = chunk == 0 ? 0 : 1;
-      if (!h->graph[which])
-        if (int rc = rig_capture(h, which == 0, n, &h->graph[which])) { rig_drop_graphs(h); return rc; }
-      CC_HIP(hipGraphLaunch(h->graph[which], h->stream));
-    } else {
-      if (chunk == 0) rig_enqueue_prep(h);
-      for (int i = 0; i < n; ++i)
-        if (int rc = rig_enqueue_round(h, chunk == 0 && i == 0, profile)) return rc;
-      CC_HIP(hipGetLastError());
-    }
-    launched += n;
-    if (int rc = rig_read_ctl(h, &st)) return rc;
-    if (st.done && st.term == CC_FAILURE_EXCHANGE)
-      return fail(CC_ERR_COMM, "mailbox exchange timed out: a peer rank did not post within 10 s (iteration %d)", st.iter);
-    if (st.done) break;
-    if (launched > o.max_iterations + 2 * o.check_interval + 2)
-      return fail(CC_ERR_STATE, "rig LM loop did not terminate (iter=%d)", st.iter);
+  if (r->use_graph && h->graph_iters != o.check_interval) { rig_drop_graphs(h); h->graph_iters = o.check_interval; }
+  return 0;
+}
+
+static int rig_launch(cc_rig* h, RigRun* r, int chunk) {
+  CC_HIP(hipSetDevice(h->device));
+  const int n = r->o.check_interval + (chunk == 0 ? 1 : 0);
+  if (r->use_graph) {
+    const int which = chunk == 0 ? 0 : 1;
+    if (!h->graph[which])
+      if (int rc = rig_capture(h, which == 0, n, &h->graph[which])) { rig_drop_graphs(h); return rc; }
+    CC_HIP(hipGraphLaunch(h->graph[which], h->stream));
+  } else {
+    if (chunk == 0) rig_enqueue_prep(h);
+    for (int i = 0; i < n; ++i)
+      if (int rc = rig_enqueue_round(h, chunk == 0 && i == 0, r->profile)) return rc;
+    CC_HIP(hipGetLastError());
   }
+  r->launched += n;
+  return 0;
+}
+
+static int rig_wait(cc_rig* h, RigRun* r) {
+  CC_HIP(hipSetDevice(h->device));
+  if (int rc = rig_read_ctl(h, &r->st)) return rc;
+  if (r->st.done && r->st.term == CC_FAILURE_EXCHANGE)
+    return fail(CC_ERR_COMM, "mailbox exchange timed out: a peer rank did not post within 10 s (iteration %d)", r->st.iter);
+  if (!r->st.done && r->launched > r->o.max_iterations + 2 * r->o.check_interval + 2)
+    return fail(CC_ERR_STATE, "rig LM loop did not terminate (iter=%d)", r->st.iter);
+  return 0;
+}
+
+static int rig_finish(cc_rig* h, RigRun* r, cc_summary* summary) {
+  const LmCtl& st = r->st;
+  CC_HIP(hipSetDevice(h->device));
   if (summary) {
     cc_iteration* user_log = summary->log;
     const int cap = summary->log_capacity;
@@ -1904,7 +2027,7 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
     summary->log_len = n;
     if (n > 0) CC_HIP(hipMemcpy(user_log, h->d.log, (size_t)n * sizeof(cc_iteration), hipMemcpyDeviceToHost));
     for (int i = 0; i < CC_K_COUNT; ++i) { summary->kernel_ms[i] = 0.0; summary->kernel_launches[i] = 0; }
-    if (profile) {
+    if (r->profile) {
       for (size_t i = 0; i < h->event_kind.size(); ++i) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, h->events[2 * i], h->events[2 * i + 1]) == hipSuccess) {
@@ -1913,12 +2036,29 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
         }
       }
     }
-    summary->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    summary->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - r->t0).count();
   }
   for (auto e : h->events) hipEventDestroy(e);
   h->events.clear();
   h->event_kind.clear();
   return CC_OK;
+}
+}  // namespace cc
+
+extern "C" {
+
+int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
+  using namespace cc;
+  if (!h || !h->have_state) return fail(CC_ERR_STATE, "cc_rig_solve: no state set");
+  if (h->d.kmode && !h->have_intr) return fail(CC_ERR_STATE, "cc_rig_solve: cc_rigk_set_intrinsics has not been called");
+  RigRun r;
+  if (int rc = rig_begin(h, opt, &r)) return rc;
+  for (int chunk = 0;; ++chunk) {
+    if (int rc = rig_launch(h, &r, chunk)) return rc;
+    if (int rc = rig_wait(h, &r)) return rc;
+    if (r.st.done) break;
+  }
+  return rig_finish(h, &r, summary);
 }
 
 int cc_rig_get_state(cc_rig* h, double* cam_q, double* cam_t, double* frame_q, double* frame_t, double* obs_cost) {
@@ -2088,6 +2228,84 @@ int cc_rig_optimize(const cc_options* opt, int32_t device, int64_t C, int64_t F,
   if (!rc) rc = cc_rig_solve(h, &o, summary);
   if (!rc) rc = cc_rig_get_state(h, cam_q, cam_t, frame_q, frame_t, obs_cost);
   cc_rig_destroy(h);
+  return rc;
+}
+
+
+// Multi-device rig solve driven by ONE host thread (SURVEY.md 8(b) thread model; cf. cc_intrinsics_optimize_multi):
+// frames sharded contiguously by observation count, cameras and world points replicated, mailboxes wired inside the
+// process, every device's chunk enqueued before any is waited for. A device id may appear several times.
+int cc_rig_optimize_multi(const cc_options* opt, int32_t n_devices, const int32_t* devices, int64_t C, int64_t F,
+                          int64_t n_world, const int64_t* off, const uint32_t* obs_cam, const uint64_t* obs_world,
+                          const float* obs_uv, const float* world_xyz, double* cam_q, double* cam_t,
+                          const uint8_t* cam_frozen, double* frame_q, double* frame_t, double huber_a,
+                          double* obs_cost, cc_summary* summary) {
+  using namespace cc;
+  if (n_devices < 1 || !devices || n_devices > kP2pMaxRanks)
+    return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_optimize_multi: 1..%d devices", kP2pMaxRanks);
+  if (!off || F < 1 || !cam_q || !cam_t || !frame_q || !frame_t) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_optimize_multi: bad arguments");
+  const int n = (int)std::min<int64_t>(n_devices, F);
+  if (n == 1)
+    return cc_rig_optimize(opt, devices[0], C, F, n_world, off, obs_cam, obs_world, obs_uv, world_xyz, cam_q, cam_t, cam_frozen,
+                           frame_q, frame_t, huber_a, obs_cost, summary);
+  std::vector<int64_t> first((size_t)n + 1);
+  if (int rc = cc_partition_frames(F, off, n, first.data())) return rc;
+  std::vector<cc_rig*> hs((size_t)n, nullptr);
+  int rc = 0;
+  for (int r = 0; r < n && !rc; ++r) {
+    const int64_t f0 = first[(size_t)r], f1 = first[(size_t)r + 1], o0 = off[f0];
+    std::vector<int64_t> so((size_t)(f1 - f0) + 1);
+    for (int64_t f = f0; f <= f1; ++f) so[(size_t)(f - f0)] = off[f] - o0;
+    rc = cc_rig_create(devices[r], C, f1 - f0, n_world, so.data(), obs_cam ? obs_cam + o0 : nullptr, obs_world ? obs_world + o0 : nullptr,
+                       obs_uv ? obs_uv + 2 * o0 : nullptr, world_xyz, cam_frozen, huber_a, &hs[(size_t)r]);
+  }
+  if (!rc) {
+    // a camera is part of the problem if ANY shard observes it (all shards live in this process: no exchange needed)
+    std::vector<double> flags((size_t)C, 0.0);
+    for (auto* h : hs) for (int64_t c = 0; c < C; ++c) if (h->seen[(size_t)c]) flags[(size_t)c] = 1.0;
+    std::vector<Mailbox*> boxes;
+    std::vector<int> devs;
+    for (auto* h : hs) { boxes.push_back(&h->mailbox); devs.push_back(h->device); }
+    for (int r = 0; r < n && !rc; ++r) {
+      cc_rig* h = hs[(size_t)r];
+      int k0 = 0, k1 = 0;
+      rig_exchange_bounds(h, &k0, &k1);
+      rc = hipSetDevice(h->device) == hipSuccess ? mailbox_alloc(&h->mailbox, k0, k1) : fail(CC_ERR_HIP, "hipSetDevice failed");
+    }
+    for (int r = 0; r < n && !rc; ++r) {
+      cc_rig* h = hs[(size_t)r];
+      rc = mailbox_wire_local(&h->mailbox, r, n, boxes.data(), devs.data(), &h->d.x);
+      if (!rc) { h->d.comm = 1; h->d.rank = r; h->d.nranks = n; h->exchange = true; rc = rig_adopt_global_cameras(h, flags); }
+    }
+  }
+  for (int r = 0; r < n && !rc; ++r) {
+    const int64_t f0 = first[(size_t)r];
+    rc = cc_rig_set_state(hs[(size_t)r], cam_q, cam_t, frame_q + 4 * f0, frame_t + 3 * f0);
+  }
+  cc_options o;
+  if (opt) o = *opt; else { cc_options_init(&o); o.max_iterations = 1000; }  // extrinsics_calibrator.cpp:211
+  o.use_graph = 0;
+  std::vector<RigRun> runs((size_t)n);
+  for (int r = 0; r < n && !rc; ++r) rc = rig_begin(hs[(size_t)r], &o, &runs[(size_t)r]);
+  for (int chunk = 0; !rc; ++chunk) {
+    for (int r = 0; r < n && !rc; ++r) rc = rig_launch(hs[(size_t)r], &runs[(size_t)r], chunk);
+    for (int r = 0; r < n && !rc; ++r) rc = rig_wait(hs[(size_t)r], &runs[(size_t)r]);
+    if (rc) break;
+    bool all_done = true, any_done = false;
+    for (auto& run : runs) { all_done = all_done && run.st.done; any_done = any_done || run.st.done; }
+    if (all_done) break;
+    if (any_done) rc = fail(CC_ERR_STATE, "cc_rig_optimize_multi: the shards disagree about termination");
+  }
+  if (!rc) rc = rig_finish(hs[0], &runs[0], summary);
+  for (int r = 0; r < n && !rc; ++r) {
+    const int64_t f0 = first[(size_t)r];
+    rc = cc_rig_get_state(hs[(size_t)r], r == 0 ? cam_q : nullptr, r == 0 ? cam_t : nullptr, frame_q + 4 * f0, frame_t + 3 * f0,
+                          obs_cost ? obs_cost + off[f0] : nullptr);
+  }
+  const std::string err = rc ? last_error() : std::string();
+  for (auto* h : hs) if (h) { hipSetDevice(h->device); hipStreamSynchronize(h->stream); }   // nobody frees a mailbox a peer still writes
+  for (auto* h : hs) cc_rig_destroy(h);
+  if (rc) last_error() = err;
   return rc;
 }
 

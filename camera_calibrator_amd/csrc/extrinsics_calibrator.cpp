@@ -104,10 +104,17 @@ void ExtrinsicsCalibrator::Optimize() {
   const double huber_a = 3.0f / 500.0f;  // extrinsics_calibrator.cpp:176 (float literal, as in the reference)
   last_status_ = 0;
   if (N > 0 && C > 0 && F > 0) {
-    last_status_ = cc_rig_optimize(&options, device_, (int64_t)C, (int64_t)F, (int64_t)Pn, offsets.data(), obs_cam.data(),
-                                   obs_world.data(), obs_uv.data(), world.data(), cam_q.data(), cam_t.data(), frozen.data(),
-                                   frame_q.data(), frame_t.data(), huber_a, half_rho.data(), &summary);
-    if (last_status_ == CC_ERR_NO_DEVICE || last_status_ == CC_ERR_HIP || last_status_ == CC_ERR_BAD_ARGUMENT)
+    if (devices_.size() > 1) {
+      std::vector<int32_t> devs(devices_.begin(), devices_.end());
+      last_status_ = cc_rig_optimize_multi(&options, (int32_t)devs.size(), devs.data(), (int64_t)C, (int64_t)F, (int64_t)Pn, offsets.data(),
+                                           obs_cam.data(), obs_world.data(), obs_uv.data(), world.data(), cam_q.data(), cam_t.data(),
+                                           frozen.data(), frame_q.data(), frame_t.data(), huber_a, half_rho.data(), &summary);
+    } else {
+      last_status_ = cc_rig_optimize(&options, device_, (int64_t)C, (int64_t)F, (int64_t)Pn, offsets.data(), obs_cam.data(),
+                                     obs_world.data(), obs_uv.data(), world.data(), cam_q.data(), cam_t.data(), frozen.data(),
+                                     frame_q.data(), frame_t.data(), huber_a, half_rho.data(), &summary);
+    }
+    if (last_status_ == CC_ERR_NO_DEVICE || last_status_ == CC_ERR_HIP || last_status_ == CC_ERR_BAD_ARGUMENT || last_status_ == CC_ERR_COMM)
       throw std::runtime_error(std::string("ExtrinsicsCalibrator::Optimize: ") + cc_last_error());  // no silent CPU path
   }
   last_iterations_ = summary.iterations;

@@ -38,7 +38,9 @@ class ExtrinsicsCalibrator {
   void RemoveObservationFrames(const std::vector<size_t> observation_frame_ids);
 
   // ---- additions of this build (not in the reference) ----
-  void SetDevice(int device) { device_ = device; }
+  void SetDevice(int device) { device_ = device; devices_.clear(); }
+  /// Several GPUs: the observation frames are sharded over them, one host thread drives all (cc_rig_optimize_multi).
+  void SetDevices(const std::vector<int>& devices) { devices_ = devices; if (!devices.empty()) device_ = devices[0]; }
   void SetVerbose(bool verbose) { verbose_ = verbose; }
   int LastStatus() const { return last_status_; }
   int LastIterations() const { return last_iterations_; }
@@ -77,6 +79,7 @@ class ExtrinsicsCalibrator {
   std::vector<PointRef> point_refs_;
   std::set<size_t> frozen_;
   int device_{0};
+  std::vector<int> devices_;
   bool verbose_{true};
   int last_status_{0};
   int last_iterations_{0};

@@ -144,6 +144,17 @@ int cc_intrinsics_optimize(const cc_options* opt, int32_t device, int64_t n_fram
                            double* intr9, uint32_t const_mask, double* q_wxyz, double* t_xyz,
                            cc_summary* summary);
 
+/* Multi-GPU inside ONE process, ONE host thread (SURVEY.md 8(b) thread model): the one-shot call over several
+ * devices. Frames are sharded contiguously by observation count (cc_partition_frames), one handle + stream per
+ * device, the per-iteration exchange (112 + 16 doubles) goes through mailboxes in peer HBM wired inside the process
+ * (hipDeviceEnablePeerAccess, no hipIpc), every device's launches are enqueued before any device is waited for.
+ * devices[i] may repeat (several shards on one GPU). n_devices 1..8; with 1 it is cc_intrinsics_optimize.
+ * Calibrator::SetDevices selects it behind the class surface. */
+int cc_intrinsics_optimize_multi(const cc_options* opt, int32_t n_devices, const int32_t* devices,
+                                 int64_t n_frames, const int64_t* frame_offsets, const float* uv,
+                                 const float* xyz, double* intr9, uint32_t const_mask, double* q_wxyz,
+                                 double* t_xyz, cc_summary* summary);
+
 /* Multi-GPU: one process per GPU, each owning a contiguous shard of frames. Rank 0 calls
  * cc_comm_get_unique_id and broadcasts the 128 bytes (e.g. over torch.distributed); every rank
  * then attaches its handle. Per LM iteration the handles all-reduce (RCCL, sum, fp64) only the
@@ -240,6 +251,15 @@ int cc_rig_optimize(const cc_options* opt, int32_t device, int64_t n_cams, int64
                     const uint64_t* obs_world, const float* obs_uv, const float* world_xyz,
                     double* cam_q, double* cam_t, const uint8_t* cam_frozen, double* frame_q,
                     double* frame_t, double huber_a, double* obs_cost, cc_summary* summary);
+
+/* The same over several devices from one host thread (cf. cc_intrinsics_optimize_multi): frames sharded, cameras and
+ * world points replicated; ExtrinsicsCalibrator::SetDevices selects it behind the class surface. */
+int cc_rig_optimize_multi(const cc_options* opt, int32_t n_devices, const int32_t* devices, int64_t n_cams,
+                          int64_t n_frames, int64_t n_world, const int64_t* obs_frame_offsets,
+                          const uint32_t* obs_cam, const uint64_t* obs_world, const float* obs_uv,
+                          const float* world_xyz, double* cam_q, double* cam_t, const uint8_t* cam_frozen,
+                          double* frame_q, double* frame_t, double huber_a, double* obs_cost,
+                          cc_summary* summary);
 
 /* ---------------------------------------------------------------------------------------------
  * Zhang's closed-form initialisation on the device: what Calibrator::Estimate does before calling

@@ -18,16 +18,24 @@ from camera_calibrator_amd import capi
 C, F, M = int(os.environ.get("C", 4)), int(os.environ.get("F", 400)), int(os.environ.get("M", 300))
 K = os.environ.get("K", "none")
 REPS = int(os.environ.get("REPS", 5))
-sc = capi.rig_scenario(C, F, M)
-cq, ct = capi.affine_to_qt(sc["cam_T"])
-fq, ft = capi.affine_to_qt(sc["frame_T"])
 if K == "none":
+    sc = capi.rig_scenario(C, F, M)
+    cq, ct = capi.affine_to_qt(sc["cam_T"])
+    fq, ft = capi.affine_to_qt(sc["frame_T"])
+    n_obs = len(sc["obs_cam"])
     prob = capi.RigProblem(C, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"], sc["world_xyz"], sc["cam_frozen"])
 else:
-    px = (sc["obs_uv"].astype(np.float64) * 1000.0 + np.array([800.0, 500.0])).astype(np.float32)
-    prob = capi.RigProblem(C, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], px, sc["world_xyz"], sc["cam_frozen"], huber_a=0.0,
+    from camera_calibrator_amd import harness
+    k = harness.rigk_case(C, F, M, per_camera=K == "per_camera")
+    cq, ct, fq, ft = k["cam_q0"], k["cam_t0"], k["frame_q0"], k["frame_t0"]
+    n_obs = len(k["obs_cam"])
+    prob = capi.RigProblem(C, k["frame_offsets"], k["obs_cam"], k["obs_world"], k["obs_uv_pix"], k["world_xyz"], k["cam_frozen"], huber_a=0.0,
                            with_intrinsics=True if K == "shared" else "per_camera")
-    prob.set_intrinsics(np.array([1020.0, 980.0, 805.0, 495.0, 0, 0, 0, 0, 0]), 0)
+    if K == "shared":
+        prob.set_intrinsics(k["intr0"], 0)
+    else:
+        for c in range(C):
+            prob.set_camera_intrinsics(c, k["intr0"][c], 0)
 prob.set_state(cq, ct, fq, ft)
 o = capi.default_options(max_iterations=1000)
 s = prob.solve(o, log_capacity=0)
@@ -37,7 +45,6 @@ for _ in range(REPS):
     t0 = time.perf_counter()
     s = prob.solve(o, log_capacity=0)
     ts.append(time.perf_counter() - t0)
-n_obs = len(sc["obs_cam"])
 print(json.dumps(dict(cams=C, frames=F, pts=M, intrinsics=K, observations=n_obs, iterations=s["iterations"], termination=s["termination"],
                       gpu_solve_ms=float(np.median(ts) * 1e3), gpu_us_per_iteration=float(np.median(ts) * 1e6 / max(1, s["iterations"])),
                       gpu_residuals_per_s=2.0 * n_obs * s["iterations"] / float(np.median(ts)), final_cost=s["final_cost"])))
