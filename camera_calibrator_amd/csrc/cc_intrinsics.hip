@@ -28,6 +28,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -47,14 +48,15 @@ enum { PC_S = 0, PC_B = 45, PC_HDIAG = 54, PC_FAIL = 63, PC_GS = 64, PC_GMAXP = 
 
 struct IntrDev {
   int64_t F, N;
+  int32_t T, tpad_;   // sweep workgroups (tiles of observations) per frame: 1, or more when there are too few frames to fill the chip
   const float* uv;
   const float* xyz;
   const int64_t* off;
   double* intr;       // [2][16]
   double* pose;       // [2][F][8]
-  double* blocks;     // [2][F][256]
-  double* stats;      // [F][4]
-  double* hd0;        // [F][16] diag of H_ss,f at the initial point (Jacobi scaling)
+  double* blocks;     // [2][F][T][256]: per-tile partial Gram blocks (the consumers add the T tiles)
+  double* stats;      // [F*T][4]
+  double* hd0;        // [F*T][16] diag of H_ss (per tile) at the initial point (Jacobi scaling)
   double* sp;         // [F][8]  Jacobi scale of the pose block
   double* Y;          // [F][64]
   double* partial;    // [kElimMaxBlocks][80]
@@ -141,7 +143,10 @@ __device__ __forceinline__ void row_v(const double* k, const ObsCommon& c, doubl
 }
 
 // ---------------------------------------------------------------------------------------------
-// sweep: one workgroup (4 waves) per frame
+// sweep: one workgroup (4 waves) per frame -- or, when the frames alone cannot fill the chip (a shard of a
+// strong-scaled problem: 125 frames per GPU at eight GPUs), T workgroups per frame, each sweeping a contiguous
+// tile of the frame's observations into a partial Gram block of its own (the elimination adds the T tiles).
+// Every tile repeats the (cheap) pose update of its frame; tile 0 alone publishes it and owns the model-cost term.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int in_solve) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -149,7 +154,9 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
   double* s_blk = s_stage;                                      // [2048] cross-wave reduce + block copy (after the loop)
   double* sm = s_stage + 4 * kStageDoublesPerWave;              // [256] prologue scratch
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t f = blockIdx.x;
+  const int T = P.T;
+  const int64_t f = (int64_t)blockIdx.x / T;
+  const int tile = (int)(blockIdx.x - f * T);
   // ---- one global round trip gathers every input of the prologue; nothing in it depends on the
   // control block (both buffers of the ping-pong state are fetched, the right one is picked later)
   // sm[0..59] Y, [60..66] pose buf 0, [67..73] pose buf 1, [74..82] intr buf 0, [83..91] intr buf 1,
@@ -158,7 +165,12 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
   // sm[158] step^2 (pose part), sm[159] |x_cand|^2 (pose part); sm[160..169] pose/intr of `cur`
   const LmCtl* ctl = P.ctl;
   const int done = ctl->done, phase = ctl->phase, step_valid = ctl->step_valid, cur = ctl->cur;
-  const int64_t s0 = P.off[f], s1 = P.off[f + 1];
+  int64_t s0 = P.off[f], s1 = P.off[f + 1];
+  if (T > 1) {   // this workgroup's tile of the frame
+    const int64_t len = (s1 - s0 + T - 1) / T;
+    s0 = s0 + tile * len < s1 ? s0 + tile * len : s1;
+    s1 = s0 + len < s1 ? s0 + len : s1;
+  }
   if (tid < 116) {
     double v;
     if (tid < 60) v = P.Y[f * kYStride + tid];
@@ -171,14 +183,19 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
     else v = P.sp[f * 8 + (tid - 110)];
     sm[tid] = v;
   }
-  const double g_old0 = P.blocks[(size_t)f * 256 + tid];
-  const double g_old1 = P.blocks[((size_t)P.F + f) * 256 + tid];
+  double g_old0 = 0.0, g_old1 = 0.0;
+  if (tile == 0) {   // previous Gram block of the frame (model-cost term): sum of its tiles
+    for (int k = 0; k < T; ++k) {
+      g_old0 += P.blocks[((size_t)f * T + k) * 256 + tid];
+      g_old1 += P.blocks[(((size_t)P.F + f) * T + k) * 256 + tid];
+    }
+  }
   if (done) return;
   if (phase != 0 && !step_valid) return;
   // mailbox exchange: this round's statistics will be exchanged by decide_elim<3> (which evaluates the
   // same predicate); advance their epoch here so that it cannot change while that kernel reads it.
   // Only sweeps that belong to a solve count (cc_intrinsics_eval / profile_sweep are rank-local).
-  if (P.x.on && in_solve && f == 0 && tid == 0) P.x.seq[1] += 1ull;
+  if (P.x.on && in_solve && blockIdx.x == 0 && tid == 0) P.x.seq[1] += 1ull;
   const int dst = phase == 0 ? cur : (cur ^ 1);
   const double g_old = cur ? g_old1 : g_old0;
   // first pass of observations: issued now, consumed after the prologue
@@ -209,7 +226,7 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
     sm[120 + j] = d;
     const double kc = sm[intr_o + j] + d;
     sm[148 + j] = kc;
-    if (f == 0 && phase != 0) P.intr[dst * 16 + j] = kc;
+    if (blockIdx.x == 0 && phase != 0) P.intr[dst * 16 + j] = kc;
   }
   __syncthreads();
   if (tid == 0) {
@@ -228,11 +245,13 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
       for (int i = 0; i < 4; ++i) { const double d = qn[i] - q[i]; step2 += d * d; q[i] = qn[i]; }
 #pragma unroll
       for (int i = 0; i < 3; ++i) { const double tn = t[i] + dp[3 + i]; const double d = tn - t[i]; step2 += d * d; t[i] = tn; }
-      double* pose_dst = P.pose + ((size_t)dst * P.F + f) * 8;
+      if (tile == 0) {
+        double* pose_dst = P.pose + ((size_t)dst * P.F + f) * 8;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) pose_dst[i] = q[i];
+        for (int i = 0; i < 4; ++i) pose_dst[i] = q[i];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) pose_dst[4 + i] = t[i];
+        for (int i = 0; i < 3; ++i) pose_dst[4 + i] = t[i];
+      }
     }
     double R[9];
     quat_to_R(q, R);
@@ -248,7 +267,7 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
   // model-cost term of this frame: q_f = d^T g_f + 1/2 d^T H_f d over the frame's 15x15 block at
   // the accepted point (Ceres: model_cost_change = -(J d)^T (r + J d / 2))
   double qterm = 0.0;
-  if (phase != 0) {
+  if (phase != 0 && tile == 0) {
     const int a = tid >> 4, b = tid & 15;
     if (a < 15) qterm = b < 15 ? 0.5 * sm[120 + a] * g_old * sm[120 + b] : sm[120 + a] * g_old;
   }
@@ -312,21 +331,20 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
   if (lane == 0) sm[170 + wave] = qw;
   __syncthreads();
   const double g = (s_blk[tid] + s_blk[256 + tid]) + (s_blk[512 + tid] + s_blk[768 + tid]);
-  P.blocks[((size_t)dst * P.F + f) * 256 + tid] = g;
+  P.blocks[(((size_t)dst * P.F + f) * T + tile) * 256 + tid] = g;
   double* G = s_blk + 1024;  // full block for the few threads that derive per-frame scalars
   G[tid] = g;
   __syncthreads();
-  if (tid == 0) {
-    double* st = P.stats + f * kStatsCols;
+  if (tid == 0) {   // per-tile statistics row; the per-frame quantities ride on tile 0
+    double* st = P.stats + (size_t)blockIdx.x * kStatsCols;
     st[ST_COST] = 0.5 * G[255];
     st[ST_QMODEL] = (sm[170] + sm[171]) + (sm[172] + sm[173]);
-    st[ST_STEP2] = sm[158];
-    st[ST_XNORM2] = sm[159];
+    st[ST_STEP2] = tile == 0 ? sm[158] : 0.0;
+    st[ST_XNORM2] = tile == 0 ? sm[159] : 0.0;
   }
-  if (phase == 0) {
-    if (tid < 6) P.sp[f * 8 + tid] = P.opts->jacobi_scaling ? 1.0 / (1.0 + sqrt(G[(9 + tid) * 17])) : 1.0;
-    else if (tid >= 16 && tid < 25) P.hd0[f * 16 + (tid - 16)] = G[(tid - 16) * 17];
-  }
+  // initial evaluation: diagonal of the shared block for its Jacobi scale (the pose blocks' scale needs the sum
+  // over the tiles: the first elimination derives it, k_intr_decide_elim)
+  if (phase == 0 && tid >= 16 && tid < 25) P.hd0[(size_t)blockIdx.x * 16 + (tid - 16)] = G[(tid - 16) * 17];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -343,12 +361,13 @@ __device__ __forceinline__ void reduce_frame_stats(const IntrDev& P, bool want_s
   if (want_stats) {
     // 16 independent loads in flight per thread: one round trip per 1024 frames
     const int col = tid & 3;
-    for (int64_t fb = tid >> 2; fb < P.F; fb += 16 * 64) {
+    const int64_t R = P.F * P.T;   // one row per sweep workgroup
+    for (int64_t fb = tid >> 2; fb < R; fb += 16 * 64) {
       double v[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         const int64_t f = fb + u * 64;
-        v[u] = f < P.F ? P.stats[f * kStatsCols + col] : 0.0;
+        v[u] = f < R ? P.stats[f * kStatsCols + col] : 0.0;
       }
       a += (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
            (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
@@ -363,12 +382,13 @@ __device__ __forceinline__ void reduce_frame_stats(const IntrDev& P, bool want_s
   if (want_hd) {
     const int cp = tid & 7;
     const d2* hd2 = reinterpret_cast<const d2*>(P.hd0);
-    for (int64_t fb = tid >> 3; fb < P.F; fb += 16 * 32) {
+    const int64_t R = P.F * P.T;
+    for (int64_t fb = tid >> 3; fb < R; fb += 16 * 32) {
       d2 v[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         const int64_t f = fb + u * 32;
-        v[u] = f < P.F ? hd2[f * 8 + cp] : d2{0.0, 0.0};
+        v[u] = f < R ? hd2[f * 8 + cp] : d2{0.0, 0.0};
       }
       h0 += (((v[0].x + v[1].x) + (v[2].x + v[3].x)) + ((v[4].x + v[5].x) + (v[6].x + v[7].x))) +
             (((v[8].x + v[9].x) + (v[10].x + v[11].x)) + ((v[12].x + v[13].x) + (v[14].x + v[15].x)));
@@ -514,6 +534,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish) {
   __shared__ double Zs[16][64];
   __shared__ double red[16][kPartialCols];
+  __shared__ double Gs[16 * 256];   // tiled frames only: the 16 frames' Gram blocks summed over their tiles
   __shared__ double s_w[128];
   __shared__ double s_tot[16];
   __shared__ double s_ss[16];
@@ -610,6 +631,8 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
 #endif
   if (!stop) {
   const int cur = s_ctl.cur;
+  const int T = P.T;
+  const bool jac = P.opts->jacobi_scaling != 0;
   const double inv_radius = 1.0 / s_ctl.radius;
   const double mn = P.opts->min_lm_diagonal, mx = P.opts->max_lm_diagonal;
 
@@ -641,25 +664,59 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
   for (int64_t base = (int64_t)blockIdx.x * 16; base < P.F; base += (int64_t)gridDim.x * 16) {
     const int64_t f = base + g;
     const bool valid = f < P.F;
-    const double* G = P.blocks + ((size_t)cur * P.F + (valid ? f : 0)) * 256;
+    const double* G = P.blocks + ((size_t)cur * P.F + (valid ? f : 0)) * T * 256;
+    // entry `idx` of the frame's Gram block. Tiled frames (T > 1): the block's 16 frames are summed over their
+    // tiles into LDS first (T round trips of 16 coalesced loads per thread), then read from there.
+    if (T > 1) {
+      __syncthreads();   // (previous iteration's readers)
+      double a[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) a[u] = 0.0;
+      for (int k = 0; k < T; ++k) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int64_t fu = base + u;
+          v[u] = fu < P.F ? P.blocks[(((size_t)cur * P.F + fu) * T + k) * 256 + tid] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a[u] += v[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) Gs[u * 256 + tid] = a[u];
+      __syncthreads();
+    }
+    const double* Gl = Gs + g * 256;
+    auto gsum = [&](int idx) { return T > 1 ? Gl[idx] : G[idx]; };
     double fail = 0.0;
     double gv[5];
 #pragma unroll
-    for (int r = 0; r < 5; ++r) gv[r] = G[gi[r]];
-    const double gp = fabs(G[(9 + l6) * 16 + 15]);
+    for (int r = 0; r < 5; ++r) gv[r] = gsum(gi[r]);
+    const double gp = fabs(gsum((9 + l6) * 16 + 15));
     // column l (< 10) of [H_ps | g_p], loaded with everything else in one round trip
     const int col = l < 9 ? l : 15;
     double w[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) w[i] = G[(9 + i) * 16 + col];
+    for (int i = 0; i < 6; ++i) w[i] = gsum((9 + i) * 16 + col);
     if (valid) {
       double s[6], L[21];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) s[i] = P.sp[f * 8 + i];
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) L[tri(i, j)] = gsum((9 + i) * 16 + 9 + j);
+      if (phase == 0) {
+        // first elimination: Jacobi scale of this frame's pose block (Ceres: 1 / (1 + sqrt(diag J^T J)), once)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s[i] = jac ? 1.0 / (1.0 + sqrt(L[tri(i, i)])) : 1.0;
+        if (l < 6) P.sp[f * 8 + l] = jac ? 1.0 / (1.0 + sqrt(gsum((9 + l) * 17))) : 1.0;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s[i] = P.sp[f * 8 + i];
+      }
 #pragma unroll
       for (int i = 0; i < 6; ++i)
 #pragma unroll
-        for (int j = 0; j <= i; ++j) L[tri(i, j)] = s[i] * G[(9 + i) * 16 + 9 + j] * s[j];
+        for (int j = 0; j <= i; ++j) L[tri(i, j)] = s[i] * L[tri(i, j)] * s[j];
 #pragma unroll
       for (int i = 0; i < 6; ++i) L[tri(i, i)] += clampd(L[tri(i, i)], mn, mx) * inv_radius;
       // in-place Cholesky (lower), fully unrolled so L stays in registers (redundant per lane);
@@ -975,7 +1032,7 @@ struct Probe {  // optional hipEvent bracket around one launch
 
 static void launch_sweep(cc_intrinsics* h, bool profile, bool in_solve = false) {
   Probe p(h, CC_K_SWEEP, profile);
-  hipLaunchKernelGGL(k_intr_sweep, dim3((unsigned)h->F), dim3(kSweepThreads), kSweepLdsBytes, h->stream, h->d, in_solve ? 1 : 0);
+  hipLaunchKernelGGL(k_intr_sweep, dim3((unsigned)(h->F * h->d.T)), dim3(kSweepThreads), kSweepLdsBytes, h->stream, h->d, in_solve ? 1 : 0);
 }
 
 static void launch_reset(cc_intrinsics* h) {
@@ -1070,6 +1127,8 @@ int cc_intrinsics_create(int32_t device, int64_t F, const int64_t* off, const fl
   for (int64_t f = 0; f < F; ++f)
     if (off[f + 1] < off[f]) return fail(CC_ERR_BAD_ARGUMENT, "frame_offsets must be non-decreasing");
   const int64_t N = off[F];
+  if (F >= ((int64_t)1 << 28) || N >= ((int64_t)1 << 40))   // launch grids are 32-bit (F * tiles workgroups)
+    return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_create: problem too large (frames < 2^28, observations < 2^40)");
   if (N > 0 && (!uv || !xyz)) return fail(CC_ERR_BAD_ARGUMENT, "uv/xyz are NULL");
   if (int rc = select_device(device)) return rc;
   cc_intrinsics* h = new cc_intrinsics();
@@ -1116,6 +1175,20 @@ int intr_create_impl(cc_intrinsics* h, const int64_t* off, const float* uv, cons
   if (int rc = stream_get(h->device, &h->stream)) return rc;
   IntrDev& d = h->d;
   d.F = F; d.N = N; d.rank = 0; d.nranks = 1; d.mask = 0;
+  {
+    // Sweep workgroups per frame. A frame is cut into tiles only when that shortens the critical path of the
+    // iteration: few frames (every tile still gets a CU of its own) AND long ones (a tile keeps at least two passes
+    // of 256 observations). Measured on MI355X (scripts/time_sweep_tiles.py, profiles/r02/sweep_tiles.jsonl): at
+    // 125 x 500 two tiles take the sweep from 8.5 to 7.2 us but cost the elimination as much (it adds the tiles up),
+    // so shards of BASELINE configs[2] stay untiled; 32 frames x 4000 points is where tiles pay.
+    // CC_SWEEP_TILES overrides (tests, experiments).
+    const int64_t per_frame = F > 0 ? (N + F - 1) / F : 0;
+    int64_t T = std::min<int64_t>((per_frame + 2 * kSweepThreads - 1) / (2 * kSweepThreads), 256 / std::max<int64_t>(F, 1));
+    if (const char* env = getenv("CC_SWEEP_TILES")) T = atoi(env);
+    d.T = (int32_t)std::max<int64_t>(1, std::min<int64_t>(T, 8));
+    d.tpad_ = 0;
+  }
+  const size_t FT = (size_t)F * d.T;
   // One device arena for every buffer of the handle: a one-shot caller (Calibrator::Optimize) pays for
   // one hipMalloc / hipMemset / hipFree instead of two dozen of each (destroy: 1.3 ms -> 0.1 ms).
   // Layout: [zero-initialised state | observations], 256-byte aligned pieces.
@@ -1125,8 +1198,8 @@ int intr_create_impl(cc_intrinsics* h, const int64_t* off, const float* uv, cons
   d.log_cap = 4096;
   const size_t o_intr = take(2 * 16 * sizeof(double));
   const size_t o_pose = take((size_t)2 * F * 8 * sizeof(double));
-  const size_t o_stats = take((size_t)F * kStatsCols * sizeof(double));
-  const size_t o_hd0 = take((size_t)F * 16 * sizeof(double));
+  const size_t o_stats = take(FT * kStatsCols * sizeof(double));
+  const size_t o_hd0 = take(FT * 16 * sizeof(double));
   const size_t o_sp = take((size_t)F * 8 * sizeof(double));
   const size_t o_Y = take((size_t)F * kYStride * sizeof(double));
   const size_t o_partial = take((size_t)kElimMaxBlocks * kPartialCols * sizeof(double));
@@ -1141,7 +1214,7 @@ int intr_create_impl(cc_intrinsics* h, const int64_t* off, const float* uv, cons
   const size_t o_iintr = take(16 * sizeof(double));
   const size_t o_ipose = take((size_t)F * 8 * sizeof(double));
   const size_t zeroed = cursor;                       // everything above starts as zeros
-  const size_t o_blocks = take((size_t)2 * F * 256 * sizeof(double));
+  const size_t o_blocks = take((size_t)2 * FT * 256 * sizeof(double));
   const size_t o_log = take((size_t)d.log_cap * sizeof(cc_iteration));
   const size_t o_uv = take(n1 * 2 * sizeof(float));
   const size_t o_xyz = take(n1 * 3 * sizeof(float));
@@ -1279,13 +1352,26 @@ int cc_intrinsics_eval(cc_intrinsics* h, double* blocks, double* cost) {
   CC_HIP(hipMemcpyAsync(h->d.ctl, &st, sizeof(st), hipMemcpyHostToDevice, h->stream));
   CC_HIP(hipStreamSynchronize(h->stream));
   const int cur = st.cur & 1;
-  if (blocks)
-    CC_HIP(hipMemcpy(blocks, h->d.blocks + (size_t)cur * h->F * 256, (size_t)h->F * 256 * sizeof(double), hipMemcpyDeviceToHost));
+  const int64_t T = h->d.T, FT = h->F * T;
+  if (blocks) {
+    if (T == 1) {
+      CC_HIP(hipMemcpy(blocks, h->d.blocks + (size_t)cur * h->F * 256, (size_t)h->F * 256 * sizeof(double), hipMemcpyDeviceToHost));
+    } else {   // a frame's block is the sum of its tiles
+      std::vector<double> tiles((size_t)FT * 256);
+      CC_HIP(hipMemcpy(tiles.data(), h->d.blocks + (size_t)cur * FT * 256, tiles.size() * sizeof(double), hipMemcpyDeviceToHost));
+      for (int64_t f = 0; f < h->F; ++f)
+        for (int i = 0; i < 256; ++i) {
+          double a = tiles[(size_t)(f * T) * 256 + i];
+          for (int64_t k = 1; k < T; ++k) a += tiles[(size_t)(f * T + k) * 256 + i];
+          blocks[(size_t)f * 256 + i] = a;
+        }
+    }
+  }
   if (cost) {
-    std::vector<double> stats((size_t)h->F * kStatsCols);
+    std::vector<double> stats((size_t)FT * kStatsCols);
     CC_HIP(hipMemcpy(stats.data(), h->d.stats, stats.size() * sizeof(double), hipMemcpyDeviceToHost));
     double c = 0.0;
-    for (int64_t f = 0; f < h->F; ++f) c += stats[f * kStatsCols + ST_COST];
+    for (int64_t f = 0; f < FT; ++f) c += stats[f * kStatsCols + ST_COST];
     *cost = c;
   }
   return CC_OK;
