@@ -14,6 +14,9 @@ namespace py = pybind11;
 
 #ifdef CC_HAVE_EIGEN
 #include <pybind11/eigen.h>
+// With Eigen the Affine3f <-> 4x4 conversion has to be the reference's own caster (src/binds.cpp:10-45): it is
+// part of the interface (only the top 3x4 is read on load) and is restated here as it stands there. Dead code in
+// this image (no Eigen installed); the mini_eigen casters below are what runs.
 namespace pybind11 { namespace detail {
 template <typename T> struct type_caster<Eigen::Transform<T, 3, 2, 0>> {
   using Type = Eigen::Transform<T, 3, 2, 0>;

@@ -1276,13 +1276,21 @@ extern "C" {
 void cc_intrinsics_destroy(cc_intrinsics* h) {
   if (!h) return;
   hipSetDevice(h->device);
-  if (h->stream) hipStreamSynchronize(h->stream);
+  bool stream_ok = true;
+  if (h->stream) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    stream_ok = hipStreamSynchronize(h->stream) == hipSuccess &&
+                hipStreamIsCapturing(h->stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
+    (void)hipGetLastError();
+  }
   cc::drop_graphs(h);
+  for (auto e : h->events) hipEventDestroy(e);
   if (h->comm) cc::comm_destroy(h->comm);
   cc::exchange_release(h);
   if (h->arena) hipFree(h->arena);
   cc::pinned_block_put(h->pinned);
-  cc::stream_put(h->device, h->stream);   // synchronised above
+  if (stream_ok) cc::stream_put(h->device, h->stream);   // idle and reusable
+  else if (h->stream) hipStreamDestroy(h->stream);      // never hand a failed / capturing stream to the next handle
   delete h;
 }
 

@@ -89,27 +89,37 @@ static void inv3f(const float* m, float* o) {
 }
 
 static int run_points(int device, const float* K, const float* dist, int64_t n, const float* in, float* out, bool undist) {
-  if (n < 0 || !K || !dist || (n > 0 && (!in || !out))) return fail(CC_ERR_BAD_ARGUMENT, "cc_(un)distort: bad arguments");
+  if (n < 0 || n >= ((int64_t)1 << 39) || !K || !dist || (n > 0 && (!in || !out)))   // 32-bit launch grid of 256-thread blocks
+    return fail(CC_ERR_BAD_ARGUMENT, "cc_(un)distort: bad arguments");
   if (int rc = select_device(device)) return rc;
   if (n == 0) return CC_OK;
   PointParams P;
   P.fx = K[0]; P.fy = K[4]; P.px = K[2]; P.py = K[5];
   P.k1 = dist[0]; P.k2 = dist[1]; P.p1 = dist[2]; P.p2 = dist[3]; P.k3 = dist[4];
   inv3f(K, P.Ki);
-  float2 *din = nullptr, *dout = nullptr;
+  // one scratch allocation (input | output) and a cached stream per call: the Python workflow calls this once per
+  // frame (cam_calibration.py:85-97), so the fixed cost matters more than the kernel
+  hipStream_t stream = nullptr;
+  if (int rc = stream_get(device, &stream)) return rc;
+  float2* buf = nullptr;
   struct Release {
-    float2 **a, **b;
-    ~Release() { hipFree(*a); hipFree(*b); }
-  } release{&din, &dout};
-  CC_HIP(hipMalloc(&din, (size_t)n * sizeof(float2)));
-  CC_HIP(hipMalloc(&dout, (size_t)n * sizeof(float2)));
-  CC_HIP(hipMemcpy(din, in, (size_t)n * sizeof(float2), hipMemcpyHostToDevice));
+    float2** p; int device; hipStream_t s;
+    ~Release() {
+      const bool ok = hipStreamSynchronize(s) == hipSuccess;
+      if (*p) hipFree(*p);
+      if (ok) stream_put(device, s); else hipStreamDestroy(s);
+    }
+  } release{&buf, device, stream};
+  CC_HIP(hipMalloc(&buf, (size_t)2 * n * sizeof(float2)));
+  float2 *din = buf, *dout = buf + n;
+  CC_HIP(hipMemcpyAsync(din, in, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, stream));
   const int threads = 256;
   const unsigned blocks = (unsigned)((n + threads - 1) / threads);
-  if (undist) hipLaunchKernelGGL(k_undistort, dim3(blocks), dim3(threads), 0, 0, P, n, din, dout);
-  else hipLaunchKernelGGL(k_distort, dim3(blocks), dim3(threads), 0, 0, P, n, din, dout);
+  if (undist) hipLaunchKernelGGL(k_undistort, dim3(blocks), dim3(threads), 0, stream, P, n, din, dout);
+  else hipLaunchKernelGGL(k_distort, dim3(blocks), dim3(threads), 0, stream, P, n, din, dout);
   CC_HIP(hipGetLastError());
-  CC_HIP(hipMemcpy(out, dout, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost));
+  CC_HIP(hipMemcpyAsync(out, dout, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost, stream));
+  CC_HIP(hipStreamSynchronize(stream));
   return CC_OK;
 }
 

@@ -307,6 +307,8 @@ extern "C" int cc_zhang_init(int32_t device, int64_t F, const int64_t* off, cons
   for (int64_t f = 0; f < F; ++f)
     if (off[f + 1] - off[f] < 4) return fail(CC_ERR_BAD_ARGUMENT, "cc_zhang_init: frame %lld has fewer than 4 points", (long long)f);
   const int64_t N = off[F];
+  if (F >= ((int64_t)1 << 28) || N >= ((int64_t)1 << 40))   // launch grids are 32-bit
+    return fail(CC_ERR_BAD_ARGUMENT, "cc_zhang_init: problem too large (frames < 2^28, observations < 2^40)");
   if (!uv || !xyz) return fail(CC_ERR_BAD_ARGUMENT, "cc_zhang_init: NULL arrays");
   if (int rc = select_device(device)) return rc;
   // one scratch arena (one hipMalloc / hipFree per call), 256-byte aligned pieces

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_sample_line_has_every_contract_field():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r01", "bench_sample.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02", "bench_sample.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -23,6 +23,10 @@ def test_committed_sample_line_has_every_contract_field():
     c = d["cpu_baseline"]
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(c) and c["kind"] in ("reference", "port") and c["cores"] == 1
     assert abs(d["value"] - 2 * d["config"]["observations_total"] * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+    # round 2: the rig configurations ride in the same line, the CPU baseline says how it was built
+    assert "-march=native" in c["sample"] and set(("rig_c4_poses", "rig_c5_poses")) <= set(d["configs"])
+    for v in d["configs"].values():
+        assert set(("iterations", "ms_per_iteration", "dominant_kernel", "dominant_kernel_ms_per_launch", "dominant_kernel_hbm_frac")) <= set(v)
 
 
 def test_bench_refuses_to_run_without_a_gpu():
