@@ -123,6 +123,8 @@ def main():
         torch.cuda.synchronize()
 
     opts = capi.default_options()
+    if os.environ.get("CC_BENCH_GRAPH") == "0":   # experiment: eager launches instead of hipGraph replays
+        opts.use_graph = 0
 
     class Leg:
         """One sharded intrinsics problem of F_total frames: this rank's handle, attached to its peers."""

@@ -53,6 +53,8 @@ struct IntrDev {
   const float* xyz;
   const int64_t* off;
   double* intr;       // [2][16]
+  const double* init_intr;   // [16]   state of the last set_state (restart source)
+  const double* init_pose;   // [F][8]
   double* pose;       // [2][F][8]
   double* blocks;     // [2][F][T][256]: per-tile partial Gram blocks (the consumers add the T tiles)
   double* stats;      // [F*T][4]
@@ -148,7 +150,7 @@ __device__ __forceinline__ void row_v(const double* k, const ObsCommon& c, doubl
 // tile of the frame's observations into a partial Gram block of its own (the elimination adds the T tiles).
 // Every tile repeats the (cheap) pose update of its frame; tile 0 alone publishes it and owns the model-cost term.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int in_solve) {
+__global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int flags) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* s_stage = reinterpret_cast<double*>(smem_raw);       // [4][1024]
   double* s_blk = s_stage;                                      // [2048] cross-wave reduce + block copy (after the loop)
@@ -163,8 +165,14 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
   // [92..100] ds (scaled), [101..109] ss, [110..115] sp
   // sm[120..134] unscaled step (9 shared, 6 pose); sm[136..144] R; [145..147] t; [148..156] intr_cand
   // sm[158] step^2 (pose part), sm[159] |x_cand|^2 (pose part); sm[160..169] pose/intr of `cur`
+  // flags: bit 0 = part of a solve (mailbox epochs advance), bit 1 = RESTART: first launch of a solve that starts
+  // from the state of the last set_state. The restart sweep ignores the stale control block (it behaves as if
+  // it were zero: initial evaluation into buffer 0), takes poses and intrinsics from the initial-state arrays and
+  // restores buffer 0 from them on the way, so a restart costs no kernel of its own.
+  const bool in_solve = (flags & 1) != 0, restart = (flags & 2) != 0;
   const LmCtl* ctl = P.ctl;
-  const int done = ctl->done, phase = ctl->phase, step_valid = ctl->step_valid, cur = ctl->cur;
+  const int done = restart ? 0 : ctl->done, phase = restart ? 0 : ctl->phase, step_valid = restart ? 0 : ctl->step_valid,
+            cur = restart ? 0 : ctl->cur;
   int64_t s0 = P.off[f], s1 = P.off[f + 1];
   if (T > 1) {   // this workgroup's tile of the frame
     const int64_t len = (s1 - s0 + T - 1) / T;
@@ -174,9 +182,9 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
   if (tid < 116) {
     double v;
     if (tid < 60) v = P.Y[f * kYStride + tid];
-    else if (tid < 67) v = P.pose[(size_t)f * 8 + (tid - 60)];
+    else if (tid < 67) v = restart ? P.init_pose[(size_t)f * 8 + (tid - 60)] : P.pose[(size_t)f * 8 + (tid - 60)];
     else if (tid < 74) v = P.pose[((size_t)P.F + f) * 8 + (tid - 67)];
-    else if (tid < 83) v = P.intr[tid - 74];
+    else if (tid < 83) v = restart ? P.init_intr[tid - 74] : P.intr[tid - 74];
     else if (tid < 92) v = P.intr[16 + (tid - 83)];
     else if (tid < 101) v = P.ds[tid - 92];
     else if (tid < 110) v = P.ss[tid - 101];
@@ -196,6 +204,11 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
   // same predicate); advance their epoch here so that it cannot change while that kernel reads it.
   // Only sweeps that belong to a solve count (cc_intrinsics_eval / profile_sweep are rank-local).
   if (P.x.on && in_solve && blockIdx.x == 0 && tid == 0) P.x.seq[1] += 1ull;
+  if (restart) {   // restore buffer 0 (what the restore kernel did) and clear the arrival counter of the elimination
+    if (tile == 0 && tid >= 60 && tid < 67) P.pose[(size_t)f * 8 + (tid - 60)] = sm[tid];
+    if (blockIdx.x == 0 && tid >= 74 && tid < 83) P.intr[tid - 74] = sm[tid];
+    if (blockIdx.x == 0 && tid == 0) *P.arrive = 0u;
+  }
   const int dst = phase == 0 ? cur : (cur ^ 1);
   const double g_old = cur ? g_old1 : g_old0;
   // first pass of observations: issued now, consumed after the prologue
@@ -546,12 +559,16 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
   constexpr bool kFused = MODE != 2;
   const int tid = threadIdx.x, g = tid >> 4, l = tid & 15;
   const LmCtl* ctl = P.ctl;
-  if (ctl->done) {
+  // bit 2 of `publish`: RESTART, first elimination of a solve from the initial state: the control block in memory
+  // is stale and counts as zero (cf. the restart sweep)
+  const bool restart = (publish & 4) != 0;
+  publish &= 3;
+  if (!restart && ctl->done) {
     if (publish && blockIdx.x == 0 && tid == 0) publish_to_host(P, *ctl);
     return;
   }
-  const int phase = ctl->phase;
-  const bool pending = ctl->cand_pending != 0;
+  const int phase = restart ? 0 : ctl->phase;
+  const bool pending = !restart && ctl->cand_pending != 0;
   const bool need = phase == 0 || (pending && ctl->step_valid);
 #if CC_ABLATE_D == 1
   if (ctl->gmax == 1e30) return;  // marker set by cc_intrinsics_profile_kernel
@@ -584,7 +601,8 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
     __syncthreads();
   }
   if (tid == 0) {
-    LmCtl c = *ctl;
+    LmCtl c{};
+    if (!restart) c = *ctl;
     const LmOpts o = *P.opts;
     const int len0 = c.log_len;
     if (phase == 0) {
@@ -819,6 +837,9 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
   __syncthreads();
   if (!s_last) return;
   if (tid == 0) __hip_atomic_store(P.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+#if CC_ABLATE_D == 7
+  if (ctl->gmax == 1e30) return;
+#endif
   double* sv = &red[0][0];            // [kVecSolve] reduced sums (the staging rows are no longer needed)
   double* s_part = &red[2][0];        // [3][kPartialCols]
   if (!stop) {
@@ -869,6 +890,9 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
       __syncthreads();
     }
   }
+#if CC_ABLATE_D == 8
+  if (ctl->gmax == 1e30) return;
+#endif
   if (tid != 0) return;
   LmCtl c = s_ctl;
   cc_iteration* e = s_logged ? &s_log : nullptr;
@@ -993,9 +1017,9 @@ struct cc_intrinsics {
   cc::LmOpts cached_opts{};     // what the device currently holds
   bool opts_valid = false;
   bool ctl_fresh = false;       // the next solve starts from the point of the last set_state
-  bool reset_pending = false;   // ... and the device buffers have not been restored yet (lazy: the restart is the
-                                // first node of the solve's graph, cc_intrinsics_reset costs no launch of its own)
-  // [0]: restart + initial evaluation + check_interval iterations, [1]: check_interval iterations,
+  bool reset_pending = false;   // ... and the device buffers have not been restored yet (lazy: the first round of the
+                                // solve runs as the restart round, cc_intrinsics_reset costs no launch of its own)
+  // [0]: initial evaluation as the restart round + check_interval iterations, [1]: check_interval iterations,
   // [2]: initial evaluation + check_interval iterations (continuing from the accepted point of the last solve)
   hipGraphExec_t graph[3] = {nullptr, nullptr, nullptr};
   int graph_iters = 0;
@@ -1030,9 +1054,9 @@ struct Probe {  // optional hipEvent bracket around one launch
   }
 };
 
-static void launch_sweep(cc_intrinsics* h, bool profile, bool in_solve = false) {
+static void launch_sweep(cc_intrinsics* h, bool profile, int flags = 0) {
   Probe p(h, CC_K_SWEEP, profile);
-  hipLaunchKernelGGL(k_intr_sweep, dim3((unsigned)(h->F * h->d.T)), dim3(kSweepThreads), kSweepLdsBytes, h->stream, h->d, in_solve ? 1 : 0);
+  hipLaunchKernelGGL(k_intr_sweep, dim3((unsigned)(h->F * h->d.T)), dim3(kSweepThreads), kSweepLdsBytes, h->stream, h->d, flags);
 }
 
 static void launch_reset(cc_intrinsics* h) {
@@ -1044,21 +1068,22 @@ static void launch_reset(cc_intrinsics* h) {
 // evaluation, same launches). RCCL route: the solve step is a pair of kernels around the all-reduce of the
 // reduced sums at the head of the round (left out of the initial round: nothing to solve yet).
 // publish: last round of a host chunk -> its final kernel hands the control block to the host.
-static int enqueue_round(cc_intrinsics* h, bool profile, bool initial, bool publish) {
-  const int pub = publish ? 1 : 0;
+static int enqueue_round(cc_intrinsics* h, bool profile, bool initial, bool publish, bool restart = false) {
+  const int pub = (publish ? 1 : 0) | (restart ? 4 : 0);
+  const int sweep_flags = 1 | (restart ? 2 : 0);
   if (h->comm) {
     if (!initial) {
       { Probe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_intr_solve<1>, dim3(1), dim3(kSolveThreads), 0, h->stream, h->d, h->elim_blocks, 0); }
       { Probe p(h, CC_K_ALLREDUCE, profile); if (int rc = comm_allreduce_sum(h->comm, h->d.vec_solve, kVecSolve, h->stream)) return rc; }
       { Probe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_intr_solve<2>, dim3(1), dim3(kSolveThreads), 0, h->stream, h->d, h->elim_blocks, 0); }
     }
-    launch_sweep(h, profile, true);
+    launch_sweep(h, profile, 1);
     { Probe p(h, CC_K_DECIDE, profile); hipLaunchKernelGGL(k_intr_stats_reduce, dim3(1), dim3(256), 0, h->stream, h->d); }
     { Probe p(h, CC_K_ALLREDUCE, profile); if (int rc = comm_allreduce_sum(h->comm, h->d.vec_decide, 16, h->stream)) return rc; }
     { Probe p(h, CC_K_ELIM, profile); hipLaunchKernelGGL(k_intr_decide_elim<2>, dim3(h->elim_blocks), dim3(256), 0, h->stream, h->d, 0); }
     return 0;
   }
-  launch_sweep(h, profile, true);
+  launch_sweep(h, profile, sweep_flags);
   Probe p(h, CC_K_ELIM, profile);
   if (h->exchange) hipLaunchKernelGGL(k_intr_decide_elim<3>, dim3(h->elim_blocks), dim3(256), 0, h->stream, h->d, pub);
   else hipLaunchKernelGGL(k_intr_decide_elim<0>, dim3(h->elim_blocks), dim3(256), 0, h->stream, h->d, pub);
@@ -1251,6 +1276,8 @@ int intr_create_impl(cc_intrinsics* h, const int64_t* off, const float* uv, cons
   d.log = reinterpret_cast<cc_iteration*>(base + o_log);
   h->init_intr = reinterpret_cast<double*>(base + o_iintr);
   h->init_pose = reinterpret_cast<double*>(base + o_ipose);
+  d.init_intr = h->init_intr;
+  d.init_pose = h->init_pose;
   static_assert(16 + sizeof(LmCtl) <= 192 && sizeof(LmCtl) <= 160 && sizeof(LmOpts) <= 160, "one cached 512-byte pinned block holds all three");
   h->pinned = pinned_block_get();
   if (!h->pinned) return fail(CC_ERR_HIP, "hipHostMalloc failed");
@@ -1388,15 +1415,16 @@ int cc_intrinsics_eval(cc_intrinsics* h, double* blocks, double* cost) {
 }  // extern "C"
 
 namespace cc {
-// Captures `rounds` rounds (optionally behind the restore kernel) into an executable graph. On any failure the
+// Captures `rounds` rounds (the first one optionally as the restart round) into an executable graph. On any failure the
 // stream is taken out of capture mode again and nothing is kept (a stream left capturing would poison the
 // process-wide stream cache it returns to).
 static int capture_chunk(cc_intrinsics* h, bool with_reset, bool initial, int rounds, hipGraphExec_t* out) {
   hipGraph_t g = nullptr;
   CC_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
   int rc = 0;
-  if (with_reset) launch_reset(h);
-  for (int i = 0; i < rounds && !rc; ++i) rc = enqueue_round(h, false, initial && i == 0, i == rounds - 1);
+  static const bool restore_kernel = getenv("CC_RESTORE_KERNEL") != nullptr;   // A/B knob: restore by a kernel of its own
+  if (with_reset && restore_kernel) launch_reset(h);
+  for (int i = 0; i < rounds && !rc; ++i) rc = enqueue_round(h, false, initial && i == 0, i == rounds - 1, with_reset && !restore_kernel && i == 0);
   const hipError_t e_end = hipStreamEndCapture(h->stream, &g);
   if (rc || e_end != hipSuccess) {
     if (g) hipGraphDestroy(g);
@@ -1475,9 +1503,11 @@ static int solve_launch(cc_intrinsics* h, SolveRun* r, int chunk) {
     CC_HIP(hipGraphLaunch(h->graph[which], h->stream));
     h->reset_pending = false;
   } else {
-    if (int rc = flush_reset(h)) return rc;
+    const bool restart = chunk == 0 && h->reset_pending && !h->comm;
+    if (restart) h->reset_pending = false;
+    else if (int rc = flush_reset(h)) return rc;
     for (int i = 0; i < n; ++i)
-      if (int rc = enqueue_round(h, r->profile, chunk == 0 && i == 0, i == n - 1)) return rc;
+      if (int rc = enqueue_round(h, r->profile, chunk == 0 && i == 0, i == n - 1, restart && i == 0)) return rc;
     CC_HIP(hipGetLastError());
   }
   r->launched += n;

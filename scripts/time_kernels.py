@@ -1,4 +1,5 @@
-"""Isolated timings of the three kernels of one intrinsics LM iteration (developer aid)."""
+"""Isolated timing of the decide + elim + solve kernel of one intrinsics LM iteration (developer aid; with an
+ablation build in CC_LIB_PATH: how far into the kernel the time goes, scripts/ablate_decide.sh)."""
 import ctypes as C
 import os
 import sys
@@ -16,7 +17,7 @@ prob = capi.IntrinsicsProblem(off, uv, xyz)
 prob.set_state(intr0, q0.astype(np.float64), t0.astype(np.float64))
 prob.solve(capi.default_options(max_iterations=2))
 out = {}
-for name, which in (("decide_elim", 1), ("solve", 2)):
+for name, which in (("decide_elim_solve", 1),):
     ts = []
     for _ in range(3):
         ms = C.c_double()
