@@ -80,6 +80,14 @@ struct RigDev {
   const int16_t* dmap;       // [DE] offset of direct entry e inside a group block
   const uint8_t* tile_i;     // [nT] tile pairs (ti <= tj), row-major upper triangle
   const uint8_t* tile_j;
+  // where the solve step puts reduced value e (host-built, rig_layout): >= 0 element of the LDS matrix (row * (S + 1)
+  // + col), -1 nowhere, <= -2 entry -(d + 2) of the gradient (direct sums) / of the right-hand side (tiles)
+  const int32_t* dir_dst;    // [ND]
+  const int32_t* dir_next;   // [ND] next direct entry that adds into the same place (an intrinsics set shared by cameras), -1: none
+  const int16_t* dir_sa;     // [ND] the two shared columns whose Jacobi scales multiply the entry
+  const int16_t* dir_sb;
+  const int32_t* tile_dst;   // [nT * 256]
+  const int32_t* colpin;     // [S] -1: free column; (intrinsics set << 4) | component: constant when that mask bit is set
   double* cam;      // [2][C][8] q(4) t(3)
   double* pose;     // [2][F][8]
   double* camrec;   // [C][32] R(9) t(3) unscaled step(6)
@@ -387,23 +395,25 @@ __global__ __launch_bounds__(kRigThreads, HK ? 2 : 4) void k_rig_sweep(RigDev P)
 }
 
 // ---------------------------------------------------------------------------------------------
-// update: per frame, back-substitute the pose step and form the candidate pose. 16 lanes/frame.
+// update: per frame, back-substitute the pose step and form the candidate pose. 16 lanes/frame, 16 frames per
+// 256-thread block (`fblk` = which sixteen). SC1: the shared step `ds` was written by another workgroup of the
+// SAME launch (fused into k_rig_reduce): read it with sc1 loads.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rig_update(RigDev P) {
-  const LmCtl* ctl = P.ctl;
-  if (ctl->done) return;
-  const int phase = ctl->phase;
-  if (phase != 0 && !ctl->step_valid) return;
-  const int cur = ctl->cur, dst = phase == 0 ? cur : (cur ^ 1);
+template <bool SC1>
+__device__ __forceinline__ void rig_update_body(const RigDev& P, int phase, int cur, int64_t fblk) {
+  const int dst = phase == 0 ? cur : (cur ^ 1);
   const int tid = threadIdx.x, l = tid & 15;
-  const int64_t f = (int64_t)blockIdx.x * 16 + (tid >> 4);
+  const int64_t f = fblk * 16 + (tid >> 4);
   const bool valid = f < P.F;
   const int64_t fc = valid ? f : 0;
   double u[6] = {0, 0, 0, 0, 0, 0};
   if (phase != 0) {
     const double* Yf = P.Y + (size_t)fc * 6 * P.SW;
     for (int k = l; k < P.SW; k += 16) {
-      const double d = k < P.S ? P.ds[k] : 1.0;
+      double d = 1.0;
+      if (k < P.S)
+        d = SC1 ? __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(P.ds) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                : P.ds[k];
 #pragma unroll
       for (int i = 0; i < 6; ++i) u[i] += Yf[i * P.SW + k] * d;
     }
@@ -447,6 +457,14 @@ __global__ __launch_bounds__(256) void k_rig_update(RigDev P) {
   for (int i = 0; i < 6; ++i) rec[12 + i] = dp[i];
   P.fstats[f * 2] = step2;
   P.fstats[f * 2 + 1] = active ? q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + t[0] * t[0] + t[1] * t[1] + t[2] * t[2] : 0.0;
+}
+
+__global__ __launch_bounds__(256) void k_rig_update(RigDev P) {
+  const LmCtl* ctl = P.ctl;
+  if (ctl->done) return;
+  const int phase = ctl->phase;
+  if (phase != 0 && !ctl->step_valid) return;
+  rig_update_body<false>(P, phase, ctl->cur, blockIdx.x);
 }
 
 // deterministic block-wide sum of one value per thread (256 threads); result valid for thread 0
@@ -853,6 +871,7 @@ __global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
   // direct sums: four waves each hold partial sums of the same entries
 #pragma unroll
   for (int r0 = 0; r0 < kRigDirectPerLane; r0 += 16) {
+    if (r0 * 64 >= P.ND) continue;   // (uniform) nothing left in this chunk
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; ++r)
@@ -896,6 +915,11 @@ __device__ __forceinline__ void untri(int idx, int& i, int& j) {  // packed lowe
   j = idx - tri(i, 0);
 }
 
+// shared step: write-through, so that workgroups of the same launch can read it behind a flag (sc1 loads)
+__device__ __forceinline__ void store_ds(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 struct RigVal {   // reader of reduced value e
   const RigDev& P; unsigned long long epoch; long long t0; int* s_ok;
   template <int SRC>
@@ -911,7 +935,7 @@ struct RigVal {   // reader of reduced value e
 // writes the camera / intrinsics records the sweep reads, from the current parameters plus (step_ok) the step
 // x (LDS, scaled shared step with the sign of b: the step is -x * ss). Returns this thread's share of
 // (step^2, |x_cand|^2) of the shared block. All 256 threads call.
-__device__ __forceinline__ void rig_candidates(const RigDev& P, const double* x, bool have_step, int cur, int dst,
+__device__ __forceinline__ void rig_candidates(const RigDev& P, const double* x, const double* ss, bool have_step, int cur, int dst,
                                                double& step2, double& xn2) {
   const int tid = threadIdx.x;
   step2 = 0.0; xn2 = 0.0;
@@ -923,7 +947,7 @@ __device__ __forceinline__ void rig_candidates(const RigDev& P, const double* x,
     if (have_step) {
       if (p0 >= 0) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) dc[k] = -x[p0 + k] * P.ss[p0 + k];
+        for (int k = 0; k < 6; ++k) dc[k] = -x[p0 + k] * ss[p0 + k];
         double qn[4];
         quat_plus(q, dc, qn);
 #pragma unroll
@@ -955,7 +979,7 @@ __device__ __forceinline__ void rig_candidates(const RigDev& P, const double* x,
     const int k0 = P.kscol[s];
     const double kc = P.intr[((size_t)cur * P.CK + s) * 16 + j];
     double dk = 0.0;
-    if (have_step && k0 >= 0 && !((P.kmask[s] >> j) & 1u)) dk = -x[k0 + j] * P.ss[k0 + j];
+    if (have_step && k0 >= 0 && !((P.kmask[s] >> j) & 1u)) dk = -x[k0 + j] * ss[k0 + j];
     const double kn = kc + dk;
     if (have_step) {
       P.intr[((size_t)dst * P.CK + s) * 16 + j] = kn;
@@ -1010,8 +1034,10 @@ __device__ void rig_solve_block(const RigDev& P, double* smem) {
   double* s_gs = s_b + 128;               // [128] unscaled shared gradient
   double* s_hd = s_gs + 128;              // [128] diagonal of the scaled H_ss
   double* s_inv = s_hd + 128;             // [128] 1 / L_jj
+  double* s_ss = s_inv + 128;             // [128] Jacobi scale of the shared block
   __shared__ int s_ok, s_cholok, s_stepok, s_go;
   __shared__ double s4[4];
+  __shared__ double s8[8];
   __shared__ LmCtl s_c;
   const int tid = threadIdx.x, lane = tid & 63;
   const LmCtl* cn = P.ctl_next;
@@ -1019,107 +1045,67 @@ __device__ void rig_solve_block(const RigDev& P, double* smem) {
   const double radius = cn->radius;
   const LmOpts o = *P.opts;
   RigVal val{P, SRC == 2 ? P.x.seq[0] + 1ull : 0ull, wall_clock64(), &s_ok};
-  if (tid == 0) { s_ok = 1; s_cholok = 1; s_stepok = 0; s_go = 0; }
+  if (tid == 0) { s_ok = 1; s_cholok = 1; s_stepok = 0; s_go = 0; s_c = *cn; }
   for (int i = tid; i < S * LD; i += 256) A[i] = 0.0;
-  if (tid < 128) { s_b[tid] = 0.0; s_gs[tid] = 0.0; s_hd[tid] = 0.0; s_inv[tid] = 0.0; }
+  if (tid < 128) { s_b[tid] = 0.0; s_gs[tid] = 0.0; s_hd[tid] = 0.0; s_inv[tid] = 0.0; s_ss[tid] = tid < S ? P.ss[tid] : 0.0; }
+  const int pin = tid < S ? P.colpin[tid] : -1;
+  const bool pinned = pin >= 0 && ((P.kmask[pin >> 4] >> (pin & 15)) & 1u) != 0;
   __syncthreads();
-  // ---- 1. one pass over the reduced values (loads batched eight deep: one round trip per batch, not per value):
-  // per-camera sums of the shared-block entries -> scaled H_ss (lower triangle) and unscaled gradient, minus the
-  // Schur products Z^T Z. An element of A gets at most two contributions (one of each kind), added with LDS
-  // atomics onto zero: x + y is commutative, so the result does not depend on who comes first. An intrinsics
-  // set shared by several cameras is summed by the first of them, in camera order.
+  // ---- 1. one pass over the reduced values (loads batched eight deep: one round trip per batch, not per value;
+  // where a value goes comes from host-built tables, fetched in the same round trip): per-camera sums of the
+  // shared-block entries -> scaled H_ss (lower triangle) and unscaled gradient, minus the Schur products Z^T Z.
+  // An element of A gets at most two contributions (one of each kind), added with LDS atomics onto zero: x + y is
+  // commutative, so the result does not depend on who comes first. An intrinsics set shared by several cameras
+  // is summed along its chain (dir_next), in camera order, by the first camera's thread.
   constexpr int NB = SRC == 2 ? 1 : 8;   // (a mailbox read is a polling loop of its own: no batching there)
   const double fail = val.get<SRC>(P.pc_fail);
   const double gm_r = (tid < P.nranks && tid < 32) ? val.get<SRC>(P.PC + tid) : 0.0;
   for (int e0 = 0; e0 < P.ND; e0 += NB * 256) {
     double v[NB];
-    int dst[NB];    // >= 0: element of A (scaled by sc); -1: nothing; <= -2: gradient entry -(dst + 2)
-    double sc[NB];
-    int hdp[NB];    // diagonal entry of the scaled H_ss
+    int d[NB], sa[NB], sb[NB];
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
       const int e = e0 + u * 256 + tid;
-      v[u] = 0.0; dst[u] = -1; sc[u] = 0.0; hdp[u] = -1;
+      v[u] = 0.0; d[u] = -1; sa[u] = 0; sb[u] = 0;
       if (e >= P.ND) continue;
-      const int co = e / P.DE, idx = e - co * P.DE;
-      const int c = P.obs_cam[co];
-      const int p0 = P.pcol[c], k0 = P.kcol[c];
-      if (idx < 27) {
-        if (p0 < 0) continue;
-        v[u] = val.get<SRC>(P.pc_dir + e);
-        if (idx < 21) {
-          int i, j;
-          untri(idx, i, j);
-          dst[u] = (p0 + i) * LD + p0 + j; sc[u] = P.ss[p0 + i] * P.ss[p0 + j];
-          if (i == j) hdp[u] = p0 + i;
-        } else {
-          dst[u] = -2 - (p0 + idx - 21);
-        }
-      } else if (idx < 81) {
-        if (p0 < 0 || k0 < 0) continue;
-        const int t = idx - 27, i = t / 9, j = t - i * 9;   // H_ck[i][j]; intrinsics columns follow all pose columns
-        v[u] = val.get<SRC>(P.pc_dir + e);
-        dst[u] = (k0 + j) * LD + p0 + i; sc[u] = P.ss[k0 + j] * P.ss[p0 + i];
-      } else {
-        if (k0 < 0) continue;
-        bool first = true;
-        for (int co2 = 0; co2 < co; ++co2) first = first && P.kcol[P.obs_cam[co2]] != k0;
-        if (!first) continue;
-        double acc = 0.0;
-        for (int co2 = co; co2 < P.CO; ++co2)
-          if (P.kcol[P.obs_cam[co2]] == k0) acc += val.get<SRC>(P.pc_dir + co2 * P.DE + idx);
-        v[u] = acc;
-        if (idx < 126) {
-          int i, j;
-          untri(idx - 81, i, j);
-          dst[u] = (k0 + i) * LD + k0 + j; sc[u] = P.ss[k0 + i] * P.ss[k0 + j];
-          if (i == j) hdp[u] = k0 + i;
-        } else {
-          dst[u] = -2 - (k0 + idx - 126);
-        }
-      }
+      d[u] = P.dir_dst[e];
+      if (d[u] == -1) continue;
+      sa[u] = P.dir_sa[e]; sb[u] = P.dir_sb[e];
+      double acc = val.get<SRC>(P.pc_dir + e);
+      for (int n = P.dir_next[e]; n >= 0; n = P.dir_next[n]) acc += val.get<SRC>(P.pc_dir + n);
+      v[u] = acc;
     }
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
-      if (dst[u] >= 0) {
-        const double x = sc[u] * v[u];
-        __hip_atomic_fetch_add(&A[dst[u]], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (hdp[u] >= 0) s_hd[hdp[u]] = x;
-      } else if (dst[u] <= -2) {
-        s_gs[-2 - dst[u]] = v[u];
+      if (d[u] >= 0) {
+        const double x = s_ss[sa[u]] * v[u] * s_ss[sb[u]];
+        __hip_atomic_fetch_add(&A[d[u]], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (sa[u] == sb[u]) s_hd[sa[u]] = x;
+      } else if (d[u] <= -2) {
+        s_gs[-2 - d[u]] = v[u];
       }
     }
   }
-  // Schur products (upper tile pairs; element (r, c) of pair (ti, tj) is (p, q), p <= q; column S is the rhs)
   for (int i0 = 0; i0 < P.nT * 256; i0 += NB * 256) {
     double v[NB];
-    int dst[NB];   // >= 0: A element, <= -2: rhs entry
+    int d[NB];
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
       const int i = i0 + u * 256 + tid;
-      v[u] = 0.0; dst[u] = -1;
+      v[u] = 0.0; d[u] = -1;
       if (i >= P.nT * 256) continue;
-      const int t = i >> 8, r = (i >> 4) & 15, c = i & 15;
-      const int p = 16 * P.tile_i[t] + r, q = 16 * P.tile_j[t] + c;
-      if (p > q || p >= S || q > S) continue;
-      v[u] = val.get<SRC>(i);
-      dst[u] = q < S ? q * LD + p : -2 - p;
+      d[u] = P.tile_dst[i];
+      if (d[u] != -1) v[u] = val.get<SRC>(i);
     }
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
-      if (dst[u] >= 0) __hip_atomic_fetch_add(&A[dst[u]], -v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      else if (dst[u] <= -2) s_b[-2 - dst[u]] = -v[u];
+      if (d[u] >= 0) __hip_atomic_fetch_add(&A[d[u]], -v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else if (d[u] <= -2) s_b[-2 - d[u]] = -v[u];
     }
   }
   __syncthreads();
-  // ---- 3. right-hand side, LM diagonal, constant coordinates (held intrinsics) become identity rows
-  bool pinned = false;
-  if (tid < S) {
-    const int info = P.colinfo[tid], kind = (info >> 4) & 15, comp = info & 15;
-    if (kind == 1) pinned = (P.kmask[P.kset[P.obs_cam[info >> 8]]] >> comp) & 1u;
-    else if (kind == 2) pinned = (P.kmask[0] >> comp) & 1u;
-    s_b[tid] = pinned ? 0.0 : s_b[tid] + P.ss[tid] * s_gs[tid];
-  }
+  // ---- 2. right-hand side, LM diagonal, constant coordinates (held intrinsics) become identity rows
+  if (tid < S) s_b[tid] = pinned ? 0.0 : s_b[tid] + s_ss[tid] * s_gs[tid];
   __syncthreads();
   if (tid < S) {
     if (pinned) {
@@ -1139,7 +1125,7 @@ __device__ void rig_solve_block(const RigDev& P, double* smem) {
   }
   __syncthreads();
   if (tid == 0) {
-    LmCtl c = *cn;
+    LmCtl c = s_c;
     const double gmax = fmax(fmax(s4[0], s4[1]), fmax(s4[2], s4[3]));
     if (c.log_len > 0 && c.log_len <= P.log_cap && P.log[c.log_len - 1].accepted) P.log[c.log_len - 1].gradient_max_norm = gmax;
     if (s_ok == 0) { c.done = 1; c.term = CC_FAILURE_EXCHANGE; }
@@ -1153,9 +1139,13 @@ __device__ void rig_solve_block(const RigDev& P, double* smem) {
     if (tid < 64) {
       double b0 = lane < S ? s_b[lane] : 0.0, vinv = 0.0;
       int ok = 0;
-      if (S <= 8) chol_wave<8>(A, S, LD, b0, vinv, ok);
+      if (S <= 4) chol_wave<4>(A, S, LD, b0, vinv, ok);
+      else if (S <= 8) chol_wave<8>(A, S, LD, b0, vinv, ok);
+      else if (S <= 12) chol_wave<12>(A, S, LD, b0, vinv, ok);
       else if (S <= 16) chol_wave<16>(A, S, LD, b0, vinv, ok);
+      else if (S <= 20) chol_wave<20>(A, S, LD, b0, vinv, ok);
       else if (S <= 24) chol_wave<24>(A, S, LD, b0, vinv, ok);
+      else if (S <= 28) chol_wave<28>(A, S, LD, b0, vinv, ok);
       else if (S <= 32) chol_wave<32>(A, S, LD, b0, vinv, ok);
       else if (S <= 40) chol_wave<40>(A, S, LD, b0, vinv, ok);
       else if (S <= 48) chol_wave<48>(A, S, LD, b0, vinv, ok);
@@ -1180,7 +1170,8 @@ __device__ void rig_solve_block(const RigDev& P, double* smem) {
         }
       }
       const bool step_ok = s_cholok != 0 && ok != 0 && __all(i0 >= S || isfinite(b0));
-      if (i0 < S) { s_b[i0] = b0; P.ds[i0] = -b0; }
+      if (i0 < S) { s_b[i0] = b0; store_ds(P.ds + i0, -b0); }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the update blocks of this launch read ds behind a flag
       if (lane == 0) s_stepok = step_ok ? 1 : 0;
     }
     __syncthreads();
@@ -1249,8 +1240,9 @@ __device__ void rig_solve_block(const RigDev& P, double* smem) {
       }
       const bool fin = (i0 >= S || isfinite(b0)) && (i1 >= S || isfinite(b1));
       const bool step_ok = s_cholok != 0 && __all(fin);
-      if (i0 < S) { s_b[i0] = b0; P.ds[i0] = -b0; }
-      if (i1 < S) { s_b[i1] = b1; P.ds[i1] = -b1; }
+      if (i0 < S) { s_b[i0] = b0; store_ds(P.ds + i0, -b0); }
+      if (i1 < S) { s_b[i1] = b1; store_ds(P.ds + i1, -b1); }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) s_stepok = step_ok ? 1 : 0;
     }
     __syncthreads();
@@ -1258,9 +1250,15 @@ __device__ void rig_solve_block(const RigDev& P, double* smem) {
   // ---- camera / intrinsics candidates and records (nothing moves unless a valid step exists)
   double st2 = 0.0, xs2 = 0.0;
   const bool have_step = s_go != 0 && s_stepok != 0;
-  if (have_step) rig_candidates(P, s_b, true, cur, dst, st2, xs2);
-  const double st = block_sum256(st2, s4);
-  const double xs = block_sum256(xs2, s4);
+  if (have_step) rig_candidates(P, s_b, s_ss, true, cur, dst, st2, xs2);
+  {   // both block sums behind one pair of barriers
+    const double a = wave_sum(st2), b2 = wave_sum(xs2);
+    __syncthreads();
+    if (lane == 0) { s8[tid >> 6] = a; s8[4 + (tid >> 6)] = b2; }
+    __syncthreads();
+  }
+  const double st = (s8[0] + s8[1]) + (s8[2] + s8[3]);
+  const double xs = (s8[4] + s8[5]) + (s8[6] + s8[7]);
   if (tid == 0) {
     LmCtl c = s_c;
     if (s_go) {
@@ -1292,16 +1290,20 @@ __global__ __launch_bounds__(256) void k_rig_records(RigDev P) {
   const LmCtl* ctl = P.ctl;
   if (ctl->done || ctl->phase != 0) return;
   double a, b;
-  rig_candidates(P, nullptr, false, ctl->cur, ctl->cur, a, b);
+  rig_candidates(P, nullptr, nullptr, false, ctl->cur, ctl->cur, a, b);
 }
 
 // ---------------------------------------------------------------------------------------------
-// reduce (+ solve): column sums (max for the last column) of the elimination partial rows, 16 columns per
-// block, 16 row groups per column, 16 loads in flight per thread. Deterministic.
+// reduce (+ solve + update): column sums (max for the last column) of the elimination partial rows, 16 columns
+// per block and step, 16 row groups per column, 16 loads in flight per thread. Deterministic.
 // MODE 0 (single GPU): the sums are stored write-through, the block arrives on a counter and the LAST block
 // to arrive runs the solve step on them (sc1 loads, no fence: MI355X guide, valid hand-off forms).
-// MODE 3 (mailbox exchange): every block posts its 16 sums straight into all ranks' mailboxes; the last block
+// MODE 3 (mailbox exchange): every block posts its sums straight into all ranks' mailboxes; the last block
 // to arrive collects them in rank order inside the solve step. MODE 2 (RCCL): sums -> P.vec, nothing else.
+// MODES 0 and 3 then run the POSE UPDATE in the same launch: the grid is at most one block per CU (all of them
+// resident), the blocks that are not last wait for a flag word the solver stores (epoch | done | step_valid | cur,
+// sc1, behind its drained sc1 stores of the shared step) and every block updates its share of the frames. The wait is
+// bounded (10 s of the wall clock) like the mailbox polls.
 // ---------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P) {
@@ -1310,62 +1312,67 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P) {
   __shared__ double s_post[48];
   __shared__ double s_tail;
   __shared__ int s_last;
+  __shared__ unsigned s_flag;
   const LmCtl* cn = P.ctl_next;
   if (cn->done) {
     if (MODE != 2 && blockIdx.x == 0 && threadIdx.x == 0) *P.ctl = *cn;
     return;
   }
   if (cn->phase == 0) return;
-  const int tid = threadIdx.x, c = tid & 15, grp = tid >> 4;  // 16 columns x 16 row groups per block
-  const int o = blockIdx.x * 16 + c;
-  const bool is_max = o == P.pc_gmax;
-  double a = 0.0;
-  if (o < P.PC) {
-    for (int r0 = grp; r0 < P.nblk; r0 += 256) {
-      double v[16];
+  const int tid = threadIdx.x, c = tid & 15, grp = tid >> 4;  // 16 columns x 16 row groups per step
+  unsigned epoch0 = 0;
+  if (MODE != 2) epoch0 = __hip_atomic_load(P.arrive + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 3;   // before we arrive
+  for (int first = blockIdx.x * 16; first < P.PC; first += gridDim.x * 16) {
+    const int o = first + c;
+    const bool is_max = o == P.pc_gmax;
+    double a = 0.0;
+    if (o < P.PC) {
+      for (int r0 = grp; r0 < P.nblk; r0 += 256) {
+        double v[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = r0 + 16 * u < P.nblk ? P.partial[(size_t)(r0 + 16 * u) * P.PC + o] : 0.0;
-      if (is_max) {
+        for (int u = 0; u < 16; ++u) v[u] = r0 + 16 * u < P.nblk ? P.partial[(size_t)(r0 + 16 * u) * P.PC + o] : 0.0;
+        if (is_max) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) a = fmax(a, v[u]);
-      } else {
-        a += (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
-             (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+          for (int u = 0; u < 16; ++u) a = fmax(a, v[u]);
+        } else {
+          a += (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
+               (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+        }
       }
     }
-  }
-  s_r[grp][c] = a;
-  __syncthreads();
-  if (tid < 16 && o < P.PC) {
-    double r = 0.0;
-    if (is_max) { for (int g2 = 0; g2 < 16; ++g2) r = fmax(r, s_r[g2][c]); }
-    else {
-      r = (((s_r[0][c] + s_r[1][c]) + (s_r[2][c] + s_r[3][c])) + ((s_r[4][c] + s_r[5][c]) + (s_r[6][c] + s_r[7][c]))) +
-          (((s_r[8][c] + s_r[9][c]) + (s_r[10][c] + s_r[11][c])) + ((s_r[12][c] + s_r[13][c]) + (s_r[14][c] + s_r[15][c])));
-    }
-    unsigned long long* vw = reinterpret_cast<unsigned long long*>(P.vec);
-    if (is_max) {   // the per-rank slot carries the max (a sum exchange then keeps it); the column itself is 0
-      if (MODE == 0) __hip_atomic_store(vw + P.PC + P.rank, (unsigned long long)__double_as_longlong(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else P.vec[P.PC + P.rank] = r;
-      s_tail = r;
-      r = 0.0;
-    }
-    if (MODE == 0) __hip_atomic_store(vw + o, (unsigned long long)__double_as_longlong(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else P.vec[o] = r;
-    s_post[c] = r;
-  }
-  if (MODE == 3) {
-    // mailbox exchange (kind 0): the block that owns the max column also posts the 32 per-rank max slots
-    // (ours set, the others zero). The epoch is stable here: only the solve step advances it.
+    __syncthreads();   // (readers of the previous step)
+    s_r[grp][c] = a;
     __syncthreads();
-    const unsigned long long epoch = P.x.seq[0] + 1ull;
-    const int first = blockIdx.x * 16;
-    const int ncol = P.PC - first < 16 ? P.PC - first : 16;
-    p2p_post(P.x, 0, epoch, P.rank, P.nranks, s_post, ncol, first);
-    if (first <= P.pc_gmax && P.pc_gmax < first + 16) {
-      if (tid < 32) s_post[16 + tid] = tid == P.rank ? s_tail : 0.0;
+    if (tid < 16 && o < P.PC) {
+      double r = 0.0;
+      if (is_max) { for (int g2 = 0; g2 < 16; ++g2) r = fmax(r, s_r[g2][c]); }
+      else {
+        r = (((s_r[0][c] + s_r[1][c]) + (s_r[2][c] + s_r[3][c])) + ((s_r[4][c] + s_r[5][c]) + (s_r[6][c] + s_r[7][c]))) +
+            (((s_r[8][c] + s_r[9][c]) + (s_r[10][c] + s_r[11][c])) + ((s_r[12][c] + s_r[13][c]) + (s_r[14][c] + s_r[15][c])));
+      }
+      unsigned long long* vw = reinterpret_cast<unsigned long long*>(P.vec);
+      if (is_max) {   // the per-rank slot carries the max (a sum exchange then keeps it); the column itself is 0
+        if (MODE == 0) __hip_atomic_store(vw + P.PC + P.rank, (unsigned long long)__double_as_longlong(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else P.vec[P.PC + P.rank] = r;
+        s_tail = r;
+        r = 0.0;
+      }
+      if (MODE == 0) __hip_atomic_store(vw + o, (unsigned long long)__double_as_longlong(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else P.vec[o] = r;
+      s_post[c] = r;
+    }
+    if (MODE == 3) {
+      // mailbox exchange (kind 0): the block that owns the max column also posts the 32 per-rank max slots
+      // (ours set, the others zero). The epoch is stable here: only the solve step advances it.
       __syncthreads();
-      p2p_post(P.x, 0, epoch, P.rank, P.nranks, s_post + 16, 32, P.PC);
+      const unsigned long long epoch = P.x.seq[0] + 1ull;
+      const int ncol = P.PC - first < 16 ? P.PC - first : 16;
+      p2p_post(P.x, 0, epoch, P.rank, P.nranks, s_post, ncol, first);
+      if (first <= P.pc_gmax && P.pc_gmax < first + 16) {
+        if (tid < 32) s_post[16 + tid] = tid == P.rank ? s_tail : 0.0;
+        __syncthreads();
+        p2p_post(P.x, 0, epoch, P.rank, P.nranks, s_post + 16, 32, P.PC);
+      }
     }
   }
   if (MODE == 2) return;
@@ -1377,9 +1384,32 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P) {
     s_last = prev + 1u == gridDim.x;
   }
   __syncthreads();
-  if (!s_last) return;
-  if (tid == 0) __hip_atomic_store(P.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
-  rig_solve_block<MODE == 0 ? 1 : 2>(P, reinterpret_cast<double*>(smem_raw));
+  if (s_last) {
+    if (tid == 0) __hip_atomic_store(P.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+    rig_solve_block<MODE == 0 ? 1 : 2>(P, reinterpret_cast<double*>(smem_raw));
+    // the shared step (sc1 stores of wave 0) has been drained inside; hand the outcome to the waiting blocks
+    __syncthreads();
+    if (tid == 0) {
+      const LmCtl* c = P.ctl;   // written by this very thread a moment ago
+      s_flag = ((epoch0 + 1u) << 3) | (c->done ? 4u : 0u) | (c->step_valid ? 2u : 0u) | (unsigned)(c->cur & 1);
+      __hip_atomic_store(P.arrive + 1, s_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else if (tid == 0) {
+    const long long t0 = wall_clock64();
+    unsigned f;
+    for (;;) {
+      f = __hip_atomic_load(P.arrive + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((f >> 3) == epoch0 + 1u) break;
+      if (wall_clock64() - t0 > kP2pTimeoutTicks) { f = 4u; break; }   // treat as done: nothing is updated
+      __builtin_amdgcn_s_sleep(2);
+    }
+    s_flag = f;
+  }
+  __syncthreads();
+  const unsigned flag = s_flag;
+  if ((flag & 4u) || !(flag & 2u)) return;   // done, or no valid step: the poses stay
+  const int cur = (int)(flag & 1u);
+  for (int64_t fblk = blockIdx.x; fblk * 16 < P.F; fblk += gridDim.x) rig_update_body<true>(P, 1, cur, fblk);
 }
 
 // per-observation robustified cost at the accepted point (extrinsics_calibrator.cpp:219-225)
@@ -1568,6 +1598,56 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
   }
   std::vector<uint8_t> ti, tj;
   for (int a = 0; a < d.T; ++a) for (int b = a; b < d.T; ++b) { ti.push_back((uint8_t)a); tj.push_back((uint8_t)b); }
+  // solve-step tables: where reduced value e goes
+  const int LD = S + 1;
+  std::vector<int32_t> dir_dst((size_t)std::max(CO * DE, 1), -1), dir_next((size_t)std::max(CO * DE, 1), -1);
+  std::vector<int16_t> dir_sa((size_t)std::max(CO * DE, 1), 0), dir_sb((size_t)std::max(CO * DE, 1), 0);
+  auto untri_h = [](int idx, int& i, int& j) { i = 0; while ((i + 1) * (i + 2) / 2 <= idx) ++i; j = idx - i * (i + 1) / 2; };
+  for (int co = 0; co < CO; ++co) {
+    const int c = obs_cam[(size_t)co], p0 = pcol[(size_t)c], k0 = kcol[(size_t)c];
+    for (int idx = 0; idx < DE; ++idx) {
+      const size_t e = (size_t)co * DE + idx;
+      if (idx < 21) {
+        if (p0 < 0) continue;
+        int i, j; untri_h(idx, i, j);
+        dir_dst[e] = (p0 + i) * LD + p0 + j; dir_sa[e] = (int16_t)(p0 + i); dir_sb[e] = (int16_t)(p0 + j);
+      } else if (idx < 27) {
+        if (p0 >= 0) dir_dst[e] = -2 - (p0 + idx - 21);
+      } else if (idx < 81) {
+        if (p0 < 0 || k0 < 0) continue;
+        const int t = idx - 27, i = t / 9, j = t - i * 9;   // H_ck[i][j]; intrinsics columns follow all pose columns
+        dir_dst[e] = (k0 + j) * LD + p0 + i; dir_sa[e] = (int16_t)(k0 + j); dir_sb[e] = (int16_t)(p0 + i);
+      } else {
+        if (k0 < 0) continue;
+        // an intrinsics set shared by several cameras: the first camera's entry collects the others' along a chain
+        int prev = -1, next = -1;
+        for (int co2 = 0; co2 < co; ++co2) if (kcol[(size_t)obs_cam[(size_t)co2]] == k0) prev = co2;
+        for (int co2 = CO - 1; co2 > co; --co2) if (kcol[(size_t)obs_cam[(size_t)co2]] == k0) next = co2;
+        if (next >= 0) dir_next[e] = next * DE + idx;
+        if (prev >= 0) continue;
+        if (idx < 126) {
+          int i, j; untri_h(idx - 81, i, j);
+          dir_dst[e] = (k0 + i) * LD + k0 + j; dir_sa[e] = (int16_t)(k0 + i); dir_sb[e] = (int16_t)(k0 + j);
+        } else {
+          dir_dst[e] = -2 - (k0 + idx - 126);
+        }
+      }
+    }
+  }
+  std::vector<int32_t> tile_dst((size_t)d.nT * 256, -1);
+  for (int t = 0; t < d.nT; ++t)
+    for (int r = 0; r < 16; ++r)
+      for (int c2 = 0; c2 < 16; ++c2) {
+        const int pp = 16 * ti[(size_t)t] + r, qq = 16 * tj[(size_t)t] + c2;
+        if (pp > qq || pp >= S || qq > S) continue;
+        tile_dst[(size_t)t * 256 + r * 16 + c2] = qq < S ? qq * LD + pp : -2 - pp;
+      }
+  std::vector<int32_t> colpin((size_t)std::max(S, 1), -1);
+  for (int k = 0; k < S; ++k) {
+    const int info = colinfo[(size_t)k], kind = (info >> 4) & 15, comp = info & 15;
+    if (kind == 1) colpin[(size_t)k] = (kset[(size_t)obs_cam[(size_t)(info >> 8)]] << 4) | comp;
+    else if (kind == 2) colpin[(size_t)k] = comp;
+  }
   std::vector<int32_t> fslot((size_t)F * std::max(CO, 1), -1);
   for (int64_t g = 0; g < h->NG; ++g) fslot[(size_t)h->gframe_h[(size_t)g] * CO + cobs[(size_t)h->gcam_h[(size_t)g]]] = (int32_t)g;
   if (int rc = dev_upload(h, &d.pcol, pcol)) return rc;
@@ -1580,6 +1660,12 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
   if (int rc = dev_upload(h, &d.tile_i, ti)) return rc;
   if (int rc = dev_upload(h, &d.tile_j, tj)) return rc;
   if (int rc = dev_upload(h, &d.fslot, fslot)) return rc;
+  if (int rc = dev_upload(h, &d.dir_dst, dir_dst)) return rc;
+  if (int rc = dev_upload(h, &d.dir_next, dir_next)) return rc;
+  if (int rc = dev_upload(h, &d.dir_sa, dir_sa)) return rc;
+  if (int rc = dev_upload(h, &d.dir_sb, dir_sb)) return rc;
+  if (int rc = dev_upload(h, &d.tile_dst, tile_dst)) return rc;
+  if (int rc = dev_upload(h, &d.colpin, colpin)) return rc;
   if (!h->d_cam_fixed) { if (int rc = dev_alloc(h, &h->d_cam_fixed, (size_t)C)) return rc; d.cam_fixed = h->d_cam_fixed; }
   CC_HIP(hipMemcpy(h->d_cam_fixed, fixed.data(), fixed.size(), hipMemcpyHostToDevice));
   if (int rc = dev_zeroed(h, &d.Y, (size_t)F * 6 * d.SW)) return rc;
@@ -1587,7 +1673,7 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
   if (int rc = dev_zeroed(h, &d.vec, (size_t)d.PC + 32)) return rc;
   if (int rc = dev_zeroed(h, &d.vec_stats, (size_t)4 + kRigMaxS + 1)) return rc;
   h->elim_lds = ((size_t)24 * d.ZS + 4 * 32 + 4 * 1024) * sizeof(double);
-  h->solve_lds = ((size_t)S * (S + 1) + 4 * 128) * sizeof(double);
+  h->solve_lds = ((size_t)S * (S + 1) + 5 * 128) * sizeof(double);
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_reduce<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
@@ -1627,17 +1713,20 @@ static int rig_enqueue_round(cc_rig* h, bool initial, bool profile) {
   { RigProbe p(h, CC_K_ELIM, profile);
     if (d.kmode) hipLaunchKernelGGL(k_rig_elim<true>, dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d);
     else hipLaunchKernelGGL(k_rig_elim<false>, dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d); }
-  const unsigned rblocks = (unsigned)((d.PC + 15) / 16);
+  // Every block of this launch must be resident at once (the blocks wait for each other's flag, k_rig_reduce): 64
+  // blocks is a quarter of the chip, which leaves room for the kernels of other processes on the same GPU (the
+  // multi-process tests put up to four ranks on one GPU, and a rank's solver waits for the OTHER ranks' launches).
+  const unsigned rblocks = (unsigned)std::min((d.PC + 15) / 16, 64);
   if (h->comm) {
     { RigProbe p(h, CC_K_REDUCE, profile); hipLaunchKernelGGL(k_rig_reduce<2>, dim3(rblocks), dim3(256), 0, h->stream, d); }
     { RigProbe p(h, CC_K_ALLREDUCE, profile); if (int rc = comm_allreduce_sum(h->comm, d.vec, d.PC + 32, h->stream)) return rc; }
     { RigProbe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_rig_solve, dim3(1), dim3(256), h->solve_lds, h->stream, d); }
-  } else {
+    { RigProbe p(h, CC_K_UPDATE, profile); hipLaunchKernelGGL(k_rig_update, dim3((unsigned)((h->F + 15) / 16)), dim3(256), 0, h->stream, d); }
+  } else {   // reduce + solve step + pose update in one launch
     RigProbe p(h, CC_K_SOLVE, profile);
     if (h->exchange) hipLaunchKernelGGL(k_rig_reduce<3>, dim3(rblocks), dim3(256), h->solve_lds, h->stream, d);
     else hipLaunchKernelGGL(k_rig_reduce<0>, dim3(rblocks), dim3(256), h->solve_lds, h->stream, d);
   }
-  { RigProbe p(h, CC_K_UPDATE, profile); hipLaunchKernelGGL(k_rig_update, dim3((unsigned)((h->F + 15) / 16)), dim3(256), 0, h->stream, d); }
   return 0;
 }
 
