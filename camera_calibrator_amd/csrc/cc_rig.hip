@@ -229,8 +229,11 @@ __device__ __forceinline__ void gram_rows_ab(const double* sa, const double* sb,
 // camera's 9 intrinsics (its own set or the one shared by all cameras); the row is [J_cam(6) J_frame(6) r 0 0 0 | J_k(9) 0...] and the group block has
 // three tiles: AA (as before), AB (first half x intrinsics), BB (intrinsics x intrinsics).
 // ---------------------------------------------------------------------------------------------
+#ifndef CC_RIG_SWEEP_WAVES
+#define CC_RIG_SWEEP_WAVES 4   // waves per SIMD the poses-only sweep is compiled for (A/B knob)
+#endif
 template <bool HK>
-__global__ __launch_bounds__(kRigThreads, HK ? 2 : 4) void k_rig_sweep(RigDev P) {
+__global__ __launch_bounds__(kRigThreads, HK ? 2 : CC_RIG_SWEEP_WAVES) void k_rig_sweep(RigDev P) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int kTiles = HK ? 2 : 1;
   double* s_stage = reinterpret_cast<double*>(smem_raw);

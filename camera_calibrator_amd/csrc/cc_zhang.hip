@@ -3,11 +3,11 @@
 //
 //   k_zhang_gram   : per frame, rows of the DLT system (geometry.cpp:79-97) -> A^T A (9x9, fp64) with
 //                    the same LDS-staged v_mfma_f64_16x16x4_f64 contraction as the Jacobian sweep.
-//   k_zhang_eig9   : one thread per frame: cyclic Jacobi eigen-decomposition of A^T A in registers,
-//                    homography = eigenvector of the smallest eigenvalue (= last right singular
-//                    vector of A, which the reference takes from Eigen::JacobiSVD), stored as float.
+//   k_zhang_eig9   : one thread per frame: homography = eigenvector of the smallest eigenvalue of A^T A (= last
+//                    right singular vector of A, which the reference takes from Eigen::JacobiSVD) by inverse
+//                    iteration in registers, stored as float.
 //   k_zhang_k      : one block: Zhang's V b = 0 system (geometry.cpp:123-177) as 6x6 normal equations,
-//                    Jacobi eigenvector, closed-form K.
+//                    smallest eigenvector by inverse iteration, closed-form K.
 //   k_zhang_poses  : one thread per frame: RecoverExtrinsics + FixRotationMatrix (geometry.cpp:179-203)
 //                    and the quaternion of calibrator.cpp:63.
 // The normal-equation form squares the condition number of the DLT system; on the generator's data
@@ -59,6 +59,61 @@ __device__ __forceinline__ void jacobi_eigen(double (&A)[N][N], double (&V)[N][N
           V[r][q] = s * vrp + c * vrq;
         }
       }
+  }
+}
+
+// Unit eigenvector of the SMALLEST eigenvalue of a symmetric positive semi-definite N x N matrix (registers):
+// inverse iteration on A + mu I (mu = 1e-13 trace: keeps the Cholesky pivots positive when the smallest eigenvalue
+// is zero up to rounding, as for exact data or four-point homographies). The smallest eigenvalue of a DLT Gram
+// matrix is noise-sized and the next one is not, so the iteration gains many digits per step; 12 steps, ~1.5 kflop
+// in ~60 registers, against ~26 kflop and 162 live doubles (spilling) for the full Jacobi decomposition it replaces.
+template <int N>
+__device__ __forceinline__ void smallest_eigvec(const double (&A)[N][N], double (&x)[N]) {
+  double tr = 0.0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) tr += A[i][i];
+  const double mu = 1e-13 * tr + 1e-300;
+  double L[N][N], inv[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    double d = A[j][j] + mu;
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+    d = fmax(d, 1e-30 * tr + 1e-300);
+    const double r = rsqrt(d);
+    inv[j] = r;
+    L[j][j] = d * r;
+#pragma unroll
+    for (int i = j + 1; i < N; ++i) {
+      double a = A[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) a -= L[i][k] * L[j][k];
+      L[i][j] = a * r;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i] = (i & 1) ? 0.7 : 1.0;   // not orthogonal to anything in particular
+  for (int it = 0; it < 12; ++it) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double a = x[i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) a -= L[i][k] * x[k];
+      x[i] = a * inv[i];
+    }
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+      double a = x[i];
+#pragma unroll
+      for (int k = i + 1; k < N; ++k) a -= L[k][i] * x[k];
+      x[i] = a * inv[i];
+    }
+    double n2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) n2 += x[i] * x[i];
+    const double rn = rsqrt(n2);
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] *= rn;
   }
 }
 
@@ -116,23 +171,13 @@ __global__ __launch_bounds__(kZhangThreads, 4) void k_zhang_gram(int64_t F, cons
 __global__ __launch_bounds__(64) void k_zhang_eig9(int64_t F, const double* gram, float* Hs /*[F][9] row-major*/) {
   const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= F) return;
-  double A[9][9], V[9][9];
+  double A[9][9];
 #pragma unroll
   for (int i = 0; i < 9; ++i)
 #pragma unroll
     for (int j = 0; j < 9; ++j) A[i][j] = gram[f * 256 + i * 16 + j];
-  jacobi_eigen<9>(A, V, 12);
-  int best = 0;
-  double lo = A[0][0];
-#pragma unroll
-  for (int i = 1; i < 9; ++i)
-    if (A[i][i] < lo) { lo = A[i][i]; best = i; }
   double h[9];
-#pragma unroll
-  for (int c = 0; c < 9; ++c) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) if (c == best) h[i] = V[i][c];
-  }
+  smallest_eigvec<9>(A, h);
 #pragma unroll
   for (int i = 0; i < 9; ++i) Hs[f * 9 + i] = (float)h[i];
 }
@@ -177,7 +222,7 @@ __global__ __launch_bounds__(256) void k_zhang_k(int64_t F, const float* Hs, flo
   }
   __syncthreads();
   if (tid != 0) return;
-  double A[6][6], V[6][6];
+  double A[6][6];
   {
     int e = 0;
 #pragma unroll
@@ -190,18 +235,8 @@ __global__ __launch_bounds__(256) void k_zhang_k(int64_t F, const float* Hs, flo
       }
   }
   A[1][1] += (double)F * (double)F;  // zero-skew row (0, n, 0, 0, 0, 0), geometry.cpp:150-152
-  jacobi_eigen<6>(A, V, 12);
-  int best = 0;
-  double lo = A[0][0];
-#pragma unroll
-  for (int i = 1; i < 6; ++i)
-    if (A[i][i] < lo) { lo = A[i][i]; best = i; }
   double b[6];
-#pragma unroll
-  for (int c = 0; c < 6; ++c) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) if (c == best) b[i] = V[i][c];
-  }
+  smallest_eigvec<6>(A, b);
   const double B11 = b[0], B12 = b[1], B22 = b[2], B13 = b[3], B23 = b[4], B33 = b[5];
   const double den = B11 * B22 - B12 * B12;
   const double v0 = (B12 * B13 - B11 * B23) / den;
