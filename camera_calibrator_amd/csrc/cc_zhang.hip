@@ -63,29 +63,33 @@ __device__ __forceinline__ void jacobi_eigen(double (&A)[N][N], double (&V)[N][N
 }
 
 // Unit eigenvector of the SMALLEST eigenvalue of a symmetric positive semi-definite N x N matrix (registers):
-// inverse iteration on A + mu I (mu = 1e-13 trace: keeps the Cholesky pivots positive when the smallest eigenvalue
-// is zero up to rounding, as for exact data or four-point homographies). The smallest eigenvalue of a DLT Gram
-// matrix is noise-sized and the next one is not, so the iteration gains many digits per step; 12 steps, ~1.5 kflop
-// in ~60 registers, against ~26 kflop and 162 live doubles (spilling) for the full Jacobi decomposition it replaces.
+// inverse iteration x <- A^-1 x with A^-1 applied as S (S A S + mu I)^-1 S, S = diag(A)^-1/2. The equilibration
+// matters: DLT Gram matrices are badly graded (no Hartley normalisation in the reference, geometry.cpp:70-105; a
+// nearly edge-on board gives world coordinates of 1e5 and eigenvalues from 1e-1 to 1e16), and a Cholesky of the raw
+// matrix loses the small eigen-space entirely there, while the unit-diagonal one keeps it to ~1e-6 (float32, the
+// precision H is stored in). mu = 1e-14 N keeps the pivots positive when the smallest eigenvalue is zero up to
+// rounding (exact data, four-point homographies). The smallest eigenvalue is noise-sized and the next one is not,
+// so the iteration gains many digits per step; 12 steps, ~1.5 kflop in ~70 registers, against ~26 kflop and 162
+// live doubles (spilling) for the full Jacobi decomposition it replaces.
 template <int N>
 __device__ __forceinline__ void smallest_eigvec(const double (&A)[N][N], double (&x)[N]) {
-  double tr = 0.0;
+  double sc[N];
 #pragma unroll
-  for (int i = 0; i < N; ++i) tr += A[i][i];
-  const double mu = 1e-13 * tr + 1e-300;
+  for (int i = 0; i < N; ++i) sc[i] = A[i][i] > 0.0 ? rsqrt(A[i][i]) : 1.0;
+  const double mu = 1e-14 * N;
   double L[N][N], inv[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    double d = A[j][j] + mu;
+    double d = sc[j] * A[j][j] * sc[j] + mu;
 #pragma unroll
     for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
-    d = fmax(d, 1e-30 * tr + 1e-300);
+    d = fmax(d, 1e-30);
     const double r = rsqrt(d);
     inv[j] = r;
     L[j][j] = d * r;
 #pragma unroll
     for (int i = j + 1; i < N; ++i) {
-      double a = A[i][j];
+      double a = sc[i] * A[i][j] * sc[j];
 #pragma unroll
       for (int k = 0; k < j; ++k) a -= L[i][k] * L[j][k];
       L[i][j] = a * r;
@@ -96,7 +100,7 @@ __device__ __forceinline__ void smallest_eigvec(const double (&A)[N][N], double 
   for (int it = 0; it < 12; ++it) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      double a = x[i];
+      double a = x[i] * sc[i];
 #pragma unroll
       for (int k = 0; k < i; ++k) a -= L[i][k] * x[k];
       x[i] = a * inv[i];
@@ -110,7 +114,7 @@ __device__ __forceinline__ void smallest_eigvec(const double (&A)[N][N], double 
     }
     double n2 = 0.0;
 #pragma unroll
-    for (int i = 0; i < N; ++i) n2 += x[i] * x[i];
+    for (int i = 0; i < N; ++i) { x[i] *= sc[i]; n2 += x[i] * x[i]; }
     const double rn = rsqrt(n2);
 #pragma unroll
     for (int i = 0; i < N; ++i) x[i] *= rn;

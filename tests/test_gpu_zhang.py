@@ -44,6 +44,27 @@ def test_zhang_init_feeds_the_solver_to_the_same_minimum():
     assert np.all(np.abs(ig[:4] - io[:4]) <= 1e-9 * np.abs(io[:4])) and np.all(np.abs(ig[4:] - io[4:]) <= 1e-9)
 
 
+def test_zhang_init_at_full_size_with_badly_graded_frames():
+    """BASELINE.json configs[2] size: some of the 1000 random planes are nearly edge-on (world coordinates of 1e5,
+    DLT singular values spread over 1.5e7): the normal-equation route must still deliver a homography of float32
+    quality for every frame, and the solver must start from it as it does from the SVD route."""
+    off, uv, xyz = po.make_intrinsics_problem(1000, 500)
+    Kg, qg, tg, Hg = capi.zhang_init(off, uv, xyz, want_homographies=True)
+    Ko, qo, to = po.zhang_init(off, uv, xyz)
+    assert np.allclose(Kg, Ko, rtol=2e-5, atol=1e-4)
+    sign = np.sign(np.sum(qg * qo, axis=1, keepdims=True))
+    assert np.abs(qg - sign * qo).max() < 2e-4 and np.abs(tg - to).max() < 2e-4
+    for f in (875, 0, 500, 999):
+        Ho = po.estimate_homography(xyz[off[f]:off[f + 1]], uv[off[f]:off[f + 1]])
+        a, b = Hg[f] / np.linalg.norm(Hg[f]), Ho / np.linalg.norm(Ho)
+        if np.sum(a * b) < 0:
+            b = -b
+        assert np.abs(a - b).max() < 2e-5
+    intr0 = np.array([Kg[0, 0], Kg[1, 1], Kg[0, 2], Kg[1, 2], 0, 0, 0, 0, 0], dtype=np.float64)
+    r = capi.intrinsics_optimize(off, uv, xyz, intr0, qg.astype(np.float64), tg.astype(np.float64))
+    assert r[3]["iterations"] == 4 and r[3]["termination"] == "FUNCTION"
+
+
 def test_zhang_init_rejects_bad_input():
     off, uv, xyz = po.make_intrinsics_problem(2, 10)
     with pytest.raises(capi.CcError):
