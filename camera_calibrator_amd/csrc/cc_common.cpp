@@ -82,6 +82,44 @@ int stream_get(int device, hipStream_t* out) {
   return CC_OK;
 }
 
+namespace {
+struct Scratch { void* p = nullptr; size_t bytes = 0; bool busy = false; };
+std::vector<Scratch> g_scratch;   // per device, guarded by g_cache_mu
+constexpr size_t kScratchKeep = (size_t)64 << 20;
+}  // namespace
+
+int scratch_get(int device, size_t bytes, void** out, bool* cached) {
+  *cached = false;
+  if (bytes <= kScratchKeep) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    if ((int)g_scratch.size() <= device) g_scratch.resize((size_t)device + 1);
+    Scratch& s = g_scratch[(size_t)device];
+    if (!s.busy) {
+      if (s.bytes < bytes) {
+        if (s.p) hipFree(s.p);
+        s.p = nullptr; s.bytes = 0;
+        if (hipMalloc(&s.p, bytes) != hipSuccess) { (void)hipGetLastError(); s.p = nullptr; return fail(CC_ERR_HIP, "hipMalloc(%zu) failed", bytes); }
+        s.bytes = bytes;
+      }
+      s.busy = true;
+      *out = s.p;
+      *cached = true;
+      return CC_OK;
+    }
+  }
+  CC_HIP(hipMalloc(out, bytes));
+  return CC_OK;
+}
+
+void scratch_put(int device, void* p, size_t, bool cached) {
+  if (!p) return;
+  if (cached) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    if ((int)g_scratch.size() > device && g_scratch[(size_t)device].p == p) { g_scratch[(size_t)device].busy = false; return; }
+  }
+  hipFree(p);
+}
+
 void stream_put(int device, hipStream_t s) {
   if (!s) return;
   std::lock_guard<std::mutex> lk(g_cache_mu);

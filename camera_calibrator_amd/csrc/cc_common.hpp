@@ -36,6 +36,11 @@ void* pinned_block_get();
 void pinned_block_put(void* p);
 int stream_get(int device, hipStream_t* out);
 void stream_put(int device, hipStream_t s);
+// One reusable scratch buffer per device for the point kernels (Distort / Undistort are called once per frame by the
+// Python workflow): grows to the largest request (<= 64 MiB kept), handed out to one caller at a time; a second
+// concurrent caller simply gets a fresh allocation. scratch_put frees what was not taken from / cannot go back to the cache.
+int scratch_get(int device, size_t bytes, void** out, bool* cached);
+void scratch_put(int device, void* p, size_t bytes, bool cached);
 
 // ---------------------------------------------------------------------------------------------
 // Mailbox exchange between the ranks of one node (device side: cc_device.hpp; host side: cc_comm.cpp)

@@ -97,20 +97,26 @@ static int run_points(int device, const float* K, const float* dist, int64_t n, 
   P.fx = K[0]; P.fy = K[4]; P.px = K[2]; P.py = K[5];
   P.k1 = dist[0]; P.k2 = dist[1]; P.p1 = dist[2]; P.p2 = dist[3]; P.k3 = dist[4];
   inv3f(K, P.Ki);
-  // one scratch allocation (input | output) and a cached stream per call: the Python workflow calls this once per
-  // frame (cam_calibration.py:85-97), so the fixed cost matters more than the kernel
+  // cached stream and cached scratch buffer (input | output): the Python workflow calls this once per frame
+  // (cam_calibration.py:85-97), so the fixed cost matters more than the kernel
   hipStream_t stream = nullptr;
   if (int rc = stream_get(device, &stream)) return rc;
   float2* buf = nullptr;
+  bool cached = false;
+  const size_t bytes = (size_t)2 * n * sizeof(float2);
   struct Release {
-    float2** p; int device; hipStream_t s;
+    float2** p; int device; hipStream_t s; size_t bytes; bool* cached;
     ~Release() {
       const bool ok = hipStreamSynchronize(s) == hipSuccess;
-      if (*p) hipFree(*p);
+      scratch_put(device, *p, bytes, *cached);
       if (ok) stream_put(device, s); else hipStreamDestroy(s);
     }
-  } release{&buf, device, stream};
-  CC_HIP(hipMalloc(&buf, (size_t)2 * n * sizeof(float2)));
+  } release{&buf, device, stream, bytes, &cached};
+  {
+    void* raw = nullptr;
+    if (int rc = scratch_get(device, bytes, &raw, &cached)) return rc;
+    buf = static_cast<float2*>(raw);
+  }
   float2 *din = buf, *dout = buf + n;
   CC_HIP(hipMemcpyAsync(din, in, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, stream));
   const int threads = 256;
