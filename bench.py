@@ -360,6 +360,8 @@ def main():
                 k: (prof["kernel_ms"][k] / prof["kernel_launches"][k] if prof["kernel_launches"][k] else None)
                 for k in prof["kernel_ms"]
             },
+            "kernel_ms_labels": "eager launches with hipEvents around each: sweep = k_intr_sweep, elim = k_intr_decide_elim "
+                                "(statistics + trust-region decision + pose elimination + 9x9 solve step in one launch)",
         }
         if strong is not None:
             result["strong_scaling"] = strong
@@ -452,6 +454,8 @@ def rig_configs(capi, device):
                 "dominant_kernel_fp64_frac": RIG_FLOP_PER_OBS * n_obs / (sweep_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                 "algorithmic_bytes_per_launch": ab,
                 "kernel_ms_per_launch_eager": per_launch,
+                "kernel_ms_labels": "sweep = k_rig_sweep, decide = k_rig_init (once per solve), elim = k_rig_elim, "
+                                    "solve = k_rig_reduce (column sums + reduced solve + pose update in one launch)",
                 "final_cost": s["final_cost"],
             }
     return out
