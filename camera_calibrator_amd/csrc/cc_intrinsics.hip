@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
   // [92..100] ds (scaled), [101..109] ss, [110..115] sp
   // sm[120..134] unscaled step (9 shared, 6 pose); sm[136..144] R; [145..147] t; [148..156] intr_cand
   // sm[158] step^2 (pose part), sm[159] |x_cand|^2 (pose part); sm[160..169] pose/intr of `cur`
-  // flags: bit 0 = part of a solve (mailbox epochs advance), bit 1 = RESTART: first launch of a solve that starts
+  // flags: bit 0 = part of a solve (mailbox epochs advance), bit 2 = fetch only the current Gram buffer, bit 1 = RESTART: first launch of a solve that starts
   // from the state of the last set_state. The restart sweep ignores the stale control block (it behaves as if
   // it were zero: initial evaluation into buffer 0), takes poses and intrinsics from the initial-state arrays and
   // restores buffer 0 from them on the way, so a restart costs no kernel of its own.
@@ -191,11 +191,22 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
     else v = P.sp[f * 8 + (tid - 110)];
     sm[tid] = v;
   }
+  // previous Gram block of the frame (model-cost term): sum of its tiles. When the grid is one residency round
+  // (<= 1024 workgroups) BOTH ping-pong buffers are fetched in the gather round trip, because waiting for the control
+  // block first would put a dependent round trip on every workgroup's critical path; with more workgroups than
+  // slots that latency hides behind the other workgroups of the CU and the second 2 KB per frame are pure waste
+  // (flags bit 2, set by the host): only the current buffer is fetched, after the control block.
   double g_old0 = 0.0, g_old1 = 0.0;
-  if (tile == 0) {   // previous Gram block of the frame (model-cost term): sum of its tiles
-    for (int k = 0; k < T; ++k) {
-      g_old0 += P.blocks[((size_t)f * T + k) * 256 + tid];
-      g_old1 += P.blocks[(((size_t)P.F + f) * T + k) * 256 + tid];
+  if (tile == 0) {
+    if (flags & 4) {
+      const size_t base = cur ? (size_t)P.F : 0;
+      for (int k = 0; k < T; ++k) g_old0 += P.blocks[((base + f) * T + k) * 256 + tid];
+      g_old1 = g_old0;
+    } else {
+      for (int k = 0; k < T; ++k) {
+        g_old0 += P.blocks[((size_t)f * T + k) * 256 + tid];
+        g_old1 += P.blocks[(((size_t)P.F + f) * T + k) * 256 + tid];
+      }
     }
   }
   if (done) return;
@@ -1056,6 +1067,7 @@ struct Probe {  // optional hipEvent bracket around one launch
 
 static void launch_sweep(cc_intrinsics* h, bool profile, int flags = 0) {
   Probe p(h, CC_K_SWEEP, profile);
+  if (h->F * h->d.T > 1024) flags |= 4;   // more workgroups than residency slots: fetch only the current Gram buffer
   hipLaunchKernelGGL(k_intr_sweep, dim3((unsigned)(h->F * h->d.T)), dim3(kSweepThreads), kSweepLdsBytes, h->stream, h->d, flags);
 }
 

@@ -241,26 +241,31 @@ __global__ __launch_bounds__(kRigThreads, HK ? 2 : CC_RIG_SWEEP_WAVES) void k_ri
   double* sm = s_stage + 4 * kTiles * kStageDoublesPerWave;  // [256]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t g = blockIdx.x;
-  const LmCtl* ctl = P.ctl;
-  if (ctl->done) return;
-  const int phase = ctl->phase;
-  if (phase != 0 && !ctl->step_valid) return;
-  const int cur = ctl->cur, dst = phase == 0 ? cur : (cur ^ 1);
+  // the group's indices do not depend on the control block: all five loads leave in one round trip
   const int f = P.gframe[g], c = P.gcam[g];
+  const int64_t s0 = P.goff[g], s1 = P.goff[g + 1];
+  const LmCtl* ctl = P.ctl;
+  const int done = ctl->done, phase = ctl->phase, step_valid = ctl->step_valid, cur = ctl->cur;
+  if (done) return;
+  if (phase != 0 && !step_valid) return;
+  const int dst = phase == 0 ? cur : (cur ^ 1);
   const bool fixed = P.cam_fixed[c] != 0;
   const int ks = HK ? P.kset[c] : 0;
   // observations are fetched one pass ahead: pixel + world index, then the gathered world point (two
   // dependent round trips); the first pass is issued here, under the prologue
-  const int64_t s0 = P.goff[g], s1 = P.goff[g + 1];
   // passes of THIS wave: a wave whose 64 slots of a pass all lie beyond the group skips that pass
   // (wave-uniform; the main loop holds no workgroup barrier)
-  const int64_t wrem = s1 - s0 - (tid >> 6) * 64;
+  // The 64-observation chunks are dealt to the waves starting at wave (g mod 4): wave w of every workgroup of a CU
+  // sits on SIMD w, and with e.g. 300 observations per group (5 chunks) a fixed deal would give SIMD 0 twice the
+  // passes of the others.
+  const int otid = (((tid >> 6) - (int)(g & 3)) & 3) * 64 + lane;   // this thread's slot in the group's pass
+  const int64_t wrem = s1 - s0 - (otid >> 6) * 64;
   const int npass = wrem > 0 ? (int)((wrem + kRigThreads - 1) / kRigThreads) : 0;
   const float2* uv2 = reinterpret_cast<const float2*>(P.uv);
   float2 nm = make_float2(0.f, 0.f);
   float nX0 = 0.f, nX1 = 0.f, nX2 = 1.f;
   if (npass > 0) {
-    const int64_t idx = s0 + tid;
+    const int64_t idx = s0 + otid;
     const int64_t ic = idx < s1 ? idx : s0;
     nm = uv2[ic];
     const int64_t w = P.widx[ic];
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(kRigThreads, HK ? 2 : CC_RIG_SWEEP_WAVES) void k_ri
   d4 ab0 = {0.0, 0.0, 0.0, 0.0}, ab1 = {0.0, 0.0, 0.0, 0.0}, bb0 = {0.0, 0.0, 0.0, 0.0}, bb1 = {0.0, 0.0, 0.0, 0.0};
   double cost = 0.0;
   for (int p = 0; p < npass; ++p) {
-    const int64_t idx = s0 + (int64_t)p * kRigThreads + tid;
+    const int64_t idx = s0 + (int64_t)p * kRigThreads + otid;
     const bool valid = idx < s1;
     const float2 m = nm;
     const float X0 = nX0, X1 = nX1, X2 = nX2;
