@@ -160,7 +160,7 @@ def main():
         def _attach(self):
             # The two per-iteration reductions are <= 1 KB: within a node they go through mailboxes in peer HBM
             # (cc_intrinsics_exchange_*, stores over xGMI, graph-captured); RCCL all-reduce is the fallback (and the
-            # only choice beyond 8 ranks). CC_EXCHANGE=mailbox|rccl forces one.
+            # only choice beyond 8 ranks). CC_EXCHANGE=mailbox|rccl|replicas forces one.
             prob = self.prob
             want = os.environ.get("CC_EXCHANGE", "auto")
             if want in ("auto", "mailbox") and world <= 8:
@@ -206,11 +206,43 @@ def main():
                     dist.barrier()
                     prob.close()
                     self.prob = prob = self._make()
+            if want == "replicas":   # rehearsal of the last resort below
+                self.exchange = "none: independent replicas (forced by CC_EXCHANGE=replicas)"
+                return
             if self.exchange == "none":
-                uid = [capi.comm_get_unique_id() if rank == 0 else None]
+                ok, why = True, ""
+                try:
+                    uid = [capi.comm_get_unique_id() if rank == 0 else None]
+                except capi.CcError as e:
+                    uid, ok, why = [None], False, str(e)
                 dist.broadcast_object_list(uid, src=0)
-                prob.comm_init(uid[0], rank, world)
-                self.exchange = "rccl"
+                ok = all_ok(uid[0] is not None)
+                if ok:
+                    try:   # same acceptance test as for the mailboxes: one complete solve, identical bits on every rank
+                        prob.comm_init(uid[0], rank, world)
+                        prob.reset()
+                        chk = prob.solve(capi.default_options(), log_capacity=0)
+                        intr_chk, _, _ = prob.get_state()
+                        mine = (intr_chk.tobytes(), chk["final_cost"])
+                    except capi.CcError as e:
+                        ok, why, mine = False, str(e), None
+                        print(f"[bench rank {rank}] RCCL exchange failed: {e}", file=sys.stderr)
+                    parts = [None] * world
+                    dist.all_gather_object(parts, mine)
+                    ok = all(p is not None and p == parts[0] for p in parts)
+                if ok:
+                    self.exchange = "rccl"
+                elif want == "rccl":
+                    raise SystemExit(f"CC_EXCHANGE=rccl but the RCCL exchange is not usable here: {why}")
+                else:
+                    # last resort, so that the run still reports something honest: every rank solves its own shard as
+                    # an independent problem (no joint intrinsics; DESIGN.md section 4 calls this "replicas")
+                    if rank == 0:
+                        print("[bench] neither exchange route works on this node: running independent replicas", file=sys.stderr)
+                    dist.barrier()
+                    prob.close()
+                    self.prob = self._make()
+                    self.exchange = "none: independent replicas (both exchange routes failed)"
 
         def run_steps(self, k):
             """Run exactly k LM iterations as consecutive complete solves; returns (solves, last summary)."""
@@ -329,7 +361,8 @@ def main():
                             f"{args.points} pts per GPU, radial-tangential distortion, Zhang init, "
                             f"reference solver options (calibrator.cpp:314-321)",
                 "frames_total": leg.F_total, "points_per_frame": args.points,
-                "observations_total": n_obs_total, "parallelism": f"frame-sharded x{world}", "exchange": leg.exchange,
+                "observations_total": n_obs_total, "parallelism": (f"independent replicas x{world}" if world > 1 and leg.exchange.startswith("none") else f"frame-sharded x{world}"),
+                "exchange": leg.exchange,
             },
             "lm_iterations_per_sec": it_per_s,
             "solves_in_timed_region": solves,
