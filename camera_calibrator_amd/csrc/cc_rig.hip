@@ -39,6 +39,8 @@ namespace cc {
 constexpr int kRigMaxS = 127;   // shared tangent coordinates: S + 1 (right-hand side) <= 128 = 8 column tiles of 16
 constexpr int kRigThreads = 256;
 constexpr int kRigSweepLdsBytes = (4 * kStageDoublesPerWave + 256) * 8;
+constexpr int kRigSweepLdsBytes2 = (2 * kStageDoublesPerWave + 256) * 8;   // two-wave workgroups
+constexpr int kRigSweepLdsBytes1 = (1 * kStageDoublesPerWave + 256) * 8;   // one-wave workgroups
 constexpr int kRigSweepLdsBytesK = (8 * kStageDoublesPerWave + 256) * 8;  // with intrinsics: two staged tiles per wave
 constexpr int kRigK = 9;              // intrinsics per set (extension)
 constexpr int kRigMaxElimBlocks = 256;
@@ -232,13 +234,19 @@ __device__ __forceinline__ void gram_rows_ab(const double* sa, const double* sb,
 #ifndef CC_RIG_SWEEP_WAVES
 #define CC_RIG_SWEEP_WAVES 4   // waves per SIMD the poses-only sweep is compiled for (A/B knob)
 #endif
-template <bool HK>
-__global__ __launch_bounds__(kRigThreads, HK ? 2 : CC_RIG_SWEEP_WAVES) void k_rig_sweep(RigDev P) {
+// NW = waves per workgroup: 4, or 2 for the poses-only problem when the groups are small and outnumber the
+// residency slots of four-wave workgroups (BASELINE configs[3]: 1600 groups of 300 observations = 5 chunks; twice as
+// many half-size workgroups are all resident at once and split the chunks 3 + 2 instead of 2 + 1 + 1 + 1).
+template <bool HK, int NW>
+__global__ __launch_bounds__(NW * 64, HK ? 2 : CC_RIG_SWEEP_WAVES) void k_rig_sweep(RigDev P) {
+  static_assert(NW == 4 || ((NW == 2 || NW == 1) && !HK), "small workgroups exist for the poses-only sweep");
+  constexpr int NT = NW * 64;      // threads
+  constexpr int EPT = 256 / NT;    // block entries per thread
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int kTiles = HK ? 2 : 1;
   double* s_stage = reinterpret_cast<double*>(smem_raw);
   double* s_blk = s_stage;
-  double* sm = s_stage + 4 * kTiles * kStageDoublesPerWave;  // [256]
+  double* sm = s_stage + NW * kTiles * kStageDoublesPerWave;  // [256]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t g = blockIdx.x;
   // the group's indices do not depend on the control block: all five loads leave in one round trip
@@ -255,12 +263,12 @@ __global__ __launch_bounds__(kRigThreads, HK ? 2 : CC_RIG_SWEEP_WAVES) void k_ri
   // dependent round trips); the first pass is issued here, under the prologue
   // passes of THIS wave: a wave whose 64 slots of a pass all lie beyond the group skips that pass
   // (wave-uniform; the main loop holds no workgroup barrier)
-  // The 64-observation chunks are dealt to the waves starting at wave (g mod 4): wave w of every workgroup of a CU
+  // The 64-observation chunks are dealt to the waves starting at wave (g mod NW): wave w of every workgroup of a CU
   // sits on SIMD w, and with e.g. 300 observations per group (5 chunks) a fixed deal would give SIMD 0 twice the
   // passes of the others.
-  const int otid = (((tid >> 6) - (int)(g & 3)) & 3) * 64 + lane;   // this thread's slot in the group's pass
+  const int otid = (((tid >> 6) - (int)(g & (NW - 1))) & (NW - 1)) * 64 + lane;   // this thread's slot in the group's pass
   const int64_t wrem = s1 - s0 - (otid >> 6) * 64;
-  const int npass = wrem > 0 ? (int)((wrem + kRigThreads - 1) / kRigThreads) : 0;
+  const int npass = wrem > 0 ? (int)((wrem + NT - 1) / NT) : 0;
   const float2* uv2 = reinterpret_cast<const float2*>(P.uv);
   float2 nm = make_float2(0.f, 0.f);
   float nX0 = 0.f, nX1 = 0.f, nX2 = 1.f;
@@ -276,27 +284,35 @@ __global__ __launch_bounds__(kRigThreads, HK ? 2 : CC_RIG_SWEEP_WAVES) void k_ri
   else if (tid < 64) sm[tid] = P.frec[(size_t)f * 32 + (tid - 32)];
   else if (HK && tid < 96) sm[tid] = P.krec[ks * 32 + (tid - 64)];
   const size_t gs = (size_t)P.gstride;
-  double g_old = 0.0, g_ab = 0.0, g_bb = 0.0;
+  double g_old[EPT], g_ab = 0.0, g_bb = 0.0;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) g_old[e] = 0.0;
   if (phase != 0) {
     const double* old = P.gblocks + ((size_t)cur * P.NG + g) * gs;
-    g_old = old[tid];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) g_old[e] = old[tid + e * NT];
     if (HK) { g_ab = old[256 + tid]; g_bb = old[512 + tid]; }
   }
   __syncthreads();
   // model-cost term of the group: d = [dc(6) df(6) (dk(9))], q = d^T g + 1/2 d^T H d over its block
   double qterm = 0.0;
   if (phase != 0) {
-    const int a = tid >> 4, b = tid & 15;
-    const double da = a < 6 ? sm[12 + a] : (a < 12 ? sm[32 + 12 + (a - 6)] : 0.0);
-    if (a < 12) {
-      if (b < 12) {
-        const double db = b < 6 ? sm[12 + b] : sm[32 + 12 + (b - 6)];
-        qterm = 0.5 * da * g_old * db;
-      } else if (b == 12) {
-        qterm = da * g_old;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int a = (tid + e * NT) >> 4, b = tid & 15;
+      const double da = a < 6 ? sm[12 + a] : (a < 12 ? sm[32 + 12 + (a - 6)] : 0.0);
+      if (a < 12) {
+        if (b < 12) {
+          const double db = b < 6 ? sm[12 + b] : sm[32 + 12 + (b - 6)];
+          qterm += 0.5 * da * g_old[e] * db;
+        } else if (b == 12) {
+          qterm += da * g_old[e];
+        }
       }
     }
     if (HK) {
+      const int a = tid >> 4, b = tid & 15;
+      const double da = a < 6 ? sm[12 + a] : (a < 12 ? sm[32 + 12 + (a - 6)] : 0.0);
       const double dkb = b < 9 ? sm[64 + 16 + b] : 0.0;
       if (a < 12) qterm += da * g_ab * dkb;            // cross term, counted once (1/2 * 2)
       else if (a == 12) qterm += g_ab * dkb;           // gradient with respect to the intrinsics
@@ -317,12 +333,12 @@ __global__ __launch_bounds__(kRigThreads, HK ? 2 : CC_RIG_SWEEP_WAVES) void k_ri
   d4 ab0 = {0.0, 0.0, 0.0, 0.0}, ab1 = {0.0, 0.0, 0.0, 0.0}, bb0 = {0.0, 0.0, 0.0, 0.0}, bb1 = {0.0, 0.0, 0.0, 0.0};
   double cost = 0.0;
   for (int p = 0; p < npass; ++p) {
-    const int64_t idx = s0 + (int64_t)p * kRigThreads + otid;
+    const int64_t idx = s0 + (int64_t)p * NT + otid;
     const bool valid = idx < s1;
     const float2 m = nm;
     const float X0 = nX0, X1 = nX1, X2 = nX2;
     if (p + 1 < npass) {
-      const int64_t idn = idx + kRigThreads;
+      const int64_t idn = idx + NT;
       const int64_t ic = idn < s1 ? idn : s0;
       nm = uv2[ic];
       const int64_t w = P.widx[ic];
@@ -387,8 +403,13 @@ __global__ __launch_bounds__(kRigThreads, HK ? 2 : CC_RIG_SWEEP_WAVES) void k_ri
   if (lane == 0) { sm[140 + wave] = qw; sm[144 + wave] = cw; }
   __syncthreads();
   double* out = P.gblocks + ((size_t)dst * P.NG + g) * gs;
-  const double gv = (s_blk[tid] + s_blk[256 + tid]) + (s_blk[512 + tid] + s_blk[768 + tid]);
-  out[tid] = gv;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int t = tid + e * NT;
+    const double gv = NW == 4 ? (s_blk[t] + s_blk[256 + t]) + (s_blk[512 + t] + s_blk[768 + t]) : (NW == 2 ? s_blk[t] + s_blk[256 + t] : s_blk[t]);
+    out[t] = gv;
+    if (phase == 0 && (t >> 4) < 6 && (t & 15) == (t >> 4)) P.ghd0[g * 8 + (t >> 4)] = gv;  // diag of H_cc
+  }
   if (HK) {
     out[256 + tid] = (s_blk[1024 + tid] + s_blk[1280 + tid]) + (s_blk[1536 + tid] + s_blk[1792 + tid]);
     const double bv = (s_blk[2048 + tid] + s_blk[2304 + tid]) + (s_blk[2560 + tid] + s_blk[2816 + tid]);
@@ -396,10 +417,9 @@ __global__ __launch_bounds__(kRigThreads, HK ? 2 : CC_RIG_SWEEP_WAVES) void k_ri
     if (phase == 0 && (tid >> 4) < 9 && (tid & 15) == (tid >> 4)) P.ghdk[g * 16 + (tid >> 4)] = bv;  // diag of H_kk
   }
   if (tid == 0) {
-    P.gstats[g * 2] = (sm[144] + sm[145]) + (sm[146] + sm[147]);
-    P.gstats[g * 2 + 1] = (sm[140] + sm[141]) + (sm[142] + sm[143]);
+    P.gstats[g * 2] = NW == 4 ? (sm[144] + sm[145]) + (sm[146] + sm[147]) : (NW == 2 ? sm[144] + sm[145] : sm[144]);
+    P.gstats[g * 2 + 1] = NW == 4 ? (sm[140] + sm[141]) + (sm[142] + sm[143]) : (NW == 2 ? sm[140] + sm[141] : sm[140]);
   }
-  if (phase == 0 && (tid >> 4) < 6 && (tid & 15) == (tid >> 4)) P.ghd0[g * 8 + (tid >> 4)] = gv;  // diag of H_cc
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1466,6 +1486,7 @@ struct cc_rig {
   hipStream_t stream = nullptr;
   cc::RigDev d{};
   int64_t C = 0, F = 0, N = 0, NG = 0, P = 0;
+  int sweep_waves = 4;       // waves per workgroup of the poses-only sweep (2: small groups that outnumber the slots)
   int kmode = 0;
   std::vector<int64_t> perm;  // sorted position -> caller's observation index
   std::vector<void*> allocs;    // the chunks dev_alloc carves buffers from
@@ -1711,8 +1732,10 @@ static void rig_exchange_bounds(const cc_rig* h, int* doubles_kind0, int* double
 static int rig_enqueue_round(cc_rig* h, bool initial, bool profile) {
   const RigDev& d = h->d;
   { RigProbe p(h, CC_K_SWEEP, profile);
-    if (d.kmode) hipLaunchKernelGGL(k_rig_sweep<true>, dim3((unsigned)h->NG), dim3(kRigThreads), kRigSweepLdsBytesK, h->stream, d);
-    else hipLaunchKernelGGL(k_rig_sweep<false>, dim3((unsigned)h->NG), dim3(kRigThreads), kRigSweepLdsBytes, h->stream, d); }
+    if (d.kmode) hipLaunchKernelGGL((k_rig_sweep<true, 4>), dim3((unsigned)h->NG), dim3(kRigThreads), kRigSweepLdsBytesK, h->stream, d);
+    else if (h->sweep_waves == 2) hipLaunchKernelGGL((k_rig_sweep<false, 2>), dim3((unsigned)h->NG), dim3(128), kRigSweepLdsBytes2, h->stream, d);
+    else if (h->sweep_waves == 1) hipLaunchKernelGGL((k_rig_sweep<false, 1>), dim3((unsigned)h->NG), dim3(64), kRigSweepLdsBytes1, h->stream, d);
+    else hipLaunchKernelGGL((k_rig_sweep<false, 4>), dim3((unsigned)h->NG), dim3(kRigThreads), kRigSweepLdsBytes, h->stream, d); }
   if (h->comm || h->exchange) {
     { RigProbe p(h, CC_K_DECIDE, profile); hipLaunchKernelGGL(k_rig_stats, dim3(1), dim3(256), 0, h->stream, d); }
     if (h->comm) { RigProbe p(h, CC_K_ALLREDUCE, profile); if (int rc = comm_allreduce_sum(h->comm, d.vec_stats, 4 + d.S, h->stream)) return rc; }
@@ -1870,6 +1893,16 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   if (int rc = dev_zeroed(h, &d.camrec, (size_t)C * 32)) return rc;
   if (int rc = dev_zeroed(h, &d.frec, (size_t)F * 32)) return rc;
   if (int rc = dev_alloc(h, &d.gblocks, (size_t)2 * NG * d.gstride)) return rc;
+  {
+    // sweep workgroup size (poses-only problem; measured on MI355X, profiles/r02/rig_sweep_waves.txt): a workgroup per
+    // (frame, camera) group of 4, 2 or 1 waves. Fewer waves per group = more, smaller workgroups in flight at
+    // different phases (better latency hiding, no cross-wave reduction) but less parallelism inside a group:
+    // one wave when the groups alone oversubscribe the chip's 4096 wave slots or have a single 64-observation chunk,
+    // two when they at least fill a quarter of them, four otherwise. CC_RIG_SWEEP_WG_WAVES forces one (A/B, tests).
+    const double per_group = NG > 0 ? (double)N / (double)NG : 0.0;
+    h->sweep_waves = kmode ? 4 : ((NG >= 4096 || per_group <= 64.0) ? 1 : (NG >= 1024 ? 2 : 4));
+    if (const char* e = getenv("CC_RIG_SWEEP_WG_WAVES")) { const int v = atoi(e); if (!kmode && (v == 1 || v == 2 || v == 4)) h->sweep_waves = v; }
+  }
   if (int rc = dev_zeroed(h, &d.intr, 2 * CKn * 16)) return rc;
   if (int rc = dev_zeroed(h, &d.krec, CKn * 32)) return rc;
   if (int rc = dev_zeroed(h, &d.ghdk, (size_t)(kmode ? NG * 16 : 16))) return rc;
@@ -1894,8 +1927,10 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   if (int rc = dev_alloc(h, &h->d_cost, (size_t)N)) return rc;
   h->h_ctl = reinterpret_cast<LmCtl*>(pinned_block_get());
   if (!h->h_ctl) return fail(CC_ERR_HIP, "hipHostMalloc failed");
-  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_sweep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kRigSweepLdsBytes));
-  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_sweep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kRigSweepLdsBytesK));
+  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_sweep<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kRigSweepLdsBytes));
+  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_sweep<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kRigSweepLdsBytes2));
+  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_sweep<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kRigSweepLdsBytes1));
+  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_sweep<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kRigSweepLdsBytesK));
   guard.ok = true;
   *out = h;
   return CC_OK;

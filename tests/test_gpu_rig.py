@@ -46,6 +46,17 @@ def test_rig_default_options_match_oracle(cams, frames, pts):
     assert np.array_equal(g[0][0], o[0][0]) and np.array_equal(g[1][0], o[1][0])   # frozen camera untouched
 
 
+@pytest.mark.parametrize("waves", [1, 2, 4])
+@pytest.mark.parametrize("cams,frames,pts", [(3, 30, 150), (5, 12, 70)])
+def test_rig_sweep_workgroup_sizes_give_the_same_solve(monkeypatch, waves, cams, frames, pts):
+    """The poses-only sweep runs with 1, 2 or 4 waves per (frame, camera) group depending on the problem's shape
+    (cc_rig.hip, rig_create_impl); every variant must match the oracle, whatever the heuristic would pick."""
+    monkeypatch.setenv("CC_RIG_SWEEP_WG_WAVES", str(waves))
+    sc = po.rig_scenario(cams, frames, pts)
+    g, o = _both(sc, cams)
+    _assert_same(g, o)
+
+
 def test_rig_converged_minimiser_and_golden():
     import os
     gld = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rig_2x50x4.npz"))
