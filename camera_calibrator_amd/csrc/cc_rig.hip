@@ -1018,45 +1018,119 @@ __device__ __forceinline__ void rig_candidates(const RigDev& P, const double* x,
   }
 }
 
-// Cholesky + forward substitution of an S x S system (S <= SMAX <= 64) on ONE wave, matrix rows in REGISTERS:
-// lane i keeps row i of the lower triangle (loaded from LDS, row stride LD); column j's pivot and multipliers
-// travel through v_readlane, so a column step is two scalar reads and one FMA per trailing column with no LDS
-// round trip and no barrier on the dependent chain (the LDS version below pays ~0.4 us per column for them).
-// Rows / columns S..SMAX-1 are identity. On return: L (lower) is back in LDS, b holds y = L^-1 b (lane i: y_i),
-// vinv lane j = 1 / L_jj, ok = every pivot positive and finite.
-template <int SMAX>
-__device__ __noinline__ void chol_wave(double* A, int S, int LD, double& b, double& vinv, int& ok_out) {
-  const int lane = threadIdx.x & 63;
-  double a[SMAX];
+// One panel (columns j0 .. j0 + nc - 1, nc <= 8) of the Cholesky factorisation of the S x S system in LDS, on ONE
+// wave: lane i keeps the panel's entries of row i (and, TWO, of row i + 64) in registers. A column step takes the
+// pivot with v_readlane, scales the column, puts it into the LDS vector `colbuf` and reads the multipliers of the
+// panel's remaining columns back as uniform-address LDS reads (LDS operations of one wave execute in order: no
+// barrier). The forward substitution of the right-hand side (b0 / b1: rows i / i + 64) rides along; v0 / v1 collect
+// 1 / L_ii. The loop over panels is rolled (rig_solve_block), so the code stays a few hundred instructions:
+// the fully unrolled whole-matrix-in-registers form this replaces ran 20 KB of straight-line code once per launch and
+// was bound by instruction fetch (profiles/r02/rig_reduce_breakdown.txt).
+template <bool TWO>
+__device__ __forceinline__ void chol_panel(double* A, int S, int LD, int j0, int nc, double* colbuf, double& b0, double& b1,
+                                           double& v0, double& v1, bool& okw) {
+  const int lane = threadIdx.x & 63, i0 = lane, i1 = lane + 64;
+  double p0[8], p1[8];
 #pragma unroll
-  for (int k = 0; k < SMAX; ++k) a[k] = (lane < S && k <= lane) ? A[(size_t)lane * LD + k] : (k == lane ? 1.0 : 0.0);
-  bool ok = true;
-  vinv = 0.0;
-#pragma unroll
-  for (int j = 0; j < SMAX; ++j) {
-    const double d = readlane_d(a[j], j);
-    ok = ok && (d > 0.0) && isfinite(d);
-    const double inv = rsqrt(d);
-    const double l = lane == j ? d * inv : a[j] * inv;
-    a[j] = l;
-    if (lane == j) vinv = inv;
-#pragma unroll
-    for (int k = j + 1; k < SMAX; ++k) a[k] -= l * readlane_d(l, k);
-    // the forward substitution rides along: y_j = b_j / L_jj, b_i -= L_ij y_j (i > j)
-    const double yj = readlane_d(b, j) * inv;
-    b = lane == j ? yj : (lane > j ? b - l * yj : b);
+  for (int c = 0; c < 8; ++c) {
+    const int col = j0 + c;
+    // (unconditional loads from a clamped row, then a select: conditional loads become one branch and one wait each)
+    const double x0 = A[(size_t)(i0 < S ? i0 : S - 1) * LD + col];
+    const double x1 = TWO ? A[(size_t)(i1 < S ? i1 : S - 1) * LD + col] : 0.0;
+    p0[c] = (c < nc && i0 < S && col <= i0) ? x0 : 0.0;
+    p1[c] = (TWO && c < nc && i1 < S && col <= i1) ? x1 : 0.0;
   }
-  if (lane < S) {
+  // The pivot of the NEXT column is taken ahead of the column's own update (two lane reads and one FMA, the very
+  // operation the update performs on that entry, so the value is the same bit for bit): its reciprocal square root is
+  // then computed while the LDS round trip of the multipliers is in flight instead of behind it.
+  double d = (!TWO || j0 < 64) ? readlane_d(p0[0], j0 & 63) : readlane_d(p1[0], j0 & 63);
+  double inv = rsqrt(d);
 #pragma unroll
-    for (int k = 0; k < SMAX; ++k)
-      if (k <= lane) A[(size_t)lane * LD + k] = a[k];
+  for (int c = 0; c < 8; ++c) {
+    if (c < nc) {   // (uniform)
+      const int col = j0 + c;
+      okw = okw && (d > 0.0) && isfinite(d);
+      const double l0 = i0 == col ? d * inv : (i0 > col ? p0[c] * inv : 0.0);
+      const double l1 = TWO ? (i1 == col ? d * inv : (i1 > col ? p1[c] * inv : 0.0)) : 0.0;
+      const double inv_c = inv;
+      p0[c] = l0;
+      if (i0 == col) v0 = inv;
+      colbuf[i0] = l0;
+      if (TWO) { p1[c] = l1; if (i1 == col) v1 = inv; colbuf[i1] = l1; }
+      wave_lds_fence();
+      if (c + 1 < 8 && c + 1 < nc) {
+        const int cn = col + 1;
+        const double ln = (!TWO || cn < 64) ? readlane_d(l0, cn & 63) : readlane_d(l1, cn & 63);          // L[cn][col]
+        const double pn = (!TWO || cn < 64) ? readlane_d(p0[c + 1], cn & 63) : readlane_d(p1[c + 1], cn & 63);
+        d = fma(-ln, ln, pn);
+        inv = rsqrt(d);
+      }
+      // (no test against nc here: columns beyond the panel's end are computed on whatever colbuf holds and never
+      // stored -- a uniform branch per column would put every LDS read behind its own wait)
+      double m[8];
+#pragma unroll
+      for (int c2 = c + 1; c2 < 8; ++c2) m[c2] = colbuf[j0 + c2];   // L[j0 + c2][col], same address in every lane
+#pragma unroll
+      for (int c2 = c + 1; c2 < 8; ++c2) {
+        p0[c2] = fma(-l0, m[c2], p0[c2]);
+        if (TWO) p1[c2] = fma(-l1, m[c2], p1[c2]);
+      }
+      // forward substitution: y_col = b_col / L_col,col, b_i -= L_i,col y_col (i > col)
+      const double yj = ((!TWO || col < 64) ? readlane_d(b0, col & 63) : readlane_d(b1, col & 63)) * inv_c;
+      b0 = i0 == col ? yj : (i0 > col ? b0 - l0 * yj : b0);
+      if (TWO) b1 = i1 == col ? yj : (i1 > col ? b1 - l1 * yj : b1);
+      wave_lds_fence();
+    }
   }
-  ok_out = ok ? 1 : 0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int col = j0 + c;
+    if (c < nc && i0 < S && col <= i0) A[(size_t)i0 * LD + col] = p0[c];
+    if (TWO && c < nc && i1 < S && col <= i1) A[(size_t)i1 * LD + col] = p1[c];
+  }
 }
+
+// Backward substitution L^T x = y on the same wave (lane i: rows i and, TWO, i + 64; v = 1 / L_ii). The factor entries
+// a lane needs do not depend on the running solution: they are fetched eight steps ahead and pre-multiplied by
+// 1 / L_jj, so that a step is one lane read and one FMA on the dependent chain; x_i = b_i / L_ii is formed at the end.
+template <bool TWO>
+__device__ __forceinline__ void chol_backward(const double* A, int S, int LD, double& b0, double& b1, double v0, double v1) {
+  const int lane = threadIdx.x & 63, i0 = lane, i1 = lane + 64;
+  for (int j0 = S - 1; j0 >= 0; j0 -= 8) {
+    double a0[8], a1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = j0 - u, jr = j >= 0 ? j : 0;
+      // (unconditional loads from row jr, then a select: a conditional load is a branch and a wait of its own)
+      const double x0 = A[(size_t)jr * LD + i0];
+      const double x1 = TWO ? A[(size_t)jr * LD + (i1 < LD ? i1 : 0)] : 0.0;
+      const double vj = (!TWO || jr < 64) ? readlane_d(v0, jr & 63) : readlane_d(v1, jr & 63);
+      a0[u] = (j >= 0 && i0 < j) ? x0 * vj : 0.0;
+      a1[u] = (TWO && j >= 0 && i1 < j) ? x1 * vj : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int jr = j0 - u >= 0 ? j0 - u : 0;   // (steps below row 0 multiply by the zeros selected above)
+      const double bj = (!TWO || jr < 64) ? readlane_d(b0, jr & 63) : readlane_d(b1, jr & 63);   // final: rows > j are done
+      b0 -= a0[u] * bj;
+      if (TWO) b1 -= a1[u] * bj;
+    }
+  }
+  b0 *= v0;
+  if (TWO) b1 *= v1;
+}
+
+// Timing-only builds (-DCC_RIG_TIMING, scripts/time_rig_reduce.py): the solving block leaves wall-clock marks
+// (100 MHz) in shared_stats[8..]; the product build compiles them away.
+#ifdef CC_RIG_TIMING
+#define RIG_MARK(i) do { if (threadIdx.x == 0) P.shared_stats[8 + (i)] = (double)wall_clock64(); } while (0)
+#else
+#define RIG_MARK(i) do { } while (0)
+#endif
 
 template <int SRC>
 __device__ void rig_solve_block(const RigDev& P, double* smem) {
-  const int S = P.S, LD = S + 1;
+  const int S = P.S, LD = (S + 1) | 1;   // odd row stride: a column walks all LDS banks
   double* A = smem;                       // [S][LD] lower triangle of the reduced system
   double* s_b = A + (size_t)S * LD;       // [128] right-hand side, then the solution x
   double* s_gs = s_b + 128;               // [128] unscaled shared gradient
@@ -1132,6 +1206,7 @@ __device__ void rig_solve_block(const RigDev& P, double* smem) {
     }
   }
   __syncthreads();
+  RIG_MARK(3);
   // ---- 2. right-hand side, LM diagonal, constant coordinates (held intrinsics) become identity rows
   if (tid < S) s_b[tid] = pinned ? 0.0 : s_b[tid] + s_ss[tid] * s_gs[tid];
   __syncthreads();
@@ -1162,119 +1237,97 @@ __device__ void rig_solve_block(const RigDev& P, double* smem) {
     s_c = c;
   }
   __syncthreads();
-  if (s_go && S <= 64) {
-    // ---- factorisation and forward substitution in registers on wave 0, backward substitution from LDS
-    if (tid < 64) {
-      double b0 = lane < S ? s_b[lane] : 0.0, vinv = 0.0;
-      int ok = 0;
-      if (S <= 4) chol_wave<4>(A, S, LD, b0, vinv, ok);
-      else if (S <= 8) chol_wave<8>(A, S, LD, b0, vinv, ok);
-      else if (S <= 12) chol_wave<12>(A, S, LD, b0, vinv, ok);
-      else if (S <= 16) chol_wave<16>(A, S, LD, b0, vinv, ok);
-      else if (S <= 20) chol_wave<20>(A, S, LD, b0, vinv, ok);
-      else if (S <= 24) chol_wave<24>(A, S, LD, b0, vinv, ok);
-      else if (S <= 28) chol_wave<28>(A, S, LD, b0, vinv, ok);
-      else if (S <= 32) chol_wave<32>(A, S, LD, b0, vinv, ok);
-      else if (S <= 40) chol_wave<40>(A, S, LD, b0, vinv, ok);
-      else if (S <= 48) chol_wave<48>(A, S, LD, b0, vinv, ok);
-      else if (S <= 56) chol_wave<56>(A, S, LD, b0, vinv, ok);
-      else chol_wave<64>(A, S, LD, b0, vinv, ok);
-      wave_lds_fence();
-      const int i0 = lane;
-      for (int j0 = S - 1; j0 >= 0; j0 -= 8) {
-        double a0[8];
+  RIG_MARK(4);
+  if (s_go) {
+    // ---- Cholesky of the damped reduced system in LDS, eight columns at a time (S <= 127):
+    //   panel:    wave 0 (chol_panel), forward substitution included;
+    //   trailing: all 256 threads, A[i][k] -= sum_c L[i][c] L[k][c] over the panel's columns; two barriers per panel.
+    const int i0 = lane, i1 = lane + 64;
+    double b0 = 0.0, b1 = 0.0, v0 = 0.0, v1 = 0.0;
+    bool okw = true;
+    if (tid < 64) { b0 = i0 < S ? s_b[i0] : 0.0; b1 = i1 < S ? s_b[i1] : 0.0; }
+#ifdef CC_RIG_TIMING
+    long long tw = 0, tt = 0;
+#endif
+    for (int j0 = 0; j0 < S; j0 += 8) {
+      const int nc = S - j0 < 8 ? S - j0 : 8;
+#ifdef CC_RIG_TIMING
+      const long long ta = wall_clock64();
+#endif
+      if (tid < 64) {
+        if (S <= 64) chol_panel<false>(A, S, LD, j0, nc, s_inv, b0, b1, v0, v1, okw);
+        else chol_panel<true>(A, S, LD, j0, nc, s_inv, b0, b1, v0, v1, okw);
+      }
+      __syncthreads();
+#ifdef CC_RIG_TIMING
+      const long long tb = wall_clock64();
+      tw += tb - ta;
+#endif
+      const int t0 = j0 + nc;
+      if (t0 < S) {
+        // trailing triangle rows t0..S-1, columns t0..row, as a flat list of elements dealt to the threads three at a
+        // time: all LDS reads of a batch are issued before its first write (the elements are distinct and none lies
+        // in the panel's columns, which the compiler cannot know), so a batch costs one LDS round trip, not three
+        const int nt = S - t0, ne = nt * (nt + 1) / 2;
+        for (int e0 = 0; e0 < ne; e0 += 3 * 256) {
+          double acc[3], li[3][8], lk[3][8];
+          int at[3];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int j = j0 - u;
-          a0[u] = (j >= 0 && i0 < j) ? A[(size_t)j * LD + i0] : 0.0;
-        }
+          for (int u = 0; u < 3; ++u) {
+            const int e = e0 + u * 256 + tid;
+            at[u] = -1;
+            acc[u] = 0.0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int j = j0 - u;
-          if (j >= 0) {
-            const double xj = readlane_d(b0, j) * readlane_d(vinv, j);
-            if (i0 == j) b0 = xj; else b0 -= a0[u] * xj;
+            for (int c = 0; c < 8; ++c) { li[u][c] = 0.0; lk[u][c] = 0.0; }
+            if (e < ne) {
+              int n = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+              while (n * (n + 1) / 2 > e) --n;
+              while ((n + 1) * (n + 2) / 2 <= e) ++n;
+              const int i = t0 + n, k = t0 + (e - n * (n + 1) / 2);
+              at[u] = i * LD + k;
+              acc[u] = A[at[u]];
+#pragma unroll
+              for (int c = 0; c < 8; ++c) {   // (loads past the panel's end stay inside the LDS block; selected away)
+                const double x = A[(size_t)i * LD + j0 + c], y = A[(size_t)k * LD + j0 + c];
+                li[u][c] = c < nc ? x : 0.0;
+                lk[u][c] = c < nc ? y : 0.0;
+              }
+            }
           }
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[u] -= li[u][c] * lk[u][c];
+          }
+#pragma unroll
+          for (int u = 0; u < 3; ++u)
+            if (at[u] >= 0) A[at[u]] = acc[u];
         }
       }
-      const bool step_ok = s_cholok != 0 && ok != 0 && __all(i0 >= S || isfinite(b0));
+      __syncthreads();
+#ifdef CC_RIG_TIMING
+      tt += wall_clock64() - tb;
+#endif
+    }
+#ifdef CC_RIG_TIMING
+    if (tid == 0) { P.shared_stats[16] = (double)tw; P.shared_stats[17] = (double)tt; P.shared_stats[18] = (double)wall_clock64(); }
+#endif
+    if (tid < 64) {
+      if (S <= 64) chol_backward<false>(A, S, LD, b0, b1, v0, v1);
+      else chol_backward<true>(A, S, LD, b0, b1, v0, v1);
+      const bool fin = (i0 >= S || isfinite(b0)) && (i1 >= S || isfinite(b1));
+      const bool step_ok = s_cholok != 0 && __all(okw) && __all(fin);
       if (i0 < S) { s_b[i0] = b0; store_ds(P.ds + i0, -b0); }
+      if (i1 < S) { s_b[i1] = b1; store_ds(P.ds + i1, -b1); }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the update blocks of this launch read ds behind a flag
       if (lane == 0) s_stepok = step_ok ? 1 : 0;
     }
     __syncthreads();
-  } else if (s_go) {
-    // right-looking Cholesky, lower triangle in place, ONE barrier per step: every thread derives
-    // 1/sqrt(pivot) itself, the trailing update uses the unscaled column times inv^2, and the
-    // scaled column is written in the same step by the threads that own it.
-    const int ti = tid >> 4, tk = tid & 15;  // 16 x 16 thread tile over the trailing block
-    for (int j = 0; j < S; ++j) {
-      const double d = A[(size_t)j * LD + j];
-      if (tid == 0 && (!(d > 0.0) || !isfinite(d))) s_cholok = 0;
-      const double inv = rsqrt(d), inv2 = inv * inv;
-      for (int r = j + 1 + ti; r < S; r += 16) {
-        const double arj = A[(size_t)r * LD + j] * inv2;
-        for (int k = j + 1 + tk; k <= r; k += 16) A[(size_t)r * LD + k] -= arj * A[(size_t)k * LD + j];
-      }
-      __syncthreads();
-      for (int r = tid; r < S; r += 256)
-        if (r > j) A[(size_t)r * LD + j] *= inv;
-      if (tid == 0) { A[(size_t)j * LD + j] = d * inv; s_inv[j] = inv; }
-      // (column j is read again only by the substitutions, after the final barrier)
-    }
-    __syncthreads();
-    if (tid < 64) {
-      // forward / backward substitution on wave 0: lane i owns rows i and i + 64
-      const int i0 = lane, i1 = lane + 64;
-      double b0 = i0 < S ? s_b[i0] : 0.0, b1 = i1 < S ? s_b[i1] : 0.0;
-      const double v0 = i0 < S ? s_inv[i0] : 0.0, v1 = i1 < S ? s_inv[i1] : 0.0;
-      // the factor entries a lane needs do not depend on the running solution: fetch them eight
-      // steps ahead so that only the lane reads and the FMA sit on the dependent chain
-      for (int j0 = 0; j0 < S; j0 += 8) {
-        double a0[8], a1[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int j = j0 + u;
-          a0[u] = (j < S && i0 > j && i0 < S) ? A[(size_t)i0 * LD + j] : 0.0;
-          a1[u] = (j < S && i1 > j && i1 < S) ? A[(size_t)i1 * LD + j] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int j = j0 + u;
-          if (j < S) {
-            const double yj = j < 64 ? readlane_d(b0, j) * readlane_d(v0, j) : readlane_d(b1, j - 64) * readlane_d(v1, j - 64);
-            if (i0 == j) b0 = yj; else b0 -= a0[u] * yj;
-            if (i1 == j) b1 = yj; else b1 -= a1[u] * yj;
-          }
-        }
-      }
-      for (int j0 = S - 1; j0 >= 0; j0 -= 8) {
-        double a0[8], a1[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int j = j0 - u;
-          a0[u] = (j >= 0 && i0 < j) ? A[(size_t)j * LD + i0] : 0.0;
-          a1[u] = (j >= 0 && i1 < j) ? A[(size_t)j * LD + i1] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int j = j0 - u;
-          if (j >= 0) {
-            const double xj = j < 64 ? readlane_d(b0, j) * readlane_d(v0, j) : readlane_d(b1, j - 64) * readlane_d(v1, j - 64);
-            if (i0 == j) b0 = xj; else b0 -= a0[u] * xj;
-            if (i1 == j) b1 = xj; else b1 -= a1[u] * xj;
-          }
-        }
-      }
-      const bool fin = (i0 >= S || isfinite(b0)) && (i1 >= S || isfinite(b1));
-      const bool step_ok = s_cholok != 0 && __all(fin);
-      if (i0 < S) { s_b[i0] = b0; store_ds(P.ds + i0, -b0); }
-      if (i1 < S) { s_b[i1] = b1; store_ds(P.ds + i1, -b1); }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) s_stepok = step_ok ? 1 : 0;
-    }
-    __syncthreads();
+#ifdef CC_RIG_TIMING
+    if (tid == 0) P.shared_stats[19] = (double)wall_clock64();
+#endif
   }
+  RIG_MARK(5);
   // ---- camera / intrinsics candidates and records (nothing moves unless a valid step exists)
   double st2 = 0.0, xs2 = 0.0;
   const bool have_step = s_go != 0 && s_stepok != 0;
@@ -1299,6 +1352,7 @@ __device__ void rig_solve_block(const RigDev& P, double* smem) {
     *P.ctl = c;
     *P.ctl_next = c;
   }
+  RIG_MARK(6);
 }
 
 // RCCL route: the solve step as a kernel of its own (after the all-reduce of P.vec)
@@ -1348,6 +1402,9 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P) {
   }
   if (cn->phase == 0) return;
   const int tid = threadIdx.x, c = tid & 15, grp = tid >> 4;  // 16 columns x 16 row groups per step
+#ifdef CC_RIG_TIMING
+  const long long t_entry = wall_clock64();
+#endif
   unsigned epoch0 = 0;
   if (MODE != 2) epoch0 = __hip_atomic_load(P.arrive + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 3;   // before we arrive
   for (int first = blockIdx.x * 16; first < P.PC; first += gridDim.x * 16) {
@@ -1404,6 +1461,9 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P) {
     }
   }
   if (MODE == 2) return;
+#ifdef CC_RIG_TIMING
+  const long long t_sums = wall_clock64();
+#endif
   // ---- last-block-done: every storing wave drains its stores, the block arrives, the last one solves
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -1414,6 +1474,10 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P) {
   __syncthreads();
   if (s_last) {
     if (tid == 0) __hip_atomic_store(P.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+#ifdef CC_RIG_TIMING
+    if (tid == 0) { P.shared_stats[8] = (double)t_entry; P.shared_stats[9] = (double)t_sums; }
+#endif
+    RIG_MARK(2);
     rig_solve_block<MODE == 0 ? 1 : 2>(P, reinterpret_cast<double*>(smem_raw));
     // the shared step (sc1 stores of wave 0) has been drained inside; hand the outcome to the waiting blocks
     __syncthreads();
@@ -1438,6 +1502,9 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P) {
   if ((flag & 4u) || !(flag & 2u)) return;   // done, or no valid step: the poses stay
   const int cur = (int)(flag & 1u);
   for (int64_t fblk = blockIdx.x; fblk * 16 < P.F; fblk += gridDim.x) rig_update_body<true>(P, 1, cur, fblk);
+#ifdef CC_RIG_TIMING
+  if (s_last) { __syncthreads(); RIG_MARK(7); }
+#endif
 }
 
 // per-observation robustified cost at the accepted point (extrinsics_calibrator.cpp:219-225)
@@ -1628,7 +1695,7 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
   std::vector<uint8_t> ti, tj;
   for (int a = 0; a < d.T; ++a) for (int b = a; b < d.T; ++b) { ti.push_back((uint8_t)a); tj.push_back((uint8_t)b); }
   // solve-step tables: where reduced value e goes
-  const int LD = S + 1;
+  const int LD = (S + 1) | 1;   // row stride of the reduced system in the solve step's LDS (odd)
   std::vector<int32_t> dir_dst((size_t)std::max(CO * DE, 1), -1), dir_next((size_t)std::max(CO * DE, 1), -1);
   std::vector<int16_t> dir_sa((size_t)std::max(CO * DE, 1), 0), dir_sb((size_t)std::max(CO * DE, 1), 0);
   auto untri_h = [](int idx, int& i, int& j) { i = 0; while ((i + 1) * (i + 2) / 2 <= idx) ++i; j = idx - i * (i + 1) / 2; };
@@ -1702,7 +1769,7 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
   if (int rc = dev_zeroed(h, &d.vec, (size_t)d.PC + 32)) return rc;
   if (int rc = dev_zeroed(h, &d.vec_stats, (size_t)4 + kRigMaxS + 1)) return rc;
   h->elim_lds = ((size_t)24 * d.ZS + 4 * 32 + 4 * 1024) * sizeof(double);
-  h->solve_lds = ((size_t)S * (S + 1) + 5 * 128) * sizeof(double);
+  h->solve_lds = ((size_t)S * ((S + 1) | 1) + 5 * 128) * sizeof(double);
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_reduce<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
@@ -1915,7 +1982,7 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   if (int rc = dev_zeroed(h, &d.sp, (size_t)F * 8)) return rc;
   if (int rc = dev_zeroed(h, &d.ss, (size_t)128)) return rc;
   if (int rc = dev_zeroed(h, &d.ds, (size_t)128)) return rc;
-  if (int rc = dev_zeroed(h, &d.shared_stats, (size_t)4)) return rc;
+  if (int rc = dev_zeroed(h, &d.shared_stats, (size_t)32)) return rc;   // [0..3] statistics, [8..] timing marks (CC_RIG_TIMING builds)
   if (int rc = dev_zeroed(h, &d.ctl, (size_t)1)) return rc;
   if (int rc = dev_zeroed(h, &d.ctl_next, (size_t)1)) return rc;
   if (int rc = dev_zeroed(h, &d.arrive, (size_t)16)) return rc;

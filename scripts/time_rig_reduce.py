@@ -1,0 +1,29 @@
+"""Where the time of the rig path's reduce + solve + update launch goes: wall-clock marks left by the solving block of
+a timing-only build (scripts/build_variant.sh rigtime cc_rig.hip -DCC_RIG_TIMING; CC_LIB_PATH=scripts/ablate_build/libcc_rigtime.so).
+Env: C F M (cameras, frames, points per frame). Prints the stage durations in microseconds (last iteration of a solve)."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C
+import numpy as np
+import torch  # noqa: F401
+from camera_calibrator_amd import capi
+
+Cc, F, M = int(os.environ.get("C", 4)), int(os.environ.get("F", 400)), int(os.environ.get("M", 300))
+sc = capi.rig_scenario(Cc, F, M)
+cq, ct = capi.affine_to_qt(sc["cam_T"]); fq, ft = capi.affine_to_qt(sc["frame_T"])
+prob = capi.RigProblem(Cc, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"], sc["world_xyz"], sc["cam_frozen"])
+prob.set_state(cq, ct, fq, ft)
+rows = []
+for _ in range(5):
+    prob.reset()
+    s = prob.solve(capi.default_options(max_iterations=12), log_capacity=0)
+    buf = np.zeros(32)
+    capi._check(capi.lib().cc_rig_debug_fetch(prob._h, b"shared_stats", buf.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(32)))
+    t = buf[8:16] / 100.0   # 100 MHz ticks -> us
+    rows.append(np.concatenate([np.diff(t), [buf[16] / 100.0, buf[17] / 100.0, (buf[19] - buf[18]) / 100.0]]))
+prob.close()
+d = np.median(np.array(rows), axis=0)
+names = ["column sums", "drain + arrival", "reads + assembly", "rhs/diagonal/tests", "factorisation + substitutions",
+         "candidates + control block", "flag + pose update", "(of the factorisation: panels on wave 0)", "(trailing updates)",
+         "(backward substitution + step store)"]
+print(json.dumps({"cams": Cc, "frames": F, "pts": M, "total_us": float(d[:7].sum()), **{n: round(float(v), 2) for n, v in zip(names, d)}}))
