@@ -80,6 +80,7 @@ struct RigDev {
   const int32_t* colinfo;    // [SW] (observed camera j << 8) | (kind << 4) | component; kind 0 pose, 1 own intrinsics,
                              //      2 intrinsics shared by all cameras, 3 right-hand side
   const int16_t* dmap;       // [DE] offset of direct entry e inside a group block
+  const int32_t* dent;       // [ND] direct entry e -> (observed camera << 16) | offset inside its group block
   const uint8_t* tile_i;     // [nT] tile pairs (ti <= tj), row-major upper triangle
   const uint8_t* tile_j;
   // where the solve step puts reduced value e (host-built, rig_layout): >= 0 element of the LDS matrix (row * (S + 1)
@@ -511,8 +512,22 @@ __device__ __forceinline__ void rig_reduce_stats(const RigDev& P, bool want, dou
   if (want) {
     const d2* gs2 = reinterpret_cast<const d2*>(P.gstats);
     const d2* fs2 = reinterpret_cast<const d2*>(P.fstats);
-    for (int64_t i = tid; i < P.NG; i += 256) { const d2 v = gs2[i]; a[0] += v.x; a[1] += v.y; }
-    for (int64_t i = tid; i < P.F; i += 256) { const d2 v = fs2[i]; a[2] += v.x; a[3] += v.y; }
+    // up to sixteen loads in flight per thread: one round trip per 4096 groups instead of one per 256 (the plain loop waited
+    // for every load: 20 us for the 16000 groups of BASELINE configs[4], in every block of the elimination)
+    for (int64_t i0 = 0; i0 < P.NG; i0 += 16 * 256) {
+      d2 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { const int64_t i = i0 + u * 256 + tid; v[u] = i < P.NG ? gs2[i] : d2{0.0, 0.0}; }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { a[0] += v[u].x; a[1] += v[u].y; }
+    }
+    for (int64_t i0 = 0; i0 < P.F; i0 += 8 * 256) {
+      d2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int64_t i = i0 + u * 256 + tid; v[u] = i < P.F ? fs2[i] : d2{0.0, 0.0}; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a[2] += v[u].x; a[3] += v[u].y; }
+    }
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) a[k] = wave_sum(a[k]);
@@ -651,7 +666,16 @@ __global__ __launch_bounds__(256) void k_rig_init(RigDev P) {
 //   the (SW x SW) product Z^T Z goes to wave (index mod 4), 6 k-steps of v_mfma_f64_16x16x4_f64.
 // Partial row of a block: [nT tiles x 256 | ND direct sums | Cholesky failures | max |g_frame|].
 // ---------------------------------------------------------------------------------------------
-template <bool HK>
+// (timing-only builds: block 0 leaves wall-clock marks in shared_stats[20..], scripts/time_rig_reduce.py)
+#ifdef CC_RIG_TIMING
+#define ELIM_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) P.shared_stats[20 + (i)] = (double)wall_clock64(); } while (0)
+#else
+#define ELIM_MARK(i) do { } while (0)
+#endif
+
+// NR = direct-sum accumulators per lane: 8 covers ND <= 512 (the usual rigs: <= 18 observed cameras with poses only, 3 with
+// intrinsics), 24 the full range; the small variant exists because the kernel sits at the register limit.
+template <bool HK, int NR>
 __global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* s_Z = reinterpret_cast<double*>(smem_raw);         // [24][ZS] staged Z rows of the four frames
@@ -664,42 +688,20 @@ __global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
   __shared__ LmCtl s_ctl;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const LmCtl* ctl = P.ctl;
-  if (ctl->done || ctl->phase == 0) return;
-  const bool pending = ctl->cand_pending != 0;
-  if (P.comm) {
-    if (tid < 4) s_tot[tid] = P.vec_stats[tid];
-    __syncthreads();
-  } else {
-    rig_reduce_stats(P, pending && ctl->step_valid, s16, s_tot);
-  }
-  if (tid == 0) {
-    LmCtl c = *ctl;
-    const LmOpts o = *P.opts;
-    if (pending) {
-      double step2 = s_tot[2], xn2 = s_tot[3];
-      if (c.step_valid) { step2 += P.shared_stats[0]; xn2 += P.shared_stats[1]; }
-      cc_iteration rec;
-      const int len0 = c.log_len;
-      lm_decide(c, o, &rec, s_tot[0], s_tot[1], step2, xn2);
-      if (blockIdx.x == 0 && c.log_len != len0 && c.log_len <= P.log_cap) P.log[c.log_len - 1] = rec;
-    }
-    s_ctl = c;
-    if (blockIdx.x == 0) *P.ctl_next = c;
-  }
-  if (tid < P.S) s_ss[tid] = P.ss[tid];
-  for (int i = tid; i < 24 * P.ZS; i += 256) s_Z[i] = 0.0;   // padding columns stay zero
-  __syncthreads();
-  if (s_ctl.done) return;
-  const int cur = s_ctl.cur;
-  const double inv_radius = 1.0 / s_ctl.radius;
-  const double mn = P.opts->min_lm_diagonal, mx = P.opts->max_lm_diagonal;
-  const bool first_elim = ctl->phase == 1 && s_ctl.iter == 0 && !pending;   // Jacobi scale of the frame blocks
-  const bool jac = P.opts->jacobi_scaling != 0;
-  const int SW = P.SW, S = P.S, CO = P.CO, ZS = P.ZS;
-  const size_t gs = (size_t)P.gstride;
-  const double* blocks = P.gblocks + (size_t)cur * P.NG * gs;
-
-  // ---- static (frame-independent) description of what this lane owns
+#ifdef CC_RIG_TIMING
+  const long long tm0 = wall_clock64();
+#endif
+  const int ctl_done = ctl->done, ctl_phase = ctl->phase;
+  // what thread 0 needs for the trust-region decision, fetched now instead of behind the statistics barrier
+  const LmCtl c_in = *ctl;
+  const LmOpts o_in = *P.opts;
+  const double sh0 = P.shared_stats[0], sh1 = P.shared_stats[1];
+  // ---- loads that do not depend on the trust-region decision go out first, under the statistics round trip: the
+  // lane's static tables and the group slots of the block's first four frames
+  const int CO = P.CO;
+  const int64_t f_first = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int gj_first = (f_first < P.F && (int)(threadIdx.x & 63) < CO) ? P.fslot[f_first * CO + (threadIdx.x & 63)] : -1;
+  // static (frame-independent) description of what this lane owns
   // frame-block entry of lane e < 27 (offset inside a group's AA tile); lanes holding a diagonal entry also
   // store the frame's Jacobi scale in the first elimination
   int a_off = 0, sp_i = -1;
@@ -714,38 +716,102 @@ __global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
   }
   // shared columns of this lane: k = lane and lane + 64
   int c_kind[2], c_co[2], c_comp[2];
-  double c_ss[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int k = lane + 64 * h;
-    c_kind[h] = -1; c_co[h] = 0; c_comp[h] = 0; c_ss[h] = 0.0;
-    if (k < SW) {
+    c_kind[h] = -1; c_co[h] = 0; c_comp[h] = 0;
+    if (k < P.SW) {
       const int info = P.colinfo[k];
       c_kind[h] = (info >> 4) & 15; c_co[h] = info >> 8; c_comp[h] = info & 15;
-      c_ss[h] = k < S ? s_ss[k] : 1.0;
     }
   }
   // direct-sum entries of this lane: e = lane + 64 r -> (observed camera, offset inside the group block)
-  int d_co[kRigDirectPerLane], d_off[kRigDirectPerLane];
-  double dacc[kRigDirectPerLane];
+  int d_ent[NR];   // (observed camera << 16) | offset, -1: nothing (packed: registers are scarce here)
+  double dacc[NR];
 #pragma unroll
-  for (int r = 0; r < kRigDirectPerLane; ++r) {
+  for (int r = 0; r < NR; ++r) {
     const int e = lane + 64 * r;
-    d_co[r] = -1; d_off[r] = 0; dacc[r] = 0.0;
-    if (e < P.ND) { d_co[r] = e / P.DE; d_off[r] = P.dmap[e - d_co[r] * P.DE]; }
+    dacc[r] = 0.0;
+    const int t = P.dent[e < P.ND ? e : 0];   // (unconditional load + select: a conditional load waits on its own)
+    d_ent[r] = e < P.ND ? t : -1;
   }
+  // tile pairs of this wave's accumulators
+  int t_ij[kRigTilesPerWave];   // ti | tj << 8, wave-uniform (scalar registers)
+#pragma unroll
+  for (int u = 0; u < kRigTilesPerWave; ++u) {
+    const int idx = 4 * u + wave, ic = idx < P.nT ? idx : 0;
+    t_ij[u] = __builtin_amdgcn_readfirstlane((int)P.tile_i[ic] | ((int)P.tile_j[ic] << 8));
+  }
+  if (ctl_done || ctl_phase == 0) return;
+#ifdef CC_RIG_TIMING
+  const long long tm1 = wall_clock64();
+#endif
+  const bool pending = ctl->cand_pending != 0;
+  if (P.comm) {
+    if (tid < 4) s_tot[tid] = P.vec_stats[tid];
+    __syncthreads();
+  } else {
+    rig_reduce_stats(P, pending && ctl->step_valid, s16, s_tot);
+  }
+  if (tid == 0) {
+    LmCtl c = c_in;
+    const LmOpts& o = o_in;
+    if (pending) {
+      double step2 = s_tot[2], xn2 = s_tot[3];
+      if (c.step_valid) { step2 += sh0; xn2 += sh1; }
+      cc_iteration rec;
+      const int len0 = c.log_len;
+      lm_decide(c, o, &rec, s_tot[0], s_tot[1], step2, xn2);
+      if (blockIdx.x == 0 && c.log_len != len0 && c.log_len <= P.log_cap) P.log[c.log_len - 1] = rec;
+    }
+    s_ctl = c;
+    if (blockIdx.x == 0) *P.ctl_next = c;
+  }
+  if (tid < P.S) s_ss[tid] = P.ss[tid];
+  for (int i = tid; i < 24 * P.ZS; i += 256) s_Z[i] = 0.0;   // padding columns stay zero
+  __syncthreads();
+#ifdef CC_RIG_TIMING
+  const long long tm2 = wall_clock64();
+#endif
+  if (s_ctl.done) return;
+  const int cur = s_ctl.cur;
+  const double inv_radius = 1.0 / s_ctl.radius;
+  const double mn = P.opts->min_lm_diagonal, mx = P.opts->max_lm_diagonal;
+  const bool first_elim = ctl->phase == 1 && s_ctl.iter == 0 && !pending;   // Jacobi scale of the frame blocks
+  const bool jac = P.opts->jacobi_scaling != 0;
+  const int SW = P.SW, S = P.S, ZS = P.ZS;
+  const size_t gs = (size_t)P.gstride;
+  const double* blocks = P.gblocks + (size_t)cur * P.NG * gs;
+
+  double c_ss[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) { const int k = lane + 64 * h; c_ss[h] = k < S ? s_ss[k] : (k < SW ? 1.0 : 0.0); }
   d4 acc[kRigTilesPerWave];
 #pragma unroll
   for (int u = 0; u < kRigTilesPerWave; ++u) acc[u] = d4{0.0, 0.0, 0.0, 0.0};
   double gmax = 0.0, nfail = 0.0;
   double* As = s_A + wave * 32;
+#ifdef CC_RIG_TIMING
+  if (blockIdx.x == 0 && tid == 0) { P.shared_stats[20] = (double)tm0; P.shared_stats[21] = (double)tm1; P.shared_stats[22] = (double)tm2; }
+#endif
+  ELIM_MARK(3);
 
+  int gj_next = gj_first;
+  const int nr = (P.ND + 63) >> 6;   // direct-sum registers in use (uniform)
   for (int64_t fb = (int64_t)blockIdx.x * 4; fb < P.F; fb += (int64_t)gridDim.x * 4) {
     const int64_t f = fb + wave;
-    const bool live = f < P.F && P.fgoff[f + 1] > P.fgoff[f];   // wave-uniform
+    // group of (frame, observed camera j) on lane j: fetched one pass ahead (-1 beyond the last frame)
+    const int gj = gj_next;
+    {
+      const int64_t fn = f + (int64_t)gridDim.x * 4;
+      gj_next = (fn < P.F && lane < CO) ? P.fslot[fn * CO + lane] : -1;
+    }
+    const bool live = __any(gj >= 0);   // the frame has observations (wave-uniform)
     if (live) {
-      // group of (frame, observed camera j) on lane j
-      const int gj = lane < CO ? P.fslot[f * CO + lane] : -1;
+      // the frame's Jacobi scale (overwritten below in the first elimination, which computes it)
+      double sf[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) sf[i] = P.sp[f * 8 + i];
       // ---- loads: frame block entries (lanes < 27, summed over the groups), column data, direct entries
       double a_e = 0.0;
       for (int j0 = 0; j0 < CO; j0 += 8) {
@@ -784,15 +850,24 @@ __global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
             }
         }
       }
+      // direct entries, eight registers per round trip: unconditional loads (group 0 stands in where a lane has
+      // nothing to fetch) followed by selects -- a load inside a lane-dependent `if` gets a wait of its own
+      constexpr int DB = NR <= 8 ? 8 : 4;   // loads per round trip (the large variant has no registers to spare)
 #pragma unroll
-      for (int r = 0; r < kRigDirectPerLane; ++r) {
-        const int g = __shfl(gj, d_co[r] < 0 ? 0 : d_co[r], 64);
-        if (d_co[r] >= 0 && g >= 0) dacc[r] += blocks[(size_t)g * gs + d_off[r]];
-      }
-      double sf[6];
-      if (!first_elim) {
+      for (int r0 = 0; r0 < NR; r0 += DB) {
+        if (r0 < nr) {   // (uniform)
+          double dx[DB];
+          bool dk[DB];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) sf[i] = P.sp[f * 8 + i];
+          for (int u = 0; u < DB; ++u) {
+            const int t = d_ent[r0 + u];
+            const int g = __shfl(gj, t < 0 ? 0 : (t >> 16), 64);
+            dk[u] = t >= 0 && g >= 0;
+            dx[u] = blocks[(size_t)(dk[u] ? g : 0) * gs + (t & 0xffff)];
+          }
+#pragma unroll
+          for (int u = 0; u < DB; ++u) dacc[r0 + u] += dk[u] ? dx[u] : 0.0;
+        }
       }
       // ---- broadcast the frame block
       if (lane < 27) As[lane] = a_e;
@@ -801,6 +876,7 @@ __global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
 #pragma unroll
       for (int i = 0; i < 27; ++i) A[i] = As[i];
       wave_lds_fence();
+      if (fb == (int64_t)blockIdx.x * 4) ELIM_MARK(4);
       if (first_elim) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) sf[i] = jac ? 1.0 / (1.0 + sqrt(A[tri(i, i)])) : 1.0;
@@ -832,6 +908,7 @@ __global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
         }
       }
       if (!ok) nfail += 1.0;
+      if (fb == (int64_t)blockIdx.x * 4) ELIM_MARK(5);
 #pragma unroll
       for (int i = 0; i < 6; ++i) gmax = fmax(gmax, fabs(A[21 + i]));
       // ---- columns: z = L^-1 w, y = L^-T z
@@ -867,12 +944,13 @@ __global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
         for (int i = 0; i < 6; ++i) s_Z[(wave * 6 + i) * ZS + k] = 0.0;
     }
     __syncthreads();
+    if (fb == (int64_t)blockIdx.x * 4) ELIM_MARK(6);
     // ---- Schur products of the four staged frames on the matrix cores
 #pragma unroll
     for (int u = 0; u < kRigTilesPerWave; ++u) {
       const int idx = 4 * u + wave;
       if (idx < P.nT) {
-        const int ti = P.tile_i[idx], tj = P.tile_j[idx];
+        const int ti = t_ij[u] & 255, tj = t_ij[u] >> 8;
         const int col = lane & 15, sub = lane >> 4;
 #pragma unroll
         for (int ksx = 0; ksx < 6; ++ksx) {
@@ -883,7 +961,9 @@ __global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
       }
     }
     __syncthreads();
+    if (fb == (int64_t)blockIdx.x * 4) ELIM_MARK(7);
   }
+  ELIM_MARK(8);
 
   // ---- one partial row per block
   double* prow = P.partial + (size_t)blockIdx.x * P.PC;
@@ -898,12 +978,12 @@ __global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
   }
   // direct sums: four waves each hold partial sums of the same entries
 #pragma unroll
-  for (int r0 = 0; r0 < kRigDirectPerLane; r0 += 16) {
+  for (int r0 = 0; r0 < NR; r0 += 16) {
     if (r0 * 64 >= P.ND) continue;   // (uniform) nothing left in this chunk
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      if (r0 + r < kRigDirectPerLane) s_red[wave * 1024 + r * 64 + lane] = dacc[r0 + r];
+      if (r0 + r < NR) s_red[wave * 1024 + r * 64 + lane] = dacc[r0 + r];
     __syncthreads();
     for (int i = tid; i < 1024; i += 256) {
       const int e = r0 * 64 + i;
@@ -917,6 +997,7 @@ __global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
     prow[P.pc_fail] = (s_fg[4] + s_fg[5]) + (s_fg[6] + s_fg[7]);
     prow[P.pc_gmax] = fmax(fmax(s_fg[0], s_fg[1]), fmax(s_fg[2], s_fg[3]));
   }
+  ELIM_MARK(9);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1753,6 +1834,11 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
   if (int rc = dev_upload(h, &d.obs_cam, obs_cam)) return rc;
   if (int rc = dev_upload(h, &d.colinfo, colinfo)) return rc;
   if (int rc = dev_upload(h, &d.dmap, dmap)) return rc;
+  {
+    std::vector<int32_t> dent((size_t)CO * DE);
+    for (int c = 0; c < CO; ++c) for (int e = 0; e < DE; ++e) dent[(size_t)c * DE + e] = (c << 16) | (int)(uint16_t)dmap[(size_t)e];
+    if (int rc = dev_upload(h, &d.dent, dent)) return rc;
+  }
   if (int rc = dev_upload(h, &d.tile_i, ti)) return rc;
   if (int rc = dev_upload(h, &d.tile_j, tj)) return rc;
   if (int rc = dev_upload(h, &d.fslot, fslot)) return rc;
@@ -1770,8 +1856,10 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
   if (int rc = dev_zeroed(h, &d.vec_stats, (size_t)4 + kRigMaxS + 1)) return rc;
   h->elim_lds = ((size_t)24 * d.ZS + 4 * 32 + 4 * 1024) * sizeof(double);
   h->solve_lds = ((size_t)S * ((S + 1) | 1) + 5 * 128) * sizeof(double);
-  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
-  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
+  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
+  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
+  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<false, kRigDirectPerLane>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
+  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<true, kRigDirectPerLane>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_reduce<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_reduce<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
@@ -1809,8 +1897,11 @@ static int rig_enqueue_round(cc_rig* h, bool initial, bool profile) {
   }
   if (initial) { RigProbe p(h, CC_K_DECIDE, profile); hipLaunchKernelGGL(k_rig_init, dim3(1), dim3(256), 0, h->stream, d); }
   { RigProbe p(h, CC_K_ELIM, profile);
-    if (d.kmode) hipLaunchKernelGGL(k_rig_elim<true>, dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d);
-    else hipLaunchKernelGGL(k_rig_elim<false>, dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d); }
+    const bool small = d.ND <= 8 * 64;
+    if (d.kmode && small) hipLaunchKernelGGL((k_rig_elim<true, 8>), dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d);
+    else if (d.kmode) hipLaunchKernelGGL((k_rig_elim<true, kRigDirectPerLane>), dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d);
+    else if (small) hipLaunchKernelGGL((k_rig_elim<false, 8>), dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d);
+    else hipLaunchKernelGGL((k_rig_elim<false, kRigDirectPerLane>), dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d); }
   // Every block of this launch must be resident at once (the blocks wait for each other's flag, k_rig_reduce): 64
   // blocks is a quarter of the chip, which leaves room for the kernels of other processes on the same GPU (the
   // multi-process tests put up to four ranks on one GPU, and a rank's solver waits for the OTHER ranks' launches).
