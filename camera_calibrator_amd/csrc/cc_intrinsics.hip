@@ -171,25 +171,51 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
   // restores buffer 0 from them on the way, so a restart costs no kernel of its own.
   const bool in_solve = (flags & 1) != 0, restart = (flags & 2) != 0;
   const LmCtl* ctl = P.ctl;
-  const int done = restart ? 0 : ctl->done, phase = restart ? 0 : ctl->phase, step_valid = restart ? 0 : ctl->step_valid,
-            cur = restart ? 0 : ctl->cur;
+  // (read unconditionally, then select: loads behind `restart ? 0 :` would each wait on their own)
+  const int c_done = ctl->done, c_phase = ctl->phase, c_valid = ctl->step_valid, c_cur = ctl->cur;
+  const int done = restart ? 0 : c_done, phase = restart ? 0 : c_phase, step_valid = restart ? 0 : c_valid,
+            cur = restart ? 0 : c_cur;
   int64_t s0 = P.off[f], s1 = P.off[f + 1];
   if (T > 1) {   // this workgroup's tile of the frame
     const int64_t len = (s1 - s0 + T - 1) / T;
     s0 = s0 + tile * len < s1 ? s0 + tile * len : s1;
     s1 = s0 + len < s1 ? s0 + len : s1;
   }
-  if (tid < 116) {
-    double v;
-    if (tid < 60) v = P.Y[f * kYStride + tid];
-    else if (tid < 67) v = restart ? P.init_pose[(size_t)f * 8 + (tid - 60)] : P.pose[(size_t)f * 8 + (tid - 60)];
-    else if (tid < 74) v = P.pose[((size_t)P.F + f) * 8 + (tid - 67)];
-    else if (tid < 83) v = restart ? P.init_intr[tid - 74] : P.intr[tid - 74];
-    else if (tid < 92) v = P.intr[16 + (tid - 83)];
-    else if (tid < 101) v = P.ds[tid - 92];
-    else if (tid < 110) v = P.ss[tid - 101];
-    else v = P.sp[f * 8 + (tid - 110)];
-    sm[tid] = v;
+  // first pass of observations: issued FIRST (needs only the frame's offsets), consumed after the prologue. It used to
+  // sit behind the gather below, whose accumulation loop over the tiles made the compiler wait for the old Gram block
+  // before issuing anything else: a second dependent round trip in front of every workgroup's main loop.
+  const float2* uv2 = reinterpret_cast<const float2*>(P.uv);
+  // passes of THIS wave: a wave whose 64 slots of a pass all lie beyond the frame skips that pass
+  // (wave-uniform; the main loop holds no workgroup barrier)
+  const int64_t wrem = s1 - s0 - wave * 64;
+  const int npass = wrem > 0 ? (int)((wrem + kSweepThreads - 1) / kSweepThreads) : 0;
+  // UNCONDITIONAL loads (idle slots re-read a valid observation; the arena holds one slot even when N = 0): inside an
+  // `if` the loaded registers are merged with the defaults at the end of the region, and that merge waits for the
+  // load -- the "prefetch" then stalls the wave for a full memory round trip where it is issued.
+  const int64_t safe0 = s0 < P.N ? s0 : 0;
+  float2 nm;
+  float nX0, nX1, nX2;
+  {
+    const int64_t idx = s0 + tid;
+    const int64_t ic = idx < s1 ? idx : safe0;
+    nm = uv2[ic];
+    nX0 = P.xyz[ic * 3]; nX1 = P.xyz[ic * 3 + 1]; nX2 = P.xyz[ic * 3 + 2];
+  }
+  // gather: one load per thread from a selected address; it is stored to LDS only after the loads of the old Gram
+  // block below have been issued (the store needs the data: placed here it made them a round trip of their own)
+  double gv;
+  {
+    const double* src;
+    if (tid < 60) src = P.Y + f * kYStride + tid;
+    else if (tid < 67) src = (restart ? P.init_pose : P.pose) + (size_t)f * 8 + (tid - 60);
+    else if (tid < 74) src = P.pose + ((size_t)P.F + f) * 8 + (tid - 67);
+    else if (tid < 83) src = (restart ? P.init_intr : P.intr) + (tid - 74);
+    else if (tid < 92) src = P.intr + 16 + (tid - 83);
+    else if (tid < 101) src = P.ds + (tid - 92);
+    else if (tid < 110) src = P.ss + (tid - 101);
+    else if (tid < 116) src = P.sp + f * 8 + (tid - 110);
+    else src = P.ss;   // (threads without a slot: any readable word)
+    gv = *src;
   }
   // previous Gram block of the frame (model-cost term): sum of its tiles. When the grid is one residency round
   // (<= 1024 workgroups) BOTH ping-pong buffers are fetched in the gather round trip, because waiting for the control
@@ -198,10 +224,16 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
   // (flags bit 2, set by the host): only the current buffer is fetched, after the control block.
   double g_old0 = 0.0, g_old1 = 0.0;
   if (tile == 0) {
-    if (flags & 4) {
+    if (T == 1) {   // (straight line: no loop-carried sum, so no wait here)
+      if (flags & 4) {
+        g_old0 = P.blocks[((cur ? (size_t)P.F : 0) + f) * 256 + tid];   // (selected below: a copy here would wait)
+      } else {
+        g_old0 = P.blocks[(size_t)f * 256 + tid];
+        g_old1 = P.blocks[((size_t)P.F + f) * 256 + tid];
+      }
+    } else if (flags & 4) {
       const size_t base = cur ? (size_t)P.F : 0;
       for (int k = 0; k < T; ++k) g_old0 += P.blocks[((base + f) * T + k) * 256 + tid];
-      g_old1 = g_old0;
     } else {
       for (int k = 0; k < T; ++k) {
         g_old0 += P.blocks[((size_t)f * T + k) * 256 + tid];
@@ -209,6 +241,7 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
       }
     }
   }
+  if (tid < 116) sm[tid] = gv;
   if (done) return;
   if (phase != 0 && !step_valid) return;
   // mailbox exchange: this round's statistics will be exchanged by decide_elim<3> (which evaluates the
@@ -221,21 +254,7 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
     if (blockIdx.x == 0 && tid == 0) *P.arrive = 0u;
   }
   const int dst = phase == 0 ? cur : (cur ^ 1);
-  const double g_old = cur ? g_old1 : g_old0;
-  // first pass of observations: issued now, consumed after the prologue
-  const float2* uv2 = reinterpret_cast<const float2*>(P.uv);
-  // passes of THIS wave: a wave whose 64 slots of a pass all lie beyond the frame skips that pass
-  // (wave-uniform; the main loop holds no workgroup barrier)
-  const int64_t wrem = s1 - s0 - wave * 64;
-  const int npass = wrem > 0 ? (int)((wrem + kSweepThreads - 1) / kSweepThreads) : 0;
-  float2 nm = make_float2(0.f, 0.f);
-  float nX0 = 0.f, nX1 = 0.f, nX2 = 1.f;
-  if (npass > 0) {
-    const int64_t idx = s0 + tid;
-    const int64_t ic = idx < s1 ? idx : s0;
-    nm = uv2[ic];
-    nX0 = P.xyz[ic * 3]; nX1 = P.xyz[ic * 3 + 1]; nX2 = P.xyz[ic * 3 + 2];
-  }
+  const double g_old = (flags & 4) ? g_old0 : (cur ? g_old1 : g_old0);
   __syncthreads();
   const int pose_o = cur ? 67 : 60, intr_o = cur ? 83 : 74;
   if (tid < 6) {
@@ -314,9 +333,9 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
     const bool valid = idx < s1;  // only the last pass of a frame has idle lanes
     const float2 m = nm;
     const float X0 = nX0, X1 = nX1, X2 = nX2;
-    if (p + 1 < npass) {
+    {   // next pass, unconditionally (the last pass fetches a slot nobody uses: cheaper than the wait a branch costs)
       const int64_t nidx = idx + kSweepThreads;
-      const int64_t ic = nidx < s1 ? nidx : s0;
+      const int64_t ic = nidx < s1 ? nidx : safe0;
       nm = uv2[ic];
       nX0 = P.xyz[ic * 3]; nX1 = P.xyz[ic * 3 + 1]; nX2 = P.xyz[ic * 3 + 2];
     }
@@ -378,7 +397,8 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
 // All threads of the 256-thread block must call; result valid for every thread after return.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void reduce_frame_stats(const IntrDev& P, bool want_stats, bool want_hd,
-                                                   double* s_w /*[4][16]*/, double* out /*[16] shared*/) {
+                                                   double* s_w /*[4][16]*/, double* out /*[16] shared*/,
+                                                   unsigned long long* s_in = nullptr, unsigned long long word = 0ull) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // stats: thread t -> column t & 3, row group t >> 2 (64 groups)
   double a = 0.0;
@@ -424,6 +444,7 @@ __device__ __forceinline__ void reduce_frame_stats(const IntrDev& P, bool want_s
   for (int o = 8; o < 64; o <<= 1) { h0 += __shfl_xor(h0, o, 64); h1 += __shfl_xor(h1, o, 64); }
   if (lane < 4) s_w[wave * 16 + lane] = a;
   if (lane < 8) { s_w[64 + wave * 16 + 2 * lane] = h0; s_w[64 + wave * 16 + 2 * lane + 1] = h1; }
+  if (s_in && tid < 48) s_in[tid] = word;   // the caller's gathered word rides on this barrier (k_intr_decide_elim)
   __syncthreads();
   if (tid < 4) out[tid] = (s_w[tid] + s_w[16 + tid]) + (s_w[32 + tid] + s_w[48 + tid]);
   else if (tid >= 4 && tid < 13) {
@@ -451,8 +472,7 @@ __global__ __launch_bounds__(256) void k_intr_stats_reduce(IntrDev P) {
 // iteration's log record (NULL when there is none). Writes the scaled shared step P.ds.
 // V layout: [0..79] column sums (col 73 unused), [80 + rank] each rank's max |pose gradient|.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void intr_solve_step(const IntrDev& P, const double* V, LmCtl& c, cc_iteration* e) {
-  const LmOpts o = *P.opts;
+__device__ __forceinline__ void intr_solve_step(const IntrDev& P, const double* V, LmCtl& c, cc_iteration* e, const LmOpts& o) {
   // gradient of the accepted point: max-norm over the tangent coordinates
   double gmax = 0.0;
   for (int r = 0; r < P.nranks && r < 32; ++r) gmax = fmax(gmax, V[kPartialCols + r]);
@@ -569,24 +589,70 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
   __shared__ unsigned char pj[48], pk[48];
   constexpr bool kFused = MODE != 2;
   const int tid = threadIdx.x, g = tid >> 4, l = tid & 15;
+  // Timing-only builds (-DCC_INTR_TIMING, scripts/time_intr_decide.py): thread 0 keeps wall-clock marks (100 MHz) of the
+  // stages in registers; the block that turns out to be the last to arrive -- the critical path -- leaves them in
+  // vec_solve[32..] (unused on a single GPU). The product build compiles this away.
+#ifdef CC_INTR_TIMING
+  long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define DE_MARK(i) do { tm[i] = wall_clock64(); } while (0)
+#define DE_MARK_LATE(i) do { if (tid == 0 && tm[3] != 0) P.vec_solve[32 + (i)] = (double)wall_clock64(); } while (0)   // (full launches only)
+#else
+#define DE_MARK(i) do { } while (0)
+#define DE_MARK_LATE(i) do { } while (0)
+#endif
+  DE_MARK(0);
   const LmCtl* ctl = P.ctl;
   // bit 2 of `publish`: RESTART, first elimination of a solve from the initial state: the control block in memory
   // is stale and counts as zero (cf. the restart sweep)
   const bool restart = (publish & 4) != 0;
   publish &= 3;
-  if (!restart && ctl->done) {
-    if (publish && blockIdx.x == 0 && tid == 0) publish_to_host(P, *ctl);
+  // Everything the decision needs comes in ONE vector round trip: thread t fetches one 8-byte word of
+  // [control block (18) | options (12) | intrinsics, both buffers (9 + 9)] into LDS, and -- single GPU -- the
+  // statistics rows are requested in the same round trip, before anybody knows whether this launch needs them (that
+  // is written in the control block still on its way). Reading the fields one by one (`restart ? 0 : ctl->phase`,
+  // `*P.opts` in thread 0's branch, ...) compiled to seven dependent scalar-load round trips, ~2.5 us of a 14 us kernel.
+  // The kernel's arguments are one large by-value struct; the compiler fetches its fields from the kernarg segment
+  // where they are first used, each fetch a scalar load with a full wait behind it (eight dependent rounds before the
+  // first global load left). Naming the fields here makes them live at this point: one batch of scalar loads, one wait.
+  asm volatile("" ::"s"(P.F), "s"(P.T), "s"(P.stats), "s"(P.hd0), "s"(P.ctl), "s"(P.opts), "s"(P.intr), "s"(P.blocks),
+               "s"(P.sp), "s"(P.Y), "s"(P.partial), "s"(P.ss), "s"(P.arrive));
+  __shared__ unsigned long long s_in[64];
+  unsigned long long word;
+  {
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(ctl);
+    if (tid < 18) src = reinterpret_cast<const unsigned long long*>(ctl) + tid;
+    else if (tid < 30) src = reinterpret_cast<const unsigned long long*>(P.opts) + (tid - 18);
+    else if (tid < 39) src = reinterpret_cast<const unsigned long long*>(P.intr) + (tid - 30);
+    else if (tid < 48) src = reinterpret_cast<const unsigned long long*>(P.intr) + 16 + (tid - 39);
+    word = *src;
+  }
+  static_assert(sizeof(LmCtl) == 18 * 8 && sizeof(LmOpts) == 12 * 8, "layout of the gathered decision inputs");
+  if (MODE == 0) {
+    reduce_frame_stats(P, true, restart, s_w, s_tot, s_in, word);   // (restart: the initial evaluation, known from the launch)
+  } else {
+    if (tid < 48) s_in[tid] = word;
+    __syncthreads();
+  }
+  const LmCtl& c_in = *reinterpret_cast<const LmCtl*>(s_in);
+  const LmOpts& o_in = *reinterpret_cast<const LmOpts*>(s_in + 18);
+  const double* k_in0 = reinterpret_cast<const double*>(s_in + 30);
+  const double* k_in1 = reinterpret_cast<const double*>(s_in + 39);
+  if (!restart && c_in.done) {
+    if (publish && blockIdx.x == 0 && tid == 0) publish_to_host(P, c_in);
     return;
   }
-  const int phase = restart ? 0 : ctl->phase;
-  const bool pending = !restart && ctl->cand_pending != 0;
-  const bool need = phase == 0 || (pending && ctl->step_valid);
+  const int phase = restart ? 0 : c_in.phase;
+  const bool pending = !restart && c_in.cand_pending != 0;
+  const bool need = phase == 0 || (pending && c_in.step_valid);
 #if CC_ABLATE_D == 1
   if (ctl->gmax == 1e30) return;  // marker set by cc_intrinsics_profile_kernel
 #endif
+  DE_MARK(1);
   bool exchange_ok = true;
   if (MODE == 0) {
-    reduce_frame_stats(P, need, phase == 0, s_w, s_tot);
+    // (an initial evaluation that was not announced by the launch flag -- the first solve after set_state -- needs
+    // the diagonal sums too: reduce again, the rare case)
+    if (phase == 0 && !restart) reduce_frame_stats(P, true, true, s_w, s_tot);
   } else if (MODE == 3) {
     // mailbox exchange (kind 1): block 0 reduces this rank's statistics and posts them into every
     // rank's mailbox (its own included); all blocks then poll the local words and add the slots
@@ -613,27 +679,39 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
   }
   if (tid == 0) {
     LmCtl c{};
-    if (!restart) c = *ctl;
-    const LmOpts o = *P.opts;
+    if (!restart) c = c_in;
+    const LmOpts o = o_in;
     const int len0 = c.log_len;
+    // (single GPU: the statistics were reduced before `need` was known; a launch that does not need them sees zeros,
+    // as it did when the reduction was skipped)
+    double tot[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tot[i] = (MODE != 0 || need) ? s_tot[i] : 0.0;
+    const double* kc0 = c.cur ? k_in1 : k_in0;   // accepted intrinsics
+    const double* kc1 = c.cur ? k_in0 : k_in1;   // candidate
     if (phase == 0) {
-      const double* k = P.intr + c.cur * 16;
-      double xn2 = s_tot[ST_XNORM2];
+      double xn2 = tot[ST_XNORM2];
+#pragma unroll
       for (int i = 0; i < 9; ++i) {
-        xn2 += k[i] * k[i];
+        const double ki = kc0[i];
+        xn2 += ki * ki;
         const double sc = o.jacobi_scaling ? 1.0 / (1.0 + sqrt(s_tot[4 + i])) : 1.0;
         s_ss[i] = sc;
         if (blockIdx.x == 0) P.ss[i] = sc;
       }
-      lm_init(c, o, s_tot[ST_COST], sqrt(xn2));
+      lm_init(c, o, tot[ST_COST], sqrt(xn2));
     } else if (pending) {
-      double step2 = s_tot[ST_STEP2], xn2 = s_tot[ST_XNORM2];
+      double step2 = tot[ST_STEP2], xn2 = tot[ST_XNORM2];
       if (c.step_valid) {
-        const double* kc = P.intr + (c.cur ^ 1) * 16;
-        const double* k0 = P.intr + c.cur * 16;
-        for (int i = 0; i < 9; ++i) { const double d = kc[i] - k0[i]; step2 += d * d; xn2 += kc[i] * kc[i]; }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          const double kc = kc1[i], k0 = kc0[i];
+          const double d = kc - k0;
+          step2 += d * d;
+          xn2 += kc * kc;
+        }
       }
-      lm_decide(c, o, &s_log, s_tot[ST_COST], s_tot[ST_QMODEL], step2, xn2);
+      lm_decide(c, o, &s_log, tot[ST_COST], tot[ST_QMODEL], step2, xn2);
     }
     if (!exchange_ok) { c.done = 1; c.term = CC_FAILURE_EXCHANGE; }
     s_ctl = c;
@@ -654,6 +732,7 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
   }
   __syncthreads();
   const bool stop = s_ctl.done != 0;   // the same answer in every block
+  DE_MARK(2);
   if (stop && !kFused) return;
 #if CC_ABLATE_D == 3
   if (ctl->gmax == 1e30) return;  // marker set by cc_intrinsics_profile_kernel
@@ -661,9 +740,9 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
   if (!stop) {
   const int cur = s_ctl.cur;
   const int T = P.T;
-  const bool jac = P.opts->jacobi_scaling != 0;
+  const bool jac = o_in.jacobi_scaling != 0;
   const double inv_radius = 1.0 / s_ctl.radius;
-  const double mn = P.opts->min_lm_diagonal, mx = P.opts->max_lm_diagonal;
+  const double mn = o_in.min_lm_diagonal, mx = o_in.max_lm_diagonal;
 
   // Output slots l*5 + r of this lane: what they read is the same for every frame, so the source
   // index, the scales and the Z columns live in registers and the loads go out with the Cholesky's.
@@ -770,6 +849,7 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
         }
       }
       if (!ok) fail = 1.0;
+      if (base == (int64_t)blockIdx.x * 16) DE_MARK(3);
 #if CC_ABLATE_D == 4
       if (L[20] != 123.0 && ctl->gmax == 1e30) return;
 #endif
@@ -799,6 +879,7 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
       }
     }
     __syncthreads();
+    if (base == (int64_t)blockIdx.x * 16) DE_MARK(4);
 #if CC_ABLATE_D == 5
     if (ctl->gmax == 1e30) return;
 #endif
@@ -815,6 +896,7 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
     }
     __syncthreads();
   }
+  DE_MARK(5);
 #if CC_ABLATE_D == 6
   if (ctl->gmax == 1e30) { if (acc[0] + acc[1] + acc[2] + acc[3] + acc[4] + gacc + facc == 123.0) P.partial[tid] = 0; return; }
 #endif
@@ -848,6 +930,10 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
   __syncthreads();
   if (!s_last) return;
   if (tid == 0) __hip_atomic_store(P.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+#ifdef CC_INTR_TIMING
+  if (tid == 0 && tm[3] != 0) { for (int i = 0; i < 6; ++i) P.vec_solve[32 + i] = (double)tm[i]; }
+#endif
+  DE_MARK_LATE(6);
 #if CC_ABLATE_D == 7
   if (ctl->gmax == 1e30) return;
 #endif
@@ -904,16 +990,18 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
 #if CC_ABLATE_D == 8
   if (ctl->gmax == 1e30) return;
 #endif
+  DE_MARK_LATE(7);
   if (tid != 0) return;
   LmCtl c = s_ctl;
   cc_iteration* e = s_logged ? &s_log : nullptr;
   if (!exchange_ok) { c.done = 1; c.term = CC_FAILURE_EXCHANGE; }
-  else if (!stop) intr_solve_step(P, sv, c, e);
+  else if (!stop) intr_solve_step(P, sv, c, e, o_in);
   if (publish == 2) return;   // timing replay (cc_intrinsics_profile_kernel): the state stays as it is
   if (e && c.log_len <= P.log_cap) P.log[c.log_len - 1] = *e;
   *P.ctl = c;
   *P.ctl_next = c;
   if (publish) publish_to_host(P, c);
+  DE_MARK_LATE(8);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -974,7 +1062,8 @@ __global__ __launch_bounds__(kSolveThreads) void k_intr_solve(IntrDev P, int nbl
     cc_iteration* e = (c.log_len > 0 && c.log_len <= P.log_cap) ? &P.log[c.log_len - 1] : nullptr;
     cc_iteration rec;
     if (e) rec = *e;
-    intr_solve_step(P, sv, c, e ? &rec : nullptr);
+    const LmOpts o = *P.opts;
+    intr_solve_step(P, sv, c, e ? &rec : nullptr, o);
     if (e && rec.accepted) e->gradient_max_norm = rec.gradient_max_norm;
   }
   *P.ctl = c;
@@ -1648,6 +1737,17 @@ int cc_intrinsics_optimize_multi(const cc_options* opt, int32_t n_devices, const
   cleanup();
   if (rc) last_error() = err;
   return rc;
+}
+
+// Scripts only (not in the public header): copy of a device vector. name: "vec_solve" (timing marks of timing-only builds).
+int cc_intrinsics_debug_fetch(cc_intrinsics* h, const char* name, double* out, int64_t n) {
+  using namespace cc;
+  if (!h || !name || !out || n < 0 || n > kVecSolve || std::string(name) != "vec_solve")
+    return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_debug_fetch: bad arguments");
+  CC_HIP(hipSetDevice(h->device));
+  CC_HIP(hipStreamSynchronize(h->stream));
+  CC_HIP(hipMemcpy(out, h->d.vec_solve, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  return CC_OK;
 }
 
 int cc_intrinsics_profile_sweep(cc_intrinsics* h, int32_t n, double* avg_ms) {

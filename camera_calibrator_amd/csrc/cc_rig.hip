@@ -271,9 +271,12 @@ __global__ __launch_bounds__(NW * 64, HK ? 2 : CC_RIG_SWEEP_WAVES) void k_rig_sw
   const int64_t wrem = s1 - s0 - (otid >> 6) * 64;
   const int npass = wrem > 0 ? (int)((wrem + NT - 1) / NT) : 0;
   const float2* uv2 = reinterpret_cast<const float2*>(P.uv);
-  float2 nm = make_float2(0.f, 0.f);
-  float nX0 = 0.f, nX1 = 0.f, nX2 = 1.f;
-  if (npass > 0) {
+  // UNCONDITIONAL loads (idle slots re-read the group's first observation; groups are never empty): inside an `if`
+  // the loaded registers are merged with the defaults at the end of the region and that merge waits for the load,
+  // i.e. the prefetch would stall the wave for the full round trips where it is issued.
+  float2 nm;
+  float nX0, nX1, nX2;
+  {
     const int64_t idx = s0 + otid;
     const int64_t ic = idx < s1 ? idx : s0;
     nm = uv2[ic];
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(NW * 64, HK ? 2 : CC_RIG_SWEEP_WAVES) void k_rig_sw
     const bool valid = idx < s1;
     const float2 m = nm;
     const float X0 = nX0, X1 = nX1, X2 = nX2;
-    if (p + 1 < npass) {
+    {   // next pass, unconditionally (see above)
       const int64_t idn = idx + NT;
       const int64_t ic = idn < s1 ? idn : s0;
       nm = uv2[ic];
