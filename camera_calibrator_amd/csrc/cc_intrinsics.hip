@@ -156,6 +156,13 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
   double* s_blk = s_stage;                                      // [2048] cross-wave reduce + block copy (after the loop)
   double* sm = s_stage + 4 * kStageDoublesPerWave;              // [256] prologue scratch
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (timing-only builds, scripts/time_intr_decide.py: the middle workgroup leaves wall-clock marks in vec_solve[48..])
+#ifdef CC_INTR_TIMING
+#define SW_MARK(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) P.vec_solve[48 + (i)] = (double)wall_clock64(); } while (0)
+#else
+#define SW_MARK(i) do { } while (0)
+#endif
+  SW_MARK(0);
   const int T = P.T;
   const int64_t f = (int64_t)blockIdx.x / T;
   const int tile = (int)(blockIdx.x - f * T);
@@ -256,6 +263,7 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
   const int dst = phase == 0 ? cur : (cur ^ 1);
   const double g_old = (flags & 4) ? g_old0 : (cur ? g_old1 : g_old0);
   __syncthreads();
+  SW_MARK(1);
   const int pose_o = cur ? 67 : 60, intr_o = cur ? 83 : 74;
   if (tid < 6) {
     const double* Yr = sm + tid * 10;
@@ -272,6 +280,7 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
     if (blockIdx.x == 0 && phase != 0) P.intr[dst * 16 + j] = kc;
   }
   __syncthreads();
+  SW_MARK(2);
   if (tid == 0) {
     double q[4], t[3], dp[6];
 #pragma unroll
@@ -306,6 +315,7 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
     sm[159] = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + t[0] * t[0] + t[1] * t[1] + t[2] * t[2];
   }
   __syncthreads();
+  SW_MARK(3);
 
   // model-cost term of this frame: q_f = d^T g_f + 1/2 d^T H_f d over the frame's 15x15 block at
   // the accepted point (Ceres: model_cost_change = -(J d)^T (r + J d / 2))
@@ -363,11 +373,13 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
     wave_lds_fence();
     gram_rows(stage, lane, acc0, acc1);
     wave_lds_fence();
+    if (p == 0) SW_MARK(4);
   }
 
   // ---- cross-wave reduction of the 16x16 block + model-cost term ---------------------------
   // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
   __syncthreads();  // s_blk aliases the staging buffers
+  SW_MARK(5);
 #pragma unroll
   for (int r = 0; r < 4; ++r) s_blk[wave * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc0[r] + acc1[r];
   const double qw = wave_sum(qterm);
@@ -378,6 +390,7 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
   double* G = s_blk + 1024;  // full block for the few threads that derive per-frame scalars
   G[tid] = g;
   __syncthreads();
+  SW_MARK(6);
   if (tid == 0) {   // per-tile statistics row; the per-frame quantities ride on tile 0
     double* st = P.stats + (size_t)blockIdx.x * kStatsCols;
     st[ST_COST] = 0.5 * G[255];
@@ -388,6 +401,7 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
   // initial evaluation: diagonal of the shared block for its Jacobi scale (the pose blocks' scale needs the sum
   // over the tiles: the first elimination derives it, k_intr_decide_elim)
   if (phase == 0 && tid >= 16 && tid < 25) P.hd0[(size_t)blockIdx.x * 16 + (tid - 16)] = G[(tid - 16) * 17];
+  SW_MARK(7);
 }
 
 // ---------------------------------------------------------------------------------------------
