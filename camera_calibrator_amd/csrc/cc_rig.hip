@@ -250,6 +250,13 @@ __global__ __launch_bounds__(NW * 64, HK ? 2 : CC_RIG_SWEEP_WAVES) void k_rig_sw
   double* sm = s_stage + NW * kTiles * kStageDoublesPerWave;  // [256]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t g = blockIdx.x;
+  // (timing-only builds: the middle workgroup leaves wall-clock marks in shared_stats[32..], scripts/time_rig_reduce.py)
+#ifdef CC_RIG_TIMING
+#define RSW_MARK(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) P.shared_stats[32 + (i)] = (double)wall_clock64(); } while (0)
+#else
+#define RSW_MARK(i) do { } while (0)
+#endif
+  RSW_MARK(0);
   // the group's indices do not depend on the control block: all five loads leave in one round trip
   const int f = P.gframe[g], c = P.gcam[g];
   const int64_t s0 = P.goff[g], s1 = P.goff[g + 1];
@@ -298,6 +305,7 @@ __global__ __launch_bounds__(NW * 64, HK ? 2 : CC_RIG_SWEEP_WAVES) void k_rig_sw
     if (HK) { g_ab = old[256 + tid]; g_bb = old[512 + tid]; }
   }
   __syncthreads();
+  RSW_MARK(1);
   // model-cost term of the group: d = [dc(6) df(6) (dk(9))], q = d^T g + 1/2 d^T H d over its block
   double qterm = 0.0;
   if (phase != 0) {
@@ -336,6 +344,7 @@ __global__ __launch_bounds__(NW * 64, HK ? 2 : CC_RIG_SWEEP_WAVES) void k_rig_sw
   d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
   d4 ab0 = {0.0, 0.0, 0.0, 0.0}, ab1 = {0.0, 0.0, 0.0, 0.0}, bb0 = {0.0, 0.0, 0.0, 0.0}, bb1 = {0.0, 0.0, 0.0, 0.0};
   double cost = 0.0;
+  RSW_MARK(2);
   for (int p = 0; p < npass; ++p) {
     const int64_t idx = s0 + (int64_t)p * NT + otid;
     const bool valid = idx < s1;
@@ -392,7 +401,9 @@ __global__ __launch_bounds__(NW * 64, HK ? 2 : CC_RIG_SWEEP_WAVES) void k_rig_sw
     gram_rows(stage, lane, acc0, acc1);
     if (HK) { gram_rows_ab(stage, stage_b, lane, ab0, ab1); gram_rows(stage_b, lane, bb0, bb1); }
     wave_lds_fence();
+    if (p == 0) RSW_MARK(3);
   }
+  RSW_MARK(4);
   __syncthreads();
   const int slot = ((lane >> 4)) * 16 + (lane & 15);
 #pragma unroll
@@ -424,6 +435,7 @@ __global__ __launch_bounds__(NW * 64, HK ? 2 : CC_RIG_SWEEP_WAVES) void k_rig_sw
     P.gstats[g * 2] = NW == 4 ? (sm[144] + sm[145]) + (sm[146] + sm[147]) : (NW == 2 ? sm[144] + sm[145] : sm[144]);
     P.gstats[g * 2 + 1] = NW == 4 ? (sm[140] + sm[141]) + (sm[142] + sm[143]) : (NW == 2 ? sm[140] + sm[141] : sm[140]);
   }
+  RSW_MARK(5);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2076,7 +2088,7 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   if (int rc = dev_zeroed(h, &d.sp, (size_t)F * 8)) return rc;
   if (int rc = dev_zeroed(h, &d.ss, (size_t)128)) return rc;
   if (int rc = dev_zeroed(h, &d.ds, (size_t)128)) return rc;
-  if (int rc = dev_zeroed(h, &d.shared_stats, (size_t)32)) return rc;   // [0..3] statistics, [8..] timing marks (CC_RIG_TIMING builds)
+  if (int rc = dev_zeroed(h, &d.shared_stats, (size_t)48)) return rc;   // [0..3] statistics, [8..] timing marks (CC_RIG_TIMING builds)
   if (int rc = dev_zeroed(h, &d.ctl, (size_t)1)) return rc;
   if (int rc = dev_zeroed(h, &d.ctl_next, (size_t)1)) return rc;
   if (int rc = dev_zeroed(h, &d.arrive, (size_t)16)) return rc;

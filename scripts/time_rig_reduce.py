@@ -13,16 +13,17 @@ sc = capi.rig_scenario(Cc, F, M)
 cq, ct = capi.affine_to_qt(sc["cam_T"]); fq, ft = capi.affine_to_qt(sc["frame_T"])
 prob = capi.RigProblem(Cc, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"], sc["world_xyz"], sc["cam_frozen"])
 prob.set_state(cq, ct, fq, ft)
-rows, erows = [], []
+rows, erows, swrows = [], [], []
 for _ in range(5):
     prob.reset()
     s = prob.solve(capi.default_options(max_iterations=12), log_capacity=0)
-    buf = np.zeros(32)
-    capi._check(capi.lib().cc_rig_debug_fetch(prob._h, b"shared_stats", buf.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(32)))
+    buf = np.zeros(48)
+    capi._check(capi.lib().cc_rig_debug_fetch(prob._h, b"shared_stats", buf.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(48)))
     t = buf[8:16] / 100.0   # 100 MHz ticks -> us
     rows.append(np.concatenate([np.diff(t), [buf[16] / 100.0, buf[17] / 100.0, (buf[19] - buf[18]) / 100.0]]))
     e = buf[20:30] / 100.0
     erows.append(np.diff(e))
+    swrows.append(np.diff(buf[33:38] / 100.0))   # (mark 0 belongs to the solve's last, empty launch)
 prob.close()
 d = np.median(np.array(rows), axis=0)
 ed = np.median(np.array(erows), axis=0)
@@ -31,6 +32,9 @@ enames = ["control block read", "statistics + decision", "lane tables", "frame l
 names = ["column sums", "drain + arrival", "reads + assembly", "rhs/diagonal/tests", "factorisation + substitutions",
          "candidates + control block", "flag + pose update", "(of the factorisation: panels on wave 0)", "(trailing updates)",
          "(backward substitution + step store)"]
+swd = np.median(np.array(swrows), axis=0)
+print(json.dumps({"kernel": "k_rig_sweep (middle workgroup, from the records barrier on)", "cams": Cc, "frames": F, "pts": M, "total_us": float(swd.sum()),
+                  **{n: round(float(v), 2) for n, v in zip(["model-cost term + rotation setup", "first pass", "remaining passes", "cross-wave reduction + block store"], swd)}}))
 print(json.dumps({"kernel": "k_rig_elim (block 0)", "cams": Cc, "frames": F, "pts": M, "total_us": float(ed.sum()),
                   **{n: round(float(v), 2) for n, v in zip(enames, ed)}}))
 print(json.dumps({"kernel": "k_rig_reduce (solving block)", "cams": Cc, "frames": F, "pts": M, "total_us": float(d[:7].sum()), **{n: round(float(v), 2) for n, v in zip(names, d)}}))
