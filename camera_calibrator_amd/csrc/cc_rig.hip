@@ -1266,11 +1266,15 @@ __device__ void rig_solve_block(const RigDev& P, double* smem) {
       const int e = e0 + u * 256 + tid;
       v[u] = 0.0; d[u] = -1; sa[u] = 0; sb[u] = 0;
       if (e >= P.ND) continue;
+      // (the value is requested together with its table entries, not behind them: one round trip instead of two; the
+      // mailbox reader polls and stays conditional)
+      double acc = SRC == 2 ? 0.0 : val.get<SRC>(P.pc_dir + e);
       d[u] = P.dir_dst[e];
-      if (d[u] == -1) continue;
       sa[u] = P.dir_sa[e]; sb[u] = P.dir_sb[e];
-      double acc = val.get<SRC>(P.pc_dir + e);
-      for (int n = P.dir_next[e]; n >= 0; n = P.dir_next[n]) acc += val.get<SRC>(P.pc_dir + n);
+      const int nx = P.dir_next[e];
+      if (d[u] == -1) continue;
+      if (SRC == 2) acc = val.get<SRC>(P.pc_dir + e);
+      for (int n = nx; n >= 0; n = P.dir_next[n]) acc += val.get<SRC>(P.pc_dir + n);
       v[u] = acc;
     }
 #pragma unroll
@@ -1292,8 +1296,9 @@ __device__ void rig_solve_block(const RigDev& P, double* smem) {
       const int i = i0 + u * 256 + tid;
       v[u] = 0.0; d[u] = -1;
       if (i >= P.nT * 256) continue;
+      if (SRC != 2) v[u] = val.get<SRC>(i);   // (with the table entry, not behind it)
       d[u] = P.tile_dst[i];
-      if (d[u] != -1) v[u] = val.get<SRC>(i);
+      if (SRC == 2 && d[u] != -1) v[u] = val.get<SRC>(i);
     }
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
@@ -1920,7 +1925,9 @@ static int rig_enqueue_round(cc_rig* h, bool initial, bool profile) {
   // Every block of this launch must be resident at once (the blocks wait for each other's flag, k_rig_reduce): 64
   // blocks is a quarter of the chip, which leaves room for the kernels of other processes on the same GPU (the
   // multi-process tests put up to four ranks on one GPU, and a rank's solver waits for the OTHER ranks' launches).
-  const unsigned rblocks = (unsigned)std::min((d.PC + 15) / 16, 64);
+  // enough blocks for the column sums AND for the pose update fused behind them (16 frames per block and pass): a small
+  // reduced system (the reference's 2-camera test: 18 blocks of sums) would otherwise update 1000 frames in four passes
+  const unsigned rblocks = (unsigned)std::min<int64_t>(64, std::max<int64_t>((d.PC + 15) / 16, (h->F + 15) / 16));
   if (h->comm) {
     { RigProbe p(h, CC_K_REDUCE, profile); hipLaunchKernelGGL(k_rig_reduce<2>, dim3(rblocks), dim3(256), 0, h->stream, d); }
     { RigProbe p(h, CC_K_ALLREDUCE, profile); if (int rc = comm_allreduce_sum(h->comm, d.vec, d.PC + 32, h->stream)) return rc; }
