@@ -214,23 +214,58 @@ __device__ __forceinline__ void rigk_obs(const double* k, const RigObs& o, doubl
   r.Bv0 = fy * dxy * iz; r.Bv1 = fy * dyy * iz; r.Bv2 = -(fy * dxy * x + fy * dyy * y) * iz;
 }
 
-// Gram tile between two staged 16-column halves of the same 64 rows: D[i][j] += sum_rows a[i] b[j]
-__device__ __forceinline__ void gram_rows_ab(const double* sa, const double* sb, int lane, d4& acc0, d4& acc1) {
+// Second product of the sweep with intrinsics. The 22 columns of a row are X = [J_cam(6) J_frame(6) r k0 k1 k2] (tile
+// T1) and Y = [k3 .. k8]; tile T2 holds [Y(6) | X0..X9]. X^T X covers every pair inside X; this product,
+// P2[a][b] = sum_rows T2[a] * B[b] with B = [Y(6) | X10..X15 | 0 0 0 0], covers Y^T Y, X0..9^T Y and Y^T X10..15 -- all
+// 253 pairs with two matrix products per row set instead of the three of an [X | K]-by-halves split (AA, AB, BB).
+// The B operand needs no tile of its own: lane column c reads T2 (c < 6) or T1 column c + 4 (6 <= c < 12), else zero.
+__device__ __forceinline__ void gram_rows_p2(const double* t1, const double* t2, int lane, d4& acc0, d4& acc1) {
   const int c = lane & 15, sub = lane >> 4;
+  const double* bt = c < 6 ? t2 : t1;
+  const int cb = c < 6 ? c : (c < 12 ? c + 4 : 0);
+  const bool bz = c >= 12;
 #pragma unroll
   for (int m = 0; m < 16; m += 2) {
     const int r0 = 4 * m + sub, r1 = 4 * (m + 1) + sub;
-    const int o0 = r0 * 16 + (((c >> 1) ^ (r0 & 7)) << 1) + (c & 1), o1 = r1 * 16 + (((c >> 1) ^ (r1 & 7)) << 1) + (c & 1);
-    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[o0], sb[o0], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[o1], sb[o1], acc1, 0, 0, 0);
+    const double a0 = t2[r0 * 16 + (((c >> 1) ^ (r0 & 7)) << 1) + (c & 1)];
+    const double a1 = t2[r1 * 16 + (((c >> 1) ^ (r1 & 7)) << 1) + (c & 1)];
+    const double x0 = bt[r0 * 16 + (((cb >> 1) ^ (r0 & 7)) << 1) + (cb & 1)];
+    const double x1 = bt[r1 * 16 + (((cb >> 1) ^ (r1 & 7)) << 1) + (cb & 1)];
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bz ? 0.0 : x0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bz ? 0.0 : x1, acc1, 0, 0, 0);
   }
+}
+
+// Where entry (i, j) of output tile t (0: AA = [cam frame r]^2, 1: AB = [cam frame r] x K, 2: BB = K x K; the layout
+// the elimination and the solve step read) comes from: returns 0 (zero), 1 (P1 = X^T X) or 2 (P2), index in `e`.
+__device__ __forceinline__ int rigk_out_source(int t, int i, int j, int& e) {
+  e = 0;
+  if (t == 0) {
+    if (i < 13 && j < 13) { e = i * 16 + j; return 1; }
+    return 0;
+  }
+  if (t == 1) {   // <X_i, K_j>
+    if (i >= 13 || j >= 9) return 0;
+    if (j < 3) { e = i * 16 + 13 + j; return 1; }
+    const int m = j - 3;
+    e = i < 10 ? (6 + i) * 16 + m : m * 16 + 6 + (i - 10);
+    return 2;
+  }
+  // <K_i, K_j>
+  if (i >= 9 || j >= 9) return 0;
+  if (i < 3 && j < 3) { e = (13 + i) * 16 + 13 + j; return 1; }
+  if (i < 3) { e = (j - 3) * 16 + 9 + i; return 2; }
+  if (j < 3) { e = (i - 3) * 16 + 9 + j; return 2; }
+  e = (i - 3) * 16 + (j - 3);
+  return 2;
 }
 
 // ---------------------------------------------------------------------------------------------
 // sweep: one workgroup per (frame, camera) group. HK = false: the reference's problem (normalised
 // observations, poses only, one 16x16 Gram tile). HK = true (extension): pixel observations through the
-// camera's 9 intrinsics (its own set or the one shared by all cameras); the row is [J_cam(6) J_frame(6) r 0 0 0 | J_k(9) 0...] and the group block has
-// three tiles: AA (as before), AB (first half x intrinsics), BB (intrinsics x intrinsics).
+// camera's 9 intrinsics (its own set or the one shared by all cameras); the row has 22 columns
+// [J_cam(6) J_frame(6) r | J_k(9)]; two matrix products per row set cover all their pairs (gram_rows_p2) and the epilogue
+// scatters them into the group block's three tiles AA ([cam frame r]^2), AB ([cam frame r] x K), BB (K x K).
 // ---------------------------------------------------------------------------------------------
 #ifndef CC_RIG_SWEEP_WAVES
 #define CC_RIG_SWEEP_WAVES 4   // waves per SIMD the poses-only sweep is compiled for (A/B knob)
@@ -342,7 +377,7 @@ __global__ __launch_bounds__(NW * 64, HK ? 2 : CC_RIG_SWEEP_WAVES) void k_rig_sw
   double* stage = s_stage + wave * kTiles * kStageDoublesPerWave;
   double* stage_b = stage + kStageDoublesPerWave;
   d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-  d4 ab0 = {0.0, 0.0, 0.0, 0.0}, ab1 = {0.0, 0.0, 0.0, 0.0}, bb0 = {0.0, 0.0, 0.0, 0.0}, bb1 = {0.0, 0.0, 0.0, 0.0};
+  d4 ab0 = {0.0, 0.0, 0.0, 0.0}, ab1 = {0.0, 0.0, 0.0, 0.0};   // (with intrinsics: the second product, gram_rows_p2)
   double cost = 0.0;
   RSW_MARK(2);
   for (int p = 0; p < npass; ++p) {
@@ -376,30 +411,43 @@ __global__ __launch_bounds__(NW * 64, HK ? 2 : CC_RIG_SWEEP_WAVES) void k_rig_sw
 #pragma unroll
       for (int k = 0; k < 16; ++k) v[k] = 0.0;
     }
-    stage_row(stage, lane, v);
     if (HK) {
+      // X = [cam frame r k0 k1 k2], T2 = [k3..k8 | X0..X9] (see gram_rows_p2)
+      double jk[9];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) vb[k] = (k < 9 && valid && !(kmask & (1u << k))) ? sr * ko.ju[k] : 0.0;
-      stage_row(stage_b, lane, vb);
+      for (int k = 0; k < 9; ++k) jk[k] = (valid && !(kmask & (1u << k))) ? sr * ko.ju[k] : 0.0;
+      v[13] = jk[0]; v[14] = jk[1]; v[15] = jk[2];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) vb[k] = jk[3 + k];
+#pragma unroll
+      for (int k = 0; k < 10; ++k) vb[6 + k] = v[k];
     }
+    stage_row(stage, lane, v);
+    if (HK) stage_row(stage_b, lane, vb);
     wave_lds_fence();
     gram_rows(stage, lane, acc0, acc1);
-    if (HK) { gram_rows_ab(stage, stage_b, lane, ab0, ab1); gram_rows(stage_b, lane, bb0, bb1); }
+    if (HK) gram_rows_p2(stage, stage_b, lane, ab0, ab1);
     wave_lds_fence();
     rig_row(o, Rc, Bv0, Bv1, Bv2, rv, sr, fixed, v);
     if (!valid) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) v[k] = 0.0;
     }
-    stage_row(stage, lane, v);
     if (HK) {
+      double jk[9];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) vb[k] = (k < 9 && valid && !(kmask & (1u << k))) ? sr * ko.jv[k] : 0.0;
-      stage_row(stage_b, lane, vb);
+      for (int k = 0; k < 9; ++k) jk[k] = (valid && !(kmask & (1u << k))) ? sr * ko.jv[k] : 0.0;
+      v[13] = jk[0]; v[14] = jk[1]; v[15] = jk[2];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) vb[k] = jk[3 + k];
+#pragma unroll
+      for (int k = 0; k < 10; ++k) vb[6 + k] = v[k];
     }
+    stage_row(stage, lane, v);
+    if (HK) stage_row(stage_b, lane, vb);
     wave_lds_fence();
     gram_rows(stage, lane, acc0, acc1);
-    if (HK) { gram_rows_ab(stage, stage_b, lane, ab0, ab1); gram_rows(stage_b, lane, bb0, bb1); }
+    if (HK) gram_rows_p2(stage, stage_b, lane, ab0, ab1);
     wave_lds_fence();
     if (p == 0) RSW_MARK(3);
   }
@@ -409,27 +457,33 @@ __global__ __launch_bounds__(NW * 64, HK ? 2 : CC_RIG_SWEEP_WAVES) void k_rig_sw
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     s_blk[wave * 256 + slot + 64 * r] = acc0[r] + acc1[r];
-    if (HK) {
-      s_blk[1024 + wave * 256 + slot + 64 * r] = ab0[r] + ab1[r];
-      s_blk[2048 + wave * 256 + slot + 64 * r] = bb0[r] + bb1[r];
-    }
+    if (HK) s_blk[1024 + wave * 256 + slot + 64 * r] = ab0[r] + ab1[r];
   }
   const double qw = wave_sum(qterm), cw = wave_sum(cost);
   if (lane == 0) { sm[140 + wave] = qw; sm[144 + wave] = cw; }
   __syncthreads();
   double* out = P.gblocks + ((size_t)dst * P.NG + g) * gs;
+  if (!HK) {
 #pragma unroll
-  for (int e = 0; e < EPT; ++e) {
-    const int t = tid + e * NT;
-    const double gv = NW == 4 ? (s_blk[t] + s_blk[256 + t]) + (s_blk[512 + t] + s_blk[768 + t]) : (NW == 2 ? s_blk[t] + s_blk[256 + t] : s_blk[t]);
-    out[t] = gv;
-    if (phase == 0 && (t >> 4) < 6 && (t & 15) == (t >> 4)) P.ghd0[g * 8 + (t >> 4)] = gv;  // diag of H_cc
-  }
-  if (HK) {
-    out[256 + tid] = (s_blk[1024 + tid] + s_blk[1280 + tid]) + (s_blk[1536 + tid] + s_blk[1792 + tid]);
-    const double bv = (s_blk[2048 + tid] + s_blk[2304 + tid]) + (s_blk[2560 + tid] + s_blk[2816 + tid]);
-    out[512 + tid] = bv;
-    if (phase == 0 && (tid >> 4) < 9 && (tid & 15) == (tid >> 4)) P.ghdk[g * 16 + (tid >> 4)] = bv;  // diag of H_kk
+    for (int e = 0; e < EPT; ++e) {
+      const int t = tid + e * NT;
+      const double gv = NW == 4 ? (s_blk[t] + s_blk[256 + t]) + (s_blk[512 + t] + s_blk[768 + t]) : (NW == 2 ? s_blk[t] + s_blk[256 + t] : s_blk[t]);
+      out[t] = gv;
+      if (phase == 0 && (t >> 4) < 6 && (t & 15) == (t >> 4)) P.ghd0[g * 8 + (t >> 4)] = gv;  // diag of H_cc
+    }
+  } else {
+    // the two products P1 = X^T X (s_blk[0..]) and P2 (s_blk[1024..]) scattered into the block layout [AA | AB | BB]
+    const int i = tid >> 4, j = tid & 15;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      int e;
+      const int src = rigk_out_source(t, i, j, e);
+      const double* b = s_blk + (src == 2 ? 1024 : 0) + e;
+      const double val = src == 0 ? 0.0 : (b[0] + b[256]) + (b[512] + b[768]);
+      out[t * 256 + tid] = val;
+      if (t == 0 && phase == 0 && i < 6 && j == i) P.ghd0[g * 8 + i] = val;    // diag of H_cc
+      if (t == 2 && phase == 0 && i < 9 && j == i) P.ghdk[g * 16 + i] = val;   // diag of H_kk
+    }
   }
   if (tid == 0) {
     P.gstats[g * 2] = NW == 4 ? (sm[144] + sm[145]) + (sm[146] + sm[147]) : (NW == 2 ? sm[144] + sm[145] : sm[144]);
