@@ -611,20 +611,55 @@ __device__ __forceinline__ void rig_reduce_stats(const RigDev& P, bool want, dou
 
 // Sum over this rank's groups of the diagonal entry of shared column k at the initial point (Jacobi scaling of
 // the shared block). All 256 threads call; the result is valid for thread 0.
-__device__ __forceinline__ double rig_column_diag_sum(const RigDev& P, int k, double* s4) {
-  const int info = P.colinfo[k], kind = (info >> 4) & 15, comp = info & 15, co = info >> 8;
+// Diagonal of the shared block at the initial point, all S columns -> out[0..S) (LDS), for the Jacobi scale. The columns
+// of one camera (6 pose coordinates, kind 0) or of one intrinsics set (9, kinds 1 and 2) are consecutive and sum over the
+// same groups, so a run is reduced together: the group indices of four steps are fetched first, then their values (two
+// round trips per 1024 groups and run, fixed summation order). The first version walked one column at a time with a
+// dependent index -> value load pair per step: 138 us for BASELINE configs[4], once per solve.
+__device__ __forceinline__ void rig_diag_sums(const RigDev& P, double* s4, double* out, int only_run = -1) {
   const int tid = threadIdx.x;
-  double h = 0.0;
-  if (kind == 2) {
-    for (int64_t g = tid; g < P.NG; g += 256) h += P.ghdk[g * 16 + comp];
-  } else {
-    const int c = P.obs_cam[co];
-    for (int i = P.cam_goff[c] + tid; i < P.cam_goff[c + 1]; i += 256) {
-      const int g = P.cam_glist[i];
-      h += kind == 0 ? P.ghd0[(size_t)g * 8 + comp] : P.ghdk[(size_t)g * 16 + comp];
+  int run = 0;
+  for (int k = 0; k < P.S; ++run) {
+    const int info = P.colinfo[k], kind = (info >> 4) & 15, co = info >> 8;
+    const int n = kind == 0 ? 6 : kRigK;
+    if (only_run >= 0 && run != only_run) { k += n; continue; }   // (k_rig_init: one run per block)
+    const double* src = kind == 0 ? P.ghd0 : P.ghdk;
+    const int stride = kind == 0 ? 8 : 16;
+    int64_t lo = 0, hi = P.NG;
+    if (kind != 2) { const int c = P.obs_cam[co]; lo = P.cam_goff[c]; hi = P.cam_goff[c + 1]; }
+    double h[kRigK];
+#pragma unroll
+    for (int c = 0; c < kRigK; ++c) h[c] = 0.0;
+    for (int64_t i0 = lo; i0 < hi; i0 += 4 * 256) {
+      int64_t g[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t i = i0 + u * 256 + tid;
+        const int64_t ic = i < hi ? i : lo;   // (unconditional loads; idle slots are selected away below)
+        g[u] = kind == 2 ? ic : (int64_t)P.cam_glist[ic];
+      }
+      double v[4][kRigK];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < kRigK; ++c) v[u][c] = c < n ? src[(size_t)g[u] * stride + c] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool live = i0 + u * 256 + tid < hi;
+#pragma unroll
+        for (int c = 0; c < kRigK; ++c) h[c] += live ? v[u][c] : 0.0;
+      }
     }
+#pragma unroll
+    for (int c = 0; c < kRigK; ++c) {
+      if (c < n) {   // (uniform)
+        const double sum = block_sum256(h[c], s4);
+        if (tid == 0) out[k + c] = sum;
+      }
+    }
+    k += n;
   }
-  return block_sum256(h, s4);
+  __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -642,9 +677,10 @@ __global__ __launch_bounds__(256) void k_rig_stats(RigDev P) {
   const bool need = phase == 0 || (ctl->cand_pending && ctl->step_valid);
   rig_reduce_stats(P, need, s16, s_out);
   if (tid < 4) P.vec_stats[tid] = need ? s_out[tid] : 0.0;
-  for (int k = 0; k < P.S; ++k) {
-    const double s = phase == 0 ? rig_column_diag_sum(P, k, s4) : 0.0;
-    if (tid == 0) P.vec_stats[4 + k] = s;
+  {
+    __shared__ double s_diag[kRigMaxS + 1];
+    if (phase == 0) rig_diag_sums(P, s4, s_diag);
+    for (int k = tid; k < P.S; k += 256) P.vec_stats[4 + k] = phase == 0 ? s_diag[k] : 0.0;
   }
   if (P.x.on) {
     // mailbox exchange (kind 1): post the local statistics, wait for every rank's, write the sums back
@@ -696,28 +732,46 @@ __global__ __launch_bounds__(256) void k_rig_init(RigDev P) {
   if (ctl->done || ctl->phase != 0) return;
   const int tid = threadIdx.x;
   const bool jac = P.opts->jacobi_scaling != 0;
+  // Single GPU: 1 + (runs of columns) blocks. Block r > 0 sums the diagonal of run r - 1 (one camera's poses or one
+  // intrinsics set) and writes its Jacobi scales; block 0 does the rest. Nothing is exchanged between the blocks. (One
+  // block doing all runs took 130 us at BASELINE configs[4]: tens of thousands of scattered 8-byte loads through one CU.)
+  if (blockIdx.x > 0) {
+    if (P.comm) return;
+    for (int k = tid; k < kRigMaxS + 1; k += 256) s_ss[k] = -1.0;
+    __syncthreads();
+    rig_diag_sums(P, s4, s_ss, (int)blockIdx.x - 1);
+    for (int k = tid; k < P.S; k += 256)
+      if (s_ss[k] >= 0.0) P.ss[k] = jac ? 1.0 / (1.0 + sqrt(s_ss[k])) : 1.0;
+    return;
+  }
   if (P.comm) {
     if (tid < 4) s_out[tid] = P.vec_stats[tid];
-    if (tid < P.S) s_ss[tid] = jac ? 1.0 / (1.0 + sqrt(P.vec_stats[4 + tid])) : 1.0;
+    if (tid < P.S) P.ss[tid] = jac ? 1.0 / (1.0 + sqrt(P.vec_stats[4 + tid])) : 1.0;
   } else {
     rig_reduce_stats(P, true, s16, s_out);
-    for (int k = 0; k < P.S; ++k) {
-      const double s = rig_column_diag_sum(P, k, s4);
-      if (tid == 0) s_ss[k] = jac ? 1.0 / (1.0 + sqrt(s)) : 1.0;
-    }
   }
   __syncthreads();
-  if (tid < P.S) P.ss[tid] = s_ss[tid];
+  // |x|^2 of the shared block: one value per thread and step (thread 0 walking the cameras alone waited for 65
+  // dependent loads at BASELINE configs[4])
+  double x2 = 0.0;
+  {
+    const int cur0 = ctl->cur;
+    for (int i = tid; i < P.C * 7; i += 256) {
+      const int cc2 = i / 7;
+      const double v = P.cam[((size_t)cur0 * P.C + cc2) * 8 + (i - cc2 * 7)];
+      x2 += P.cam_fixed[cc2] ? 0.0 : v * v;
+    }
+    for (int i = tid; i < P.CK * kRigK; i += 256) {   // every intrinsic of a set that is in the problem counts in |x|
+      const int ks = i / kRigK;
+      const double v = P.intr[((size_t)cur0 * P.CK + ks) * 16 + (i - ks * kRigK)];
+      x2 += P.kscol[ks] >= 0 ? v * v : 0.0;
+    }
+  }
+  const double x2_shared = block_sum256(x2, s4);
   if (tid == 0) {
     LmCtl c = *ctl;
     const LmOpts o = *P.opts;
-    double xn2 = s_out[3];
-    for (int cc2 = 0; cc2 < P.C; ++cc2)
-      if (!P.cam_fixed[cc2])
-        for (int i = 0; i < 7; ++i) { const double v = P.cam[((size_t)c.cur * P.C + cc2) * 8 + i]; xn2 += v * v; }
-    for (int s = 0; s < P.CK; ++s)   // every intrinsic of a set that is in the problem counts in |x|
-      if (P.kscol[s] >= 0)
-        for (int j = 0; j < kRigK; ++j) { const double v = P.intr[((size_t)c.cur * P.CK + s) * 16 + j]; xn2 += v * v; }
+    const double xn2 = s_out[3] + x2_shared;
     lm_init(c, o, s_out[0], sqrt(xn2));
     *P.ctl = c;
     *P.ctl_next = c;
@@ -1708,6 +1762,7 @@ struct cc_rig {
   hipStream_t stream = nullptr;
   cc::RigDev d{};
   int64_t C = 0, F = 0, N = 0, NG = 0, P = 0;
+  int n_runs = 0;            // runs of shared columns (one per optimised camera, one per intrinsics set): blocks of k_rig_init
   int sweep_waves = 4;       // waves per workgroup of the poses-only sweep (2: small groups that outnumber the slots)
   int kmode = 0;
   std::vector<int64_t> perm;  // sorted position -> caller's observation index
@@ -1906,6 +1961,8 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
   if (int rc = dev_upload(h, &d.kset, kset)) return rc;
   if (int rc = dev_upload(h, &d.kscol, kscol)) return rc;
   if (int rc = dev_upload(h, &d.obs_cam, obs_cam)) return rc;
+  h->n_runs = 0;
+  for (int32_t info : colinfo) if ((info & 15) == 0 && ((info >> 4) & 15) < 3) ++h->n_runs;
   if (int rc = dev_upload(h, &d.colinfo, colinfo)) return rc;
   if (int rc = dev_upload(h, &d.dmap, dmap)) return rc;
   {
@@ -1969,7 +2026,7 @@ static int rig_enqueue_round(cc_rig* h, bool initial, bool profile) {
     { RigProbe p(h, CC_K_DECIDE, profile); hipLaunchKernelGGL(k_rig_stats, dim3(1), dim3(256), 0, h->stream, d); }
     if (h->comm) { RigProbe p(h, CC_K_ALLREDUCE, profile); if (int rc = comm_allreduce_sum(h->comm, d.vec_stats, 4 + d.S, h->stream)) return rc; }
   }
-  if (initial) { RigProbe p(h, CC_K_DECIDE, profile); hipLaunchKernelGGL(k_rig_init, dim3(1), dim3(256), 0, h->stream, d); }
+  if (initial) { RigProbe p(h, CC_K_DECIDE, profile); hipLaunchKernelGGL(k_rig_init, dim3(1 + (unsigned)h->n_runs), dim3(256), 0, h->stream, d); }
   { RigProbe p(h, CC_K_ELIM, profile);
     const bool small = d.ND <= 8 * 64;
     if (d.kmode && small) hipLaunchKernelGGL((k_rig_elim<true, 8>), dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d);
