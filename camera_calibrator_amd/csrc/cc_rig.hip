@@ -804,6 +804,10 @@ __global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
   double* s_Z = reinterpret_cast<double*>(smem_raw);         // [24][ZS] staged Z rows of the four frames
   double* s_A = s_Z + 24 * P.ZS;                             // [4][32] frame block broadcast, per wave
   double* s_red = s_A + 4 * 32;                              // [4][1024] cross-wave reduction scratch
+  // large variant (NR > 8): the direct-sum accumulators of a wave live in LDS, one slot per lane and register index --
+  // as registers they pushed the kernel over the 512-VGPR limit (48 spilled VGPRs, scratch traffic in the frame loop)
+  constexpr bool kLdsAcc = NR > 8;
+  double* s_dacc = s_red + 4 * 1024;                         // [4][NR * 64] (large variant only)
   __shared__ double s_ss[kRigMaxS + 1];
   __shared__ double s16[16];
   __shared__ double s_tot[4];
@@ -850,11 +854,11 @@ __global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
   }
   // direct-sum entries of this lane: e = lane + 64 r -> (observed camera, offset inside the group block)
   int d_ent[NR];   // (observed camera << 16) | offset, -1: nothing (packed: registers are scarce here)
-  double dacc[NR];
+  double dacc[kLdsAcc ? 1 : NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const int e = lane + 64 * r;
-    dacc[r] = 0.0;
+    if (kLdsAcc) s_dacc[(wave * NR + r) * 64 + lane] = 0.0; else dacc[r] = 0.0;
     const int t = P.dent[e < P.ND ? e : 0];   // (unconditional load + select: a conditional load waits on its own)
     d_ent[r] = e < P.ND ? t : -1;
   }
@@ -989,7 +993,10 @@ __global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
             dx[u] = blocks[(size_t)(dk[u] ? g : 0) * gs + (t & 0xffff)];
           }
 #pragma unroll
-          for (int u = 0; u < DB; ++u) dacc[r0 + u] += dk[u] ? dx[u] : 0.0;
+          for (int u = 0; u < DB; ++u) {
+            if (kLdsAcc) s_dacc[(wave * NR + r0 + u) * 64 + lane] += dk[u] ? dx[u] : 0.0;   // (own slot: no conflict)
+            else dacc[r0 + u] += dk[u] ? dx[u] : 0.0;
+          }
         }
       }
       // ---- broadcast the frame block
@@ -1100,8 +1107,13 @@ __global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
     }
   }
   // direct sums: four waves each hold partial sums of the same entries
+  if (kLdsAcc) {
+    __syncthreads();
+    for (int e = tid; e < P.ND; e += 256)
+      prow[P.pc_dir + e] = (s_dacc[e] + s_dacc[NR * 64 + e]) + (s_dacc[2 * NR * 64 + e] + s_dacc[3 * NR * 64 + e]);
+  }
 #pragma unroll
-  for (int r0 = 0; r0 < NR; r0 += 16) {
+  for (int r0 = 0; r0 < (kLdsAcc ? 0 : NR); r0 += 16) {
     if (r0 * 64 >= P.ND) continue;   // (uniform) nothing left in this chunk
     __syncthreads();
 #pragma unroll
@@ -1985,7 +1997,7 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
   if (int rc = dev_zeroed(h, &d.partial, (size_t)d.nblk * d.PC)) return rc;
   if (int rc = dev_zeroed(h, &d.vec, (size_t)d.PC + 32)) return rc;
   if (int rc = dev_zeroed(h, &d.vec_stats, (size_t)4 + kRigMaxS + 1)) return rc;
-  h->elim_lds = ((size_t)24 * d.ZS + 4 * 32 + 4 * 1024) * sizeof(double);
+  h->elim_lds = ((size_t)24 * d.ZS + 4 * 32 + 4 * 1024 + (d.ND > 8 * 64 ? 4 * kRigDirectPerLane * 64 : 0)) * sizeof(double);
   h->solve_lds = ((size_t)S * ((S + 1) | 1) + 5 * 128) * sizeof(double);
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
