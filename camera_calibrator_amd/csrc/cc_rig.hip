@@ -41,7 +41,7 @@ constexpr int kRigThreads = 256;
 constexpr int kRigSweepLdsBytes = (4 * kStageDoublesPerWave + 256) * 8;
 constexpr int kRigSweepLdsBytes2 = (2 * kStageDoublesPerWave + 256) * 8;   // two-wave workgroups
 constexpr int kRigSweepLdsBytes1 = (1 * kStageDoublesPerWave + 256) * 8;   // one-wave workgroups
-constexpr int kRigSweepLdsBytesK = (8 * kStageDoublesPerWave + 256) * 8;  // with intrinsics: two staged tiles per wave
+constexpr int kRigSweepLdsBytesK = (4 * kStageDoublesPerWave + 4 * 512 + 256) * 8;  // with intrinsics: per wave one 64 x 16 tile and one 64 x 8 (three workgroups per CU)
 constexpr int kRigK = 9;              // intrinsics per set (extension)
 constexpr int kRigMaxElimBlocks = 256;
 constexpr int kRigDirectPerLane = 24; // direct-sum accumulators per lane in the elim kernel (ND <= 1536)
@@ -215,24 +215,35 @@ __device__ __forceinline__ void rigk_obs(const double* k, const RigObs& o, doubl
 }
 
 // Second product of the sweep with intrinsics. The 22 columns of a row are X = [J_cam(6) J_frame(6) r k0 k1 k2] (tile
-// T1) and Y = [k3 .. k8]; tile T2 holds [Y(6) | X0..X9]. X^T X covers every pair inside X; this product,
-// P2[a][b] = sum_rows T2[a] * B[b] with B = [Y(6) | X10..X15 | 0 0 0 0], covers Y^T Y, X0..9^T Y and Y^T X10..15 -- all
-// 253 pairs with two matrix products per row set instead of the three of an [X | K]-by-halves split (AA, AB, BB).
-// The B operand needs no tile of its own: lane column c reads T2 (c < 6) or T1 column c + 4 (6 <= c < 12), else zero.
-__device__ __forceinline__ void gram_rows_p2(const double* t1, const double* t2, int lane, d4& acc0, d4& acc1) {
+// T1, 64 x 16, swizzled) and Y = [k3 .. k8] (tile TY, 64 x 8, plain). X^T X covers every pair inside X; this product,
+// P2[a][b] = sum_rows A[a] * B[b] with A = [Y(6) | X0..X9] and B = [Y(6) | X10..X15 | 0 0 0 0], covers Y^T Y, X0..9^T Y
+// and Y^T X10..15 -- all 253 pairs with two matrix products per row set instead of the three of an [X | K]-by-halves
+// split (AA, AB, BB). Neither operand needs a tile of its own: a lane reads TY or a shifted column of T1.
+__device__ __forceinline__ void gram_rows_p2(const double* t1, const double* ty, int lane, d4& acc0, d4& acc1) {
   const int c = lane & 15, sub = lane >> 4;
-  const double* bt = c < 6 ? t2 : t1;
-  const int cb = c < 6 ? c : (c < 12 ? c + 4 : 0);
+  const int ca = c < 6 ? c : c - 6;                       // A: TY column c, or T1 column c - 6
+  const int cb = c < 6 ? c : (c < 12 ? c + 4 : 0);       // B: TY column c, T1 column c + 4, or nothing
   const bool bz = c >= 12;
 #pragma unroll
   for (int m = 0; m < 16; m += 2) {
     const int r0 = 4 * m + sub, r1 = 4 * (m + 1) + sub;
-    const double a0 = t2[r0 * 16 + (((c >> 1) ^ (r0 & 7)) << 1) + (c & 1)];
-    const double a1 = t2[r1 * 16 + (((c >> 1) ^ (r1 & 7)) << 1) + (c & 1)];
-    const double x0 = bt[r0 * 16 + (((cb >> 1) ^ (r0 & 7)) << 1) + (cb & 1)];
-    const double x1 = bt[r1 * 16 + (((cb >> 1) ^ (r1 & 7)) << 1) + (cb & 1)];
+    const double a0 = c < 6 ? ty[r0 * 8 + ca] : t1[r0 * 16 + (((ca >> 1) ^ (r0 & 7)) << 1) + (ca & 1)];
+    const double a1 = c < 6 ? ty[r1 * 8 + ca] : t1[r1 * 16 + (((ca >> 1) ^ (r1 & 7)) << 1) + (ca & 1)];
+    const double x0 = c < 6 ? ty[r0 * 8 + cb] : t1[r0 * 16 + (((cb >> 1) ^ (r0 & 7)) << 1) + (cb & 1)];
+    const double x1 = c < 6 ? ty[r1 * 8 + cb] : t1[r1 * 16 + (((cb >> 1) ^ (r1 & 7)) << 1) + (cb & 1)];
     acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bz ? 0.0 : x0, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bz ? 0.0 : x1, acc1, 0, 0, 0);
+  }
+}
+
+// one row of TY per lane: six doubles at [lane][0..5] of a 64 x 8 tile
+__device__ __forceinline__ void stage_row_y(double* ty, int lane, const double* y) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    d2 val;
+    val.x = y[2 * j];
+    val.y = y[2 * j + 1];
+    *reinterpret_cast<d2*>(&ty[lane * 8 + 2 * j]) = val;
   }
 }
 
@@ -274,15 +285,14 @@ __device__ __forceinline__ int rigk_out_source(int t, int i, int j, int& e) {
 // residency slots of four-wave workgroups (BASELINE configs[3]: 1600 groups of 300 observations = 5 chunks; twice as
 // many half-size workgroups are all resident at once and split the chunks 3 + 2 instead of 2 + 1 + 1 + 1).
 template <bool HK, int NW>
-__global__ __launch_bounds__(NW * 64, HK ? 2 : CC_RIG_SWEEP_WAVES) void k_rig_sweep(RigDev P) {
+__global__ __launch_bounds__(NW * 64, HK ? 3 : CC_RIG_SWEEP_WAVES) void k_rig_sweep(RigDev P) {
   static_assert(NW == 4 || ((NW == 2 || NW == 1) && !HK), "small workgroups exist for the poses-only sweep");
   constexpr int NT = NW * 64;      // threads
   constexpr int EPT = 256 / NT;    // block entries per thread
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  constexpr int kTiles = HK ? 2 : 1;
   double* s_stage = reinterpret_cast<double*>(smem_raw);
   double* s_blk = s_stage;
-  double* sm = s_stage + NW * kTiles * kStageDoublesPerWave;  // [256]
+  double* sm = s_stage + NW * kStageDoublesPerWave + (HK ? NW * 512 : 0);  // [256]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t g = blockIdx.x;
   // (timing-only builds: the middle workgroup leaves wall-clock marks in shared_stats[32..], scripts/time_rig_reduce.py)
@@ -374,8 +384,8 @@ __global__ __launch_bounds__(NW * 64, HK ? 2 : CC_RIG_SWEEP_WAVES) void k_rig_sw
   const double ha = P.huber_a;
   const uint32_t kmask = HK ? P.kmask[ks] : 0u;
 
-  double* stage = s_stage + wave * kTiles * kStageDoublesPerWave;
-  double* stage_b = stage + kStageDoublesPerWave;
+  double* stage = s_stage + wave * kStageDoublesPerWave;
+  double* stage_b = s_stage + NW * kStageDoublesPerWave + wave * 512;   // (with intrinsics) the 64 x 8 tile TY of this wave
   d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
   d4 ab0 = {0.0, 0.0, 0.0, 0.0}, ab1 = {0.0, 0.0, 0.0, 0.0};   // (with intrinsics: the second product, gram_rows_p2)
   double cost = 0.0;
@@ -405,25 +415,23 @@ __global__ __launch_bounds__(NW * 64, HK ? 2 : CC_RIG_SWEEP_WAVES) void k_rig_sw
     double rho, sr;
     huber(ha, ru * ru + rv * rv, rho, sr);
     if (valid) cost += 0.5 * rho;
-    double v[16], vb[16];
+    double v[16], vb[6];
     rig_row(o, Rc, Bu0, Bu1, Bu2, ru, sr, fixed, v);
     if (!valid) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) v[k] = 0.0;
     }
     if (HK) {
-      // X = [cam frame r k0 k1 k2], T2 = [k3..k8 | X0..X9] (see gram_rows_p2)
+      // X = [cam frame r k0 k1 k2] -> T1, Y = [k3..k8] -> TY (see gram_rows_p2)
       double jk[9];
 #pragma unroll
       for (int k = 0; k < 9; ++k) jk[k] = (valid && !(kmask & (1u << k))) ? sr * ko.ju[k] : 0.0;
       v[13] = jk[0]; v[14] = jk[1]; v[15] = jk[2];
 #pragma unroll
       for (int k = 0; k < 6; ++k) vb[k] = jk[3 + k];
-#pragma unroll
-      for (int k = 0; k < 10; ++k) vb[6 + k] = v[k];
     }
     stage_row(stage, lane, v);
-    if (HK) stage_row(stage_b, lane, vb);
+    if (HK) stage_row_y(stage_b, lane, vb);
     wave_lds_fence();
     gram_rows(stage, lane, acc0, acc1);
     if (HK) gram_rows_p2(stage, stage_b, lane, ab0, ab1);
@@ -440,11 +448,9 @@ __global__ __launch_bounds__(NW * 64, HK ? 2 : CC_RIG_SWEEP_WAVES) void k_rig_sw
       v[13] = jk[0]; v[14] = jk[1]; v[15] = jk[2];
 #pragma unroll
       for (int k = 0; k < 6; ++k) vb[k] = jk[3 + k];
-#pragma unroll
-      for (int k = 0; k < 10; ++k) vb[6 + k] = v[k];
     }
     stage_row(stage, lane, v);
-    if (HK) stage_row(stage_b, lane, vb);
+    if (HK) stage_row_y(stage_b, lane, vb);
     wave_lds_fence();
     gram_rows(stage, lane, acc0, acc1);
     if (HK) gram_rows_p2(stage, stage_b, lane, ab0, ab1);
