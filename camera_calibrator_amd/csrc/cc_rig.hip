@@ -503,15 +503,53 @@ __global__ __launch_bounds__(NW * 64, HK ? 3 : CC_RIG_SWEEP_WAVES) void k_rig_sw
 // 256-thread block (`fblk` = which sixteen). SC1: the shared step `ds` was written by another workgroup of the
 // SAME launch (fused into k_rig_reduce): read it with sc1 loads.
 // ---------------------------------------------------------------------------------------------
-template <bool SC1>
-__device__ __forceinline__ void rig_update_body(const RigDev& P, int phase, int cur, int64_t fblk) {
+// What the update of a frame needs besides the shared step: fetched by the blocks of k_rig_reduce WHILE they wait for
+// the solving block's flag (SW <= 32: two Y columns per lane), so that only the step itself is read behind the flag.
+// Everything unconditional (all sixteen lanes of a frame fetch the frame's scalars: same addresses, one transaction).
+struct RigUpdPre {
+  double y[2][6], p0[7], p1[7], sp[6];
+  int g0, g1;
+};
+__device__ __forceinline__ void rig_update_prefetch(const RigDev& P, int64_t fblk, RigUpdPre& x) {
+  const int tid = threadIdx.x, l = tid & 15;
+  const int64_t f = fblk * 16 + (tid >> 4);
+  const int64_t fc = f < P.F ? f : 0;
+  const double* Yf = P.Y + (size_t)fc * 6 * P.SW;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int k = l + 16 * h, kc = k < P.SW ? k : 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x.y[h][i] = Yf[i * P.SW + kc];
+  }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) { x.p0[i] = P.pose[(size_t)fc * 8 + i]; x.p1[i] = P.pose[((size_t)P.F + fc) * 8 + i]; }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) x.sp[i] = P.sp[fc * 8 + i];
+  x.g0 = P.fgoff[fc]; x.g1 = P.fgoff[fc + 1];
+}
+
+template <bool SC1, bool PRE = false>
+__device__ __forceinline__ void rig_update_body(const RigDev& P, int phase, int cur, int64_t fblk, const RigUpdPre& pre) {
   const int dst = phase == 0 ? cur : (cur ^ 1);
   const int tid = threadIdx.x, l = tid & 15;
   const int64_t f = fblk * 16 + (tid >> 4);
   const bool valid = f < P.F;
   const int64_t fc = valid ? f : 0;
   double u[6] = {0, 0, 0, 0, 0, 0};
-  if (phase != 0) {
+  if (phase != 0 && PRE) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = l + 16 * h;
+      double d = 1.0;   // (column S is the right-hand side)
+      const double dk = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(P.ds) + (k < P.S ? k : 0),
+                                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      if (k < P.S) d = dk;
+      if (k < P.SW) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) u[i] += pre.y[h][i] * d;
+      }
+    }
+  } else if (phase != 0) {
     const double* Yf = P.Y + (size_t)fc * 6 * P.SW;
     for (int k = l; k < P.SW; k += 16) {
       double d = 1.0;
@@ -521,6 +559,8 @@ __device__ __forceinline__ void rig_update_body(const RigDev& P, int phase, int 
 #pragma unroll
       for (int i = 0; i < 6; ++i) u[i] += Yf[i * P.SW + k] * d;
     }
+  }
+  if (phase != 0) {   // the sixteen lanes of a frame add up their columns
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
 #pragma unroll
@@ -528,15 +568,32 @@ __device__ __forceinline__ void rig_update_body(const RigDev& P, int phase, int 
     }
   }
   if (!valid || l != 0) return;
-  const bool active = P.fgoff[f + 1] > P.fgoff[f];
-  const double* pc = P.pose + ((size_t)cur * P.F + f) * 8;
-  double q[4] = {pc[0], pc[1], pc[2], pc[3]}, t[3] = {pc[4], pc[5], pc[6]};
+  bool active;
+  double q[4], t[3], spf[6];
+  if (PRE) {
+    active = pre.g1 > pre.g0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = cur ? pre.p1[i] : pre.p0[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = cur ? pre.p1[4 + i] : pre.p0[4 + i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) spf[i] = pre.sp[i];
+  } else {
+    active = P.fgoff[f + 1] > P.fgoff[f];
+    const double* pc = P.pose + ((size_t)cur * P.F + f) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = pc[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = pc[4 + i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) spf[i] = phase != 0 ? P.sp[f * 8 + i] : 0.0;
+  }
   double dp[6] = {0, 0, 0, 0, 0, 0};
   double step2 = 0.0;
   if (phase != 0) {
     if (active) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) dp[i] = -u[i] * P.sp[f * 8 + i];
+      for (int i = 0; i < 6; ++i) dp[i] = -u[i] * spf[i];
       double qn[4];
       quat_plus(q, dp, qn);
 #pragma unroll
@@ -568,7 +625,8 @@ __global__ __launch_bounds__(256) void k_rig_update(RigDev P) {
   if (ctl->done) return;
   const int phase = ctl->phase;
   if (phase != 0 && !ctl->step_valid) return;
-  rig_update_body<false>(P, phase, ctl->cur, blockIdx.x);
+  RigUpdPre none;   // (unused: PRE = false)
+  rig_update_body<false, false>(P, phase, ctl->cur, blockIdx.x, none);
 }
 
 // deterministic block-wide sum of one value per thread (256 threads); result valid for thread 0
@@ -1699,6 +1757,11 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P) {
     s_last = prev + 1u == gridDim.x;
   }
   __syncthreads();
+  // every block -- the solving one included -- requests what the update of its first sixteen frames needs NOW, before it
+  // waits (or solves): behind the flag only the shared step is still to be read
+  RigUpdPre pre;
+  const bool use_pre = P.SW <= 32 && (int64_t)blockIdx.x * 16 < P.F;
+  rig_update_prefetch(P, blockIdx.x, pre);   // (unconditional: loads inside an `if` would be waited for at its end)
   if (s_last) {
     if (tid == 0) __hip_atomic_store(P.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
 #ifdef CC_RIG_TIMING
@@ -1713,7 +1776,8 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P) {
       s_flag = ((epoch0 + 1u) << 3) | (c->done ? 4u : 0u) | (c->step_valid ? 2u : 0u) | (unsigned)(c->cur & 1);
       __hip_atomic_store(P.arrive + 1, s_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-  } else if (tid == 0) {
+  }
+  if (!s_last && tid == 0) {
     const long long t0 = wall_clock64();
     unsigned f;
     for (;;) {
@@ -1728,9 +1792,12 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P) {
   const unsigned flag = s_flag;
   if ((flag & 4u) || !(flag & 2u)) return;   // done, or no valid step: the poses stay
   const int cur = (int)(flag & 1u);
-  for (int64_t fblk = blockIdx.x; fblk * 16 < P.F; fblk += gridDim.x) rig_update_body<true>(P, 1, cur, fblk);
+  if (use_pre) rig_update_body<true, true>(P, 1, cur, blockIdx.x, pre);
+  for (int64_t fblk = use_pre ? (int64_t)blockIdx.x + gridDim.x : (int64_t)blockIdx.x; fblk * 16 < P.F; fblk += gridDim.x)
+    rig_update_body<true, false>(P, 1, cur, fblk, pre);
 #ifdef CC_RIG_TIMING
-  if (s_last) { __syncthreads(); RIG_MARK(7); }
+  __syncthreads();
+  if (threadIdx.x == 0 && s_last) P.shared_stats[15] = (double)wall_clock64();   // mark 7 (written this way: RIG_MARK(7) inside `if (s_last)` trips a register-class bug of the compiler)
 #endif
 }
 
