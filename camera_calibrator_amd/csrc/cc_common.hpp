@@ -145,16 +145,48 @@ __device__ inline void lm_init(LmCtl& st, const LmOpts& o, double cost, double x
   if (o.max_iterations <= 0) { st.done = 1; st.term = CC_NO_CONVERGENCE; }
 }
 
-// One LM iteration's decision. Inputs are the globally reduced quantities of the candidate point.
+// One LM iteration's decision, in two halves with exactly the arithmetic of the single function they replace.
+// lm_trial: is the step valid, did a tolerance fire, is the candidate accepted (TrustRegionStepEvaluator::StepQuality).
+// It does not touch the state, so a kernel can act on `accept` (which buffer holds the point to eliminate next) while
+// lm_apply -- radius update, non-monotonic bookkeeping, log record, iteration limit -- is still running.
+struct LmTrial {
+  int valid;        // the linear solve succeeded and the model predicts a decrease
+  int conv;         // 0 none, 1 parameter tolerance, 2 function tolerance
+  int accept;       // candidate accepted (st.cur flips)
+  double mcc, step_norm, cand_cost, cost_change, quality;
+};
+
+__device__ inline LmTrial lm_trial(const LmCtl& st, const LmOpts& o, double cand_cost, double q_model, double step2) {
+  LmTrial t;
+  t.mcc = -q_model;
+  t.valid = st.step_valid && (t.mcc > 0.0) && isfinite(t.mcc);
+  t.conv = 0; t.accept = 0; t.step_norm = 0.0; t.cost_change = 0.0; t.quality = 0.0;
+  t.cand_cost = cand_cost;
+  if (!t.valid) return t;
+  t.step_norm = sqrt(step2);
+  if (!isfinite(t.cand_cost)) t.cand_cost = 1.7976931348623157e308;
+  t.cost_change = st.x_cost - t.cand_cost;
+  if (t.step_norm <= o.parameter_tolerance * (st.x_norm + o.parameter_tolerance)) { t.conv = 1; return t; }
+  if (fabs(t.cost_change) <= o.function_tolerance * st.x_cost) { t.conv = 2; return t; }
+  // TrustRegionStepEvaluator::StepQuality
+  if (!(t.cand_cost < 1.7976931348623157e308)) {
+    t.quality = -1.7976931348623157e308;
+  } else {
+    const double rel = (st.current_cost - t.cand_cost) / t.mcc;
+    const double hist = (st.reference_cost - t.cand_cost) / (st.acc_ref + t.mcc);
+    t.quality = fmax(rel, hist);
+  }
+  t.accept = t.quality > o.min_relative_decrease;
+  return t;
+}
+
 // An accepted candidate flips st.cur. The gradient-tolerance test of the new point is made by the
 // solve step, which owns the reduced gradient (lm_finalize; it also completes the log record).
-__device__ inline void lm_decide(LmCtl& st, const LmOpts& o, cc_iteration* e,
-                                 double cand_cost, double q_model, double step2, double xnorm2_cand) {
+__device__ inline void lm_apply(LmCtl& st, const LmOpts& o, cc_iteration* e, const LmTrial& t, double xnorm2_cand) {
   st.iter++;
   if (st.step_valid) st.sweeps++;
-  const double mcc = -q_model;
-  const bool valid = st.step_valid && (mcc > 0.0) && isfinite(mcc);
-  if (!valid) {
+  const double mcc = t.mcc;
+  if (!t.valid) {
     // HandleInvalidStep + LevenbergMarquardtStrategy::StepIsInvalid
     st.n_invalid++;
     st.radius /= st.decrease_factor;
@@ -163,26 +195,15 @@ __device__ inline void lm_decide(LmCtl& st, const LmOpts& o, cc_iteration* e,
     if (st.n_invalid >= o.max_consecutive_invalid_steps) { st.done = 1; st.term = CC_FAILURE_INVALID_STEPS; }
   } else {
     st.n_invalid = 0;
-    const double step_norm = sqrt(step2);
-    if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
-    const double cost_change = st.x_cost - cand_cost;
-    if (step_norm <= o.parameter_tolerance * (st.x_norm + o.parameter_tolerance)) {
+    const double step_norm = t.step_norm, cand_cost = t.cand_cost, cost_change = t.cost_change, quality = t.quality;
+    if (t.conv == 1) {
       st.done = 1; st.term = CC_CONVERGENCE_PARAMETER;
       lm_log(st, e, st.x_cost, cost_change, mcc, 0.0, step_norm, 0, 1);
-    } else if (fabs(cost_change) <= o.function_tolerance * st.x_cost) {
+    } else if (t.conv == 2) {
       st.done = 1; st.term = CC_CONVERGENCE_FUNCTION;
       lm_log(st, e, st.x_cost, cost_change, mcc, 0.0, step_norm, 0, 1);
     } else {
-      // TrustRegionStepEvaluator::StepQuality
-      double quality;
-      if (!(cand_cost < 1.7976931348623157e308)) {
-        quality = -1.7976931348623157e308;
-      } else {
-        const double rel = (st.current_cost - cand_cost) / mcc;
-        const double hist = (st.reference_cost - cand_cost) / (st.acc_ref + mcc);
-        quality = fmax(rel, hist);
-      }
-      if (quality > o.min_relative_decrease) {
+      if (t.accept) {
         st.cur ^= 1;
         st.x_cost = cand_cost;
         st.x_norm = sqrt(xnorm2_cand);
@@ -217,6 +238,12 @@ __device__ inline void lm_decide(LmCtl& st, const LmOpts& o, cc_iteration* e,
   if (!st.done && st.iter >= o.max_iterations) { st.done = 1; st.term = CC_NO_CONVERGENCE; }
   st.step_valid = 0;
   st.cand_pending = 0;
+}
+
+__device__ inline void lm_decide(LmCtl& st, const LmOpts& o, cc_iteration* e,
+                                 double cand_cost, double q_model, double step2, double xnorm2_cand) {
+  const LmTrial t = lm_trial(st, o, cand_cost, q_model, step2);
+  lm_apply(st, o, e, t, xnorm2_cand);
 }
 
 // Second half of FinalizeIterationAndCheckIfMinimizerCanContinue, run by the solve step once the gradient
