@@ -387,20 +387,19 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
   __syncthreads();
   const double g = (s_blk[tid] + s_blk[256 + tid]) + (s_blk[512 + tid] + s_blk[768 + tid]);
   P.blocks[(((size_t)dst * P.F + f) * T + tile) * 256 + tid] = g;
-  double* G = s_blk + 1024;  // full block for the few threads that derive per-frame scalars
-  G[tid] = g;
-  __syncthreads();
   SW_MARK(6);
-  if (tid == 0) {   // per-tile statistics row; the per-frame quantities ride on tile 0
+  // per-tile statistics row (the per-frame quantities ride on tile 0): written by the thread that holds entry (15, 15)
+  // = sum r^2 of the block, no third barrier and no LDS copy of the block
+  if (tid == 255) {
     double* st = P.stats + (size_t)blockIdx.x * kStatsCols;
-    st[ST_COST] = 0.5 * G[255];
+    st[ST_COST] = 0.5 * g;
     st[ST_QMODEL] = (sm[170] + sm[171]) + (sm[172] + sm[173]);
     st[ST_STEP2] = tile == 0 ? sm[158] : 0.0;
     st[ST_XNORM2] = tile == 0 ? sm[159] : 0.0;
   }
-  // initial evaluation: diagonal of the shared block for its Jacobi scale (the pose blocks' scale needs the sum
-  // over the tiles: the first elimination derives it, k_intr_decide_elim)
-  if (phase == 0 && tid >= 16 && tid < 25) P.hd0[(size_t)blockIdx.x * 16 + (tid - 16)] = G[(tid - 16) * 17];
+  // initial evaluation: diagonal of the shared block for its Jacobi scale, by the threads that hold it (the pose
+  // blocks' scale needs the sum over the tiles: the first elimination derives it, k_intr_decide_elim)
+  if (phase == 0 && tid < 9 * 17 && tid % 17 == 0) P.hd0[(size_t)blockIdx.x * 16 + tid / 17] = g;
   SW_MARK(7);
 }
 
