@@ -78,8 +78,12 @@ def test_rig_huber_off_equals_l2():
     _assert_same(g, o)
 
 
-def test_rig_ragged_visibility_unobserved_camera_and_empty_frame():
-    sc = po.rig_scenario(3, 20, 6)
+@pytest.mark.parametrize("waves,pts", [(None, 6), (1, 90), (2, 90), (4, 90)])
+def test_rig_ragged_visibility_unobserved_camera_and_empty_frame(monkeypatch, waves, pts):
+    """(with the sweep's workgroup size forced: groups of ragged size, more than one 64-observation chunk)"""
+    if waves is not None:
+        monkeypatch.setenv("CC_RIG_SWEEP_WG_WAVES", str(waves))
+    sc = po.rig_scenario(3, 20, pts)
     rng = np.random.default_rng(0)
     keep = (sc["obs_cam"] != 2) & (rng.uniform(size=len(sc["obs_cam"])) > 0.3)   # camera 2 sees nothing; random drop-outs
     off0 = sc["frame_offsets"]
