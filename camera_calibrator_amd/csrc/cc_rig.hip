@@ -64,6 +64,8 @@ struct RigDev {
   const float* uv;        // [N] float2, (frame, camera)-sorted
   const int32_t* widx;    // [N] world point index
   const float* wxyz;      // [3P]
+  const float* oxyz;      // [3N] world point of every observation (wxyz gathered once at creation: the sweep's prefetch is one
+                          //      independent load per observation instead of an index -> point chain)
   const int64_t* goff;    // [NG+1] observation range of each group
   const int32_t* gframe;  // [NG]
   const int32_t* gcam;    // [NG]
@@ -332,8 +334,7 @@ __global__ __launch_bounds__(NW * 64, HK ? 3 : CC_RIG_SWEEP_WAVES) void k_rig_sw
     const int64_t idx = s0 + otid;
     const int64_t ic = idx < s1 ? idx : s0;
     nm = uv2[ic];
-    const int64_t w = P.widx[ic];
-    nX0 = P.wxyz[w * 3]; nX1 = P.wxyz[w * 3 + 1]; nX2 = P.wxyz[w * 3 + 2];
+    nX0 = P.oxyz[ic * 3]; nX1 = P.oxyz[ic * 3 + 1]; nX2 = P.oxyz[ic * 3 + 2];
   }
   // sm[0..31] camera record, sm[32..63] frame record, sm[64..95] intrinsics record (candidate, step)
   if (tid < 32) sm[tid] = P.camrec[c * 32 + tid];
@@ -399,8 +400,7 @@ __global__ __launch_bounds__(NW * 64, HK ? 3 : CC_RIG_SWEEP_WAVES) void k_rig_sw
       const int64_t idn = idx + NT;
       const int64_t ic = idn < s1 ? idn : s0;
       nm = uv2[ic];
-      const int64_t w = P.widx[ic];
-      nX0 = P.wxyz[w * 3]; nX1 = P.wxyz[w * 3 + 1]; nX2 = P.wxyz[w * 3 + 2];
+      nX0 = P.oxyz[ic * 3]; nX1 = P.oxyz[ic * 3 + 1]; nX2 = P.oxyz[ic * 3 + 2];
     }
     RigObs o;
     rig_common(Rf, tf, Rc, tc, (double)X0, (double)X1, (double)X2, (double)m.x, (double)m.y, o);
@@ -1801,6 +1801,14 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P) {
 #endif
 }
 
+// creation: world point of every observation
+__global__ void k_rig_expand_xyz(int64_t n, const int32_t* widx, const float* wxyz, float* oxyz) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t w = widx[i];
+  oxyz[i * 3] = wxyz[w * 3]; oxyz[i * 3 + 1] = wxyz[w * 3 + 1]; oxyz[i * 3 + 2] = wxyz[w * 3 + 2];
+}
+
 // per-observation robustified cost at the accepted point (extrinsics_calibrator.cpp:219-225)
 __global__ void k_rig_obs_cost(RigDev P, int cur, double* out /*sorted order*/) {
   const int64_t g = blockIdx.x;
@@ -2255,6 +2263,11 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
     if (int rc = dev_alloc(h, &w, (size_t)n_world * 3)) return rc;
     if (n_world > 0) CC_HIP(hipMemcpy(w, world_xyz, (size_t)n_world * 3 * sizeof(float), hipMemcpyHostToDevice));
     d.wxyz = w;
+    float* ox = nullptr;
+    if (int rc = dev_alloc(h, &ox, (size_t)N * 3)) return rc;
+    hipLaunchKernelGGL(k_rig_expand_xyz, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, N, d.widx, d.wxyz, ox);
+    CC_HIP(hipGetLastError());
+    d.oxyz = ox;
   }
   if (int rc = dev_upload(h, &d.goff, goff)) return rc;
   if (int rc = dev_upload(h, &d.gframe, gframe)) return rc;
