@@ -1515,7 +1515,9 @@ __device__ void rig_solve_block(const RigDev& P, double* smem) {
   if (tid == 0) {
     LmCtl c = s_c;
     const double gmax = fmax(fmax(s4[0], s4[1]), fmax(s4[2], s4[3]));
-    if (c.log_len > 0 && c.log_len <= P.log_cap && P.log[c.log_len - 1].accepted) P.log[c.log_len - 1].gradient_max_norm = gmax;
+    // (stored whether or not the step was accepted: after a rejected step the accepted point, hence its gradient and this
+    // very value, is unchanged -- testing the record's `accepted` flag first was a global load on the solving block's path)
+    if (c.log_len > 0 && c.log_len <= P.log_cap) P.log[c.log_len - 1].gradient_max_norm = gmax;
     if (s_ok == 0) { c.done = 1; c.term = CC_FAILURE_EXCHANGE; }
     else if (lm_finalize(c, o, gmax)) s_go = 1;
     if (fail > 0.0) s_cholok = 0;
