@@ -206,6 +206,15 @@ def test_rig_many_cameras_only_optimised_ones_cost_columns():
     _assert_same(g, o)
 
 
+def test_rig_twenty_two_cameras_take_the_large_elimination_variant():
+    """22 observed cameras (21 optimised: 126 shared coordinates, the limit is 127) carry 594 direct-sum entries, more
+    than the small-register variant of the elimination holds: the variant with LDS accumulators runs (cc_rig.hip,
+    k_rig_elim<HK, 24>), the factorisation works on two rows per lane (S > 64)."""
+    sc = po.rig_scenario(22, 24, 10)
+    g, o = _both(sc, 22)
+    _assert_same(g, o)
+
+
 def test_rig_too_many_optimised_cameras_is_an_error_not_a_wrong_answer():
     sc = po.rig_scenario(23, 4, 3)     # 22 optimised cameras = 132 shared coordinates > 127
     with pytest.raises(capi.CcError, match="at most 127"):
