@@ -219,6 +219,17 @@ class IntrinsicsProblem:
         _check(lib().cc_intrinsics_solve(self._h, C.byref(opt), C.byref(s)))
         return _summary_dict(s, log)
 
+    def solve_lean(self, options):
+        """cc_intrinsics_solve without a log and without building the Python summary (timing loops: the dictionary
+        costs more host time per solve than the C call's own overhead). Returns the iteration count."""
+        s = getattr(self, "_lean_summary", None)
+        if s is None:
+            s = self._lean_summary = Summary()
+            s.log = None
+            s.log_capacity = 0
+        _check(lib().cc_intrinsics_solve(self._h, C.byref(options), C.byref(s)))
+        return s.iterations
+
     def profile_sweep(self, n=50):
         ms = C.c_double()
         _check(lib().cc_intrinsics_profile_sweep(self._h, C.c_int32(n), C.byref(ms)))
