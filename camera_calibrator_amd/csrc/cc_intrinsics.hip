@@ -224,11 +224,8 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
     else src = P.ss;   // (threads without a slot: any readable word)
     gv = *src;
   }
-  // previous Gram block of the frame (model-cost term): sum of its tiles. When the grid is one residency round
-  // (<= 1024 workgroups) BOTH ping-pong buffers are fetched in the gather round trip, because waiting for the control
-  // block first would put a dependent round trip on every workgroup's critical path; with more workgroups than
-  // slots that latency hides behind the other workgroups of the CU and the second 2 KB per frame are pure waste
-  // (flags bit 2, set by the host): only the current buffer is fetched, after the control block.
+  // previous Gram block of the frame (model-cost term): sum of its tiles, from the current buffer (flags bit 2; without it
+  // both ping-pong buffers are fetched and the right one is picked later: round 1's form, kept for A/B)
   double g_old0 = 0.0, g_old1 = 0.0;
   if (tile == 0) {
     if (T == 1) {   // (straight line: no loop-carried sum, so no wait here)
@@ -1169,7 +1166,12 @@ struct Probe {  // optional hipEvent bracket around one launch
 
 static void launch_sweep(cc_intrinsics* h, bool profile, int flags = 0) {
   Probe p(h, CC_K_SWEEP, profile);
-  if (h->F * h->d.T > 1024) flags |= 4;   // more workgroups than residency slots: fetch only the current Gram buffer
+  // Only the CURRENT Gram buffer of a frame is fetched for the model-cost term (flag bit 2). Round 1 fetched both ping-pong
+  // buffers so as not to wait for the control block; with the control block read by scalar loads at the top of the kernel
+  // the index is there when the gather is issued: A/B at 1000 x 500, sweep 17.41 vs 17.42 us, iteration 42.50 vs 42.41 us,
+  // and 2 KB per frame less traffic. CC_SWEEP_SINGLE_BUFFER=0 brings the double fetch back for that A/B.
+  static const bool both_env = [] { const char* e = getenv("CC_SWEEP_SINGLE_BUFFER"); return e && atoi(e) == 0; }();
+  if (!both_env || h->F * h->d.T > 1024) flags |= 4;
   hipLaunchKernelGGL(k_intr_sweep, dim3((unsigned)(h->F * h->d.T)), dim3(kSweepThreads), kSweepLdsBytes, h->stream, h->d, flags);
 }
 
