@@ -286,6 +286,27 @@ def intrinsics_optimize(frame_offsets, uv, xyz, intr, q, t, const_mask=0, option
     return intr, q, t, _summary_dict(s, log)
 
 
+def intrinsics_estimate(frame_offsets, uv, xyz, distortion5=None, const_mask=0, options=None, device=0, log_capacity=1024):
+    """cc_intrinsics_estimate (= Calibrator::Estimate: Zhang initialisation + solve, one upload).
+    Returns (K_init float32 3x3, intr, q, t, summary)."""
+    off = np.ascontiguousarray(frame_offsets, dtype=np.int64)
+    F = len(off) - 1
+    uv, xyz = _f32(uv), _f32(xyz)
+    opt = options if options is not None else default_options()
+    log = (Iteration * max(1, log_capacity))()
+    s = Summary()
+    s.log = C.cast(log, C.POINTER(Iteration))
+    s.log_capacity = log_capacity
+    K = np.zeros(9, dtype=np.float32)
+    intr, q, t = np.zeros(9), np.zeros((F, 4)), np.zeros((F, 3))
+    d5 = _f64(distortion5) if distortion5 is not None else None
+    _check(lib().cc_intrinsics_estimate(C.byref(opt), C.c_int32(device), C.c_int64(F), _p(off, C.c_int64), _p(uv, C.c_float),
+                                        _p(xyz, C.c_float), _p(d5, C.c_double) if d5 is not None else None,
+                                        C.c_uint32(const_mask), _p(K, C.c_float), _p(intr, C.c_double), _p(q, C.c_double),
+                                        _p(t, C.c_double), C.byref(s)))
+    return K.reshape(3, 3), intr, q, t, _summary_dict(s, log)
+
+
 HUBER_A = float(np.float32(3.0) / np.float32(500.0))  # extrinsics_calibrator.cpp:176
 
 

@@ -38,6 +38,35 @@ void Calibrator::Estimate(const std::vector<Points2D>& pixels_per_view, const st
     }
   }
   float K9[9];
+  if (devices_.size() <= 1) {
+    // one device: the fused entry point (one upload of the observations for initialisation and solve together);
+    // same numbers as the two calls below exchange through camera_matrix_ and the float poses
+    double intr[kNumIntrinsics], dist5[5];
+    for (int i = 0; i < 5; ++i) dist5[i] = distortion_(i);
+    uint32_t frozen = 0;
+    for (int idx : frozen_intrinsics_)
+      if (idx >= 0 && idx < kNumIntrinsics) frozen |= 1u << idx;
+    std::vector<double> qd(4 * n_img), td(3 * n_img);
+    cc_options options;
+    cc_options_init(&options);  // non-monotonic steps, 100 iterations: calibrator.cpp:314-321
+    cc_summary summary{};
+    last_status_ = cc_intrinsics_estimate(&options, device_, (int64_t)n_img, offsets.data(), uv.data(), xyz.data(), dist5, frozen,
+                                          K9, intr, qd.data(), td.data(), &summary);
+    if (last_status_ != 0) throw std::runtime_error(std::string("Calibrator::Estimate: ") + cc_last_error());
+    last_iterations_ = summary.iterations;
+    last_final_cost_ = summary.final_cost;
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) camera_matrix_(r, c) = K9[r * 3 + c];
+    camera_matrix_(0, 0) = static_cast<float>(intr[FX]);
+    camera_matrix_(1, 1) = static_cast<float>(intr[FY]);
+    camera_matrix_(0, 2) = static_cast<float>(intr[PX]);
+    camera_matrix_(1, 2) = static_cast<float>(intr[PY]);
+    distortion_(0) = static_cast<float>(intr[K1]);
+    distortion_(1) = static_cast<float>(intr[K2]);
+    distortion_(2) = static_cast<float>(intr[P1]);
+    distortion_(3) = static_cast<float>(intr[P2]);
+    distortion_(4) = static_cast<float>(intr[K3]);
+    return;
+  }
   std::vector<float> q(4 * n_img), t(3 * n_img);
   const int rc = cc_zhang_init(device_, (int64_t)n_img, offsets.data(), uv.data(), xyz.data(), K9, q.data(), t.data(), nullptr);
   if (rc != 0) throw std::runtime_error(std::string("Calibrator::Estimate: ") + cc_last_error());

@@ -34,6 +34,8 @@ int select_device(int device);
 // until the process ends.
 void* pinned_block_get();
 void pinned_block_put(void* p);
+int zhang_on_device(hipStream_t stream, int64_t F, const int64_t* doff, const float* duv, const float* dxyz,
+                    double* dgram, float* dH, float* dK, float* dq, float* dt);   // cc_zhang.hip
 int stream_get(int device, hipStream_t* out);
 void stream_put(int device, hipStream_t s);
 // One reusable scratch buffer per device for the point kernels (Distort / Undistort are called once per frame by the

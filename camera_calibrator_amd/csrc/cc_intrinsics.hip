@@ -1852,6 +1852,55 @@ int cc_intrinsics_optimize(const cc_options* opt, int32_t device, int64_t F, con
   return rc;
 }
 
+// Calibrator::Estimate in ONE call: the observations are uploaded once, Zhang's closed-form initialisation
+// (calibrator.cpp:47-66) runs on the handle's own device arrays, its K and poses -- rounded to float exactly as the
+// two-step path cc_zhang_init -> cc_intrinsics_optimize hands them over -- start the solve. Same results as the two
+// calls, one 20-byte-per-observation upload, one allocation and one pair of host packing loops less.
+int cc_intrinsics_estimate(const cc_options* opt, int32_t device, int64_t F, const int64_t* off, const float* uv,
+                           const float* xyz, const double* distortion5, uint32_t mask, float* K_init9, double* intr9,
+                           double* q, double* t, cc_summary* summary) {
+  using namespace cc;
+  if (F < 3 || !off || !uv || !xyz || !intr9 || !q || !t)
+    return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_estimate: needs >= 3 frames and non-NULL arrays");
+  for (int64_t f = 0; f < F; ++f)
+    if (off[f + 1] - off[f] < 4) return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_estimate: frame %lld has fewer than 4 points", (long long)f);
+  cc_intrinsics* h = nullptr;
+  int rc = cc_intrinsics_create(device, F, off, uv, xyz, &h);
+  if (rc) return rc;
+  struct Guard { cc_intrinsics* h; void* scratch; ~Guard() { if (scratch) hipFree(scratch); cc_intrinsics_destroy(h); } } guard{h, nullptr};
+  // scratch of the initialisation: gram double[F][256] | H float[9F] | K float[9] | q float[4F] | t float[3F]
+  size_t cursor = 0;
+  auto take = [&](size_t bytes) { const size_t at = cursor; cursor += (bytes + 255) & ~(size_t)255; return at; };
+  const size_t o_gram = take((size_t)F * 256 * sizeof(double)), o_H = take((size_t)F * 9 * sizeof(float)), o_K = take(9 * sizeof(float));
+  const size_t o_q = take((size_t)F * 4 * sizeof(float)), o_t = take((size_t)F * 3 * sizeof(float));
+  CC_HIP(hipMalloc(&guard.scratch, cursor));
+  char* sc = static_cast<char*>(guard.scratch);
+  float* dK = reinterpret_cast<float*>(sc + o_K);
+  float* dq = reinterpret_cast<float*>(sc + o_q);
+  float* dt = reinterpret_cast<float*>(sc + o_t);
+  if ((rc = zhang_on_device(h->stream, F, h->d.off, h->d.uv, h->d.xyz, reinterpret_cast<double*>(sc + o_gram),
+                            reinterpret_cast<float*>(sc + o_H), dK, dq, dt)))
+    return rc;
+  float K9[9];
+  std::vector<float> qf((size_t)F * 4), tf((size_t)F * 3);
+  CC_HIP(hipMemcpyAsync(K9, dK, sizeof(K9), hipMemcpyDeviceToHost, h->stream));
+  CC_HIP(hipMemcpyAsync(qf.data(), dq, qf.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  CC_HIP(hipMemcpyAsync(tf.data(), dt, tf.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  CC_HIP(hipStreamSynchronize(h->stream));
+  if (K_init9) std::memcpy(K_init9, K9, sizeof(K9));
+  // intrinsics order fx fy px py k1 k2 p1 p2 k3 (calibrator.cpp:168-179); the distortion starts from the caller's
+  intr9[0] = K9[0]; intr9[1] = K9[4]; intr9[2] = K9[2]; intr9[3] = K9[5];
+  for (int i = 0; i < 5; ++i) intr9[4 + i] = distortion5 ? distortion5[i] : 0.0;
+  for (size_t i = 0; i < qf.size(); ++i) q[i] = qf[i];
+  for (size_t i = 0; i < tf.size(); ++i) t[i] = tf[i];
+  if ((rc = cc_intrinsics_set_state(h, intr9, mask, q, t))) return rc;
+  cc_options o;
+  if (opt) o = *opt; else cc_options_init(&o);
+  o.use_graph = 0;   // one solve per handle: capturing and instantiating a graph cannot pay off
+  if ((rc = cc_intrinsics_solve(h, &o, summary))) return rc;
+  return cc_intrinsics_get_state(h, intr9, q, t);
+}
+
 int cc_intrinsics_comm_init(cc_intrinsics* h, const uint8_t id[128], int32_t rank, int32_t nranks) {
   using namespace cc;
   if (!h || !id || rank < 0 || nranks < 1 || rank >= nranks || nranks > 32)

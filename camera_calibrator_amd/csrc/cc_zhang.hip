@@ -338,6 +338,20 @@ __global__ __launch_bounds__(64) void k_zhang_poses(int64_t F, const float* Hs, 
 
 }  // namespace cc
 
+namespace cc {
+// The four kernels on arrays that are already on the device (cc_intrinsics_estimate: the handle's own copies), on
+// `stream`. Scratch: gram double[F][256], H float[9F]; outputs K float[9], q float[4F], t float[3F] (device).
+int zhang_on_device(hipStream_t stream, int64_t F, const int64_t* doff, const float* duv, const float* dxyz,
+                    double* dgram, float* dH, float* dK, float* dq, float* dt) {
+  hipLaunchKernelGGL(k_zhang_gram, dim3((unsigned)F), dim3(kZhangThreads), kZhangLdsBytes, stream, F, doff, duv, dxyz, dgram);
+  hipLaunchKernelGGL(k_zhang_eig9, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, stream, F, dgram, dH);
+  hipLaunchKernelGGL(k_zhang_k, dim3(1), dim3(256), 0, stream, F, dH, dK);
+  hipLaunchKernelGGL(k_zhang_poses, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, stream, F, dH, dK, dq, dt);
+  CC_HIP(hipGetLastError());
+  return CC_OK;
+}
+}  // namespace cc
+
 extern "C" int cc_zhang_init(int32_t device, int64_t F, const int64_t* off, const float* uv, const float* xyz,
                              float* K9, float* q_wxyz, float* t_xyz, float* homographies) {
   using namespace cc;
@@ -374,11 +388,7 @@ extern "C" int cc_zhang_init(int32_t device, int64_t F, const int64_t* off, cons
   CC_HIP(hipMemcpy(duv, uv, (size_t)N * 2 * sizeof(float), hipMemcpyHostToDevice));
   CC_HIP(hipMemcpy(dxyz, xyz, (size_t)N * 3 * sizeof(float), hipMemcpyHostToDevice));
   CC_HIP(hipMemcpy(doff, off, (size_t)(F + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_zhang_gram, dim3((unsigned)F), dim3(kZhangThreads), kZhangLdsBytes, 0, F, doff, duv, dxyz, dgram);
-  hipLaunchKernelGGL(k_zhang_eig9, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, 0, F, dgram, dH);
-  hipLaunchKernelGGL(k_zhang_k, dim3(1), dim3(256), 0, 0, F, dH, dK);
-  hipLaunchKernelGGL(k_zhang_poses, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, 0, F, dH, dK, dq, dt);
-  CC_HIP(hipGetLastError());
+  if (int rc = zhang_on_device(nullptr, F, doff, duv, dxyz, dgram, dH, dK, dq, dt)) return rc;
   CC_HIP(hipMemcpy(K9, dK, 9 * sizeof(float), hipMemcpyDeviceToHost));
   if (q_wxyz) CC_HIP(hipMemcpy(q_wxyz, dq, (size_t)F * 4 * sizeof(float), hipMemcpyDeviceToHost));
   if (t_xyz) CC_HIP(hipMemcpy(t_xyz, dt, (size_t)F * 3 * sizeof(float), hipMemcpyDeviceToHost));

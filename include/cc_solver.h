@@ -144,6 +144,16 @@ int cc_intrinsics_optimize(const cc_options* opt, int32_t device, int64_t n_fram
                            double* intr9, uint32_t const_mask, double* q_wxyz, double* t_xyz,
                            cc_summary* summary);
 
+/* Calibrator::Estimate in one call (calibrator.cpp:47-68: Zhang initialisation, then Optimize): the observations are
+ * uploaded once, cc_zhang_init's kernels run on the handle's device copies, and the solve starts from their K and poses
+ * rounded to float -- exactly what the two calls cc_zhang_init + cc_intrinsics_optimize exchange through the class
+ * members, so the results are identical. distortion5 (k1 k2 p1 p2 k3) = the object's current distortion (may be NULL:
+ * zeros); K_init9 (may be NULL) receives Zhang's K; intr9 / q_wxyz [4F] / t_xyz [3F] receive the optimised state.
+ * Needs >= 3 frames with >= 4 points each. */
+int cc_intrinsics_estimate(const cc_options* opt, int32_t device, int64_t n_frames, const int64_t* frame_offsets,
+                           const float* uv, const float* xyz, const double* distortion5, uint32_t const_mask,
+                           float* K_init9, double* intr9, double* q_wxyz, double* t_xyz, cc_summary* summary);
+
 /* Multi-GPU inside ONE process, ONE host thread (SURVEY.md 8(b) thread model): the one-shot call over several
  * devices. Frames are sharded contiguously by observation count (cc_partition_frames), one handle + stream per
  * device, the per-iteration exchange (112 + 16 doubles) goes through mailboxes in peer HBM wired inside the process

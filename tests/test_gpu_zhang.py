@@ -72,3 +72,19 @@ def test_zhang_init_rejects_bad_input():
     off, uv, xyz = po.make_intrinsics_problem(3, [10, 3, 10])
     with pytest.raises(capi.CcError):
         capi.zhang_init(off, uv, xyz)          # a homography needs >= 4 points
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frames,pts,mask", [(20, 88, 0), (200, 200, 1 << 8)])
+def test_estimate_in_one_call_equals_initialisation_plus_optimize(frames, pts, mask):
+    """cc_intrinsics_estimate (what Calibrator::Estimate calls on one device) = cc_zhang_init followed by
+    cc_intrinsics_optimize from its float K and poses: same bits, one upload."""
+    off, uv, xyz = capi.make_intrinsics_problem(frames, pts)
+    K0, q0, t0 = capi.zhang_init(off, uv, xyz)
+    intr0 = np.array([K0[0, 0], K0[1, 1], K0[0, 2], K0[1, 2], 0, 0, 0, 0, 0], dtype=np.float64)
+    i2, q2, t2, s2 = capi.intrinsics_optimize(off, uv, xyz, intr0, q0.astype(np.float64), t0.astype(np.float64), const_mask=mask)
+    K1, i1, q1, t1, s1 = capi.intrinsics_estimate(off, uv, xyz, const_mask=mask)
+    assert np.array_equal(K1, K0)
+    assert s1["iterations"] == s2["iterations"] and s1["termination"] == s2["termination"]
+    assert np.array_equal(i1, i2) and np.array_equal(q1, q2) and np.array_equal(t1, t2)
+    assert s1["final_cost"] == s2["final_cost"]
