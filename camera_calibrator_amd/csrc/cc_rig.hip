@@ -499,6 +499,218 @@ __global__ __launch_bounds__(NW * 64, HK ? 3 : CC_RIG_SWEEP_WAVES) void k_rig_sw
 }
 
 // ---------------------------------------------------------------------------------------------
+// sweep of the reference's problem (poses only) WITHOUT the matrix pipe. Inside a (frame, camera) group both poses are
+// constants, and every row's frame columns are one 6 x 6 matrix applied to its camera columns (rig_row):
+//     J_frame = J_cam * M,   M = | Rc            0  |   rows: camera (rotation, translation), columns: frame,
+//                                | 2 [Rc_i x tf] Rc |   Rc_i = i-th row of the camera rotation, tf = frame translation
+// (m = Rc^T B and b x m = Rc^T (a x B) - tf x m, a = Rc (b + tf)). So a group needs the Gram of SEVEN columns
+// [J_cam(6) r], 28 unique numbers accumulated by each lane on its own observations with plain FMAs (21 per row: the
+// normalised-image rows have one structural zero each) -- against 2 x 16 matrix instructions of 64 cycles per 64
+// observations for the 16 x 16 product, half of which is the redundant triangle and a quarter padding. The block
+// the other kernels read (same 16 x 16 layout [cam frame r]) is assembled once per group: CF = CC M, FF = M^T CC M,
+// g_f = M^T g_c. A fixed camera zeroes its own blocks AFTER the frame blocks were derived from them.
+// Rounding differs from the 13-column product by O(eps (|a| / |b|)^2) in the frame-rotation block (a: point relative to
+// the camera pose's origin, b: rotated world point).
+// ---------------------------------------------------------------------------------------------
+template <int SKIP>
+__device__ __forceinline__ void adj_accumulate(const double* w, double* acc) {
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      if (i != SKIP && j != SKIP) acc[i * (i + 1) / 2 + j] = fma(w[i], w[j], acc[i * (i + 1) / 2 + j]);
+    }
+  }
+}
+
+// 32 per-lane values -> their sums over a half wave, value e left in lanes e and e + 32: each exchange halves the values
+// a lane carries (31 exchanges and adds instead of 32 x 5)
+template <int N>
+__device__ __forceinline__ void reduce_scatter_step(double* p, int lane) {
+  const bool up = (lane & N) != 0;     // N = lane distance of this step = number of values kept
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const double lo = p[i], hi = p[i + N];
+    const double send = up ? lo : hi, keep = up ? hi : lo;
+    p[i] = keep + __shfl_xor(send, N, 64);
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 4) void k_rig_sweep_adj(RigDev P) {
+  constexpr int NT = NW * 64;      // threads
+  constexpr int EPT = 256 / NT;    // block entries per thread
+  __shared__ double sm[64];            // camera record [0..31], frame record [32..63]
+  __shared__ double s_red[NW * 32];    // per wave: 28 Gram sums, cost, model-cost term
+  __shared__ double s_g[32];           // their totals
+  __shared__ double s_m[36], s_t[42];  // M; CC M (36) and M^T g_c (6)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t g = blockIdx.x;
+  RSW_MARK(0);
+  const int f = P.gframe[g], c = P.gcam[g];
+  const int64_t s0 = P.goff[g], s1 = P.goff[g + 1];
+  const LmCtl* ctl = P.ctl;
+  const int done = ctl->done, phase = ctl->phase, step_valid = ctl->step_valid, cur = ctl->cur;
+  if (done) return;
+  if (phase != 0 && !step_valid) return;
+  const int dst = phase == 0 ? cur : (cur ^ 1);
+  const bool fixed = P.cam_fixed[c] != 0;
+  // chunks dealt to the waves starting at wave (g mod NW), observations fetched one pass ahead by unconditional loads:
+  // see k_rig_sweep
+  const int otid = (((tid >> 6) - (int)(g & (NW - 1))) & (NW - 1)) * 64 + lane;
+  const int64_t wrem = s1 - s0 - (otid >> 6) * 64;
+  const int npass = wrem > 0 ? (int)((wrem + NT - 1) / NT) : 0;
+  const float2* uv2 = reinterpret_cast<const float2*>(P.uv);
+  float2 nm;
+  float nX0, nX1, nX2;
+  {
+    const int64_t idx = s0 + otid;
+    const int64_t ic = idx < s1 ? idx : s0;
+    nm = uv2[ic];
+    nX0 = P.oxyz[ic * 3]; nX1 = P.oxyz[ic * 3 + 1]; nX2 = P.oxyz[ic * 3 + 2];
+  }
+  if (tid < 32) sm[tid] = P.camrec[c * 32 + tid];
+  else if (tid < 64) sm[tid] = P.frec[(size_t)f * 32 + (tid - 32)];
+  const size_t gs = (size_t)P.gstride;
+  double g_old[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) g_old[e] = 0.0;
+  if (phase != 0) {
+    const double* old = P.gblocks + ((size_t)cur * P.NG + g) * gs;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) g_old[e] = old[tid + e * NT];
+  }
+  __syncthreads();
+  RSW_MARK(1);
+  double acc[32];
+#pragma unroll
+  for (int e = 0; e < 32; ++e) acc[e] = 0.0;
+  // model-cost term of the group: d = [dc(6) df(6)], q = d^T g + 1/2 d^T H d over its block (value 29)
+  if (phase != 0) {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int a = (tid + e * NT) >> 4, b = tid & 15;
+      const double da = a < 6 ? sm[12 + a] : (a < 12 ? sm[32 + 12 + (a - 6)] : 0.0);
+      if (a < 12) {
+        if (b < 12) {
+          const double db = b < 6 ? sm[12 + b] : sm[32 + 12 + (b - 6)];
+          acc[29] += 0.5 * da * g_old[e] * db;
+        } else if (b == 12) {
+          acc[29] += da * g_old[e];
+        }
+      }
+    }
+  }
+  double Rc[9], tc[3], Rf[9], tf[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { Rc[i] = rfl(sm[i]); Rf[i] = rfl(sm[32 + i]); }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { tc[i] = rfl(sm[9 + i]); tf[i] = rfl(sm[32 + 9 + i]); }
+  if (tid < 36) {
+    const int a = tid / 6, b = tid % 6;
+    double v = 0.0;
+    if ((a < 3) == (b < 3)) {
+      v = sm[3 * (a % 3) + (b % 3)];
+    } else if (a >= 3) {   // 2 (Rc_i x tf)_b
+      const int i = a - 3, b1 = (b + 1) % 3, b2 = (b + 2) % 3;
+      v = 2.0 * (sm[3 * i + b1] * sm[32 + 9 + b2] - sm[3 * i + b2] * sm[32 + 9 + b1]);
+    }
+    s_m[tid] = v;
+  }
+  const double ha = P.huber_a;
+  RSW_MARK(2);
+  for (int p = 0; p < npass; ++p) {
+    const int64_t idx = s0 + (int64_t)p * NT + otid;
+    const bool valid = idx < s1;
+    const float2 m = nm;
+    const float X0 = nX0, X1 = nX1, X2 = nX2;
+    {
+      const int64_t idn = idx + NT;
+      const int64_t ic = idn < s1 ? idn : s0;
+      nm = uv2[ic];
+      nX0 = P.oxyz[ic * 3]; nX1 = P.oxyz[ic * 3 + 1]; nX2 = P.oxyz[ic * 3 + 2];
+    }
+    RigObs o;
+    rig_common(Rf, tf, Rc, tc, (double)X0, (double)X1, (double)X2, (double)m.x, (double)m.y, o);
+    double rho, sr;
+    huber(ha, o.ru * o.ru + o.rv * o.rv, rho, sr);
+    if (valid) acc[28] += 0.5 * rho;
+    if (!valid) sr = 0.0;
+    // rows as rig_row forms them, camera columns and residual only; B_u = (iz, 0, -x iz), B_v = (0, iz, -y iz)
+    const double Bu0 = o.iz, Bu2 = -o.x * o.iz, Bv1 = o.iz, Bv2 = -o.y * o.iz;
+    double w[7];
+    w[0] = sr * (2.0 * (Bu2 * o.a1)); w[1] = sr * (2.0 * (Bu0 * o.a2 - Bu2 * o.a0)); w[2] = sr * (2.0 * (-(Bu0 * o.a1)));
+    w[3] = sr * Bu0; w[4] = 0.0; w[5] = sr * Bu2; w[6] = sr * o.ru;
+    adj_accumulate<4>(w, acc);
+    w[0] = sr * (2.0 * (Bv2 * o.a1 - Bv1 * o.a2)); w[1] = sr * (2.0 * (-(Bv2 * o.a0))); w[2] = sr * (2.0 * (Bv1 * o.a0));
+    w[3] = 0.0; w[4] = sr * Bv1; w[5] = sr * Bv2; w[6] = sr * o.rv;
+    adj_accumulate<3>(w, acc);
+    if (p == 0) RSW_MARK(3);
+  }
+  RSW_MARK(4);
+  reduce_scatter_step<16>(acc, lane);   // bit 4 of the lane picks the upper sixteen values,
+  reduce_scatter_step<8>(acc, lane);    // bit 3 the upper eight of those, ...: lane l ends up with value l & 31
+  reduce_scatter_step<4>(acc, lane);
+  reduce_scatter_step<2>(acc, lane);
+  reduce_scatter_step<1>(acc, lane);
+  acc[0] += __shfl_xor(acc[0], 32, 64);
+  if (lane < 32) s_red[wave * 32 + lane] = acc[0];
+  __syncthreads();
+  if (tid < 32) {
+    double t = s_red[tid];
+#pragma unroll
+    for (int w2 = 1; w2 < NW; ++w2) t += s_red[w2 * 32 + tid];
+    s_g[tid] = t;
+  }
+  __syncthreads();
+  // CC M and M^T g_c; CC[i][b] = s_g[tri(max, min)], g_c[a] = s_g[tri(6, a)]
+  if (tid < 42) {
+    double v = 0.0;
+    if (tid < 36) {
+      const int i = tid / 6, j = tid % 6;
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        const int hi = i > b ? i : b, lo = i > b ? b : i;
+        v = fma(s_g[hi * (hi + 1) / 2 + lo], s_m[b * 6 + j], v);
+      }
+    } else {
+      const int j = tid - 36;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) v = fma(s_m[a * 6 + j], s_g[21 + a], v);
+    }
+    s_t[tid] = v;
+  }
+  __syncthreads();
+  double* out = P.gblocks + ((size_t)dst * P.NG + g) * gs;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int t = tid + e * NT;
+    const int ti = t >> 4, tj = t & 15;
+    const int i = ti > tj ? ti : tj, j = ti > tj ? tj : ti;     // i >= j: both triangles get the same number
+    double gv = 0.0;
+    if (i < 6) {
+      gv = fixed ? 0.0 : s_g[i * (i + 1) / 2 + j];
+    } else if (i < 12) {
+      if (j < 6) {
+        gv = fixed ? 0.0 : s_t[j * 6 + (i - 6)];
+      } else {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) gv = fma(s_m[a * 6 + (i - 6)], s_t[a * 6 + (j - 6)], gv);
+      }
+    } else if (i == 12) {
+      gv = j < 6 ? (fixed ? 0.0 : s_g[21 + j]) : (j < 12 ? s_t[36 + (j - 6)] : s_g[27]);
+    }
+    out[t] = gv;
+    if (phase == 0 && ti < 6 && tj == ti) P.ghd0[g * 8 + ti] = gv;  // diag of H_cc
+  }
+  if (tid == 0) {
+    P.gstats[g * 2] = s_g[28];
+    P.gstats[g * 2 + 1] = s_g[29];
+  }
+  RSW_MARK(5);
+}
+
+// ---------------------------------------------------------------------------------------------
 // update: per frame, back-substitute the pose step and form the candidate pose. 16 lanes/frame, 16 frames per
 // 256-thread block (`fblk` = which sixteen). SC1: the shared step `ds` was written by another workgroup of the
 // SAME launch (fused into k_rig_reduce): read it with sc1 loads.
@@ -1859,6 +2071,7 @@ struct cc_rig {
   int64_t C = 0, F = 0, N = 0, NG = 0, P = 0;
   int n_runs = 0;            // runs of shared columns (one per optimised camera, one per intrinsics set): blocks of k_rig_init
   int sweep_waves = 4;       // waves per workgroup of the poses-only sweep (2: small groups that outnumber the slots)
+  bool sweep_adjoint = true; // poses-only sweep: 7-column Gram + per-group assembly (k_rig_sweep_adj); CC_RIG_SWEEP_MFMA=1: the 13-column matrix-pipe sweep
   int kmode = 0;
   std::vector<int64_t> perm;  // sorted position -> caller's observation index
   std::vector<void*> allocs;    // the chunks dev_alloc carves buffers from
@@ -2114,6 +2327,9 @@ static int rig_enqueue_round(cc_rig* h, bool initial, bool profile) {
   const RigDev& d = h->d;
   { RigProbe p(h, CC_K_SWEEP, profile);
     if (d.kmode) hipLaunchKernelGGL((k_rig_sweep<true, 4>), dim3((unsigned)h->NG), dim3(kRigThreads), kRigSweepLdsBytesK, h->stream, d);
+    else if (h->sweep_adjoint && h->sweep_waves == 4) hipLaunchKernelGGL((k_rig_sweep_adj<4>), dim3((unsigned)h->NG), dim3(256), 0, h->stream, d);
+    else if (h->sweep_adjoint && h->sweep_waves == 2) hipLaunchKernelGGL((k_rig_sweep_adj<2>), dim3((unsigned)h->NG), dim3(128), 0, h->stream, d);
+    else if (h->sweep_adjoint) hipLaunchKernelGGL((k_rig_sweep_adj<1>), dim3((unsigned)h->NG), dim3(64), 0, h->stream, d);
     else if (h->sweep_waves == 2) hipLaunchKernelGGL((k_rig_sweep<false, 2>), dim3((unsigned)h->NG), dim3(128), kRigSweepLdsBytes2, h->stream, d);
     else if (h->sweep_waves == 1) hipLaunchKernelGGL((k_rig_sweep<false, 1>), dim3((unsigned)h->NG), dim3(64), kRigSweepLdsBytes1, h->stream, d);
     else hipLaunchKernelGGL((k_rig_sweep<false, 4>), dim3((unsigned)h->NG), dim3(kRigThreads), kRigSweepLdsBytes, h->stream, d); }
@@ -2292,6 +2508,7 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
     // two when they at least fill a quarter of them, four otherwise. CC_RIG_SWEEP_WG_WAVES forces one (A/B, tests).
     const double per_group = NG > 0 ? (double)N / (double)NG : 0.0;
     h->sweep_waves = kmode ? 4 : ((NG >= 4096 || per_group <= 64.0) ? 1 : (NG >= 1024 ? 2 : 4));
+    if (const char* e = getenv("CC_RIG_SWEEP_MFMA")) h->sweep_adjoint = atoi(e) == 0;
     if (const char* e = getenv("CC_RIG_SWEEP_WG_WAVES")) { const int v = atoi(e); if (!kmode && (v == 1 || v == 2 || v == 4)) h->sweep_waves = v; }
   }
   if (int rc = dev_zeroed(h, &d.intr, 2 * CKn * 16)) return rc;
