@@ -101,6 +101,7 @@ struct RigDev {
   double* gstats;   // [NG][2] cost, model term
   double* fstats;   // [F][2] step^2, |x|^2
   double* ghd0;     // [NG][8] diag of H_cc at the initial point
+  double* gcomp;    // [2][NG][64] (poses-only sweep k_rig_sweep_adj) per group and buffer: 7-column Gram (28), M (36)
   double* sp;       // [F][8]
   double* ss;       // [128]
   double* ds;       // [128] scaled shared step
@@ -512,6 +513,11 @@ __global__ __launch_bounds__(NW * 64, HK ? 3 : CC_RIG_SWEEP_WAVES) void k_rig_sw
 // Rounding differs from the 13-column product by O(eps (|a| / |b|)^2) in the frame-rotation block (a: point relative to
 // the camera pose's origin, b: rotated world point).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void untri(int idx, int& i, int& j) {  // packed lower index -> (i >= j)
+  i = 0;
+  while (tri(i + 1, 0) <= idx) ++i;
+  j = idx - tri(i, 0);
+}
 template <int SKIP>
 __device__ __forceinline__ void adj_accumulate(const double* w, double* acc) {
 #pragma unroll
@@ -523,27 +529,69 @@ __device__ __forceinline__ void adj_accumulate(const double* w, double* acc) {
   }
 }
 
-// 32 per-lane values -> their sums over a half wave, value e left in lanes e and e + 32: each exchange halves the values
-// a lane carries (31 exchanges and adds instead of 32 x 5)
+// 32 per-lane values -> their 64-lane sums, value e left in lanes 2e and 2e + 1. Each exchange halves the values a lane
+// carries (31 exchanges and adds instead of 32 x 6), and none of them goes through the LDS crossbar: the two widest
+// are the lane-swap instructions of gfx950 (v_permlane32_swap: lanes 32..63 of the first register <-> lanes 0..31 of the
+// second; v_permlane16_swap: odd 16-lane rows of the first <-> even rows of the second -- after either, first + second
+// is the pairwise sum of the first register's values in the lower lanes / even rows and of the second's in the others),
+// the rest DPP moves inside a row. Partner masks 32, 16, 8, 7 (half-row mirror), 2, 1 are independent, so every value
+// collects all 64 lanes; the lane bit that picks the half kept in each step (5, 4, 3, 2, 1) differs between partners and
+// all earlier ones agree.
 template <int N>
-__device__ __forceinline__ void reduce_scatter_step(double* p, int lane) {
-  const bool up = (lane & N) != 0;     // N = lane distance of this step = number of values kept
+__device__ __forceinline__ void reduce_swap32(double* p) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const auto l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(p[i]), (unsigned)__double2loint(p[i + N]), false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(p[i]), (unsigned)__double2hiint(p[i + N]), false, false);
+    p[i] = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+  }
+}
+template <int N>
+__device__ __forceinline__ void reduce_swap16(double* p) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const auto l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(p[i]), (unsigned)__double2loint(p[i + N]), false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(p[i]), (unsigned)__double2hiint(p[i + N]), false, false);
+    p[i] = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+  }
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int N, int CTRL, int BIT>
+__device__ __forceinline__ void reduce_dpp(double* p, int lane) {
+  const bool up = (lane & BIT) != 0;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     const double lo = p[i], hi = p[i + N];
     const double send = up ? lo : hi, keep = up ? hi : lo;
-    p[i] = keep + __shfl_xor(send, N, 64);
+    p[i] = keep + dpp_f64<CTRL>(send);
   }
 }
+__device__ __forceinline__ void reduce_scatter32(double* p, int lane) {
+  reduce_swap32<16>(p);
+  reduce_swap16<8>(p);
+  reduce_dpp<4, 0x128, 8>(p, lane);   // row_ror:8
+  reduce_dpp<2, 0x141, 4>(p, lane);   // row_half_mirror
+  reduce_dpp<1, 0x4E, 2>(p, lane);    // quad_perm:[2,3,0,1]
+  p[0] += dpp_f64<0xB1>(p[0]);        // quad_perm:[1,0,3,2]
+}
 
+#ifndef CC_RIG_ADJ_WAVES
+#define CC_RIG_ADJ_WAVES 4   // waves per SIMD this sweep is compiled for (A/B knob)
+#endif
 template <int NW>
-__global__ __launch_bounds__(NW * 64, 4) void k_rig_sweep_adj(RigDev P) {
+__global__ __launch_bounds__(NW * 64, CC_RIG_ADJ_WAVES) void k_rig_sweep_adj(RigDev P) {
   constexpr int NT = NW * 64;      // threads
-  constexpr int EPT = 256 / NT;    // block entries per thread
   __shared__ double sm[64];            // camera record [0..31], frame record [32..63]
+  __shared__ double s_old[64];         // the accepted point's compact record of this group (gcomp)
+  __shared__ double s_e[8];            // step of the seven columns: e = dc + M_old df, 1
   __shared__ double s_red[NW * 32];    // per wave: 28 Gram sums, cost, model-cost term
   __shared__ double s_g[32];           // their totals
-  __shared__ double s_m[36], s_t[42];  // M; CC M (36) and M^T g_c (6)
+  __shared__ double s_m[36];           // M
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t g = blockIdx.x;
   RSW_MARK(0);
@@ -569,53 +617,49 @@ __global__ __launch_bounds__(NW * 64, 4) void k_rig_sweep_adj(RigDev P) {
     nm = uv2[ic];
     nX0 = P.oxyz[ic * 3]; nX1 = P.oxyz[ic * 3 + 1]; nX2 = P.oxyz[ic * 3 + 2];
   }
-  if (tid < 32) sm[tid] = P.camrec[c * 32 + tid];
-  else if (tid < 64) sm[tid] = P.frec[(size_t)f * 32 + (tid - 32)];
-  const size_t gs = (size_t)P.gstride;
-  double g_old[EPT];
-#pragma unroll
-  for (int e = 0; e < EPT; ++e) g_old[e] = 0.0;
-  if (phase != 0) {
-    const double* old = P.gblocks + ((size_t)cur * P.NG + g) * gs;
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) g_old[e] = old[tid + e * NT];
+  if (tid < 64) {
+    // (both buffers hold valid memory: the record of `cur` is read whatever the phase, used only behind phase != 0)
+    const double rec = tid < 32 ? P.camrec[c * 32 + tid] : P.frec[(size_t)f * 32 + (tid - 32)];
+    const double old = P.gcomp[((size_t)cur * P.NG + g) * 64 + tid];
+    sm[tid] = rec;
+    s_old[tid] = old;
   }
   __syncthreads();
   RSW_MARK(1);
   double acc[32];
 #pragma unroll
   for (int e = 0; e < 32; ++e) acc[e] = 0.0;
-  // model-cost term of the group: d = [dc(6) df(6)], q = d^T g + 1/2 d^T H d over its block (value 29)
-  if (phase != 0) {
+  // the chain of both poses as one: a = Rc (Rf X + tf) = Rca X + tca (the frame columns are not formed row by row, so
+  // the rotated world point is not needed on its own). Uniform addresses: scalar loads, the values live in SGPRs.
+  double Rca[9], tca[3], tcs[3];
+  {
+    const double* cr = P.camrec + (size_t)c * 32;
+    const double* fr = P.frec + (size_t)f * 32;
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-      const int a = (tid + e * NT) >> 4, b = tid & 15;
-      const double da = a < 6 ? sm[12 + a] : (a < 12 ? sm[32 + 12 + (a - 6)] : 0.0);
-      if (a < 12) {
-        if (b < 12) {
-          const double db = b < 6 ? sm[12 + b] : sm[32 + 12 + (b - 6)];
-          acc[29] += 0.5 * da * g_old[e] * db;
-        } else if (b == 12) {
-          acc[29] += da * g_old[e];
-        }
-      }
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Rca[3 * i + j] = cr[3 * i] * fr[j] + cr[3 * i + 1] * fr[3 + j] + cr[3 * i + 2] * fr[6 + j];
+      tca[i] = cr[3 * i] * fr[9] + cr[3 * i + 1] * fr[10] + cr[3 * i + 2] * fr[11];
+      tcs[i] = cr[9 + i];
     }
   }
-  double Rc[9], tc[3], Rf[9], tf[3];
+  if (tid < 48) {   // M[a][b], a = tid >> 3, b = tid & 7 < 6
+    const int a = tid >> 3, b = tid & 7;
+    const int a3 = a < 3 ? a : a - 3, b3 = b < 3 ? b : b - 3;
+    const int b1 = b3 == 2 ? 0 : b3 + 1, b2 = b3 == 0 ? 2 : b3 - 1;
+    const double diag = sm[3 * a3 + (b3 < 3 ? b3 : 0)];
+    const double cross = 2.0 * (sm[3 * a3 + b1] * sm[32 + 9 + b2] - sm[3 * a3 + b2] * sm[32 + 9 + b1]);   // 2 (Rc_i x tf)_b
+    const double v = (a < 3) == (b < 3) ? diag : (a >= 3 ? cross : 0.0);
+    if (b < 6) s_m[a * 6 + b] = v;
+  }
+  // model-cost term of the group at the accepted point, q = d^T g + 1/2 d^T H d with d = [dc df]: every row's J d is
+  // J_cam e, e = dc + M_old df (dc = 0 for a fixed camera), so q = 1/2 (e' G7 e' - G7[6][6]) with e' = [e 1]
+  if (phase != 0 && tid < 8) {
+    double e = tid < 6 ? (fixed ? 0.0 : sm[12 + tid]) : (tid == 6 ? 1.0 : 0.0);
+    const int row = tid < 6 ? tid : 0;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) { Rc[i] = rfl(sm[i]); Rf[i] = rfl(sm[32 + i]); }
-#pragma unroll
-  for (int i = 0; i < 3; ++i) { tc[i] = rfl(sm[9 + i]); tf[i] = rfl(sm[32 + 9 + i]); }
-  if (tid < 36) {
-    const int a = tid / 6, b = tid % 6;
-    double v = 0.0;
-    if ((a < 3) == (b < 3)) {
-      v = sm[3 * (a % 3) + (b % 3)];
-    } else if (a >= 3) {   // 2 (Rc_i x tf)_b
-      const int i = a - 3, b1 = (b + 1) % 3, b2 = (b + 2) % 3;
-      v = 2.0 * (sm[3 * i + b1] * sm[32 + 9 + b2] - sm[3 * i + b2] * sm[32 + 9 + b1]);
-    }
-    s_m[tid] = v;
+    for (int b = 0; b < 6; ++b) e = fma(tid < 6 ? s_old[28 + row * 6 + b] : 0.0, sm[32 + 12 + b], e);
+    s_e[tid] = e;
   }
   const double ha = P.huber_a;
   RSW_MARK(2);
@@ -631,7 +675,14 @@ __global__ __launch_bounds__(NW * 64, 4) void k_rig_sweep_adj(RigDev P) {
       nX0 = P.oxyz[ic * 3]; nX1 = P.oxyz[ic * 3 + 1]; nX2 = P.oxyz[ic * 3 + 2];
     }
     RigObs o;
-    rig_common(Rf, tf, Rc, tc, (double)X0, (double)X1, (double)X2, (double)m.x, (double)m.y, o);
+    o.a0 = Rca[0] * X0 + Rca[1] * X1 + Rca[2] * X2 + tca[0];
+    o.a1 = Rca[3] * X0 + Rca[4] * X1 + Rca[5] * X2 + tca[1];
+    o.a2 = Rca[6] * X0 + Rca[7] * X1 + Rca[8] * X2 + tca[2];
+    o.iz = 1.0 / (o.a2 + tcs[2]);
+    o.x = (o.a0 + tcs[0]) * o.iz;
+    o.y = (o.a1 + tcs[1]) * o.iz;
+    o.ru = o.x - (double)m.x;
+    o.rv = o.y - (double)m.y;
     double rho, sr;
     huber(ha, o.ru * o.ru + o.rv * o.rv, rho, sr);
     if (valid) acc[28] += 0.5 * rho;
@@ -648,62 +699,60 @@ __global__ __launch_bounds__(NW * 64, 4) void k_rig_sweep_adj(RigDev P) {
     if (p == 0) RSW_MARK(3);
   }
   RSW_MARK(4);
-  reduce_scatter_step<16>(acc, lane);   // bit 4 of the lane picks the upper sixteen values,
-  reduce_scatter_step<8>(acc, lane);    // bit 3 the upper eight of those, ...: lane l ends up with value l & 31
-  reduce_scatter_step<4>(acc, lane);
-  reduce_scatter_step<2>(acc, lane);
-  reduce_scatter_step<1>(acc, lane);
-  acc[0] += __shfl_xor(acc[0], 32, 64);
-  if (lane < 32) s_red[wave * 32 + lane] = acc[0];
-  __syncthreads();
-  if (tid < 32) {
-    double t = s_red[tid];
-#pragma unroll
-    for (int w2 = 1; w2 < NW; ++w2) t += s_red[w2 * 32 + tid];
-    s_g[tid] = t;
+  if (phase != 0 && tid < 27) {
+    int i, j;
+    untri(tid, i, j);
+    acc[29] = (i == j ? 0.5 : 1.0) * s_e[i] * s_e[j] * s_old[tid];
   }
-  __syncthreads();
-  // CC M and M^T g_c; CC[i][b] = s_g[tri(max, min)], g_c[a] = s_g[tri(6, a)]
-  if (tid < 42) {
-    double v = 0.0;
-    if (tid < 36) {
-      const int i = tid / 6, j = tid % 6;
+  reduce_scatter32(acc, lane);   // value e in lanes 2e, 2e + 1
+  const int ve = lane >> 1;
+  if (NW > 1) {
+    if ((lane & 1) == 0) s_red[wave * 32 + ve] = acc[0];
+    __syncthreads();
+    if (tid < 32) {
+      double t = s_red[tid];
 #pragma unroll
-      for (int b = 0; b < 6; ++b) {
-        const int hi = i > b ? i : b, lo = i > b ? b : i;
-        v = fma(s_g[hi * (hi + 1) / 2 + lo], s_m[b * 6 + j], v);
-      }
-    } else {
-      const int j = tid - 36;
-#pragma unroll
-      for (int a = 0; a < 6; ++a) v = fma(s_m[a * 6 + j], s_g[21 + a], v);
+      for (int w2 = 1; w2 < NW; ++w2) t += s_red[w2 * 32 + tid];
+      s_g[tid] = t;
     }
-    s_t[tid] = v;
+  } else if ((lane & 1) == 0) {
+    s_g[ve] = acc[0];
   }
   __syncthreads();
-  double* out = P.gblocks + ((size_t)dst * P.NG + g) * gs;
+  if (wave != 0) return;
+  // The block the other kernels read, [cam frame r]^2 in a 16 x 16 tile, is N^T G7 N with N (7 x 13) = [I6 M 0; 0 0 1]
+  // (the identity zeroed for a fixed camera): two matrix products, T = G7 N and N^T T. The first product's result rows
+  // k and k + 4 sit in the very lanes that feed them to the second as its B operand.
+  const int k0 = lane >> 4, j = lane & 15;
+  const double mv0 = s_m[k0 * 6 + (j >= 6 && j < 12 ? j - 6 : 0)];
+  const double mv1 = s_m[(k0 < 2 ? k0 + 4 : 0) * 6 + (j >= 6 && j < 12 ? j - 6 : 0)];
+  const double id = fixed ? 0.0 : 1.0;
+  const double n0 = j < 6 ? (j == k0 ? id : 0.0) : (j < 12 ? mv0 : 0.0);                       // N[k0][j], k0 = 0..3
+  const double n1 = k0 < 2 ? (j < 6 ? (j == k0 + 4 ? id : 0.0) : (j < 12 ? mv1 : 0.0))       // N[k0 + 4][j]: rows 4, 5,
+                           : (k0 == 2 && j == 12 ? 1.0 : 0.0);                                //   the residual row 6, nothing
+  const int gi = j < 7 ? j : 0;
+  const int h0 = gi > k0 ? gi : k0, l0 = gi > k0 ? k0 : gi;
+  const int k1 = k0 + 4 < 7 ? k0 + 4 : 0;
+  const int h1 = gi > k1 ? gi : k1, l1 = gi > k1 ? k1 : gi;
+  const double gv0 = s_g[h0 * (h0 + 1) / 2 + l0], gv1 = s_g[h1 * (h1 + 1) / 2 + l1];
+  const double a0 = j < 7 ? gv0 : 0.0;                       // G7[j][k0]
+  const double a1 = (j < 7 && k0 + 4 < 7) ? gv1 : 0.0;       // G7[j][k0 + 4]
+  d4 T = {0.0, 0.0, 0.0, 0.0};
+  T = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, n0, T, 0, 0, 0);
+  T = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, n1, T, 0, 0, 0);
+  d4 B = {0.0, 0.0, 0.0, 0.0};
+  B = __builtin_amdgcn_mfma_f64_16x16x4f64(n0, T[0], B, 0, 0, 0);
+  B = __builtin_amdgcn_mfma_f64_16x16x4f64(n1, T[1], B, 0, 0, 0);
+  double* out = P.gblocks + ((size_t)dst * P.NG + g) * (size_t)P.gstride;
 #pragma unroll
-  for (int e = 0; e < EPT; ++e) {
-    const int t = tid + e * NT;
-    const int ti = t >> 4, tj = t & 15;
-    const int i = ti > tj ? ti : tj, j = ti > tj ? tj : ti;     // i >= j: both triangles get the same number
-    double gv = 0.0;
-    if (i < 6) {
-      gv = fixed ? 0.0 : s_g[i * (i + 1) / 2 + j];
-    } else if (i < 12) {
-      if (j < 6) {
-        gv = fixed ? 0.0 : s_t[j * 6 + (i - 6)];
-      } else {
-#pragma unroll
-        for (int a = 0; a < 6; ++a) gv = fma(s_m[a * 6 + (i - 6)], s_t[a * 6 + (j - 6)], gv);
-      }
-    } else if (i == 12) {
-      gv = j < 6 ? (fixed ? 0.0 : s_g[21 + j]) : (j < 12 ? s_t[36 + (j - 6)] : s_g[27]);
-    }
-    out[t] = gv;
-    if (phase == 0 && ti < 6 && tj == ti) P.ghd0[g * 8 + ti] = gv;  // diag of H_cc
+  for (int r = 0; r < 4; ++r) {
+    const int row = k0 + 4 * r;
+    out[row * 16 + j] = B[r];
+    if (phase == 0 && row < 6 && row == j) P.ghd0[g * 8 + row] = B[r];  // diag of H_cc
   }
-  if (tid == 0) {
+  // compact record of this point for the next sweep's model-cost term: G7 (28) and M (36)
+  P.gcomp[((size_t)dst * P.NG + g) * 64 + lane] = lane < 28 ? s_g[lane < 28 ? lane : 0] : s_m[lane >= 28 ? lane - 28 : 0];
+  if (lane == 0) {
     P.gstats[g * 2] = s_g[28];
     P.gstats[g * 2 + 1] = s_g[29];
   }
@@ -1429,11 +1478,6 @@ __device__ __forceinline__ double readlane_d(double x, int l) {
   return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ void untri(int idx, int& i, int& j) {  // packed lower index -> (i >= j)
-  i = 0;
-  while (tri(i + 1, 0) <= idx) ++i;
-  j = idx - tri(i, 0);
-}
 
 // shared step: write-through, so that workgroups of the same launch can read it behind a flag (sc1 loads)
 __device__ __forceinline__ void store_ds(double* p, double v) {
@@ -2507,8 +2551,10 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
     // one wave when the groups alone oversubscribe the chip's 4096 wave slots or have a single 64-observation chunk,
     // two when they at least fill a quarter of them, four otherwise. CC_RIG_SWEEP_WG_WAVES forces one (A/B, tests).
     const double per_group = NG > 0 ? (double)N / (double)NG : 0.0;
-    h->sweep_waves = kmode ? 4 : ((NG >= 4096 || per_group <= 64.0) ? 1 : (NG >= 1024 ? 2 : 4));
     if (const char* e = getenv("CC_RIG_SWEEP_MFMA")) h->sweep_adjoint = atoi(e) == 0;
+    h->sweep_waves = kmode ? 4 : ((NG >= 4096 || per_group <= 64.0) ? 1 : (NG >= 1024 ? 2 : 4));
+    // (k_rig_sweep_adj: one wave per group is the fastest at every measured shape that has a thousand groups)
+    if (!kmode && h->sweep_adjoint) h->sweep_waves = (NG >= 1024 || per_group <= 64.0) ? 1 : (NG >= 512 ? 2 : 4);
     if (const char* e = getenv("CC_RIG_SWEEP_WG_WAVES")) { const int v = atoi(e); if (!kmode && (v == 1 || v == 2 || v == 4)) h->sweep_waves = v; }
   }
   if (int rc = dev_zeroed(h, &d.intr, 2 * CKn * 16)) return rc;
@@ -2520,6 +2566,7 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   if (int rc = dev_zeroed(h, &d.gstats, (size_t)NG * 2)) return rc;
   if (int rc = dev_zeroed(h, &d.fstats, (size_t)F * 2)) return rc;
   if (int rc = dev_zeroed(h, &d.ghd0, (size_t)NG * 8)) return rc;
+  if (int rc = dev_zeroed(h, &d.gcomp, (size_t)2 * NG * 64)) return rc;
   if (int rc = dev_zeroed(h, &d.sp, (size_t)F * 8)) return rc;
   if (int rc = dev_zeroed(h, &d.ss, (size_t)128)) return rc;
   if (int rc = dev_zeroed(h, &d.ds, (size_t)128)) return rc;
