@@ -606,17 +606,24 @@ __global__ __launch_bounds__(NW * 64, CC_RIG_ADJ_WAVES) void k_rig_sweep_adj(Rig
   // chunks dealt to the waves starting at wave (g mod NW), observations fetched one pass ahead by unconditional loads:
   // see k_rig_sweep
   const int otid = (((tid >> 6) - (int)(g & (NW - 1))) & (NW - 1)) * 64 + lane;
-  const int64_t wrem = s1 - s0 - (otid >> 6) * 64;
-  const int npass = wrem > 0 ? (int)((wrem + NT - 1) / NT) : 0;
-  const float2* uv2 = reinterpret_cast<const float2*>(P.uv);
-  float2 nm;
-  float nX0, nX1, nX2;
-  {
-    const int64_t idx = s0 + otid;
-    const int64_t ic = idx < s1 ? idx : s0;
-    nm = uv2[ic];
-    nX0 = P.oxyz[ic * 3]; nX1 = P.oxyz[ic * 3 + 1]; nX2 = P.oxyz[ic * 3 + 2];
-  }
+  const int n = (int)(s1 - s0);                                   // observations of the group (never empty)
+  const int wrem = n - (otid >> 6) * 64;
+  const int npass = wrem > 0 ? (wrem + NT - 1) / NT : 0;
+  // Observations are fetched TWO passes ahead (two register sets, the loop unrolled by two): one pass of the other
+  // waves on the SIMD does not cover the memory latency once the whole chip streams. Unconditional loads (idle slots
+  // re-read the group's first observation), 32-bit offsets from the group's uniform base.
+  const float2* uvg = reinterpret_cast<const float2*>(P.uv) + s0;
+  struct F3 { float x, y, z; };
+  const F3* xg = reinterpret_cast<const F3*>(P.oxyz) + s0;
+  struct ObsRaw { float2 m; F3 X; };
+  auto fetch = [&](int k, ObsRaw& r) {
+    const int kc = k < n ? k : 0;
+    r.m = uvg[kc];
+    r.X = xg[kc];
+  };
+  ObsRaw oa, ob;
+  fetch(otid, oa);
+  fetch(otid + NT, ob);
   if (tid < 64) {
     // (both buffers hold valid memory: the record of `cur` is read whatever the phase, used only behind phase != 0)
     const double rec = tid < 32 ? P.camrec[c * 32 + tid] : P.frec[(size_t)f * 32 + (tid - 32)];
@@ -638,8 +645,8 @@ __global__ __launch_bounds__(NW * 64, CC_RIG_ADJ_WAVES) void k_rig_sweep_adj(Rig
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) Rca[3 * i + j] = cr[3 * i] * fr[j] + cr[3 * i + 1] * fr[3 + j] + cr[3 * i + 2] * fr[6 + j];
-      tca[i] = cr[3 * i] * fr[9] + cr[3 * i + 1] * fr[10] + cr[3 * i + 2] * fr[11];
+      for (int j = 0; j < 3; ++j) Rca[3 * i + j] = rfl(cr[3 * i] * fr[j] + cr[3 * i + 1] * fr[3 + j] + cr[3 * i + 2] * fr[6 + j]);
+      tca[i] = rfl(cr[3 * i] * fr[9] + cr[3 * i + 1] * fr[10] + cr[3 * i + 2] * fr[11]);
       tcs[i] = cr[9 + i];
     }
   }
@@ -663,17 +670,11 @@ __global__ __launch_bounds__(NW * 64, CC_RIG_ADJ_WAVES) void k_rig_sweep_adj(Rig
   }
   const double ha = P.huber_a;
   RSW_MARK(2);
-  for (int p = 0; p < npass; ++p) {
-    const int64_t idx = s0 + (int64_t)p * NT + otid;
-    const bool valid = idx < s1;
-    const float2 m = nm;
-    const float X0 = nX0, X1 = nX1, X2 = nX2;
-    {
-      const int64_t idn = idx + NT;
-      const int64_t ic = idn < s1 ? idn : s0;
-      nm = uv2[ic];
-      nX0 = P.oxyz[ic * 3]; nX1 = P.oxyz[ic * 3 + 1]; nX2 = P.oxyz[ic * 3 + 2];
-    }
+  struct ObsD { double u, v, X0, X1, X2; };
+  auto widen = [](const ObsRaw& r, ObsD& d) { d.u = (double)r.m.x; d.v = (double)r.m.y; d.X0 = (double)r.X.x; d.X1 = (double)r.X.y; d.X2 = (double)r.X.z; };
+  auto pass = [&](int k, const ObsD& r) {
+    const bool valid = k < n;
+    const double X0 = r.X0, X1 = r.X1, X2 = r.X2;
     RigObs o;
     o.a0 = Rca[0] * X0 + Rca[1] * X1 + Rca[2] * X2 + tca[0];
     o.a1 = Rca[3] * X0 + Rca[4] * X1 + Rca[5] * X2 + tca[1];
@@ -681,8 +682,8 @@ __global__ __launch_bounds__(NW * 64, CC_RIG_ADJ_WAVES) void k_rig_sweep_adj(Rig
     o.iz = 1.0 / (o.a2 + tcs[2]);
     o.x = (o.a0 + tcs[0]) * o.iz;
     o.y = (o.a1 + tcs[1]) * o.iz;
-    o.ru = o.x - (double)m.x;
-    o.rv = o.y - (double)m.y;
+    o.ru = o.x - r.u;
+    o.rv = o.y - r.v;
     double rho, sr;
     huber(ha, o.ru * o.ru + o.rv * o.rv, rho, sr);
     if (valid) acc[28] += 0.5 * rho;
@@ -696,7 +697,25 @@ __global__ __launch_bounds__(NW * 64, CC_RIG_ADJ_WAVES) void k_rig_sweep_adj(Rig
     w[0] = sr * (2.0 * (Bv2 * o.a1 - Bv1 * o.a2)); w[1] = sr * (2.0 * (-(Bv2 * o.a0))); w[2] = sr * (2.0 * (Bv1 * o.a0));
     w[3] = 0.0; w[4] = sr * Bv1; w[5] = sr * Bv2; w[6] = sr * o.rv;
     adj_accumulate<3>(w, acc);
+  };
+  // (each register set is widened to doubles BEFORE it is refilled: the loaded registers are then dead and the refill
+  // reuses them -- a set kept alive across its own refill would be rotated by copies that wait for every load in flight)
+  int p = 0;
+  for (; p + 1 < npass; p += 2) {    // pairs of passes, no branch inside (a conditional second half brings the copies back)
+    const int k = p * NT + otid;
+    ObsD d;
+    widen(oa, d);
+    fetch(k + 2 * NT, oa);
+    pass(k, d);
     if (p == 0) RSW_MARK(3);
+    widen(ob, d);
+    fetch(k + 3 * NT, ob);
+    pass(k + NT, d);
+  }
+  if (p < npass) {
+    ObsD d;
+    widen(oa, d);
+    pass(p * NT + otid, d);
   }
   RSW_MARK(4);
   if (phase != 0 && tid < 27) {
