@@ -101,7 +101,8 @@ struct RigDev {
   double* gstats;   // [NG][2] cost, model term
   double* fstats;   // [F][2] step^2, |x|^2
   double* ghd0;     // [NG][8] diag of H_cc at the initial point
-  double* gcomp;    // [2][NG][64] (poses-only sweep k_rig_sweep_adj) per group and buffer: 7-column Gram (28), M (36)
+  double* gcomp;    // compact record per group and buffer for the next sweep's model-cost term: [2][NG][64] 7-column Gram (28),
+                    // M (36) (k_rig_sweep_adj); with intrinsics [2][NG][320] 16-column Gram (256), M (36) (k_rig_sweep_adjk)
   double* sp;       // [F][8]
   double* ss;       // [128]
   double* ds;       // [128] scaled shared step
@@ -776,6 +777,218 @@ __global__ __launch_bounds__(NW * 64, CC_RIG_ADJ_WAVES) void k_rig_sweep_adj(Rig
     P.gstats[g * 2 + 1] = s_g[29];
   }
   RSW_MARK(5);
+}
+
+// ---------------------------------------------------------------------------------------------
+// EXTENSION (pixel observations through the camera's intrinsics): the same idea with the matrix pipe. A row's 22 columns
+// [J_cam(6) J_frame(6) r | J_k(9)] carry only SIXTEEN independent ones, X = [J_cam(6) r J_k(9)]: one 16 x 16 product
+// per row set instead of the two of k_rig_sweep<true> (gram_rows_p2), one staged tile instead of two, no frame columns to
+// form. The three tiles the other kernels read are assembled per group from G = X^T X and N (7 x 13) = [I6 M 0; 0 0 1]:
+// AA = N^T G[0:7, 0:7] N, AB = N^T G[0:7, 7:16], BB = G[7:16, 7:16]. The compact record kept for the next sweep's
+// model-cost term is G itself and M: q = 1/2 (e'^T G e' - G[6][6]), e' = [dc + M_old df, 1, dk].
+// ---------------------------------------------------------------------------------------------
+#ifndef CC_RIG_ADJK_WAVES
+#define CC_RIG_ADJK_WAVES 3   // waves per SIMD the sweep with intrinsics is compiled for (A/B knob)
+#endif
+constexpr int kRigCompK = 320;   // doubles per group and buffer of the compact record with intrinsics: G (256), M (36)
+__global__ __launch_bounds__(256, CC_RIG_ADJK_WAVES) void k_rig_sweep_adjk(RigDev P) {
+  constexpr int NW = 4, NT = 256;
+  __shared__ __attribute__((aligned(16))) double s_stage[NW * kStageDoublesPerWave];   // per wave 64 x 16; then the four partial products
+  __shared__ double sm[96];        // camera record, frame record, intrinsics record (candidate [0..8], step [16..24])
+  __shared__ double s_G[256];      // G
+  __shared__ double s_mold[36];    // M of the accepted point
+  __shared__ double s_e[16];       // e'
+  __shared__ double s_m[36];       // M
+  __shared__ double s_w[8];        // per wave: model-cost term, cost
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t g = blockIdx.x;
+  const int f = P.gframe[g], c = P.gcam[g];
+  const int64_t s0 = P.goff[g], s1 = P.goff[g + 1];
+  const LmCtl* ctl = P.ctl;
+  const int done = ctl->done, phase = ctl->phase, step_valid = ctl->step_valid, cur = ctl->cur;
+  if (done) return;
+  if (phase != 0 && !step_valid) return;
+  const int dst = phase == 0 ? cur : (cur ^ 1);
+  const bool fixed = P.cam_fixed[c] != 0;
+  const int ks = P.kset[c];
+  const int otid = (((tid >> 6) - (int)(g & (NW - 1))) & (NW - 1)) * 64 + lane;
+  const int n = (int)(s1 - s0);
+  const int wrem = n - (otid >> 6) * 64;
+  const int npass = wrem > 0 ? (wrem + NT - 1) / NT : 0;
+  const float2* uvg = reinterpret_cast<const float2*>(P.uv) + s0;
+  struct F3 { float x, y, z; };
+  const F3* xg = reinterpret_cast<const F3*>(P.oxyz) + s0;
+  struct ObsRaw { float2 m; F3 X; };
+  auto fetch = [&](int k, ObsRaw& r) {
+    const int kc = k < n ? k : 0;
+    r.m = uvg[kc];
+    r.X = xg[kc];
+  };
+  ObsRaw oa, ob;
+  fetch(otid, oa);
+  fetch(otid + NT, ob);
+  const double* comp_old = P.gcomp + ((size_t)cur * P.NG + g) * kRigCompK;
+  {
+    const double rec = tid < 32 ? P.camrec[c * 32 + tid] : (tid < 64 ? P.frec[(size_t)f * 32 + (tid - 32)] : P.krec[ks * 32 + ((tid - 64) & 31)]);
+    const double mo = comp_old[256 + (tid < 36 ? tid : 0)];
+    if (tid < 96) sm[tid] = rec;
+    if (tid < 36) s_mold[tid] = mo;
+  }
+  const double g_old = comp_old[tid];
+  __syncthreads();
+  double Rca[9], tca[3], tcs[3], kk[9];
+  {
+    const double* cr = P.camrec + (size_t)c * 32;
+    const double* fr = P.frec + (size_t)f * 32;
+    const double* kr = P.krec + (size_t)ks * 32;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Rca[3 * i + j] = rfl(cr[3 * i] * fr[j] + cr[3 * i + 1] * fr[3 + j] + cr[3 * i + 2] * fr[6 + j]);
+      tca[i] = rfl(cr[3 * i] * fr[9] + cr[3 * i + 1] * fr[10] + cr[3 * i + 2] * fr[11]);
+      tcs[i] = cr[9 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) kk[i] = kr[i];
+  }
+  if (tid < 48) {   // M[a][b], a = tid >> 3, b = tid & 7 < 6 (see k_rig_sweep_adj)
+    const int a = tid >> 3, b = tid & 7;
+    const int a3 = a < 3 ? a : a - 3, b3 = b < 3 ? b : b - 3;
+    const int b1 = b3 == 2 ? 0 : b3 + 1, b2 = b3 == 0 ? 2 : b3 - 1;
+    const double diag = sm[3 * a3 + (b3 < 3 ? b3 : 0)];
+    const double cross = 2.0 * (sm[3 * a3 + b1] * sm[32 + 9 + b2] - sm[3 * a3 + b2] * sm[32 + 9 + b1]);
+    const double v = (a < 3) == (b < 3) ? diag : (a >= 3 ? cross : 0.0);
+    if (b < 6) s_m[a * 6 + b] = v;
+  } else if (tid >= 64 && tid < 80) {   // e'
+    const int t = tid - 64;
+    double e = t < 6 ? (fixed ? 0.0 : sm[12 + t]) : (t == 6 ? 1.0 : sm[64 + 16 + (t - 7)]);
+    const int row = t < 6 ? t : 0;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) e = fma(t < 6 ? s_mold[row * 6 + b] : 0.0, sm[32 + 12 + b], e);
+    s_e[t] = e;
+  }
+  __syncthreads();
+  double qterm = 0.0;
+  if (phase != 0 && tid != 6 * 16 + 6) qterm = 0.5 * s_e[tid >> 4] * s_e[tid & 15] * g_old;
+  const double ha = P.huber_a;
+  const uint32_t kmask = P.kmask[ks];
+  double* stage = s_stage + wave * kStageDoublesPerWave;
+  d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+  double cost = 0.0;
+  struct ObsD { double u, v, X0, X1, X2; };
+  auto widen = [](const ObsRaw& r, ObsD& d) { d.u = (double)r.m.x; d.v = (double)r.m.y; d.X0 = (double)r.X.x; d.X1 = (double)r.X.y; d.X2 = (double)r.X.z; };
+  auto pass = [&](int k, const ObsD& r) {
+    const bool valid = k < n;
+    RigObs o;
+    o.a0 = Rca[0] * r.X0 + Rca[1] * r.X1 + Rca[2] * r.X2 + tca[0];
+    o.a1 = Rca[3] * r.X0 + Rca[4] * r.X1 + Rca[5] * r.X2 + tca[1];
+    o.a2 = Rca[6] * r.X0 + Rca[7] * r.X1 + Rca[8] * r.X2 + tca[2];
+    o.iz = 1.0 / (o.a2 + tcs[2]);
+    o.x = (o.a0 + tcs[0]) * o.iz;
+    o.y = (o.a1 + tcs[1]) * o.iz;
+    RigKObs ko;
+    rigk_obs(kk, o, r.u, r.v, ko);
+    double rho, sr;
+    huber(ha, ko.ru * ko.ru + ko.rv * ko.rv, rho, sr);
+    if (valid) cost += 0.5 * rho;
+    if (!valid) sr = 0.0;
+    double w[16];
+    w[0] = sr * (2.0 * (ko.Bu2 * o.a1 - ko.Bu1 * o.a2)); w[1] = sr * (2.0 * (ko.Bu0 * o.a2 - ko.Bu2 * o.a0)); w[2] = sr * (2.0 * (ko.Bu1 * o.a0 - ko.Bu0 * o.a1));
+    w[3] = sr * ko.Bu0; w[4] = sr * ko.Bu1; w[5] = sr * ko.Bu2; w[6] = sr * ko.ru;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) w[7 + q] = (kmask & (1u << q)) ? 0.0 : sr * ko.ju[q];
+    stage_row(stage, lane, w);
+    wave_lds_fence();
+    gram_rows(stage, lane, acc0, acc1);
+    wave_lds_fence();
+    w[0] = sr * (2.0 * (ko.Bv2 * o.a1 - ko.Bv1 * o.a2)); w[1] = sr * (2.0 * (ko.Bv0 * o.a2 - ko.Bv2 * o.a0)); w[2] = sr * (2.0 * (ko.Bv1 * o.a0 - ko.Bv0 * o.a1));
+    w[3] = sr * ko.Bv0; w[4] = sr * ko.Bv1; w[5] = sr * ko.Bv2; w[6] = sr * ko.rv;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) w[7 + q] = (kmask & (1u << q)) ? 0.0 : sr * ko.jv[q];
+    stage_row(stage, lane, w);
+    wave_lds_fence();
+    gram_rows(stage, lane, acc0, acc1);
+    wave_lds_fence();
+  };
+  int p = 0;
+  for (; p + 1 < npass; p += 2) {
+    const int k = p * NT + otid;
+    ObsD d;
+    widen(oa, d);
+    fetch(k + 2 * NT, oa);
+    pass(k, d);
+    widen(ob, d);
+    fetch(k + 3 * NT, ob);
+    pass(k + NT, d);
+  }
+  if (p < npass) {
+    ObsD d;
+    widen(oa, d);
+    pass(p * NT + otid, d);
+  }
+  __syncthreads();
+  {
+    const int slot = (lane >> 4) * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_stage[wave * 256 + slot + 64 * r] = acc0[r] + acc1[r];
+  }
+  const double qw = wave_sum(qterm), cw = wave_sum(cost);
+  if (lane == 0) { s_w[wave] = qw; s_w[4 + wave] = cw; }
+  __syncthreads();
+  const double Gt = (s_stage[tid] + s_stage[256 + tid]) + (s_stage[512 + tid] + s_stage[768 + tid]);
+  s_G[tid] = Gt;
+  __syncthreads();
+  double* out = P.gblocks + ((size_t)dst * P.NG + g) * (size_t)P.gstride;
+  const int k0 = lane >> 4, j = lane & 15;
+  if (wave < 2) {
+    const double mv0 = s_m[k0 * 6 + (j >= 6 && j < 12 ? j - 6 : 0)];
+    const double mv1 = s_m[(k0 < 2 ? k0 + 4 : 0) * 6 + (j >= 6 && j < 12 ? j - 6 : 0)];
+    const double id = fixed ? 0.0 : 1.0;
+    const double n0 = j < 6 ? (j == k0 ? id : 0.0) : (j < 12 ? mv0 : 0.0);                       // N[k0][j]
+    const double n1 = k0 < 2 ? (j < 6 ? (j == k0 + 4 ? id : 0.0) : (j < 12 ? mv1 : 0.0))       // N[k0 + 4][j]
+                             : (k0 == 2 && j == 12 ? 1.0 : 0.0);
+    const int k1 = k0 < 3 ? k0 + 4 : 0;
+    d4 B = {0.0, 0.0, 0.0, 0.0};
+    if (wave == 0) {          // AA = N^T (G7 N)
+      const int gi = j < 7 ? j : 0;
+      const double gv0 = s_G[gi * 16 + k0], gv1 = s_G[gi * 16 + k1];
+      const double a0 = j < 7 ? gv0 : 0.0, a1 = (j < 7 && k0 < 3) ? gv1 : 0.0;
+      d4 T = {0.0, 0.0, 0.0, 0.0};
+      T = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, n0, T, 0, 0, 0);
+      T = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, n1, T, 0, 0, 0);
+      B = __builtin_amdgcn_mfma_f64_16x16x4f64(n0, T[0], B, 0, 0, 0);
+      B = __builtin_amdgcn_mfma_f64_16x16x4f64(n1, T[1], B, 0, 0, 0);
+    } else {                  // AB = N^T G[0:7, 7:16]
+      const int hj = j < 9 ? 7 + j : 7;
+      const double hv0 = s_G[k0 * 16 + hj], hv1 = s_G[k1 * 16 + hj];
+      const double h0 = j < 9 ? hv0 : 0.0, h1 = (j < 9 && k0 < 3) ? hv1 : 0.0;
+      B = __builtin_amdgcn_mfma_f64_16x16x4f64(n0, h0, B, 0, 0, 0);
+      B = __builtin_amdgcn_mfma_f64_16x16x4f64(n1, h1, B, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = k0 + 4 * r;
+      out[wave * 256 + row * 16 + j] = B[r];
+      if (wave == 0 && phase == 0 && row < 6 && row == j) P.ghd0[g * 8 + row] = B[r];   // diag of H_cc
+    }
+  } else if (wave == 2) {     // BB = G[7:16, 7:16]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = k0 + 4 * r;
+      const bool in = row < 9 && j < 9;
+      const double gv = s_G[(in ? 7 + row : 0) * 16 + (in ? 7 + j : 0)];
+      const double val = in ? gv : 0.0;
+      out[512 + row * 16 + j] = val;
+      if (phase == 0 && row < 9 && row == j) P.ghdk[g * 16 + row] = val;   // diag of H_kk
+    }
+  } else {
+    if (lane == 0) {
+      P.gstats[g * 2] = (s_w[4] + s_w[5]) + (s_w[6] + s_w[7]);
+      P.gstats[g * 2 + 1] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    }
+    if (lane < 36) P.gcomp[((size_t)dst * P.NG + g) * kRigCompK + 256 + lane] = s_m[lane];
+  }
+  P.gcomp[((size_t)dst * P.NG + g) * kRigCompK + tid] = Gt;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2389,7 +2602,8 @@ static void rig_exchange_bounds(const cc_rig* h, int* doubles_kind0, int* double
 static int rig_enqueue_round(cc_rig* h, bool initial, bool profile) {
   const RigDev& d = h->d;
   { RigProbe p(h, CC_K_SWEEP, profile);
-    if (d.kmode) hipLaunchKernelGGL((k_rig_sweep<true, 4>), dim3((unsigned)h->NG), dim3(kRigThreads), kRigSweepLdsBytesK, h->stream, d);
+    if (d.kmode && h->sweep_adjoint) hipLaunchKernelGGL(k_rig_sweep_adjk, dim3((unsigned)h->NG), dim3(256), 0, h->stream, d);
+    else if (d.kmode) hipLaunchKernelGGL((k_rig_sweep<true, 4>), dim3((unsigned)h->NG), dim3(kRigThreads), kRigSweepLdsBytesK, h->stream, d);
     else if (h->sweep_adjoint && h->sweep_waves == 4) hipLaunchKernelGGL((k_rig_sweep_adj<4>), dim3((unsigned)h->NG), dim3(256), 0, h->stream, d);
     else if (h->sweep_adjoint && h->sweep_waves == 2) hipLaunchKernelGGL((k_rig_sweep_adj<2>), dim3((unsigned)h->NG), dim3(128), 0, h->stream, d);
     else if (h->sweep_adjoint) hipLaunchKernelGGL((k_rig_sweep_adj<1>), dim3((unsigned)h->NG), dim3(64), 0, h->stream, d);
@@ -2585,7 +2799,7 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   if (int rc = dev_zeroed(h, &d.gstats, (size_t)NG * 2)) return rc;
   if (int rc = dev_zeroed(h, &d.fstats, (size_t)F * 2)) return rc;
   if (int rc = dev_zeroed(h, &d.ghd0, (size_t)NG * 8)) return rc;
-  if (int rc = dev_zeroed(h, &d.gcomp, (size_t)2 * NG * 64)) return rc;
+  if (int rc = dev_zeroed(h, &d.gcomp, (size_t)2 * NG * (kmode ? kRigCompK : 64))) return rc;
   if (int rc = dev_zeroed(h, &d.sp, (size_t)F * 8)) return rc;
   if (int rc = dev_zeroed(h, &d.ss, (size_t)128)) return rc;
   if (int rc = dev_zeroed(h, &d.ds, (size_t)128)) return rc;
