@@ -1,0 +1,103 @@
+"""The two formulations of the rig sweep give the same numbers.
+
+Default: per (frame, camera) group only the columns [J_cam(6) r (J_k(9))] are accumulated and the frame blocks follow
+from the group's adjoint, J_frame = J_cam M (cc_rig.hip, k_rig_sweep_adj / k_rig_sweep_adjk). CC_RIG_SWEEP_MFMA=1 keeps
+the first formulation (every row's 13 / 22 columns through the matrix pipe, k_rig_sweep). Compared here: the group blocks
+of the initial evaluation of a solve (what the elimination reads), entry by entry, and complete solves against the oracle under either."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from camera_calibrator_amd import capi
+from oracle import pyoracle as po
+from tests.helpers import rigk_case
+from tests.test_gpu_rig import _assert_same, _both
+from tests.test_gpu_rigk import _assert_same as _assert_same_k, _both as _both_k
+
+pytestmark = pytest.mark.gpu
+
+
+def _fetch(prob, name, n):
+    buf = np.zeros(n)
+    capi._check(capi.lib().cc_rig_debug_fetch(prob._h, name.encode(), buf.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(n)))
+    return buf
+
+
+def _group_count(sc_or_k, cams):
+    off, cam = np.asarray(sc_or_k["frame_offsets"]), np.asarray(sc_or_k["obs_cam"])
+    return sum(len(np.unique(cam[off[f]:off[f + 1]])) for f in range(len(off) - 1))
+
+
+def _blocks_poses_only(monkeypatch, mfma, sc, cams, frozen, huber_a):
+    monkeypatch.setenv("CC_RIG_SWEEP_MFMA", str(mfma))
+    cq, ct = po.affine_to_qt(sc["cam_T"])
+    fq, ft = po.affine_to_qt(sc["frame_T"])
+    prob = capi.RigProblem(cams, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"], sc["world_xyz"], frozen, huber_a=huber_a)
+    prob.set_state(cq, ct, fq, ft)
+    cost = prob.solve(capi.default_options(max_iterations=1))["initial_cost"]    # (cc_rig_eval does not run the sweep)
+    blocks = _fetch(prob, "gblocks", _group_count(sc, cams) * 256).reshape(-1, 16, 16)   # buffer 0: the initial point
+    prob.close()
+    return cost, blocks
+
+
+@pytest.mark.parametrize("cams,frames,pts,huber_a", [(3, 30, 150, capi.HUBER_A), (4, 25, 70, 0.0), (2, 40, 5, capi.HUBER_A)])
+def test_group_blocks_of_both_sweeps_agree(monkeypatch, cams, frames, pts, huber_a):
+    sc = po.rig_scenario(cams, frames, pts)
+    frozen = np.array(sc["cam_frozen"], dtype=np.uint8).copy()
+    c1, b1 = _blocks_poses_only(monkeypatch, 1, sc, cams, frozen, huber_a)
+    c0, b0 = _blocks_poses_only(monkeypatch, 0, sc, cams, frozen, huber_a)
+    assert np.isclose(c0, c1, rtol=1e-13)
+    assert b0.shape == b1.shape and np.abs(b1).max() > 0
+    # per block: camera, frame, cross and gradient entries against the block's largest entry of that kind
+    for sl in [(slice(0, 6), slice(0, 6)), (slice(6, 12), slice(6, 12)), (slice(0, 6), slice(6, 12)), (slice(12, 13), slice(0, 13))]:
+        a, b = b0[:, sl[0], sl[1]], b1[:, sl[0], sl[1]]
+        scale = np.abs(b).max(axis=(1, 2), keepdims=True)
+        scale[scale == 0] = 1.0
+        assert (np.abs(a - b) / scale).max() < 1e-11
+    assert np.array_equal(b0[:, 13:, :], np.zeros_like(b0[:, 13:, :])) and np.array_equal(b0[:, :, 13:], np.zeros_like(b0[:, :, 13:]))
+    # frozen camera (camera 0 of the scenario): its own rows and columns are zero in both, its frames' blocks are not
+    assert frozen[0] == 1
+    zero_cam = np.abs(b0[:, :6, :]).max(axis=(1, 2)) == 0
+    assert zero_cam.any() and np.array_equal(zero_cam, np.abs(b1[:, :6, :]).max(axis=(1, 2)) == 0)
+    assert np.all(np.diagonal(b0[zero_cam][:, 6:12, 6:12], axis1=1, axis2=2) > 0)
+
+
+@pytest.mark.parametrize("mfma", [0, 1])
+@pytest.mark.parametrize("cams,frames,pts", [(3, 30, 150), (4, 40, 30), (2, 300, 4)])
+def test_rig_solve_matches_the_oracle_under_either_sweep(monkeypatch, mfma, cams, frames, pts):
+    monkeypatch.setenv("CC_RIG_SWEEP_MFMA", str(mfma))
+    sc = po.rig_scenario(cams, frames, pts)
+    g, o = _both(sc, cams)
+    _assert_same(g, o)
+
+
+@pytest.mark.parametrize("mfma", [0, 1])
+@pytest.mark.parametrize("cams,frames,pts,mask,huber_a", [(3, 20, 300, 0, 0.0), (4, 60, 30, (1 << 8) | (1 << 6), 1.5)])
+def test_rigk_solve_matches_the_oracle_under_either_sweep(monkeypatch, mfma, cams, frames, pts, mask, huber_a):
+    monkeypatch.setenv("CC_RIG_SWEEP_MFMA", str(mfma))
+    k = rigk_case(cams, frames, pts)
+    g, o = _both_k(k, const_mask=mask, huber_a=huber_a)
+    _assert_same_k(g, o)
+
+
+def test_rigk_tiles_of_both_sweeps_agree(monkeypatch):
+    k = rigk_case(3, 24, 90)
+    out = []
+    for mfma in (1, 0):
+        monkeypatch.setenv("CC_RIG_SWEEP_MFMA", str(mfma))
+        prob = capi.RigProblem(k["cams"], k["frame_offsets"], k["obs_cam"], k["obs_world"], k["obs_uv_pix"], k["world_xyz"],
+                               k["cam_frozen"], huber_a=2.0, with_intrinsics=True)
+        prob.set_intrinsics(k["intr0"], 1 << 7)
+        prob.set_state(k["cam_q0"], k["cam_t0"], k["frame_q0"], k["frame_t0"])
+        cost = prob.solve(capi.default_options(max_iterations=1))["initial_cost"]
+        tiles = _fetch(prob, "gblocks", _group_count(k, k["cams"]) * 768).reshape(-1, 3, 16, 16)   # buffer 0: the initial point
+        prob.close()
+        out.append((cost, tiles))
+    (c1, t1), (c0, t0) = out
+    assert np.isclose(c0, c1, rtol=1e-13)
+    for t in range(3):
+        scale = np.abs(t1[:, t]).max(axis=(1, 2), keepdims=True)
+        assert scale.min() > 0
+        assert (np.abs(t0[:, t] - t1[:, t]) / scale).max() < 1e-11
+    assert np.abs(t0[:, 1, :, 7]).max() == 0 and np.abs(t0[:, 2, 7, :]).max() == 0    # the intrinsic held constant has no column
