@@ -689,14 +689,16 @@ __global__ __launch_bounds__(NW * 64, CC_RIG_ADJ_WAVES) void k_rig_sweep_adj(Rig
     huber(ha, o.ru * o.ru + o.rv * o.rv, rho, sr);
     if (valid) acc[28] += 0.5 * rho;
     if (!valid) sr = 0.0;
-    // rows as rig_row forms them, camera columns and residual only; B_u = (iz, 0, -x iz), B_v = (0, iz, -y iz)
-    const double Bu0 = o.iz, Bu2 = -o.x * o.iz, Bv1 = o.iz, Bv2 = -o.y * o.iz;
+    // rows as rig_row forms them, camera columns and residual only, with B_u = (iz, 0, -x iz), B_v = (0, iz, -y iz):
+    // u: sr [2 Bu2 a1, 2 (Bu0 a2 - Bu2 a0), -2 Bu0 a1, Bu0, 0, Bu2, ru], v: sr [2 (Bv2 a1 - Bv1 a2), -2 Bv2 a0, 2 Bv1 a0, 0, Bv1, Bv2, rv]
+    const double pz = sr * o.iz, qu = -(pz * o.x), qv = -(pz * o.y);     // sr Bu0 = sr Bv1, sr Bu2, sr Bv2
+    const double pz2 = pz + pz, qu2 = qu + qu, qv2 = qv + qv;
     double w[7];
-    w[0] = sr * (2.0 * (Bu2 * o.a1)); w[1] = sr * (2.0 * (Bu0 * o.a2 - Bu2 * o.a0)); w[2] = sr * (2.0 * (-(Bu0 * o.a1)));
-    w[3] = sr * Bu0; w[4] = 0.0; w[5] = sr * Bu2; w[6] = sr * o.ru;
+    w[0] = qu2 * o.a1; w[1] = pz2 * o.a2 - qu2 * o.a0; w[2] = -(pz2 * o.a1);
+    w[3] = pz; w[4] = 0.0; w[5] = qu; w[6] = sr * o.ru;
     adj_accumulate<4>(w, acc);
-    w[0] = sr * (2.0 * (Bv2 * o.a1 - Bv1 * o.a2)); w[1] = sr * (2.0 * (-(Bv2 * o.a0))); w[2] = sr * (2.0 * (Bv1 * o.a0));
-    w[3] = 0.0; w[4] = sr * Bv1; w[5] = sr * Bv2; w[6] = sr * o.rv;
+    w[0] = qv2 * o.a1 - pz2 * o.a2; w[1] = -(qv2 * o.a0); w[2] = pz2 * o.a0;
+    w[3] = 0.0; w[4] = pz; w[5] = qv; w[6] = sr * o.rv;
     adj_accumulate<3>(w, acc);
   };
   // (each register set is widened to doubles BEFORE it is refilled: the loaded registers are then dead and the refill
