@@ -620,7 +620,11 @@ __global__ __launch_bounds__(NW * 64, CC_RIG_ADJ_WAVES) void k_rig_sweep_adj(Rig
   auto fetch = [&](int k, ObsRaw& r) {
     const int kc = k < n ? k : 0;
     r.m = uvg[kc];
+#ifdef CC_EXP_NOXYZ
+    r.X = xg[kc & 1];
+#else
     r.X = xg[kc];
+#endif
   };
   ObsRaw oa, ob;
   fetch(otid, oa);
@@ -1156,6 +1160,7 @@ __device__ __forceinline__ void rig_reduce_stats(const RigDev& P, bool want, dou
 #pragma unroll
       for (int u = 0; u < 8; ++u) { a[2] += v[u].x; a[3] += v[u].y; }
     }
+    // (measured: clamped unconditional loads + selects are 1-2 us slower here than these selects on the loaded value)
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) a[k] = wave_sum(a[k]);
@@ -2628,7 +2633,8 @@ static int rig_enqueue_round(cc_rig* h, bool initial, bool profile) {
   // multi-process tests put up to four ranks on one GPU, and a rank's solver waits for the OTHER ranks' launches).
   // enough blocks for the column sums AND for the pose update fused behind them (16 frames per block and pass): a small
   // reduced system (the reference's 2-camera test: 18 blocks of sums) would otherwise update 1000 frames in four passes
-  const unsigned rblocks = (unsigned)std::min<int64_t>(64, std::max<int64_t>((d.PC + 15) / 16, (h->F + 15) / 16));
+  static const int rcap = getenv("CC_RIG_REDUCE_BLOCKS") ? std::max(1, atoi(getenv("CC_RIG_REDUCE_BLOCKS"))) : 128;   // (A/B knob; 2000 frames: 124.4 us per iteration with 128, 127.2 with 64)
+  const unsigned rblocks = (unsigned)std::min<int64_t>(rcap, std::max<int64_t>((d.PC + 15) / 16, (h->F + 15) / 16));
   if (h->comm) {
     { RigProbe p(h, CC_K_REDUCE, profile); hipLaunchKernelGGL(k_rig_reduce<2>, dim3(rblocks), dim3(256), 0, h->stream, d); }
     { RigProbe p(h, CC_K_ALLREDUCE, profile); if (int rc = comm_allreduce_sum(h->comm, d.vec, d.PC + 32, h->stream)) return rc; }
