@@ -38,8 +38,10 @@ PTS_PER_FRAME = 500
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # MI355X fp64 vector = matrix peak (AMD datasheet)
 FLOP_PER_OBS = 800.0       # ~0.8 kflop fp64 per observation and Jacobian sweep
-RIG_FLOP_PER_OBS = 750.0   # estimate in the same spirit: ~200 (two poses, projection, 2x12 Jacobian, Huber) + 544 (Gram) -- the
-                           # problem's count; the sweep executes ~230 per observation since it forms the camera columns only
+# fp64 flops the rig sweeps EXECUTE per observation (counted in the ISA of the main loops): poses only, k_rig_sweep_adj --
+# composed pose chain, projection, division, Huber test, two 7-entry rows, 42 FMAs of the 7-column Gram; with intrinsics,
+# k_rig_sweep_adjk -- ~200 of pixel model and rows + 1024 of the 16 x 16 product of two rows on the matrix pipe
+RIG_FLOP_PER_OBS = {"poses": 210.0, "shared_intrinsics": 1230.0}
 
 
 def algorithmic_bytes_sweep(n_obs, n_frames):
@@ -63,6 +65,19 @@ def load_traffic(frames, points):
         shape = t.get("shape", {})
         if shape.get("frames") == frames and shape.get("points_per_frame") == points:
             return t.get("sweep_hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def load_rig_traffic(cams, frames, points, variant):
+    """HBM bytes per launch of the rig sweep from the committed PMC profile -- only for the profiled shape and variant."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f).get("rig_sweep", {})
+        sh = t.get("shape", {})
+        if (sh.get("cams"), sh.get("frames"), sh.get("points_per_frame"), sh.get("variant")) == (cams, frames, points, variant):
+            return t.get("hbm_bytes_per_launch")
     except Exception:
         pass
     return None
@@ -501,8 +516,9 @@ def rig_configs(capi, device):
                 "residuals_per_sec": 2.0 * n_obs * s["iterations"] / t_solve,
                 "dominant_kernel": "k_rig_sweep_adj" if variant == "poses" else "k_rig_sweep_adjk", "dominant_kernel_ms_per_launch": sweep_ms,
                 "dominant_kernel_hbm_frac": ab / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "dominant_kernel_fp64_frac": RIG_FLOP_PER_OBS * n_obs / (sweep_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                "dominant_kernel_fp64_frac": RIG_FLOP_PER_OBS[variant] * n_obs / (sweep_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                 "algorithmic_bytes_per_launch": ab,
+                "dominant_kernel_traffic": load_rig_traffic(C_, F, M, variant),
                 "kernel_ms_per_launch_eager": per_launch,
                 "kernel_ms_labels": "sweep = k_rig_sweep_adj / k_rig_sweep_adjk (per group the columns [J_cam r (J_k)] only, frame blocks "
                                     "through the group's adjoint), decide = k_rig_init (once per solve), elim = k_rig_elim, "
