@@ -797,9 +797,12 @@ __global__ __launch_bounds__(NW * 64, CC_RIG_ADJ_WAVES) void k_rig_sweep_adj(Rig
 #define CC_RIG_ADJK_WAVES 3   // waves per SIMD the sweep with intrinsics is compiled for (A/B knob)
 #endif
 constexpr int kRigCompK = 320;   // doubles per group and buffer of the compact record with intrinsics: G (256), M (36)
-__global__ __launch_bounds__(256, CC_RIG_ADJK_WAVES) void k_rig_sweep_adjk(RigDev P) {
-  constexpr int NW = 4, NT = 256;
-  __shared__ __attribute__((aligned(16))) double s_stage[NW * kStageDoublesPerWave];   // per wave 64 x 16; then the four partial products
+// NW = waves per workgroup: one when the groups alone fill the chip (every wave then amortises the prologue, the
+// cross-lane epilogue and the assembly over all passes of its group and there is no cross-wave reduction), four otherwise.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, CC_RIG_ADJK_WAVES) void k_rig_sweep_adjk(RigDev P) {
+  constexpr int NT = NW * 64, EPT = 256 / NT;
+  __shared__ __attribute__((aligned(16))) double s_stage[NW * kStageDoublesPerWave];   // per wave 64 x 16; then the partial products
   __shared__ double sm[96];        // camera record, frame record, intrinsics record (candidate [0..8], step [16..24])
   __shared__ double s_G[256];      // G
   __shared__ double s_mold[36];    // M of the accepted point
@@ -835,12 +838,17 @@ __global__ __launch_bounds__(256, CC_RIG_ADJK_WAVES) void k_rig_sweep_adjk(RigDe
   fetch(otid + NT, ob);
   const double* comp_old = P.gcomp + ((size_t)cur * P.NG + g) * kRigCompK;
   {
-    const double rec = tid < 32 ? P.camrec[c * 32 + tid] : (tid < 64 ? P.frec[(size_t)f * 32 + (tid - 32)] : P.krec[ks * 32 + ((tid - 64) & 31)]);
+    // records: camera [0..31], frame [32..63], intrinsics [64..95]; M of the accepted point
+    const double r0 = tid < 32 ? P.camrec[c * 32 + tid] : (tid < 64 ? P.frec[(size_t)f * 32 + (tid - 32)] : P.krec[ks * 32 + ((tid - 64) & 31)]);
+    const double r1 = P.krec[ks * 32 + (tid & 31)];
     const double mo = comp_old[256 + (tid < 36 ? tid : 0)];
-    if (tid < 96) sm[tid] = rec;
+    if (tid < 96) sm[tid] = r0;
+    if (NW == 1 && tid < 32) sm[64 + tid] = r1;
     if (tid < 36) s_mold[tid] = mo;
   }
-  const double g_old = comp_old[tid];
+  double g_old[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) g_old[e] = comp_old[tid + e * NT];
   __syncthreads();
   double Rca[9], tca[3], tcs[3], kk[9];
   {
@@ -865,8 +873,8 @@ __global__ __launch_bounds__(256, CC_RIG_ADJK_WAVES) void k_rig_sweep_adjk(RigDe
     const double cross = 2.0 * (sm[3 * a3 + b1] * sm[32 + 9 + b2] - sm[3 * a3 + b2] * sm[32 + 9 + b1]);
     const double v = (a < 3) == (b < 3) ? diag : (a >= 3 ? cross : 0.0);
     if (b < 6) s_m[a * 6 + b] = v;
-  } else if (tid >= 64 && tid < 80) {   // e'
-    const int t = tid - 64;
+  } else if (tid < 64) {   // e'
+    const int t = tid - 48;
     double e = t < 6 ? (fixed ? 0.0 : sm[12 + t]) : (t == 6 ? 1.0 : sm[64 + 16 + (t - 7)]);
     const int row = t < 6 ? t : 0;
 #pragma unroll
@@ -875,7 +883,13 @@ __global__ __launch_bounds__(256, CC_RIG_ADJK_WAVES) void k_rig_sweep_adjk(RigDe
   }
   __syncthreads();
   double qterm = 0.0;
-  if (phase != 0 && tid != 6 * 16 + 6) qterm = 0.5 * s_e[tid >> 4] * s_e[tid & 15] * g_old;
+  if (phase != 0) {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int t = tid + e * NT;
+      if (t != 6 * 16 + 6) qterm += 0.5 * s_e[t >> 4] * s_e[t & 15] * g_old[e];
+    }
+  }
   const double ha = P.huber_a;
   const uint32_t kmask = P.kmask[ks];
   double* stage = s_stage + wave * kStageDoublesPerWave;
@@ -932,69 +946,79 @@ __global__ __launch_bounds__(256, CC_RIG_ADJK_WAVES) void k_rig_sweep_adjk(RigDe
     widen(oa, d);
     pass(p * NT + otid, d);
   }
-  __syncthreads();
+  if (NW > 1) __syncthreads();   // (every wave done with its staging tile before the partial products overwrite them)
   {
     const int slot = (lane >> 4) * 16 + (lane & 15);
+    double* dstp = NW > 1 ? s_stage + wave * 256 : s_G;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s_stage[wave * 256 + slot + 64 * r] = acc0[r] + acc1[r];
+    for (int r = 0; r < 4; ++r) dstp[slot + 64 * r] = acc0[r] + acc1[r];
   }
   const double qw = wave_sum(qterm), cw = wave_sum(cost);
   if (lane == 0) { s_w[wave] = qw; s_w[4 + wave] = cw; }
   __syncthreads();
-  const double Gt = (s_stage[tid] + s_stage[256 + tid]) + (s_stage[512 + tid] + s_stage[768 + tid]);
-  s_G[tid] = Gt;
-  __syncthreads();
+  if (NW > 1) {
+    s_G[tid] = (s_stage[tid] + s_stage[256 + tid]) + (s_stage[512 + tid] + s_stage[768 + tid]);
+    __syncthreads();
+  }
   double* out = P.gblocks + ((size_t)dst * P.NG + g) * (size_t)P.gstride;
   const int k0 = lane >> 4, j = lane & 15;
-  if (wave < 2) {
-    const double mv0 = s_m[k0 * 6 + (j >= 6 && j < 12 ? j - 6 : 0)];
-    const double mv1 = s_m[(k0 < 2 ? k0 + 4 : 0) * 6 + (j >= 6 && j < 12 ? j - 6 : 0)];
-    const double id = fixed ? 0.0 : 1.0;
-    const double n0 = j < 6 ? (j == k0 ? id : 0.0) : (j < 12 ? mv0 : 0.0);                       // N[k0][j]
-    const double n1 = k0 < 2 ? (j < 6 ? (j == k0 + 4 ? id : 0.0) : (j < 12 ? mv1 : 0.0))       // N[k0 + 4][j]
-                             : (k0 == 2 && j == 12 ? 1.0 : 0.0);
-    const int k1 = k0 < 3 ? k0 + 4 : 0;
-    d4 B = {0.0, 0.0, 0.0, 0.0};
-    if (wave == 0) {          // AA = N^T (G7 N)
-      const int gi = j < 7 ? j : 0;
-      const double gv0 = s_G[gi * 16 + k0], gv1 = s_G[gi * 16 + k1];
-      const double a0 = j < 7 ? gv0 : 0.0, a1 = (j < 7 && k0 < 3) ? gv1 : 0.0;
-      d4 T = {0.0, 0.0, 0.0, 0.0};
-      T = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, n0, T, 0, 0, 0);
-      T = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, n1, T, 0, 0, 0);
-      B = __builtin_amdgcn_mfma_f64_16x16x4f64(n0, T[0], B, 0, 0, 0);
-      B = __builtin_amdgcn_mfma_f64_16x16x4f64(n1, T[1], B, 0, 0, 0);
-    } else {                  // AB = N^T G[0:7, 7:16]
-      const int hj = j < 9 ? 7 + j : 7;
-      const double hv0 = s_G[k0 * 16 + hj], hv1 = s_G[k1 * 16 + hj];
-      const double h0 = j < 9 ? hv0 : 0.0, h1 = (j < 9 && k0 < 3) ? hv1 : 0.0;
-      B = __builtin_amdgcn_mfma_f64_16x16x4f64(n0, h0, B, 0, 0, 0);
-      B = __builtin_amdgcn_mfma_f64_16x16x4f64(n1, h1, B, 0, 0, 0);
-    }
+  auto role = [&](int what) {
+    if (what < 2) {
+      const double mv0 = s_m[k0 * 6 + (j >= 6 && j < 12 ? j - 6 : 0)];
+      const double mv1 = s_m[(k0 < 2 ? k0 + 4 : 0) * 6 + (j >= 6 && j < 12 ? j - 6 : 0)];
+      const double id = fixed ? 0.0 : 1.0;
+      const double n0 = j < 6 ? (j == k0 ? id : 0.0) : (j < 12 ? mv0 : 0.0);                       // N[k0][j]
+      const double n1 = k0 < 2 ? (j < 6 ? (j == k0 + 4 ? id : 0.0) : (j < 12 ? mv1 : 0.0))       // N[k0 + 4][j]
+                               : (k0 == 2 && j == 12 ? 1.0 : 0.0);
+      const int k1 = k0 < 3 ? k0 + 4 : 0;
+      d4 B = {0.0, 0.0, 0.0, 0.0};
+      if (what == 0) {          // AA = N^T (G7 N)
+        const int gi = j < 7 ? j : 0;
+        const double gv0 = s_G[gi * 16 + k0], gv1 = s_G[gi * 16 + k1];
+        const double a0 = j < 7 ? gv0 : 0.0, a1 = (j < 7 && k0 < 3) ? gv1 : 0.0;
+        d4 T = {0.0, 0.0, 0.0, 0.0};
+        T = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, n0, T, 0, 0, 0);
+        T = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, n1, T, 0, 0, 0);
+        B = __builtin_amdgcn_mfma_f64_16x16x4f64(n0, T[0], B, 0, 0, 0);
+        B = __builtin_amdgcn_mfma_f64_16x16x4f64(n1, T[1], B, 0, 0, 0);
+      } else {                  // AB = N^T G[0:7, 7:16]
+        const int hj = j < 9 ? 7 + j : 7;
+        const double hv0 = s_G[k0 * 16 + hj], hv1 = s_G[k1 * 16 + hj];
+        const double h0 = j < 9 ? hv0 : 0.0, h1 = (j < 9 && k0 < 3) ? hv1 : 0.0;
+        B = __builtin_amdgcn_mfma_f64_16x16x4f64(n0, h0, B, 0, 0, 0);
+        B = __builtin_amdgcn_mfma_f64_16x16x4f64(n1, h1, B, 0, 0, 0);
+      }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = k0 + 4 * r;
-      out[wave * 256 + row * 16 + j] = B[r];
-      if (wave == 0 && phase == 0 && row < 6 && row == j) P.ghd0[g * 8 + row] = B[r];   // diag of H_cc
-    }
-  } else if (wave == 2) {     // BB = G[7:16, 7:16]
+      for (int r = 0; r < 4; ++r) {
+        const int row = k0 + 4 * r;
+        out[what * 256 + row * 16 + j] = B[r];
+        if (what == 0 && phase == 0 && row < 6 && row == j) P.ghd0[g * 8 + row] = B[r];   // diag of H_cc
+      }
+    } else if (what == 2) {     // BB = G[7:16, 7:16]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = k0 + 4 * r;
-      const bool in = row < 9 && j < 9;
-      const double gv = s_G[(in ? 7 + row : 0) * 16 + (in ? 7 + j : 0)];
-      const double val = in ? gv : 0.0;
-      out[512 + row * 16 + j] = val;
-      if (phase == 0 && row < 9 && row == j) P.ghdk[g * 16 + row] = val;   // diag of H_kk
+      for (int r = 0; r < 4; ++r) {
+        const int row = k0 + 4 * r;
+        const bool in = row < 9 && j < 9;
+        const double gv = s_G[(in ? 7 + row : 0) * 16 + (in ? 7 + j : 0)];
+        const double val = in ? gv : 0.0;
+        out[512 + row * 16 + j] = val;
+        if (phase == 0 && row < 9 && row == j) P.ghdk[g * 16 + row] = val;   // diag of H_kk
+      }
+    } else {
+      if (lane == 0) {
+        P.gstats[g * 2] = NW > 1 ? (s_w[4] + s_w[5]) + (s_w[6] + s_w[7]) : s_w[4];
+        P.gstats[g * 2 + 1] = NW > 1 ? (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]) : s_w[0];
+      }
+      if (lane < 36) P.gcomp[((size_t)dst * P.NG + g) * kRigCompK + 256 + lane] = s_m[lane];
     }
+  };
+  if (NW > 1) {
+    role(wave);
   } else {
-    if (lane == 0) {
-      P.gstats[g * 2] = (s_w[4] + s_w[5]) + (s_w[6] + s_w[7]);
-      P.gstats[g * 2 + 1] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
-    }
-    if (lane < 36) P.gcomp[((size_t)dst * P.NG + g) * kRigCompK + 256 + lane] = s_m[lane];
+    role(0); role(1); role(2); role(3);
   }
-  P.gcomp[((size_t)dst * P.NG + g) * kRigCompK + tid] = Gt;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) P.gcomp[((size_t)dst * P.NG + g) * kRigCompK + tid + e * NT] = s_G[tid + e * NT];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2609,7 +2633,8 @@ static void rig_exchange_bounds(const cc_rig* h, int* doubles_kind0, int* double
 static int rig_enqueue_round(cc_rig* h, bool initial, bool profile) {
   const RigDev& d = h->d;
   { RigProbe p(h, CC_K_SWEEP, profile);
-    if (d.kmode && h->sweep_adjoint) hipLaunchKernelGGL(k_rig_sweep_adjk, dim3((unsigned)h->NG), dim3(256), 0, h->stream, d);
+    if (d.kmode && h->sweep_adjoint && h->sweep_waves == 1) hipLaunchKernelGGL(k_rig_sweep_adjk<1>, dim3((unsigned)h->NG), dim3(64), 0, h->stream, d);
+    else if (d.kmode && h->sweep_adjoint) hipLaunchKernelGGL(k_rig_sweep_adjk<4>, dim3((unsigned)h->NG), dim3(256), 0, h->stream, d);
     else if (d.kmode) hipLaunchKernelGGL((k_rig_sweep<true, 4>), dim3((unsigned)h->NG), dim3(kRigThreads), kRigSweepLdsBytesK, h->stream, d);
     else if (h->sweep_adjoint && h->sweep_waves == 4) hipLaunchKernelGGL((k_rig_sweep_adj<4>), dim3((unsigned)h->NG), dim3(256), 0, h->stream, d);
     else if (h->sweep_adjoint && h->sweep_waves == 2) hipLaunchKernelGGL((k_rig_sweep_adj<2>), dim3((unsigned)h->NG), dim3(128), 0, h->stream, d);
@@ -2796,7 +2821,8 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
     h->sweep_waves = kmode ? 4 : ((NG >= 4096 || per_group <= 64.0) ? 1 : (NG >= 1024 ? 2 : 4));
     // (k_rig_sweep_adj: one wave per group is the fastest at every measured shape that has a thousand groups)
     if (!kmode && h->sweep_adjoint) h->sweep_waves = (NG >= 1024 || per_group <= 64.0) ? 1 : (NG >= 512 ? 2 : 4);
-    if (const char* e = getenv("CC_RIG_SWEEP_WG_WAVES")) { const int v = atoi(e); if (!kmode && (v == 1 || v == 2 || v == 4)) h->sweep_waves = v; }
+    if (kmode && h->sweep_adjoint) h->sweep_waves = (NG >= 1024 || per_group <= 64.0) ? 1 : 4;
+    if (const char* e = getenv("CC_RIG_SWEEP_WG_WAVES")) { const int v = atoi(e); if ((!kmode && (v == 1 || v == 2 || v == 4)) || (kmode && h->sweep_adjoint && (v == 1 || v == 4))) h->sweep_waves = v; }
   }
   if (int rc = dev_zeroed(h, &d.intr, 2 * CKn * 16)) return rc;
   if (int rc = dev_zeroed(h, &d.krec, CKn * 32)) return rc;
