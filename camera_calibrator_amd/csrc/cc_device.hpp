@@ -11,11 +11,42 @@ constexpr int kStageDoublesPerWave = 64 * 16;  // 64 observations x one row (u o
 
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // packed lower, i >= j
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// Cross-lane sums without the LDS crossbar (`__shfl_xor` = two ds_bpermute and a wait per step): DPP moves inside a
+// 16-lane row, and across rows the lane-swap instructions of gfx950 -- v_permlane16_swap exchanges the odd rows of its
+// first register with the even rows of the second, v_permlane32_swap lanes 32..63 of the first with lanes 0..31 of the
+// second; fed two copies of v, first + second is v + (v of the partner row / half) in every lane.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ double row_pair_sum(double v) {    // lanes l and l ^ 16
+  const auto l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+  const auto h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+  return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+__device__ __forceinline__ double half_pair_sum(double v) {   // lanes l and l ^ 32
+  const auto l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+  const auto h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+  return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+// sum over the lanes of a wave that agree in the low LOG2 bits of the lane index (LOG2 = 0: all 64), in every lane
+template <int LOG2 = 0>
+__device__ __forceinline__ double wave_sum_mod(double v) {
+  static_assert(LOG2 >= 0 && LOG2 <= 3, "strides 1, 2, 4, 8");
+#ifdef CC_SHFL_WAVE_SUM   // (A/B: the ds_bpermute butterfly)
+#pragma unroll
+  for (int o = 1 << LOG2; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+#endif
+  if (LOG2 == 0) v += dpp_f64<0xB1>(v);    // quad_perm:[1,0,3,2]
+  if (LOG2 <= 1) v += dpp_f64<0x4E>(v);    // quad_perm:[2,3,0,1]
+  if (LOG2 <= 2) v += dpp_f64<0x124>(v);   // row_ror:4
+  v += dpp_f64<0x128>(v);                  // row_ror:8
+  return half_pair_sum(row_pair_sum(v));
+}
+__device__ __forceinline__ double wave_sum(double v) { return wave_sum_mod<0>(v); }
 
 // LDS accesses of one wave execute in order; the fence only stops the compiler from moving
 // the staged-row reads above the writes of other lanes (no instruction is emitted).

@@ -428,8 +428,7 @@ __device__ __forceinline__ void reduce_frame_stats(const IntrDev& P, bool want_s
     }
   }
   // combine the 16 row groups of a wave that share a column (lane bits 2..5)
-#pragma unroll
-  for (int o = 4; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
+  a = wave_sum_mod<2>(a);
   // hd0 (initial round only): thread t -> column pair t & 7 (16-byte loads), row group t >> 3 of 32;
   // 16 loads in flight per thread, one round trip per 512 frames
   double h0 = 0.0, h1 = 0.0;
@@ -450,8 +449,8 @@ __device__ __forceinline__ void reduce_frame_stats(const IntrDev& P, bool want_s
             (((v[8].y + v[9].y) + (v[10].y + v[11].y)) + ((v[12].y + v[13].y) + (v[14].y + v[15].y)));
     }
   }
-#pragma unroll
-  for (int o = 8; o < 64; o <<= 1) { h0 += __shfl_xor(h0, o, 64); h1 += __shfl_xor(h1, o, 64); }
+  h0 = wave_sum_mod<3>(h0);
+  h1 = wave_sum_mod<3>(h1);
   if (lane < 4) s_w[wave * 16 + lane] = a;
   if (lane < 8) { s_w[64 + wave * 16 + 2 * lane] = h0; s_w[64 + wave * 16 + 2 * lane + 1] = h1; }
   if (s_in && tid < 48) s_in[tid] = word;   // the caller's gathered word rides on this barrier (k_intr_decide_elim)

@@ -556,12 +556,6 @@ __device__ __forceinline__ void reduce_swap16(double* p) {
     p[i] = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
   }
 }
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
 template <int N, int CTRL, int BIT>
 __device__ __forceinline__ void reduce_dpp(double* p, int lane) {
   const bool up = (lane & BIT) != 0;
