@@ -47,6 +47,31 @@ __device__ __forceinline__ double wave_sum_mod(double v) {
   return half_pair_sum(row_pair_sum(v));
 }
 __device__ __forceinline__ double wave_sum(double v) { return wave_sum_mod<0>(v); }
+// sum / maximum over the sixteen lanes of a row (lanes 16k .. 16k+15), in every lane
+__device__ __forceinline__ double row16_sum(double v) {
+#ifdef CC_SHFL_WAVE_SUM
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+#endif
+  v += dpp_f64<0xB1>(v);    // quad_perm:[1,0,3,2]
+  v += dpp_f64<0x4E>(v);    // quad_perm:[2,3,0,1]
+  v += dpp_f64<0x141>(v);   // row_half_mirror: the other quad of the half row
+  v += dpp_f64<0x140>(v);   // row_mirror: the other half row
+  return v;
+}
+__device__ __forceinline__ double row16_max(double v) {
+#ifdef CC_SHFL_WAVE_SUM
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+#endif
+  v = fmax(v, dpp_f64<0xB1>(v));
+  v = fmax(v, dpp_f64<0x4E>(v));
+  v = fmax(v, dpp_f64<0x141>(v));
+  v = fmax(v, dpp_f64<0x140>(v));
+  return v;
+}
 
 // LDS accesses of one wave execute in order; the fence only stops the compiler from moving
 // the staged-row reads above the writes of other lanes (no instruction is emitted).

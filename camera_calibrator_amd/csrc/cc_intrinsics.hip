@@ -912,8 +912,7 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
 #pragma unroll
   for (int r = 0; r < 5; ++r)
     if (l * 5 + r != PC_FAIL && l * 5 + r != PC_GMAXP) red[g][l * 5 + r] = acc[r];
-#pragma unroll
-  for (int o = 1; o < 16; o <<= 1) gacc = fmax(gacc, __shfl_xor(gacc, o, 64));
+  gacc = row16_max(gacc);
   if (l == 0) { red[g][PC_FAIL] = facc; red[g][PC_GMAXP] = gacc; }
   __syncthreads();
   if (tid < kPartialCols) {

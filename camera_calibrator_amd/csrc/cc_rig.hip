@@ -1079,10 +1079,7 @@ __device__ __forceinline__ void rig_update_body(const RigDev& P, int phase, int 
   }
   if (phase != 0) {   // the sixteen lanes of a frame add up their columns
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) u[i] += __shfl_xor(u[i], o, 64);
-    }
+    for (int i = 0; i < 6; ++i) u[i] = row16_sum(u[i]);
   }
   if (!valid || l != 0) return;
   bool active;
