@@ -101,3 +101,21 @@ def test_rigk_tiles_of_both_sweeps_agree(monkeypatch):
         assert scale.min() > 0
         assert (np.abs(t0[:, t] - t1[:, t]) / scale).max() < 1e-11
     assert np.abs(t0[:, 1, :, 7]).max() == 0 and np.abs(t0[:, 2, 7, :]).max() == 0    # the intrinsic held constant has no column
+
+
+@pytest.mark.parametrize("waves", [1, 4])
+@pytest.mark.parametrize("per_camera", [False, True])
+def test_rigk_sweep_workgroup_sizes_give_the_same_solve(monkeypatch, waves, per_camera):
+    """The sweep with intrinsics runs with one wave per (frame, camera) group when there are at least 1024 groups and with
+    four otherwise; either must match the oracle on a shape the heuristic would give the other (ragged last chunks: 90 and
+    300 observations per group)."""
+    from tests.test_gpu_rigk import _assert_same_pc, _both_pc
+    monkeypatch.setenv("CC_RIG_SWEEP_WG_WAVES", str(waves))
+    for cams, frames, pts in [(3, 24, 90), (2, 12, 300)]:
+        k = rigk_case(cams, frames, pts, per_camera=per_camera)
+        if per_camera:
+            g, o = _both_pc(k, huber_a=1.5)
+            _assert_same_pc(g, o)
+        else:
+            g, o = _both_k(k, const_mask=1 << 5, huber_a=1.5)
+            _assert_same_k(g, o)
