@@ -321,6 +321,12 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
     const int a = tid >> 4, b = tid & 15;
     if (a < 15) qterm = b < 15 ? 0.5 * sm[120 + a] * g_old * sm[120 + b] : sm[120 + a] * g_old;
   }
+  // reduced HERE, not next to its use behind the main loop: kept alive across the loop it was the one value that did
+  // not fit the 128 registers of four waves per SIMD (a spill: 1 KB of scratch traffic per workgroup)
+  {
+    const double qw = wave_sum(qterm);
+    if (lane == 0) sm[170 + wave] = qw;
+  }
 
   double R[9], tt[3], kk[9];
 #pragma unroll
@@ -379,8 +385,6 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
   SW_MARK(5);
 #pragma unroll
   for (int r = 0; r < 4; ++r) s_blk[wave * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc0[r] + acc1[r];
-  const double qw = wave_sum(qterm);
-  if (lane == 0) sm[170 + wave] = qw;
   __syncthreads();
   const double g = (s_blk[tid] + s_blk[256 + tid]) + (s_blk[512 + tid] + s_blk[768 + tid]);
   P.blocks[(((size_t)dst * P.F + f) * T + tile) * 256 + tid] = g;

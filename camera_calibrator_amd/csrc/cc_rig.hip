@@ -579,7 +579,7 @@ __device__ __forceinline__ void reduce_scatter32(double* p, int lane) {
 #define CC_RIG_ADJ_WAVES 4   // waves per SIMD this sweep is compiled for (A/B knob)
 #endif
 template <int NW>
-__global__ __launch_bounds__(NW * 64, CC_RIG_ADJ_WAVES) void k_rig_sweep_adj(RigDev P) {
+__global__ __launch_bounds__(NW * 64, NW == 1 ? CC_RIG_ADJ_WAVES : 3) void k_rig_sweep_adj(RigDev P) {   // (NW > 1: few, large groups -- registers rather than residency)
   constexpr int NT = NW * 64;      // threads
   __shared__ double sm[64];            // camera record [0..31], frame record [32..63]
   __shared__ double s_old[64];         // the accepted point's compact record of this group (gcomp)
