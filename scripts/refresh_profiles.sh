@@ -35,15 +35,17 @@ cp $(find $OUT/rigtrace5 -name "*kernel_stats.csv" | head -1) $OUT/rig_c5_kernel
 cd /tmp
 export C=8 F=2000 M=500
 K=shared rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rigtrace5k -- python3 $R/scripts/bench_rig.py > /dev/null 2>&1
+C=4 F=400 M=300 K=shared rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rigtrace4k -- python3 $R/scripts/bench_rig.py > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_rig_fetch -- python3 $R/scripts/bench_rig.py > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_rig_write -- python3 $R/scripts/bench_rig.py > /dev/null 2>&1
 unset C F M
 cd $R
 cp $(find $OUT/rigtrace5k -name "*kernel_stats.csv" | head -1) $OUT/rig_c5_shared_kernel_stats.csv
+cp $(find $OUT/rigtrace4k -name "*kernel_stats.csv" | head -1) $OUT/rig_c4_shared_kernel_stats.csv
 echo "counter,kernel,dispatches,mean_KB,min_KB,max_KB" > $OUT/pmc_rig_c5_summary.csv
 python scripts/pmc_summarise.py FETCH_SIZE $OUT/pmc_rig_fetch >> $OUT/pmc_rig_c5_summary.csv
 python scripts/pmc_summarise.py WRITE_SIZE $OUT/pmc_rig_write >> $OUT/pmc_rig_c5_summary.csv
-rm -rf $OUT/rigtrace5k $OUT/pmc_rig_fetch $OUT/pmc_rig_write
+rm -rf $OUT/rigtrace5k $OUT/rigtrace4k $OUT/pmc_rig_fetch $OUT/pmc_rig_write
 # both formulations of the rig sweep and its workgroup sizes, same box
 bash scripts/ab_rig_sweep.sh > /dev/null 2>&1 && cp gpurun_out/ab_rig_sweep.txt $OUT/rig_sweep_ab.txt
 echo "rig done"
