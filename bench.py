@@ -20,7 +20,8 @@ HBM over xGMI, RCCL as the fallback).  The same line also carries `strong_scalin
 exactly as written, the FIXED 1000 x 500 problem split N ways.
 
 At N=1 the line additionally carries `configs` (BASELINE.json configs[3], configs[4]: the rig path at full
-size, poses only = the reference's problem, and with the shared-intrinsics extension) and `cpu_baseline`.
+size, poses only = the reference's problem, with the shared-intrinsics extension and, at configs[4] size, with one set
+of intrinsics per camera) and `cpu_baseline`.
 """
 import argparse
 import json
@@ -41,7 +42,7 @@ FLOP_PER_OBS = 800.0       # ~0.8 kflop fp64 per observation and
 # fp64 flops the rig sweeps EXECUTE per observation (counted in the ISA of the main loops): poses only, k_rig_sweep_adj --
 # composed pose chain, projection, division, Huber test, two 7-entry rows, 42 FMAs of the 7-column Gram; with intrinsics,
 # k_rig_sweep_adjk -- ~200 of pixel model and rows + 1024 of the 16 x 16 product of two rows on the matrix pipe
-RIG_FLOP_PER_OBS = {"poses": 210.0, "shared_intrinsics": 1230.0}
+RIG_FLOP_PER_OBS = {"poses": 210.0, "shared_intrinsics": 1230.0, "per_camera_intrinsics": 1230.0}
 
 
 def algorithmic_bytes_sweep(n_obs, n_frames):
@@ -473,7 +474,7 @@ def rig_configs(capi, device):
     from camera_calibrator_amd import harness
     out = {}
     for name, (C_, F, M) in (("rig_c4", (4, 400, 300)), ("rig_c5", (8, 2000, 500))):
-        for variant in ("poses", "shared_intrinsics"):
+        for variant in ("poses", "shared_intrinsics") + (("per_camera_intrinsics",) if name == "rig_c5" else ()):
             if variant == "poses":
                 sc = capi.rig_scenario(C_, F, M)
                 cq, ct = capi.affine_to_qt(sc["cam_T"])
@@ -484,12 +485,17 @@ def rig_configs(capi, device):
             else:
                 # extension: pixel observations of a rig through the fixture camera of test_calibrator.cpp:14-19
                 # (camera_calibrator_amd/harness.py, the scenario of the parity tests)
-                k = harness.rigk_case(C_, F, M)
+                per_cam = variant == "per_camera_intrinsics"     # configs[4]: "full intrinsics+extrinsics co-optimisation"
+                k = harness.rigk_case(C_, F, M, per_camera=per_cam)
                 cq, ct, fq, ft = k["cam_q0"], k["cam_t0"], k["frame_q0"], k["frame_t0"]
                 n_obs, n_world = len(k["obs_cam"]), len(k["world_xyz"])
                 prob = capi.RigProblem(C_, k["frame_offsets"], k["obs_cam"], k["obs_world"], k["obs_uv_pix"], k["world_xyz"],
-                                       k["cam_frozen"], huber_a=0.0, device=device, with_intrinsics=True)
-                prob.set_intrinsics(k["intr0"], 0)
+                                       k["cam_frozen"], huber_a=0.0, device=device, with_intrinsics="per_camera" if per_cam else True)
+                if per_cam:
+                    for c in range(C_):
+                        prob.set_camera_intrinsics(c, k["intr0"][c], 0)
+                else:
+                    prob.set_intrinsics(k["intr0"], 0)
             prob.set_state(cq, ct, fq, ft)
             o = capi.default_options(max_iterations=1000)
             s = prob.solve(o, log_capacity=0)
