@@ -122,6 +122,7 @@ struct RigDev {
   double huber_a;
   // EXTENSION: intrinsics in the shared block, pixel observations. kmode 0: off.
   int32_t kmode, gstride;
+  int32_t init_slices;   // blocks of k_rig_init that share the diagonal sums of a set of intrinsics common to all cameras
   const uint32_t* kmask;  // [max(CK,1)] bit i: intrinsic i of the set is held constant
   double* intr;       // [2][max(CK,1)][16]
   double* krec;       // [max(CK,1)][32]: candidate intrinsics [0..8], unscaled step [16..24]
@@ -1195,7 +1196,7 @@ __device__ __forceinline__ void rig_reduce_stats(const RigDev& P, bool want, dou
 // same groups, so a run is reduced together: the group indices of four steps are fetched first, then their values (two
 // round trips per 1024 groups and run, fixed summation order). The first version walked one column at a time with a
 // dependent index -> value load pair per step: 138 us for BASELINE configs[4], once per solve.
-__device__ __forceinline__ void rig_diag_sums(const RigDev& P, double* s4, double* out, int only_run = -1) {
+__device__ __forceinline__ void rig_diag_sums(const RigDev& P, double* s4, double* out, int only_run = -1, int slice = 0, int nslices = 1) {
   const int tid = threadIdx.x;
   int run = 0;
   for (int k = 0; k < P.S; ++run) {
@@ -1206,6 +1207,11 @@ __device__ __forceinline__ void rig_diag_sums(const RigDev& P, double* s4, doubl
     const int stride = kind == 0 ? 8 : 16;
     int64_t lo = 0, hi = P.NG;
     if (kind != 2) { const int c = P.obs_cam[co]; lo = P.cam_goff[c]; hi = P.cam_goff[c + 1]; }
+    else if (nslices > 1) {   // (k_rig_init: a set shared by all cameras is summed by several blocks, each over a slice of the groups)
+      const int64_t len = (P.NG + nslices - 1) / nslices;
+      lo = (int64_t)slice * len < P.NG ? (int64_t)slice * len : P.NG;
+      hi = lo + len < P.NG ? lo + len : P.NG;
+    }
     double h[kRigK];
 #pragma unroll
     for (int c = 0; c < kRigK; ++c) h[c] = 0.0;
@@ -1316,11 +1322,39 @@ __global__ __launch_bounds__(256) void k_rig_init(RigDev P) {
   // block doing all runs took 130 us at BASELINE configs[4]: tens of thousands of scattered 8-byte loads through one CU.)
   if (blockIdx.x > 0) {
     if (P.comm) return;
+    // which run, and which slice of it (a set of intrinsics shared by all cameras sums over EVERY group: 16000 at
+    // BASELINE configs[4], 61 us in one block; init_slices blocks take a slice each and the last one to arrive adds the
+    // partial sums up in slice order)
+    int b = (int)blockIdx.x - 1, run = 0, slice = 0, ns = 1, k0 = 0;
+    for (int k = 0; k < P.S; ++run) {
+      const int kind = (P.colinfo[k] >> 4) & 15;
+      const int cnt = kind == 2 ? P.init_slices : 1;
+      if (b < cnt) { slice = b; ns = cnt; k0 = k; break; }
+      b -= cnt;
+      k += kind == 0 ? 6 : kRigK;
+    }
     for (int k = tid; k < kRigMaxS + 1; k += 256) s_ss[k] = -1.0;
     __syncthreads();
-    rig_diag_sums(P, s4, s_ss, (int)blockIdx.x - 1);
-    for (int k = tid; k < P.S; k += 256)
-      if (s_ss[k] >= 0.0) P.ss[k] = jac ? 1.0 / (1.0 + sqrt(s_ss[k])) : 1.0;
+    rig_diag_sums(P, s4, s_ss, run, slice, ns);
+    if (ns == 1) {
+      for (int k = tid; k < P.S; k += 256)
+        if (s_ss[k] >= 0.0) P.ss[k] = jac ? 1.0 / (1.0 + sqrt(s_ss[k])) : 1.0;
+      return;
+    }
+    __shared__ int s_last_slice;
+    unsigned long long* part = reinterpret_cast<unsigned long long*>(P.partial);   // (free until the first elimination)
+    if (tid < kRigK) __hip_atomic_store(part + slice * 16 + tid, (unsigned long long)__double_as_longlong(s_ss[k0 + tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_last_slice = __hip_atomic_fetch_add(P.arrive + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (unsigned)ns;
+    __syncthreads();
+    if (!s_last_slice) return;
+    if (tid == 0) __hip_atomic_store(P.arrive + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next solve
+    if (tid < kRigK) {
+      double t = 0.0;
+      for (int q = 0; q < ns; ++q) t += __longlong_as_double((long long)__hip_atomic_load(part + q * 16 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      P.ss[k0 + tid] = jac ? 1.0 / (1.0 + sqrt(t)) : 1.0;
+    }
     return;
   }
   if (P.comm) {
@@ -2368,6 +2402,7 @@ struct cc_rig {
   cc::RigDev d{};
   int64_t C = 0, F = 0, N = 0, NG = 0, P = 0;
   int n_runs = 0;            // runs of shared columns (one per optimised camera, one per intrinsics set): blocks of k_rig_init
+  int n_shared_runs = 0;     // of which sets of intrinsics common to all cameras (summed by init_slices blocks each)
   int sweep_waves = 4;       // waves per workgroup of the poses-only sweep (2: small groups that outnumber the slots)
   bool sweep_adjoint = true; // poses-only sweep: 7-column Gram + per-group assembly (k_rig_sweep_adj); CC_RIG_SWEEP_MFMA=1: the 13-column matrix-pipe sweep
   int kmode = 0;
@@ -2568,7 +2603,8 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
   if (int rc = dev_upload(h, &d.kscol, kscol)) return rc;
   if (int rc = dev_upload(h, &d.obs_cam, obs_cam)) return rc;
   h->n_runs = 0;
-  for (int32_t info : colinfo) if ((info & 15) == 0 && ((info >> 4) & 15) < 3) ++h->n_runs;
+  h->n_shared_runs = 0;
+  for (int32_t info : colinfo) if ((info & 15) == 0 && ((info >> 4) & 15) < 3) { ++h->n_runs; if (((info >> 4) & 15) == 2) ++h->n_shared_runs; }
   if (int rc = dev_upload(h, &d.colinfo, colinfo)) return rc;
   if (int rc = dev_upload(h, &d.dmap, dmap)) return rc;
   {
@@ -2637,7 +2673,7 @@ static int rig_enqueue_round(cc_rig* h, bool initial, bool profile) {
     { RigProbe p(h, CC_K_DECIDE, profile); hipLaunchKernelGGL(k_rig_stats, dim3(1), dim3(256), 0, h->stream, d); }
     if (h->comm) { RigProbe p(h, CC_K_ALLREDUCE, profile); if (int rc = comm_allreduce_sum(h->comm, d.vec_stats, 4 + d.S, h->stream)) return rc; }
   }
-  if (initial) { RigProbe p(h, CC_K_DECIDE, profile); hipLaunchKernelGGL(k_rig_init, dim3(1 + (unsigned)h->n_runs), dim3(256), 0, h->stream, d); }
+  if (initial) { RigProbe p(h, CC_K_DECIDE, profile); hipLaunchKernelGGL(k_rig_init, dim3(1 + (unsigned)h->n_runs + (unsigned)h->n_shared_runs * (unsigned)(d.init_slices - 1)), dim3(256), 0, h->stream, d); }
   { RigProbe p(h, CC_K_ELIM, profile);
     const bool small = d.ND <= 8 * 64;
     if (d.kmode && small) hipLaunchKernelGGL((k_rig_elim<true, 8>), dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d);
@@ -2775,6 +2811,7 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   d.huber_a = (kmode && !(huber_a > 0.0)) ? 1e300 : huber_a;   // extension: a <= 0 switches the loss off
   d.comm = 0; d.rank = 0; d.nranks = 1;
   d.kmode = kmode; d.gstride = kmode ? 768 : 256;
+  d.init_slices = (int32_t)std::min<int64_t>(16, std::max<int64_t>(1, (NG + 511) / 512));
   { const float* p; if (int rc = dev_upload(h, &p, uv)) return rc; d.uv = p; }
   if (int rc = dev_upload(h, &d.widx, widx)) return rc;
   {
