@@ -2096,40 +2096,58 @@ __device__ void rig_solve_block(const RigDev& P, double* smem) {
 #endif
       const int t0 = j0 + nc;
 #ifndef CC_CHOL_TRAIL_VALU
-      if (t0 < S) {
+      if (t0 < S && S > 64) {
+        // (large systems only -- cameras with their own intrinsics; for S <= 64 the element-wise form below is as fast
+        // or faster: S = 18, 48.7 vs 49.6 us per iteration)
         // trailing update A[t0.., t0..] -= P P^T (P = the panel's columns, rows t0..S-1) ON THE MATRIX PIPE: the lower
         // 16 x 16 tiles of the trailing triangle are dealt to the four waves, two v_mfma_f64_16x16x4_f64 per tile (k = 8
         // panel columns); per element 3 LDS operations instead of the 18 of the element-wise form below (S = 114: the
         // trailing updates were a third of the solve step).
         const int nt = S - t0, n16 = (nt + 15) >> 4, ntile = n16 * (n16 + 1) / 2;
         const int wv = tid >> 6, ln = tid & 63, kq = ln >> 4, c16 = ln & 15;
-        for (int t = wv; t < ntile; t += 4) {
-          int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-          while (ti * (ti + 1) / 2 > t) --ti;
-          while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-          const int tj = t - ti * (ti + 1) / 2;
-          const int R = t0 + 16 * ti, Cc = t0 + 16 * tj;
-          const bool ina = R + c16 < S, inb = Cc + c16 < S;
-          const int ra = ina ? R + c16 : S - 1, rb = inb ? Cc + c16 : S - 1;      // (unconditional loads, then selects)
-          const double xa0 = A[(size_t)ra * LD + j0 + kq], xa1 = A[(size_t)ra * LD + j0 + 4 + kq];
-          const double xb0 = A[(size_t)rb * LD + j0 + kq], xb1 = A[(size_t)rb * LD + j0 + 4 + kq];
-          const double a0 = (ina && kq < nc) ? xa0 : 0.0, a1 = (ina && 4 + kq < nc) ? xa1 : 0.0;
-          const double b0m = (inb && kq < nc) ? xb0 : 0.0, b1m = (inb && 4 + kq < nc) ? xb1 : 0.0;
-          d4 T = {0.0, 0.0, 0.0, 0.0};
-          T = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0m, T, 0, 0, 0);
-          T = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1m, T, 0, 0, 0);
+        // two tiles per round: every LDS read of both (operands and the elements to update) is issued before the first
+        // matrix instruction -- one LDS round trip and one matrix-pipe latency per pair instead of per tile
+        for (int tb = wv; tb < ntile; tb += 8) {
+          double a0[2], a1[2], b0m[2], b1m[2], old[2][4];
+          int at[2][4];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int t = tb + 4 * u;
+            const bool live = t < ntile;
+            const int tc = live ? t : 0;
+            int ti = (int)((sqrtf(8.0f * (float)tc + 1.0f) - 1.0f) * 0.5f);
+            ti = ti * (ti + 1) / 2 > tc ? ti - 1 : ti;
+            ti = (ti + 1) * (ti + 2) / 2 <= tc ? ti + 1 : ti;
+            const int tj = tc - ti * (ti + 1) / 2;
+            const int R = t0 + 16 * ti, Cc = t0 + 16 * tj;
+            const bool ina = live && R + c16 < S, inb = live && Cc + c16 < S;
+            const int ra = ina ? R + c16 : S - 1, rb = inb ? Cc + c16 : S - 1;      // (unconditional loads, then selects)
+            const double xa0 = A[(size_t)ra * LD + j0 + kq], xa1 = A[(size_t)ra * LD + j0 + 4 + kq];
+            const double xb0 = A[(size_t)rb * LD + j0 + kq], xb1 = A[(size_t)rb * LD + j0 + 4 + kq];
+            a0[u] = (ina && kq < nc) ? xa0 : 0.0; a1[u] = (ina && 4 + kq < nc) ? xa1 : 0.0;
+            b0m[u] = (inb && kq < nc) ? xb0 : 0.0; b1m[u] = (inb && 4 + kq < nc) ? xb1 : 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = R + kq + 4 * r, col = Cc + c16;
+              at[u][r] = (live && row < S && col <= row) ? row * LD + col : -1;
+              old[u][r] = A[at[u][r] >= 0 ? at[u][r] : 0];
+            }
+          }
+          d4 T0 = {0.0, 0.0, 0.0, 0.0}, T1 = {0.0, 0.0, 0.0, 0.0};
+          T0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], b0m[0], T0, 0, 0, 0);
+          T1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], b0m[1], T1, 0, 0, 0);
+          T0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[0], b1m[0], T0, 0, 0, 0);
+          T1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[1], b1m[1], T1, 0, 0, 0);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int row = R + kq + 4 * r, col = Cc + c16;
-            const bool in = row < S && col <= row;
-            const int at = in ? row * LD + col : 0;
-            const double old = A[at];
-            if (in) A[at] = old - T[r];
+            if (at[0][r] >= 0) A[at[0][r]] = old[0][r] - T0[r];
+            if (at[1][r] >= 0) A[at[1][r]] = old[1][r] - T1[r];
           }
         }
-      }
+      } else if (t0 < S) {
 #else
       if (t0 < S) {
+#endif
         // trailing triangle rows t0..S-1, columns t0..row, as a flat list of elements dealt to the threads three at a
         // time: all LDS reads of a batch are issued before its first write (the elements are distinct and none lies
         // in the panel's columns, which the compiler cannot know), so a batch costs one LDS round trip, not three
@@ -2169,7 +2187,6 @@ __device__ void rig_solve_block(const RigDev& P, double* smem) {
             if (at[u] >= 0) A[at[u]] = acc[u];
         }
       }
-#endif
       __syncthreads();
 #ifdef CC_RIG_TIMING
       tt += wall_clock64() - tb;

@@ -9,9 +9,22 @@ import torch  # noqa: F401
 from camera_calibrator_amd import capi
 
 Cc, F, M = int(os.environ.get("C", 4)), int(os.environ.get("F", 400)), int(os.environ.get("M", 300))
-sc = capi.rig_scenario(Cc, F, M)
-cq, ct = capi.affine_to_qt(sc["cam_T"]); fq, ft = capi.affine_to_qt(sc["frame_T"])
-prob = capi.RigProblem(Cc, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"], sc["world_xyz"], sc["cam_frozen"])
+K = os.environ.get("K", "none")     # none | shared | per_camera (the intrinsics extension)
+if K == "none":
+    sc = capi.rig_scenario(Cc, F, M)
+    cq, ct = capi.affine_to_qt(sc["cam_T"]); fq, ft = capi.affine_to_qt(sc["frame_T"])
+    prob = capi.RigProblem(Cc, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"], sc["world_xyz"], sc["cam_frozen"])
+else:
+    from camera_calibrator_amd import harness
+    k = harness.rigk_case(Cc, F, M, per_camera=K == "per_camera")
+    cq, ct, fq, ft = k["cam_q0"], k["cam_t0"], k["frame_q0"], k["frame_t0"]
+    prob = capi.RigProblem(Cc, k["frame_offsets"], k["obs_cam"], k["obs_world"], k["obs_uv_pix"], k["world_xyz"], k["cam_frozen"], huber_a=0.0,
+                           with_intrinsics=True if K == "shared" else "per_camera")
+    if K == "shared":
+        prob.set_intrinsics(k["intr0"], 0)
+    else:
+        for c in range(Cc):
+            prob.set_camera_intrinsics(c, k["intr0"][c], 0)
 prob.set_state(cq, ct, fq, ft)
 rows, erows, swrows = [], [], []
 for _ in range(5):
@@ -37,4 +50,4 @@ print(json.dumps({"kernel": "k_rig_sweep (middle workgroup, from the records bar
                   **{n: round(float(v), 2) for n, v in zip(["model-cost term + rotation setup", "first pass", "remaining passes", "cross-wave reduction + block store"], swd)}}))
 print(json.dumps({"kernel": "k_rig_elim (block 0)", "cams": Cc, "frames": F, "pts": M, "total_us": float(ed.sum()),
                   **{n: round(float(v), 2) for n, v in zip(enames, ed)}}))
-print(json.dumps({"kernel": "k_rig_reduce (solving block)", "cams": Cc, "frames": F, "pts": M, "total_us": float(d[:7].sum()), **{n: round(float(v), 2) for n, v in zip(names, d)}}))
+print(json.dumps({"kernel": "k_rig_reduce (solving block)", "cams": Cc, "frames": F, "pts": M, "intrinsics": K, "total_us": float(d[:7].sum()), **{n: round(float(v), 2) for n, v in zip(names, d)}}))
