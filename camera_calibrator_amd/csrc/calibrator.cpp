@@ -52,7 +52,13 @@ void Calibrator::Estimate(const std::vector<Points2D>& pixels_per_view, const st
     cc_summary summary{};
     last_status_ = cc_intrinsics_estimate(&options, device_, (int64_t)n_img, offsets.data(), uv.data(), xyz.data(), dist5, frozen,
                                           K9, intr, qd.data(), td.data(), &summary);
-    if (last_status_ != 0) throw std::runtime_error(std::string("Calibrator::Estimate: ") + cc_last_error());
+    // Same contract as the two-step path below: environment errors (no device, HIP, exchange) and the Zhang
+    // preconditions (cc_zhang_init's CC_ERR_BAD_ARGUMENT: < 3 frames, < 4 points in a frame) throw; a solver-level
+    // status (CC_ERR_STATE: the LM loop gave up) does not -- it goes to LastStatus() as Optimize() documents, and the
+    // class holds Zhang's K plus whatever point the solver reached, as after cc_zhang_init + Optimize. The
+    // reference's Estimate never throws (calibrator.cpp:47-68).
+    if (last_status_ == CC_ERR_NO_DEVICE || last_status_ == CC_ERR_HIP || last_status_ == CC_ERR_COMM || last_status_ == CC_ERR_BAD_ARGUMENT)
+      throw std::runtime_error(std::string("Calibrator::Estimate: ") + cc_last_error());
     last_iterations_ = summary.iterations;
     last_final_cost_ = summary.final_cost;
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) camera_matrix_(r, c) = K9[r * 3 + c];

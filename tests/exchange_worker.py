@@ -10,13 +10,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def rig_main(rank, world, frames, pts, out, dist, capi):
-    """argv[7] = "rig:<cams>" (the reference's rig problem) or "rigk:<cams>" (extension: + shared intrinsics)."""
+    """argv[7] = "rig:<cams>" (the reference's rig problem), "rigk:<cams>" (extension: + shared intrinsics) or
+    "rigkpc:<cams>" (extension: + one set of intrinsics per camera)."""
     from oracle import pyoracle as po      # scenario generator only (test input)
     with_k = sys.argv[7].startswith("rigk")
+    per_cam = sys.argv[7].startswith("rigkpc")
     cams = int(sys.argv[7].split(":")[1])
     if with_k:
         from tests.helpers import rigk_case
-        k = rigk_case(cams, frames, pts)
+        k = rigk_case(cams, frames, pts, per_camera=per_cam)
         sc = dict(frame_offsets=k["frame_offsets"], obs_cam=k["obs_cam"], obs_world=k["obs_world"], obs_uv=k["obs_uv_pix"],
                   world_xyz=k["world_xyz"], cam_frozen=k["cam_frozen"])
         cq, ct, fq, ft = k["cam_q0"], k["cam_t0"], k["frame_q0"], k["frame_t0"]
@@ -29,8 +31,12 @@ def rig_main(rank, world, frames, pts, out, dist, capi):
     f0, f1 = int(first[rank]), int(first[rank + 1])
     o0, o1 = int(off[f0]), int(off[f1])
     prob = capi.RigProblem(cams, off[f0:f1 + 1] - o0, sc["obs_cam"][o0:o1], sc["obs_world"][o0:o1], sc["obs_uv"][o0:o1],
-                           sc["world_xyz"], sc["cam_frozen"], **(dict(huber_a=0.0, with_intrinsics=True) if with_k else {}))
-    if with_k:
+                           sc["world_xyz"], sc["cam_frozen"],
+                           **(dict(huber_a=0.0, with_intrinsics="per_camera" if per_cam else True) if with_k else {}))
+    if per_cam:
+        for c in range(cams):
+            prob.set_camera_intrinsics(c, k["intr0"][c], 1 << 8)
+    elif with_k:
         prob.set_intrinsics(k["intr0"], 1 << 8)
     prob.set_state(cq, ct, fq[f0:f1], ft[f0:f1])
     handles = [None] * world
@@ -47,7 +53,7 @@ def rig_main(rank, world, frames, pts, out, dist, capi):
         res[name + "_iters"] = np.array(s["iterations"])
         res[name + "_termname"] = np.array(s["termination"])
         if with_k:
-            res[name + "_intr"] = prob.get_intrinsics()
+            res[name + "_intr"] = prob.get_camera_intrinsics() if per_cam else prob.get_intrinsics()
     dist.barrier()
     prob.close()
     np.savez(out, f0=f0, f1=f1, o0=o0, o1=o1, **res)

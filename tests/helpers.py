@@ -24,3 +24,22 @@ def block_rel_err(a, b):
 TIGHT = dict(function_tolerance=1e-15, gradient_tolerance=1e-13, parameter_tolerance=1e-14, max_iterations=60)
 
 
+
+
+def rig_outlier_case(cams, frames, pts, frac=0.10, seed=1, lo=0.02, hi=0.06):
+    """The reference's rig test scenario (test_extrinsics_calibrator.cpp:48-134, through the oracle's generator) with
+    PLANTED OUTLIERS: a fraction `frac` of the normalised image points is displaced by +-U(lo, hi) per axis, several
+    times the Huber constant a = 3/500 (extrinsics_calibrator.cpp:175-176), so that those residuals sit in the linear
+    tail of the loss AT THE MINIMISER (in the plain scenario the noise is +-0.004 per axis and no residual does).
+    Returns the scenario dict plus `outlier` (bool per observation) and the initial poses as quaternion/translation."""
+    sc = po.rig_scenario(cams, frames, pts)
+    rng = np.random.default_rng(seed)
+    n = len(sc["obs_cam"])
+    outlier = rng.random(n) < frac
+    shift = rng.uniform(lo, hi, size=(n, 2)) * rng.choice([-1.0, 1.0], size=(n, 2))
+    uv = sc["obs_uv"].astype(np.float64)
+    uv[outlier] += shift[outlier]
+    sc = dict(sc, obs_uv=uv.astype(np.float32), outlier=outlier)
+    sc["cam_q0"], sc["cam_t0"] = po.affine_to_qt(sc["cam_T"])
+    sc["frame_q0"], sc["frame_t0"] = po.affine_to_qt(sc["frame_T"])
+    return sc

@@ -153,3 +153,34 @@ def test_sharded_rig_with_intrinsics_over_the_mailbox_exchange(world, cams, fram
             assert np.abs(r[name + "_cam_t"] - ref[1]).max() < 1e-8
             f0, f1 = int(r["f0"]), int(r["f1"])
             assert np.abs(r[name + "_frame_t"] - ref[3][f0:f1]).max() < 1e-7
+
+
+def test_three_ranks_with_per_camera_intrinsics_share_one_gpu_without_starving_each_other(tmp_path):
+    """Round 2's hang, as a test: the fused reduce + solve + update launch of the rig path keeps its blocks spinning until
+    the launch's solving block has run, and with 114 shared coordinates (8 cameras with intrinsics of their own) that
+    launch holds 110 KB of LDS per block -- one block per CU. Three ranks on one GPU asking for 128 blocks each do not
+    fit 256 CUs: the spinning blocks of one rank kept another rank's solving block off the chip and the solve ended in
+    a 10 s timeout. The grid is now sized from the occupancy query and the ranks sharing the device
+    (rig_size_reduce_grid); a wait that does time out is reported as CC_ERR_COMM instead of being passed over."""
+    from tests.helpers import rigk_case
+    world, cams, frames, pts = 3, 8, 45, 12
+    ranks = _run_ranks(world, frames, pts, tmp_path, extra=(f"rigkpc:{cams}",))
+    k = rigk_case(cams, frames, pts, per_camera=True)
+    prob = capi.RigProblem(cams, k["frame_offsets"], k["obs_cam"], k["obs_world"], k["obs_uv_pix"], k["world_xyz"], k["cam_frozen"],
+                           huber_a=0.0, with_intrinsics="per_camera")
+    for c in range(cams):
+        prob.set_camera_intrinsics(c, k["intr0"][c], 1 << 8)
+    prob.set_state(k["cam_q0"], k["cam_t0"], k["frame_q0"], k["frame_t0"])
+    s = prob.solve(capi.default_options(max_iterations=1000))
+    intr = prob.get_camera_intrinsics()
+    ref = prob.get_state()
+    prob.close()
+    for name in ("default", "nograph"):
+        for r in ranks:
+            assert np.array_equal(r[name + "_intr"], ranks[0][name + "_intr"]) and np.array_equal(r[name + "_cam_t"], ranks[0][name + "_cam_t"])
+            assert str(r[name + "_termname"]) == s["termination"] and int(r[name + "_iters"]) == s["iterations"]
+            assert np.allclose(r[name + "_costs"], [l["cost"] for l in s["log"]], rtol=1e-9)
+            assert np.allclose(r[name + "_intr"][:, :4], intr[:, :4], rtol=1e-8) and np.allclose(r[name + "_intr"][:, 4:], intr[:, 4:], atol=1e-7)
+            assert np.abs(r[name + "_cam_t"] - ref[1]).max() < 1e-7
+            f0, f1 = int(r["f0"]), int(r["f1"])
+            assert np.abs(r[name + "_frame_t"] - ref[3][f0:f1]).max() < 1e-7

@@ -30,9 +30,9 @@ def _assert_same(g, o):
     assert sg["termination"] == so["termination"] and sg["iterations"] == so["iterations"]
     assert [l["accepted"] for l in sg["log"]] == [l["accepted"] for l in so["log"]]
     assert np.allclose([l["cost"] for l in sg["log"]], [l["cost"] for l in so["log"]], rtol=1e-9)
-    assert np.allclose(g[0][:4], o[0][:4], rtol=1e-9) and np.allclose(g[0][4:], o[0][4:], atol=1e-8)
+    assert np.allclose(g[0][:4], o[0][:4], rtol=1e-11) and np.allclose(g[0][4:], o[0][4:], atol=1e-11)   # (measured <= 5e-14: profiles/r03/rigk_deviation.jsonl)
     for a in range(1, 5):
-        assert np.abs(g[a] - o[a]).max() < 1e-8
+        assert np.abs(g[a] - o[a]).max() < 1e-11
     assert np.allclose(g[5], o[5], rtol=1e-6, atol=1e-12)
 
 
@@ -101,12 +101,12 @@ def test_rigk_c5_full_size_against_the_committed_oracle_result_and_properties():
     assert np.allclose([l["cost"] for l in s1["log"]], gld["costs"], rtol=1e-9)
     assert np.isclose(s1["initial_cost"], float(gld["initial_cost"]), rtol=1e-10)
     assert np.isclose(s1["final_cost"], float(gld["final_cost"]), rtol=1e-10)
-    assert np.allclose(intr[:4], gld["intr"][:4], rtol=1e-9) and np.allclose(intr[4:], gld["intr"][4:], atol=1e-8)
-    assert np.abs(r1[0] - gld["cam_q"]).max() < 1e-8 and np.abs(r1[1] - gld["cam_t"]).max() < 1e-8
+    assert np.allclose(intr[:4], gld["intr"][:4], rtol=1e-11) and np.allclose(intr[4:], gld["intr"][4:], atol=1e-11)
+    assert np.abs(r1[0] - gld["cam_q"]).max() < 1e-11 and np.abs(r1[1] - gld["cam_t"]).max() < 1e-11
     pick = gld["frame_pick"]
-    assert np.abs(r1[2][pick] - gld["frame_q"]).max() < 1e-8 and np.abs(r1[3][pick] - gld["frame_t"]).max() < 1e-8
-    assert np.allclose(r1[4][:64], gld["obs_cost_head"], rtol=1e-6, atol=1e-12)
-    assert np.isclose(r1[4].sum(), float(gld["obs_cost_sum"]), rtol=1e-9)
+    assert np.abs(r1[2][pick] - gld["frame_q"]).max() < 1e-11 and np.abs(r1[3][pick] - gld["frame_t"]).max() < 1e-11
+    assert np.allclose(r1[4][:64], gld["obs_cost_head"], rtol=1e-8, atol=1e-12)
+    assert np.isclose(r1[4].sum(), float(gld["obs_cost_sum"]), rtol=1e-11)
     # properties
     assert np.array_equal(r1[0][0], k["cam_q0"][0]) and np.array_equal(r1[1][0], k["cam_t0"][0])
     assert np.isclose(r1[4].sum(), s1["final_cost"], rtol=1e-9) and r1[4].shape == (8_000_000,)
@@ -118,6 +118,15 @@ def test_rigk_c5_full_size_against_the_committed_oracle_result_and_properties():
 
 
 # ---- one set of intrinsics per camera (cc_rigk_create_per_camera) ----
+
+# Tolerances of the per-camera variant against the oracle (measured deviations: scripts/rigk_deviation.py,
+# profiles/r03/rigk_deviation.jsonl).
+# Largest deviations seen over five shapes up to 8 x 2000 x 500 (S = 114): focal lengths / principal point 2.4e-14
+# relative, distortion 8.2e-14, poses 1.5e-14, per-observation costs 4.7e-10 relative, per-iteration costs 8.2e-13 --
+# the rounding floor of a different summation order, nothing more: the 1e-7 / 1e-8 the round-2 tests allowed were
+# simply loose. (The problem is well conditioned at that level: a 2-ulp perturbation of the initial intrinsics moves
+# the oracle's own answer by 1e-14, tests/test_oracle_rigk.py.)
+PC_TOL = dict(intr_rel=1e-11, dist_abs=1e-11, pose=1e-11, obs_cost_rel=1e-8)
 
 def _both_pc(k, const_masks=None, huber_a=0.0, **kw):
     prob = capi.RigProblem(k["cams"], k["frame_offsets"], k["obs_cam"], k["obs_world"], k["obs_uv_pix"], k["world_xyz"],
@@ -134,15 +143,19 @@ def _both_pc(k, const_masks=None, huber_a=0.0, **kw):
     return g, o
 
 
-def _assert_same_pc(g, o):
+PC_TOL_HUBER = dict(intr_rel=1e-9, dist_abs=1e-9, pose=1e-9, obs_cost_rel=1e-6)   # (robust loss active: not measured separately)
+
+
+def _assert_same_pc(g, o, tol=None):
+    tol = tol or PC_TOL
     sg, so = g[6], o[6]
     assert sg["termination"] == so["termination"] and sg["iterations"] == so["iterations"]
     assert [l["accepted"] for l in sg["log"]] == [l["accepted"] for l in so["log"]]
     assert np.allclose([l["cost"] for l in sg["log"]], [l["cost"] for l in so["log"]], rtol=1e-9)
-    assert np.allclose(g[0][:, :4], o[0][:, :4], rtol=1e-8) and np.allclose(g[0][:, 4:], o[0][:, 4:], atol=1e-7)
+    assert np.allclose(g[0][:, :4], o[0][:, :4], rtol=tol["intr_rel"]) and np.allclose(g[0][:, 4:], o[0][:, 4:], atol=tol["dist_abs"])
     for a in range(1, 5):
-        assert np.abs(g[a] - o[a]).max() < 1e-7
-    assert np.allclose(g[5], o[5], rtol=1e-5, atol=1e-11)
+        assert np.abs(g[a] - o[a]).max() < tol["pose"]
+    assert np.allclose(g[5], o[5], rtol=tol["obs_cost_rel"], atol=1e-11)
 
 
 @pytest.mark.parametrize("cams,frames,pts", [(2, 60, 20), (3, 150, 40), (8, 60, 60), (1, 40, 20)])
@@ -155,7 +168,7 @@ def test_rigk_per_camera_masks_huber_and_an_unobserved_camera():
     k = rigk_case(3, 60, 25, per_camera=True)
     masks = np.array([(1 << 8) | (1 << 5), 0, 1 << 8], dtype=np.uint32)
     g, o = _both_pc(k, const_masks=masks, huber_a=1.5)
-    _assert_same_pc(g, o)
+    _assert_same_pc(g, o, PC_TOL_HUBER)
     assert g[0][0, 8] == k["intr0"][0, 8] and g[0][0, 5] == k["intr0"][0, 5] and g[0][2, 8] == k["intr0"][2, 8]
     keep = k["obs_cam"] != 2
     offs = np.concatenate([[0], np.cumsum([keep[k["frame_offsets"][f]:k["frame_offsets"][f + 1]].sum() for f in range(60)])])
@@ -165,20 +178,38 @@ def test_rigk_per_camera_masks_huber_and_an_unobserved_camera():
     assert np.array_equal(g[0][2], k["intr0"][2]) and np.array_equal(g[1][2], k["cam_q0"][2])
 
 
-def test_rigk_per_camera_c5_size_runs_and_recovers_the_cameras():
+def test_rigk_per_camera_c5_full_size_against_the_committed_oracle_result_and_properties():
     """BASELINE.json configs[4] as worded ("full intrinsics+extrinsics co-optimisation"): 8 cameras x 2000 frames x
-    500 points with a camera model of its own per camera: 114 shared coordinates. Properties only at this size (the
-    oracle needs minutes for a dense 114-wide reduction on 8M observations): planted cameras recovered, frozen pose
-    untouched, per-observation costs add up, second solve is a fixed point."""
-    k = rigk_case(8, 2000, 500, per_camera=True)
+    500 points with a camera model of its own per camera: 114 shared coordinates. The oracle's answer is a committed
+    fixture (tests/golden/make_rigk_pc_c5.py): same trajectory (accept/reject sequence, per-iteration costs), same
+    intrinsics per camera, camera poses, a subset of the frame poses, per-observation costs. Plus the size-independent
+    properties: planted cameras recovered, frozen pose untouched, per-observation costs add up, second solve is a
+    fixed point."""
+    import os
+    gld = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rigk_pc_c5_oracle.npz"))
+    k = rigk_case(int(gld["cams"]), int(gld["frames"]), int(gld["pts"]), per_camera=True)
     prob = capi.RigProblem(8, k["frame_offsets"], k["obs_cam"], k["obs_world"], k["obs_uv_pix"], k["world_xyz"], k["cam_frozen"],
                            huber_a=0.0, with_intrinsics="per_camera")
-    prob.set_intrinsics(k["intr0"][0], 0)
+    for c in range(8):
+        prob.set_camera_intrinsics(c, k["intr0"][c], 0)
     prob.set_state(k["cam_q0"], k["cam_t0"], k["frame_q0"], k["frame_t0"])
     s1 = prob.solve(capi.default_options(max_iterations=200))
     intr = prob.get_camera_intrinsics()
     r1 = prob.get_state()
-    assert s1["termination"] in ("FUNCTION", "PARAMETER", "GRADIENT") and s1["final_cost"] < 1e-2 * s1["initial_cost"]
+    # against the oracle's committed result
+    assert s1["termination"] == str(gld["termination"]) and s1["iterations"] == int(gld["iterations"])
+    assert [l["accepted"] for l in s1["log"]] == list(gld["accepted"])
+    assert np.allclose([l["cost"] for l in s1["log"]], gld["costs"], rtol=1e-9)
+    assert np.isclose(s1["initial_cost"], float(gld["initial_cost"]), rtol=1e-10)
+    assert np.isclose(s1["final_cost"], float(gld["final_cost"]), rtol=1e-10)
+    assert np.allclose(intr[:, :4], gld["intr"][:, :4], rtol=PC_TOL["intr_rel"]) and np.allclose(intr[:, 4:], gld["intr"][:, 4:], atol=PC_TOL["dist_abs"])
+    assert np.abs(r1[0] - gld["cam_q"]).max() < PC_TOL["pose"] and np.abs(r1[1] - gld["cam_t"]).max() < PC_TOL["pose"]
+    pick = gld["frame_pick"]
+    assert np.abs(r1[2][pick] - gld["frame_q"]).max() < PC_TOL["pose"] and np.abs(r1[3][pick] - gld["frame_t"]).max() < PC_TOL["pose"]
+    assert np.allclose(r1[4][:64], gld["obs_cost_head"], rtol=PC_TOL["obs_cost_rel"], atol=1e-12)
+    assert np.isclose(r1[4].sum(), float(gld["obs_cost_sum"]), rtol=1e-11)
+    # properties
+    assert s1["final_cost"] < 1e-2 * s1["initial_cost"]
     assert np.abs(intr[:, :2] / k["intr_true"][:, :2] - 1).max() < 2e-3 and np.abs(intr[:, 2:4] - k["intr_true"][:, 2:4]).max() < 2.0
     assert np.array_equal(r1[0][0], k["cam_q0"][0]) and np.array_equal(r1[1][0], k["cam_t0"][0])
     assert np.isclose(r1[4].sum(), s1["final_cost"], rtol=1e-9) and r1[4].shape == (8_000_000,)
