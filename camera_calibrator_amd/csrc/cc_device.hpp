@@ -73,6 +73,47 @@ __device__ __forceinline__ double row16_max(double v) {
   return v;
 }
 
+// value of lane l (a constant once the caller's loops are unrolled) in every lane: two v_readlane_b32 into scalar registers
+__device__ __forceinline__ double lane_bcast(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// Dense SPD solve A x = b with the matrix distributed BY ROWS over the lanes of one wave: lane i < S holds row i of A in
+// a[0..i] (what it holds beyond the diagonal is ignored, lanes >= S hold anything finite) and b_i. Right-looking Cholesky,
+// fully unrolled: the pivot and the multipliers of column j are read from their lanes into scalar registers
+// (v_readlane), every lane updates its own row -- no LDS, no barrier, S (S + 1) / 2 lane reads for the factor and as many
+// again for the two substitutions. x comes back wave-uniform (the same in every lane). Returns whether every pivot was
+// positive and finite. The elimination order of every element is that of the usual left-looking loop (k ascending).
+template <int S>
+__device__ __forceinline__ bool chol_solve_rows(double (&a)[S], double b, double (&x)[S]) {
+  bool ok = true;
+  double inv[S];
+#pragma unroll
+  for (int j = 0; j < S; ++j) {
+    const double d = lane_bcast(a[j], j);
+    ok = ok && (d > 0.0) && isfinite(d);
+    const double r = rsqrt(d);
+    inv[j] = r;
+    a[j] *= r;   // column j of L (lane j: d * rsqrt(d) = L_jj)
+#pragma unroll
+    for (int k = j + 1; k < S; ++k) a[k] = fma(-a[j], lane_bcast(a[j], k), a[k]);
+  }
+#pragma unroll
+  for (int j = 0; j < S; ++j) {   // L y = b
+    const double y = lane_bcast(b, j) * inv[j];
+    x[j] = y;
+    b = fma(-a[j], y, b);
+  }
+#pragma unroll
+  for (int i = S - 1; i >= 0; --i) {   // L^T x = y: L_ki is element i of lane k's row
+    double acc = x[i];
+#pragma unroll
+    for (int k = i + 1; k < S; ++k) acc = fma(-lane_bcast(a[i], k), x[k], acc);
+    x[i] = acc * inv[i];
+  }
+  return ok;
+}
+
 // LDS accesses of one wave execute in order; the fence only stops the compiler from moving
 // the staged-row reads above the writes of other lanes (no instruction is emitted).
 __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
@@ -110,6 +151,28 @@ __device__ __forceinline__ void gram_rows(const double* stage, int lane, d4& acc
     acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc1, 0, 0, 0);
   }
+}
+
+// The same contraction with its schedule pinned: all sixteen operand reads are issued first, then the sixteen matrix
+// products, each waiting only for its own operand (the scheduler may not move anything across the barrier between the
+// two groups). Inside the persistent kernel's round loop the compiler otherwise interleaves read / wait / product one
+// operand at a time -- every product then sits behind a full LDS round trip (13.5 us instead of 8.4 for the two passes
+// of a 500-point frame at four waves per SIMD).
+__device__ __forceinline__ void gram_rows_ahead(const double* stage, int lane, d4& acc0, d4& acc1) {
+  const int c = lane & 15, sub = lane >> 4;
+  double a[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    const int r = 4 * m + sub;
+    a[m] = stage[r * 16 + (((c >> 1) ^ (r & 7)) << 1) + (c & 1)];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int m = 0; m < 16; m += 2) {
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], a[m], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m + 1], a[m + 1], acc1, 0, 0, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 

@@ -22,6 +22,7 @@
 #include "cc_common.hpp"
 #include "cc_device.hpp"
 #include "cc_intrinsics_dev.hpp"
+#include "cc_intrinsics_persist.hpp"
 
 #ifndef CC_ABLATE
 #define CC_ABLATE 0  // timing-only experiments (scripts/ablate_sweep.sh); 0 = product build
@@ -449,19 +450,6 @@ __device__ __forceinline__ void intr_solve_step(const IntrDev& P, const double* 
   }
   c.step_valid = ok ? 1 : 0;
   c.cand_pending = 1;
-}
-
-// Hands the control block to the host without a copy engine in the way: payload words first, then the
-// sequence word the host spins on (system-scope stores into pinned host memory; one thread).
-__device__ __forceinline__ void publish_to_host(const IntrDev& P, const LmCtl& c) {
-  if (!P.host_pub) return;
-  const unsigned long long* w = reinterpret_cast<const unsigned long long*>(&c);
-#pragma unroll
-  for (int i = 0; i < (int)(sizeof(LmCtl) / 8); ++i)
-    __hip_atomic_store(P.host_pub + 2 + i, w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  const unsigned long long seq = *P.pub_seq + 1ull;
-  *P.pub_seq = seq;
-  __hip_atomic_store(P.host_pub, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1033,6 +1021,11 @@ struct cc_intrinsics {
   bool exchange = false;
   std::vector<hipEvent_t> events;
   std::vector<int> event_kind;
+  // persistent per-solve kernel (cc_intrinsics_persist.hip): usable when every frame gets a team of a resident workgroup
+  bool persist_ok = false;
+  cc::PersistDev pq{};
+  uint32_t p_epoch = 0;         // last epoch handed to a launch (the seam words only ever see growing epochs)
+  size_t p_box_bytes = 0;       // seam mailboxes (re-zeroed before the epochs wrap)
 };
 
 namespace cc {
@@ -1250,6 +1243,33 @@ int intr_create_impl(cc_intrinsics* h, const int64_t* off, const float* uv, cons
   const size_t o_opts = take(sizeof(LmOpts));
   const size_t o_iintr = take(16 * sizeof(double));
   const size_t o_ipose = take((size_t)F * 8 * sizeof(double));
+  // persistent kernel: frames per worker workgroup = the fewest (1, 2, 4) that still gives every frame a team of a resident
+  // workgroup -- few frames spread over the chip (a 125-frame shard: one frame per compute unit), many share them four
+  // to a unit; seam mailboxes: one statistics row and one elimination row per worker workgroup, one row per leader
+  int p_teams = 0;
+  const bool want_persist = d.T == 1 && !(getenv("CC_INTR_PERSIST") && atoi(getenv("CC_INTR_PERSIST")) == 0);
+  if (want_persist) {
+    for (int t = 1; t <= kPMaxTeams && !p_teams; t *= 2) {
+      int resident = 0;
+      if (int rc = persist_resident_workgroups(h->device, t, &resident)) return rc;
+      if ((F + t - 1) / t + 1 <= resident) p_teams = t;
+    }
+    if (const char* e = getenv("CC_INTR_PERSIST_TEAMS")) {   // (A/B: force a shape that fits)
+      const int t = atoi(e);
+      int resident = 0;
+      if ((t == 1 || t == 2 || t == 4) && !persist_resident_workgroups(h->device, t, &resident) && (F + t - 1) / t + 1 <= resident) p_teams = t;
+    }
+  }
+  const int64_t PG = p_teams ? (F + p_teams - 1) / p_teams : 1;
+  const size_t pgn = (size_t)PG;
+  const size_t o_pbox0 = cursor;
+  const size_t o_sbox = take(pgn * 2 * kPStatCols * sizeof(unsigned long long));
+  const size_t o_pbox = take(pgn * 2 * kPartialCols * sizeof(unsigned long long));
+  const size_t o_lbox = take(((pgn + kPLeaderRows - 1) / kPLeaderRows) * 2 * kPartialCols * sizeof(unsigned long long));
+  const size_t o_dbox = take(kPBcastWords * sizeof(unsigned long long));
+  const size_t o_xbox = take(kPBcastWords * sizeof(unsigned long long));
+  const size_t o_pfail = take(64);
+  h->p_box_bytes = cursor - o_pbox0;
   const size_t zeroed = cursor;                       // everything above starts as zeros
   const size_t o_blocks = take((size_t)2 * FT * 256 * sizeof(double));
   const size_t o_log = take((size_t)d.log_cap * sizeof(cc_iteration));
@@ -1303,6 +1323,22 @@ int intr_create_impl(cc_intrinsics* h, const int64_t* off, const float* uv, cons
     CC_HIP(hipHostGetDevicePointer(&dev_view, h->pinned, 0));
     d.host_pub = reinterpret_cast<unsigned long long*>(dev_view);
   }
+  h->pq.sbox = reinterpret_cast<unsigned long long*>(base + o_sbox);
+  h->pq.pbox = reinterpret_cast<unsigned long long*>(base + o_pbox);
+  h->pq.dbox = reinterpret_cast<unsigned long long*>(base + o_dbox);
+  h->pq.xbox = reinterpret_cast<unsigned long long*>(base + o_xbox);
+  h->pq.fail = reinterpret_cast<unsigned*>(base + o_pfail);
+  h->pq.lbox = reinterpret_cast<unsigned long long*>(base + o_lbox);
+  h->pq.G = (int32_t)PG;
+  h->pq.teams = p_teams;
+  {
+    const char* e = getenv("CC_INTR_PERSIST_STAGGER");
+    h->pq.stagger = e ? std::max(0, atoi(e)) : 0;
+  }
+  h->p_epoch = 0;
+  // every workgroup of the persistent launch waits for the others inside the kernel: it is only used when all of them
+  // (workers + control) are resident at once, alone on the device (shards that share a device keep the two-kernel path)
+  h->persist_ok = p_teams != 0;
   h->elim_blocks = (int)std::min<int64_t>(kElimMaxBlocks, (F + 15) / 16);
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_intr_sweep),
                              hipFuncAttributeMaxDynamicSharedMemorySize, kSweepLdsBytes));
@@ -1536,6 +1572,33 @@ static int solve_wait(cc_intrinsics* h, SolveRun* r) {
   return 0;
 }
 
+// The whole solve as one launch of the persistent kernel. Starts from buffer 0 (solve_begin moved a continued solve's
+// accepted point there) or, after set_state / reset, from the initial-state arrays.
+static int solve_persistent(cc_intrinsics* h, SolveRun* r) {
+  PersistDev q = h->pq;
+  q.max_rounds = r->o.max_iterations + 2;
+  q.restart = h->reset_pending ? 1 : 0;
+  const uint32_t need = 2u * (uint32_t)q.max_rounds + 2u;
+  if (h->p_epoch > 0xf0000000u - need) {   // before the 32-bit epochs wrap: forget every word ever stored
+    CC_HIP(hipMemsetAsync(h->pq.sbox, 0, h->p_box_bytes, h->stream));
+    h->p_epoch = 0;
+  }
+  q.epoch0 = h->p_epoch;
+  h->p_epoch += need;
+  persist_launch(h->d, q, false, h->stream);
+  CC_HIP(hipGetLastError());
+  h->reset_pending = false;
+  r->launched = q.max_rounds;
+  if (int rc = wait_published(h, &r->st)) return rc;
+  if (r->st.done && r->st.term == CC_FAILURE_EXCHANGE) {
+    CC_HIP(hipMemsetAsync(h->pq.fail, 0, sizeof(unsigned), h->stream));
+    return fail(CC_ERR_COMM, "persistent solve: a wait inside the kernel timed out (iteration %d): its %d workgroups were not all "
+                "resident, or a peer stalled", r->st.iter, h->pq.G + 1);
+  }
+  if (!r->st.done) return fail(CC_ERR_STATE, "persistent solve ended without a result (iter=%d)", r->st.iter);
+  return 0;
+}
+
 static int solve_finish(cc_intrinsics* h, SolveRun* r, cc_summary* summary) {
   const LmCtl& st = r->st;
   CC_HIP(hipSetDevice(h->device));
@@ -1577,6 +1640,11 @@ int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* sum
   if (!h || !h->have_state) return fail(CC_ERR_STATE, "cc_intrinsics_solve: no state set");
   SolveRun r;
   if (int rc = solve_begin(h, opt, &r)) return rc;
+  if (h->persist_ok && !h->comm && !h->exchange && !r.profile) {
+    // ONE launch runs the whole solve (cc_intrinsics_persist.hip); the host waits for its publication
+    if (int rc = solve_persistent(h, &r)) return rc;
+    return solve_finish(h, &r, summary);
+  }
   for (int chunk = 0;; ++chunk) {
     if (int rc = solve_launch(h, &r, chunk)) return rc;
     if (int rc = solve_wait(h, &r)) return rc;

@@ -116,4 +116,17 @@ __device__ __forceinline__ void row_v(const double* k, const ObsCommon& c, doubl
     if (mask & (1u << j)) v[j] = 0.0;
 }
 
+// Hands the control block to the host without a copy engine in the way: payload words first, then the
+// sequence word the host spins on (system-scope stores into pinned host memory; one thread).
+__device__ __forceinline__ void publish_to_host(const IntrDev& P, const LmCtl& c) {
+  if (!P.host_pub) return;
+  const unsigned long long* w = reinterpret_cast<const unsigned long long*>(&c);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(LmCtl) / 8); ++i)
+    __hip_atomic_store(P.host_pub + 2 + i, w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const unsigned long long seq = *P.pub_seq + 1ull;
+  *P.pub_seq = seq;
+  __hip_atomic_store(P.host_pub, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace cc

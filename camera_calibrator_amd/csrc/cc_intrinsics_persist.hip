@@ -1,0 +1,829 @@
+// cc_intrinsics_persist.hip -- the single-camera LM solve as ONE persistent kernel per solve (gfx950).
+//
+// Same arithmetic as the two-kernels-per-iteration path of cc_intrinsics.hip (sweep -> decide + elim + solve; replaces
+// the ceres::Solve call of Calibrator::Optimize, /root/reference/src/calibrator.cpp:314-324), restructured around what
+// bounded that path: an LM iteration is a chain of short dependent steps, and every one of them re-paid a kernel
+// boundary, a launch ramp and a gather of state out of HBM (profiles/r02/intr_stage_marks.jsonl).
+//
+// Here ONE launch runs the whole solve. Grid = G worker workgroups + 1 control workgroup, 1024 threads each, one per
+// compute unit, all resident (the host checks that before choosing this path):
+//   worker  : four TEAMS of four waves, one frame per team for the whole solve. The frame's pose (both buffers), its
+//             Y = (H_pp + D)^-1 [H_ps g_p], and BOTH 16 x 16 Gram blocks (accepted point / candidate) stay in LDS;
+//             the observations (20 B each) are the only thing re-read every round (L2 / Infinity-Cache resident).
+//             Round: back-substitute the pose step, Plus, sweep (the same LDS-staged v_mfma_f64_16x16x4_f64 Gram
+//             as k_intr_sweep) -> statistics row -> [seam 1] -> eliminate the pose block of the accepted point's
+//             Gram block (16 lanes, 6 x 6 Cholesky in registers) -> elimination row -> [seam 2].
+//   control : owns the trust-region state (LmCtl), the log and the publication to the host. Seam 1: gathers the G
+//             statistics rows, takes the decision (lm_init / lm_decide), broadcasts {done, cur, radius (, Jacobi
+//             scales)}. Seam 2: gathers the G elimination rows, gradient / radius tests, 9 x 9 reduced solve with
+//             the matrix distributed by rows over nine lanes (v_readlane pivots), broadcasts {done, valid, step}.
+// Seams are self-validating 8-byte words {epoch32 : half of a double}, stored and polled with agent-scope (sc1)
+// accesses: an aligned 8-byte store is single-copy atomic, so there is no flag, no fence, no drain (MI355X guide,
+// Guideline 16 R2). Sums over rows run in a fixed order: results do not depend on timing or placement. Every wait is
+// bounded (10 s of the wall clock); a wait that gives up sets the failure word, everybody leaves, and the host
+// returns CC_ERR_COMM.
+#include "cc_intrinsics_persist.hpp"
+
+namespace cc {
+
+typedef unsigned long long u64;
+
+// Timing-only builds (-DCC_PERSIST_TIMING, scripts/time_intr_persist.py): in round CC_PERSIST_TIMING_ROUND the middle worker
+// workgroup and the control workgroup leave wall-clock marks (100 MHz, one counter for the whole chip) in vec_solve, which
+// the persistent path does not use otherwise: worker marks [0..15], control marks [16..31]. Compiled away in the product.
+#ifdef CC_PERSIST_TIMING
+#ifndef CC_PERSIST_TIMING_ROUND
+#define CC_PERSIST_TIMING_ROUND 2
+#endif
+#define PW_MARK(i) do { if (round == CC_PERSIST_TIMING_ROUND && (int)blockIdx.x == (Q.G / 2 / kPLeaderRows) * kPLeaderRows && threadIdx.x == 0) P.vec_solve[(i)] = (double)wall_clock64(); } while (0)
+#define PC_MARK(i) do { if (round == CC_PERSIST_TIMING_ROUND && threadIdx.x == 0) P.vec_solve[16 + (i)] = (double)wall_clock64(); } while (0)
+#else
+#define PW_MARK(i) do { } while (0)
+#define PC_MARK(i) do { } while (0)
+#endif
+
+// LDS of a workgroup with TEAMS frames: one staging tile per wave, both Gram blocks and the scratch of every team, the
+// workgroup's scratch. 155,648 B at four teams (one workgroup per compute unit), 40,448 B at one.
+constexpr int persist_lds_doubles(int teams) { return teams * 4 * kStageDoublesPerWave + teams * 2 * 256 + teams * 192 + 256; }
+
+// per-team scratch (doubles)
+enum { TM_Y = 0, TM_POSE = 60, TM_SP = 76, TM_STEP = 84, TM_R = 100, TM_T = 109, TM_KC = 112, TM_STEP2 = 122, TM_XN2 = 123,
+       TM_QW = 124, TM_STAT = 128 /* cost, q_model, step^2, |x|^2, then nine diagonal entries (first round) */ };
+// workgroup scratch (doubles)
+enum { WG_INTR = 0 /* [2][16] */, WG_DEC = 64 /* flags, radius, ss[9] */, WG_SS = 66, WG_STEP = 80 /* flags, ds[9] */, WG_DS = 81,
+       WG_OPT = 100 /* jacobi, min / max LM diagonal */, WG_TAB = 104 /* pj / pk byte tables */ };
+
+// ceres::QuaternionManifold::Plus with the series coefficients of cc::quat_plus (cc_common.hpp: same values, same
+// Horner order, same bits) read from constant memory through a pointer the compiler cannot see through: written as
+// literals they are hoisted out of the round loop -- sixteen 64-bit constants parked in vector registers across the
+// sweep's main loop, which promptly spills them.
+__constant__ double kPlusCoef[16] = {-1.0 / 2, 1.0 / 24, -1.0 / 720, 1.0 / 40320, -1.0 / 3628800, 1.0 / 479001600, -1.0 / 87178291200.0,
+                                     1.0 / 20922789888000.0,   // cos(n) - 1 in n^2
+                                     -1.0 / 6, 1.0 / 120, -1.0 / 5040, 1.0 / 362880, -1.0 / 39916800, 1.0 / 6227020800.0,
+                                     -1.0 / 1307674368000.0, 1.0 / 355687428096000.0};   // sin(n) / n - 1 in n^2
+__device__ __forceinline__ void quat_plus_tab(const double* x, const double* d, double* out) {
+  const double n2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  if (n2 == 0.0) { out[0] = x[0]; out[1] = x[1]; out[2] = x[2]; out[3] = x[3]; return; }
+  double s, a0;
+  if (n2 < 0.0625) {
+    const double* c = kPlusCoef;
+    asm volatile("" : "+s"(c));
+    a0 = 1.0 + n2 * (c[0] + n2 * (c[1] + n2 * (c[2] + n2 * (c[3] + n2 * (c[4] + n2 * (c[5] + n2 * (c[6] + n2 * c[7])))))));
+    s = 1.0 + n2 * (c[8] + n2 * (c[9] + n2 * (c[10] + n2 * (c[11] + n2 * (c[12] + n2 * (c[13] + n2 * (c[14] + n2 * c[15])))))));
+  } else {
+    const double nd = sqrt(n2);
+    s = sin(nd) / nd;
+    a0 = cos(nd);
+  }
+  const double a1 = s * d[0], a2 = s * d[1], a3 = s * d[2];
+  out[0] = a0 * x[0] - a1 * x[1] - a2 * x[2] - a3 * x[3];
+  out[1] = a0 * x[1] + a1 * x[0] + a2 * x[3] - a3 * x[2];
+  out[2] = a0 * x[2] - a1 * x[3] + a2 * x[0] + a3 * x[1];
+  out[3] = a0 * x[3] + a1 * x[2] - a2 * x[1] + a3 * x[0];
+}
+
+// ~10.7 s of the 100 MHz wall clock (2^30 ticks) -- a shift and a compare against zero: kP2pTimeoutTicks as a 64-bit
+// literal gets hoisted into a register pair that then sits there across the sweep's main loop
+__device__ __forceinline__ bool timed_out(long long t0) { return ((wall_clock64() - t0) >> 30) != 0; }
+
+__device__ __forceinline__ u64 ag_ld(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ag_st(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned ag_ld32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u64 granule(unsigned tag, double v, int half) {
+  const u64 bits = (u64)__double_as_longlong(v);
+  return ((u64)tag << 32) | (half ? (bits >> 32) : (bits & 0xffffffffull));
+}
+__device__ __forceinline__ double ungranule(u64 lo, u64 hi) { return __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull))); }
+
+// One wave waits until the n doubles of a broadcast box carry `tag` and leaves them in dst[0..n) (LDS); lane l polls
+// word l. false: gave up (timeout, or somebody else already failed); the failure word is set.
+__device__ __forceinline__ bool bcast_wait(const u64* box, unsigned tag, int n, double* dst, unsigned* fail, int lane) {
+  const bool mine = lane < 2 * n;
+  const u64* p = box + (mine ? lane : 0);
+  const long long t0 = wall_clock64();
+  u64 v;
+  for (unsigned spins = 0;; ++spins) {
+    v = ag_ld(p);
+    const int ok = !mine || (unsigned)(v >> 32) == tag;
+    if (__all(ok)) break;
+    if ((spins & 63u) == 63u && (timed_out(t0) || ag_ld32(fail) != 0u)) {
+      if (lane == 0) __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  if (mine) reinterpret_cast<unsigned*>(dst)[lane] = (unsigned)v;   // word 2i = low half of double i
+  return true;
+}
+
+// Control workgroup, all 1024 threads: column sums (maximum for column `maxcol`) of the G rows of a box whose words
+// carry `tag`. Thread -> (column, row group): rows grp, grp + NG, ... are polled eight at a time (all sixteen loads in
+// flight, unconditional from clamped rows) and added in that order; the NG group sums are then added in group order.
+// out[0..ncols) valid for every thread after return. *s_ok (LDS) ends 0 when a row did not show up in time.
+template <int NC, int NG>
+__device__ __forceinline__ void gather_rows(const u64* box, int G, unsigned tag, int ncols, int maxcol, double* s_part,
+                                            double* out, unsigned* fail, int* s_ok) {
+  const int tid = threadIdx.x, col = tid % NC, grp = tid / NC;
+  if (tid == 0) *s_ok = 1;
+  __syncthreads();
+  if (grp < NG && col < ncols) {
+    double acc = 0.0;
+    bool good = true;
+    const long long t0 = wall_clock64();
+    for (int r0 = grp; r0 < G && good; r0 += 8 * NG) {
+      u64 lo[8], hi[8];
+      for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int r = r0 + u * NG;
+          const u64* p = box + (size_t)(r < G ? r : r0) * (2 * NC) + 2 * col;
+          lo[u] = ag_ld(p);
+          hi[u] = ag_ld(p + 1);
+        }
+        bool ok = true;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ok = ok && (unsigned)(lo[u] >> 32) == tag && (unsigned)(hi[u] >> 32) == tag;
+        if (ok) break;
+        if ((spins & 63u) == 63u && (timed_out(t0) || ag_ld32(fail) != 0u)) { good = false; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!good) break;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (r0 + u * NG < G) {
+          const double v = ungranule(lo[u], hi[u]);
+          acc = col == maxcol ? fmax(acc, v) : acc + v;
+        }
+      }
+    }
+    s_part[grp * NC + col] = acc;
+    if (!good) *s_ok = 0;
+  }
+  __syncthreads();
+  if (tid < ncols) {
+    double a = 0.0;
+    if (tid == maxcol) { for (int g = 0; g < NG; ++g) a = fmax(a, s_part[g * NC + tid]); }
+    else { for (int g = 0; g < NG; ++g) a += s_part[g * NC + tid]; }
+    out[tid] = a;
+  }
+  __syncthreads();
+}
+
+// Control workgroup, rounds after the first: the four column sums of the G <= 256 statistics rows. Thread -> (row, column):
+// every thread polls its own two words (all rows in ONE round trip), the rows of a wave are added by the fixed
+// cross-lane tree of wave_sum_mod, the waves in order.
+template <int THREADS>
+__device__ __forceinline__ void gather_stats4(const u64* box, int G, unsigned tag, double* s_part, double* out, unsigned* fail, int* s_ok) {
+  constexpr int RPT = 1024 / THREADS;   // rows per thread
+  const int tid = threadIdx.x, col = tid & 3, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) *s_ok = 1;
+  __syncthreads();
+  u64 lo[RPT], hi[RPT];
+  bool good = true;
+  const long long t0 = wall_clock64();
+  for (unsigned spins = 0;; ++spins) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const int r = (tid >> 2) + k * (THREADS / 4);
+      const u64* p = box + (size_t)(r < G ? r : 0) * (2 * kPStatCols) + 2 * col;
+      lo[k] = ag_ld(p);
+      hi[k] = ag_ld(p + 1);
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) ok = ok && (unsigned)(lo[k] >> 32) == tag && (unsigned)(hi[k] >> 32) == tag;   // (rows >= G read row 0)
+    if (ok) break;
+    if ((spins & 63u) == 63u && (timed_out(t0) || ag_ld32(fail) != 0u)) { good = false; break; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < RPT; ++k)
+    if ((tid >> 2) + k * (THREADS / 4) < G) acc += ungranule(lo[k], hi[k]);
+  acc = wave_sum_mod<2>(acc);
+  if (lane < 4) s_part[wave * 4 + lane] = acc;
+  if (!good) *s_ok = 0;
+  __syncthreads();
+  if (tid < 4) {
+    double a = 0.0;
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; ++w) a += s_part[w * 4 + tid];
+    out[tid] = a;
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// control workgroup
+// ---------------------------------------------------------------------------------------------
+template <int THREADS>
+__device__ __forceinline__ void persist_control(const IntrDev& P, const PersistDev& Q, double* lds) {
+  double* s_part = lds;                    // [1024] gather scratch
+  double* sv = lds + 1024;                 // [kVecSolve] reduced elimination sums (layout of cc_intrinsics.hip)
+  double* s_tot = lds + 1152;              // [16] reduced statistics
+  double* s_bc = lds + 1168;               // [16] broadcast payload
+  double* s_intr = lds + 1184;             // [2][16] accepted / candidate intrinsics
+  double* s_ss = lds + 1216;               // [16] Jacobi scales of the shared block
+  LmCtl* s_ctl = reinterpret_cast<LmCtl*>(lds + 1232);         // 18 doubles
+  LmOpts* s_opts = reinterpret_cast<LmOpts*>(lds + 1252);      // 12 doubles
+  cc_iteration* s_log = reinterpret_cast<cc_iteration*>(lds + 1264);
+  int* s_int = reinterpret_cast<int*>(lds + 1296);             // [0] gather ok, [1] a record was logged this round
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  static_assert(sizeof(cc_iteration) <= 32 * 8, "log record scratch");
+  // initial state: a fresh control block (every launch is a whole solve), options, intrinsics of the starting point
+  if (tid < (int)(sizeof(LmCtl) / 8)) reinterpret_cast<double*>(s_ctl)[tid] = 0.0;
+  if (tid >= 32 && tid < 32 + (int)(sizeof(LmOpts) / 8)) reinterpret_cast<u64*>(s_opts)[tid - 32] = reinterpret_cast<const u64*>(P.opts)[tid - 32];
+  if (tid >= 64 && tid < 64 + 32) s_intr[tid - 64] = 0.0;
+  __syncthreads();
+  if (tid < 9) s_intr[tid] = (Q.restart ? P.init_intr : P.intr)[tid];
+  if (tid == 0) s_int[1] = 0;
+  __syncthreads();
+  const LmOpts o = *s_opts;
+  const uint32_t mask = P.mask;
+
+  for (int round = 0; round < Q.max_rounds; ++round) {
+    const unsigned e1 = Q.epoch0 + 2u * (unsigned)round + 1u, e2 = e1 + 1u;
+    const bool phase0 = round == 0;
+    // ---- seam 1: statistics -> decision
+    PC_MARK(0);
+    if (phase0) gather_rows<kPStatCols, THREADS / kPStatCols>(Q.sbox, Q.G, e1, 13, -1, s_part, s_tot, Q.fail, s_int);
+    else gather_stats4<THREADS>(Q.sbox, Q.G, e1, s_part, s_tot, Q.fail, s_int);
+    PC_MARK(1);
+    if (tid == 0) {
+      LmCtl c = *s_ctl;
+      const int len0 = c.log_len;
+      const double* kc0 = s_intr + (c.cur ? 16 : 0);   // accepted intrinsics
+      const double* kc1 = s_intr + (c.cur ? 0 : 16);   // candidate
+      if (!s_int[0]) {
+        c.done = 1; c.term = CC_FAILURE_EXCHANGE;
+      } else if (phase0) {
+        double xn2 = s_tot[ST_XNORM2];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          const double ki = kc0[i];
+          xn2 += ki * ki;
+          s_ss[i] = o.jacobi_scaling ? 1.0 / (1.0 + sqrt(s_tot[4 + i])) : 1.0;
+        }
+        lm_init(c, o, s_tot[ST_COST], sqrt(xn2));
+      } else if (c.cand_pending) {
+        double step2 = s_tot[ST_STEP2], xn2 = s_tot[ST_XNORM2];
+        if (c.step_valid) {
+#pragma unroll
+          for (int i = 0; i < 9; ++i) {
+            const double kc = kc1[i], k0 = kc0[i];
+            const double d = kc - k0;
+            step2 += d * d;
+            xn2 += kc * kc;
+          }
+        }
+        lm_decide(c, o, s_log, s_tot[ST_COST], s_tot[ST_QMODEL], step2, xn2);
+      }
+      if (!c.done && round + 1 >= Q.max_rounds) { c.done = 1; c.term = CC_NO_CONVERGENCE; }   // (never first: lm_apply counts iterations)
+      *s_ctl = c;
+      s_int[1] = c.log_len != len0;
+      s_bc[0] = (double)((c.done ? 1 : 0) | ((c.cur & 1) << 1));
+      s_bc[1] = c.radius;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) s_bc[2 + i] = s_ss[i];
+    }
+    __syncthreads();
+    PC_MARK(2);
+    if (tid < 2 * (phase0 ? 11 : 2)) ag_st(Q.dbox + tid, granule(e1, s_bc[tid >> 1], tid & 1));
+    if (s_ctl->done) {
+      // a decision that ends the solve (tolerance, iteration limit) still owes its log record
+      if (tid == 0 && s_int[1] && s_ctl->log_len <= P.log_cap) P.log[s_ctl->log_len - 1] = *s_log;
+      break;
+    }
+    // ---- seam 2: elimination rows -> gradient tests, reduced solve
+    PC_MARK(3);
+    // (the leaders among the workers have added the elimination rows sixteen at a time: one round trip here)
+    gather_rows<kPartialCols, THREADS / kPartialCols>(Q.lbox, (Q.G + kPLeaderRows - 1) / kPLeaderRows, e2, kPartialCols, PC_GMAXP, s_part, sv, Q.fail, s_int);
+    PC_MARK(4);
+    if (wave == 0) {
+      const int cur = s_ctl->cur & 1;
+      const double radius = s_ctl->radius;
+      double gmax = sv[PC_GMAXP];   // (one rank: the maximum over the pose gradients is this rank's)
+#pragma unroll
+      for (int j = 0; j < 9; ++j)
+        if (!(mask & (1u << j))) gmax = fmax(gmax, fabs(sv[PC_GS + j]));
+      const bool go = s_int[0] && !(gmax <= o.gradient_tolerance) && !(radius < o.min_radius);
+      bool ok = !(sv[PC_FAIL] > 0.0);
+      double x[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) x[i] = 0.0;
+      if (go) {
+        // row `lane` of the damped reduced system (sv[0..44]: upper triangle, row-major pairs j <= k)
+        const int i = lane < 9 ? lane : 8;
+        const bool pin_i = (mask >> i) & 1u;
+        double a[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const int kk = k <= i ? k : i;                           // (entries beyond the diagonal: ignored, keep them finite)
+          const int idx = kk * 9 - kk * (kk - 1) / 2 + (i - kk);   // pair (kk, i)
+          double v = sv[idx];
+          if (k == i) v += clampd(sv[PC_HDIAG + i], o.min_lm_diagonal, o.max_lm_diagonal) / radius;
+          const bool pin_k = (mask >> kk) & 1u;
+          if (pin_i || pin_k) v = (k == i) ? 1.0 : 0.0;           // SubsetManifold: unit row / column, zero right-hand side
+          a[k] = v;
+        }
+        const double b = pin_i ? 0.0 : sv[PC_B + i];
+        ok = chol_solve_rows<9>(a, b, x) && ok;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) ok = ok && isfinite(x[j]);
+      }
+      if (lane < 9) {
+        // scaled shared step and the candidate intrinsics every worker will form from it (same expression, same bits)
+        double xs = 0.0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) xs = lane == j ? x[j] : xs;
+        const double ds = -xs;
+        s_bc[1 + lane] = ds;
+        const double d = ((mask >> lane) & 1u) ? 0.0 : ds * s_ss[lane];
+        s_intr[(cur ^ 1) * 16 + lane] = s_intr[cur * 16 + lane] + d;
+      }
+      if (lane == 0) {
+        LmCtl c = *s_ctl;
+        cc_iteration* e = s_int[1] ? s_log : nullptr;
+        if (e && e->accepted) e->gradient_max_norm = gmax;
+        if (!s_int[0]) { c.done = 1; c.term = CC_FAILURE_EXCHANGE; }
+        else if (lm_finalize(c, o, gmax)) { c.step_valid = ok ? 1 : 0; c.cand_pending = 1; }
+        if (e && c.log_len <= P.log_cap) P.log[c.log_len - 1] = *e;
+        *s_ctl = c;
+        s_bc[0] = (double)((c.done ? 1 : 0) | (c.step_valid ? 2 : 0));
+      }
+    }
+    __syncthreads();
+    PC_MARK(5);
+    if (tid < 20) ag_st(Q.xbox + tid, granule(e2, s_bc[tid >> 1], tid & 1));
+    PC_MARK(6);
+    if (s_ctl->done) break;
+  }
+  // ---- the solve is over: control block, intrinsics, publication
+  __syncthreads();
+  if (tid < 32) P.intr[tid] = s_intr[tid];
+  if (tid == 0) {
+    LmCtl c = *s_ctl;
+    if (ag_ld32(Q.fail) != 0u) { c.done = 1; c.term = CC_FAILURE_EXCHANGE; }
+    if (!c.done) { c.done = 1; c.term = CC_NO_CONVERGENCE; }
+    *P.ctl = c;
+    *P.ctl_next = c;
+    publish_to_host(P, c);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------------
+template <int TEAMS>
+__global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, PersistDev Q) {
+  constexpr int THREADS = TEAMS * 256;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* s_stage = reinterpret_cast<double*>(smem_raw);          // [4 TEAMS][1024] staging, one tile per wave
+  if ((int)blockIdx.x == Q.G) { persist_control<THREADS>(P, Q, s_stage); return; }
+  double* s_G = s_stage + TEAMS * 4 * kStageDoublesPerWave;        // [TEAMS][2][256] Gram blocks of the teams' frames
+  double* s_tm = s_G + TEAMS * 2 * 256;                            // [TEAMS][192] per-team scratch
+  double* s_wg = s_tm + TEAMS * 192;                               // [256] workgroup scratch
+  // Register budget: four teams are 1024 threads, which leaves 128 registers per lane, and the sweep's main loop needs
+  // nearly all of them. Two things keep the rest of the kernel out of its way: (1) the round loop re-derives every
+  // per-thread index from a FRESH copy of the thread id (an empty asm the compiler cannot see through), so that the
+  // dozens of LDS addresses and predicates that are the same every round are recomputed where they are used instead of
+  // being hoisted out of the round loop and held across the main loop; (2) wave-uniform values (wave, team, frame
+  // range) are read through readfirstlane, so they sit in scalar registers.
+#define CC_FRESH_TID(name) int name = tid0; asm volatile("" : "+v"(name))
+  const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6), team = wave >> 2, twave = wave & 3;
+  // The serial pieces of a team's round (pose step, Plus, the sixteen elimination lanes) run on wave `team` of the team,
+  // i.e. on waves 0, 5, 10, 15 of the workgroup: a workgroup's waves go round the four SIMDs, so waves 0, 4, 8, 12 --
+  // wave 0 of every team -- share ONE SIMD and would serialise what is already the critical path.
+  const int sbase = (team & 3) * 64;   // first ttid of the team's serial wave
+  const int64_t f = (int64_t)blockIdx.x * TEAMS + team;
+  const bool has_frame = f < P.F;
+  double* sm = s_tm + team * 192;
+  double* tstage = s_stage + team * 4 * kStageDoublesPerWave;      // this team's four tiles
+  double* s_blk = tstage;                                          // [4][256] cross-wave reduction (after the loop)
+  double* Zs = tstage + 1024;                                      // [60] elimination: L^-1 [H_ps | g_p]
+  double* red = tstage + 1100;                                     // [80] elimination row of the frame
+  unsigned char* pj = reinterpret_cast<unsigned char*>(s_wg + WG_TAB);
+  unsigned char* pk = pj + 48;
+  const uint32_t mask = P.mask;
+
+  // ---- start of the solve: pose and intrinsics of the starting point into LDS
+  {
+  const int tid = tid0, ttid = tid0 & 255;
+  if (has_frame && ttid < 8) {
+    const double v = ttid < 7 ? (Q.restart ? P.init_pose : P.pose)[(size_t)f * 8 + ttid] : 0.0;
+    sm[TM_POSE + ttid] = v;
+    sm[TM_POSE + 8 + ttid] = v;
+  }
+  if (ttid >= 64 && ttid < 64 + 60) sm[TM_Y + ttid - 64] = 0.0;
+  if (tid < 32) s_wg[WG_INTR + tid] = 0.0;
+  if (tid == 32) {
+    const LmOpts* o = P.opts;
+    s_wg[WG_OPT] = o->jacobi_scaling ? 1.0 : 0.0;
+    s_wg[WG_OPT + 1] = o->min_lm_diagonal;
+    s_wg[WG_OPT + 2] = o->max_lm_diagonal;
+  }
+  if (tid == 33) {
+    int oo = 0;
+    for (int j = 0; j < 9; ++j)
+      for (int k = j; k < 9; ++k) { pj[oo] = (unsigned char)j; pk[oo] = (unsigned char)k; ++oo; }
+  }
+  if (tid >= 64 && tid < 64 + 20) s_wg[WG_DEC + tid - 64] = 0.0;
+  if (tid >= 96 && tid < 96 + 16) s_wg[WG_STEP + tid - 96] = 0.0;
+  __syncthreads();
+  if (tid < 9) s_wg[WG_INTR + tid] = (Q.restart ? P.init_intr : P.intr)[tid];
+  }
+
+  int64_t s0 = 0, s1 = 0;
+  if (has_frame) { s0 = P.off[f]; s1 = P.off[f + 1]; }
+  const float2* uv2 = reinterpret_cast<const float2*>(P.uv);
+  const int64_t wrem = s1 - s0 - twave * 64;
+  const int npass = wrem > 0 ? (int)((wrem + kSweepThreads - 1) / kSweepThreads) : 0;
+  const int64_t safe0 = s0 < P.N ? s0 : 0;
+  // first pass of observations: in registers across the seams (the last pass of a round prefetches it again)
+  float2 nm;
+  float nX0, nX1, nX2;
+  {
+    const int64_t first = s0 + (tid0 & 255);
+    const int64_t firstc = first < s1 ? first : safe0;
+    nm = uv2[firstc];
+    nX0 = P.xyz[firstc * 3]; nX1 = P.xyz[firstc * 3 + 1]; nX2 = P.xyz[firstc * 3 + 2];
+  }
+  __syncthreads();
+
+  int cur = 0;
+  bool step_valid = true, failed = false;
+  for (int round = 0; round < Q.max_rounds; ++round) {
+    const unsigned e1 = Q.epoch0 + 2u * (unsigned)round + 1u, e2 = e1 + 1u;
+    const bool phase0 = round == 0;
+    const bool do_sweep = phase0 || step_valid;
+    const int dst = phase0 ? cur : (cur ^ 1);
+    // =========================== sweep (candidate point, or the starting point in the first round)
+    d4 acc0, acc1;
+    PW_MARK(0);
+    if (do_sweep) {
+      CC_FRESH_TID(tid);
+      const int ttid = tid & 255, lane = tid & 63;
+      const double* ds = s_wg + WG_DS;
+      const double* ss = s_wg + WG_SS;
+      if (has_frame) {
+        const int st = ttid - sbase;   // lane of the team's serial wave
+        if (st >= 0 && st < 6) {
+          const double* Yr = sm + TM_Y + st * 10;
+          double a = Yr[9];
+#pragma unroll
+          for (int j = 0; j < 9; ++j) a += Yr[j] * ds[j];
+          sm[TM_STEP + 9 + st] = phase0 ? 0.0 : -a * sm[TM_SP + st];
+        } else if (st >= 8 && st < 17) {
+          const int j = st - 8;
+          const double d = (phase0 || (mask & (1u << j))) ? 0.0 : ds[j] * ss[j];
+          sm[TM_STEP + j] = d;
+          const double kc = s_wg[WG_INTR + cur * 16 + j] + d;
+          sm[TM_KC + j] = kc;
+          if (team == 0 && !phase0) s_wg[WG_INTR + dst * 16 + j] = kc;
+        }
+      }
+      __syncthreads();
+      if (has_frame && ttid == sbase) {
+        double q[4], t[3], dp[6];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = sm[TM_POSE + cur * 8 + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t[i] = sm[TM_POSE + cur * 8 + 4 + i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dp[i] = sm[TM_STEP + 9 + i];
+        double step2 = 0.0;
+        if (!phase0) {
+          double qn[4];
+          quat_plus_tab(q, dp, qn);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { const double d = qn[i] - q[i]; step2 += d * d; q[i] = qn[i]; }
+#pragma unroll
+          for (int i = 0; i < 3; ++i) { const double tn = t[i] + dp[3 + i]; const double d = tn - t[i]; step2 += d * d; t[i] = tn; }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sm[TM_POSE + dst * 8 + i] = q[i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) sm[TM_POSE + dst * 8 + 4 + i] = t[i];
+        }
+        double R[9];
+        quat_to_R(q, R);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) sm[TM_R + i] = R[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) sm[TM_T + i] = t[i];
+        sm[TM_STEP2] = step2;
+        sm[TM_XN2] = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + t[0] * t[0] + t[1] * t[1] + t[2] * t[2];
+      }
+      __syncthreads();
+      PW_MARK(1);
+      // model-cost term of the frame over its 15 x 15 block at the accepted point (cf. k_intr_sweep)
+      {
+        double qterm = 0.0;
+        if (has_frame && !phase0) {
+          const int a = ttid >> 4, b = ttid & 15;
+          const double g_old = s_G[(team * 2 + cur) * 256 + ttid];
+          if (a < 15) qterm = b < 15 ? 0.5 * sm[TM_STEP + a] * g_old * sm[TM_STEP + b] : sm[TM_STEP + a] * g_old;
+        }
+        const double qw = wave_sum(qterm);
+        if (lane == 0) sm[TM_QW + twave] = qw;
+      }
+      double R[9], tt[3], kk[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) R[i] = rfl(sm[TM_R + i]);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) tt[i] = rfl(sm[TM_T + i]);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) kk[i] = rfl(sm[TM_KC + i]);
+      // ---- main loop: 64 observations per wave per pass, no barrier (k_intr_sweep's loop)
+      double* stage = s_stage + wave * kStageDoublesPerWave;
+      acc0 = d4{0.0, 0.0, 0.0, 0.0};
+      acc1 = d4{0.0, 0.0, 0.0, 0.0};
+      // Waves that share a SIMD (one per team) would enter the loop in lockstep -- all in the fp64 row arithmetic, then
+      // all storing to LDS, then all on the matrix pipe: team k starts k * stagger sleep units late so that one team's
+      // LDS staging falls under another's matrix products (the separately launched workgroups of k_intr_sweep were
+      // skewed by their dispatch). PersistDev::stagger, CC_INTR_PERSIST_STAGGER.
+      for (int w = 0; w < team * Q.stagger; ++w) __builtin_amdgcn_s_sleep(4);
+      PW_MARK(2);
+      for (int p = 0; p < npass; ++p) {
+        const int64_t idx = s0 + (int64_t)p * kSweepThreads + ttid;
+        const bool valid = idx < s1;
+        const float2 m = nm;
+        const float X0 = nX0, X1 = nX1, X2 = nX2;
+        {   // next pass -- after the last one, the first pass of the next round -- unconditionally
+          const int64_t nidx = p + 1 < npass ? idx + kSweepThreads : s0 + ttid;
+          const int64_t ic = nidx < s1 ? nidx : safe0;
+          nm = uv2[ic];
+          nX0 = P.xyz[ic * 3]; nX1 = P.xyz[ic * 3 + 1]; nX2 = P.xyz[ic * 3 + 2];
+        }
+        ObsCommon oc;
+        obs_common(kk, R, tt, (double)X0, (double)X1, (double)X2, oc);
+        double v[16];
+        row_u(kk, oc, (double)m.x, mask, v);
+        if (!valid) {
+#pragma unroll
+          for (int c = 0; c < 16; ++c) v[c] = 0.0;
+        }
+        stage_row(stage, lane, v);
+        wave_lds_fence();
+        gram_rows_ahead(stage, lane, acc0, acc1);
+        wave_lds_fence();
+        row_v(kk, oc, (double)m.y, mask, v);
+        if (!valid) {
+#pragma unroll
+          for (int c = 0; c < 16; ++c) v[c] = 0.0;
+        }
+        stage_row(stage, lane, v);
+        wave_lds_fence();
+        gram_rows_ahead(stage, lane, acc0, acc1);
+        wave_lds_fence();
+      }
+      // ---- cross-wave reduction of the 16 x 16 block into the frame's LDS slot
+      PW_MARK(3);
+      __syncthreads();   // s_blk aliases the staging tiles
+      PW_MARK(4);
+    }
+    if (do_sweep) {
+      CC_FRESH_TID(tid);
+      const int ttid = tid & 255, lane = tid & 63;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_blk[twave * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc0[r] + acc1[r];
+      __syncthreads();
+      const double g = (s_blk[ttid] + s_blk[256 + ttid]) + (s_blk[512 + ttid] + s_blk[768 + ttid]);
+      s_G[(team * 2 + dst) * 256 + ttid] = g;
+      if (ttid == 255) {
+        sm[TM_STAT + ST_COST] = 0.5 * g;
+        sm[TM_STAT + ST_QMODEL] = (sm[TM_QW] + sm[TM_QW + 1]) + (sm[TM_QW + 2] + sm[TM_QW + 3]);
+        sm[TM_STAT + ST_STEP2] = sm[TM_STEP2];
+        sm[TM_STAT + ST_XNORM2] = sm[TM_XN2];
+      }
+      if (phase0 && ttid < 9 * 17 && ttid % 17 == 0) sm[TM_STAT + 4 + ttid / 17] = g;
+      __syncthreads();
+    }
+    // ---- statistics row of the workgroup (teams in order) -> control
+    PW_MARK(5);
+    {
+      CC_FRESH_TID(tid);
+      const int ncols = phase0 ? 13 : 4;
+      if (tid < 2 * ncols) {
+        const int c = tid >> 1;
+        double a = 0.0;
+        if (do_sweep) {
+#pragma unroll
+          for (int k = 0; k < TEAMS; ++k)
+            if ((int64_t)blockIdx.x * TEAMS + k < P.F) a += s_tm[k * 192 + TM_STAT + c];
+        }
+        ag_st(Q.sbox + (size_t)blockIdx.x * (2 * kPStatCols) + tid, granule(e1, a, tid & 1));
+      }
+    }
+    // =========================== seam 1: the decision
+    PW_MARK(6);
+    {
+      CC_FRESH_TID(tid);
+      if (wave == 0 && !bcast_wait(Q.dbox, e1, phase0 ? 11 : 2, s_wg + WG_DEC, Q.fail, tid & 63)) s_wg[WG_DEC] = 5.0;   // done + failed
+    }
+    __syncthreads();
+    {
+      const int fl = (int)s_wg[WG_DEC];
+      cur = (fl >> 1) & 1;
+      if (fl & 4) failed = true;
+      if (fl & 1) break;
+    }
+    // =========================== elimination of the frame's pose block at the accepted point
+    PW_MARK(7);
+    CC_FRESH_TID(tid_e);
+    if (has_frame && (tid_e & 255) >= sbase && (tid_e & 255) < sbase + 16) {
+      const int l = (tid_e & 255) - sbase;
+      const double* Gl = s_G + (team * 2 + cur) * 256;
+      const double* ss = s_wg + WG_SS;
+      const bool jac = s_wg[WG_OPT] != 0.0;
+      const double mn = s_wg[WG_OPT + 1], mx = s_wg[WG_OPT + 2];
+      const double inv_radius = 1.0 / s_wg[WG_DEC + 1];
+      double s[6], L[21];
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) L[tri(i, j)] = Gl[(9 + i) * 16 + 9 + j];
+      if (phase0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s[i] = jac ? 1.0 / (1.0 + sqrt(L[tri(i, i)])) : 1.0;
+        if (l < 6) {
+          double sl = 0.0;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) sl = l == i ? s[i] : sl;
+          sm[TM_SP + l] = sl;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s[i] = sm[TM_SP + i];
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) L[tri(i, j)] = s[i] * L[tri(i, j)] * s[j];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) L[tri(i, i)] += clampd(L[tri(i, i)], mn, mx) * inv_radius;
+      bool ok = true;
+      double Li[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        double d = L[tri(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= L[tri(j, k)] * L[tri(j, k)];
+        ok = ok && (d > 0.0) && isfinite(d);
+        const double inv = rsqrt(d);
+        L[tri(j, j)] = d * inv;
+        Li[j] = inv;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+          double a = L[tri(i, j)];
+#pragma unroll
+          for (int k = 0; k < j; ++k) a -= L[tri(i, k)] * L[tri(j, k)];
+          L[tri(i, j)] = a * inv;
+        }
+      }
+      // the factor is the same in all sixteen lanes: from here on it lives in scalar registers (48 of them), not in 54
+      // vector registers next to each lane's own columns
+#pragma unroll
+      for (int i = 0; i < 21; ++i) L[i] = rfl(L[i]);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { Li[i] = rfl(Li[i]); s[i] = rfl(s[i]); }
+      if (l < 10) {
+        const double sc = l < 9 ? ss[l] : 1.0;
+        const int col = l < 9 ? l : 15;
+        double w[6], z[6], y[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[i] = Gl[(9 + i) * 16 + col];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          double a = s[i] * w[i] * sc;
+#pragma unroll
+          for (int k = 0; k < i; ++k) a -= L[tri(i, k)] * z[k];
+          z[i] = a * Li[i];
+        }
+#pragma unroll
+        for (int i = 5; i >= 0; --i) {
+          double a = z[i];
+#pragma unroll
+          for (int k = i + 1; k < 6; ++k) a -= L[tri(k, i)] * y[k];
+          y[i] = a * Li[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          Zs[i * 10 + l] = z[i];
+          sm[TM_Y + i * 10 + l] = y[i];
+        }
+      }
+      wave_lds_fence();   // (the sixteen lanes are one wave: its LDS operations execute in order)
+      // output slots l * 5 + r of this lane (layout of k_intr_decide_elim's partial row)
+      double accv[5];
+      int zj[5], zk[5];
+      bool use_z[5];
+#pragma unroll
+      for (int r = 0; r < 5; ++r) {
+        const int o = l * 5 + r;
+        int gi = 0;
+        double sa = 0.0, sb = 0.0;
+        zj[r] = 0; zk[r] = 0; use_z[r] = false;
+        if (o < 45) {
+          const int j = pj[o], k = pk[o];
+          gi = j * 16 + k; zj[r] = j; zk[r] = k; sa = ss[j]; sb = ss[k]; use_z[r] = true;
+        } else if (o < 54) {
+          const int j = o - 45;
+          gi = j * 16 + 15; zj[r] = j; zk[r] = 9; sa = ss[j]; sb = 1.0; use_z[r] = true;
+        } else if (o < 63) {
+          const int j = o - 54;
+          gi = j * 17; sa = ss[j] * ss[j]; sb = 1.0;
+        } else if (o >= PC_GS && o < PC_GS + 9) {
+          gi = (o - PC_GS) * 16 + 15; sa = 1.0; sb = 1.0;
+        }
+        accv[r] = sa * Gl[gi] * sb;
+      }
+      const int l6 = l < 6 ? l : l - 6 < 6 ? l - 6 : l - 12;
+      const double gp = fabs(Gl[(9 + l6) * 16 + 15]);
+#pragma unroll
+      for (int r = 0; r < 5; ++r) {
+        double zz = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) zz += Zs[i * 10 + zj[r]] * Zs[i * 10 + zk[r]];
+        const int o = l * 5 + r;
+        if (o != PC_FAIL && o != PC_GMAXP) red[o] = accv[r] - (use_z[r] ? zz : 0.0);
+      }
+      const double gmaxp = row16_max(gp);
+      if (l == 0) { red[PC_FAIL] = ok ? 0.0 : 1.0; red[PC_GMAXP] = gmaxp; }
+    }
+    __syncthreads();
+    // ---- elimination row of the workgroup (teams in order)
+    PW_MARK(8);
+    {
+      CC_FRESH_TID(tid);
+      if (tid < 2 * kPartialCols) {
+        const int c = tid >> 1;
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < TEAMS; ++k) {
+          if ((int64_t)blockIdx.x * TEAMS + k < P.F) {
+            const double v = s_stage[k * 4 * kStageDoublesPerWave + 1100 + c];
+            a = c == PC_GMAXP ? fmax(a, v) : a + v;
+          }
+        }
+        ag_st(Q.pbox + (size_t)blockIdx.x * (2 * kPartialCols) + tid, granule(e2, a, tid & 1));
+      }
+    }
+    PW_MARK(9);
+    // ---- every sixteenth workgroup is a LEADER: it adds up the rows of its sixteen (it would only be waiting for the
+    // step otherwise) and posts ONE row for the control, which then reads G / 16 rows in a single round trip instead of G
+    if ((blockIdx.x % kPLeaderRows) == 0) {
+      int* s_lok = reinterpret_cast<int*>(s_wg + 250);
+      const int g0 = (int)blockIdx.x, n = Q.G - g0 < kPLeaderRows ? Q.G - g0 : kPLeaderRows;
+      double* lout = s_wg + 128;        // [80]; the group sums go through team 0's staging tiles (idle between sweeps)
+      gather_rows<kPartialCols, THREADS / kPartialCols>(Q.pbox + (size_t)g0 * (2 * kPartialCols), n, e2, kPartialCols, PC_GMAXP, s_stage + 2048, lout,
+                                                        Q.fail, s_lok);
+      PW_MARK(11);
+      CC_FRESH_TID(tid);
+      // (rows that did not arrive: nothing is posted, the control's own wait gives up and ends the solve)
+      if (*s_lok && tid < 2 * kPartialCols) ag_st(Q.lbox + (size_t)(g0 / kPLeaderRows) * (2 * kPartialCols) + tid, granule(e2, lout[tid >> 1], tid & 1));
+    }
+    // =========================== seam 2: the step
+    PW_MARK(12);
+    {
+      CC_FRESH_TID(tid);
+      if (wave == 0 && !bcast_wait(Q.xbox, e2, 10, s_wg + WG_STEP, Q.fail, tid & 63)) s_wg[WG_STEP] = 5.0;
+    }
+    __syncthreads();
+    PW_MARK(10);
+    {
+      const int fl = (int)s_wg[WG_STEP];
+      step_valid = (fl & 2) != 0;
+      if (fl & 4) failed = true;
+      if (fl & 1) break;
+    }
+  }
+  // ---- the solve is over: the frame's accepted pose goes back to HBM (cc_intrinsics_get_state, the next solve)
+  if (!failed && has_frame && (tid0 & 255) < 7) P.pose[((size_t)cur * P.F + f) * 8 + (tid0 & 255)] = sm[TM_POSE + cur * 8 + (tid0 & 255)];
+  asm volatile("" ::"v"(nm.x), "v"(nX0), "v"(nX1), "v"(nX2));   // (the last prefetch has no consumer)
+}
+
+template <int TEAMS>
+static int resident_of(int device, int* out) {
+  const int lds = persist_lds_doubles(TEAMS) * 8;
+  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_intr_persist<TEAMS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  int per_cu = 0, cus = 0;
+  CC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_intr_persist<TEAMS>, TEAMS * 256, lds));
+  CC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+  // one workgroup per compute unit, whatever the query admits: a workgroup's teams are meant to have a CU to themselves
+  *out = per_cu >= 1 ? cus : 0;
+  return 0;
+}
+
+int persist_resident_workgroups(int device, int teams, int* out) {
+  return teams == 1 ? resident_of<1>(device, out) : teams == 2 ? resident_of<2>(device, out) : resident_of<4>(device, out);
+}
+
+void persist_launch(const IntrDev& P, const PersistDev& Q, bool exchange, hipStream_t stream) {
+  (void)exchange;
+  const dim3 grid((unsigned)Q.G + 1u);
+  if (Q.teams == 1) hipLaunchKernelGGL(k_intr_persist<1>, grid, dim3(256), persist_lds_doubles(1) * 8, stream, P, Q);
+  else if (Q.teams == 2) hipLaunchKernelGGL(k_intr_persist<2>, grid, dim3(512), persist_lds_doubles(2) * 8, stream, P, Q);
+  else hipLaunchKernelGGL(k_intr_persist<4>, grid, dim3(1024), persist_lds_doubles(4) * 8, stream, P, Q);
+}
+
+}  // namespace cc

@@ -1,0 +1,34 @@
+// cc_intrinsics_persist.hpp -- interface between the host side of the intrinsics solver (cc_intrinsics.hip) and the
+// persistent per-solve kernel (cc_intrinsics_persist.hip).
+#pragma once
+#include "cc_intrinsics_dev.hpp"
+
+namespace cc {
+
+constexpr int kPMaxTeams = 4;                     // frames (teams of four waves) per worker workgroup: 1, 2 or 4
+constexpr int kPStatCols = 16;                    // doubles per statistics row (4 sums; + 9 diagonal sums in the first round)
+constexpr int kPBcastWords = 64;                  // words per broadcast box
+constexpr int kPLeaderRows = 16;                  // elimination rows a leader workgroup adds up before the control sees them
+
+// Seam mailboxes of one handle: self-validating 8-byte words {epoch32 : half of a double}, agent-scope stores and
+// loads (cc_intrinsics_persist.hip). Device memory, zeroed at creation; epochs only ever grow.
+struct PersistDev {
+  unsigned long long* sbox;   // [G][2 * kPStatCols]   worker g's statistics row
+  unsigned long long* pbox;   // [G][2 * kPartialCols] worker g's elimination row
+  unsigned long long* lbox;   // [ceil(G / 16)][2 * kPartialCols] sum of sixteen elimination rows (by the leader among them)
+  unsigned long long* dbox;   // [kPBcastWords] decision broadcast: flags, radius, (first round) the nine Jacobi scales
+  unsigned long long* xbox;   // [kPBcastWords] step broadcast: flags, scaled shared step
+  unsigned* fail;             // [1] a wait inside the kernel timed out
+  int32_t G;                  // worker workgroups; the control workgroup is block G
+  int32_t teams;              // frames per worker workgroup (1, 2, 4): workgroups of 256 * teams threads
+  uint32_t epoch0;            // epochs of this launch: epoch0 + 1 ...
+  int32_t max_rounds;         // hard bound of the round loop (max_iterations + 2)
+  int32_t restart;            // start from the state of the last set_state (init arrays) instead of buffer 0
+  int32_t stagger;            // team k enters the sweep's main loop k * stagger sleep units late (0: in lockstep)
+};
+
+// workgroups of the `teams`-frame variant that can be resident on `device` at once (occupancy query x CUs)
+int persist_resident_workgroups(int device, int teams, int* out);
+void persist_launch(const IntrDev& P, const PersistDev& Q, bool exchange, hipStream_t stream);
+
+}  // namespace cc
