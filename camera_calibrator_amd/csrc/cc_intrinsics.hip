@@ -1265,8 +1265,8 @@ int intr_create_impl(cc_intrinsics* h, const int64_t* off, const float* uv, cons
   const size_t o_pbox0 = cursor;
   const size_t o_sbox = take(pgn * 2 * kPStatCols * sizeof(unsigned long long));
   const size_t o_pbox = take(pgn * 2 * kPartialCols * sizeof(unsigned long long));
+  const size_t o_rbox = take(pgn * 2 * kPartialCols * sizeof(unsigned long long));
   const size_t o_lbox = take(((pgn + kPLeaderRows - 1) / kPLeaderRows) * 2 * kPartialCols * sizeof(unsigned long long));
-  const size_t o_dbox = take(kPBcastWords * sizeof(unsigned long long));
   const size_t o_xbox = take(kPBcastWords * sizeof(unsigned long long));
   const size_t o_pfail = take(64);
   h->p_box_bytes = cursor - o_pbox0;
@@ -1325,7 +1325,7 @@ int intr_create_impl(cc_intrinsics* h, const int64_t* off, const float* uv, cons
   }
   h->pq.sbox = reinterpret_cast<unsigned long long*>(base + o_sbox);
   h->pq.pbox = reinterpret_cast<unsigned long long*>(base + o_pbox);
-  h->pq.dbox = reinterpret_cast<unsigned long long*>(base + o_dbox);
+  h->pq.rbox = reinterpret_cast<unsigned long long*>(base + o_rbox);
   h->pq.xbox = reinterpret_cast<unsigned long long*>(base + o_xbox);
   h->pq.fail = reinterpret_cast<unsigned*>(base + o_pfail);
   h->pq.lbox = reinterpret_cast<unsigned long long*>(base + o_lbox);
@@ -1578,7 +1578,7 @@ static int solve_persistent(cc_intrinsics* h, SolveRun* r) {
   PersistDev q = h->pq;
   q.max_rounds = r->o.max_iterations + 2;
   q.restart = h->reset_pending ? 1 : 0;
-  const uint32_t need = 2u * (uint32_t)q.max_rounds + 2u;
+  const uint32_t need = 3u * (uint32_t)q.max_rounds + 3u;
   if (h->p_epoch > 0xf0000000u - need) {   // before the 32-bit epochs wrap: forget every word ever stored
     CC_HIP(hipMemsetAsync(h->pq.sbox, 0, h->p_box_bytes, h->stream));
     h->p_epoch = 0;
@@ -1721,11 +1721,16 @@ int cc_intrinsics_optimize_multi(const cc_options* opt, int32_t n_devices, const
 // Scripts only (not in the public header): copy of a device vector. name: "vec_solve" (timing marks of timing-only builds).
 int cc_intrinsics_debug_fetch(cc_intrinsics* h, const char* name, double* out, int64_t n) {
   using namespace cc;
-  if (!h || !name || !out || n < 0 || n > kVecSolve || std::string(name) != "vec_solve")
-    return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_debug_fetch: bad arguments");
+  if (!h || !name || !out || n < 0) return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_debug_fetch: bad arguments");
+  const std::string k(name);
+  const double* src = nullptr;
+  int64_t cap = 0;
+  if (k == "vec_solve") { src = h->d.vec_solve; cap = kVecSolve; }
+  else if (k == "stats") { src = h->d.stats; cap = h->F * h->d.T * kStatsCols; }   // (timing builds of the persistent kernel: per-workgroup marks)
+  if (!src || n > cap) return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_debug_fetch: unknown buffer or too long");
   CC_HIP(hipSetDevice(h->device));
   CC_HIP(hipStreamSynchronize(h->stream));
-  CC_HIP(hipMemcpy(out, h->d.vec_solve, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  CC_HIP(hipMemcpy(out, src, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
   return CC_OK;
 }
 

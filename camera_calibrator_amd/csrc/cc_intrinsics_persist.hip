@@ -37,21 +37,28 @@ typedef unsigned long long u64;
 #endif
 #define PW_MARK(i) do { if (round == CC_PERSIST_TIMING_ROUND && (int)blockIdx.x == (Q.G / 2 / kPLeaderRows) * kPLeaderRows && threadIdx.x == 0) P.vec_solve[(i)] = (double)wall_clock64(); } while (0)
 #define PC_MARK(i) do { if (round == CC_PERSIST_TIMING_ROUND && threadIdx.x == 0) P.vec_solve[16 + (i)] = (double)wall_clock64(); } while (0)
+// every worker workgroup: four marks per round in P.stats (unused by the persistent path) -> the skew between workgroups
+#define PG_MARK(i) do { if (round == CC_PERSIST_TIMING_ROUND && threadIdx.x == 0) P.stats[(size_t)blockIdx.x * 4 + (i)] = (double)wall_clock64(); } while (0)
 #else
+#define PG_MARK(i) do { } while (0)
 #define PW_MARK(i) do { } while (0)
 #define PC_MARK(i) do { } while (0)
 #endif
 
 // LDS of a workgroup with TEAMS frames: one staging tile per wave, both Gram blocks and the scratch of every team, the
-// workgroup's scratch. 155,648 B at four teams (one workgroup per compute unit), 40,448 B at one.
-constexpr int persist_lds_doubles(int teams) { return teams * 4 * kStageDoublesPerWave + teams * 2 * 256 + teams * 192 + 256; }
+// workgroup's scratch. 157,696 B at four teams (one workgroup per compute unit), 42,496 B at one.
+constexpr int persist_lds_doubles(int teams) { return teams * 4 * kStageDoublesPerWave + teams * 2 * 256 + teams * 192 + 512; }
 
 // per-team scratch (doubles)
 enum { TM_Y = 0, TM_POSE = 60, TM_SP = 76, TM_STEP = 84, TM_R = 100, TM_T = 109, TM_KC = 112, TM_STEP2 = 122, TM_XN2 = 123,
        TM_QW = 124, TM_STAT = 128 /* cost, q_model, step^2, |x|^2, then nine diagonal entries (first round) */ };
 // workgroup scratch (doubles)
-enum { WG_INTR = 0 /* [2][16] */, WG_DEC = 64 /* flags, radius, ss[9] */, WG_SS = 66, WG_STEP = 80 /* flags, ds[9] */, WG_DS = 81,
-       WG_OPT = 100 /* jacobi, min / max LM diagonal */, WG_TAB = 104 /* pj / pk byte tables */ };
+enum { WG_INTR = 0 /* [2][16] */, WG_X = 64 /* the control's last broadcast: flags, radius, nine doubles */, WG_DS = 66 /* ... the step */,
+       WG_SS = 80 /* Jacobi scales of the shared block (first broadcast) */, WG_OPT = 100 /* jacobi, min / max LM diagonal, max radius */,
+       WG_TAB = 104 /* pj / pk byte tables */,
+       // slot table of the elimination row (80 slots; built once per solve, when the Jacobi scales arrive): scale factors,
+       // source entry of the Gram block, the two columns of Z whose product is subtracted (| 1 << 16: there is one)
+       WG_TSA = 256, WG_TSB = 336, WG_TGI = 416 /* int[80] */, WG_TZ = 456 /* int[80] */ };
 
 // ceres::QuaternionManifold::Plus with the series coefficients of cc::quat_plus (cc_common.hpp: same values, same
 // Horner order, same bits) read from constant memory through a pointer the compiler cannot see through: written as
@@ -95,6 +102,10 @@ __device__ __forceinline__ u64 granule(unsigned tag, double v, int half) {
 }
 __device__ __forceinline__ double ungranule(u64 lo, u64 hi) { return __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull))); }
 
+// The trust-region radius after an accepted step of quality >= 0.937: Ceres' r / max(1/3, 1 - (2 rho - 1)^3) with the
+// maximum taken by its first argument (lm_apply, cc_common.hpp). Workers and control evaluate this one expression.
+__device__ __forceinline__ double persist_spec_radius(double radius, double max_radius) { return fmin(max_radius, radius / (1.0 / 3.0)); }
+
 // One wave waits until the n doubles of a broadcast box carry `tag` and leaves them in dst[0..n) (LDS); lane l polls
 // word l. false: gave up (timeout, or somebody else already failed); the failure word is set.
 __device__ __forceinline__ bool bcast_wait(const u64* box, unsigned tag, int n, double* dst, unsigned* fail, int lane) {
@@ -117,10 +128,10 @@ __device__ __forceinline__ bool bcast_wait(const u64* box, unsigned tag, int n, 
 }
 
 // Control workgroup, all 1024 threads: column sums (maximum for column `maxcol`) of the G rows of a box whose words
-// carry `tag`. Thread -> (column, row group): rows grp, grp + NG, ... are polled eight at a time (all sixteen loads in
-// flight, unconditional from clamped rows) and added in that order; the NG group sums are then added in group order.
+// carry `tag`. Thread -> (column, row group): rows grp, grp + NG, ... are polled BATCH at a time (all 2 BATCH loads in
+// flight, unconditional from clamped rows; BATCH = what sixteen rows need where there are never more) and added in that order; the NG group sums are then added in group order.
 // out[0..ncols) valid for every thread after return. *s_ok (LDS) ends 0 when a row did not show up in time.
-template <int NC, int NG>
+template <int NC, int NG, int BATCH = 8>
 __device__ __forceinline__ void gather_rows(const u64* box, int G, unsigned tag, int ncols, int maxcol, double* s_part,
                                             double* out, unsigned* fail, int* s_ok) {
   const int tid = threadIdx.x, col = tid % NC, grp = tid / NC;
@@ -130,11 +141,11 @@ __device__ __forceinline__ void gather_rows(const u64* box, int G, unsigned tag,
     double acc = 0.0;
     bool good = true;
     const long long t0 = wall_clock64();
-    for (int r0 = grp; r0 < G && good; r0 += 8 * NG) {
-      u64 lo[8], hi[8];
+    for (int r0 = grp; r0 < G && good; r0 += BATCH * NG) {
+      u64 lo[BATCH], hi[BATCH];
       for (unsigned spins = 0;; ++spins) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < BATCH; ++u) {
           const int r = r0 + u * NG;
           const u64* p = box + (size_t)(r < G ? r : r0) * (2 * NC) + 2 * col;
           lo[u] = ag_ld(p);
@@ -142,14 +153,14 @@ __device__ __forceinline__ void gather_rows(const u64* box, int G, unsigned tag,
         }
         bool ok = true;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) ok = ok && (unsigned)(lo[u] >> 32) == tag && (unsigned)(hi[u] >> 32) == tag;
+        for (int u = 0; u < BATCH; ++u) ok = ok && (unsigned)(lo[u] >> 32) == tag && (unsigned)(hi[u] >> 32) == tag;
         if (ok) break;
         if ((spins & 63u) == 63u && (timed_out(t0) || ag_ld32(fail) != 0u)) { good = false; break; }
         __builtin_amdgcn_s_sleep(1);
       }
       if (!good) break;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < BATCH; ++u) {
         if (r0 + u * NG < G) {
           const double v = ungranule(lo[u], hi[u]);
           acc = col == maxcol ? fmax(acc, v) : acc + v;
@@ -242,16 +253,20 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
   const uint32_t mask = P.mask;
 
   for (int round = 0; round < Q.max_rounds; ++round) {
-    const unsigned e1 = Q.epoch0 + 2u * (unsigned)round + 1u, e2 = e1 + 1u;
+    const unsigned e1 = Q.epoch0 + 3u * (unsigned)round + 1u, e2 = e1 + 1u, e3 = e1 + 2u;
     const bool phase0 = round == 0;
-    // ---- seam 1: statistics -> decision
+    // ---- statistics -> decision. Meanwhile the workers eliminate on the ASSUMPTION that the candidate is accepted with
+    // a quality >= 0.937, where Ceres' radius update r / max(1/3, 1 - (2 rho - 1)^3) is exactly r / (1/3): the usual
+    // outcome of an LM step that works. A decision that says otherwise (rejection, a mediocre step, the first round) is
+    // a MISS: it is broadcast on its own and the workers eliminate again with what it says.
     PC_MARK(0);
     if (phase0) gather_rows<kPStatCols, THREADS / kPStatCols>(Q.sbox, Q.G, e1, 13, -1, s_part, s_tot, Q.fail, s_int);
     else gather_stats4<THREADS>(Q.sbox, Q.G, e1, s_part, s_tot, Q.fail, s_int);
     PC_MARK(1);
     if (tid == 0) {
       LmCtl c = *s_ctl;
-      const int len0 = c.log_len;
+      const int len0 = c.log_len, prev_cur = c.cur & 1, was_valid = c.step_valid;
+      const double prev_radius = c.radius;
       const double* kc0 = s_intr + (c.cur ? 16 : 0);   // accepted intrinsics
       const double* kc1 = s_intr + (c.cur ? 0 : 16);   // candidate
       if (!s_int[0]) {
@@ -281,23 +296,29 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
       if (!c.done && round + 1 >= Q.max_rounds) { c.done = 1; c.term = CC_NO_CONVERGENCE; }   // (never first: lm_apply counts iterations)
       *s_ctl = c;
       s_int[1] = c.log_len != len0;
-      s_bc[0] = (double)((c.done ? 1 : 0) | ((c.cur & 1) << 1));
+      // did the workers' assumption hold? (the same expression they evaluate: persist_spec_radius)
+      s_int[2] = !phase0 && was_valid && !c.done && (c.cur & 1) == (prev_cur ^ 1) && c.radius == persist_spec_radius(prev_radius, o.max_radius);
+      s_bc[0] = (double)((c.done ? 1 : 0) | ((c.cur & 1) << 3));
       s_bc[1] = c.radius;
 #pragma unroll
-      for (int i = 0; i < 9; ++i) s_bc[2 + i] = s_ss[i];
+      for (int i = 0; i < 9; ++i) s_bc[2 + i] = phase0 ? s_ss[i] : 0.0;
     }
     __syncthreads();
     PC_MARK(2);
-    if (tid < 2 * (phase0 ? 11 : 2)) ag_st(Q.dbox + tid, granule(e1, s_bc[tid >> 1], tid & 1));
-    if (s_ctl->done) {
-      // a decision that ends the solve (tolerance, iteration limit) still owes its log record
-      if (tid == 0 && s_int[1] && s_ctl->log_len <= P.log_cap) P.log[s_ctl->log_len - 1] = *s_log;
-      break;
+    const bool hit = s_int[2] != 0;
+    if (s_ctl->done || !hit) {
+      if (tid < 22) ag_st(Q.xbox + tid, granule(e2, s_bc[tid >> 1], tid & 1));
+      if (s_ctl->done) {
+        // a decision that ends the solve (tolerance, iteration limit) still owes its log record
+        if (tid == 0 && s_int[1] && s_ctl->log_len <= P.log_cap) P.log[s_ctl->log_len - 1] = *s_log;
+        break;
+      }
     }
-    // ---- seam 2: elimination rows -> gradient tests, reduced solve
+    // ---- elimination rows (of the assumption, or of the second elimination after a miss) -> gradient tests, reduced solve
+    const unsigned erow = hit ? e2 : e3;
     PC_MARK(3);
     // (the leaders among the workers have added the elimination rows sixteen at a time: one round trip here)
-    gather_rows<kPartialCols, THREADS / kPartialCols>(Q.lbox, (Q.G + kPLeaderRows - 1) / kPLeaderRows, e2, kPartialCols, PC_GMAXP, s_part, sv, Q.fail, s_int);
+    gather_rows<kPartialCols, THREADS / kPartialCols, (kPLeaderRows + THREADS / kPartialCols - 1) / (THREADS / kPartialCols)>(Q.lbox, (Q.G + kPLeaderRows - 1) / kPLeaderRows, erow, kPartialCols, PC_GMAXP, s_part, sv, Q.fail, s_int);
     PC_MARK(4);
     if (wave == 0) {
       const int cur = s_ctl->cur & 1;
@@ -308,26 +329,30 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
         if (!(mask & (1u << j))) gmax = fmax(gmax, fabs(sv[PC_GS + j]));
       const bool go = s_int[0] && !(gmax <= o.gradient_tolerance) && !(radius < o.min_radius);
       bool ok = !(sv[PC_FAIL] > 0.0);
+      PC_MARK(7);
       double x[9];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) x[i] = 0.0;
-      if (go) {
-        // row `lane` of the damped reduced system (sv[0..44]: upper triangle, row-major pairs j <= k)
+      {
+        // row `lane` of the damped reduced system (sv[0..44]: upper triangle, row-major pairs j <= k). Built and solved
+        // whether or not the tests above let the solve go on: nothing else waits on this wave, and a branch on `go`
+        // would put the gradient maximum in front of the factorisation.
         const int i = lane < 9 ? lane : 8;
         const bool pin_i = (mask >> i) & 1u;
+        const double damp = clampd(sv[PC_HDIAG + i], o.min_lm_diagonal, o.max_lm_diagonal) / radius;   // (ONE division per lane)
         double a[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
           const int kk = k <= i ? k : i;                           // (entries beyond the diagonal: ignored, keep them finite)
           const int idx = kk * 9 - kk * (kk - 1) / 2 + (i - kk);   // pair (kk, i)
           double v = sv[idx];
-          if (k == i) v += clampd(sv[PC_HDIAG + i], o.min_lm_diagonal, o.max_lm_diagonal) / radius;
+          if (k == i) v += damp;
           const bool pin_k = (mask >> kk) & 1u;
           if (pin_i || pin_k) v = (k == i) ? 1.0 : 0.0;           // SubsetManifold: unit row / column, zero right-hand side
           a[k] = v;
         }
         const double b = pin_i ? 0.0 : sv[PC_B + i];
+        PC_MARK(8);
         ok = chol_solve_rows<9>(a, b, x) && ok;
+        PC_MARK(9);
 #pragma unroll
         for (int j = 0; j < 9; ++j) ok = ok && isfinite(x[j]);
       }
@@ -336,26 +361,37 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
         double xs = 0.0;
 #pragma unroll
         for (int j = 0; j < 9; ++j) xs = lane == j ? x[j] : xs;
-        const double ds = -xs;
-        s_bc[1 + lane] = ds;
+        const double ds = go ? -xs : 0.0;
+        s_bc[2 + lane] = ds;
         const double d = ((mask >> lane) & 1u) ? 0.0 : ds * s_ss[lane];
         s_intr[(cur ^ 1) * 16 + lane] = s_intr[cur * 16 + lane] + d;
       }
       if (lane == 0) {
-        LmCtl c = *s_ctl;
-        cc_iteration* e = s_int[1] ? s_log : nullptr;
-        if (e && e->accepted) e->gradient_max_norm = gmax;
-        if (!s_int[0]) { c.done = 1; c.term = CC_FAILURE_EXCHANGE; }
-        else if (lm_finalize(c, o, gmax)) { c.step_valid = ok ? 1 : 0; c.cand_pending = 1; }
-        if (e && c.log_len <= P.log_cap) P.log[c.log_len - 1] = *e;
-        *s_ctl = c;
-        s_bc[0] = (double)((c.done ? 1 : 0) | (c.step_valid ? 2 : 0));
+        // the flags first (they are what the broadcast waits for), the control block and the log record behind them:
+        // lm_finalize below sets `done` exactly when `go` is false
+        s_bc[0] = (double)((go ? 0 : 1) | (go && ok ? 2 : 0) | (hit ? 4 : 0) | (cur << 3));
+        s_bc[1] = radius;
       }
+      PC_MARK(10);
     }
     __syncthreads();
     PC_MARK(5);
-    if (tid < 20) ag_st(Q.xbox + tid, granule(e2, s_bc[tid >> 1], tid & 1));
+    if (tid < 22) ag_st(Q.xbox + tid, granule(erow, s_bc[tid >> 1], tid & 1));
     PC_MARK(6);
+    if (tid == 0) {
+      // (on the control block in LDS: only the fields lm_finalize touches move, not 144 bytes each way)
+      double gmax = sv[PC_GMAXP];
+#pragma unroll
+      for (int j = 0; j < 9; ++j)
+        if (!(mask & (1u << j))) gmax = fmax(gmax, fabs(sv[PC_GS + j]));
+      const bool ok = ((int)s_bc[0] & 2) != 0;
+      cc_iteration* e = s_int[1] ? s_log : nullptr;
+      if (e && e->accepted) e->gradient_max_norm = gmax;
+      if (!s_int[0]) { s_ctl->done = 1; s_ctl->term = CC_FAILURE_EXCHANGE; }
+      else if (lm_finalize(*s_ctl, o, gmax)) { s_ctl->step_valid = ok ? 1 : 0; s_ctl->cand_pending = 1; }
+      if (e && s_ctl->log_len <= P.log_cap) P.log[s_ctl->log_len - 1] = *e;
+    }
+    __syncthreads();
     if (s_ctl->done) break;
   }
   // ---- the solve is over: control block, intrinsics, publication
@@ -382,7 +418,7 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
   if ((int)blockIdx.x == Q.G) { persist_control<THREADS>(P, Q, s_stage); return; }
   double* s_G = s_stage + TEAMS * 4 * kStageDoublesPerWave;        // [TEAMS][2][256] Gram blocks of the teams' frames
   double* s_tm = s_G + TEAMS * 2 * 256;                            // [TEAMS][192] per-team scratch
-  double* s_wg = s_tm + TEAMS * 192;                               // [256] workgroup scratch
+  double* s_wg = s_tm + TEAMS * 192;                               // [512] workgroup scratch
   // Register budget: four teams are 1024 threads, which leaves 128 registers per lane, and the sweep's main loop needs
   // nearly all of them. Two things keep the rest of the kernel out of its way: (1) the round loop re-derives every
   // per-thread index from a FRESH copy of the thread id (an empty asm the compiler cannot see through), so that the
@@ -421,14 +457,14 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
     s_wg[WG_OPT] = o->jacobi_scaling ? 1.0 : 0.0;
     s_wg[WG_OPT + 1] = o->min_lm_diagonal;
     s_wg[WG_OPT + 2] = o->max_lm_diagonal;
+    s_wg[WG_OPT + 3] = o->max_radius;
   }
   if (tid == 33) {
     int oo = 0;
     for (int j = 0; j < 9; ++j)
       for (int k = j; k < 9; ++k) { pj[oo] = (unsigned char)j; pk[oo] = (unsigned char)k; ++oo; }
   }
-  if (tid >= 64 && tid < 64 + 20) s_wg[WG_DEC + tid - 64] = 0.0;
-  if (tid >= 96 && tid < 96 + 16) s_wg[WG_STEP + tid - 96] = 0.0;
+  if (tid >= 64 && tid < 64 + 32) s_wg[WG_X + tid - 64] = 0.0;
   __syncthreads();
   if (tid < 9) s_wg[WG_INTR + tid] = (Q.restart ? P.init_intr : P.intr)[tid];
   }
@@ -451,15 +487,17 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
   __syncthreads();
 
   int cur = 0;
+  double radius = 1.0;   // trust-region radius of the accepted point (known from the first broadcast on)
   bool step_valid = true, failed = false;
   for (int round = 0; round < Q.max_rounds; ++round) {
-    const unsigned e1 = Q.epoch0 + 2u * (unsigned)round + 1u, e2 = e1 + 1u;
+    const unsigned e1 = Q.epoch0 + 3u * (unsigned)round + 1u, e2 = e1 + 1u, e3 = e1 + 2u;
     const bool phase0 = round == 0;
     const bool do_sweep = phase0 || step_valid;
     const int dst = phase0 ? cur : (cur ^ 1);
     // =========================== sweep (candidate point, or the starting point in the first round)
     d4 acc0, acc1;
     PW_MARK(0);
+    PG_MARK(0);
     if (do_sweep) {
       CC_FRESH_TID(tid);
       const int ttid = tid & 255, lane = tid & 63;
@@ -614,35 +652,23 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
         ag_st(Q.sbox + (size_t)blockIdx.x * (2 * kPStatCols) + tid, granule(e1, a, tid & 1));
       }
     }
-    // =========================== seam 1: the decision
-    PW_MARK(6);
-    {
-      CC_FRESH_TID(tid);
-      if (wave == 0 && !bcast_wait(Q.dbox, e1, phase0 ? 11 : 2, s_wg + WG_DEC, Q.fail, tid & 63)) s_wg[WG_DEC] = 5.0;   // done + failed
-    }
-    __syncthreads();
-    {
-      const int fl = (int)s_wg[WG_DEC];
-      cur = (fl >> 1) & 1;
-      if (fl & 4) failed = true;
-      if (fl & 1) break;
-    }
-    // =========================== elimination of the frame's pose block at the accepted point
-    PW_MARK(7);
+    // =========================== elimination of the frame's pose block at buffer cur_e under radius_e, the workgroup's
+    // row -> box (tag), and -- leaders -- the sum of sixteen rows -> lbox (tag)
+    auto eliminate_and_post = [&](const int cur_e, const double radius_e, const bool first, u64* box, const unsigned tag) {
     CC_FRESH_TID(tid_e);
     if (has_frame && (tid_e & 255) >= sbase && (tid_e & 255) < sbase + 16) {
       const int l = (tid_e & 255) - sbase;
-      const double* Gl = s_G + (team * 2 + cur) * 256;
+      const double* Gl = s_G + (team * 2 + cur_e) * 256;
       const double* ss = s_wg + WG_SS;
       const bool jac = s_wg[WG_OPT] != 0.0;
       const double mn = s_wg[WG_OPT + 1], mx = s_wg[WG_OPT + 2];
-      const double inv_radius = 1.0 / s_wg[WG_DEC + 1];
+      const double inv_radius = 1.0 / radius_e;
       double s[6], L[21];
 #pragma unroll
       for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int j = 0; j <= i; ++j) L[tri(i, j)] = Gl[(9 + i) * 16 + 9 + j];
-      if (phase0) {
+      if (first) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) s[i] = jac ? 1.0 / (1.0 + sqrt(L[tri(i, i)])) : 1.0;
         if (l < 6) {
@@ -680,6 +706,7 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
           L[tri(i, j)] = a * inv;
         }
       }
+      PW_MARK(13);
       // the factor is the same in all sixteen lanes: from here on it lives in scalar registers (48 of them), not in 54
       // vector registers next to each lane's own columns
 #pragma unroll
@@ -712,40 +739,30 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
           sm[TM_Y + i * 10 + l] = y[i];
         }
       }
+      PW_MARK(14);
       wave_lds_fence();   // (the sixteen lanes are one wave: its LDS operations execute in order)
-      // output slots l * 5 + r of this lane (layout of k_intr_decide_elim's partial row)
+      // output slots l * 5 + r of this lane, from the slot table: five independent lookups, no branches (written out per
+      // slot kind, every branch ended in a wait for its own LDS reads)
+      const int* tgi = reinterpret_cast<const int*>(s_wg + WG_TGI);
+      const int* tz = reinterpret_cast<const int*>(s_wg + WG_TZ);
       double accv[5];
-      int zj[5], zk[5];
-      bool use_z[5];
+      int zz_[5];
 #pragma unroll
       for (int r = 0; r < 5; ++r) {
         const int o = l * 5 + r;
-        int gi = 0;
-        double sa = 0.0, sb = 0.0;
-        zj[r] = 0; zk[r] = 0; use_z[r] = false;
-        if (o < 45) {
-          const int j = pj[o], k = pk[o];
-          gi = j * 16 + k; zj[r] = j; zk[r] = k; sa = ss[j]; sb = ss[k]; use_z[r] = true;
-        } else if (o < 54) {
-          const int j = o - 45;
-          gi = j * 16 + 15; zj[r] = j; zk[r] = 9; sa = ss[j]; sb = 1.0; use_z[r] = true;
-        } else if (o < 63) {
-          const int j = o - 54;
-          gi = j * 17; sa = ss[j] * ss[j]; sb = 1.0;
-        } else if (o >= PC_GS && o < PC_GS + 9) {
-          gi = (o - PC_GS) * 16 + 15; sa = 1.0; sb = 1.0;
-        }
-        accv[r] = sa * Gl[gi] * sb;
+        zz_[r] = tz[o];
+        accv[r] = s_wg[WG_TSA + o] * Gl[tgi[o]] * s_wg[WG_TSB + o];
       }
       const int l6 = l < 6 ? l : l - 6 < 6 ? l - 6 : l - 12;
       const double gp = fabs(Gl[(9 + l6) * 16 + 15]);
 #pragma unroll
       for (int r = 0; r < 5; ++r) {
+        const int zj = zz_[r] & 255, zk = (zz_[r] >> 8) & 255;
         double zz = 0.0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) zz += Zs[i * 10 + zj[r]] * Zs[i * 10 + zk[r]];
+        for (int i = 0; i < 6; ++i) zz += Zs[i * 10 + zj] * Zs[i * 10 + zk];
         const int o = l * 5 + r;
-        if (o != PC_FAIL && o != PC_GMAXP) red[o] = accv[r] - (use_z[r] ? zz : 0.0);
+        if (o != PC_FAIL && o != PC_GMAXP) red[o] = accv[r] - ((zz_[r] >> 16) ? zz : 0.0);
       }
       const double gmaxp = row16_max(gp);
       if (l == 0) { red[PC_FAIL] = ok ? 0.0 : 1.0; red[PC_GMAXP] = gmaxp; }
@@ -765,37 +782,88 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
             a = c == PC_GMAXP ? fmax(a, v) : a + v;
           }
         }
-        ag_st(Q.pbox + (size_t)blockIdx.x * (2 * kPartialCols) + tid, granule(e2, a, tid & 1));
+        ag_st(box + (size_t)blockIdx.x * (2 * kPartialCols) + tid, granule(tag, a, tid & 1));
       }
     }
     PW_MARK(9);
+    PG_MARK(2);
     // ---- every sixteenth workgroup is a LEADER: it adds up the rows of its sixteen (it would only be waiting for the
     // step otherwise) and posts ONE row for the control, which then reads G / 16 rows in a single round trip instead of G
     if ((blockIdx.x % kPLeaderRows) == 0) {
       int* s_lok = reinterpret_cast<int*>(s_wg + 250);
       const int g0 = (int)blockIdx.x, n = Q.G - g0 < kPLeaderRows ? Q.G - g0 : kPLeaderRows;
       double* lout = s_wg + 128;        // [80]; the group sums go through team 0's staging tiles (idle between sweeps)
-      gather_rows<kPartialCols, THREADS / kPartialCols>(Q.pbox + (size_t)g0 * (2 * kPartialCols), n, e2, kPartialCols, PC_GMAXP, s_stage + 2048, lout,
+      gather_rows<kPartialCols, THREADS / kPartialCols, (kPLeaderRows + THREADS / kPartialCols - 1) / (THREADS / kPartialCols)>(box + (size_t)g0 * (2 * kPartialCols), n, tag, kPartialCols, PC_GMAXP, s_stage + 2048, lout,
                                                         Q.fail, s_lok);
       PW_MARK(11);
       CC_FRESH_TID(tid);
       // (rows that did not arrive: nothing is posted, the control's own wait gives up and ends the solve)
-      if (*s_lok && tid < 2 * kPartialCols) ag_st(Q.lbox + (size_t)(g0 / kPLeaderRows) * (2 * kPartialCols) + tid, granule(e2, lout[tid >> 1], tid & 1));
+      if (*s_lok && tid < 2 * kPartialCols) ag_st(Q.lbox + (size_t)(g0 / kPLeaderRows) * (2 * kPartialCols) + tid, granule(tag, lout[tid >> 1], tid & 1));
     }
-    // =========================== seam 2: the step
-    PW_MARK(12);
-    {
+    };
+    // one wave waits for the control's broadcast `tag` (flags, radius, nine doubles) -> s_wg[WG_X ..]
+    auto wait_bcast = [&](const unsigned tag) {
       CC_FRESH_TID(tid);
-      if (wave == 0 && !bcast_wait(Q.xbox, e2, 10, s_wg + WG_STEP, Q.fail, tid & 63)) s_wg[WG_STEP] = 5.0;
-    }
-    __syncthreads();
+      if (wave == 0 && !bcast_wait(Q.xbox, tag, 11, s_wg + WG_X, Q.fail, tid & 63)) s_wg[WG_X] = 17.0;   // done + failed
+      __syncthreads();
+    };
+
+    // =========================== the assumed decision: candidate accepted, radius at its clamp (see the control).
+    // Eliminating NOW, next to the control's gathering and deciding, takes a seam out of the round when it holds.
+    PW_MARK(6);
+    PG_MARK(1);
+    const bool spec = !phase0 && do_sweep;
+    const double radius_spec = persist_spec_radius(radius, s_wg[WG_OPT + 3]);
+    if (spec) eliminate_and_post(dst, radius_spec, false, Q.pbox, e2);
+    PW_MARK(7);
+    wait_bcast(e2);
     PW_MARK(10);
-    {
-      const int fl = (int)s_wg[WG_STEP];
-      step_valid = (fl & 2) != 0;
-      if (fl & 4) failed = true;
-      if (fl & 1) break;
+    PG_MARK(3);
+    int fl = (int)s_wg[WG_X];
+    if (fl & 16) failed = true;
+    if (fl & 1) { cur = (fl >> 3) & 1; break; }
+    if (fl & 4) {   // the assumption held: this broadcast IS the step
+      cur = dst;
+      radius = radius_spec;
+    } else {        // it did not (or there was none): eliminate with what the decision says, then wait for the step
+      cur = (fl >> 3) & 1;
+      radius = s_wg[WG_X + 1];
+      if (phase0) {
+        CC_FRESH_TID(tid);
+        if (tid < 9) s_wg[WG_SS + tid] = s_wg[WG_X + 2 + tid];
+        __syncthreads();
+        if (tid < kPartialCols) {   // slot `tid` of the elimination row (layout of k_intr_decide_elim's partial row)
+          const double* ss = s_wg + WG_SS;
+          const int o = tid;
+          int gi = 0, z = 0;
+          double sa = 0.0, sb = 0.0;
+          if (o < 45) {
+            const int j = pj[o], k = pk[o];
+            gi = j * 16 + k; z = j | (k << 8) | (1 << 16); sa = ss[j]; sb = ss[k];
+          } else if (o < 54) {
+            const int j = o - 45;
+            gi = j * 16 + 15; z = j | (9 << 8) | (1 << 16); sa = ss[j]; sb = 1.0;
+          } else if (o < 63) {
+            const int j = o - 54;
+            gi = j * 17; sa = ss[j] * ss[j]; sb = 1.0;
+          } else if (o >= PC_GS && o < PC_GS + 9) {
+            gi = (o - PC_GS) * 16 + 15; sa = 1.0; sb = 1.0;
+          }
+          s_wg[WG_TSA + o] = sa;
+          s_wg[WG_TSB + o] = sb;
+          reinterpret_cast<int*>(s_wg + WG_TGI)[o] = gi;
+          reinterpret_cast<int*>(s_wg + WG_TZ)[o] = z;
+        }
+        __syncthreads();
+      }
+      eliminate_and_post(cur, radius, phase0, Q.rbox, e3);
+      wait_bcast(e3);
+      PW_MARK(12);
+      fl = (int)s_wg[WG_X];
+      if (fl & 16) failed = true;
+      if (fl & 1) { cur = (fl >> 3) & 1; break; }
     }
+    step_valid = (fl & 2) != 0;
   }
   // ---- the solve is over: the frame's accepted pose goes back to HBM (cc_intrinsics_get_state, the next solve)
   if (!failed && has_frame && (tid0 & 255) < 7) P.pose[((size_t)cur * P.F + f) * 8 + (tid0 & 255)] = sm[TM_POSE + cur * 8 + (tid0 & 255)];

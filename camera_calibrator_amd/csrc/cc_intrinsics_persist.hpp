@@ -14,15 +14,15 @@ constexpr int kPLeaderRows = 16;                  // elimination rows a leader w
 // loads (cc_intrinsics_persist.hip). Device memory, zeroed at creation; epochs only ever grow.
 struct PersistDev {
   unsigned long long* sbox;   // [G][2 * kPStatCols]   worker g's statistics row
-  unsigned long long* pbox;   // [G][2 * kPartialCols] worker g's elimination row
+  unsigned long long* pbox;   // [G][2 * kPartialCols] worker g's elimination row (under the assumed decision)
+  unsigned long long* rbox;   // [G][2 * kPartialCols] ... of its second elimination in a round (after a decision the workers did not assume)
   unsigned long long* lbox;   // [ceil(G / 16)][2 * kPartialCols] sum of sixteen elimination rows (by the leader among them)
-  unsigned long long* dbox;   // [kPBcastWords] decision broadcast: flags, radius, (first round) the nine Jacobi scales
-  unsigned long long* xbox;   // [kPBcastWords] step broadcast: flags, scaled shared step
+  unsigned long long* xbox;   // [kPBcastWords] the control's broadcasts: flags, radius, nine doubles (step; Jacobi scales in the first round)
   unsigned* fail;             // [1] a wait inside the kernel timed out
   int32_t G;                  // worker workgroups; the control workgroup is block G
   int32_t teams;              // frames per worker workgroup (1, 2, 4): workgroups of 256 * teams threads
   uint32_t epoch0;            // epochs of this launch: epoch0 + 1 ...
-  int32_t max_rounds;         // hard bound of the round loop (max_iterations + 2)
+  int32_t max_rounds;         // hard bound of the round loop (max_iterations + 2); three epochs per round
   int32_t restart;            // start from the state of the last set_state (init arrays) instead of buffer 0
   int32_t stagger;            // team k enters the sweep's main loop k * stagger sleep units late (0: in lockstep)
 };

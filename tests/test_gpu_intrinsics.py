@@ -28,9 +28,14 @@ def _solve_both(case, const_mask=0, **opt_kw):
 def _assert_intrinsics_close(ig, io):
     assert np.all(np.abs(ig[:4] - io[:4]) <= 1e-9 * np.abs(io[:4]))
     assert np.all(np.abs(ig[4:] - io[4:]) <= 1e-9)
+    # float32 write-back (calibrator.cpp:326-335): identical or +-1 ulp -- for the entries whose float32 spacing is not
+    # finer than the fp64 tolerance above. p2 ~ -7e-6 has a float32 ulp of 9e-13, a thousand times below the 1e-9 the
+    # distortion coefficients are compared to (and below what a cost that is flat to 1e-15 determines them to): there the
+    # absolute tolerance is the criterion.
     f32g, f32o = ig.astype(np.float32), io.astype(np.float32)
     ulp = np.abs(f32g.view(np.int32).astype(np.int64) - f32o.view(np.int32).astype(np.int64))
-    assert ulp.max() <= 1, ulp
+    coarse = np.spacing(np.abs(f32o)).astype(np.float64) >= 1e-9
+    assert ulp[coarse].max() <= 1, ulp
 
 
 def _assert_same_minimiser_up_to_noise_level_steps(sg, so, ig, io):
