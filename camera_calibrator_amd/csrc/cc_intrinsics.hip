@@ -963,6 +963,19 @@ __global__ __launch_bounds__(kSolveThreads) void k_intr_solve(IntrDev P, int nbl
   if (publish) publish_to_host(P, c);
 }
 
+// one-off (attach time): sum of one number per rank through the mailboxes (kind 1) -- do ALL ranks fit the persistent kernel?
+__global__ __launch_bounds__(64) void k_intr_flag_exchange(IntrDev P, double mine, double* out, int* ok) {
+  __shared__ double s_post[16];
+  __shared__ int s_ok;
+  const int tid = threadIdx.x;
+  if (tid < 16) s_post[tid] = tid == 0 ? mine : 0.0;
+  __syncthreads();
+  const unsigned long long epoch = P.x.seq[1] + 1ull;
+  p2p_post(P.x, 1, epoch, P.rank, P.nranks, s_post, 16);
+  const double a = p2p_collect(P.x, 1, epoch, P.rank, P.nranks, 16, &s_ok);
+  if (tid == 0) { *out = a; P.x.seq[1] = epoch; *ok = s_ok; }
+}
+
 // restores the initial point into buffer 0 and clears the control blocks and the arrival counter (first
 // node of a solve-from-the-initial-state graph, or one launch per restart)
 __global__ __launch_bounds__(256) void k_intr_reset(IntrDev P, const double* init_intr, const double* init_pose) {
@@ -1022,7 +1035,10 @@ struct cc_intrinsics {
   std::vector<hipEvent_t> events;
   std::vector<int> event_kind;
   // persistent per-solve kernel (cc_intrinsics_persist.hip): usable when every frame gets a team of a resident workgroup
-  bool persist_ok = false;
+  bool persist_ok = false;      // ... on a device of its own
+  bool persist_x_ok = false;    // ... as one rank of an exchange: every rank fits next to the ranks it shares its device with,
+                                // and every rank said so (cc_intrinsics_exchange_attach / cc_intrinsics_optimize_multi agree on it)
+  int p_resident = 0;           // resident workgroups of the chosen shape on this device
   cc::PersistDev pq{};
   uint32_t p_epoch = 0;         // last epoch handed to a launch (the seam words only ever see growing epochs)
   size_t p_box_bytes = 0;       // seam mailboxes (re-zeroed before the epochs wrap)
@@ -1192,6 +1208,35 @@ int cc_intrinsics_exchange_attach(cc_intrinsics* h, int32_t rank, int32_t nranks
   h->d.rank = rank;
   h->d.nranks = nranks;
   h->exchange = true;
+  // Which form of the solver the ranks run must be ONE decision (the two forms add the reduced system up in different
+  // orders and solve it by different code: mixed, the ranks' intrinsics would drift apart in the last bits). A rank fits
+  // the persistent kernel when its workgroups are resident next to those of the ranks it shares its device with (the
+  // pigeonhole bound over the devices this process sees: one rank per GPU -> 1); the ranks exchange that bit. COLLECTIVE
+  // from here on: every rank must attach (10 s); a single rank skips it.
+  h->persist_x_ok = false;
+  if (h->persist_ok) {
+    int ndev = 1;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) ndev = 1;
+    const int co = getenv("CC_INTR_CO_RESIDENT") ? std::max(1, atoi(getenv("CC_INTR_CO_RESIDENT"))) : (nranks + ndev - 1) / ndev;
+    h->persist_x_ok = (int64_t)(h->pq.G + 1) * co <= h->p_resident;
+  }
+  if (nranks > 1) {
+    double* d_out = nullptr;
+    int* d_ok = nullptr;
+    CC_HIP(hipMalloc(&d_out, sizeof(double)));
+    CC_HIP(hipMalloc(&d_ok, sizeof(int)));
+    hipLaunchKernelGGL(k_intr_flag_exchange, dim3(1), dim3(64), 0, h->stream, h->d, h->persist_x_ok ? 1.0 : 0.0, d_out, d_ok);
+    double sum = 0.0;
+    int ok = 0;
+    const hipError_t e1 = hipMemcpyAsync(&sum, d_out, sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    const hipError_t e2 = hipMemcpyAsync(&ok, d_ok, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+    const hipError_t e3 = hipStreamSynchronize(h->stream);
+    hipFree(d_out);
+    hipFree(d_ok);
+    CC_HIP(e1); CC_HIP(e2); CC_HIP(e3);
+    if (!ok) return fail(CC_ERR_COMM, "cc_intrinsics_exchange_attach: a peer rank did not attach within 10 s");
+    h->persist_x_ok = sum == (double)nranks;
+  }
   return CC_OK;
 }
 
@@ -1252,12 +1297,12 @@ int intr_create_impl(cc_intrinsics* h, const int64_t* off, const float* uv, cons
     for (int t = 1; t <= kPMaxTeams && !p_teams; t *= 2) {
       int resident = 0;
       if (int rc = persist_resident_workgroups(h->device, t, &resident)) return rc;
-      if ((F + t - 1) / t + 1 <= resident) p_teams = t;
+      if ((F + t - 1) / t + 1 <= resident) { p_teams = t; h->p_resident = resident; }
     }
     if (const char* e = getenv("CC_INTR_PERSIST_TEAMS")) {   // (A/B: force a shape that fits)
       const int t = atoi(e);
       int resident = 0;
-      if ((t == 1 || t == 2 || t == 4) && !persist_resident_workgroups(h->device, t, &resident) && (F + t - 1) / t + 1 <= resident) p_teams = t;
+      if ((t == 1 || t == 2 || t == 4) && !persist_resident_workgroups(h->device, t, &resident) && (F + t - 1) / t + 1 <= resident) { p_teams = t; h->p_resident = resident; }
     }
   }
   const int64_t PG = p_teams ? (F + p_teams - 1) / p_teams : 1;
@@ -1574,7 +1619,12 @@ static int solve_wait(cc_intrinsics* h, SolveRun* r) {
 
 // The whole solve as one launch of the persistent kernel. Starts from buffer 0 (solve_begin moved a continued solve's
 // accepted point there) or, after set_state / reset, from the initial-state arrays.
-static int solve_persistent(cc_intrinsics* h, SolveRun* r) {
+static bool use_persistent(const cc_intrinsics* h, const SolveRun* r) {
+  return !h->comm && !r->profile && (h->exchange ? h->persist_x_ok : h->persist_ok);
+}
+
+static int persistent_launch(cc_intrinsics* h, SolveRun* r) {
+  CC_HIP(hipSetDevice(h->device));
   PersistDev q = h->pq;
   q.max_rounds = r->o.max_iterations + 2;
   q.restart = h->reset_pending ? 1 : 0;
@@ -1585,18 +1635,30 @@ static int solve_persistent(cc_intrinsics* h, SolveRun* r) {
   }
   q.epoch0 = h->p_epoch;
   h->p_epoch += need;
-  persist_launch(h->d, q, false, h->stream);
+  persist_launch(h->d, q, h->exchange, h->stream);
   CC_HIP(hipGetLastError());
   h->reset_pending = false;
   r->launched = q.max_rounds;
+  return 0;
+}
+
+static int persistent_wait(cc_intrinsics* h, SolveRun* r) {
+  CC_HIP(hipSetDevice(h->device));
   if (int rc = wait_published(h, &r->st)) return rc;
   if (r->st.done && r->st.term == CC_FAILURE_EXCHANGE) {
     CC_HIP(hipMemsetAsync(h->pq.fail, 0, sizeof(unsigned), h->stream));
     return fail(CC_ERR_COMM, "persistent solve: a wait inside the kernel timed out (iteration %d): its %d workgroups were not all "
-                "resident, or a peer stalled", r->st.iter, h->pq.G + 1);
+                "resident, or a peer rank did not post within 10 s", r->st.iter, h->pq.G + 1);
   }
   if (!r->st.done) return fail(CC_ERR_STATE, "persistent solve ended without a result (iter=%d)", r->st.iter);
   return 0;
+}
+
+// The whole solve as one launch of the persistent kernel. Starts from buffer 0 (solve_begin moved a continued solve's
+// accepted point there) or, after set_state / reset, from the initial-state arrays.
+static int solve_persistent(cc_intrinsics* h, SolveRun* r) {
+  if (int rc = persistent_launch(h, r)) return rc;
+  return persistent_wait(h, r);
 }
 
 static int solve_finish(cc_intrinsics* h, SolveRun* r, cc_summary* summary) {
@@ -1640,7 +1702,7 @@ int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* sum
   if (!h || !h->have_state) return fail(CC_ERR_STATE, "cc_intrinsics_solve: no state set");
   SolveRun r;
   if (int rc = solve_begin(h, opt, &r)) return rc;
-  if (h->persist_ok && !h->comm && !h->exchange && !r.profile) {
+  if (use_persistent(h, &r)) {
     // ONE launch runs the whole solve (cc_intrinsics_persist.hip); the host waits for its publication
     if (int rc = solve_persistent(h, &r)) return rc;
     return solve_finish(h, &r, summary);
@@ -1698,7 +1760,21 @@ int cc_intrinsics_optimize_multi(const cc_options* opt, int32_t n_devices, const
   o.use_graph = 0;   // one solve per handle: capturing and instantiating a graph cannot pay off
   std::vector<SolveRun> runs((size_t)n);
   for (int r = 0; r < n && !rc; ++r) rc = solve_begin(hs[(size_t)r], &o, &runs[(size_t)r]);
-  for (int chunk = 0; !rc; ++chunk) {
+  // the persistent form, when EVERY shard fits it next to the shards that share its device (all in this process: no
+  // exchange needed to agree): one launch per shard, all enqueued before any is waited for
+  bool all_persist = !rc;
+  for (int r = 0; r < n && all_persist; ++r) {
+    cc_intrinsics* h = hs[(size_t)r];
+    int co = 0;
+    for (auto* g : hs) if (g->device == h->device) ++co;
+    all_persist = h->persist_ok && (int64_t)(h->pq.G + 1) * co <= h->p_resident && !runs[(size_t)r].profile;
+  }
+  for (auto* h : hs) if (h) h->persist_x_ok = all_persist;
+  if (all_persist) {
+    for (int r = 0; r < n && !rc; ++r) rc = persistent_launch(hs[(size_t)r], &runs[(size_t)r]);
+    for (int r = 0; r < n && !rc; ++r) rc = persistent_wait(hs[(size_t)r], &runs[(size_t)r]);
+  }
+  for (int chunk = 0; !rc && !all_persist; ++chunk) {
     for (int r = 0; r < n && !rc; ++r) rc = solve_launch(hs[(size_t)r], &runs[(size_t)r], chunk);
     for (int r = 0; r < n && !rc; ++r) rc = solve_wait(hs[(size_t)r], &runs[(size_t)r]);
     if (rc) break;

@@ -262,6 +262,23 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
     PC_MARK(0);
     if (phase0) gather_rows<kPStatCols, THREADS / kPStatCols>(Q.sbox, Q.G, e1, 13, -1, s_part, s_tot, Q.fail, s_int);
     else gather_stats4<THREADS>(Q.sbox, Q.G, e1, s_part, s_tot, Q.fail, s_int);
+    if (P.x.on) {
+      // several GPUs (mailbox exchange, cc_device.hpp): this rank's sums go into every rank's mailbox, the slots are added
+      // in rank order -- the same sequence of exchanges, payloads and sums as k_intr_decide_elim<3> makes, skipped like
+      // there in a round that has no candidate to judge
+      const bool need = phase0 || (s_ctl->cand_pending && s_ctl->step_valid);
+      if (need) {
+        if (tid >= 13 && tid < 16) s_tot[tid] = 0.0;
+        __syncthreads();
+        const unsigned long long epoch = P.x.seq[1] + 1ull;
+        p2p_post(P.x, 1, epoch, P.rank, P.nranks, s_tot, 16);
+        int* s_ok2 = s_int + 4;
+        const double a = p2p_collect(P.x, 1, epoch, P.rank, P.nranks, 16, s_ok2);
+        if (tid < 16) s_tot[tid] = a;
+        if (tid == 0) { P.x.seq[1] = epoch; if (!*s_ok2) s_int[0] = 0; }
+        __syncthreads();
+      }
+    }
     PC_MARK(1);
     if (tid == 0) {
       LmCtl c = *s_ctl;
@@ -319,11 +336,31 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
     PC_MARK(3);
     // (the leaders among the workers have added the elimination rows sixteen at a time: one round trip here)
     gather_rows<kPartialCols, THREADS / kPartialCols, (kPLeaderRows + THREADS / kPartialCols - 1) / (THREADS / kPartialCols)>(Q.lbox, (Q.G + kPLeaderRows - 1) / kPLeaderRows, erow, kPartialCols, PC_GMAXP, s_part, sv, Q.fail, s_int);
+    if (P.x.on) {
+      // all-reduce of the 112 sums through the mailboxes (kind 0): the maximum of the pose gradients rides in a slot per rank
+      if (tid >= kPartialCols && tid < kVecSolve) sv[tid] = 0.0;
+      __syncthreads();
+      if (tid == 0) { sv[kPartialCols + P.rank] = sv[PC_GMAXP]; sv[PC_GMAXP] = 0.0; }
+      __syncthreads();
+      const unsigned long long epoch = P.x.seq[0] + 1ull;
+      p2p_post(P.x, 0, epoch, P.rank, P.nranks, sv, kVecSolve);
+      int* s_ok2 = s_int + 4;
+      const double a = p2p_collect(P.x, 0, epoch, P.rank, P.nranks, kVecSolve, s_ok2);
+      if (tid < kVecSolve) sv[tid] = a;
+      if (tid == 0) { P.x.seq[0] = epoch; if (!*s_ok2) s_int[0] = 0; }
+      __syncthreads();
+      if (tid == 0) {
+        double g = 0.0;
+        for (int r = 0; r < P.nranks && r < 32; ++r) g = fmax(g, sv[kPartialCols + r]);
+        sv[PC_GMAXP] = g;
+      }
+      __syncthreads();
+    }
     PC_MARK(4);
     if (wave == 0) {
       const int cur = s_ctl->cur & 1;
       const double radius = s_ctl->radius;
-      double gmax = sv[PC_GMAXP];   // (one rank: the maximum over the pose gradients is this rank's)
+      double gmax = sv[PC_GMAXP];   // (the maximum over the pose gradients of all ranks)
 #pragma unroll
       for (int j = 0; j < 9; ++j)
         if (!(mask & (1u << j))) gmax = fmax(gmax, fabs(sv[PC_GS + j]));

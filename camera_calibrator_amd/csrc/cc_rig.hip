@@ -2769,7 +2769,10 @@ static int rig_size_reduce_grid(cc_rig* h) {
   if (per_cu < 1 || cus < 1) return fail(CC_ERR_HIP, "k_rig_reduce does not fit a compute unit (%zu bytes of LDS)", h->solve_lds);
   if (per_cu > 1) per_cu -= 1;
   per_cu = std::min(per_cu, 8);
-  const int64_t resident = std::max<int64_t>(1, (int64_t)per_cu * cus / co);
+  // ... and an eighth of the chip stays free: the kernels of the OTHER ranks that run before their own reduce launches
+  // (sweep, elimination) need somewhere to go while this rank's blocks spin, and a grid that needs every last compute
+  // unit hangs on the first one that is not available (three ranks x 85 blocks of 110 KB on 256 units did, round 3)
+  const int64_t resident = std::max<int64_t>(1, (int64_t)per_cu * cus * 7 / 8 / co);
   const int64_t want = std::max<int64_t>((h->d.PC + 15) / 16, (h->F + 15) / 16);
   const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(rcap, want), resident));
   if (blocks != h->reduce_blocks) rig_drop_graphs(h);   // the grid is baked into captured launches

@@ -42,7 +42,8 @@ def _run_ranks(world, frames, pts, tmp_path, extra=()):
                 p.kill()
         raise
     for r, p in enumerate(procs):
-        assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"
+        assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}\n" + "\n".join(
+            f"---- rank {k} (rc {q.returncode}) ----\n{logs[k][-1200:]}" for k, q in enumerate(procs) if k != r)
     return [np.load(o) for o in outs]
 
 
