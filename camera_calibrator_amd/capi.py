@@ -78,7 +78,7 @@ EXPORTED_SYMBOLS = [
     "cc_options_init", "cc_last_error", "cc_version", "cc_device_count",
     "cc_intrinsics_create", "cc_intrinsics_destroy", "cc_intrinsics_set_state",
     "cc_intrinsics_reset", "cc_intrinsics_get_state", "cc_intrinsics_eval",
-    "cc_intrinsics_solve", "cc_intrinsics_profile_sweep", "cc_intrinsics_optimize", "cc_intrinsics_estimate", "cc_comm_get_unique_id",
+    "cc_intrinsics_solve", "cc_intrinsics_solver_form", "cc_intrinsics_profile_sweep", "cc_intrinsics_profile_solve", "cc_intrinsics_optimize", "cc_intrinsics_estimate", "cc_comm_get_unique_id",
     "cc_intrinsics_comm_init", "cc_intrinsics_exchange_export", "cc_intrinsics_exchange_attach", "cc_partition_frames", "cc_distort", "cc_undistort",
     "cc_rig_create", "cc_rig_destroy", "cc_rig_set_state", "cc_rig_reset", "cc_rig_solve",
     "cc_rig_get_state", "cc_rig_eval", "cc_rig_optimize", "cc_rig_comm_init", "cc_rig_exchange_export", "cc_rig_exchange_attach", "cc_rigk_create",
@@ -234,6 +234,17 @@ class IntrinsicsProblem:
         ms = C.c_double()
         _check(lib().cc_intrinsics_profile_sweep(self._h, C.c_int32(n), C.byref(ms)))
         return ms.value
+
+    def solver_form(self):
+        """0: two kernels per LM iteration; 1, 2, 4: the persistent per-solve kernel with that many frames per workgroup."""
+        return int(lib().cc_intrinsics_solver_form(self._h))
+
+    def profile_solve(self, options=None, n=20):
+        """Persistent form: (average ms per launch = per complete solve, evaluations per launch), hipEvents on the solver's stream."""
+        options = options if options is not None else default_options()
+        ms, sw = C.c_double(), C.c_int32()
+        _check(lib().cc_intrinsics_profile_solve(self._h, C.byref(options), C.c_int32(n), C.byref(ms), C.byref(sw)))
+        return ms.value, sw.value
 
     def comm_init(self, unique_id, rank, nranks):
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))

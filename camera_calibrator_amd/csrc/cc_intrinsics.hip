@@ -1810,6 +1810,45 @@ int cc_intrinsics_debug_fetch(cc_intrinsics* h, const char* name, double* out, i
   return CC_OK;
 }
 
+int cc_intrinsics_solver_form(cc_intrinsics* h) {
+  if (!h || h->comm) return 0;
+  return (h->exchange ? h->persist_x_ok : h->persist_ok) ? h->pq.teams : 0;
+}
+
+int cc_intrinsics_profile_solve(cc_intrinsics* h, const cc_options* opt, int32_t n, double* avg_launch_ms, int32_t* sweeps_per_launch) {
+  using namespace cc;
+  if (!h || n < 1 || !avg_launch_ms) return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_profile_solve: bad arguments");
+  if (!h->have_state) return fail(CC_ERR_STATE, "cc_intrinsics_profile_solve: no state set");
+  if (!h->persist_ok || h->comm || h->exchange) return fail(CC_ERR_STATE, "cc_intrinsics_profile_solve: the handle does not use the persistent form on a device of its own");
+  CC_HIP(hipSetDevice(h->device));
+  hipEvent_t e0, e1;
+  CC_HIP(hipEventCreate(&e0));
+  CC_HIP(hipEventCreate(&e1));
+  double total = 0.0;
+  int sweeps = 0, rc = 0;
+  for (int i = 0; i <= n && !rc; ++i) {   // (the first one warms up and is not counted)
+    SolveRun r;
+    if ((rc = cc_intrinsics_reset(h))) break;
+    if ((rc = solve_begin(h, opt, &r))) break;
+    if (r.profile) { rc = fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_profile_solve: profile_kernels selects the two-kernel form"); break; }
+    hipEventRecord(e0, h->stream);
+    if ((rc = persistent_launch(h, &r))) break;
+    hipEventRecord(e1, h->stream);
+    if ((rc = persistent_wait(h, &r))) break;
+    if (hipEventSynchronize(e1) != hipSuccess) { rc = fail(CC_ERR_HIP, "hipEventSynchronize failed"); break; }
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = fail(CC_ERR_HIP, "hipEventElapsedTime failed"); break; }
+    if (i > 0) total += ms;
+    sweeps = r.st.sweeps;
+  }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  if (rc) return rc;
+  *avg_launch_ms = total / n;
+  if (sweeps_per_launch) *sweeps_per_launch = sweeps;
+  return CC_OK;
+}
+
 int cc_intrinsics_profile_sweep(cc_intrinsics* h, int32_t n, double* avg_ms) {
   using namespace cc;
   if (!h || n < 1 || !avg_ms) return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_profile_sweep: bad arguments");

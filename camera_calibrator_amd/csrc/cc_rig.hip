@@ -29,6 +29,7 @@
 #include <chrono>
 #include <cstring>
 #include <numeric>
+#include <type_traits>
 #include <vector>
 
 #include "cc_common.hpp"
@@ -121,6 +122,8 @@ struct RigDev {
   unsigned* arrive;      // [16] words right behind *ctl_next (the host reads both in one copy): [0] blocks of k_rig_reduce that
                          // have stored their sums (last-block-done), [1] flag word of the fused pose update, [2] slices of
                          // k_rig_init that have arrived, [3] FAILURE word: an in-kernel wait of k_rig_reduce timed out
+  unsigned long long* pub_seq;   // [1] device: chunks published so far
+  unsigned long long* host_pub;  // pinned host memory: [0] sequence word the host spins on, [2..19] control block, [20] failure word
   double huber_a;
   // EXTENSION: intrinsics in the shared block, pixel observations. kmode 0: off.
   int32_t kmode, gstride;
@@ -2097,7 +2100,42 @@ __device__ void rig_solve_block(const RigDev& P, double* smem) {
   }
   __syncthreads();
   RIG_MARK(4);
-  if (s_go) {
+  // Small reduced systems (poses of one to four optimised cameras: S = 6, 12, 18, 24 -- BASELINE configs[3] is S = 18): the
+  // whole solve on wave 0 with the matrix distributed by rows over the lanes (chol_solve_rows, cc_device.hpp): pivots and
+  // multipliers travel through v_readlane, no LDS vector, no panel loop, no barrier. S = 18: 7.5 -> ~3 us for the
+  // factorisation and both substitutions (profiles/r03/rig_stage_marks.jsonl). CC_RIG_PANEL_ONLY=1 (build flag) keeps the
+  // panel form for A/B.
+#ifndef CC_RIG_PANEL_ONLY
+  const bool small_rows = S == 6 || S == 12 || S == 18 || S == 24;
+#else
+  const bool small_rows = false;
+#endif
+  if (s_go && small_rows) {
+    if (tid < 64) {
+      bool okw = true;
+      double xs = 0.0;
+      auto solve_rows = [&](auto tag) {
+        constexpr int SS = decltype(tag)::value;
+        const int i = lane < SS ? lane : SS - 1;   // (lanes beyond the system repeat its last row: finite, never read)
+        double a[SS], x[SS];
+#pragma unroll
+        for (int k = 0; k < SS; ++k) a[k] = A[(size_t)i * LD + (k <= i ? k : i)];
+        okw = chol_solve_rows<SS>(a, s_b[i], x);
+#pragma unroll
+        for (int k = 0; k < SS; ++k) xs = lane == k ? x[k] : xs;
+      };
+      if (S == 6) solve_rows(std::integral_constant<int, 6>{});
+      else if (S == 12) solve_rows(std::integral_constant<int, 12>{});
+      else if (S == 18) solve_rows(std::integral_constant<int, 18>{});
+      else solve_rows(std::integral_constant<int, 24>{});
+      const bool fin = lane >= S || isfinite(xs);
+      const bool step_ok = s_cholok != 0 && okw && __all(fin);
+      if (lane < S) { s_b[lane] = xs; store_ds(P.ds + lane, -xs); }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the update blocks of this launch read ds behind a flag
+      if (lane == 0) s_stepok = step_ok ? 1 : 0;
+    }
+    __syncthreads();
+  } else if (s_go) {
     // ---- Cholesky of the damped reduced system in LDS, eight columns at a time (S <= 127):
     //   panel:    wave 0 (chol_panel), forward substitution included;
     //   trailing: all 256 threads, A[i][k] -= sum_c L[i][c] L[k][c] over the panel's columns; two barriers per panel.
@@ -2298,8 +2336,24 @@ __global__ __launch_bounds__(256) void k_rig_records(RigDev P) {
 // sc1, behind its drained sc1 stores of the shared step) and every block updates its share of the frames. The wait is
 // bounded (10 s of the wall clock) like the mailbox polls.
 // ---------------------------------------------------------------------------------------------
+// Hands the control block (and the failure word of the in-kernel waits) to the host without a copy engine in the way:
+// payload first, then the sequence word the host spins on (system-scope stores into pinned host memory; one thread).
+// Last reduce launch of a host chunk only (cf. publish_to_host, cc_intrinsics_dev.hpp).
+__device__ __forceinline__ void rig_publish(const RigDev& P, const LmCtl& c) {
+  if (!P.host_pub) return;
+  const unsigned long long* w = reinterpret_cast<const unsigned long long*>(&c);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(LmCtl) / 8); ++i)
+    __hip_atomic_store(P.host_pub + 2 + i, w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const unsigned failed = __hip_atomic_load(P.arrive + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(P.host_pub + 2 + sizeof(LmCtl) / 8, (unsigned long long)failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const unsigned long long seq = *P.pub_seq + 1ull;
+  *P.pub_seq = seq;
+  __hip_atomic_store(P.host_pub, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <int MODE>
-__global__ __launch_bounds__(256) void k_rig_reduce(RigDev P) {
+__global__ __launch_bounds__(256) void k_rig_reduce(RigDev P, int publish) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   __shared__ double s_r[16][16];
   __shared__ double s_post[48];
@@ -2308,13 +2362,16 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P) {
   __shared__ unsigned s_flag;
   const LmCtl* cn = P.ctl_next;
   if (cn->done) {
-    if (MODE != 2 && blockIdx.x == 0 && threadIdx.x == 0) *P.ctl = *cn;
+    if (MODE != 2 && blockIdx.x == 0 && threadIdx.x == 0) { *P.ctl = *cn; if (publish) rig_publish(P, *cn); }
     return;
   }
   if (cn->phase == 0) return;
   // an earlier launch of this solve gave up waiting (below): the state is half updated, the host will report it
-  // (rig_read_ctl); do not wait another ten seconds per remaining round of the chunk
-  if (MODE != 2 && __hip_atomic_load(P.arrive + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+  // (rig_wait); do not wait another ten seconds per remaining round of the chunk
+  if (MODE != 2 && __hip_atomic_load(P.arrive + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+    if (publish && blockIdx.x == 0 && threadIdx.x == 0) rig_publish(P, *cn);
+    return;
+  }
   const int tid = threadIdx.x, c = tid & 15, grp = tid >> 4;  // 16 columns x 16 row groups per step
 #ifdef CC_RIG_TIMING
   const long long t_entry = wall_clock64();
@@ -2404,6 +2461,8 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P) {
       const LmCtl* c = P.ctl;   // written by this very thread a moment ago
       s_flag = ((epoch0 + 1u) << 3) | (c->done ? 4u : 0u) | (c->step_valid ? 2u : 0u) | (unsigned)(c->cur & 1);
       __hip_atomic_store(P.arrive + 1, s_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (the host only decides on it whether another chunk follows; whoever reads poses synchronises the stream first)
+      if (publish) rig_publish(P, *c);
     }
   }
   if (!s_last && tid == 0) {
@@ -2505,6 +2564,7 @@ struct cc_rig {
   double* d_cost = nullptr;
   bool have_state = false;
   cc::LmCtl* h_ctl = nullptr;
+  void* pinned = nullptr;       // the pinned block h_ctl and host_pub live in
   hipGraphExec_t graph[2] = {nullptr, nullptr};
   int graph_iters = 0;
   cc::Comm* comm = nullptr;
@@ -2519,6 +2579,12 @@ struct cc_rig {
   std::vector<int32_t> gframe_h, gcam_h;   // host copies of the group tables (layout rebuilds)
   std::vector<int64_t> fgoff_h;
   size_t elim_lds = 0, solve_lds = 0;
+  volatile unsigned long long* host_pub = nullptr;   // = h_ctl's pinned block: [0] sequence word, [2..19] control block, [20] failure word
+  unsigned long long pub_count = 0;                  // chunks published so far
+  cc::LmCtl last_st{};          // control block as the last solve / reset left it (no read-back at the start of a solve)
+  bool st_known = false;
+  cc::LmOpts cached_opts{};     // what the device holds
+  bool opts_valid = false;
   int co_resident = 1;         // shards / processes whose k_rig_reduce launches share this device (cc_rig_optimize_multi counts them,
                                // cc_rig_exchange_attach derives ceil(ranks / visible devices); CC_RIG_CO_RESIDENT overrides)
   int reduce_blocks = 0;       // grid of the fused reduce + solve + update launch (rig_size_reduce_grid)
@@ -2784,7 +2850,7 @@ static int rig_size_reduce_grid(cc_rig* h) {
 // One round: sweep -> [statistics exchange] -> [init, first round only] -> decision + elimination ->
 // reduce + solve step -> pose update (what the next round's sweep evaluates). The first round of a solve is
 // the initial evaluation.
-static int rig_enqueue_round(cc_rig* h, bool initial, bool profile) {
+static int rig_enqueue_round(cc_rig* h, bool initial, bool profile, bool publish = false) {
   const RigDev& d = h->d;
   { RigProbe p(h, CC_K_SWEEP, profile);
     if (d.kmode && h->sweep_adjoint && h->sweep_waves == 1) hipLaunchKernelGGL(k_rig_sweep_adjk<1>, dim3((unsigned)h->NG), dim3(64), 0, h->stream, d);
@@ -2810,14 +2876,14 @@ static int rig_enqueue_round(cc_rig* h, bool initial, bool profile) {
   // (every block of the fused launch must be resident at once: its grid comes from rig_size_reduce_grid, rig_begin)
   const unsigned rblocks = (unsigned)std::max(1, h->reduce_blocks);
   if (h->comm) {
-    { RigProbe p(h, CC_K_REDUCE, profile); hipLaunchKernelGGL(k_rig_reduce<2>, dim3(rblocks), dim3(256), 0, h->stream, d); }
+    { RigProbe p(h, CC_K_REDUCE, profile); hipLaunchKernelGGL(k_rig_reduce<2>, dim3(rblocks), dim3(256), 0, h->stream, d, 0); }
     { RigProbe p(h, CC_K_ALLREDUCE, profile); if (int rc = comm_allreduce_sum(h->comm, d.vec, d.PC + 32, h->stream)) return rc; }
     { RigProbe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_rig_solve, dim3(1), dim3(256), h->solve_lds, h->stream, d); }
     { RigProbe p(h, CC_K_UPDATE, profile); hipLaunchKernelGGL(k_rig_update, dim3((unsigned)((h->F + 15) / 16)), dim3(256), 0, h->stream, d); }
   } else {   // reduce + solve step + pose update in one launch
     RigProbe p(h, CC_K_SOLVE, profile);
-    if (h->exchange) hipLaunchKernelGGL(k_rig_reduce<3>, dim3(rblocks), dim3(256), h->solve_lds, h->stream, d);
-    else hipLaunchKernelGGL(k_rig_reduce<0>, dim3(rblocks), dim3(256), h->solve_lds, h->stream, d);
+    if (h->exchange) hipLaunchKernelGGL(k_rig_reduce<3>, dim3(rblocks), dim3(256), h->solve_lds, h->stream, d, publish ? 1 : 0);
+    else hipLaunchKernelGGL(k_rig_reduce<0>, dim3(rblocks), dim3(256), h->solve_lds, h->stream, d, publish ? 1 : 0);
   }
   return 0;
 }
@@ -2839,6 +2905,28 @@ static int rig_read_ctl(cc_rig* h, LmCtl* c, bool* wait_failed = nullptr) {
   CC_HIP(hipStreamSynchronize(h->stream));
   *c = *h->h_ctl;
   if (wait_failed) *wait_failed = reinterpret_cast<const unsigned*>(h->h_ctl + 1)[3] != 0u;
+  return 0;
+}
+
+// Waits for the chunk just enqueued: spins on the sequence word its last reduce launch stores into pinned host memory
+// (no copy engine, no stream synchronisation on the way), then takes the control block and the failure word from next
+// to it. A stream that has gone idle without the word showing up (a kernel fault) falls back to a copy.
+static int rig_wait_published(cc_rig* h, LmCtl* c, bool* wait_failed) {
+  const unsigned long long want = ++h->pub_count;
+  for (unsigned spins = 0;; ++spins) {
+    if (__atomic_load_n(const_cast<const unsigned long long*>(h->host_pub), __ATOMIC_ACQUIRE) == want) break;
+    if ((spins & 0xfffu) == 0xfffu) {
+      const hipError_t q = hipStreamQuery(h->stream);
+      if (q == hipSuccess) {
+        if (__atomic_load_n(const_cast<const unsigned long long*>(h->host_pub), __ATOMIC_ACQUIRE) == want) break;
+        h->pub_count = __atomic_load_n(const_cast<const unsigned long long*>(h->host_pub), __ATOMIC_ACQUIRE);
+        return rig_read_ctl(h, c, wait_failed);
+      }
+      if (q != hipErrorNotReady) return fail(CC_ERR_HIP, "stream failed while waiting for the rig solver: %s", hipGetErrorString(q));
+    }
+  }
+  std::memcpy(c, const_cast<const unsigned long long*>(h->host_pub) + 2, sizeof(LmCtl));
+  *wait_failed = h->host_pub[2 + sizeof(LmCtl) / 8] != 0ull;
   return 0;
 }
 
@@ -2990,18 +3078,34 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   if (int rc = dev_zeroed(h, &d.ss, (size_t)128)) return rc;
   if (int rc = dev_zeroed(h, &d.ds, (size_t)128)) return rc;
   if (int rc = dev_zeroed(h, &d.shared_stats, (size_t)48)) return rc;   // [0..3] statistics, [8..] timing marks (CC_RIG_TIMING builds)
-  if (int rc = dev_zeroed(h, &d.ctl, (size_t)1)) return rc;
-  if (int rc = dev_zeroed(h, &d.ctl_next, (size_t)2)) return rc;       // control block | 16 synchronisation words (RigDev::arrive)
-  static_assert(sizeof(LmCtl) % 16 == 0 && 2 * sizeof(LmCtl) >= sizeof(LmCtl) + 16 * sizeof(unsigned), "arrive words behind ctl_next");
-  d.arrive = reinterpret_cast<unsigned*>(d.ctl_next + 1);
+  // one piece: control block | its copy for the host (ctl_next) | 16 synchronisation words (RigDev::arrive) | publication
+  // counter -- a solve starts by zeroing the first three with ONE fill (rig_begin)
+  if (int rc = dev_zeroed(h, &d.ctl, (size_t)4)) return rc;
+  static_assert(sizeof(LmCtl) % 16 == 0 && sizeof(LmCtl) >= 16 * sizeof(unsigned) + 8, "arrive words and the counter behind ctl_next");
+  d.ctl_next = d.ctl + 1;
+  d.arrive = reinterpret_cast<unsigned*>(d.ctl + 2);
+  d.pub_seq = reinterpret_cast<unsigned long long*>(d.ctl + 3);
   if (int rc = dev_alloc(h, &d.opts, (size_t)1)) return rc;
   d.log_cap = 4096;
   if (int rc = dev_alloc(h, &d.log, (size_t)d.log_cap)) return rc;
   if (int rc = dev_alloc(h, &h->init_cam, (size_t)C * 8)) return rc;
   if (int rc = dev_alloc(h, &h->init_pose, (size_t)F * 8)) return rc;
   if (int rc = dev_alloc(h, &h->d_cost, (size_t)N)) return rc;
-  h->h_ctl = reinterpret_cast<LmCtl*>(pinned_block_get());
-  if (!h->h_ctl) return fail(CC_ERR_HIP, "hipHostMalloc failed");
+  {
+    // one cached 512-byte pinned block: [0..191] publication (sequence word, control block, failure word) | [192..] staging
+    // of rig_read_ctl
+    char* pin = static_cast<char*>(pinned_block_get());
+    if (!pin) return fail(CC_ERR_HIP, "hipHostMalloc failed");
+    h->pinned = pin;
+    h->host_pub = reinterpret_cast<volatile unsigned long long*>(pin);
+    h->h_ctl = reinterpret_cast<LmCtl*>(pin + 192);
+    static_assert(16 + sizeof(LmCtl) + 8 <= 192 && 192 + sizeof(LmCtl) + 16 <= 512, "pinned block layout");
+    h->host_pub[0] = 0ull;   // (a recycled block may carry an old sequence number; the device counter starts at 0)
+    h->pub_count = 0;
+    void* dev_view = nullptr;
+    CC_HIP(hipHostGetDevicePointer(&dev_view, pin, 0));
+    d.host_pub = reinterpret_cast<unsigned long long*>(dev_view);
+  }
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_sweep<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kRigSweepLdsBytes));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_sweep<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kRigSweepLdsBytes2));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_sweep<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kRigSweepLdsBytes1));
@@ -3087,7 +3191,7 @@ void cc_rig_destroy(cc_rig* h) {
   if (h->comm) cc::comm_destroy(h->comm);
   cc::mailbox_release(&h->mailbox);
   for (void* p : h->allocs) hipFree(p);
-  cc::pinned_block_put(h->h_ctl);
+  cc::pinned_block_put(h->pinned);
   if (stream_ok) cc::stream_put(h->device, h->stream);   // idle and reusable
   else if (h->stream) hipStreamDestroy(h->stream);      // never hand a failed stream to the next handle
   delete h;
@@ -3119,6 +3223,8 @@ int cc_rig_reset(cc_rig* h) {
   CC_HIP(hipSetDevice(h->device));
   LmCtl c{};
   if (int rc = rig_write_ctl(h, c)) return rc;
+  h->last_st = c;
+  h->st_known = true;
   CC_HIP(hipMemcpyAsync(h->d.cam, h->init_cam, (size_t)h->C * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   CC_HIP(hipMemcpyAsync(h->d.pose, h->init_pose, (size_t)h->F * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   if (h->d.kmode) CC_HIP(hipMemcpyAsync(h->d.intr, h->init_intr, (size_t)h->d.CK * 16 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -3135,7 +3241,7 @@ static int rig_capture(cc_rig* h, bool first_chunk, int rounds, hipGraphExec_t* 
   CC_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
   int rc = 0;
   if (first_chunk) rig_enqueue_prep(h);
-  for (int i = 0; i < rounds && !rc; ++i) rc = rig_enqueue_round(h, first_chunk && i == 0, false);
+  for (int i = 0; i < rounds && !rc; ++i) rc = rig_enqueue_round(h, first_chunk && i == 0, false, i == rounds - 1);
   const hipError_t e_end = hipStreamEndCapture(h->stream, &g);
   if (rc || e_end != hipSuccess) {
     if (g) hipGraphDestroy(g);
@@ -3170,8 +3276,11 @@ static int rig_begin(cc_rig* h, const cc_options* opt, RigRun* r) {
   r->use_graph = o.use_graph != 0 && !h->comm && !r->profile;
   r->launched = 0;
   CC_HIP(hipSetDevice(h->device));
-  LmCtl st;
-  if (int rc = rig_read_ctl(h, &st)) return rc;
+  // (the control block a solve starts from is the one the last solve published or the zeros of a reset: the host has it)
+  LmCtl st = h->last_st;
+  if (!h->st_known)
+    if (int rc = rig_read_ctl(h, &st)) return rc;
+  h->st_known = false;   // until this solve has ended
   if (st.cur & 1) {
     CC_HIP(hipMemcpyAsync(h->d.cam, h->d.cam + (size_t)h->C * 8, (size_t)h->C * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     CC_HIP(hipMemcpyAsync(h->d.pose, h->d.pose + (size_t)h->F * 8, (size_t)h->F * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -3179,11 +3288,15 @@ static int rig_begin(cc_rig* h, const cc_options* opt, RigRun* r) {
   }
   LmOpts lo;
   opts_from_public(o, &lo);
-  CC_HIP(hipMemcpyAsync(h->d.opts, &lo, sizeof(lo), hipMemcpyHostToDevice, h->stream));
-  LmCtl c{};
-  if (int rc = rig_write_ctl(h, c)) return rc;
+  if (!h->opts_valid || std::memcmp(&lo, &h->cached_opts, sizeof(lo)) != 0) {   // (uploaded when they change, not per solve)
+    CC_HIP(hipMemcpyAsync(h->d.opts, &lo, sizeof(lo), hipMemcpyHostToDevice, h->stream));
+    h->cached_opts = lo;
+    h->opts_valid = true;
+  }
   if (int rc = rig_size_reduce_grid(h)) return rc;
-  CC_HIP(hipMemsetAsync(h->d.arrive, 0, 16 * sizeof(unsigned), h->stream));   // counters, flag word, failure word (a failed solve may have left any of them behind)
+  // fresh control block (both copies) and synchronisation words -- counters, flag word, failure word: a failed solve may
+  // have left any of them behind -- in ONE fill (they are one piece of memory, rig_create_impl)
+  CC_HIP(hipMemsetAsync(h->d.ctl, 0, 2 * sizeof(LmCtl) + 16 * sizeof(unsigned), h->stream));
   for (auto e : h->events) hipEventDestroy(e);
   h->events.clear();
   h->event_kind.clear();
@@ -3202,7 +3315,7 @@ static int rig_launch(cc_rig* h, RigRun* r, int chunk) {
   } else {
     if (chunk == 0) rig_enqueue_prep(h);
     for (int i = 0; i < n; ++i)
-      if (int rc = rig_enqueue_round(h, chunk == 0 && i == 0, r->profile)) return rc;
+      if (int rc = rig_enqueue_round(h, chunk == 0 && i == 0, r->profile, i == n - 1)) return rc;
     CC_HIP(hipGetLastError());
   }
   r->launched += n;
@@ -3212,7 +3325,8 @@ static int rig_launch(cc_rig* h, RigRun* r, int chunk) {
 static int rig_wait(cc_rig* h, RigRun* r) {
   CC_HIP(hipSetDevice(h->device));
   bool wait_failed = false;
-  if (int rc = rig_read_ctl(h, &r->st, &wait_failed)) return rc;
+  if (int rc = (h->comm ? rig_read_ctl(h, &r->st, &wait_failed) : rig_wait_published(h, &r->st, &wait_failed))) return rc;
+  if (r->st.done) { h->last_st = r->st; h->st_known = true; }
   if (wait_failed)
     return fail(CC_ERR_COMM, "k_rig_reduce: the solving block did not publish within 10 s (iteration %d): its launch was not fully "
                 "resident (%d blocks; shards or processes sharing the device? CC_RIG_CO_RESIDENT) or a peer rank stalled", r->st.iter, h->reduce_blocks);

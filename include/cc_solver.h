@@ -128,14 +128,28 @@ int cc_intrinsics_get_state(cc_intrinsics* h, double* intr9, double* q_wxyz, dou
  * total cost 1/2 sum r^2. */
 int cc_intrinsics_eval(cc_intrinsics* h, double* blocks, double* cost);
 
-/* Runs the LM loop on the device from the current state. */
+/* Runs the LM loop on the device from the current state (replaces the ceres::Solve call, calibrator.cpp:323-324).
+ * Two forms, same arithmetic, chosen when the handle is created (cc_intrinsics_solver_form):
+ *   persistent -- ONE kernel launch per solve: every frame keeps a team of a resident workgroup for the whole solve
+ *     (pose, Gram blocks and back-substitution matrix in LDS), a control workgroup takes the trust-region decisions;
+ *     used whenever every frame fits a resident team (<= 4 frames per compute unit: 1020 frames on an MI355X) and the
+ *     device is the solve's own; CC_INTR_PERSIST=0 disables it;
+ *   two kernels per LM iteration (sweep, decide + eliminate + solve), replayed from a captured graph -- any size. */
 int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* summary);
+/* 0: two kernels per iteration; 1, 2, 4: the persistent kernel with that many frames per workgroup. With an exchange
+ * attached the answer is what the ranks agreed on (cc_intrinsics_exchange_attach). */
+int cc_intrinsics_solver_form(cc_intrinsics* h);
 
 /* Measurement aid: launches `n` steady-state Jacobian sweeps (candidate step + sweep, exactly the
  * kernel an LM iteration runs) back to back on the solver's stream between two hipEvents and
  * returns the average ms per launch. Needs a completed cc_intrinsics_solve with >= 1 iteration.
  * The accepted point is left untouched. */
 int cc_intrinsics_profile_sweep(cc_intrinsics* h, int32_t n, double* avg_ms);
+/* Measurement aid for the persistent form (one launch = one complete solve): runs `n` solves from the state of the
+ * last set_state, each launch bracketed by two hipEvents on the solver's stream; returns the average ms per launch
+ * and the evaluations (initial + one per LM iteration) a launch made. CC_ERR_STATE when the handle does not use the
+ * persistent form or has an exchange attached. */
+int cc_intrinsics_profile_solve(cc_intrinsics* h, const cc_options* opt, int32_t n, double* avg_launch_ms, int32_t* sweeps_per_launch);
 
 /* One-shot convenience: create + set_state + solve + get_state + destroy. This is the call
  * Calibrator::Optimize makes in place of calibrator.cpp:236-324. */
@@ -178,7 +192,8 @@ int cc_intrinsics_comm_init(cc_intrinsics* h, const uint8_t id[128], int32_t ran
  * on flags in their own memory (cc_device.hpp). The iteration stays three/four kernels inside one
  * captured graph. Protocol: every rank calls _export (allocates the mailbox, returns its 64-byte
  * hipIpcMemHandle), the caller all-gathers the handles over its control plane (rank order), every
- * rank calls _attach with all nranks*64 bytes. All ranks must then call cc_intrinsics_solve /
+ * rank calls _attach with all nranks*64 bytes (COLLECTIVE for nranks > 1: the ranks agree, through the mailboxes,
+ * on the form of the solver they all run; a peer that does not attach within 10 s -> CC_ERR_COMM). All ranks must then call cc_intrinsics_solve /
  * cc_intrinsics_reset the same number of times with the same options. A peer that does not show
  * up within 10 s makes the solve return CC_ERR_COMM (termination CC_FAILURE_EXCHANGE) instead of
  * hanging. Keep the handle alive until every rank has finished its last solve. */
