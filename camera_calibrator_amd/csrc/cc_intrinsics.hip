@@ -1635,7 +1635,10 @@ static int persistent_launch(cc_intrinsics* h, SolveRun* r) {
   }
   q.epoch0 = h->p_epoch;
   h->p_epoch += need;
-  persist_launch(h->d, q, h->exchange, h->stream);
+  q.timeout_shift = h->exchange ? 30 : 27;
+  // (CC_INTR_PERSIST_TEST_NO_CONTROL: test hook for the rerun in the two-kernel form, tests/test_gpu_intrinsics.py)
+  static const bool drop_control = getenv("CC_INTR_PERSIST_TEST_NO_CONTROL") != nullptr;
+  persist_launch(h->d, q, drop_control && !h->exchange, h->stream);
   CC_HIP(hipGetLastError());
   h->reset_pending = false;
   r->launched = q.max_rounds;
@@ -1650,7 +1653,17 @@ static int persistent_wait(cc_intrinsics* h, SolveRun* r) {
     return fail(CC_ERR_COMM, "persistent solve: a wait inside the kernel timed out (iteration %d): its %d workgroups were not all "
                 "resident, or a peer rank did not post within 10 s", r->st.iter, h->pq.G + 1);
   }
-  if (!r->st.done) return fail(CC_ERR_STATE, "persistent solve ended without a result (iter=%d)", r->st.iter);
+  if (!r->st.done) {
+    // the control workgroup never published: did the workers give up waiting for it?
+    unsigned failed = 0;
+    CC_HIP(hipStreamSynchronize(h->stream));
+    CC_HIP(hipMemcpy(&failed, h->pq.fail, sizeof(failed), hipMemcpyDeviceToHost));
+    if (failed) {
+      CC_HIP(hipMemsetAsync(h->pq.fail, 0, sizeof(unsigned), h->stream));
+      return fail(CC_ERR_COMM, "persistent solve: the workers' waits timed out and the control workgroup never ran (%d workgroups not all resident)", h->pq.G + 1);
+    }
+    return fail(CC_ERR_STATE, "persistent solve ended without a result (iter=%d)", r->st.iter);
+  }
   return 0;
 }
 
@@ -1704,8 +1717,25 @@ int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* sum
   if (int rc = solve_begin(h, opt, &r)) return rc;
   if (use_persistent(h, &r)) {
     // ONE launch runs the whole solve (cc_intrinsics_persist.hip); the host waits for its publication
-    if (int rc = solve_persistent(h, &r)) return rc;
-    return solve_finish(h, &r, summary);
+    const bool was_restart = h->reset_pending;
+    const int rc = solve_persistent(h, &r);
+    if (rc == CC_OK) return solve_finish(h, &r, summary);
+    if (rc != CC_ERR_COMM || h->exchange) return rc;
+    // A wait inside the kernel gave up after 1.3 s: its workgroups were not all resident (another process on the device,
+    // a compute-unit mask). Nothing was written back, so the solve is run again -- and this handle keeps to -- the
+    // two-kernel form, which needs no co-residency. (Another GPU form of the same arithmetic, not a fallback off the GPU.)
+    h->persist_ok = false;
+    CC_HIP(hipStreamSynchronize(h->stream));
+    CC_HIP(hipMemsetAsync(h->pq.fail, 0, sizeof(unsigned), h->stream));
+    if (was_restart) {
+      h->reset_pending = true;
+    } else {
+      LmCtl zero{};
+      if (int rc2 = write_ctl(h, zero)) return rc2;
+      CC_HIP(hipMemsetAsync(h->d.arrive, 0, sizeof(unsigned), h->stream));
+    }
+    h->ctl_fresh = true;
+    if (int rc2 = solve_begin(h, opt, &r)) return rc2;
   }
   for (int chunk = 0;; ++chunk) {
     if (int rc = solve_launch(h, &r, chunk)) return rc;

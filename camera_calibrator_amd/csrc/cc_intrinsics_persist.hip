@@ -89,9 +89,9 @@ __device__ __forceinline__ void quat_plus_tab(const double* x, const double* d, 
   out[3] = a0 * x[3] + a1 * x[2] - a2 * x[1] + a3 * x[0];
 }
 
-// ~10.7 s of the 100 MHz wall clock (2^30 ticks) -- a shift and a compare against zero: kP2pTimeoutTicks as a 64-bit
-// literal gets hoisted into a register pair that then sits there across the sweep's main loop
-__device__ __forceinline__ bool timed_out(long long t0) { return ((wall_clock64() - t0) >> 30) != 0; }
+// 2^shift ticks of the 100 MHz wall clock (PersistDev::timeout_shift) -- a shift and a compare against zero: a 64-bit
+// literal to compare with gets hoisted into a register pair that then sits there across the sweep's main loop
+__device__ __forceinline__ bool timed_out(long long t0, int shift) { return ((wall_clock64() - t0) >> shift) != 0; }
 
 __device__ __forceinline__ u64 ag_ld(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ag_st(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -108,7 +108,7 @@ __device__ __forceinline__ double persist_spec_radius(double radius, double max_
 
 // One wave waits until the n doubles of a broadcast box carry `tag` and leaves them in dst[0..n) (LDS); lane l polls
 // word l. false: gave up (timeout, or somebody else already failed); the failure word is set.
-__device__ __forceinline__ bool bcast_wait(const u64* box, unsigned tag, int n, double* dst, unsigned* fail, int lane) {
+__device__ __forceinline__ bool bcast_wait(const u64* box, unsigned tag, int n, double* dst, unsigned* fail, int lane, int tshift) {
   const bool mine = lane < 2 * n;
   const u64* p = box + (mine ? lane : 0);
   const long long t0 = wall_clock64();
@@ -117,7 +117,7 @@ __device__ __forceinline__ bool bcast_wait(const u64* box, unsigned tag, int n, 
     v = ag_ld(p);
     const int ok = !mine || (unsigned)(v >> 32) == tag;
     if (__all(ok)) break;
-    if ((spins & 63u) == 63u && (timed_out(t0) || ag_ld32(fail) != 0u)) {
+    if ((spins & 63u) == 63u && (timed_out(t0, tshift) || ag_ld32(fail) != 0u)) {
       if (lane == 0) __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return false;
     }
@@ -133,7 +133,7 @@ __device__ __forceinline__ bool bcast_wait(const u64* box, unsigned tag, int n, 
 // out[0..ncols) valid for every thread after return. *s_ok (LDS) ends 0 when a row did not show up in time.
 template <int NC, int NG, int BATCH = 8>
 __device__ __forceinline__ void gather_rows(const u64* box, int G, unsigned tag, int ncols, int maxcol, double* s_part,
-                                            double* out, unsigned* fail, int* s_ok) {
+                                            double* out, unsigned* fail, int* s_ok, int tshift) {
   const int tid = threadIdx.x, col = tid % NC, grp = tid / NC;
   if (tid == 0) *s_ok = 1;
   __syncthreads();
@@ -155,7 +155,7 @@ __device__ __forceinline__ void gather_rows(const u64* box, int G, unsigned tag,
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) ok = ok && (unsigned)(lo[u] >> 32) == tag && (unsigned)(hi[u] >> 32) == tag;
         if (ok) break;
-        if ((spins & 63u) == 63u && (timed_out(t0) || ag_ld32(fail) != 0u)) { good = false; break; }
+        if ((spins & 63u) == 63u && (timed_out(t0, tshift) || ag_ld32(fail) != 0u)) { good = false; break; }
         __builtin_amdgcn_s_sleep(1);
       }
       if (!good) break;
@@ -184,7 +184,7 @@ __device__ __forceinline__ void gather_rows(const u64* box, int G, unsigned tag,
 // every thread polls its own two words (all rows in ONE round trip), the rows of a wave are added by the fixed
 // cross-lane tree of wave_sum_mod, the waves in order.
 template <int THREADS>
-__device__ __forceinline__ void gather_stats4(const u64* box, int G, unsigned tag, double* s_part, double* out, unsigned* fail, int* s_ok) {
+__device__ __forceinline__ void gather_stats4(const u64* box, int G, unsigned tag, double* s_part, double* out, unsigned* fail, int* s_ok, int tshift) {
   constexpr int RPT = 1024 / THREADS;   // rows per thread
   const int tid = threadIdx.x, col = tid & 3, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) *s_ok = 1;
@@ -204,7 +204,7 @@ __device__ __forceinline__ void gather_stats4(const u64* box, int G, unsigned ta
 #pragma unroll
     for (int k = 0; k < RPT; ++k) ok = ok && (unsigned)(lo[k] >> 32) == tag && (unsigned)(hi[k] >> 32) == tag;   // (rows >= G read row 0)
     if (ok) break;
-    if ((spins & 63u) == 63u && (timed_out(t0) || ag_ld32(fail) != 0u)) { good = false; break; }
+    if ((spins & 63u) == 63u && (timed_out(t0, tshift) || ag_ld32(fail) != 0u)) { good = false; break; }
     __builtin_amdgcn_s_sleep(1);
   }
   double acc = 0.0;
@@ -260,8 +260,8 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
     // outcome of an LM step that works. A decision that says otherwise (rejection, a mediocre step, the first round) is
     // a MISS: it is broadcast on its own and the workers eliminate again with what it says.
     PC_MARK(0);
-    if (phase0) gather_rows<kPStatCols, THREADS / kPStatCols>(Q.sbox, Q.G, e1, 13, -1, s_part, s_tot, Q.fail, s_int);
-    else gather_stats4<THREADS>(Q.sbox, Q.G, e1, s_part, s_tot, Q.fail, s_int);
+    if (phase0) gather_rows<kPStatCols, THREADS / kPStatCols>(Q.sbox, Q.G, e1, 13, -1, s_part, s_tot, Q.fail, s_int, Q.timeout_shift);
+    else gather_stats4<THREADS>(Q.sbox, Q.G, e1, s_part, s_tot, Q.fail, s_int, Q.timeout_shift);
     if (P.x.on) {
       // several GPUs (mailbox exchange, cc_device.hpp): this rank's sums go into every rank's mailbox, the slots are added
       // in rank order -- the same sequence of exchanges, payloads and sums as k_intr_decide_elim<3> makes, skipped like
@@ -335,7 +335,7 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
     const unsigned erow = hit ? e2 : e3;
     PC_MARK(3);
     // (the leaders among the workers have added the elimination rows sixteen at a time: one round trip here)
-    gather_rows<kPartialCols, THREADS / kPartialCols, (kPLeaderRows + THREADS / kPartialCols - 1) / (THREADS / kPartialCols)>(Q.lbox, (Q.G + kPLeaderRows - 1) / kPLeaderRows, erow, kPartialCols, PC_GMAXP, s_part, sv, Q.fail, s_int);
+    gather_rows<kPartialCols, THREADS / kPartialCols, (kPLeaderRows + THREADS / kPartialCols - 1) / (THREADS / kPartialCols)>(Q.lbox, (Q.G + kPLeaderRows - 1) / kPLeaderRows, erow, kPartialCols, PC_GMAXP, s_part, sv, Q.fail, s_int, Q.timeout_shift);
     if (P.x.on) {
       // all-reduce of the 112 sums through the mailboxes (kind 0): the maximum of the pose gradients rides in a slot per rank
       if (tid >= kPartialCols && tid < kVecSolve) sv[tid] = 0.0;
@@ -433,7 +433,9 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
   }
   // ---- the solve is over: control block, intrinsics, publication
   __syncthreads();
-  if (tid < 32) P.intr[tid] = s_intr[tid];
+  // (after a wait that gave up nothing is written back: buffer 0 still holds the point the solve started from, so the host
+  // can run it again in the other form)
+  if (tid < 32 && ag_ld32(Q.fail) == 0u) P.intr[tid] = s_intr[tid];
   if (tid == 0) {
     LmCtl c = *s_ctl;
     if (ag_ld32(Q.fail) != 0u) { c.done = 1; c.term = CC_FAILURE_EXCHANGE; }
@@ -831,7 +833,7 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
       const int g0 = (int)blockIdx.x, n = Q.G - g0 < kPLeaderRows ? Q.G - g0 : kPLeaderRows;
       double* lout = s_wg + 128;        // [80]; the group sums go through team 0's staging tiles (idle between sweeps)
       gather_rows<kPartialCols, THREADS / kPartialCols, (kPLeaderRows + THREADS / kPartialCols - 1) / (THREADS / kPartialCols)>(box + (size_t)g0 * (2 * kPartialCols), n, tag, kPartialCols, PC_GMAXP, s_stage + 2048, lout,
-                                                        Q.fail, s_lok);
+                                                        Q.fail, s_lok, Q.timeout_shift);
       PW_MARK(11);
       CC_FRESH_TID(tid);
       // (rows that did not arrive: nothing is posted, the control's own wait gives up and ends the solve)
@@ -841,7 +843,7 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
     // one wave waits for the control's broadcast `tag` (flags, radius, nine doubles) -> s_wg[WG_X ..]
     auto wait_bcast = [&](const unsigned tag) {
       CC_FRESH_TID(tid);
-      if (wave == 0 && !bcast_wait(Q.xbox, tag, 11, s_wg + WG_X, Q.fail, tid & 63)) s_wg[WG_X] = 17.0;   // done + failed
+      if (wave == 0 && !bcast_wait(Q.xbox, tag, 11, s_wg + WG_X, Q.fail, tid & 63, Q.timeout_shift)) s_wg[WG_X] = 17.0;   // done + failed
       __syncthreads();
     };
 
@@ -923,9 +925,9 @@ int persist_resident_workgroups(int device, int teams, int* out) {
   return teams == 1 ? resident_of<1>(device, out) : teams == 2 ? resident_of<2>(device, out) : resident_of<4>(device, out);
 }
 
-void persist_launch(const IntrDev& P, const PersistDev& Q, bool exchange, hipStream_t stream) {
-  (void)exchange;
-  const dim3 grid((unsigned)Q.G + 1u);
+void persist_launch(const IntrDev& P, const PersistDev& Q, bool drop_control, hipStream_t stream) {
+  // (drop_control: test hook -- the grid goes out WITHOUT its control workgroup, every worker's first wait gives up)
+  const dim3 grid((unsigned)Q.G + (drop_control ? 0u : 1u));
   if (Q.teams == 1) hipLaunchKernelGGL(k_intr_persist<1>, grid, dim3(256), persist_lds_doubles(1) * 8, stream, P, Q);
   else if (Q.teams == 2) hipLaunchKernelGGL(k_intr_persist<2>, grid, dim3(512), persist_lds_doubles(2) * 8, stream, P, Q);
   else hipLaunchKernelGGL(k_intr_persist<4>, grid, dim3(1024), persist_lds_doubles(4) * 8, stream, P, Q);

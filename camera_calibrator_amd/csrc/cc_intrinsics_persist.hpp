@@ -25,10 +25,12 @@ struct PersistDev {
   int32_t max_rounds;         // hard bound of the round loop (max_iterations + 2); three epochs per round
   int32_t restart;            // start from the state of the last set_state (init arrays) instead of buffer 0
   int32_t stagger;            // team k enters the sweep's main loop k * stagger sleep units late (0: in lockstep)
+  int32_t timeout_shift;      // a wait gives up after 2^shift ticks of the 100 MHz wall clock: 27 (1.3 s) alone on the device,
+                              // 30 (10.7 s, the mailbox exchange's patience) with peer ranks
 };
 
 // workgroups of the `teams`-frame variant that can be resident on `device` at once (occupancy query x CUs)
 int persist_resident_workgroups(int device, int teams, int* out);
-void persist_launch(const IntrDev& P, const PersistDev& Q, bool exchange, hipStream_t stream);
+void persist_launch(const IntrDev& P, const PersistDev& Q, bool drop_control, hipStream_t stream);
 
 }  // namespace cc

@@ -207,3 +207,39 @@ def test_rccl_path_with_a_single_rank_communicator():
     assert s1["iterations"] == s0["iterations"] and s1["termination"] == s0["termination"]
     assert np.allclose([l["cost"] for l in s1["log"]], [l["cost"] for l in s0["log"]], rtol=1e-12)
     assert np.allclose(i1, i0, rtol=1e-12, atol=1e-14) and np.allclose(q1, q0, atol=1e-13)
+
+
+def test_persistent_solve_that_cannot_get_its_grid_is_rerun_in_the_two_kernel_form():
+    """The persistent per-solve kernel needs every one of its workgroups resident at once; on a device it does not have
+    to itself (another process, a compute-unit mask) a wait inside it gives up after 1.3 s, nothing is written back, and
+    cc_intrinsics_solve runs the solve again in the two-kernel form -- same answer, and the handle stays with that form.
+    Forced here by launching the grid WITHOUT its control workgroup (CC_INTR_PERSIST_TEST_NO_CONTROL, read once per
+    process: hence a process of its own)."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, time, numpy as np
+        sys.path.insert(0, %r)
+        from camera_calibrator_amd import capi
+        from oracle import pyoracle as po
+        from tests.helpers import intrinsics_case
+        case = intrinsics_case(20, 88)
+        prob = capi.IntrinsicsProblem(case["off"], case["uv"], case["xyz"])
+        prob.set_state(case["intr0"], case["q0"], case["t0"])
+        assert prob.solver_form() in (1, 2, 4)
+        t0 = time.time()
+        s = prob.solve(capi.default_options())
+        dt = time.time() - t0
+        assert prob.solver_form() == 0 and dt > 1.0, (prob.solver_form(), dt)
+        ig, qg, tg = prob.get_state()
+        s2 = prob.solve(capi.default_options())          # continues from the accepted point, two-kernel form, no stall
+        prob.close()
+        io, qo, to, so = po.intrinsics_solve(case["off"], case["uv"], case["xyz"], case["intr0"], case["q0"], case["t0"])
+        assert s["iterations"] == so["iterations"] and s["termination"] == so["termination"]
+        assert np.allclose(ig[:4], io[:4], rtol=1e-9) and np.allclose(ig[4:], io[4:], atol=1e-9)
+        assert np.abs(qg - qo).max() < 1e-9 and np.abs(tg - to).max() < 1e-9
+        assert s2["iterations"] <= 2
+        print("rerun ok", dt)
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CC_INTR_PERSIST_TEST_NO_CONTROL="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert r.returncode == 0 and "rerun ok" in r.stdout, r.stdout[-3000:]
