@@ -216,6 +216,8 @@ def test_persistent_solve_that_cannot_get_its_grid_is_rerun_in_the_two_kernel_fo
     Forced here by launching the grid WITHOUT its control workgroup (CC_INTR_PERSIST_TEST_NO_CONTROL, read once per
     process: hence a process of its own)."""
     import os, subprocess, sys, textwrap
+    if os.environ.get("CC_INTR_PERSIST") == "0":
+        pytest.skip("the persistent kernel is switched off in this environment (tests/test_gpu_persist.py, two-kernel form)")
     code = textwrap.dedent("""
         import sys, time, numpy as np
         sys.path.insert(0, %r)
