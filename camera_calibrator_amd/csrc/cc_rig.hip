@@ -1289,14 +1289,14 @@ __global__ __launch_bounds__(256) void k_rig_stats(RigDev P) {
   rig_reduce_stats(P, need, s16, s_out);
   if (tid < 4) P.vec_stats[tid] = need ? s_out[tid] : 0.0;
   {
-    __shared__ double s_diag[kRigMaxS + 1];
+    __shared__ double s_diag[256];
     if (phase == 0) rig_diag_sums(P, s4, s_diag);
     for (int k = tid; k < P.S; k += 256) P.vec_stats[4 + k] = phase == 0 ? s_diag[k] : 0.0;
   }
   if (P.x.on) {
     // mailbox exchange (kind 1): post the local statistics, wait for every rank's, write the sums back
     // (k_rig_init / k_rig_elim read vec_stats as they do after an all-reduce)
-    __shared__ double s_post[4 + kRigMaxS + 1];
+    __shared__ double s_post[4 + 256];
     __shared__ int s_ok;
     __syncthreads();
     const int n = 4 + P.S;
@@ -1338,7 +1338,7 @@ __global__ __launch_bounds__(256) void k_rig_init(RigDev P) {
   __shared__ double s4[4];
   __shared__ double s16[16];
   __shared__ double s_out[4];
-  __shared__ double s_ss[kRigMaxS + 1];
+  __shared__ double s_ss[256];
   const LmCtl* ctl = P.ctl;
   // Only block 0 looks at the control block: it ends by storing lm_init's result (phase = 1) into it, so a block of this
   // launch that is dispatched late (busy or partitioned GPU) would see the flipped phase, return, and leave its run's
@@ -1364,7 +1364,7 @@ __global__ __launch_bounds__(256) void k_rig_init(RigDev P) {
       b -= cnt;
       k += kind == 0 ? 6 : kRigK;
     }
-    for (int k = tid; k < kRigMaxS + 1; k += 256) s_ss[k] = -1.0;
+    for (int k = tid; k < 256; k += 256) s_ss[k] = -1.0;
     __syncthreads();
     rig_diag_sums(P, s4, s_ss, run, slice, ns);
     if (ns == 1) {
@@ -2496,6 +2496,421 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P, int publish) {
 #endif
 }
 
+// =============================================================================================
+// LARGE reduced systems (128 <= S <= 255: more than 21 optimised cameras, or more than 8 with intrinsics of their own;
+// the reference takes any number of cameras, extrinsics_calibrator.cpp:9-17). The kernels above are built around
+// S + 1 <= 128 (two shared columns per lane, nine tile accumulators per wave, the reduced system in LDS with a row stride);
+// rather than bend them, such problems run the same arithmetic in a plainer form -- correctness first, no tuning:
+//   k_rig_elim_big : one block per frame at a time, thread k owns shared column k (S + 1 <= 256); the 6 x 6 factor is
+//                    computed by every thread; Schur products Z^T Z accumulated per 16 x 16 tile with plain FMAs, entry
+//                    `tid` of every tile in a register (<= 136 tiles); the direct sums in LDS. Same partial-row layout.
+//   k_rig_reduce<2>: the column sums (unchanged) -> P.vec
+//   k_rig_solve_big: one block; the reduced system as a PACKED lower triangle in LDS (S <= 190) or with its row stride in
+//                    global memory; left-looking Cholesky, thread i owns row i, two barriers per column; column-oriented
+//                    substitutions; the tests, candidates and control block of rig_solve_block.
+//   k_rig_update   : unchanged.
+// Sweep, init, records, statistics: unchanged (their shared-column arrays hold 256 entries).
+// =============================================================================================
+constexpr int kRigBigMaxS = 255;
+constexpr int kRigBigTiles = 136;   // upper tile pairs of a 16 x 16 tile grid
+__host__ __device__ constexpr int big_tile(int a, int b) { return a * 16 - a * (a - 1) / 2 + (b - a); }   // (a <= b < 16)
+
+template <bool HK>
+__global__ __launch_bounds__(256) void k_rig_elim_big(RigDev P) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* s_Z = reinterpret_cast<double*>(smem_raw);   // [6][256] staged Z rows of the block's current frame
+  double* s_d = s_Z + 6 * 256;                          // [ND] direct sums of the block
+  __shared__ double s_A[32];
+  __shared__ double s_ss[kRigBigMaxS + 1];
+  __shared__ double s16[16];
+  __shared__ double s_tot[4];
+  __shared__ double s_fg[8];
+  __shared__ int s_g[64];
+  __shared__ LmCtl s_ctl;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const LmCtl* ctl = P.ctl;
+  if (ctl->done || ctl->phase == 0) return;
+  // ---- trust-region decision: every block, same answer; block 0 publishes it (as in k_rig_elim)
+  const bool pending = ctl->cand_pending != 0;
+  rig_reduce_stats(P, pending && ctl->step_valid, s16, s_tot);
+  if (tid == 0) {
+    LmCtl c = *ctl;
+    const LmOpts o = *P.opts;
+    if (pending) {
+      double step2 = s_tot[2], xn2 = s_tot[3];
+      if (c.step_valid) { step2 += P.shared_stats[0]; xn2 += P.shared_stats[1]; }
+      cc_iteration rec;
+      const int len0 = c.log_len;
+      lm_decide(c, o, &rec, s_tot[0], s_tot[1], step2, xn2);
+      if (blockIdx.x == 0 && c.log_len != len0 && c.log_len <= P.log_cap) P.log[c.log_len - 1] = rec;
+    }
+    s_ctl = c;
+    if (blockIdx.x == 0) *P.ctl_next = c;
+  }
+  if (tid < P.S) s_ss[tid] = P.ss[tid];
+  for (int i = tid; i < 6 * 256; i += 256) s_Z[i] = 0.0;
+  for (int i = tid; i < P.ND; i += 256) s_d[i] = 0.0;
+  __syncthreads();
+  if (s_ctl.done) return;
+  const int cur = s_ctl.cur;
+  const double inv_radius = 1.0 / s_ctl.radius;
+  const double mn = P.opts->min_lm_diagonal, mx = P.opts->max_lm_diagonal;
+  const bool first_elim = ctl->phase == 1 && s_ctl.iter == 0 && !pending;
+  const bool jac = P.opts->jacobi_scaling != 0;
+  const int SW = P.SW, S = P.S, CO = P.CO, T = P.T;
+  const size_t gs = (size_t)P.gstride;
+  const double* blocks = P.gblocks + (size_t)cur * P.NG * gs;
+  // this thread's shared column and frame-block entry
+  int c_kind = -1, c_co = 0, c_comp = 0;
+  if (tid < SW) { const int info = P.colinfo[tid]; c_kind = (info >> 4) & 15; c_co = info >> 8; c_comp = info & 15; }
+  const double c_ss = tid < S ? s_ss[tid] : (tid < SW ? 1.0 : 0.0);
+  int a_off = 0, sp_i = -1;
+  if (tid < 21) {
+    int i = 0;
+    while (tri(i + 1, 0) <= tid) ++i;
+    const int j = tid - tri(i, 0);
+    a_off = (6 + i) * 16 + 6 + j;
+    if (i == j) sp_i = i;
+  } else if (tid < 27) {
+    a_off = (6 + (tid - 21)) * 16 + 12;
+  }
+  double acc[kRigBigTiles];
+#pragma unroll
+  for (int t = 0; t < kRigBigTiles; ++t) acc[t] = 0.0;
+  // (failure count and gradient maximum of the block live in LDS, s_fg[0] / s_fg[1]: thread 0 alone touches them)
+  if (tid == 0) { s_fg[0] = 0.0; s_fg[1] = 0.0; }
+  const int tr = tid >> 4, tc = tid & 15;
+  for (int64_t f = blockIdx.x; f < P.F; f += gridDim.x) {
+    if (tid < 64) s_g[tid] = tid < CO ? P.fslot[f * CO + tid] : -1;
+    __syncthreads();
+    bool live = false;
+    for (int j = 0; j < CO; ++j) live = live || s_g[j] >= 0;
+    if (live) {
+      if (tid < 27) {
+        double a_e = 0.0;
+        for (int j = 0; j < CO; ++j) { const int g = s_g[j]; if (g >= 0) a_e += blocks[(size_t)g * gs + a_off]; }
+        s_A[tid] = a_e;
+        if (first_elim && sp_i >= 0) P.sp[f * 8 + sp_i] = jac ? 1.0 / (1.0 + sqrt(a_e)) : 1.0;
+      }
+      __syncthreads();
+      double A[27], sf[6];
+#pragma unroll
+      for (int i = 0; i < 27; ++i) A[i] = s_A[i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) sf[i] = first_elim ? (jac ? 1.0 / (1.0 + sqrt(A[tri(i, i)])) : 1.0) : P.sp[f * 8 + i];
+      double L[21], Li[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) L[tri(i, j)] = sf[i] * A[tri(i, j)] * sf[j];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) L[tri(i, i)] += clampd(L[tri(i, i)], mn, mx) * inv_radius;
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        double d = L[tri(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= L[tri(j, k)] * L[tri(j, k)];
+        ok = ok && (d > 0.0) && isfinite(d);
+        const double inv = rsqrt(d);
+        L[tri(j, j)] = d * inv;
+        Li[j] = inv;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+          double a = L[tri(i, j)];
+#pragma unroll
+          for (int k = 0; k < j; ++k) a -= L[tri(i, k)] * L[tri(j, k)];
+          L[tri(i, j)] = a * inv;
+        }
+      }
+      if (tid == 0) {
+        if (!ok) s_fg[0] += 1.0;
+        double gm = s_fg[1];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) gm = fmax(gm, fabs(A[21 + i]));
+        s_fg[1] = gm;
+      }
+      if (tid < SW) {
+        double w[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (c_kind == 0 || c_kind == 1) {
+          const int g = s_g[c_co];
+          if (g >= 0) {
+            const double* G = blocks + (size_t)g * gs;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) w[i] = c_kind == 0 ? G[c_comp * 16 + 6 + i] : G[256 + (6 + i) * 16 + c_comp];
+          }
+        } else if (HK && c_kind == 2) {
+          for (int j = 0; j < CO; ++j) {
+            const int g = s_g[j];
+            if (g < 0) continue;
+            const double* G = blocks + (size_t)g * gs + 256;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) w[i] += G[(6 + i) * 16 + c_comp];
+          }
+        }
+        double z[6], y[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          double a = c_kind == 3 ? sf[i] * A[21 + i] : sf[i] * w[i] * c_ss;
+#pragma unroll
+          for (int kk = 0; kk < i; ++kk) a -= L[tri(i, kk)] * z[kk];
+          z[i] = a * Li[i];
+        }
+#pragma unroll
+        for (int i = 5; i >= 0; --i) {
+          double a = z[i];
+#pragma unroll
+          for (int kk = i + 1; kk < 6; ++kk) a -= L[tri(kk, i)] * y[kk];
+          y[i] = a * Li[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          s_Z[i * 256 + tid] = z[i];
+          P.Y[((size_t)f * 6 + i) * SW + tid] = y[i];
+        }
+      }
+      for (int e = tid; e < P.ND; e += 256) {
+        const int t = P.dent[e];
+        const int g = s_g[t >> 16];
+        if (g >= 0) s_d[e] += blocks[(size_t)g * gs + (t & 0xffff)];
+      }
+      __syncthreads();
+      // Schur products of this frame: entry (tr, tc) of every upper tile pair (a, b), a <= b < T. The loops run over the
+      // largest tile grid with compile-time accumulator indices (no tables: 136 pairs of table entries in scalar registers
+      // spilled hundreds of them); which pairs exist is a uniform test.
+#pragma unroll
+      for (int a = 0; a < 16; ++a) {
+        if (a < T) {
+          double za[6];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) za[i] = s_Z[i * 256 + 16 * a + tr];
+#pragma unroll
+          for (int b = a; b < 16; ++b) {
+            if (b < T) {
+              double x = acc[big_tile(a, b)];
+#pragma unroll
+              for (int i = 0; i < 6; ++i) x = fma(za[i], s_Z[i * 256 + 16 * b + tc], x);
+              acc[big_tile(a, b)] = x;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  double* prow = P.partial + (size_t)blockIdx.x * P.PC;
+  // (the partial row numbers the pairs of the T x T grid in the same order: a, then b)
+#pragma unroll
+  for (int a = 0; a < 16; ++a)
+#pragma unroll
+    for (int b = a; b < 16; ++b)
+      if (b < T) prow[(size_t)(a * T - a * (a - 1) / 2 + (b - a)) * 256 + tid] = acc[big_tile(a, b)];
+  for (int e = tid; e < P.ND; e += 256) prow[P.pc_dir + e] = s_d[e];
+  if (tid == 0) { prow[P.pc_fail] = s_fg[0]; prow[P.pc_gmax] = s_fg[1]; }
+  (void)lane; (void)wave;
+}
+
+// accessor of the reduced system's lower triangle (rows 0..S, row S = right-hand side; S columns). In LDS: packed by
+// rows -- thread i owns row i, a batch of its entries is one base address plus immediates (packed by columns, free of
+// bank conflicts on paper, measured slower: 302 against 214 us at S = 132). In global memory: COLUMN-major with a stride,
+// so that at a fixed column the 64 lanes of a wave touch consecutive addresses (one 512-byte transaction instead of 64)
+// and the pivot row's entry is one address for the wave.
+template <bool PACKED>
+struct BigA {
+  double* p; int LD;
+  __device__ __forceinline__ double& at(int i, int k) const {   // k <= i <= S, k < S
+    return PACKED ? p[i * (i + 1) / 2 + k] : p[(size_t)k * LD + i];
+  }
+  // host-built destinations are row * LD + col (rig_layout)
+  __device__ __forceinline__ double& at_dst(int dst) const { const int i = dst / LD, k = dst - i * LD; return at(i, k); }
+};
+
+template <bool PACKED>
+__global__ __launch_bounds__(256) void k_rig_solve_big(RigDev P, double* Aglobal) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const LmCtl* cn = P.ctl_next;
+  if (cn->done) {
+    if (threadIdx.x == 0) *P.ctl = *cn;
+    return;
+  }
+  if (cn->phase == 0) return;
+  const int S = P.S, LD = (S + 1) | 1;
+  double* lds = reinterpret_cast<double*>(smem_raw);
+  double* s_b = lds;                  // [256] right-hand side -> y -> x
+  double* s_gs = s_b + 256;           // [256] unscaled shared gradient
+  double* s_hd = s_gs + 256;          // [256] diagonal of the scaled H_ss
+  double* s_inv = s_hd + 256;         // [256] 1 / L_jj
+  double* s_ss = s_inv + 256;         // [256]
+  BigA<PACKED> A{PACKED ? s_ss + 256 : Aglobal, LD};
+  __shared__ int s_cholok, s_stepok, s_go;
+  __shared__ double s4[4];
+  __shared__ double s8[8];
+  __shared__ double s_r;
+  __shared__ LmCtl s_c;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int cur = cn->cur, dst = cur ^ 1;
+  const double radius = cn->radius;
+  const LmOpts o = *P.opts;
+  if (tid == 0) { s_cholok = 1; s_stepok = 0; s_go = 0; s_c = *cn; }
+  for (int i = tid; i <= S; i += 256)   // (row S: the right-hand side)
+    for (int k = 0; k <= i && k < S; ++k) A.at(i, k) = 0.0;
+  s_b[tid] = 0.0; s_gs[tid] = 0.0; s_hd[tid] = 0.0; s_inv[tid] = 0.0; s_ss[tid] = tid < S ? P.ss[tid] : 0.0;
+  const int pin = tid < S ? P.colpin[tid] : -1;
+  const bool pinned = pin >= 0 && ((P.kmask[pin >> 4] >> (pin & 15)) & 1u) != 0;
+  __syncthreads();
+  // ---- assembly from the column sums (P.vec): direct sums, then minus the Schur products. An element gets at most one
+  // contribution of each kind; the two loops are separated by a barrier, so plain read-modify-write is safe.
+  for (int e = tid; e < P.ND; e += 256) {
+    const int d = P.dir_dst[e];
+    if (d == -1) continue;
+    double acc = P.vec[P.pc_dir + e];
+    for (int n = P.dir_next[e]; n >= 0; n = P.dir_next[n]) acc += P.vec[P.pc_dir + n];
+    if (d >= 0) {
+      const int sa = P.dir_sa[e], sb = P.dir_sb[e];
+      const double x = s_ss[sa] * acc * s_ss[sb];
+      A.at_dst(d) += x;
+      if (sa == sb) s_hd[sa] = x;
+    } else {
+      s_gs[-2 - d] = acc;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < P.nT * 256; i += 256) {
+    const int d = P.tile_dst[i];
+    if (d == -1) continue;
+    const double v = P.vec[i];
+    if (d >= 0) A.at_dst(d) -= v;
+    else s_b[-2 - d] = -v;
+  }
+  const double fail = P.vec[P.pc_fail];
+  const double gm_r = (tid < P.nranks && tid < 32) ? P.vec[P.PC + tid] : 0.0;
+  __syncthreads();
+  if (tid < S) s_b[tid] = pinned ? 0.0 : s_b[tid] + s_ss[tid] * s_gs[tid];
+  __syncthreads();
+  if (tid < S) {
+    if (pinned) {
+      for (int k = 0; k < tid; ++k) A.at(tid, k) = 0.0;
+      for (int k = tid + 1; k < S; ++k) A.at(k, tid) = 0.0;
+      A.at(tid, tid) = 1.0;
+    } else {
+      A.at(tid, tid) += clampd(s_hd[tid], o.min_lm_diagonal, o.max_lm_diagonal) / radius;
+    }
+  }
+  {
+    double g = gm_r;
+    if (tid < S && !pinned) g = fmax(g, fabs(s_gs[tid]));
+    g = wave_max(g);
+    if (lane == 0) s4[tid >> 6] = g;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    LmCtl c = s_c;
+    const double gmax = fmax(fmax(s4[0], s4[1]), fmax(s4[2], s4[3]));
+    if (c.log_len > 0 && c.log_len <= P.log_cap) P.log[c.log_len - 1].gradient_max_norm = gmax;
+    if (lm_finalize(c, o, gmax)) s_go = 1;
+    if (fail > 0.0) s_cholok = 0;
+    s_c = c;
+  }
+  __syncthreads();
+  if (s_go) {
+    // ---- left-looking Cholesky, thread i owns row i. The right-hand side is ROW S of the matrix (thread S): its forward
+    // substitution y_j = (b_j - sum_m L_jm y_m) / L_jj is the same dot product and the same scaling as every other row
+    // (carried by the pivot thread on its own it was a serial chain of j dependent loads per column: 2/3 of the step).
+    const int i = tid;
+    if (tid < S) A.at(S, tid) = s_b[tid];
+    __syncthreads();
+    for (int j = 0; j < S; ++j) {
+      double a = 0.0;
+      if (i >= j && i <= S) {
+        // dot product of rows i and j over the finished columns, sixteen columns per round trip: all loads of a batch
+        // are issued before its first FMA (written naively the loop waits for every single load)
+        a = A.at(i, j);
+        int m = 0;
+        for (; m + 16 <= j; m += 16) {
+          double x[16], y[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) { x[u] = A.at(i, m + u); y[u] = A.at(j, m + u); }
+#pragma unroll
+          for (int u = 0; u < 16; ++u) a -= x[u] * y[u];
+        }
+        {   // tail: loads from clamped columns, selected away
+          double x[16], y[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) { const int c = m + u < j ? m + u : j; x[u] = A.at(i, c); y[u] = A.at(j, c); }
+#pragma unroll
+          for (int u = 0; u < 16; ++u) a -= m + u < j ? x[u] * y[u] : 0.0;
+        }
+      }
+      if (i == j) {
+        const bool ok = (a > 0.0) && isfinite(a);
+        if (!ok) s_cholok = 0;
+        const double r = rsqrt(a);
+        s_r = r;
+        s_inv[j] = r;
+        A.at(j, j) = a * r;
+      }
+      __syncthreads();
+      if (i > j && i <= S) A.at(i, j) = a * s_r;
+      __syncthreads();
+    }
+    if (tid < S) s_b[tid] = A.at(S, tid);
+    __syncthreads();
+    // ---- backward substitution L^T x = y, column-oriented: x_k is published, every row above subtracts its share
+    // (thread i touches only its own entry between the barriers, so one barrier per step is enough; the multipliers of
+    // eight steps are fetched in one round trip, from clamped addresses, ahead of the steps that use them)
+    {
+      const int ic = i < S ? i : S - 1;
+      for (int k0 = S - 1; k0 >= 0; k0 -= 8) {
+        double l[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int kk = k0 - u > 0 ? k0 - u : 0;
+          l[u] = A.at(kk > ic ? kk : ic, ic);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int kk = k0 - u;
+          if (kk < 0) break;   // (uniform)
+          if (i == kk) s_b[kk] = s_b[kk] * s_inv[kk];
+          __syncthreads();
+          if (i < kk) s_b[i] -= l[u] * s_b[kk];
+        }
+      }
+      __syncthreads();
+    }
+    if (tid < 64) {
+      bool fin = true;
+      for (int k = lane; k < S; k += 64) {
+        fin = fin && isfinite(s_b[k]);
+        P.ds[k] = -s_b[k];
+      }
+      const bool step_ok = s_cholok != 0 && __all(fin);
+      if (lane == 0) s_stepok = step_ok ? 1 : 0;
+    }
+    __syncthreads();
+  }
+  double st2 = 0.0, xs2 = 0.0;
+  const bool have_step = s_go != 0 && s_stepok != 0;
+  if (have_step) rig_candidates(P, s_b, s_ss, true, cur, dst, st2, xs2);
+  {
+    const double a = wave_sum(st2), b2 = wave_sum(xs2);
+    __syncthreads();
+    if (lane == 0) { s8[tid >> 6] = a; s8[4 + (tid >> 6)] = b2; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    LmCtl c = s_c;
+    if (s_go) {
+      c.step_valid = have_step ? 1 : 0;
+      c.cand_pending = 1;
+      P.shared_stats[0] = (s8[0] + s8[1]) + (s8[2] + s8[3]);
+      P.shared_stats[1] = (s8[4] + s8[5]) + (s8[6] + s8[7]);
+    }
+    *P.ctl = c;
+    *P.ctl_next = c;
+  }
+}
+
 // creation: world point of every observation
 __global__ void k_rig_expand_xyz(int64_t n, const int32_t* widx, const float* wxyz, float* oxyz) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2579,6 +2994,9 @@ struct cc_rig {
   std::vector<int32_t> gframe_h, gcam_h;   // host copies of the group tables (layout rebuilds)
   std::vector<int64_t> fgoff_h;
   size_t elim_lds = 0, solve_lds = 0;
+  bool big = false;             // 128 <= S <= 255: the plain kernels (k_rig_elim_big, k_rig_solve_big), no exchange
+  bool big_packed = false;      // ... with the reduced system as a packed triangle in LDS (else in bigA, global memory)
+  double* bigA = nullptr;
   volatile unsigned long long* host_pub = nullptr;   // = h_ctl's pinned block: [0] sequence word, [2..19] control block, [20] failure word
   unsigned long long pub_count = 0;                  // chunks published so far
   cc::LmCtl last_st{};          // control block as the last solve / reset left it (no read-back at the start of a solve)
@@ -2683,18 +3101,23 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
   }
   colinfo.push_back((0 << 8) | (3 << 4) | 0);   // right-hand side
   const int CO = (int)obs_cam.size();
-  if (S > kRigMaxS)
+  if (S > kRigBigMaxS)
     return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: %d optimised shared coordinates (6 per observed non-frozen camera%s); at most %d",
-                S, kmode ? " + 9 per intrinsics set" : "", kRigMaxS);
+                S, kmode ? " + 9 per intrinsics set" : "", kRigBigMaxS);
   if (CO > 64) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: %d observed cameras; at most 64", CO);
   const int DE = kmode ? kDEK : kDE0;
-  if (CO * DE > 64 * kRigDirectPerLane)
-    return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: %d observed cameras%s; at most %d", CO, kmode ? " with intrinsics" : "", 64 * kRigDirectPerLane / DE);
+  // beyond what the tuned kernels are built around (S <= 127 shared coordinates, 1536 direct sums): the plain ones
+  // (k_rig_elim_big, k_rig_solve_big), single GPU only
+  h->big = S > kRigMaxS || CO * DE > 64 * kRigDirectPerLane;
+  if (const char* e = getenv("CC_RIG_FORCE_BIG")) h->big = h->big || (atoi(e) != 0 && !h->comm && !h->exchange);   // (test knob: the plain kernels on any problem)
+  if (h->big && (h->comm || h->exchange))
+    return fail(CC_ERR_BAD_ARGUMENT, "%d shared coordinates, %d observed cameras%s: more than %d coordinates or %d cameras are not supported across several GPUs",
+                S, CO, kmode ? " with intrinsics" : "", kRigMaxS, 64 * kRigDirectPerLane / DE);
   d.C = (int32_t)C; d.CO = CO; d.CK = CK; d.S = S; d.SW = S + 1;
   d.T = (d.SW + 15) / 16; d.nT = d.T * (d.T + 1) / 2; d.ZS = 16 * d.T + ((d.T & 1) ? 0 : 16);
   d.DE = DE; d.ND = CO * DE;
   d.pc_dir = d.nT * 256; d.pc_fail = d.pc_dir + d.ND; d.pc_gmax = d.pc_fail + 1; d.PC = d.pc_gmax + 1;
-  d.nblk = (int)std::max<int64_t>(1, std::min<int64_t>(kRigMaxElimBlocks, (F + 3) / 4));
+  d.nblk = (int)std::max<int64_t>(1, std::min<int64_t>(kRigMaxElimBlocks, h->big ? F : (F + 3) / 4));   // (big: one frame at a time per block)
   std::vector<int16_t> dmap((size_t)DE);
   for (int i = 0; i < 6; ++i) for (int j = 0; j <= i; ++j) dmap[(size_t)(i * (i + 1) / 2 + j)] = (int16_t)(i * 16 + j);
   for (int i = 0; i < 6; ++i) dmap[(size_t)(21 + i)] = (int16_t)(i * 16 + 12);
@@ -2786,9 +3209,23 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
   if (int rc = dev_zeroed(h, &d.Y, (size_t)F * 6 * d.SW)) return rc;
   if (int rc = dev_zeroed(h, &d.partial, (size_t)d.nblk * d.PC)) return rc;
   if (int rc = dev_zeroed(h, &d.vec, (size_t)d.PC + 32)) return rc;
-  if (int rc = dev_zeroed(h, &d.vec_stats, (size_t)4 + kRigMaxS + 1)) return rc;
+  if (int rc = dev_zeroed(h, &d.vec_stats, (size_t)4 + 256)) return rc;
   h->elim_lds = ((size_t)24 * d.ZS + 4 * 32 + 4 * 1024 + (d.ND > 8 * 64 ? 4 * kRigDirectPerLane * 64 : 0)) * sizeof(double);
   h->solve_lds = ((size_t)S * ((S + 1) | 1) + 5 * 128) * sizeof(double);
+  if (h->big) {
+    h->elim_lds = ((size_t)6 * 256 + d.ND) * sizeof(double);
+    const size_t packed = ((size_t)5 * 256 + (size_t)(S + 1) * (S + 2) / 2) * sizeof(double);   // (rows 0..S: the right-hand side is row S)
+    h->big_packed = packed + 2048 <= 160 * 1024;
+    h->solve_lds = h->big_packed ? packed : (size_t)5 * 256 * sizeof(double);
+    if (!h->big_packed)
+      if (int rc = dev_zeroed(h, &h->bigA, (size_t)S * ((S + 1) | 1))) return rc;
+    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim_big<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
+    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim_big<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
+    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_solve_big<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
+    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_solve_big<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
+    rig_drop_graphs(h);
+    return 0;
+  }
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<false, kRigDirectPerLane>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
@@ -2828,6 +3265,11 @@ static int rig_size_reduce_grid(cc_rig* h) {
   const int co = env_co ? env_co : std::max(1, h->co_resident);
   const size_t key = (h->solve_lds << 8) ^ ((size_t)co << 1) ^ (h->exchange ? 1u : 0u) ^ ((size_t)h->d.PC << 40) ^ ((size_t)h->F << 20);
   if (key == h->reduce_key && h->reduce_blocks > 0) return 0;
+  if (h->big) {   // column sums only (k_rig_reduce<2>): nothing waits inside that launch
+    h->reduce_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(rcap, (h->d.PC + 15) / 16));
+    h->reduce_key = key;
+    return 0;
+  }
   int per_cu = 0, cus = 0;
   if (h->exchange) CC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rig_reduce<3>, 256, h->solve_lds));
   else CC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rig_reduce<0>, 256, h->solve_lds));
@@ -2867,6 +3309,17 @@ static int rig_enqueue_round(cc_rig* h, bool initial, bool profile, bool publish
     if (h->comm) { RigProbe p(h, CC_K_ALLREDUCE, profile); if (int rc = comm_allreduce_sum(h->comm, d.vec_stats, 4 + d.S, h->stream)) return rc; }
   }
   if (initial) { RigProbe p(h, CC_K_DECIDE, profile); hipLaunchKernelGGL(k_rig_init, dim3(1 + (unsigned)h->n_runs + (unsigned)h->n_shared_runs * (unsigned)(d.init_slices - 1)), dim3(256), 0, h->stream, d); }
+  if (h->big) {
+    { RigProbe p(h, CC_K_ELIM, profile);
+      if (d.kmode) hipLaunchKernelGGL(k_rig_elim_big<true>, dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d);
+      else hipLaunchKernelGGL(k_rig_elim_big<false>, dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d); }
+    { RigProbe p(h, CC_K_REDUCE, profile); hipLaunchKernelGGL(k_rig_reduce<2>, dim3((unsigned)std::max(1, h->reduce_blocks)), dim3(256), 0, h->stream, d, 0); }
+    { RigProbe p(h, CC_K_SOLVE, profile);
+      if (h->big_packed) hipLaunchKernelGGL(k_rig_solve_big<true>, dim3(1), dim3(256), h->solve_lds, h->stream, d, h->bigA);
+      else hipLaunchKernelGGL(k_rig_solve_big<false>, dim3(1), dim3(256), h->solve_lds, h->stream, d, h->bigA); }
+    { RigProbe p(h, CC_K_UPDATE, profile); hipLaunchKernelGGL(k_rig_update, dim3((unsigned)((h->F + 15) / 16)), dim3(256), 0, h->stream, d); }
+    return 0;
+  }
   { RigProbe p(h, CC_K_ELIM, profile);
     const bool small = d.ND <= 8 * 64;
     if (d.kmode && small) hipLaunchKernelGGL((k_rig_elim<true, 8>), dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d);
@@ -3075,8 +3528,8 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   if (int rc = dev_zeroed(h, &d.ghd0, (size_t)NG * 8)) return rc;
   if (int rc = dev_zeroed(h, &d.gcomp, (size_t)2 * NG * (kmode ? kRigCompK : 64))) return rc;
   if (int rc = dev_zeroed(h, &d.sp, (size_t)F * 8)) return rc;
-  if (int rc = dev_zeroed(h, &d.ss, (size_t)128)) return rc;
-  if (int rc = dev_zeroed(h, &d.ds, (size_t)128)) return rc;
+  if (int rc = dev_zeroed(h, &d.ss, (size_t)256)) return rc;
+  if (int rc = dev_zeroed(h, &d.ds, (size_t)256)) return rc;
   if (int rc = dev_zeroed(h, &d.shared_stats, (size_t)48)) return rc;   // [0..3] statistics, [8..] timing marks (CC_RIG_TIMING builds)
   // one piece: control block | its copy for the host (ctl_next) | 16 synchronisation words (RigDev::arrive) | publication
   // counter -- a solve starts by zeroing the first three with ONE fill (rig_begin)
@@ -3325,7 +3778,7 @@ static int rig_launch(cc_rig* h, RigRun* r, int chunk) {
 static int rig_wait(cc_rig* h, RigRun* r) {
   CC_HIP(hipSetDevice(h->device));
   bool wait_failed = false;
-  if (int rc = (h->comm ? rig_read_ctl(h, &r->st, &wait_failed) : rig_wait_published(h, &r->st, &wait_failed))) return rc;
+  if (int rc = ((h->comm || h->big) ? rig_read_ctl(h, &r->st, &wait_failed) : rig_wait_published(h, &r->st, &wait_failed))) return rc;
   if (r->st.done) { h->last_st = r->st; h->st_known = true; }
   if (wait_failed)
     return fail(CC_ERR_COMM, "k_rig_reduce: the solving block did not publish within 10 s (iteration %d): its launch was not fully "
@@ -3453,6 +3906,7 @@ int cc_rig_comm_init(cc_rig* h, const uint8_t id[128], int32_t rank, int32_t nra
   using namespace cc;
   if (!h || !id || rank < 0 || nranks < 1 || rank >= nranks || nranks > 32)
     return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_comm_init: bad arguments (nranks must be 1..32)");
+  if (h->big) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_comm_init: %d shared coordinates, %d observed cameras: problems beyond %d coordinates or %d direct sums run on one GPU only", h->d.S, h->d.CO, kRigMaxS, 64 * kRigDirectPerLane);
   CC_HIP(hipSetDevice(h->device));
   if (h->comm) { comm_destroy(h->comm); h->comm = nullptr; }
   rig_drop_graphs(h);
@@ -3495,6 +3949,7 @@ int cc_rig_exchange_attach(cc_rig* h, int32_t rank, int32_t nranks, const uint8_
   if (!h->mailbox.local) return fail(CC_ERR_STATE, "cc_rig_exchange_attach: call cc_rig_exchange_export first");
   if (h->comm) return fail(CC_ERR_STATE, "cc_rig_exchange_attach: an RCCL communicator is already attached");
   if (h->C > 128) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_exchange_attach: at most 128 cameras with the mailbox exchange");
+  if (h->big) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_exchange_attach: %d shared coordinates, %d observed cameras: problems beyond %d coordinates or %d direct sums run on one GPU only", h->d.S, h->d.CO, kRigMaxS, 64 * kRigDirectPerLane);
   CC_HIP(hipSetDevice(h->device));
   rig_drop_graphs(h);
   if (int rc = mailbox_attach(&h->mailbox, rank, nranks, handles, &h->d.x)) return rc;

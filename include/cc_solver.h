@@ -213,7 +213,8 @@ int cc_partition_frames(int64_t n_frames, const int64_t* frame_offsets, int32_t 
  * obs_world indexes world_xyz (3 floats per point). cam_frozen[c] != 0 keeps camera c constant;
  * cameras / frames without observations are left untouched (they never enter the problem).
  * Any number of cameras: only cameras that are observed and not frozen own columns of the reduced system
- * (6 each, at most 127 in all, i.e. 21 optimised cameras; at most 64 observed cameras).
+ * (6 each, at most 255 in all, i.e. 42 optimised cameras; at most 64 observed cameras). Up to 127 coordinates the
+ * tuned kernels run; beyond, plain ones on a single GPU (cc_rig_comm_init / cc_rig_exchange_attach then refuse).
  * ------------------------------------------------------------------------------------------- */
 typedef struct cc_rig cc_rig;
 
@@ -248,8 +249,8 @@ int cc_rig_exchange_attach(cc_rig* h, int32_t rank, int32_t nranks, const uint8_
  * cameras and co-optimised with the poses. Observations are PIXELS: the residual is the composition of
  * ReprojectionErrorExtrinsics (extrinsics_calibrator.cpp:51-84) and DistortNormalized/DistortPixels
  * (calibrator.cpp:70-95). huber_a is in pixels, <= 0 switches the loss off. 6 columns per optimised camera + 9
- * must stay <= 127 and at most 11 cameras may be observed. Multi-GPU through cc_rig_exchange_* /
- * cc_rig_comm_init like the plain rig problem (intrinsics replicated).
+ * must stay <= 255. Multi-GPU through cc_rig_exchange_* / cc_rig_comm_init like the plain rig problem (intrinsics
+ * replicated) while the columns stay <= 127 and at most 11 cameras are observed; larger problems run on one GPU.
  * The handle is a cc_rig: set_state / reset / solve / get_state / eval / destroy are the cc_rig_* calls;
  * cc_rigk_set_intrinsics must be called once before the first solve (const_mask bit i freezes intrinsic i). */
 int cc_rigk_create(int32_t device, int64_t n_cams, int64_t n_frames, int64_t n_world,
@@ -259,7 +260,8 @@ int cc_rigk_create(int32_t device, int64_t n_cams, int64_t n_frames, int64_t n_w
 int cc_rigk_set_intrinsics(cc_rig* h, const double* intr9, uint32_t const_mask);
 int cc_rigk_get_intrinsics(cc_rig* h, double* intr9);
 /* Same extension with one set of 9 intrinsics PER CAMERA (BASELINE.json configs[4]: "full intrinsics+extrinsics
- * co-optimisation"): shared block = 6 per optimised camera + 9 per observed camera (<= 127: eight cameras).
+ * co-optimisation"): shared block = 6 per optimised camera + 9 per observed camera (<= 255: seventeen cameras; <= 127,
+ * eight cameras, for the tuned kernels and for several GPUs).
  * cc_rigk_set_intrinsics sets every camera's set at once, cc_rigk_set_camera_intrinsics one camera's (with its own
  * constant mask, cf. Calibrator::ForceDistortionToConstant); cc_rigk_get_camera_intrinsics reads one set. */
 int cc_rigk_create_per_camera(int32_t device, int64_t n_cams, int64_t n_frames, int64_t n_world,

@@ -219,3 +219,24 @@ def test_rigk_per_camera_c5_full_size_against_the_committed_oracle_result_and_pr
     s2 = prob.solve(capi.default_options(max_iterations=200))
     prob.close()
     assert s2["iterations"] <= 2 and s2["final_cost"] <= s1["final_cost"] * (1 + 1e-9)
+
+
+def test_rigk_per_camera_with_more_than_127_shared_coordinates_matches_the_oracle():
+    """Ten cameras with a camera model of their own: 9 * 6 + 10 * 9 = 144 shared coordinates -- beyond the tuned kernels'
+    127, solved by the plain ones (cc_rig.hip, k_rig_elim_big / k_rig_solve_big)."""
+    g, o = _both_pc(rigk_case(10, 40, 30, per_camera=True))
+    _assert_same_pc(g, o)
+
+
+def test_rigk_shared_intrinsics_with_more_than_11_observed_cameras_matches_the_oracle():
+    """Fourteen cameras, one shared camera model: 13 * 6 + 9 = 87 shared coordinates, but 14 * 135 direct sums -- more than
+    the tuned elimination kernel keeps (1536); the plain kernels take over."""
+    g, o = _both(rigk_case(14, 30, 20))
+    _assert_same(g, o)
+
+
+def test_rigk_per_camera_at_the_largest_supported_size_matches_the_oracle():
+    """Seventeen cameras with a camera model of their own: 16 * 6 + 17 * 9 = 249 of at most 255 shared coordinates (reduced
+    system in global memory: its packed triangle no longer fits LDS)."""
+    g, o = _both_pc(rigk_case(17, 30, 24, per_camera=True))
+    _assert_same_pc(g, o)
