@@ -302,6 +302,31 @@ __device__ inline void quat_plus(const double* x, const double* d, double* out) 
 
 __device__ inline double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 
+// Contribution of one pose block [q(4) t(3)] with tangent gradient g = [g_rot(3) g_t(3)] to Ceres' gradient_max_norm,
+// || x - Plus(x, -g) ||_inf (TrustRegionMinimizer: the gradient tolerance is tested on the step a unit gradient descent
+// would take THROUGH the manifold). Translation: |g_t|. Quaternion: q - Plus(q, -g_rot) with Plus as in quat_plus,
+//   d_w = (1 - cos n) w - s (g.v),   d_v = (1 - cos n) v + s (w g + g x v),   n = |g_rot|, s = sin(n) / n, q = [w v],
+// evaluated with 1 - cos n as its own series (Ceres subtracts two quaternions that agree to sixteen digits when g is at
+// the tolerance; this is the same number without the cancellation). For |g_rot| >= 1/4 the block reports the tangent
+// max-norm instead: sin / cos of a "rotation" by 1e6 radians per frame and iteration is not worth a number that is only
+// ever compared with a tolerance of 1e-10 -- every decision is the same for tolerances below 0.14 (oracle: the same rule).
+__device__ inline double pose_grad_proj_max(const double* q, const double* g) {
+  const double gt = fmax(fmax(fabs(g[3]), fabs(g[4])), fabs(g[5]));
+  const double n2 = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
+  if (!(n2 < 0.0625)) return fmax(gt, fmax(fmax(fabs(g[0]), fabs(g[1])), fabs(g[2])));
+  const double c1 = n2 * (1.0 / 2 + n2 * (-1.0 / 24 + n2 * (1.0 / 720 + n2 * (-1.0 / 40320 + n2 * (1.0 / 3628800 +
+                    n2 * (-1.0 / 479001600 + n2 * (1.0 / 87178291200.0 + n2 * (-1.0 / 20922789888000.0))))))));
+  const double s = 1.0 + n2 * (-1.0 / 6 + n2 * (1.0 / 120 + n2 * (-1.0 / 5040 + n2 * (1.0 / 362880 + n2 * (-1.0 / 39916800 +
+                   n2 * (1.0 / 6227020800.0 + n2 * (-1.0 / 1307674368000.0 + n2 * (1.0 / 355687428096000.0))))))));
+  const double w = q[0], v0 = q[1], v1 = q[2], v2 = q[3];
+  const double dw = c1 * w - s * (g[0] * v0 + g[1] * v1 + g[2] * v2);
+  const double d0 = c1 * v0 + s * (w * g[0] + (g[1] * v2 - g[2] * v1));
+  const double d1 = c1 * v1 + s * (w * g[1] + (g[2] * v0 - g[0] * v2));
+  const double d2 = c1 * v2 + s * (w * g[2] + (g[0] * v1 - g[1] * v0));
+  return fmax(fmax(gt, fabs(dw)), fmax(fmax(fabs(d0), fabs(d1)), fabs(d2)));
+}
+
+
 #endif  // __HIPCC__
 
 }  // namespace cc

@@ -693,7 +693,9 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
     double gv[5];
 #pragma unroll
     for (int r = 0; r < 5; ++r) gv[r] = gsum(gi[r]);
-    const double gp = fabs(gsum((9 + l6) * 16 + 15));
+    const double gpe = gsum((9 + l6) * 16 + 15);   // entry l6 of the pose block's gradient (lanes 0..5 of the sixteen: entry l)
+    const double* qf = P.pose + ((size_t)cur * P.F + (valid ? f : 0)) * 8;
+    const double qw = qf[0], qx = qf[1], qy = qf[2], qz = qf[3];
     // column l (< 10) of [H_ps | g_p], loaded with everything else in one round trip
     const int col = l < 9 ? l : 15;
     double w[6];
@@ -784,7 +786,14 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
         for (int i = 0; i < 6; ++i) zz += Zs[g][i * 10 + zj[r]] * Zs[g][i * 10 + zk[r]];
         acc[r] += sa[r] * gv[r] * sb[r] - (use_z[r] ? zz : 0.0);
       }
-      gacc = fmax(gacc, gp);
+      {   // the frame's share of Ceres' gradient_max_norm, ||x - Plus(x, -g)||_inf (pose_grad_proj_max, cc_common.hpp)
+        const int base16 = (threadIdx.x & 63) & ~15;
+        double g6[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) g6[i] = __shfl(gpe, base16 + i, 64);
+        const double q4[4] = {qw, qx, qy, qz};
+        gacc = fmax(gacc, pose_grad_proj_max(q4, g6));
+      }
       facc += fail;
     }
     __syncthreads();

@@ -89,6 +89,24 @@ __device__ __forceinline__ void quat_plus_tab(const double* x, const double* d, 
   out[3] = a0 * x[3] + a1 * x[2] - a2 * x[1] + a3 * x[0];
 }
 
+// cc::pose_grad_proj_max (cc_common.hpp: same values, same order, same bits -- 1 - cos n is the negated Horner sum of the
+// negated coefficients) with the series read from the same table, for the same reason
+__device__ __forceinline__ double pose_grad_proj_max_tab(const double* q, const double* g) {
+  const double gt = fmax(fmax(fabs(g[3]), fabs(g[4])), fabs(g[5]));
+  const double n2 = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
+  if (!(n2 < 0.0625)) return fmax(gt, fmax(fmax(fabs(g[0]), fabs(g[1])), fabs(g[2])));
+  const double* c = kPlusCoef;
+  asm volatile("" : "+s"(c));
+  const double c1 = -(n2 * (c[0] + n2 * (c[1] + n2 * (c[2] + n2 * (c[3] + n2 * (c[4] + n2 * (c[5] + n2 * (c[6] + n2 * c[7]))))))));
+  const double s = 1.0 + n2 * (c[8] + n2 * (c[9] + n2 * (c[10] + n2 * (c[11] + n2 * (c[12] + n2 * (c[13] + n2 * (c[14] + n2 * c[15])))))));
+  const double w = q[0], v0 = q[1], v1 = q[2], v2 = q[3];
+  const double dw = c1 * w - s * (g[0] * v0 + g[1] * v1 + g[2] * v2);
+  const double d0 = c1 * v0 + s * (w * g[0] + (g[1] * v2 - g[2] * v1));
+  const double d1 = c1 * v1 + s * (w * g[1] + (g[2] * v0 - g[0] * v2));
+  const double d2 = c1 * v2 + s * (w * g[2] + (g[0] * v1 - g[1] * v0));
+  return fmax(fmax(gt, fabs(dw)), fmax(fmax(fabs(d0), fabs(d1)), fabs(d2)));
+}
+
 // 2^shift ticks of the 100 MHz wall clock (PersistDev::timeout_shift) -- a shift and a compare against zero: a 64-bit
 // literal to compare with gets hoisted into a register pair that then sits there across the sweep's main loop
 __device__ __forceinline__ bool timed_out(long long t0, int shift) { return ((wall_clock64() - t0) >> shift) != 0; }
@@ -792,8 +810,6 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
         zz_[r] = tz[o];
         accv[r] = s_wg[WG_TSA + o] * Gl[tgi[o]] * s_wg[WG_TSB + o];
       }
-      const int l6 = l < 6 ? l : l - 6 < 6 ? l - 6 : l - 12;
-      const double gp = fabs(Gl[(9 + l6) * 16 + 15]);
 #pragma unroll
       for (int r = 0; r < 5; ++r) {
         const int zj = zz_[r] & 255, zk = (zz_[r] >> 8) & 255;
@@ -803,8 +819,19 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
         const int o = l * 5 + r;
         if (o != PC_FAIL && o != PC_GMAXP) red[o] = accv[r] - ((zz_[r] >> 16) ? zz : 0.0);
       }
-      const double gmaxp = row16_max(gp);
-      if (l == 0) { red[PC_FAIL] = ok ? 0.0 : 1.0; red[PC_GMAXP] = gmaxp; }
+      if (l == 0) red[PC_FAIL] = ok ? 0.0 : 1.0;
+    }
+    // The frame's share of Ceres' gradient_max_norm, ||x - Plus(x, -g)||_inf (pose_grad_proj_max, cc_common.hpp): one lane
+    // of the team's NEXT wave -- idle here, on another SIMD -- so that the forty dependent operations run beside the
+    // elimination instead of behind it (on the elimination's own lane 0: 35.7 -> 37.4 us per iteration at configs[2]).
+    if (has_frame && (tid_e & 255) == (((team & 3) + 1) & 3) * 64) {
+      const double* Gg = s_G + (team * 2 + cur_e) * 256;
+      double q4[4], g6[6];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) q4[i] = sm[TM_POSE + cur_e * 8 + i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) g6[i] = Gg[(9 + i) * 16 + 15];
+      red[PC_GMAXP] = pose_grad_proj_max_tab(q4, g6);
     }
     __syncthreads();
     // ---- elimination row of the workgroup (teams in order)

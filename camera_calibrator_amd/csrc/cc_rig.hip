@@ -1583,6 +1583,9 @@ __global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
       double sf[6];
 #pragma unroll
       for (int i = 0; i < 6; ++i) sf[i] = P.sp[f * 8 + i];
+      // (the frame's quaternion at the point being eliminated: for the gradient norm, same round trip)
+      const double* fqp = P.pose + ((size_t)cur * P.F + f) * 8;
+      const double fq0 = fqp[0], fq1 = fqp[1], fq2 = fqp[2], fq3 = fqp[3];
       // ---- loads: frame block entries (lanes < 27, summed over the groups), column data, direct entries
       double a_e = 0.0;
       for (int j0 = 0; j0 < CO; j0 += 8) {
@@ -1683,8 +1686,10 @@ __global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
       }
       if (!ok) nfail += 1.0;
       if (fb == (int64_t)blockIdx.x * 4) ELIM_MARK(5);
-#pragma unroll
-      for (int i = 0; i < 6; ++i) gmax = fmax(gmax, fabs(A[21 + i]));
+      {   // the frame's share of Ceres' gradient_max_norm, ||x - Plus(x, -g)||_inf (pose_grad_proj_max, cc_common.hpp)
+        const double q4[4] = {fq0, fq1, fq2, fq3};
+        gmax = fmax(gmax, pose_grad_proj_max(q4, &A[21]));
+      }
       // ---- columns: z = L^-1 w, y = L^-T z
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -2082,7 +2087,19 @@ __device__ void rig_solve_block(const RigDev& P, double* smem) {
   // gradient of the accepted point: max-norm over the tangent coordinates (frames: per-rank slots)
   {
     double g = gm_r;
-    if (tid < S && !pinned) g = fmax(g, fabs(s_gs[tid]));
+    if (tid < S && !pinned) {
+      // Ceres' gradient_max_norm, ||x - Plus(x, -g)||_inf: a camera's pose block through Plus (its first coordinate's thread;
+      // pose_grad_proj_max, cc_common.hpp), every other coordinate as it is
+      const int info = P.colinfo[tid], kind = (info >> 4) & 15, comp = info & 15;
+      if (kind != 0) {
+        g = fmax(g, fabs(s_gs[tid]));
+      } else if (comp == 0) {
+        const double* qc = P.cam + ((size_t)cur * P.C + P.obs_cam[info >> 8]) * 8;
+        const double q4[4] = {qc[0], qc[1], qc[2], qc[3]};
+        const double g6[6] = {s_gs[tid], s_gs[tid + 1], s_gs[tid + 2], s_gs[tid + 3], s_gs[tid + 4], s_gs[tid + 5]};
+        g = fmax(g, pose_grad_proj_max(q4, g6));
+      }
+    }
     g = wave_max(g);
     if (lane == 0) s4[tid >> 6] = g;
   }
@@ -2625,10 +2642,9 @@ __global__ __launch_bounds__(256) void k_rig_elim_big(RigDev P) {
       }
       if (tid == 0) {
         if (!ok) s_fg[0] += 1.0;
-        double gm = s_fg[1];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) gm = fmax(gm, fabs(A[21 + i]));
-        s_fg[1] = gm;
+        const double* fqp = P.pose + ((size_t)cur * P.F + f) * 8;
+        const double q4[4] = {fqp[0], fqp[1], fqp[2], fqp[3]};
+        s_fg[1] = fmax(s_fg[1], pose_grad_proj_max(q4, &A[21]));   // Ceres' gradient_max_norm (cc_common.hpp)
       }
       if (tid < SW) {
         double w[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -2798,7 +2814,19 @@ __global__ __launch_bounds__(256) void k_rig_solve_big(RigDev P, double* Aglobal
   }
   {
     double g = gm_r;
-    if (tid < S && !pinned) g = fmax(g, fabs(s_gs[tid]));
+    if (tid < S && !pinned) {
+      // Ceres' gradient_max_norm, ||x - Plus(x, -g)||_inf: a camera's pose block through Plus (its first coordinate's thread;
+      // pose_grad_proj_max, cc_common.hpp), every other coordinate as it is
+      const int info = P.colinfo[tid], kind = (info >> 4) & 15, comp = info & 15;
+      if (kind != 0) {
+        g = fmax(g, fabs(s_gs[tid]));
+      } else if (comp == 0) {
+        const double* qc = P.cam + ((size_t)cur * P.C + P.obs_cam[info >> 8]) * 8;
+        const double q4[4] = {qc[0], qc[1], qc[2], qc[3]};
+        const double g6[6] = {s_gs[tid], s_gs[tid + 1], s_gs[tid + 2], s_gs[tid + 3], s_gs[tid + 4], s_gs[tid + 5]};
+        g = fmax(g, pose_grad_proj_max(q4, g6));
+      }
+    }
     g = wave_max(g);
     if (lane == 0) s4[tid >> 6] = g;
   }

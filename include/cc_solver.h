@@ -73,7 +73,7 @@ typedef struct cc_iteration {
   double cost_change;
   double model_cost_change;
   double relative_decrease;
-  double gradient_max_norm;
+  double gradient_max_norm;   /* Ceres': ||x - Plus(x, -g)||_inf (pose blocks with |g_rot| >= 1/4: tangent max-norm) */
   double step_norm;
   double radius;
   int32_t accepted;

@@ -76,6 +76,28 @@ void quat_plus(const double* x, const double* d, double* out) {
   out[3] = a0 * x[3] + a1 * x[2] - a2 * x[1] + a3 * x[0];
 }
 
+// Contribution of a pose block [q(4) t(3)] with tangent gradient g(6) to Ceres' gradient_max_norm,
+// || x - Plus(x, -g) ||_inf (TrustRegionMinimizer: EvaluateGradientAndJacobian / the gradient-tolerance test; Plus is
+// QuaternionManifold's, calibrator.cpp:298, extrinsics_calibrator.cpp:119,127). Written out for q - Plus(q, -g_rot) with
+// 1 - cos|g| as a series of its own (Ceres subtracts two nearly equal quaternions); blocks with |g_rot| >= 1/4 report the
+// tangent max-norm -- the HIP kernels follow the same rule (cc_common.hpp, pose_grad_proj_max), every decision is Ceres'
+// for gradient tolerances below 0.14.
+double pose_grad_proj_max(const double* q, const double* g) {
+  const double gt = std::max(std::max(std::fabs(g[3]), std::fabs(g[4])), std::fabs(g[5]));
+  const double n2 = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
+  if (!(n2 < 0.0625)) return std::max(gt, std::max(std::max(std::fabs(g[0]), std::fabs(g[1])), std::fabs(g[2])));
+  const double c1 = n2 * (1.0 / 2 + n2 * (-1.0 / 24 + n2 * (1.0 / 720 + n2 * (-1.0 / 40320 + n2 * (1.0 / 3628800 +
+                    n2 * (-1.0 / 479001600 + n2 * (1.0 / 87178291200.0 + n2 * (-1.0 / 20922789888000.0))))))));
+  const double s = 1.0 + n2 * (-1.0 / 6 + n2 * (1.0 / 120 + n2 * (-1.0 / 5040 + n2 * (1.0 / 362880 + n2 * (-1.0 / 39916800 +
+                   n2 * (1.0 / 6227020800.0 + n2 * (-1.0 / 1307674368000.0 + n2 * (1.0 / 355687428096000.0))))))));
+  const double w = q[0], v0 = q[1], v1 = q[2], v2 = q[3];
+  const double dw = c1 * w - s * (g[0] * v0 + g[1] * v1 + g[2] * v2);
+  const double d0 = c1 * v0 + s * (w * g[0] + (g[1] * v2 - g[2] * v1));
+  const double d1 = c1 * v1 + s * (w * g[1] + (g[2] * v0 - g[0] * v2));
+  const double d2 = c1 * v2 + s * (w * g[2] + (g[0] * v1 - g[1] * v0));
+  return std::max(std::max(gt, std::fabs(dw)), std::max(std::max(std::fabs(d0), std::fabs(d1)), std::fabs(d2)));
+}
+
 // ------------------------------------------------------------------------------------------
 // residual models with analytic Jacobians
 // ------------------------------------------------------------------------------------------
@@ -230,6 +252,7 @@ struct ArrowProblem {
   std::vector<uint8_t> shared_fixed;       // S: tangent coordinate not optimised
   std::vector<uint8_t> shared_amb_active;  // S_amb: parameter counts in |x| and |step|
   std::vector<uint8_t> frame_active;       // F
+  int64_t shared_pose_blocks = 0;          // leading [q t] blocks of the shared parameters (rig cameras): 7 ambient, 6 tangent each
   int num_threads = 1;
   virtual ~ArrowProblem() {}
   // Returns local cost; fills blocks if B != nullptr (all of B is overwritten).
@@ -295,10 +318,11 @@ int run_lm(ArrowProblem& P, const oc_options& o, double* shared, double* fq, dou
   auto grad_max = [&](const Blocks& b) {
     double g = 0;
     for (int64_t f = 0; f < F; ++f)
-      if (P.frame_active[f])
-        for (int i = 0; i < 6; ++i) g = std::max(g, std::fabs(b.gp[f * 6 + i]));
+      if (P.frame_active[f]) g = std::max(g, pose_grad_proj_max(&fq[f * 4], &b.gp[f * 6]));
     ar(ctx, &g, 1, 1);
-    for (int i = 0; i < S; ++i)
+    for (int64_t c = 0; c < P.shared_pose_blocks; ++c)
+      if (!P.shared_fixed[c * 6]) g = std::max(g, pose_grad_proj_max(&shared[c * 7], &b.gs[c * 6]));
+    for (int i = (int)(6 * P.shared_pose_blocks); i < S; ++i)
       if (!P.shared_fixed[i]) g = std::max(g, std::fabs(b.gs[i]));
     return g;
   };
@@ -1069,6 +1093,7 @@ static int rig_solve_impl(const oc_options* opt, int64_t C, int64_t F, const int
   if (opt) o = *opt; else { oc_options_init(&o); o.max_iterations = 1000; }
   RigProblem P;
   P.C = C; P.F = F; P.S = (int)(6 * C); P.S_amb = (int)(7 * C);
+  P.shared_pose_blocks = C;
   P.off = off; P.ocam = ocam; P.oworld = oworld; P.ouv = ouv; P.wxyz = wxyz;
   P.huber_a = huber_a;
   P.num_threads = o.num_threads;
@@ -1145,6 +1170,7 @@ int oc_rigk_solve_sets(const oc_options* opt, int64_t C, int64_t F, int64_t n_wo
   const int64_t NK = per_camera ? C : 1;
   P.NK = NK;
   P.C = C; P.F = F; P.S = (int)(6 * C + 9 * NK); P.S_amb = (int)(7 * C + 9 * NK);
+  P.shared_pose_blocks = C;
   P.off = off; P.ocam = ocam; P.oworld = oworld; P.ouv = ouv; P.wxyz = wxyz;
   P.huber_a = huber_a;
   P.kmasks.assign(kmask, kmask + NK);

@@ -218,6 +218,8 @@ def test_persistent_solve_that_cannot_get_its_grid_is_rerun_in_the_two_kernel_fo
     import os, subprocess, sys, textwrap
     if os.environ.get("CC_INTR_PERSIST") == "0":
         pytest.skip("the persistent kernel is switched off in this environment (tests/test_gpu_persist.py, two-kernel form)")
+    if os.environ.get("CC_SWEEP_TILES"):
+        pytest.skip("forced frame tiles (tests/test_gpu_tiles.py) always run the two-kernel form")
     code = textwrap.dedent("""
         import sys, time, numpy as np
         sys.path.insert(0, %r)

@@ -124,3 +124,29 @@ def test_rig_oracle_default_options_stop_near_that_fixed_point():
     dflt = _solve(sc, max_iterations=1000)
     assert dflt[5]["final_cost"] >= tight[5]["final_cost"] * (1 - 1e-12)
     assert dflt[5]["final_cost"] <= tight[5]["final_cost"] * (1 + 1e-5)
+
+
+def test_rig_oracle_reports_the_gradient_norm_ceres_reports():
+    """Ceres tests its gradient tolerance on ||x - Plus(x, -g)||_inf (TrustRegionMinimizer), not on the tangent gradient:
+    for a quaternion block that is q - Plus(q, -g_rot), four numbers instead of three. The oracle (and the kernels,
+    cc_common.hpp pose_grad_proj_max) evaluate that expression in a cancellation-free form while |g_rot| < 1/4; here it is
+    formed LITERALLY -- numerical tangent gradient of the restated objective, numpy Plus, subtraction -- at the point the
+    oracle stops at after a few iterations, and compared with what the oracle logs for that point."""
+    sc = rig_outlier_case(3, 24, 8)
+    checked = distinct = 0
+    for iters in range(2, 12):
+        cq, ct, fq, ft, _, s = _solve(sc, max_iterations=iters, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+        last = s["log"][-1]
+        if not last["accepted"] or not (1e-5 < last["gradient_max_norm"] < 0.1):
+            continue
+        tg = _Tangent(sc, cq, ct, fq, ft)
+        g = tg.grad(np.zeros(tg.n))
+        literal, tangent, k = 0.0, np.abs(g).max(), 0
+        blocks = [(cq[c], ct[c]) for c in tg.free_cams] + [(fq[f], ft[f]) for f in range(len(fq))]
+        for q, _t in blocks:
+            literal = max(literal, np.abs(q - quat_plus(q, -g[k:k + 3])).max(), np.abs(g[k + 3:k + 6]).max())
+            k += 6
+        assert np.isclose(last["gradient_max_norm"], literal, rtol=1e-5, atol=1e-9), (iters, last["gradient_max_norm"], literal, tangent)
+        checked += 1
+        distinct += abs(literal - tangent) > 2e-5 * tangent   # (a rotation block carries the maximum: the two norms differ)
+    assert checked >= 2 and distinct >= 1
