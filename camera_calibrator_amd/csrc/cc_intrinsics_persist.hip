@@ -54,9 +54,9 @@ enum { TM_Y = 0, TM_POSE = 60, TM_SP = 76, TM_STEP = 84, TM_R = 100, TM_T = 109,
        TM_QW = 124, TM_STAT = 128 /* cost, q_model, step^2, |x|^2, then nine diagonal entries (first round) */ };
 // workgroup scratch (doubles)
 enum { WG_INTR = 0 /* [2][16] */, WG_X = 64 /* the control's last broadcast: flags, radius, nine doubles */, WG_DS = 66 /* ... the step */,
-       WG_SS = 80 /* Jacobi scales of the shared block (first broadcast) */, WG_OPT = 100 /* jacobi, min / max LM diagonal, max radius */,
+       WG_SS = 80 /* scales of the shared columns as the workers see them: 1 */, WG_R0 = 96 /* initial radius */, WG_OPT = 100 /* jacobi, min / max LM diagonal, max radius */,
        WG_TAB = 104 /* pj / pk byte tables */,
-       // slot table of the elimination row (80 slots; built once per solve, when the Jacobi scales arrive): scale factors,
+       // slot table of the elimination row (80 slots; built once per solve): scale factors (1: the control scales the sums),
        // source entry of the Gram block, the two columns of Z whose product is subtracted (| 1 << 16: there is one)
        WG_TSA = 256, WG_TSB = 336, WG_TGI = 416 /* int[80] */, WG_TZ = 456 /* int[80] */ };
 
@@ -332,11 +332,12 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
       *s_ctl = c;
       s_int[1] = c.log_len != len0;
       // did the workers' assumption hold? (the same expression they evaluate: persist_spec_radius)
-      s_int[2] = !phase0 && was_valid && !c.done && (c.cur & 1) == (prev_cur ^ 1) && c.radius == persist_spec_radius(prev_radius, o.max_radius);
+      s_int[2] = phase0 ? (!c.done && c.radius == o.initial_radius)
+                        : (was_valid && !c.done && (c.cur & 1) == (prev_cur ^ 1) && c.radius == persist_spec_radius(prev_radius, o.max_radius));
       s_bc[0] = (double)((c.done ? 1 : 0) | ((c.cur & 1) << 3));
       s_bc[1] = c.radius;
 #pragma unroll
-      for (int i = 0; i < 9; ++i) s_bc[2 + i] = phase0 ? s_ss[i] : 0.0;
+      for (int i = 0; i < 9; ++i) s_bc[2 + i] = 0.0;
     }
     __syncthreads();
     PC_MARK(2);
@@ -374,6 +375,21 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
       }
       __syncthreads();
     }
+    // the workers eliminated with unit scales on the shared columns: the Jacobi scaling of the reduced system happens here
+    if (tid < 63) {
+      double f2;
+      if (tid < 45) {
+        int j = 0, rem = tid;
+        while (rem >= 9 - j) { rem -= 9 - j; ++j; }
+        f2 = s_ss[j] * s_ss[j + rem];
+      } else if (tid < 54) {
+        f2 = s_ss[tid - 45];
+      } else {
+        f2 = s_ss[tid - 54] * s_ss[tid - 54];
+      }
+      sv[tid] *= f2;
+    }
+    __syncthreads();
     PC_MARK(4);
     if (wave == 0) {
       const int cur = s_ctl->cur & 1;
@@ -417,8 +433,8 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
 #pragma unroll
         for (int j = 0; j < 9; ++j) xs = lane == j ? x[j] : xs;
         const double ds = go ? -xs : 0.0;
-        s_bc[2 + lane] = ds;
-        const double d = ((mask >> lane) & 1u) ? 0.0 : ds * s_ss[lane];
+        const double d = ((mask >> lane) & 1u) ? 0.0 : ds * s_ss[lane];   // the step in the intrinsics' own units
+        s_bc[2 + lane] = d;                                                 // (what the workers' unit-scaled Y and candidates take)
         s_intr[(cur ^ 1) * 16 + lane] = s_intr[cur * 16 + lane] + d;
       }
       if (lane == 0) {
@@ -515,15 +531,41 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
     s_wg[WG_OPT + 1] = o->min_lm_diagonal;
     s_wg[WG_OPT + 2] = o->max_lm_diagonal;
     s_wg[WG_OPT + 3] = o->max_radius;
+    s_wg[WG_R0] = o->initial_radius;
   }
   if (tid == 33) {
     int oo = 0;
     for (int j = 0; j < 9; ++j)
       for (int k = j; k < 9; ++k) { pj[oo] = (unsigned char)j; pk[oo] = (unsigned char)k; ++oo; }
   }
-  if (tid >= 64 && tid < 64 + 32) s_wg[WG_X + tid - 64] = 0.0;
+  if (tid >= 64 && tid < 64 + 16) s_wg[WG_X + tid - 64] = 0.0;
+  // The Jacobi scales of the NINE SHARED columns never reach the workers (they are sums over all frames, known to the
+  // control after the first statistics): a worker eliminates with unit scales there -- the control scales the sums it
+  // gathers, and broadcasts the step multiplied by them -- so the FIRST elimination need not wait for anything either.
+  if (tid >= 80 && tid < 80 + 16) s_wg[WG_SS + tid - 80] = 1.0;
   __syncthreads();
   if (tid < 9) s_wg[WG_INTR + tid] = (Q.restart ? P.init_intr : P.intr)[tid];
+  if (tid >= 128 && tid < 128 + kPartialCols) {   // slot o of the elimination row (layout of k_intr_decide_elim's partial row)
+    const int o = tid - 128;
+    int gi = 0, z = 0;
+    double sa = 0.0, sb = 0.0;
+    if (o < 45) {
+      const int j = pj[o], k = pk[o];
+      gi = j * 16 + k; z = j | (k << 8) | (1 << 16); sa = 1.0; sb = 1.0;
+    } else if (o < 54) {
+      const int j = o - 45;
+      gi = j * 16 + 15; z = j | (9 << 8) | (1 << 16); sa = 1.0; sb = 1.0;
+    } else if (o < 63) {
+      const int j = o - 54;
+      gi = j * 17; sa = 1.0; sb = 1.0;
+    } else if (o >= PC_GS && o < PC_GS + 9) {
+      gi = (o - PC_GS) * 16 + 15; sa = 1.0; sb = 1.0;
+    }
+    s_wg[WG_TSA + o] = sa;
+    s_wg[WG_TSB + o] = sb;
+    reinterpret_cast<int*>(s_wg + WG_TGI)[o] = gi;
+    reinterpret_cast<int*>(s_wg + WG_TZ)[o] = z;
+  }
   }
 
   int64_t s0 = 0, s1 = 0;
@@ -878,9 +920,11 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
     // Eliminating NOW, next to the control's gathering and deciding, takes a seam out of the round when it holds.
     PW_MARK(6);
     PG_MARK(1);
-    const bool spec = !phase0 && do_sweep;
-    const double radius_spec = persist_spec_radius(radius, s_wg[WG_OPT + 3]);
-    if (spec) eliminate_and_post(dst, radius_spec, false, Q.pbox, e2);
+    // (first round: the starting point is "accepted" at the initial radius unless the solve ends before it begins; its
+    // elimination also computes the frame's Jacobi scale)
+    const bool spec = do_sweep;
+    const double radius_spec = phase0 ? s_wg[WG_R0] : persist_spec_radius(radius, s_wg[WG_OPT + 3]);
+    if (spec) eliminate_and_post(dst, radius_spec, phase0, Q.pbox, e2);
     PW_MARK(7);
     wait_bcast(e2);
     PW_MARK(10);
@@ -894,35 +938,7 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
     } else {        // it did not (or there was none): eliminate with what the decision says, then wait for the step
       cur = (fl >> 3) & 1;
       radius = s_wg[WG_X + 1];
-      if (phase0) {
-        CC_FRESH_TID(tid);
-        if (tid < 9) s_wg[WG_SS + tid] = s_wg[WG_X + 2 + tid];
-        __syncthreads();
-        if (tid < kPartialCols) {   // slot `tid` of the elimination row (layout of k_intr_decide_elim's partial row)
-          const double* ss = s_wg + WG_SS;
-          const int o = tid;
-          int gi = 0, z = 0;
-          double sa = 0.0, sb = 0.0;
-          if (o < 45) {
-            const int j = pj[o], k = pk[o];
-            gi = j * 16 + k; z = j | (k << 8) | (1 << 16); sa = ss[j]; sb = ss[k];
-          } else if (o < 54) {
-            const int j = o - 45;
-            gi = j * 16 + 15; z = j | (9 << 8) | (1 << 16); sa = ss[j]; sb = 1.0;
-          } else if (o < 63) {
-            const int j = o - 54;
-            gi = j * 17; sa = ss[j] * ss[j]; sb = 1.0;
-          } else if (o >= PC_GS && o < PC_GS + 9) {
-            gi = (o - PC_GS) * 16 + 15; sa = 1.0; sb = 1.0;
-          }
-          s_wg[WG_TSA + o] = sa;
-          s_wg[WG_TSB + o] = sb;
-          reinterpret_cast<int*>(s_wg + WG_TGI)[o] = gi;
-          reinterpret_cast<int*>(s_wg + WG_TZ)[o] = z;
-        }
-        __syncthreads();
-      }
-      eliminate_and_post(cur, radius, phase0, Q.rbox, e3);
+      eliminate_and_post(cur, radius, false, Q.rbox, e3);   // (never the first round: that one always holds or ends the solve)
       wait_bcast(e3);
       PW_MARK(12);
       fl = (int)s_wg[WG_X];
