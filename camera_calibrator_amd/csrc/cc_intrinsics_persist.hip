@@ -56,9 +56,9 @@ enum { TM_Y = 0, TM_POSE = 60, TM_SP = 76, TM_STEP = 84, TM_R = 100, TM_T = 109,
 enum { WG_INTR = 0 /* [2][16] */, WG_X = 64 /* the control's last broadcast: flags, radius, nine doubles */, WG_DS = 66 /* ... the step */,
        WG_SS = 80 /* scales of the shared columns as the workers see them: 1 */, WG_R0 = 96 /* initial radius */, WG_OPT = 100 /* jacobi, min / max LM diagonal, max radius */,
        WG_TAB = 104 /* pj / pk byte tables */,
-       // slot table of the elimination row (80 slots; built once per solve): scale factors (1: the control scales the sums),
+       // slot table of the elimination row (80 slots; built once per solve; no scale factors: the control scales the sums):
        // source entry of the Gram block, the two columns of Z whose product is subtracted (| 1 << 16: there is one)
-       WG_TSA = 256, WG_TSB = 336, WG_TGI = 416 /* int[80] */, WG_TZ = 456 /* int[80] */ };
+       WG_TGI = 416 /* int[80] */, WG_TZ = 456 /* int[80] */ };
 
 // ceres::QuaternionManifold::Plus with the series coefficients of cc::quat_plus (cc_common.hpp: same values, same
 // Horner order, same bits) read from constant memory through a pointer the compiler cannot see through: written as
@@ -548,21 +548,18 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
   if (tid >= 128 && tid < 128 + kPartialCols) {   // slot o of the elimination row (layout of k_intr_decide_elim's partial row)
     const int o = tid - 128;
     int gi = 0, z = 0;
-    double sa = 0.0, sb = 0.0;
     if (o < 45) {
       const int j = pj[o], k = pk[o];
-      gi = j * 16 + k; z = j | (k << 8) | (1 << 16); sa = 1.0; sb = 1.0;
+      gi = j * 16 + k; z = j | (k << 8) | (1 << 16);
     } else if (o < 54) {
       const int j = o - 45;
-      gi = j * 16 + 15; z = j | (9 << 8) | (1 << 16); sa = 1.0; sb = 1.0;
+      gi = j * 16 + 15; z = j | (9 << 8) | (1 << 16);
     } else if (o < 63) {
       const int j = o - 54;
-      gi = j * 17; sa = 1.0; sb = 1.0;
+      gi = j * 17;
     } else if (o >= PC_GS && o < PC_GS + 9) {
-      gi = (o - PC_GS) * 16 + 15; sa = 1.0; sb = 1.0;
+      gi = (o - PC_GS) * 16 + 15;
     }
-    s_wg[WG_TSA + o] = sa;
-    s_wg[WG_TSB + o] = sb;
     reinterpret_cast<int*>(s_wg + WG_TGI)[o] = gi;
     reinterpret_cast<int*>(s_wg + WG_TZ)[o] = z;
   }
@@ -839,29 +836,35 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
         }
       }
       PW_MARK(14);
-      wave_lds_fence();   // (the sixteen lanes are one wave: its LDS operations execute in order)
-      // output slots l * 5 + r of this lane, from the slot table: five independent lookups, no branches (written out per
-      // slot kind, every branch ended in a wait for its own LDS reads)
+      if (l == 0) red[PC_FAIL] = ok ? 0.0 : 1.0;
+    }
+    // ---- the frame's elimination row: slot o of eighty on lane o mod 64 of the SAME wave (its LDS operations execute in
+    // order: a fence for the compiler, no barrier) -- two slots per lane instead of the five each of the sixteen
+    // elimination lanes built. Slot table: source entry of the Gram block, the two columns of Z whose product is subtracted.
+    if (has_frame && (tid_e & 255) >= sbase && (tid_e & 255) < sbase + 64) {
+      const int l64 = (tid_e & 255) - sbase;
+      const double* Gl = s_G + (team * 2 + cur_e) * 256;
+      wave_lds_fence();
       const int* tgi = reinterpret_cast<const int*>(s_wg + WG_TGI);
       const int* tz = reinterpret_cast<const int*>(s_wg + WG_TZ);
-      double accv[5];
-      int zz_[5];
+      double accv[2];
+      int zz_[2];
 #pragma unroll
-      for (int r = 0; r < 5; ++r) {
-        const int o = l * 5 + r;
-        zz_[r] = tz[o];
-        accv[r] = s_wg[WG_TSA + o] * Gl[tgi[o]] * s_wg[WG_TSB + o];
+      for (int r = 0; r < 2; ++r) {
+        const int o = l64 + 64 * r, oc = o < kPartialCols ? o : 0;
+        zz_[r] = tz[oc];
+        accv[r] = Gl[tgi[oc]];
       }
 #pragma unroll
-      for (int r = 0; r < 5; ++r) {
+      for (int r = 0; r < 2; ++r) {
         const int zj = zz_[r] & 255, zk = (zz_[r] >> 8) & 255;
         double zz = 0.0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) zz += Zs[i * 10 + zj] * Zs[i * 10 + zk];
-        const int o = l * 5 + r;
-        if (o != PC_FAIL && o != PC_GMAXP) red[o] = accv[r] - ((zz_[r] >> 16) ? zz : 0.0);
+        const int o = l64 + 64 * r;
+        const bool used = o < 63 || (o >= PC_GS && o < PC_GS + 9);   // (63: failures, 73: gradient maximum -- written elsewhere)
+        if (o < kPartialCols && o != PC_FAIL && o != PC_GMAXP) red[o] = used ? accv[r] - ((zz_[r] >> 16) ? zz : 0.0) : 0.0;
       }
-      if (l == 0) red[PC_FAIL] = ok ? 0.0 : 1.0;
     }
     // The frame's share of Ceres' gradient_max_norm, ||x - Plus(x, -g)||_inf (pose_grad_proj_max, cc_common.hpp): one lane
     // of the team's NEXT wave -- idle here, on another SIMD -- so that the forty dependent operations run beside the
