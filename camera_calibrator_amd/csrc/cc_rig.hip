@@ -2514,17 +2514,19 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P, int publish) {
 }
 
 // =============================================================================================
-// LARGE reduced systems (128 <= S <= 255: more than 21 optimised cameras, or more than 8 with intrinsics of their own;
-// the reference takes any number of cameras, extrinsics_calibrator.cpp:9-17). The kernels above are built around
+// LARGE reduced systems (128 <= S <= 255: more than 21 optimised cameras, or more than 8 with intrinsics of their own --
+// or more direct sums than k_rig_elim keeps, 12+ observed cameras with intrinsics; the reference takes any number of
+// cameras, extrinsics_calibrator.cpp:9-17). The kernels above are built around
 // S + 1 <= 128 (two shared columns per lane, nine tile accumulators per wave, the reduced system in LDS with a row stride);
 // rather than bend them, such problems run the same arithmetic in a plainer form -- correctness first, no tuning:
 //   k_rig_elim_big : one block per frame at a time, thread k owns shared column k (S + 1 <= 256); the 6 x 6 factor is
 //                    computed by every thread; Schur products Z^T Z accumulated per 16 x 16 tile with plain FMAs, entry
 //                    `tid` of every tile in a register (<= 136 tiles); the direct sums in LDS. Same partial-row layout.
 //   k_rig_reduce<2>: the column sums (unchanged) -> P.vec
-//   k_rig_solve_big: one block; the reduced system as a PACKED lower triangle in LDS (S <= 190) or with its row stride in
-//                    global memory; left-looking Cholesky, thread i owns row i, two barriers per column; column-oriented
-//                    substitutions; the tests, candidates and control block of rig_solve_block.
+//   k_rig_solve_big: one block; the reduced system as a lower triangle packed by rows in LDS (S <= 193) or column-major
+//                    in global memory, the right-hand side as row S; left-looking Cholesky, thread i owns row i, sixteen
+//                    columns of both rows per round trip, two barriers per column; backward substitution with one
+//                    barrier per step; the tests, candidates and control block of rig_solve_block.
 //   k_rig_update   : unchanged.
 // Sweep, init, records, statistics: unchanged (their shared-column arrays hold 256 entries).
 // =============================================================================================
@@ -2544,7 +2546,7 @@ __global__ __launch_bounds__(256) void k_rig_elim_big(RigDev P) {
   __shared__ double s_fg[8];
   __shared__ int s_g[64];
   __shared__ LmCtl s_ctl;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const LmCtl* ctl = P.ctl;
   if (ctl->done || ctl->phase == 0) return;
   // ---- trust-region decision: every block, same answer; block 0 publishes it (as in k_rig_elim)
@@ -2723,7 +2725,6 @@ __global__ __launch_bounds__(256) void k_rig_elim_big(RigDev P) {
       if (b < T) prow[(size_t)(a * T - a * (a - 1) / 2 + (b - a)) * 256 + tid] = acc[big_tile(a, b)];
   for (int e = tid; e < P.ND; e += 256) prow[P.pc_dir + e] = s_d[e];
   if (tid == 0) { prow[P.pc_fail] = s_fg[0]; prow[P.pc_gmax] = s_fg[1]; }
-  (void)lane; (void)wave;
 }
 
 // accessor of the reduced system's lower triangle (rows 0..S, row S = right-hand side; S columns). In LDS: packed by
