@@ -81,7 +81,7 @@ EXPORTED_SYMBOLS = [
     "cc_intrinsics_solve", "cc_intrinsics_solver_form", "cc_intrinsics_profile_sweep", "cc_intrinsics_profile_solve", "cc_intrinsics_optimize", "cc_intrinsics_estimate", "cc_comm_get_unique_id",
     "cc_intrinsics_comm_init", "cc_intrinsics_exchange_export", "cc_intrinsics_exchange_attach", "cc_partition_frames", "cc_distort", "cc_undistort",
     "cc_rig_create", "cc_rig_destroy", "cc_rig_set_state", "cc_rig_reset", "cc_rig_solve",
-    "cc_rig_get_state", "cc_rig_eval", "cc_rig_optimize", "cc_rig_comm_init", "cc_rig_exchange_export", "cc_rig_exchange_attach", "cc_rigk_create",
+    "cc_rig_get_state", "cc_rig_solver_form", "cc_rig_eval", "cc_rig_optimize", "cc_rig_comm_init", "cc_rig_exchange_export", "cc_rig_exchange_attach", "cc_rigk_create",
     "cc_rigk_set_intrinsics", "cc_rigk_get_intrinsics", "cc_rigk_create_per_camera", "cc_rigk_set_camera_intrinsics",
     "cc_rigk_get_camera_intrinsics", "cc_zhang_init", "cc_intrinsics_optimize_multi", "cc_rig_optimize_multi",
 ]
@@ -403,6 +403,10 @@ class RigProblem:
         _check(lib().cc_rig_get_state(self._h, _p(cq, C.c_double), _p(ct, C.c_double), _p(fq, C.c_double),
                                       _p(ft, C.c_double), _p(cost, C.c_double) if want_cost else None))
         return cq, ct, fq, ft, cost
+
+    def solver_form(self):
+        """1: the whole solve as one persistent kernel launch; 0: three kernels per LM iteration."""
+        return int(lib().cc_rig_solver_form(self._h))
 
     def eval(self):
         c = C.c_double()

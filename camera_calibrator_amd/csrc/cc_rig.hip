@@ -34,6 +34,7 @@
 
 #include "cc_common.hpp"
 #include "cc_device.hpp"
+#include "cc_persist_dev.hpp"
 
 namespace cc {
 
@@ -605,24 +606,27 @@ __device__ __forceinline__ void reduce_scatter32(double* p, int lane) {
 #ifndef CC_RIG_ADJ_WAVES
 #define CC_RIG_ADJ_WAVES 4   // waves per SIMD this sweep is compiled for (A/B knob)
 #endif
-template <int NW>
-__global__ __launch_bounds__(NW * 64, NW == 1 ? CC_RIG_ADJ_WAVES : 3) void k_rig_sweep_adj(RigDev P) {   // (NW > 1: few, large groups -- registers rather than residency)
+// The sweep of one group as a function: k_rig_sweep_adj (one workgroup per group) and the persistent per-solve kernel
+// (k_rig_persist: WL -- "wave-local": the caller is ONE wave of a larger workgroup sweeping the groups of its frame one
+// after the other, so there is no workgroup barrier in here, the scratch `lds` is the wave's own, and the camera records
+// come from `camrec` -- there: the copy the control workgroup broadcast, in LDS).
+constexpr int kRigSweepAdjLds(int NW) { return 64 + 64 + 8 + NW * 32 + 32 + 36; }   // doubles of scratch
+template <int NW, bool WL>
+__device__ __forceinline__ void rig_sweep_adj_body(const RigDev& P, const int64_t g, const int phase, const int cur, double* lds, const double* camrec) {
   constexpr int NT = NW * 64;      // threads
-  __shared__ double sm[64];            // camera record [0..31], frame record [32..63]
-  __shared__ double s_old[64];         // the accepted point's compact record of this group (gcomp)
-  __shared__ double s_e[8];            // step of the seven columns: e = dc + M_old df, 1
-  __shared__ double s_red[NW * 32];    // per wave: 28 Gram sums, cost, model-cost term
-  __shared__ double s_g[32];           // their totals
-  __shared__ double s_m[36];           // M
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t g = blockIdx.x;
+  double* sm = lds;                    // [64] camera record [0..31], frame record [32..63]
+  double* s_old = sm + 64;             // [64] the accepted point's compact record of this group (gcomp)
+  double* s_e = s_old + 64;            // [8]  step of the seven columns: e = dc + M_old df, 1
+  double* s_red = s_e + 8;             // [NW * 32] per wave: 28 Gram sums, cost, model-cost term
+  double* s_g = s_red + NW * 32;       // [32] their totals
+  double* s_m = s_g + 32;              // [36] M
+  auto sync = [] { if (WL) wave_lds_fence(); else __syncthreads(); };
+  int tid_ = WL ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+  if (WL) asm volatile("" : "+v"(tid_));   // (a fresh copy per call: nothing derived from it is hoisted out of the persistent kernel's round loop)
+  const int tid = tid_, lane = tid & 63, wave = tid >> 6;
   RSW_MARK(0);
   const int f = P.gframe[g], c = P.gcam[g];
   const int64_t s0 = P.goff[g], s1 = P.goff[g + 1];
-  const LmCtl* ctl = P.ctl;
-  const int done = ctl->done, phase = ctl->phase, step_valid = ctl->step_valid, cur = ctl->cur;
-  if (done) return;
-  if (phase != 0 && !step_valid) return;
   const int dst = phase == 0 ? cur : (cur ^ 1);
   const bool fixed = P.cam_fixed[c] != 0;
   // chunks dealt to the waves starting at wave (g mod NW), observations fetched one pass ahead by unconditional loads:
@@ -652,12 +656,12 @@ __global__ __launch_bounds__(NW * 64, NW == 1 ? CC_RIG_ADJ_WAVES : 3) void k_rig
   fetch(otid + NT, ob);
   if (tid < 64) {
     // (both buffers hold valid memory: the record of `cur` is read whatever the phase, used only behind phase != 0)
-    const double rec = tid < 32 ? P.camrec[c * 32 + tid] : P.frec[(size_t)f * 32 + (tid - 32)];
+    const double rec = tid < 32 ? camrec[c * 32 + tid] : P.frec[(size_t)f * 32 + (tid - 32)];
     const double old = P.gcomp[((size_t)cur * P.NG + g) * 64 + tid];
     sm[tid] = rec;
     s_old[tid] = old;
   }
-  __syncthreads();
+  sync();
   RSW_MARK(1);
   double acc[32];
 #pragma unroll
@@ -666,7 +670,7 @@ __global__ __launch_bounds__(NW * 64, NW == 1 ? CC_RIG_ADJ_WAVES : 3) void k_rig
   // the rotated world point is not needed on its own). Uniform addresses: scalar loads, the values live in SGPRs.
   double Rca[9], tca[3], tcs[3];
   {
-    const double* cr = P.camrec + (size_t)c * 32;
+    const double* cr = camrec + (size_t)c * 32;
     const double* fr = P.frec + (size_t)f * 32;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -755,7 +759,7 @@ __global__ __launch_bounds__(NW * 64, NW == 1 ? CC_RIG_ADJ_WAVES : 3) void k_rig
   const int ve = lane >> 1;
   if (NW > 1) {
     if ((lane & 1) == 0) s_red[wave * 32 + ve] = acc[0];
-    __syncthreads();
+    sync();
     if (tid < 32) {
       double t = s_red[tid];
 #pragma unroll
@@ -765,7 +769,7 @@ __global__ __launch_bounds__(NW * 64, NW == 1 ? CC_RIG_ADJ_WAVES : 3) void k_rig
   } else if ((lane & 1) == 0) {
     s_g[ve] = acc[0];
   }
-  __syncthreads();
+  sync();
   if (wave != 0) return;
   // The block the other kernels read, [cam frame r]^2 in a 16 x 16 tile, is N^T G7 N with N (7 x 13) = [I6 M 0; 0 0 1]
   // (the identity zeroed for a fixed camera): two matrix products, T = G7 N and N^T T. The first product's result rows
@@ -804,6 +808,16 @@ __global__ __launch_bounds__(NW * 64, NW == 1 ? CC_RIG_ADJ_WAVES : 3) void k_rig
     P.gstats[g * 2 + 1] = s_g[29];
   }
   RSW_MARK(5);
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 1 ? CC_RIG_ADJ_WAVES : 3) void k_rig_sweep_adj(RigDev P) {   // (NW > 1: few, large groups -- registers rather than residency)
+  __shared__ double s_lds[kRigSweepAdjLds(NW)];
+  const LmCtl* ctl = P.ctl;
+  const int done = ctl->done, phase = ctl->phase, step_valid = ctl->step_valid, cur = ctl->cur;
+  if (done) return;
+  if (phase != 0 && !step_valid) return;
+  rig_sweep_adj_body<NW, false>(P, blockIdx.x, phase, cur, s_lds, P.camrec);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1054,9 +1068,8 @@ struct RigUpdPre {
   double y[2][6], p0[7], p1[7], sp[6];
   int g0, g1;
 };
-__device__ __forceinline__ void rig_update_prefetch(const RigDev& P, int64_t fblk, RigUpdPre& x) {
+__device__ __forceinline__ void rig_update_prefetch(const RigDev& P, int64_t f, RigUpdPre& x) {   // f: frame of this thread's sixteen lanes
   const int tid = threadIdx.x, l = tid & 15;
-  const int64_t f = fblk * 16 + (tid >> 4);
   const int64_t fc = f < P.F ? f : 0;
   const double* Yf = P.Y + (size_t)fc * 6 * P.SW;
 #pragma unroll
@@ -1073,10 +1086,12 @@ __device__ __forceinline__ void rig_update_prefetch(const RigDev& P, int64_t fbl
 }
 
 template <bool SC1, bool PRE = false>
-__device__ __forceinline__ void rig_update_body(const RigDev& P, int phase, int cur, int64_t fblk, const RigUpdPre& pre) {
+// f: frame of this thread's sixteen lanes; ds_lds: the shared step in LDS (persistent kernel), else read from P.ds
+__device__ __forceinline__ void rig_update_body(const RigDev& P, int phase, int cur, int64_t f, const RigUpdPre& pre, const double* ds_lds = nullptr) {
   const int dst = phase == 0 ? cur : (cur ^ 1);
-  const int tid = threadIdx.x, l = tid & 15;
-  const int64_t f = fblk * 16 + (tid >> 4);
+  int tid_ = threadIdx.x;
+  if (ds_lds) asm volatile("" : "+v"(tid_));
+  const int tid = tid_, l = tid & 15;
   const bool valid = f < P.F;
   const int64_t fc = valid ? f : 0;
   double u[6] = {0, 0, 0, 0, 0, 0};
@@ -1098,7 +1113,8 @@ __device__ __forceinline__ void rig_update_body(const RigDev& P, int phase, int 
     for (int k = l; k < P.SW; k += 16) {
       double d = 1.0;
       if (k < P.S)
-        d = SC1 ? __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(P.ds) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        d = ds_lds ? ds_lds[k]
+          : SC1 ? __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(P.ds) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
                 : P.ds[k];
 #pragma unroll
       for (int i = 0; i < 6; ++i) u[i] += Yf[i * P.SW + k] * d;
@@ -1167,7 +1183,7 @@ __global__ __launch_bounds__(256) void k_rig_update(RigDev P) {
   const int phase = ctl->phase;
   if (phase != 0 && !ctl->step_valid) return;
   RigUpdPre none;   // (unused: PRE = false)
-  rig_update_body<false, false>(P, phase, ctl->cur, blockIdx.x, none);
+  rig_update_body<false, false>(P, phase, ctl->cur, (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4), none);
 }
 
 // deterministic block-wide sum of one value per thread (256 threads); result valid for thread 0
@@ -1442,9 +1458,12 @@ __global__ __launch_bounds__(256) void k_rig_init(RigDev P) {
 
 // NR = direct-sum accumulators per lane: 8 covers ND <= 512 (the usual rigs: <= 18 observed cameras with poses only, 3 with
 // intrinsics), 24 the full range; the small variant exists because the kernel sits at the register limit.
-template <bool HK, int NR>
-__global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+// The elimination as a function: k_rig_elim (a launch of its own: trust-region decision, then the elimination) and the
+// persistent per-solve kernel (PS: the decision is the control workgroup's -- which buffer holds the point to eliminate,
+// the radius, whether this is the first elimination, and the Jacobi scales of the shared columns come as arguments).
+template <bool HK, int NR, bool PS>
+__device__ __forceinline__ void rig_elim_body(const RigDev& P, char* smem_raw, const int ps_cur, const double ps_radius, const bool ps_first,
+                                              const double* ps_ss) {
   double* s_Z = reinterpret_cast<double*>(smem_raw);         // [24][ZS] staged Z rows of the four frames
   double* s_A = s_Z + 24 * P.ZS;                             // [4][32] frame block broadcast, per wave
   double* s_red = s_A + 4 * 32;                              // [4][1024] cross-wave reduction scratch
@@ -1457,21 +1476,25 @@ __global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
   __shared__ double s_tot[4];
   __shared__ double s_fg[8];
   __shared__ LmCtl s_ctl;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int tid_ = threadIdx.x;
+  if (PS) asm volatile("" : "+v"(tid_));   // (a fresh copy per call: the lane tables below are rebuilt every round of the persistent kernel instead of
+                                              //  being hoisted out of its round loop and kept -- spilled -- across the sweep)
+  const int tid = tid_, lane = tid & 63, wave = tid >> 6;
   const LmCtl* ctl = P.ctl;
 #ifdef CC_RIG_TIMING
   const long long tm0 = wall_clock64();
 #endif
-  const int ctl_done = ctl->done, ctl_phase = ctl->phase;
+  const int ctl_done = PS ? 0 : ctl->done, ctl_phase = PS ? 1 : ctl->phase;
   // what thread 0 needs for the trust-region decision, fetched now instead of behind the statistics barrier
-  const LmCtl c_in = *ctl;
-  const LmOpts o_in = *P.opts;
-  const double sh0 = P.shared_stats[0], sh1 = P.shared_stats[1];
+  LmCtl c_in;
+  LmOpts o_in;
+  double sh0 = 0.0, sh1 = 0.0;
+  if constexpr (!PS) { c_in = *ctl; o_in = *P.opts; sh0 = P.shared_stats[0]; sh1 = P.shared_stats[1]; }
   // ---- loads that do not depend on the trust-region decision go out first, under the statistics round trip: the
   // lane's static tables and the group slots of the block's first four frames
   const int CO = P.CO;
-  const int64_t f_first = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int gj_first = (f_first < P.F && (int)(threadIdx.x & 63) < CO) ? P.fslot[f_first * CO + (threadIdx.x & 63)] : -1;
+  const int64_t f_first = (int64_t)blockIdx.x * 4 + wave;
+  const int gj_first = (f_first < P.F && lane < CO) ? P.fslot[f_first * CO + lane] : -1;
   // static (frame-independent) description of what this lane owns
   // frame-block entry of lane e < 27 (offset inside a group's AA tile); lanes holding a diagonal entry also
   // store the frame's Jacobi scale in the first elimination
@@ -1517,7 +1540,9 @@ __global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
 #ifdef CC_RIG_TIMING
   const long long tm1 = wall_clock64();
 #endif
-  const bool pending = ctl->cand_pending != 0;
+  bool pending = false;
+  if constexpr (!PS) {
+  pending = ctl->cand_pending != 0;
   if (P.comm) {
     if (tid < 4) s_tot[tid] = P.vec_stats[tid];
     __syncthreads();
@@ -1538,17 +1563,18 @@ __global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
     s_ctl = c;
     if (blockIdx.x == 0) *P.ctl_next = c;
   }
-  if (tid < P.S) s_ss[tid] = P.ss[tid];
+  }   // (!PS)
+  if (tid < P.S) s_ss[tid] = (PS ? ps_ss : P.ss)[tid];
   for (int i = tid; i < 24 * P.ZS; i += 256) s_Z[i] = 0.0;   // padding columns stay zero
   __syncthreads();
 #ifdef CC_RIG_TIMING
   const long long tm2 = wall_clock64();
 #endif
-  if (s_ctl.done) return;
-  const int cur = s_ctl.cur;
-  const double inv_radius = 1.0 / s_ctl.radius;
+  if (!PS && s_ctl.done) return;
+  const int cur = PS ? ps_cur : s_ctl.cur;
+  const double inv_radius = 1.0 / (PS ? ps_radius : s_ctl.radius);
   const double mn = P.opts->min_lm_diagonal, mx = P.opts->max_lm_diagonal;
-  const bool first_elim = ctl->phase == 1 && s_ctl.iter == 0 && !pending;   // Jacobi scale of the frame blocks
+  const bool first_elim = PS ? ps_first : (ctl->phase == 1 && s_ctl.iter == 0 && !pending);   // Jacobi scale of the frame blocks
   const bool jac = P.opts->jacobi_scaling != 0;
   const int SW = P.SW, S = P.S, ZS = P.ZS;
   const size_t gs = (size_t)P.gstride;
@@ -1784,6 +1810,12 @@ __global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
   ELIM_MARK(9);
 }
 
+template <bool HK, int NR>
+__global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  rig_elim_body<HK, NR, false>(P, smem_raw, 0, 1.0, false, nullptr);
+}
+
 // ---------------------------------------------------------------------------------------------
 // The solve step, run by ONE block of 256 threads on the reduced sums (vec: [nT tiles | direct | fail | 0],
 // then one max-gradient slot per rank): assembles the damped reduced system in LDS (lower triangle), dense
@@ -1989,7 +2021,7 @@ __device__ __forceinline__ void chol_backward(const double* A, int S, int LD, do
 #endif
 
 template <int SRC>
-__device__ void rig_solve_block(const RigDev& P, double* smem) {
+__device__ void rig_solve_block(const RigDev& P, double* smem, const LmCtl* cn_in = nullptr) {   // cn_in: the persistent kernel's control block (LDS)
   const int S = P.S, LD = (S + 1) | 1;   // odd row stride: a column walks all LDS banks
   double* A = smem;                       // [S][LD] lower triangle of the reduced system
   double* s_b = A + (size_t)S * LD;       // [128] right-hand side, then the solution x
@@ -2002,7 +2034,7 @@ __device__ void rig_solve_block(const RigDev& P, double* smem) {
   __shared__ double s8[8];
   __shared__ LmCtl s_c;
   const int tid = threadIdx.x, lane = tid & 63;
-  const LmCtl* cn = P.ctl_next;
+  const LmCtl* cn = cn_in ? cn_in : P.ctl_next;
   const int cur = cn->cur, dst = cur ^ 1;
   const double radius = cn->radius;
   const LmOpts o = *P.opts;
@@ -2464,7 +2496,7 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P, int publish) {
   // waits (or solves): behind the flag only the shared step is still to be read
   RigUpdPre pre;
   const bool use_pre = P.SW <= 32 && (int64_t)blockIdx.x * 16 < P.F;
-  rig_update_prefetch(P, blockIdx.x, pre);   // (unconditional: loads inside an `if` would be waited for at its end)
+  rig_update_prefetch(P, (int64_t)blockIdx.x * 16 + (tid >> 4), pre);   // (unconditional: loads inside an `if` would be waited for at its end)
   if (s_last) {
     if (tid == 0) __hip_atomic_store(P.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
 #ifdef CC_RIG_TIMING
@@ -2504,9 +2536,9 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P, int publish) {
   const unsigned flag = s_flag;
   if ((flag & 4u) || !(flag & 2u)) return;   // done, or no valid step: the poses stay
   const int cur = (int)(flag & 1u);
-  if (use_pre) rig_update_body<true, true>(P, 1, cur, blockIdx.x, pre);
+  if (use_pre) rig_update_body<true, true>(P, 1, cur, (int64_t)blockIdx.x * 16 + (tid >> 4), pre);
   for (int64_t fblk = use_pre ? (int64_t)blockIdx.x + gridDim.x : (int64_t)blockIdx.x; fblk * 16 < P.F; fblk += gridDim.x)
-    rig_update_body<true, false>(P, 1, cur, fblk, pre);
+    rig_update_body<true, false>(P, 1, cur, fblk * 16 + (tid >> 4), pre);
 #ifdef CC_RIG_TIMING
   __syncthreads();
   if (threadIdx.x == 0 && s_last) P.shared_stats[15] = (double)wall_clock64();   // mark 7 (written this way: RIG_MARK(7) inside `if (s_last)` trips a register-class bug of the compiler)
@@ -2940,6 +2972,417 @@ __global__ __launch_bounds__(256) void k_rig_solve_big(RigDev P, double* Aglobal
   }
 }
 
+// =============================================================================================
+// THE RIG SOLVE AS ONE PERSISTENT KERNEL (round 3; poses only, single GPU, at most four frames per compute unit).
+// AN EXPERIMENT, OFF BY DEFAULT (CC_RIG_PERSIST=1): correct -- both rig test suites pass on it -- and SLOWER than the three
+// kernels it replaces: 81 against 47 us per iteration at BASELINE configs[3] size, 66 against 43 for a 2 x 1000 x 4 rig
+// (profiles/r03/rig_persist_marks.jsonl). The bodies it is glued from need up to 444 registers per thread, so a compute unit
+// holds ONE wave per SIMD: the sweep of a frame's groups runs one after the other with every memory round trip exposed
+// (25.6 us where the stand-alone sweep, sixteen waves deep, takes 9), and pose update, elimination and solve step each run
+// 1.3 - 2 x slower for the same reason. What the launch boundaries cost (~19 us) is won back only by a kernel whose per-frame
+// state lives in LDS and whose bodies fit 128 registers, as cc_intrinsics_persist.hip does; the seams, the control
+// workgroup and the host side below are what that kernel will reuse.
+// Three launches per LM iteration cost this path ~19 of its ~47 us at BASELINE configs[3] (ramp of a launch, dependent
+// read of the control block, the gap; profiles/r03/rig_c4_kernel_stats.csv): here ONE launch runs the whole solve, built
+// from the very functions the three kernels run (rig_update_body, rig_sweep_adj_body, rig_elim_body, rig_solve_block,
+// rig_candidates), with the seams of cc_intrinsics_persist.hip between them (cc_persist_dev.hpp: self-validating words,
+// no atomics, no flags, bounded waits).
+//   grid    : G = ceil(F / 4) worker workgroups + 1 control workgroup, 256 threads each, all resident (host: occupancy).
+//   worker b: frames 4b .. 4b + 3, one wave each, for the whole solve. Round: [broadcast B: step + camera records] ->
+//             pose update of its frames -> sweep of their groups (one wave: the groups of its frame one after the other)
+//             -> statistics row -> [broadcast A: decision] -> elimination of its four frames -> partial row, compacted
+//             to the K entries the reduced system uses -> posts it; then adds up ITS share of the K columns over all G
+//             rows (column c belongs to worker c mod G: every worker reads G x K / G words -- the column sums of
+//             k_rig_reduce, spread over the workers) and posts the sums.
+//   control : owns the trust-region state. Gathers the statistics rows -> decision (first round: Jacobi scales of the
+//             shared columns, |x|, lm_init -- what k_rig_init does) -> broadcast A; gathers the K column sums ->
+//             reduced solve, candidates, records (rig_solve_block, unchanged) -> broadcast B.
+// What a workgroup writes to global memory for its own later use (poses, frame records, group blocks, Y, partial row)
+// it reads back itself: plain stores and loads on one compute unit. Sums over rows run in a fixed order.
+// A wait that gives up sets the failure word (arrive[3]): nothing further happens, the host returns CC_ERR_COMM and the
+// handle goes back to the three-kernel form.
+// =============================================================================================
+struct RigPersistDev {
+  u64* sbox;            // [G][KS][2]  statistics rows: cost, model term, step^2, |x|^2, S diagonal sums (first round)
+  u64* abox;            // [2 + S][2]  broadcast A: flags (1 done | cur << 3), radius, Jacobi scales of the shared columns (first round)
+  u64* rbox;            // [G][K][2]   elimination rows (compacted)
+  u64* cbox;            // [K][2]      column sums
+  u64* ybox;            // [NB][2]     broadcast B: flags (1 done | 2 step valid | cur << 3), radius, step[S], camera records [C][32]
+  const int32_t* comp;  // [K] entry of the partial-row layout behind compact index k (the last two: failures, gradient maximum)
+  int32_t G, K, KS, NB;
+  unsigned epoch0;      // tags: epoch0 + round + 1 (boxes are zeroed when they would wrap)
+  int32_t max_rounds, timeout_shift;
+};
+
+constexpr int kRigPersistMaxS = 48;     // shared coordinates (8 optimised cameras)
+constexpr int kRigPersistMaxC = 9;      // cameras (records travel in broadcast B)
+constexpr int kRigPersistMaxNB = 2 + kRigPersistMaxS + 32 * kRigPersistMaxC;
+
+// One wave waits until the n doubles of a broadcast box carry `tag` and leaves them in dst[0..n) (LDS). false: gave up.
+__device__ __forceinline__ bool rig_bcast_wait(const u64* box, unsigned tag, int n, double* dst, unsigned* fail, int tshift) {
+  const int lane = threadIdx.x & 63;
+  constexpr int W = (2 * kRigPersistMaxNB + 63) / 64;
+  const long long t0 = wall_clock64();
+  u64 v[W];
+  for (unsigned spins = 0;; ++spins) {
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const int w = lane + 64 * j;
+      if (64 * j < 2 * n) {   // (uniform)
+        v[j] = ag_ld(box + (w < 2 * n ? w : 0));
+        ok = ok && (w >= 2 * n || (unsigned)(v[j] >> 32) == tag);
+      }
+    }
+    if (__all(ok)) break;
+    if ((spins & 63u) == 63u && (timed_out(t0, tshift) || ag_ld32(fail) != 0u)) {
+      if (lane == 0) __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    const int w = lane + 64 * j;
+    if (w < 2 * n) reinterpret_cast<unsigned*>(dst)[w] = (unsigned)v[j];   // word 2i = low half of double i
+  }
+  return true;
+}
+
+// All 256 threads: thread t (< G) waits for entry `col` of row t (NC columns per row, up to NB columns in one round trip),
+// then the block adds the G values in a fixed order (maximum for is_max). out[j] valid for every thread after return.
+template <int NB>
+__device__ __forceinline__ bool rig_gather_cols(const u64* box, int G, int rowlen, const int* cols, int ncols, int maxcol, unsigned tag, double* s4, double* out,
+                                                unsigned* fail, int tshift) {
+  const int tid = threadIdx.x;
+  __shared__ int s_good;
+  if (tid == 0) s_good = 1;
+  __syncthreads();
+  u64 lo[NB], hi[NB];
+  bool good = true;
+  if (tid < G) {
+    const long long t0 = wall_clock64();
+    for (unsigned spins = 0;; ++spins) {
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int c = cols[j < ncols ? j : 0];
+        const u64* p = box + ((size_t)tid * rowlen + c) * 2;
+        lo[j] = ag_ld(p);
+        hi[j] = ag_ld(p + 1);
+        ok = ok && (j >= ncols || ((unsigned)(lo[j] >> 32) == tag && (unsigned)(hi[j] >> 32) == tag));
+      }
+      if (ok) break;
+      if ((spins & 63u) == 63u && (timed_out(t0, tshift) || ag_ld32(fail) != 0u)) { good = false; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  if (!good) s_good = 0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    if (j < ncols) {   // (uniform)
+      const double v = (tid < G && good) ? ungranule(lo[j], hi[j]) : 0.0;
+      double r;
+      if (cols[j] == maxcol) {
+        const double m = wave_max(v);
+        __syncthreads();
+        if ((tid & 63) == 0) s4[tid >> 6] = m;
+        __syncthreads();
+        r = fmax(fmax(s4[0], s4[1]), fmax(s4[2], s4[3]));
+      } else {
+        r = block_sum256(v, s4);
+      }
+      out[j] = r;
+    }
+  }
+  __syncthreads();
+  return s_good != 0;
+}
+
+#ifdef CC_RIG_PTIMING
+#define RPW_MARK(i) do { if (round == 3 && blockIdx.x == 0 && threadIdx.x == 0) P.vec_stats[8 + (i)] = (double)wall_clock64(); } while (0)
+#define RPC_MARK(i) do { if (round == 3 && threadIdx.x == 0) P.vec_stats[40 + (i)] = (double)wall_clock64(); } while (0)
+#else
+#define RPW_MARK(i) do { } while (0)
+#define RPC_MARK(i) do { } while (0)
+#endif
+template <int NR>
+__global__ __launch_bounds__(256) void k_rig_persist(RigDev P, RigPersistDev Q) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __shared__ double s_bc[kRigPersistMaxNB];     // broadcast B of this round: flags, radius, step, camera records
+  __shared__ double s_a[2 + kRigPersistMaxS];   // broadcast A
+  __shared__ double s_ss[kRigPersistMaxS + 1];
+  __shared__ double s_row[4 + kRigPersistMaxS];
+  __shared__ double s4[4];
+  __shared__ int s_cols[16];
+  __shared__ int s_flag;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int S = P.S, C = P.C, G = Q.G, K = Q.K, KS = Q.KS, NB = Q.NB;
+  unsigned* fail = P.arrive + 3;
+
+  if ((int)blockIdx.x == G) {
+    // =========================================================================== control workgroup
+    __shared__ LmCtl s_ctl;
+    __shared__ cc_iteration s_rec;
+    __shared__ double s_tot[4 + kRigPersistMaxS];
+    __shared__ int s_has_rec;
+    double* smem = reinterpret_cast<double*>(smem_raw);
+    if (tid == 0) s_ctl = *P.ctl;   // (zeros: rig_begin)
+    for (int i = tid; i < P.PC + 32; i += 256) P.vec[i] = 0.0;   // entries the compact rows never touch stay zero
+    __syncthreads();
+    {   // records of the starting point (k_rig_records) -> broadcast B of round 0
+      double a, b;
+      rig_candidates(P, nullptr, nullptr, false, s_ctl.cur, s_ctl.cur, a, b);
+    }
+    __syncthreads();
+    bool failed = false;
+    for (int round = 0; round < Q.max_rounds; ++round) {
+      const unsigned e = Q.epoch0 + (unsigned)round + 1u;
+      const bool phase0 = round == 0;
+      // ---- broadcast B(e): what this round's sweep evaluates
+      RPC_MARK(0);
+      if (tid == 0) {
+        s_bc[0] = (double)((s_ctl.done ? 1 : 0) | ((phase0 || s_ctl.step_valid) ? 2 : 0) | ((s_ctl.cur & 1) << 3));
+        s_bc[1] = s_ctl.radius;
+      }
+      if (!phase0 && tid < S) s_bc[2 + tid] = -smem[(size_t)S * ((S + 1) | 1) + tid];   // the shared step: -x of rig_solve_block (s_b)
+      if (phase0 && tid < S) s_bc[2 + tid] = 0.0;
+      for (int i = tid; i < 32 * C; i += 256) s_bc[2 + S + i] = P.camrec[i];
+      __syncthreads();
+      for (int w = tid; w < 2 * NB; w += 256) ag_st(Q.ybox + w, granule(e, s_bc[w >> 1], w & 1));
+      if (s_ctl.done) break;
+      // ---- statistics rows -> decision
+      RPC_MARK(1);
+      const bool swept = phase0 || s_ctl.step_valid;
+      {
+        const int nst = phase0 ? KS : 4;
+        for (int c0 = 0; c0 < nst; c0 += 8) {
+          if (tid < 8) s_cols[tid] = c0 + tid;
+          __syncthreads();
+          double out8[8];
+          const int nc = nst - c0 < 8 ? nst - c0 : 8;
+          if (!rig_gather_cols<8>(Q.sbox, G, KS, s_cols, nc, -1, e, s4, out8, fail, Q.timeout_shift)) failed = true;
+          if (tid == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (j < nc) s_tot[c0 + j] = out8[j];
+          }
+          __syncthreads();
+        }
+      }
+      if (failed) break;
+      // |x|^2 of the shared block at the starting point (k_rig_init)
+      RPC_MARK(2);
+      double x2_shared = 0.0;
+      if (phase0) {
+        double x2 = 0.0;
+        const int cur0 = s_ctl.cur;
+        for (int i = tid; i < C * 7; i += 256) {
+          const int cc2 = i / 7;
+          const double v = P.cam[((size_t)cur0 * C + cc2) * 8 + (i - cc2 * 7)];
+          x2 += P.cam_fixed[cc2] ? 0.0 : v * v;
+        }
+        x2_shared = block_sum256(x2, s4);
+      }
+      if (tid == 0) {
+        LmCtl c = s_ctl;
+        const LmOpts o = *P.opts;
+        s_has_rec = 0;
+        if (phase0) {
+          for (int k = 0; k < S; ++k) s_ss[k] = o.jacobi_scaling ? 1.0 / (1.0 + sqrt(s_tot[4 + k])) : 1.0;
+          lm_init(c, o, s_tot[0], sqrt(s_tot[3] + x2_shared));
+        } else if (c.cand_pending) {
+          double step2 = swept ? s_tot[2] : 0.0, xn2 = swept ? s_tot[3] : 0.0;
+          if (c.step_valid) { step2 += P.shared_stats[0]; xn2 += P.shared_stats[1]; }
+          const int len0 = c.log_len;
+          lm_decide(c, o, &s_rec, swept ? s_tot[0] : 0.0, swept ? s_tot[1] : 0.0, step2, xn2);
+          s_has_rec = (c.log_len != len0 && c.log_len <= P.log_cap) ? 1 : 0;
+          if (s_has_rec) P.log[c.log_len - 1] = s_rec;
+        }
+        if (!c.done && round + 1 >= Q.max_rounds) { c.done = 1; c.term = CC_NO_CONVERGENCE; }
+        s_ctl = c;
+        s_a[0] = (double)((c.done ? 1 : 0) | ((c.cur & 1) << 3));
+        s_a[1] = c.radius;
+      }
+      __syncthreads();
+      if (tid < S) { s_a[2 + tid] = phase0 ? s_ss[tid] : 0.0; if (phase0) P.ss[tid] = s_ss[tid]; }
+      __syncthreads();
+      for (int w = tid; w < 2 * (2 + S); w += 256) ag_st(Q.abox + w, granule(e, s_a[w >> 1], w & 1));
+      RPC_MARK(3);
+      if (s_ctl.done) {
+        if (tid == 0) { *P.ctl = s_ctl; *P.ctl_next = s_ctl; }
+        break;
+      }
+      // ---- the K column sums -> the layout rig_solve_block reads (P.vec), then the solve step
+      if (tid == 0) s_flag = 0;
+      __syncthreads();
+      {
+        const long long t0 = wall_clock64();
+        bool good = true;
+        for (int k0 = tid; k0 < K && good; k0 += 256 * 4) {
+          u64 lo[4], hi[4];
+          for (unsigned spins = 0;; ++spins) {
+            bool ok = true;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int k = k0 + 256 * u;
+              const u64* p = Q.cbox + (size_t)(k < K ? k : k0) * 2;
+              lo[u] = ag_ld(p);
+              hi[u] = ag_ld(p + 1);
+              ok = ok && (unsigned)(lo[u] >> 32) == e && (unsigned)(hi[u] >> 32) == e;
+            }
+            if (ok) break;
+            if ((spins & 63u) == 63u && (timed_out(t0, Q.timeout_shift) || ag_ld32(fail) != 0u)) { good = false; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          if (!good) break;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 256 * u;
+            if (k < K) {
+              const double v = ungranule(lo[u], hi[u]);
+              if (k == K - 1) P.vec[P.PC + P.rank] = v;   // the gradient maximum rides in the rank's slot (k_rig_reduce)
+              else P.vec[Q.comp[k]] = v;
+            }
+          }
+        }
+        if (!good) s_flag = 1;
+      }
+      __syncthreads();
+      if (s_flag == 1) { failed = true; break; }
+      RPC_MARK(4);
+      if (tid == 0) { *P.ctl = s_ctl; *P.ctl_next = s_ctl; }   // (rig_solve_block finishes the record of this round in P.log)
+      __syncthreads();
+      rig_solve_block<0>(P, smem, &s_ctl);
+      __syncthreads();
+      RPC_MARK(5);
+      if (tid == 0) s_ctl = *P.ctl;   // as the solve step left it (this workgroup wrote it)
+      __syncthreads();
+    }
+    // ---- the solve is over
+    __syncthreads();
+    if (tid == 0) {
+      LmCtl c = s_ctl;
+      if (failed || ag_ld32(fail) != 0u) {
+        __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c.done = 1; c.term = CC_FAILURE_EXCHANGE;
+      }
+      if (!c.done) { c.done = 1; c.term = CC_NO_CONVERGENCE; }
+      *P.ctl = c;
+      *P.ctl_next = c;
+      rig_publish(P, c);
+    }
+    return;
+  }
+
+  // ============================================================================= worker workgroup
+  const int64_t fbase = (int64_t)blockIdx.x * 4;
+  const int64_t fw = fbase + wave;                              // this wave's frame
+  const int64_t g0 = P.fgoff[fbase < P.F ? fbase : P.F];
+  const int64_t g1 = P.fgoff[fbase + 4 < P.F ? fbase + 4 : P.F];   // groups of the workgroup: [g0, g1)
+  const int64_t nf = P.F - fbase < 4 ? P.F - fbase : 4;
+  double* wlds = reinterpret_cast<double*>(smem_raw) + wave * 256;   // the wave's sweep scratch (the elimination's LDS, idle then)
+  int cur = 0;
+  double radius = 1.0;
+  for (int round = 0; round < Q.max_rounds; ++round) {
+    const unsigned e = Q.epoch0 + (unsigned)round + 1u;
+    const bool phase0 = round == 0;
+    // ---- broadcast B: the step to apply and the camera records of the point to evaluate
+    RPW_MARK(0);
+    if (wave == 0 && !rig_bcast_wait(Q.ybox, e, NB, s_bc, fail, Q.timeout_shift)) s_bc[0] = 1.0;
+    __syncthreads();
+    const int flb = (int)s_bc[0];
+    RPW_MARK(1);
+    if (flb & 1) break;
+    cur = (flb >> 3) & 1;
+    const bool swept = (flb & 2) != 0;
+    if (swept) {
+      // pose update of the workgroup's frames (sixteen lanes per frame), records of the candidate
+      {
+        RigUpdPre none;
+        const int64_t fu = tid < 64 ? fbase + (tid >> 4) : P.F;
+        rig_update_body<false, false>(P, phase0 ? 0 : 1, cur, fu, none, s_bc + 2);
+      }
+      __syncthreads();
+      RPW_MARK(2);
+      if (fw < P.F)
+        for (int64_t g = P.fgoff[fw]; g < P.fgoff[fw + 1]; ++g)
+          rig_sweep_adj_body<1, true>(P, g, phase0 ? 0 : 1, cur, wlds, s_bc + 2 + S);
+      __syncthreads();
+      RPW_MARK(3);
+    }
+    // ---- statistics row of the workgroup
+    {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      if (swept) {
+        for (int64_t g = g0 + tid; g < g1; g += 256) { a0 += P.gstats[g * 2]; a1 += P.gstats[g * 2 + 1]; }
+        if (tid < nf) { a2 = P.fstats[(fbase + tid) * 2]; a3 = P.fstats[(fbase + tid) * 2 + 1]; }
+      }
+      a0 = block_sum256(a0, s4);
+      a1 = block_sum256(a1, s4);
+      a2 = block_sum256(a2, s4);
+      a3 = block_sum256(a3, s4);
+      if (tid == 0) { s_row[0] = a0; s_row[1] = a1; s_row[2] = a2; s_row[3] = a3; }
+      if (phase0 && tid < S) {   // diagonal of H_cc of the workgroup's groups, per shared column (Jacobi scaling, k_rig_init)
+        double d = 0.0;
+        for (int64_t g = g0; g < g1; ++g) {
+          const int p0 = P.pcol[P.gcam[g]];
+          if (p0 >= 0 && tid >= p0 && tid < p0 + 6) d += P.ghd0[g * 8 + (tid - p0)];
+        }
+        s_row[4 + tid] = d;
+      }
+      __syncthreads();
+      const int nst = phase0 ? KS : 4;
+      for (int w = tid; w < 2 * nst; w += 256) ag_st(Q.sbox + ((size_t)blockIdx.x * KS) * 2 + w, granule(e, s_row[w >> 1], w & 1));
+    }
+    RPW_MARK(4);
+    // ---- broadcast A: the decision
+    if (wave == 0 && !rig_bcast_wait(Q.abox, e, 2 + S, s_a, fail, Q.timeout_shift)) s_a[0] = 1.0;
+    __syncthreads();
+    const int fla = (int)s_a[0];
+    RPW_MARK(5);
+    if (fla & 1) break;
+    cur = (fla >> 3) & 1;
+    radius = s_a[1];
+    if (phase0 && tid < S) s_ss[tid] = s_a[2 + tid];
+    __syncthreads();
+    // ---- elimination of the workgroup's frames -> partial row (global, this workgroup's own) -> compact row
+    rig_elim_body<false, NR, true>(P, smem_raw, cur, radius, phase0, s_ss);
+    __syncthreads();
+    RPW_MARK(6);
+    {
+      const double* prow = P.partial + (size_t)blockIdx.x * P.PC;
+      for (int k = tid; k < K; k += 256) {
+        const double v = prow[Q.comp[k]];
+        u64* q = Q.rbox + ((size_t)blockIdx.x * K + k) * 2;
+        ag_st(q, granule(e, v, 0));
+        ag_st(q + 1, granule(e, v, 1));
+      }
+    }
+    RPW_MARK(7);
+    // ---- this workgroup's share of the column sums: columns b, b + G, ...
+    for (int c0 = (int)blockIdx.x; c0 < K; c0 += 8 * G) {
+      if (tid < 8) s_cols[tid] = c0 + tid * G < K ? c0 + tid * G : c0;
+      __syncthreads();
+      int nc = 0;
+      for (int j = 0; j < 8; ++j) nc += c0 + j * G < K ? 1 : 0;
+      double out8[8];
+      const bool ok = rig_gather_cols<8>(Q.rbox, G, K, s_cols, nc, K - 1, e, s4, out8, fail, Q.timeout_shift);
+      if (!ok) { if (tid == 0) __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      if (ok && tid < 2 * nc) {
+        const int j = tid >> 1;
+        double v = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v = j == u ? out8[u] : v;
+        ag_st(Q.cbox + (size_t)s_cols[j] * 2 + (tid & 1), granule(e, v, tid & 1));
+      }
+      __syncthreads();
+    }
+    RPW_MARK(8);
+  }
+  (void)lane; (void)radius;
+}
+
 // creation: world point of every observation
 __global__ void k_rig_expand_xyz(int64_t n, const int32_t* widx, const float* wxyz, float* oxyz) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -3024,6 +3467,11 @@ struct cc_rig {
   std::vector<int64_t> fgoff_h;
   size_t elim_lds = 0, solve_lds = 0;
   bool big = false;             // 128 <= S <= 255: the plain kernels (k_rig_elim_big, k_rig_solve_big), no exchange
+  bool persist_allowed = false; // CC_RIG_PERSIST=1: the persistent per-solve kernel where it fits (an experiment: slower than the three kernels, see k_rig_persist)
+  bool persist_ok = false;      // k_rig_persist can run this problem (poses only, <= 4 frames per compute unit, everything resident)
+  cc::RigPersistDev pq{};
+  unsigned p_epoch = 0;         // tags handed out so far
+  size_t p_box_words = 0;       // seam boxes: one allocation of this many 8-byte words (re-zeroed before the tags wrap)
   bool big_packed = false;      // ... with the reduced system as a packed triangle in LDS (else in bigA, global memory)
   double* bigA = nullptr;
   volatile unsigned long long* host_pub = nullptr;   // = h_ctl's pinned block: [0] sequence word, [2..19] control block, [20] failure word
@@ -3095,6 +3543,7 @@ struct RigProbe {  // optional hipEvent bracket around one launch
 // them. Called by create (with the locally observed cameras) and again by the multi-GPU attach calls when
 // another rank observes a camera this one does not.
 static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
+  if (const char* e = getenv("CC_RIG_PERSIST")) h->persist_allowed = atoi(e) != 0;
   RigDev& d = h->d;
   const int64_t C = h->C, F = h->F;
   const int kmode = h->kmode;
@@ -3262,6 +3711,36 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_reduce<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_reduce<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
+  // ---- the persistent per-solve kernel (k_rig_persist): poses only, four frames per compute unit, every workgroup resident
+  h->persist_ok = false;
+  if (!kmode && h->persist_allowed && S >= 1 && S <= kRigPersistMaxS && C <= kRigPersistMaxC && F <= 4 * 256) {
+    std::vector<int32_t> comp;
+    for (size_t i = 0; i < tile_dst.size(); ++i) if (tile_dst[i] != -1) comp.push_back((int32_t)i);
+    for (int e = 0; e < d.ND; ++e) if (dir_dst[(size_t)e] != -1) comp.push_back(d.pc_dir + e);
+    comp.push_back(d.pc_fail);
+    comp.push_back(d.pc_gmax);
+    RigPersistDev& q = h->pq;
+    q.G = (int32_t)((F + 3) / 4); q.K = (int32_t)comp.size(); q.KS = 4 + S; q.NB = 2 + S + 32 * (int32_t)C;
+    if (int rc = dev_upload(h, &q.comp, comp)) return rc;
+    const size_t n_s = (size_t)q.G * q.KS * 2, n_a = (size_t)(2 + S) * 2, n_r = (size_t)q.G * q.K * 2, n_c = (size_t)q.K * 2, n_y = (size_t)q.NB * 2;
+    u64* base = nullptr;
+    h->p_box_words = n_s + n_a + n_r + n_c + n_y;
+    if (int rc = dev_zeroed(h, &base, h->p_box_words)) return rc;
+    q.sbox = base; q.abox = q.sbox + n_s; q.rbox = q.abox + n_a; q.cbox = q.rbox + n_r; q.ybox = q.cbox + n_c;
+    h->p_epoch = 0;
+    const size_t pl = std::max(h->elim_lds, h->solve_lds);
+    const bool small = d.ND <= 8 * 64;
+    int per_cu = 0, cus = 0;
+    hipError_t e1 = small ? hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_persist<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl)
+                          : hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_persist<kRigDirectPerLane>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl);
+    if (e1 == hipSuccess)
+      e1 = small ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rig_persist<8>, 256, pl)
+                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rig_persist<kRigDirectPerLane>, 256, pl);
+    if (e1 == hipSuccess) e1 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+    if (e1 != hipSuccess) (void)hipGetLastError();
+    // one workgroup per compute unit is what the kernel is built for (its elimination uses most of a CU's registers)
+    h->persist_ok = e1 == hipSuccess && per_cu >= 1 && q.G + 1 <= cus;
+  }
   rig_drop_graphs(h);
   return 0;
 }
@@ -3743,6 +4222,7 @@ namespace cc {
 struct RigRun {
   cc_options o;
   bool profile = false, use_graph = false;
+  bool persist = false;   // this solve runs as ONE launch of k_rig_persist
   int launched = 0;
   LmCtl st{};
   std::chrono::steady_clock::time_point t0;
@@ -3788,6 +4268,26 @@ static int rig_begin(cc_rig* h, const cc_options* opt, RigRun* r) {
 
 static int rig_launch(cc_rig* h, RigRun* r, int chunk) {
   CC_HIP(hipSetDevice(h->device));
+  if (chunk == 0 && h->persist_ok && h->sweep_adjoint && !r->profile && !h->comm && !h->exchange && !h->big && h->co_resident <= 1) {
+    // the whole solve in one launch (k_rig_persist); the control workgroup publishes when it is over
+    RigPersistDev q = h->pq;
+    q.max_rounds = r->o.max_iterations + 2;
+    q.timeout_shift = 27;   // 1.3 s of the 100 MHz wall clock
+    if (h->p_epoch > 0x7fff0000u - (unsigned)q.max_rounds) {   // the 32-bit tags would wrap: start over on zeroed boxes
+      CC_HIP(hipMemsetAsync(h->pq.sbox, 0, h->p_box_words * sizeof(unsigned long long), h->stream));
+      h->p_epoch = 0;
+    }
+    q.epoch0 = h->p_epoch;
+    h->p_epoch += (unsigned)q.max_rounds + 2u;
+    const size_t pl = std::max(h->elim_lds, h->solve_lds);
+    const dim3 grid((unsigned)q.G + 1u);
+    if (h->d.ND <= 8 * 64) hipLaunchKernelGGL(k_rig_persist<8>, grid, dim3(256), pl, h->stream, h->d, q);
+    else hipLaunchKernelGGL(k_rig_persist<kRigDirectPerLane>, grid, dim3(256), pl, h->stream, h->d, q);
+    CC_HIP(hipGetLastError());
+    r->persist = true;
+    r->launched += q.max_rounds;
+    return 0;
+  }
   const int n = r->o.check_interval + (chunk == 0 ? 1 : 0);
   if (r->use_graph) {
     const int which = chunk == 0 ? 0 : 1;
@@ -3809,6 +4309,11 @@ static int rig_wait(cc_rig* h, RigRun* r) {
   bool wait_failed = false;
   if (int rc = ((h->comm || h->big) ? rig_read_ctl(h, &r->st, &wait_failed) : rig_wait_published(h, &r->st, &wait_failed))) return rc;
   if (r->st.done) { h->last_st = r->st; h->st_known = true; }
+  if (wait_failed && r->persist) {
+    h->persist_ok = false;   // (this handle runs the three-kernel form from now on: cc_rig_reset / set_state and solve again)
+    return fail(CC_ERR_COMM, "k_rig_persist: a workgroup waited 1.3 s for another one (round %d): the launch was not fully resident "
+                "(%d workgroups; a device shared with another process?). The handle now runs the three-kernel form", r->st.iter, h->pq.G + 1);
+  }
   if (wait_failed)
     return fail(CC_ERR_COMM, "k_rig_reduce: the solving block did not publish within 10 s (iteration %d): its launch was not fully "
                 "resident (%d blocks; shards or processes sharing the device? CC_RIG_CO_RESIDENT) or a peer rank stalled", r->st.iter, h->reduce_blocks);
@@ -3867,6 +4372,12 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
     if (r.st.done) break;
   }
   return rig_finish(h, &r, summary);
+}
+
+int cc_rig_solver_form(cc_rig* h) {
+  using namespace cc;
+  if (!h) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_solver_form: NULL handle");
+  return (h->persist_ok && h->sweep_adjoint && !h->comm && !h->exchange && !h->big && h->co_resident <= 1) ? 1 : 0;
 }
 
 int cc_rig_get_state(cc_rig* h, double* cam_q, double* cam_t, double* frame_q, double* frame_t, double* obs_cost) {
@@ -4024,7 +4535,7 @@ int cc_rig_debug_fetch(cc_rig* h, const char* name, double* out, int64_t n) {
   else if (k == "Y") src = d.Y; else if (k == "partial") src = d.partial; else if (k == "gblocks") src = d.gblocks;
   else if (k == "camrec") src = d.camrec; else if (k == "frec") src = d.frec; else if (k == "gstats") src = d.gstats;
   else if (k == "fstats") src = d.fstats; else if (k == "shared_stats") src = d.shared_stats; else if (k == "cam") src = d.cam; else if (k == "pose") src = d.pose;
-  else if (k == "vec") src = d.vec;
+  else if (k == "vec") src = d.vec; else if (k == "vec_stats") src = d.vec_stats;
   else return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_debug_fetch: unknown buffer %s", name);
   CC_HIP(hipMemcpy(out, src, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
   return CC_OK;

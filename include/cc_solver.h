@@ -227,6 +227,11 @@ int cc_rig_set_state(cc_rig* h, const double* cam_q, const double* cam_t, const 
                      const double* frame_t);
 int cc_rig_reset(cc_rig* h);
 int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary);
+/* Which form cc_rig_solve runs (without profiling): 0 -- three kernels per LM iteration (sweep, decision + elimination,
+ * reduce + solve step + pose update), any size, any exchange: the default; 1 -- the whole solve as ONE persistent kernel
+ * launch (poses only, at most 1024 frames, 48 shared coordinates, 9 cameras, the device to itself): an experiment enabled by
+ * CC_RIG_PERSIST=1, correct but slower. */
+int cc_rig_solver_form(cc_rig* h);
 /* Any output may be NULL. obs_cost[k] = 1/2 rho(|r_k|^2) at the current point, in the caller's
  * observation order (extrinsics_calibrator.cpp:219-225). */
 int cc_rig_get_state(cc_rig* h, double* cam_q, double* cam_t, double* frame_q, double* frame_t,
