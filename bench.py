@@ -552,6 +552,7 @@ def rig_configs(capi, device):
                 else:
                     prob.set_intrinsics(k["intr0"], 0)
             prob.set_state(cq, ct, fq, ft)
+            form = prob.solver_form()
             o = capi.default_options(max_iterations=1000)
             s = prob.solve(o, log_capacity=0)
             ts = []
@@ -584,19 +585,28 @@ def rig_configs(capi, device):
                 dominant.update(bound="latency", note="a chain of dependent steps on one workgroup (column sums, assembly, Cholesky of the "
                                 "reduced system, pose update behind a flag): no bandwidth or flop roofline applies; stage times in "
                                 "profiles/r03/rig_stage_marks.jsonl")
+            if form:
+                # the timed solves ran as ONE launch (lean persistent kernel + its control workgroup's launch); the per-kernel
+                # figures below are the three-kernel form's, which is what a profiled solve runs
+                dominant = {"kernel": "k_rig_persist_w (the whole solve in one launch; control workgroup: k_rig_persist_ctl)",
+                            "ms_per_launch": t_solve * 1e3, "share_of_kernel_time": 1.0, "bound": "latency",
+                            "note": "a round is a chain of dependent steps across workgroups (broadcast, pose update, sweep, elimination, "
+                                    "column sums, reduced solve): no bandwidth or flop roofline applies; round timeline in "
+                                    "profiles/r03/rig_persist_marks.jsonl"}
             out[f"{name}_{variant}"] = {
                 "workload": f"rig {C_} cameras x {F} frames x {M} pts, {variant.replace('_', ' ')}"
                             + (" (= ExtrinsicsCalibrator::Optimize)" if variant == "poses" else " (extension, pixel observations)"),
                 "observations": n_obs, "iterations": s["iterations"], "termination": s["termination"],
                 "solve_ms": t_solve * 1e3, "ms_per_iteration": t_solve * 1e3 / max(1, s["iterations"]),
                 "residuals_per_sec": 2.0 * n_obs * s["iterations"] / t_solve,
+                "solver_form": {0: "three kernels per LM iteration", 1: "persistent kernel (glued form)", 2: "lean persistent kernel: one launch per solve"}[form],
                 "dominant_kernel": dominant,
                 "sweep_kernel": {"kernel": sweep_name, "ms_per_launch": sweep_ms,
                                  "hbm_frac": ab / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  "fp64_frac": RIG_FLOP_PER_OBS[variant] * n_obs / (sweep_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                                  "algorithmic_bytes_per_launch": ab, "traffic": load_rig_traffic(C_, F, M, variant)},
                 "kernel_ms_per_launch_eager": per_launch,
-                "kernel_ms_labels": "sweep = k_rig_sweep_adj / k_rig_sweep_adjk (per group the columns [J_cam r (J_k)] only, frame blocks "
+                "kernel_ms_labels": "(the THREE-KERNEL form: what profile_kernels = 1 runs) sweep = k_rig_sweep_adj / k_rig_sweep_adjk (per group the columns [J_cam r (J_k)] only, frame blocks "
                                     "through the group's adjoint), decide = k_rig_init (once per solve), elim = k_rig_elim, "
                                     "solve = k_rig_reduce (column sums + reduced solve + pose update in one launch)",
                 "final_cost": s["final_cost"],

@@ -611,8 +611,23 @@ __device__ __forceinline__ void reduce_scatter32(double* p, int lane) {
 // after the other, so there is no workgroup barrier in here, the scratch `lds` is the wave's own, and the camera records
 // come from `camrec` -- there: the copy the control workgroup broadcast, in LDS).
 constexpr int kRigSweepAdjLds(int NW) { return 64 + 64 + 8 + NW * 32 + 32 + 36; }   // doubles of scratch
+// where a group's sweep reads and leaves things: global memory (the stand-alone kernels, k_rig_persist) or the LDS of a
+// workgroup that keeps its frames resident (k_rig_persist_w)
+struct RigSweepIO {
+  const double* camrec;     // [C][32] camera records of the point to evaluate
+  const double* frec;       // [32]    record of the group's frame
+  const double* comp_old;   // [64]    compact record of the group at the accepted point
+  double* block_out;        // [256]   the group's 16 x 16 block at the evaluated point
+  double* comp_out;         // [64]    its compact record
+  double* stats_out;        // [2]     cost, model-cost term
+  double* hd0_out;          // [8]     diagonal of H_cc (first evaluation)
+};
+__device__ __forceinline__ RigSweepIO rig_sweep_io_global(const RigDev& P, int64_t g, int cur, int dst) {
+  return RigSweepIO{P.camrec, P.frec + (size_t)P.gframe[g] * 32, P.gcomp + ((size_t)cur * P.NG + g) * 64,
+                    P.gblocks + ((size_t)dst * P.NG + g) * (size_t)P.gstride, P.gcomp + ((size_t)dst * P.NG + g) * 64, P.gstats + g * 2, P.ghd0 + g * 8};
+}
 template <int NW, bool WL>
-__device__ __forceinline__ void rig_sweep_adj_body(const RigDev& P, const int64_t g, const int phase, const int cur, double* lds, const double* camrec) {
+__device__ __forceinline__ void rig_sweep_adj_body(const RigDev& P, const int64_t g, const int phase, const int cur, double* lds, const RigSweepIO io) {
   constexpr int NT = NW * 64;      // threads
   double* sm = lds;                    // [64] camera record [0..31], frame record [32..63]
   double* s_old = sm + 64;             // [64] the accepted point's compact record of this group (gcomp)
@@ -656,8 +671,8 @@ __device__ __forceinline__ void rig_sweep_adj_body(const RigDev& P, const int64_
   fetch(otid + NT, ob);
   if (tid < 64) {
     // (both buffers hold valid memory: the record of `cur` is read whatever the phase, used only behind phase != 0)
-    const double rec = tid < 32 ? camrec[c * 32 + tid] : P.frec[(size_t)f * 32 + (tid - 32)];
-    const double old = P.gcomp[((size_t)cur * P.NG + g) * 64 + tid];
+    const double rec = tid < 32 ? io.camrec[c * 32 + tid] : io.frec[tid - 32];
+    const double old = io.comp_old[tid];
     sm[tid] = rec;
     s_old[tid] = old;
   }
@@ -670,8 +685,8 @@ __device__ __forceinline__ void rig_sweep_adj_body(const RigDev& P, const int64_
   // the rotated world point is not needed on its own). Uniform addresses: scalar loads, the values live in SGPRs.
   double Rca[9], tca[3], tcs[3];
   {
-    const double* cr = camrec + (size_t)c * 32;
-    const double* fr = P.frec + (size_t)f * 32;
+    const double* cr = io.camrec + (size_t)c * 32;
+    const double* fr = io.frec;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
 #pragma unroll
@@ -794,18 +809,18 @@ __device__ __forceinline__ void rig_sweep_adj_body(const RigDev& P, const int64_
   d4 B = {0.0, 0.0, 0.0, 0.0};
   B = __builtin_amdgcn_mfma_f64_16x16x4f64(n0, T[0], B, 0, 0, 0);
   B = __builtin_amdgcn_mfma_f64_16x16x4f64(n1, T[1], B, 0, 0, 0);
-  double* out = P.gblocks + ((size_t)dst * P.NG + g) * (size_t)P.gstride;
+  double* out = io.block_out;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = k0 + 4 * r;
     out[row * 16 + j] = B[r];
-    if (phase == 0 && row < 6 && row == j) P.ghd0[g * 8 + row] = B[r];  // diag of H_cc
+    if (phase == 0 && row < 6 && row == j) io.hd0_out[row] = B[r];  // diag of H_cc
   }
   // compact record of this point for the next sweep's model-cost term: G7 (28) and M (36)
-  P.gcomp[((size_t)dst * P.NG + g) * 64 + lane] = lane < 28 ? s_g[lane < 28 ? lane : 0] : s_m[lane >= 28 ? lane - 28 : 0];
+  io.comp_out[lane] = lane < 28 ? s_g[lane < 28 ? lane : 0] : s_m[lane >= 28 ? lane - 28 : 0];
   if (lane == 0) {
-    P.gstats[g * 2] = s_g[28];
-    P.gstats[g * 2 + 1] = s_g[29];
+    io.stats_out[0] = s_g[28];
+    io.stats_out[1] = s_g[29];
   }
   RSW_MARK(5);
 }
@@ -817,7 +832,7 @@ __global__ __launch_bounds__(NW * 64, NW == 1 ? CC_RIG_ADJ_WAVES : 3) void k_rig
   const int done = ctl->done, phase = ctl->phase, step_valid = ctl->step_valid, cur = ctl->cur;
   if (done) return;
   if (phase != 0 && !step_valid) return;
-  rig_sweep_adj_body<NW, false>(P, blockIdx.x, phase, cur, s_lds, P.camrec);
+  rig_sweep_adj_body<NW, false>(P, blockIdx.x, phase, cur, s_lds, rig_sweep_io_global(P, blockIdx.x, cur, phase == 0 ? cur : (cur ^ 1)));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2974,14 +2989,15 @@ __global__ __launch_bounds__(256) void k_rig_solve_big(RigDev P, double* Aglobal
 
 // =============================================================================================
 // THE RIG SOLVE AS ONE PERSISTENT KERNEL (round 3; poses only, single GPU, at most four frames per compute unit).
-// AN EXPERIMENT, OFF BY DEFAULT (CC_RIG_PERSIST=1): correct -- both rig test suites pass on it -- and SLOWER than the three
-// kernels it replaces: 81 against 47 us per iteration at BASELINE configs[3] size, 66 against 43 for a 2 x 1000 x 4 rig
-// (profiles/r03/rig_persist_marks.jsonl). The bodies it is glued from need up to 444 registers per thread, so a compute unit
-// holds ONE wave per SIMD: the sweep of a frame's groups runs one after the other with every memory round trip exposed
-// (25.6 us where the stand-alone sweep, sixteen waves deep, takes 9), and pose update, elimination and solve step each run
-// 1.3 - 2 x slower for the same reason. What the launch boundaries cost (~19 us) is won back only by a kernel whose per-frame
-// state lives in LDS and whose bodies fit 128 registers, as cc_intrinsics_persist.hip does; the seams, the control
-// workgroup and the host side below are what that kernel will reuse.
+// TWO FORMS. This one, k_rig_persist, GLUES the three kernels' bodies together: AN EXPERIMENT, OFF BY DEFAULT (CC_RIG_PERSIST=1,
+// used where the lean form below does not fit): correct -- the rig test suite passes on it -- and SLOWER than the three
+// kernels it replaces: 81 against 47 us per iteration at BASELINE configs[3] size (profiles/r03/rig_persist_marks.jsonl).
+// The bodies need up to 444 registers per thread, so a compute unit holds ONE wave per SIMD: the sweep of a frame's groups
+// runs one after the other with every memory round trip exposed (25.6 us where the stand-alone sweep, sixteen waves deep,
+// takes 9), and pose update, elimination and solve step each run 1.3 - 2 x slower for the same reason.
+// The LEAN form further down (k_rig_persist_w + k_rig_persist_ctl: small rigs, the per-frame state in LDS, one wave per
+// group, the workers under 128 / 256 registers) is what runs BY DEFAULT where it fits: 39 us at configs[3] size. Seams,
+// control workgroup and host side are shared.
 // Three launches per LM iteration cost this path ~19 of its ~47 us at BASELINE configs[3] (ramp of a launch, dependent
 // read of the control block, the gap; profiles/r03/rig_c4_kernel_stats.csv): here ONE launch runs the whole solve, built
 // from the very functions the three kernels run (rig_update_body, rig_sweep_adj_body, rig_elim_body, rig_solve_block,
@@ -3007,8 +3023,11 @@ struct RigPersistDev {
   u64* abox;            // [2 + S][2]  broadcast A: flags (1 done | cur << 3), radius, Jacobi scales of the shared columns (first round)
   u64* rbox;            // [G][K][2]   elimination rows (compacted)
   u64* cbox;            // [K][2]      column sums
+  u64* pbox, *pcbox;    // the same two for the elimination on the ASSUMED decision (k_rig_persist_w; null: nobody assumes)
   u64* ybox;            // [NB][2]     broadcast B: flags (1 done | 2 step valid | cur << 3), radius, step[S], camera records [C][32]
   const int32_t* comp;  // [K] entry of the partial-row layout behind compact index k (the last two: failures, gradient maximum)
+  const int32_t* slots; // [K] the same entries for k_rig_persist_w: 1 << 30 | p << 8 | q: sum_i Z[i][p] Z[i][q]; c << 16 | offset: entry of observed
+                        //     camera c's block; -1: failed factorisations; -2: gradient maximum
   int32_t G, K, KS, NB;
   unsigned epoch0;      // tags: epoch0 + round + 1 (boxes are zeroed when they would wrap)
   int32_t max_rounds, timeout_shift;
@@ -3020,7 +3039,8 @@ constexpr int kRigPersistMaxNB = 2 + kRigPersistMaxS + 32 * kRigPersistMaxC;
 
 // One wave waits until the n doubles of a broadcast box carry `tag` and leaves them in dst[0..n) (LDS). false: gave up.
 __device__ __forceinline__ bool rig_bcast_wait(const u64* box, unsigned tag, int n, double* dst, unsigned* fail, int tshift) {
-  const int lane = threadIdx.x & 63;
+  int lane = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane));   // (a fresh copy: the eleven word addresses of a lane are not worth keeping across a round)
   constexpr int W = (2 * kRigPersistMaxNB + 63) / 64;
   const long long t0 = wall_clock64();
   u64 v[W];
@@ -3106,26 +3126,23 @@ __device__ __forceinline__ bool rig_gather_cols(const u64* box, int G, int rowle
 #define RPW_MARK(i) do { } while (0)
 #define RPC_MARK(i) do { } while (0)
 #endif
-template <int NR>
-__global__ __launch_bounds__(256) void k_rig_persist(RigDev P, RigPersistDev Q) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+// The control workgroup of the persistent rig kernels (256 threads; dynamic LDS: the solve step's, rig_solve_block): block G of
+// k_rig_persist, or a launch of its own next to the lean workers of k_rig_persist_w (k_rig_persist_ctl).
+__device__ __forceinline__ void rig_persist_control(const RigDev& P, const RigPersistDev& Q, char* smem_raw) {
   __shared__ double s_bc[kRigPersistMaxNB];     // broadcast B of this round: flags, radius, step, camera records
   __shared__ double s_a[2 + kRigPersistMaxS];   // broadcast A
   __shared__ double s_ss[kRigPersistMaxS + 1];
-  __shared__ double s_row[4 + kRigPersistMaxS];
   __shared__ double s4[4];
   __shared__ int s_cols[16];
   __shared__ int s_flag;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const int S = P.S, C = P.C, G = Q.G, K = Q.K, KS = Q.KS, NB = Q.NB;
   unsigned* fail = P.arrive + 3;
-
-  if ((int)blockIdx.x == G) {
     // =========================================================================== control workgroup
     __shared__ LmCtl s_ctl;
     __shared__ cc_iteration s_rec;
     __shared__ double s_tot[4 + kRigPersistMaxS];
-    __shared__ int s_has_rec;
+    __shared__ int s_has_rec, s_hit;
     double* smem = reinterpret_cast<double*>(smem_raw);
     if (tid == 0) s_ctl = *P.ctl;   // (zeros: rig_begin)
     for (int i = tid; i < P.PC + 32; i += 256) P.vec[i] = 0.0;   // entries the compact rows never touch stay zero
@@ -3187,6 +3204,8 @@ __global__ __launch_bounds__(256) void k_rig_persist(RigDev P, RigPersistDev Q) 
       if (tid == 0) {
         LmCtl c = s_ctl;
         const LmOpts o = *P.opts;
+        const int prev_cur = c.cur & 1, was_valid = c.step_valid;
+        const double prev_radius = c.radius;
         s_has_rec = 0;
         if (phase0) {
           for (int k = 0; k < S; ++k) s_ss[k] = o.jacobi_scaling ? 1.0 / (1.0 + sqrt(s_tot[4 + k])) : 1.0;
@@ -3201,7 +3220,10 @@ __global__ __launch_bounds__(256) void k_rig_persist(RigDev P, RigPersistDev Q) 
         }
         if (!c.done && round + 1 >= Q.max_rounds) { c.done = 1; c.term = CC_NO_CONVERGENCE; }
         s_ctl = c;
-        s_a[0] = (double)((c.done ? 1 : 0) | ((c.cur & 1) << 3));
+        // did the workers' assumption hold? (the expression they evaluate: persist_spec_radius)
+        s_hit = Q.pbox != nullptr && !phase0 && swept && was_valid && !c.done && (c.cur & 1) == (prev_cur ^ 1) &&
+                c.radius == persist_spec_radius(prev_radius, o.max_radius);
+        s_a[0] = (double)((c.done ? 1 : 0) | (s_hit ? 4 : 0) | ((c.cur & 1) << 3));
         s_a[1] = c.radius;
       }
       __syncthreads();
@@ -3226,7 +3248,7 @@ __global__ __launch_bounds__(256) void k_rig_persist(RigDev P, RigPersistDev Q) 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               const int k = k0 + 256 * u;
-              const u64* p = Q.cbox + (size_t)(k < K ? k : k0) * 2;
+              const u64* p = (s_hit ? Q.pcbox : Q.cbox) + (size_t)(k < K ? k : k0) * 2;
               lo[u] = ag_ld(p);
               hi[u] = ag_ld(p + 1);
               ok = ok && (unsigned)(lo[u] >> 32) == e && (unsigned)(hi[u] >> 32) == e;
@@ -3272,8 +3294,23 @@ __global__ __launch_bounds__(256) void k_rig_persist(RigDev P, RigPersistDev Q) 
       *P.ctl_next = c;
       rig_publish(P, c);
     }
-    return;
-  }
+}
+
+template <int NR>
+__global__ __launch_bounds__(256) void k_rig_persist(RigDev P, RigPersistDev Q) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __shared__ double s_bc[kRigPersistMaxNB];     // broadcast B of this round: flags, radius, step, camera records
+  __shared__ double s_a[2 + kRigPersistMaxS];   // broadcast A
+  __shared__ double s_ss[kRigPersistMaxS + 1];
+  __shared__ double s_row[4 + kRigPersistMaxS];
+  __shared__ double s4[4];
+  __shared__ int s_cols[16];
+  __shared__ int s_flag;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int S = P.S, C = P.C, G = Q.G, K = Q.K, KS = Q.KS, NB = Q.NB;
+  unsigned* fail = P.arrive + 3;
+
+  if ((int)blockIdx.x == G) { rig_persist_control(P, Q, smem_raw); return; }
 
   // ============================================================================= worker workgroup
   const int64_t fbase = (int64_t)blockIdx.x * 4;
@@ -3307,7 +3344,11 @@ __global__ __launch_bounds__(256) void k_rig_persist(RigDev P, RigPersistDev Q) 
       RPW_MARK(2);
       if (fw < P.F)
         for (int64_t g = P.fgoff[fw]; g < P.fgoff[fw + 1]; ++g)
-          rig_sweep_adj_body<1, true>(P, g, phase0 ? 0 : 1, cur, wlds, s_bc + 2 + S);
+          {
+            RigSweepIO io = rig_sweep_io_global(P, g, cur, phase0 ? cur : (cur ^ 1));
+            io.camrec = s_bc + 2 + S;
+            rig_sweep_adj_body<1, true>(P, g, phase0 ? 0 : 1, cur, wlds, io);
+          }
       __syncthreads();
       RPW_MARK(3);
     }
@@ -3381,6 +3422,428 @@ __global__ __launch_bounds__(256) void k_rig_persist(RigDev P, RigPersistDev Q) 
     RPW_MARK(8);
   }
   (void)lane; (void)radius;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The LEAN workers of the persistent rig solve (k_rig_persist_w; small rigs: at most 4 observed cameras, 18 shared
+// coordinates) with the control workgroup as a launch of its own beside them (k_rig_persist_ctl: rig_persist_control, on a
+// second stream -- it needs 230 registers a thread, the workers must stay under 128 to put SIXTEEN waves on a compute
+// unit). Same seams, same rows, same control as k_rig_persist; what differs is where a worker keeps its four frames:
+// in LDS -- poses, frame records, the 16 x 16 blocks and compact records of their groups (both buffers), Y, the Jacobi
+// scales -- and how it works on them: one WAVE PER GROUP in the sweep (sixteen at once; k_rig_persist: four, one after
+// the other), sixteen lanes per frame in the pose update, one wave per frame in the elimination, which builds the
+// compact row straight from a slot table (cc_intrinsics_persist.hip's way) instead of going through the partial-row layout.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRpwYS = 20;          // row stride of Y / Z (S + 1 <= 19 columns)
+constexpr int kRpwMaxK = 320;       // compact row entries
+enum { RPW_Y = 0, RPW_Z = 120, RPW_POSE = 240, RPW_FREC = 256, RPW_SP = 288, RPW_A = 296, RPW_GST = 328, RPW_FST = 336, RPW_HD0 = 338, RPW_ROW = 384,
+       RPW_TEAM = RPW_ROW + kRpwMaxK };   // per-team scratch (doubles)
+enum { RPW_BC = 0, RPW_AB = 160, RPW_SS = 184, RPW_SROW = 208, RPW_SLOT = 232 /* int[320] */, RPW_S16 = 392, RPW_INFO = 408 /* int[24] colinfo, int[16] group of (team, slot) */,
+       RPW_COLS = 428 /* int[8] */, RPW_WG = 440 };   // workgroup scratch (doubles)
+constexpr int rpw_lds_doubles(int teams) { return teams * (2048 + 512 + 1024 + RPW_TEAM) + RPW_WG; }
+
+// column sums over the G rows of a box, for a workgroup of NW waves (cf. rig_gather_cols; thread t < G polls row t)
+template <int NB, int NW>
+__device__ __forceinline__ bool rig_gather_cols_w(const u64* box, int G, int rowlen, const int* cols, int ncols, int maxcol, unsigned tag, double* s16, int* s_good,
+                                                  double* out, unsigned* fail, int tshift) {
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  if (tid == 0) *s_good = 1;
+  __syncthreads();
+  u64 lo[NB], hi[NB];
+  bool good = true;
+  if (tid < G) {
+    const long long t0 = wall_clock64();
+    for (unsigned spins = 0;; ++spins) {
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int c = cols[j < ncols ? j : 0];
+        const u64* p = box + ((size_t)tid * rowlen + c) * 2;
+        lo[j] = ag_ld(p);
+        hi[j] = ag_ld(p + 1);
+        ok = ok && (j >= ncols || ((unsigned)(lo[j] >> 32) == tag && (unsigned)(hi[j] >> 32) == tag));
+      }
+      if (ok) break;
+      if ((spins & 63u) == 63u && (timed_out(t0, tshift) || ag_ld32(fail) != 0u)) { good = false; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  if (!good) *s_good = 0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    if (j < ncols) {   // (uniform)
+      const double v = (tid < G && good) ? ungranule(lo[j], hi[j]) : 0.0;
+      const bool is_max = cols[j] == maxcol;
+      const double w = is_max ? wave_max(v) : wave_sum(v);
+      __syncthreads();
+      if ((tid & 63) == 0) s16[tid >> 6] = w;
+      __syncthreads();
+      double r = s16[0];
+#pragma unroll
+      for (int u = 1; u < NW; ++u) r = is_max ? fmax(r, s16[u]) : r + s16[u];
+      out[j] = r;
+    }
+  }
+  __syncthreads();
+  return *s_good != 0;
+}
+
+// (workgroups of a launch go round the eight XCDs, and a workgroup never moves: with G = 250 workers XCDs 0 and 1 hold 32 of
+// them -- every compute unit -- so the control workgroup must be one that lands on another XCD: the LAST block of this
+// launch of (G mod 8) + 1 blocks; the others leave at once)
+__global__ __launch_bounds__(256) void k_rig_persist_ctl(RigDev P, RigPersistDev Q) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (blockIdx.x + 1 != gridDim.x) return;
+  rig_persist_control(P, Q, smem_raw);
+}
+
+template <int TEAMS>
+__global__ __launch_bounds__(TEAMS * 256) void k_rig_persist_w(RigDev P, RigPersistDev Q) {
+  extern __shared__ __attribute__((aligned(16))) double rpw_lds[];
+  constexpr int NT = TEAMS * 256;           // threads
+  double* s_tile = rpw_lds;                 // [TEAMS][4 slots][2][256]
+  double* s_comp = s_tile + TEAMS * 2048;   // [TEAMS][4][2][64]
+  double* s_sw = s_comp + TEAMS * 512;      // [TEAMS * 4 waves][256] sweep scratch
+  double* s_tm = s_sw + TEAMS * 1024;       // [TEAMS][RPW_TEAM]
+  double* s_wg = s_tm + TEAMS * RPW_TEAM;   // [RPW_WG]
+  const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6), team = wave >> 2, twave = wave & 3, lane = tid0 & 63;
+  const int S = P.S, SW = P.SW, CO = P.CO, G = Q.G, K = Q.K, KS = Q.KS, NB = Q.NB;
+  unsigned* fail = P.arrive + 3;
+  const int64_t f = (int64_t)blockIdx.x * TEAMS + team;
+  const bool has_frame = f < P.F;
+  const int g_mine = __builtin_amdgcn_readfirstlane((has_frame && twave < CO) ? P.fslot[f * CO + twave] : -1);   // the group this wave sweeps
+  double* tm = s_tm + team * RPW_TEAM;
+  double* s_bc = s_wg + RPW_BC;
+  double* s_a = s_wg + RPW_AB;
+  double* s_ss = s_wg + RPW_SS;
+  double* s_row = s_wg + RPW_SROW;
+  int* s_slot = reinterpret_cast<int*>(s_wg + RPW_SLOT);
+  double* s16 = s_wg + RPW_S16;
+  int* s_info = reinterpret_cast<int*>(s_wg + RPW_INFO);   // [0..23] colinfo, [24..39] group of (team, slot)
+  int* s_cols = reinterpret_cast<int*>(s_wg + RPW_COLS);
+  int* s_good = s_cols + 8;
+  // ---- start of the solve: poses of the workgroup's frames (buffer 0 holds the starting point: rig_begin), tables
+  for (int i = tid0; i < TEAMS * (2048 + 512); i += NT) s_tile[i] = 0.0;
+  for (int i = tid0; i < TEAMS * RPW_TEAM; i += NT) s_tm[i] = 0.0;
+  for (int i = tid0; i < K; i += NT) s_slot[i] = Q.slots[i];
+  if (tid0 < SW) s_info[tid0] = P.colinfo[tid0];
+  if (tid0 >= 64 && tid0 < 64 + 4 * TEAMS) {
+    const int t = (tid0 - 64) >> 2, j = (tid0 - 64) & 3;
+    const int64_t ff = (int64_t)blockIdx.x * TEAMS + t;
+    s_info[24 + t * 4 + j] = (ff < P.F && j < CO) ? P.fslot[ff * CO + j] : -1;
+  }
+  __syncthreads();
+  if (has_frame && twave == 0 && lane < 8) {
+    const double v = lane < 7 ? P.pose[(size_t)f * 8 + lane] : 0.0;
+    tm[RPW_POSE + lane] = v;
+    tm[RPW_POSE + 8 + lane] = v;
+  }
+  __syncthreads();
+  int cur = 0;
+  double radius = 1.0;
+  for (int round = 0; round < Q.max_rounds; ++round) {
+    const unsigned e = Q.epoch0 + (unsigned)round + 1u;
+    const bool phase0 = round == 0;
+    // ---- broadcast B: step and camera records
+    RPW_MARK(0);
+    if (wave == 0 && !rig_bcast_wait(Q.ybox, e, NB, s_bc, fail, Q.timeout_shift)) s_bc[0] = 1.0;
+    __syncthreads();
+    const int flb = (int)s_bc[0];
+    RPW_MARK(1);
+    if (flb & 1) { cur = (flb >> 3) & 1; break; }
+    cur = (flb >> 3) & 1;
+    const bool swept = (flb & 2) != 0;
+    const int dst = phase0 ? cur : (cur ^ 1);
+    if (swept) {
+      // ---- pose update of the frame (rig_update_body's arithmetic): sixteen lanes of the team's first wave
+      int ul = tid0 & 63;
+      asm volatile("" : "+v"(ul));
+      if (has_frame && twave == 0 && ul < 16) {
+        const int lane = ul;
+        double u[6] = {0, 0, 0, 0, 0, 0};
+        if (!phase0) {
+          for (int k = lane; k < SW; k += 16) {
+            const double d = k < S ? s_bc[2 + k] : 1.0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) u[i] += tm[RPW_Y + i * kRpwYS + k] * d;
+          }
+#pragma unroll
+          for (int i = 0; i < 6; ++i) u[i] = row16_sum(u[i]);
+        }
+        if (lane == 0) {
+          bool active = false;
+          for (int j = 0; j < 4; ++j) active = active || s_info[24 + team * 4 + j] >= 0;
+          double q[4], t[3], dp[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) q[i] = tm[RPW_POSE + cur * 8 + i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) t[i] = tm[RPW_POSE + cur * 8 + 4 + i];
+          double step2 = 0.0;
+          if (!phase0) {
+            if (active) {
+#pragma unroll
+              for (int i = 0; i < 6; ++i) dp[i] = -u[i] * tm[RPW_SP + i];
+              double qn[4];
+              quat_plus(q, dp, qn);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) { const double d = qn[i] - q[i]; step2 += d * d; q[i] = qn[i]; }
+#pragma unroll
+              for (int i = 0; i < 3; ++i) { const double tn = t[i] + dp[3 + i]; const double d = tn - t[i]; step2 += d * d; t[i] = tn; }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tm[RPW_POSE + dst * 8 + i] = q[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) tm[RPW_POSE + dst * 8 + 4 + i] = t[i];
+          }
+          double R[9];
+          quat_to_R(q, R);
+#pragma unroll
+          for (int i = 0; i < 9; ++i) tm[RPW_FREC + i] = R[i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) tm[RPW_FREC + 9 + i] = t[i];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) tm[RPW_FREC + 12 + i] = dp[i];
+          tm[RPW_FST] = step2;
+          tm[RPW_FST + 1] = active ? q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + t[0] * t[0] + t[1] * t[1] + t[2] * t[2] : 0.0;
+        }
+      }
+      __syncthreads();
+      // ---- sweep: one wave per group
+      RPW_MARK(2);
+      if (g_mine >= 0) {
+        const RigSweepIO io{s_bc + 2 + S, tm + RPW_FREC, s_comp + ((team * 4 + twave) * 2 + cur) * 64, s_tile + ((team * 4 + twave) * 2 + dst) * 256,
+                            s_comp + ((team * 4 + twave) * 2 + dst) * 64, tm + RPW_GST + 2 * twave, tm + RPW_HD0 + 8 * twave};
+        rig_sweep_adj_body<1, true>(P, g_mine, phase0 ? 0 : 1, cur, s_sw + wave * 256, io);
+      }
+      __syncthreads();
+      RPW_MARK(3);
+    }
+    // ---- statistics row of the workgroup (teams and slots in order)
+    {
+      int tid = tid0;
+      asm volatile("" : "+v"(tid));
+      if (tid == 0) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        if (swept) {
+          for (int t = 0; t < TEAMS; ++t) {
+            for (int j = 0; j < 4; ++j)
+              if (s_info[24 + t * 4 + j] >= 0) { a0 += s_tm[t * RPW_TEAM + RPW_GST + 2 * j]; a1 += s_tm[t * RPW_TEAM + RPW_GST + 2 * j + 1]; }
+            if ((int64_t)blockIdx.x * TEAMS + t < P.F) { a2 += s_tm[t * RPW_TEAM + RPW_FST]; a3 += s_tm[t * RPW_TEAM + RPW_FST + 1]; }
+          }
+        }
+        s_row[0] = a0; s_row[1] = a1; s_row[2] = a2; s_row[3] = a3;
+      }
+      if (phase0 && tid >= 64 && tid < 64 + S) {   // diagonal of H_cc per shared column (Jacobi scaling)
+        const int k = tid - 64, info = s_info[k], j = info >> 8, comp = info & 15;
+        double d = 0.0;
+        for (int t = 0; t < TEAMS; ++t)
+          if (s_info[24 + t * 4 + j] >= 0) d += s_tm[t * RPW_TEAM + RPW_HD0 + 8 * j + comp];
+        s_row[4 + k] = d;
+      }
+      __syncthreads();
+      const int nst = phase0 ? KS : 4;
+      if (tid < 2 * nst) ag_st(Q.sbox + ((size_t)blockIdx.x * KS) * 2 + tid, granule(e, s_row[tid >> 1], tid & 1));
+    }
+    RPW_MARK(4);
+    // ---- the assumed decision (cf. cc_intrinsics_persist.hip): candidate accepted, radius at its clamp -- the normal outcome of a
+    // step that works. The workers eliminate the candidate NOW, next to the control's gathering and deciding; when the
+    // decision is what was assumed (broadcast A says so) the rows are already where the control looks for them.
+    const bool spec = !phase0 && swept;
+    const double radius_spec = persist_spec_radius(radius, P.opts->max_radius);
+    auto eliminate_and_post = [&](const int cur_e, const double radius_e, const bool first_e, u64* rowbox, u64* colbox, const bool is_spec) {
+    // ---- elimination of the frame: the team's first wave
+    if (twave == 0) {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      double* rowt = tm + RPW_ROW;
+      bool exists[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) exists[j] = has_frame && s_info[24 + team * 4 + j] >= 0;
+      const bool live = exists[0] || exists[1] || exists[2] || exists[3];
+      const double* T0 = s_tile + ((team * 4) * 2 + cur_e) * 256;   // slot j: T0 + j * 512
+      bool ok = true;
+      double gmaxp = 0.0;
+      if (live) {
+        // frame block A = sum over the groups: lanes 0..26 (21 entries of H_ff, 6 of g_f)
+        if (ln < 27) {
+          int a_off;
+          if (ln < 21) { int i = 0; while (tri(i + 1, 0) <= ln) ++i; a_off = (6 + i) * 16 + 6 + (ln - tri(i, 0)); }
+          else a_off = (6 + (ln - 21)) * 16 + 12;
+          double a_e = 0.0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a_e += exists[j] ? T0[j * 512 + a_off] : 0.0;
+          tm[RPW_A + ln] = a_e;
+        }
+        wave_lds_fence();
+        const bool jac = P.opts->jacobi_scaling != 0;
+        const double mn = P.opts->min_lm_diagonal, mx = P.opts->max_lm_diagonal;
+        const double inv_radius = 1.0 / radius_e;
+        double sf[6], L[21], Li[6], gf[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) gf[i] = tm[RPW_A + 21 + i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int j = 0; j <= i; ++j) L[tri(i, j)] = tm[RPW_A + tri(i, j)];
+        if (first_e) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) sf[i] = jac ? 1.0 / (1.0 + sqrt(L[tri(i, i)])) : 1.0;
+          if (ln < 6) {
+            double sl = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) sl = ln == i ? sf[i] : sl;
+            tm[RPW_SP + ln] = sl;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) sf[i] = tm[RPW_SP + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int j = 0; j <= i; ++j) L[tri(i, j)] = sf[i] * L[tri(i, j)] * sf[j];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) L[tri(i, i)] += clampd(L[tri(i, i)], mn, mx) * inv_radius;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          double d = L[tri(j, j)];
+#pragma unroll
+          for (int k = 0; k < j; ++k) d -= L[tri(j, k)] * L[tri(j, k)];
+          ok = ok && (d > 0.0) && isfinite(d);
+          const double inv = rsqrt(d);
+          L[tri(j, j)] = d * inv;
+          Li[j] = inv;
+#pragma unroll
+          for (int i = j + 1; i < 6; ++i) {
+            double a = L[tri(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) a -= L[tri(i, k)] * L[tri(j, k)];
+            L[tri(i, j)] = a * inv;
+          }
+        }
+        {   // the frame's share of Ceres' gradient_max_norm (pose_grad_proj_max, cc_common.hpp)
+          double q4[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) q4[i] = tm[RPW_POSE + cur_e * 8 + i];
+          gmaxp = pose_grad_proj_max(q4, gf);
+        }
+        // the factor is the same in every lane: scalar registers from here on
+#pragma unroll
+        for (int i = 0; i < 21; ++i) L[i] = rfl(L[i]);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { Li[i] = rfl(Li[i]); sf[i] = rfl(sf[i]); }
+        if (ln < SW) {   // shared column ln (ln == S: the right-hand side)
+          const int info = s_info[ln], kind = (info >> 4) & 15, j = info >> 8, comp = info & 15;
+          const double sc = ln < S ? s_ss[ln] : 1.0;
+          const double* Tj = T0 + (kind == 0 ? j : 0) * 512;
+          const bool ex = kind == 0 && ((j == 0 && exists[0]) || (j == 1 && exists[1]) || (j == 2 && exists[2]) || (j == 3 && exists[3]));
+          double z[6], y[6];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            const double w = Tj[comp * 16 + 6 + i];
+            double a = kind == 3 ? sf[i] * gf[i] : (ex ? sf[i] * w * sc : 0.0);
+#pragma unroll
+            for (int k = 0; k < i; ++k) a -= L[tri(i, k)] * z[k];
+            z[i] = a * Li[i];
+          }
+#pragma unroll
+          for (int i = 5; i >= 0; --i) {
+            double a = z[i];
+#pragma unroll
+            for (int k = i + 1; k < 6; ++k) a -= L[tri(k, i)] * y[k];
+            y[i] = a * Li[i];
+          }
+#pragma unroll
+          for (int i = 0; i < 6; ++i) { tm[RPW_Z + i * kRpwYS + ln] = z[i]; tm[RPW_Y + i * kRpwYS + ln] = y[i]; }
+        }
+        wave_lds_fence();
+      }
+      // the frame's compact row, slot k on lane k mod 64
+      for (int k = ln; k < K; k += 64) {
+        const int code = s_slot[k];
+        double v = 0.0;
+        if (live) {
+          if (code == -1) v = ok ? 0.0 : 1.0;
+          else if (code == -2) v = gmaxp;
+          else if (code & (1 << 30)) {
+            const int pcol = (code >> 8) & 255, qcol = code & 255;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) v += tm[RPW_Z + i * kRpwYS + pcol] * tm[RPW_Z + i * kRpwYS + qcol];
+          } else {
+            const int j = code >> 16;
+            const bool ex = (j == 0 && exists[0]) || (j == 1 && exists[1]) || (j == 2 && exists[2]) || (j == 3 && exists[3]);
+            v = ex ? T0[j * 512 + (code & 0xffff)] : 0.0;
+          }
+        }
+        rowt[k] = v;
+      }
+    }
+    __syncthreads();
+    // ---- the workgroup's row (teams in order) -> granules
+    if (!is_spec) RPW_MARK(6); else RPW_MARK(9);
+    {
+      int tid = tid0;
+      asm volatile("" : "+v"(tid));
+      for (int k = tid; k < K; k += NT) {
+        double v = s_tm[RPW_ROW + k];
+        for (int t = 1; t < TEAMS; ++t) {
+          const double w = s_tm[t * RPW_TEAM + RPW_ROW + k];
+          v = k == K - 1 ? fmax(v, w) : v + w;
+        }
+        u64* q = rowbox + ((size_t)blockIdx.x * K + k) * 2;
+        ag_st(q, granule(e, v, 0));
+        ag_st(q + 1, granule(e, v, 1));
+      }
+    }
+    if (!is_spec) RPW_MARK(7); else RPW_MARK(10);
+    // ---- this workgroup's share of the column sums: columns b, b + G, ...
+    for (int c0 = (int)blockIdx.x; c0 < K; c0 += 8 * G) {
+      int tidc = tid0;
+      asm volatile("" : "+v"(tidc));
+      if (tidc < 8) s_cols[tidc] = c0 + tidc * G < K ? c0 + tidc * G : c0;
+      __syncthreads();
+      int nc = 0;
+      for (int j = 0; j < 8; ++j) nc += c0 + j * G < K ? 1 : 0;
+      double out8[8];
+      const bool okg = rig_gather_cols_w<8, TEAMS * 4>(rowbox, G, K, s_cols, nc, K - 1, e, s16, s_good, out8, fail, Q.timeout_shift);
+      if (!okg && tidc == 0) __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (okg && tidc < 2 * nc) {
+        const int j = tidc >> 1;
+        double v = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v = j == u ? out8[u] : v;
+        ag_st(colbox + (size_t)s_cols[j] * 2 + (tidc & 1), granule(e, v, tidc & 1));
+      }
+      __syncthreads();
+    }
+    };
+    if (spec) eliminate_and_post(dst, radius_spec, false, Q.pbox, Q.pcbox, true);
+    // ---- broadcast A: the decision
+    if (wave == 0 && !rig_bcast_wait(Q.abox, e, 2 + S, s_a, fail, Q.timeout_shift)) s_a[0] = 1.0;
+    __syncthreads();
+    const int fla = (int)s_a[0];
+    RPW_MARK(5);
+    if (fla & 1) { cur = (fla >> 3) & 1; break; }
+    if (fla & 4) {   // the assumption held
+      cur = dst;
+      radius = radius_spec;
+    } else {
+      cur = (fla >> 3) & 1;
+      radius = s_a[1];
+      {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        if (phase0 && tid < S) s_ss[tid] = s_a[2 + tid];
+      }
+      __syncthreads();
+      eliminate_and_post(cur, radius, phase0, Q.rbox, Q.cbox, false);
+    }
+    RPW_MARK(8);
+  }
+  // ---- the solve is over: the frame's accepted pose goes back to global memory (cc_rig_get_state, the next solve)
+  __syncthreads();
+  if (ag_ld32(fail) == 0u && has_frame && twave == 0 && lane < 7) P.pose[((size_t)cur * P.F + f) * 8 + lane] = tm[RPW_POSE + cur * 8 + lane];
 }
 
 // creation: world point of every observation
@@ -3467,8 +3930,15 @@ struct cc_rig {
   std::vector<int64_t> fgoff_h;
   size_t elim_lds = 0, solve_lds = 0;
   bool big = false;             // 128 <= S <= 255: the plain kernels (k_rig_elim_big, k_rig_solve_big), no exchange
-  bool persist_allowed = false; // CC_RIG_PERSIST=1: the persistent per-solve kernel where it fits (an experiment: slower than the three kernels, see k_rig_persist)
+  bool persist_allowed = false; // CC_RIG_PERSIST=1: also the GLUED persistent kernel (k_rig_persist) where the lean one does not fit -- an experiment: slower
+                                //   than the three kernels; CC_RIG_PERSIST=0: no persistent kernel at all (the lean form is on by default)
+  bool persist_lean_allowed = true;
+  double* d_cam_backup = nullptr;   // [C][8] cameras of the starting point (the lean persistent solve may be run again in the three-kernel form)
   bool persist_ok = false;      // k_rig_persist can run this problem (poses only, <= 4 frames per compute unit, everything resident)
+  int p_teams = 4;              // frames per workgroup of the lean form
+  bool persist_w_ok = false;    // ... and so can its lean form (k_rig_persist_w + k_rig_persist_ctl: <= 4 observed cameras, <= 18 shared coordinates)
+  hipStream_t stream2 = nullptr;   // the control workgroup's launch of the lean form
+  hipEvent_t ev_begin = nullptr;
   cc::RigPersistDev pq{};
   unsigned p_epoch = 0;         // tags handed out so far
   size_t p_box_words = 0;       // seam boxes: one allocation of this many 8-byte words (re-zeroed before the tags wrap)
@@ -3543,7 +4013,7 @@ struct RigProbe {  // optional hipEvent bracket around one launch
 // them. Called by create (with the locally observed cameras) and again by the multi-GPU attach calls when
 // another rank observes a camera this one does not.
 static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
-  if (const char* e = getenv("CC_RIG_PERSIST")) h->persist_allowed = atoi(e) != 0;
+  if (const char* e = getenv("CC_RIG_PERSIST")) { h->persist_allowed = atoi(e) != 0; h->persist_lean_allowed = atoi(e) != 0; }
   RigDev& d = h->d;
   const int64_t C = h->C, F = h->F;
   const int kmode = h->kmode;
@@ -3713,7 +4183,7 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
   // ---- the persistent per-solve kernel (k_rig_persist): poses only, four frames per compute unit, every workgroup resident
   h->persist_ok = false;
-  if (!kmode && h->persist_allowed && S >= 1 && S <= kRigPersistMaxS && C <= kRigPersistMaxC && F <= 4 * 256) {
+  if (!kmode && (h->persist_allowed || h->persist_lean_allowed) && S >= 1 && S <= kRigPersistMaxS && C <= kRigPersistMaxC && F <= 4 * 256) {
     std::vector<int32_t> comp;
     for (size_t i = 0; i < tile_dst.size(); ++i) if (tile_dst[i] != -1) comp.push_back((int32_t)i);
     for (int e = 0; e < d.ND; ++e) if (dir_dst[(size_t)e] != -1) comp.push_back(d.pc_dir + e);
@@ -3721,12 +4191,38 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
     comp.push_back(d.pc_gmax);
     RigPersistDev& q = h->pq;
     q.G = (int32_t)((F + 3) / 4); q.K = (int32_t)comp.size(); q.KS = 4 + S; q.NB = 2 + S + 32 * (int32_t)C;
+    // the lean form (k_rig_persist_w) takes the fewest frames per workgroup that still leave every XCD a compute unit for the
+    // control workgroup: fewer frames per compute unit = more of the chip in the sweep
+    const bool lean_shape = CO <= 4 && S <= 18 && (int)comp.size() <= kRpwMaxK;
+    h->p_teams = 4;
+    if (lean_shape) {
+      for (int t : {1, 2, 4}) if ((F + t - 1) / t <= 255) { h->p_teams = t; break; }   // (G = 256 would fill every XCD: no compute unit for the control)
+      q.G = (int32_t)((F + h->p_teams - 1) / h->p_teams);
+    }
     if (int rc = dev_upload(h, &q.comp, comp)) return rc;
-    const size_t n_s = (size_t)q.G * q.KS * 2, n_a = (size_t)(2 + S) * 2, n_r = (size_t)q.G * q.K * 2, n_c = (size_t)q.K * 2, n_y = (size_t)q.NB * 2;
+    {   // the same entries as the lean workers build them (k_rig_persist_w)
+      std::vector<int32_t> slots(comp.size());
+      for (size_t k = 0; k + 2 < comp.size(); ++k) {
+        const int i = comp[k];
+        if (i < d.pc_dir) {
+          const int t = i / 256, r = (i % 256) / 16, c2 = i % 16;
+          slots[k] = (1 << 30) | ((16 * ti[(size_t)t] + r) << 8) | (16 * tj[(size_t)t] + c2);
+        } else {
+          const int e = i - d.pc_dir;
+          slots[k] = ((e / DE) << 16) | (int)(uint16_t)dmap[(size_t)(e % DE)];
+        }
+      }
+      slots[comp.size() - 2] = -1;
+      slots[comp.size() - 1] = -2;
+      if (int rc = dev_upload(h, &q.slots, slots)) return rc;
+    }
+    const int Gmax = (int)std::max<int64_t>(q.G, (F + 3) / 4);   // (the glued form always has four frames per workgroup)
+    const size_t n_s = (size_t)Gmax * q.KS * 2, n_a = (size_t)(2 + S) * 2, n_r = (size_t)Gmax * q.K * 2, n_c = (size_t)q.K * 2, n_y = (size_t)q.NB * 2;
     u64* base = nullptr;
-    h->p_box_words = n_s + n_a + n_r + n_c + n_y;
+    h->p_box_words = n_s + n_a + 2 * n_r + 2 * n_c + n_y;
     if (int rc = dev_zeroed(h, &base, h->p_box_words)) return rc;
     q.sbox = base; q.abox = q.sbox + n_s; q.rbox = q.abox + n_a; q.cbox = q.rbox + n_r; q.ybox = q.cbox + n_c;
+    q.pbox = q.ybox + n_y; q.pcbox = q.pbox + n_r;
     h->p_epoch = 0;
     const size_t pl = std::max(h->elim_lds, h->solve_lds);
     const bool small = d.ND <= 8 * 64;
@@ -3739,7 +4235,24 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
     if (e1 == hipSuccess) e1 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
     if (e1 != hipSuccess) (void)hipGetLastError();
     // one workgroup per compute unit is what the kernel is built for (its elimination uses most of a CU's registers)
-    h->persist_ok = e1 == hipSuccess && per_cu >= 1 && q.G + 1 <= cus;
+    h->persist_ok = h->persist_allowed && e1 == hipSuccess && per_cu >= 1 && (F + 3) / 4 + 1 <= cus;
+    if (!h->d_cam_backup) { if (int rc = dev_zeroed(h, &h->d_cam_backup, (size_t)C * 8)) return rc; }
+    h->persist_w_ok = false;
+    if (e1 == hipSuccess && lean_shape && q.G <= 255 && cus >= 256) {
+      int pw = 0;
+      const int lb = rpw_lds_doubles(h->p_teams) * 8;
+      const void* kw = h->p_teams == 1 ? reinterpret_cast<const void*>(k_rig_persist_w<1>) : h->p_teams == 2 ? reinterpret_cast<const void*>(k_rig_persist_w<2>)
+                                                                                           : reinterpret_cast<const void*>(k_rig_persist_w<4>);
+      hipError_t e2 = hipFuncSetAttribute(kw, hipFuncAttributeMaxDynamicSharedMemorySize, lb);
+      if (e2 == hipSuccess) e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_persist_ctl), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
+      if (e2 == hipSuccess)
+        e2 = h->p_teams == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&pw, k_rig_persist_w<1>, 256, (size_t)lb)
+           : h->p_teams == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&pw, k_rig_persist_w<2>, 512, (size_t)lb)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&pw, k_rig_persist_w<4>, 1024, (size_t)lb);
+      if (e2 != hipSuccess) (void)hipGetLastError();
+      h->persist_w_ok = h->persist_lean_allowed && e2 == hipSuccess && pw >= 1;
+    }
+    if (!h->persist_w_ok) q.G = (int32_t)((F + 3) / 4);
   }
   rig_drop_graphs(h);
   return 0;
@@ -4147,6 +4660,8 @@ void cc_rig_destroy(cc_rig* h) {
   hipSetDevice(h->device);
   bool stream_ok = true;
   if (h->stream) stream_ok = hipStreamSynchronize(h->stream) == hipSuccess;
+  if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
+  if (h->ev_begin) hipEventDestroy(h->ev_begin);
   cc::rig_drop_graphs(h);
   for (auto e : h->events) hipEventDestroy(e);
   if (h->comm) cc::comm_destroy(h->comm);
@@ -4222,7 +4737,9 @@ namespace cc {
 struct RigRun {
   cc_options o;
   bool profile = false, use_graph = false;
-  bool persist = false;   // this solve runs as ONE launch of k_rig_persist
+  bool persist = false;   // this solve runs as ONE launch of k_rig_persist / k_rig_persist_w
+  bool no_persist = false;   // (a rerun after that launch could not get its workgroups resident)
+  bool rerun = false;        // set by rig_wait: the lean persistent launch gave up, nothing was written back
   int launched = 0;
   LmCtl st{};
   std::chrono::steady_clock::time_point t0;
@@ -4256,6 +4773,7 @@ static int rig_begin(cc_rig* h, const cc_options* opt, RigRun* r) {
     h->opts_valid = true;
   }
   if (int rc = rig_size_reduce_grid(h)) return rc;
+  if (h->stream2) CC_HIP(hipStreamSynchronize(h->stream2));   // (the control launch of a previous lean persistent solve: long over, but not on h->stream)
   // fresh control block (both copies) and synchronisation words -- counters, flag word, failure word: a failed solve may
   // have left any of them behind -- in ONE fill (they are one piece of memory, rig_create_impl)
   CC_HIP(hipMemsetAsync(h->d.ctl, 0, 2 * sizeof(LmCtl) + 16 * sizeof(unsigned), h->stream));
@@ -4268,7 +4786,7 @@ static int rig_begin(cc_rig* h, const cc_options* opt, RigRun* r) {
 
 static int rig_launch(cc_rig* h, RigRun* r, int chunk) {
   CC_HIP(hipSetDevice(h->device));
-  if (chunk == 0 && h->persist_ok && h->sweep_adjoint && !r->profile && !h->comm && !h->exchange && !h->big && h->co_resident <= 1) {
+  if (chunk == 0 && !r->no_persist && (h->persist_ok || h->persist_w_ok) && h->sweep_adjoint && !r->profile && !h->comm && !h->exchange && !h->big && h->co_resident <= 1) {
     // the whole solve in one launch (k_rig_persist); the control workgroup publishes when it is over
     RigPersistDev q = h->pq;
     q.max_rounds = r->o.max_iterations + 2;
@@ -4279,10 +4797,31 @@ static int rig_launch(cc_rig* h, RigRun* r, int chunk) {
     }
     q.epoch0 = h->p_epoch;
     h->p_epoch += (unsigned)q.max_rounds + 2u;
-    const size_t pl = std::max(h->elim_lds, h->solve_lds);
-    const dim3 grid((unsigned)q.G + 1u);
-    if (h->d.ND <= 8 * 64) hipLaunchKernelGGL(k_rig_persist<8>, grid, dim3(256), pl, h->stream, h->d, q);
-    else hipLaunchKernelGGL(k_rig_persist<kRigDirectPerLane>, grid, dim3(256), pl, h->stream, h->d, q);
+    static const bool lean = !(getenv("CC_RIG_PERSIST_LEAN") && atoi(getenv("CC_RIG_PERSIST_LEAN")) == 0);
+    if (h->persist_w_ok && lean) {
+      // lean workers (sixteen waves a compute unit) + the control workgroup as a launch of its own on a second stream, behind
+      // everything rig_begin put on the first
+      CC_HIP(hipMemcpyAsync(h->d_cam_backup, h->d.cam, (size_t)h->C * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+      if (!h->stream2) CC_HIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+      if (!h->ev_begin) CC_HIP(hipEventCreateWithFlags(&h->ev_begin, hipEventDisableTiming));
+      CC_HIP(hipEventRecord(h->ev_begin, h->stream));
+      CC_HIP(hipStreamWaitEvent(h->stream2, h->ev_begin, 0));
+      static const bool drop_control = getenv("CC_RIG_PERSIST_TEST_NO_CONTROL") && atoi(getenv("CC_RIG_PERSIST_TEST_NO_CONTROL")) != 0;   // (test hook: the workers' first wait gives up)
+      if (!drop_control)
+        hipLaunchKernelGGL(k_rig_persist_ctl, dim3((unsigned)(q.G % 8) + 1u), dim3(256), h->solve_lds, h->stream2, h->d, q);
+
+      const size_t lb = (size_t)rpw_lds_doubles(h->p_teams) * 8;
+      if (h->p_teams == 1) hipLaunchKernelGGL(k_rig_persist_w<1>, dim3((unsigned)q.G), dim3(256), lb, h->stream, h->d, q);
+      else if (h->p_teams == 2) hipLaunchKernelGGL(k_rig_persist_w<2>, dim3((unsigned)q.G), dim3(512), lb, h->stream, h->d, q);
+      else hipLaunchKernelGGL(k_rig_persist_w<4>, dim3((unsigned)q.G), dim3(1024), lb, h->stream, h->d, q);
+    } else {
+      q.G = (int32_t)((h->F + 3) / 4);
+      q.pbox = nullptr; q.pcbox = nullptr;   // (its workers wait for every decision)
+      const size_t pl = std::max(h->elim_lds, h->solve_lds);
+      const dim3 grid((unsigned)q.G + 1u);
+      if (h->d.ND <= 8 * 64) hipLaunchKernelGGL(k_rig_persist<8>, grid, dim3(256), pl, h->stream, h->d, q);
+      else hipLaunchKernelGGL(k_rig_persist<kRigDirectPerLane>, grid, dim3(256), pl, h->stream, h->d, q);
+    }
     CC_HIP(hipGetLastError());
     r->persist = true;
     r->launched += q.max_rounds;
@@ -4310,7 +4849,10 @@ static int rig_wait(cc_rig* h, RigRun* r) {
   if (int rc = ((h->comm || h->big) ? rig_read_ctl(h, &r->st, &wait_failed) : rig_wait_published(h, &r->st, &wait_failed))) return rc;
   if (r->st.done) { h->last_st = r->st; h->st_known = true; }
   if (wait_failed && r->persist) {
-    h->persist_ok = false;   // (this handle runs the three-kernel form from now on: cc_rig_reset / set_state and solve again)
+    const bool was_lean = h->persist_w_ok;
+    h->persist_ok = false;   // (this handle runs the three-kernel form from now on)
+    h->persist_w_ok = false;
+    if (was_lean) { r->rerun = true; return 0; }   // (the lean form keeps the starting point intact: cc_rig_solve runs the solve again)
     return fail(CC_ERR_COMM, "k_rig_persist: a workgroup waited 1.3 s for another one (round %d): the launch was not fully resident "
                 "(%d workgroups; a device shared with another process?). The handle now runs the three-kernel form", r->st.iter, h->pq.G + 1);
   }
@@ -4369,6 +4911,24 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
   for (int chunk = 0;; ++chunk) {
     if (int rc = rig_launch(h, &r, chunk)) return rc;
     if (int rc = rig_wait(h, &r)) return rc;
+    if (r.rerun) {
+      // The lean persistent launch could not get every workgroup resident (a device shared with another process, or the
+      // control launch not scheduled next to the workers): a wait inside it gave up after 1.3 s. Frame poses go back to
+      // global memory only at the end of a solve that did not fail, and the cameras of the starting point were put
+      // aside: restore them and run the solve again, three kernels per iteration (no co-residency needed).
+      CC_HIP(hipStreamSynchronize(h->stream));
+      if (h->stream2) CC_HIP(hipStreamSynchronize(h->stream2));
+      CC_HIP(hipMemcpyAsync(h->d.cam, h->d_cam_backup, (size_t)h->C * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+      h->last_st = LmCtl{};   // (buffer 0 holds the starting point)
+      h->st_known = true;
+      h->pub_count = __atomic_load_n(const_cast<const unsigned long long*>(h->host_pub), __ATOMIC_ACQUIRE);
+      r = RigRun{};
+      r.no_persist = true;
+      if (int rc = rig_begin(h, opt, &r)) return rc;
+      r.no_persist = true;
+      chunk = -1;
+      continue;
+    }
     if (r.st.done) break;
   }
   return rig_finish(h, &r, summary);
@@ -4377,7 +4937,8 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
 int cc_rig_solver_form(cc_rig* h) {
   using namespace cc;
   if (!h) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_solver_form: NULL handle");
-  return (h->persist_ok && h->sweep_adjoint && !h->comm && !h->exchange && !h->big && h->co_resident <= 1) ? 1 : 0;
+  if (!((h->persist_ok || h->persist_w_ok) && h->sweep_adjoint && !h->comm && !h->exchange && !h->big && h->co_resident <= 1)) return 0;
+  return h->persist_w_ok ? 2 : 1;
 }
 
 int cc_rig_get_state(cc_rig* h, double* cam_q, double* cam_t, double* frame_q, double* frame_t, double* obs_cost) {

@@ -227,10 +227,14 @@ int cc_rig_set_state(cc_rig* h, const double* cam_q, const double* cam_t, const 
                      const double* frame_t);
 int cc_rig_reset(cc_rig* h);
 int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary);
-/* Which form cc_rig_solve runs (without profiling): 0 -- three kernels per LM iteration (sweep, decision + elimination,
- * reduce + solve step + pose update), any size, any exchange: the default; 1 -- the whole solve as ONE persistent kernel
- * launch (poses only, at most 1024 frames, 48 shared coordinates, 9 cameras, the device to itself): an experiment enabled by
- * CC_RIG_PERSIST=1, correct but slower. */
+/* Which form cc_rig_solve runs (without profiling):
+ *   2 -- the whole solve as ONE launch of the lean persistent kernel (+ its control workgroup's launch): poses only, at most 4
+ *        observed cameras, 18 shared coordinates, ~1020 frames, the device to itself; the default where it fits. If its
+ *        workgroups cannot all be resident the solve is run again in form 0 (same result, 1.3 s late, once per handle);
+ *   0 -- three kernels per LM iteration (sweep, decision + elimination, reduce + solve step + pose update): any size, any
+ *        exchange; CC_RIG_PERSIST=0 forces it;
+ *   1 -- the glued persistent kernel (poses only, <= 1024 frames, 48 shared coordinates, 9 cameras): an experiment enabled by
+ *        CC_RIG_PERSIST=1 where form 2 does not fit; correct but slower than form 0. */
 int cc_rig_solver_form(cc_rig* h);
 /* Any output may be NULL. obs_cost[k] = 1/2 rho(|r_k|^2) at the current point, in the caller's
  * observation order (extrinsics_calibrator.cpp:219-225). */

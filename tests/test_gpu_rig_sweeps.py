@@ -31,6 +31,7 @@ def _group_count(sc_or_k, cams):
 
 def _blocks_poses_only(monkeypatch, mfma, sc, cams, frozen, huber_a):
     monkeypatch.setenv("CC_RIG_SWEEP_MFMA", str(mfma))
+    monkeypatch.setenv("CC_RIG_PERSIST", "0")    # (the group blocks are read back from global memory: the lean persistent kernel keeps them in LDS)
     cq, ct = po.affine_to_qt(sc["cam_T"])
     fq, ft = po.affine_to_qt(sc["frame_T"])
     prob = capi.RigProblem(cams, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"], sc["world_xyz"], frozen, huber_a=huber_a)
