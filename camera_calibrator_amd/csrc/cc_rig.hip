@@ -1856,9 +1856,10 @@ __device__ __forceinline__ void store_ds(double* p, double v) {
 }
 
 struct RigVal {   // reader of reduced value e
-  const RigDev& P; unsigned long long epoch; long long t0; int* s_ok;
+  const RigDev& P; unsigned long long epoch; long long t0; int* s_ok; const double* lds_vec;
   template <int SRC>
   __device__ __forceinline__ double get(int e) const {
+    if (SRC == 3) return lds_vec[e];   // (persistent kernels: the control workgroup keeps the reduced row in LDS)
     if (SRC == 0) return P.vec[e];
     if (SRC == 1)
       return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(P.vec) + e,
@@ -2036,7 +2037,7 @@ __device__ __forceinline__ void chol_backward(const double* A, int S, int LD, do
 #endif
 
 template <int SRC>
-__device__ void rig_solve_block(const RigDev& P, double* smem, const LmCtl* cn_in = nullptr) {   // cn_in: the persistent kernel's control block (LDS)
+__device__ void rig_solve_block(const RigDev& P, double* smem, const LmCtl* cn_in = nullptr, const double* vec_lds = nullptr) {   // cn_in: the persistent kernels' control block (LDS); vec_lds: their reduced row (SRC 3)
   const int S = P.S, LD = (S + 1) | 1;   // odd row stride: a column walks all LDS banks
   double* A = smem;                       // [S][LD] lower triangle of the reduced system
   double* s_b = A + (size_t)S * LD;       // [128] right-hand side, then the solution x
@@ -2053,7 +2054,7 @@ __device__ void rig_solve_block(const RigDev& P, double* smem, const LmCtl* cn_i
   const int cur = cn->cur, dst = cur ^ 1;
   const double radius = cn->radius;
   const LmOpts o = *P.opts;
-  RigVal val{P, SRC == 2 ? P.x.seq[0] + 1ull : 0ull, wall_clock64(), &s_ok};
+  RigVal val{P, SRC == 2 ? P.x.seq[0] + 1ull : 0ull, wall_clock64(), &s_ok, vec_lds};
   if (tid == 0) { s_ok = 1; s_cholok = 1; s_stepok = 0; s_go = 0; s_c = *cn; }
   for (int i = tid; i < S * LD; i += 256) A[i] = 0.0;
   if (tid < 128) { s_b[tid] = 0.0; s_gs[tid] = 0.0; s_hd[tid] = 0.0; s_inv[tid] = 0.0; s_ss[tid] = tid < S ? P.ss[tid] : 0.0; }
@@ -2194,8 +2195,8 @@ __device__ void rig_solve_block(const RigDev& P, double* smem, const LmCtl* cn_i
       else solve_rows(std::integral_constant<int, 24>{});
       const bool fin = lane >= S || isfinite(xs);
       const bool step_ok = s_cholok != 0 && okw && __all(fin);
-      if (lane < S) { s_b[lane] = xs; store_ds(P.ds + lane, -xs); }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the update blocks of this launch read ds behind a flag
+      if (lane < S) { s_b[lane] = xs; if (SRC != 3) store_ds(P.ds + lane, -xs); }
+      if (SRC != 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the update blocks of this launch read ds behind a flag (SRC 3: the step travels in a broadcast)
       if (lane == 0) s_stepok = step_ok ? 1 : 0;
     }
     __syncthreads();
@@ -2330,9 +2331,9 @@ __device__ void rig_solve_block(const RigDev& P, double* smem, const LmCtl* cn_i
       else chol_backward<true>(A, S, LD, b0, b1, v0, v1);
       const bool fin = (i0 >= S || isfinite(b0)) && (i1 >= S || isfinite(b1));
       const bool step_ok = s_cholok != 0 && __all(okw) && __all(fin);
-      if (i0 < S) { s_b[i0] = b0; store_ds(P.ds + i0, -b0); }
-      if (i1 < S) { s_b[i1] = b1; store_ds(P.ds + i1, -b1); }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the update blocks of this launch read ds behind a flag
+      if (i0 < S) { s_b[i0] = b0; if (SRC != 3) store_ds(P.ds + i0, -b0); }
+      if (i1 < S) { s_b[i1] = b1; if (SRC != 3) store_ds(P.ds + i1, -b1); }
+      if (SRC != 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the update blocks of this launch read ds behind a flag
       if (lane == 0) s_stepok = step_ok ? 1 : 0;
     }
     __syncthreads();
@@ -3144,8 +3145,9 @@ __device__ __forceinline__ void rig_persist_control(const RigDev& P, const RigPe
     __shared__ double s_tot[4 + kRigPersistMaxS];
     __shared__ int s_has_rec, s_hit;
     double* smem = reinterpret_cast<double*>(smem_raw);
+    double* vl = smem + (size_t)S * ((S + 1) | 1) + 5 * 128;   // [PC + 32] the reduced row in the layout rig_solve_block reads, behind its own LDS
     if (tid == 0) s_ctl = *P.ctl;   // (zeros: rig_begin)
-    for (int i = tid; i < P.PC + 32; i += 256) P.vec[i] = 0.0;   // entries the compact rows never touch stay zero
+    for (int i = tid; i < P.PC + 32; i += 256) vl[i] = 0.0;   // entries the compact rows never touch stay zero
     __syncthreads();
     {   // records of the starting point (k_rig_records) -> broadcast B of round 0
       double a, b;
@@ -3263,8 +3265,8 @@ __device__ __forceinline__ void rig_persist_control(const RigDev& P, const RigPe
             const int k = k0 + 256 * u;
             if (k < K) {
               const double v = ungranule(lo[u], hi[u]);
-              if (k == K - 1) P.vec[P.PC + P.rank] = v;   // the gradient maximum rides in the rank's slot (k_rig_reduce)
-              else P.vec[Q.comp[k]] = v;
+              if (k == K - 1) vl[P.PC + P.rank] = v;   // the gradient maximum rides in the rank's slot (k_rig_reduce)
+              else vl[Q.comp[k]] = v;
             }
           }
         }
@@ -3275,7 +3277,7 @@ __device__ __forceinline__ void rig_persist_control(const RigDev& P, const RigPe
       RPC_MARK(4);
       if (tid == 0) { *P.ctl = s_ctl; *P.ctl_next = s_ctl; }   // (rig_solve_block finishes the record of this round in P.log)
       __syncthreads();
-      rig_solve_block<0>(P, smem, &s_ctl);
+      rig_solve_block<3>(P, smem, &s_ctl, vl);
       __syncthreads();
       RPC_MARK(5);
       if (tid == 0) s_ctl = *P.ctl;   // as the solve step left it (this workgroup wrote it)
@@ -4224,7 +4226,7 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
     q.sbox = base; q.abox = q.sbox + n_s; q.rbox = q.abox + n_a; q.cbox = q.rbox + n_r; q.ybox = q.cbox + n_c;
     q.pbox = q.ybox + n_y; q.pcbox = q.pbox + n_r;
     h->p_epoch = 0;
-    const size_t pl = std::max(h->elim_lds, h->solve_lds);
+    const size_t pl = std::max(h->elim_lds, h->solve_lds + (size_t)(d.PC + 32) * 8);
     const bool small = d.ND <= 8 * 64;
     int per_cu = 0, cus = 0;
     hipError_t e1 = small ? hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_persist<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl)
@@ -4244,7 +4246,7 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
       const void* kw = h->p_teams == 1 ? reinterpret_cast<const void*>(k_rig_persist_w<1>) : h->p_teams == 2 ? reinterpret_cast<const void*>(k_rig_persist_w<2>)
                                                                                            : reinterpret_cast<const void*>(k_rig_persist_w<4>);
       hipError_t e2 = hipFuncSetAttribute(kw, hipFuncAttributeMaxDynamicSharedMemorySize, lb);
-      if (e2 == hipSuccess) e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_persist_ctl), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds);
+      if (e2 == hipSuccess) e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_persist_ctl), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(h->solve_lds + (size_t)(d.PC + 32) * 8));
       if (e2 == hipSuccess)
         e2 = h->p_teams == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&pw, k_rig_persist_w<1>, 256, (size_t)lb)
            : h->p_teams == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&pw, k_rig_persist_w<2>, 512, (size_t)lb)
@@ -4808,7 +4810,7 @@ static int rig_launch(cc_rig* h, RigRun* r, int chunk) {
       CC_HIP(hipStreamWaitEvent(h->stream2, h->ev_begin, 0));
       static const bool drop_control = getenv("CC_RIG_PERSIST_TEST_NO_CONTROL") && atoi(getenv("CC_RIG_PERSIST_TEST_NO_CONTROL")) != 0;   // (test hook: the workers' first wait gives up)
       if (!drop_control)
-        hipLaunchKernelGGL(k_rig_persist_ctl, dim3((unsigned)(q.G % 8) + 1u), dim3(256), h->solve_lds, h->stream2, h->d, q);
+        hipLaunchKernelGGL(k_rig_persist_ctl, dim3((unsigned)(q.G % 8) + 1u), dim3(256), h->solve_lds + (size_t)(h->d.PC + 32) * 8, h->stream2, h->d, q);
 
       const size_t lb = (size_t)rpw_lds_doubles(h->p_teams) * 8;
       if (h->p_teams == 1) hipLaunchKernelGGL(k_rig_persist_w<1>, dim3((unsigned)q.G), dim3(256), lb, h->stream, h->d, q);
@@ -4817,7 +4819,7 @@ static int rig_launch(cc_rig* h, RigRun* r, int chunk) {
     } else {
       q.G = (int32_t)((h->F + 3) / 4);
       q.pbox = nullptr; q.pcbox = nullptr;   // (its workers wait for every decision)
-      const size_t pl = std::max(h->elim_lds, h->solve_lds);
+      const size_t pl = std::max(h->elim_lds, h->solve_lds + (size_t)(h->d.PC + 32) * 8);
       const dim3 grid((unsigned)q.G + 1u);
       if (h->d.ND <= 8 * 64) hipLaunchKernelGGL(k_rig_persist<8>, grid, dim3(256), pl, h->stream, h->d, q);
       else hipLaunchKernelGGL(k_rig_persist<kRigDirectPerLane>, grid, dim3(256), pl, h->stream, h->d, q);
