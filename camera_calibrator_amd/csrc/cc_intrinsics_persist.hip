@@ -59,53 +59,6 @@ enum { WG_INTR = 0 /* [2][16] */, WG_X = 64 /* the control's last broadcast: fla
        // source entry of the Gram block, the two columns of Z whose product is subtracted (| 1 << 16: there is one)
        WG_TGI = 416 /* int[80] */, WG_TZ = 456 /* int[80] */ };
 
-// ceres::QuaternionManifold::Plus with the series coefficients of cc::quat_plus (cc_common.hpp: same values, same
-// Horner order, same bits) read from constant memory through a pointer the compiler cannot see through: written as
-// literals they are hoisted out of the round loop -- sixteen 64-bit constants parked in vector registers across the
-// sweep's main loop, which promptly spills them.
-__constant__ double kPlusCoef[16] = {-1.0 / 2, 1.0 / 24, -1.0 / 720, 1.0 / 40320, -1.0 / 3628800, 1.0 / 479001600, -1.0 / 87178291200.0,
-                                     1.0 / 20922789888000.0,   // cos(n) - 1 in n^2
-                                     -1.0 / 6, 1.0 / 120, -1.0 / 5040, 1.0 / 362880, -1.0 / 39916800, 1.0 / 6227020800.0,
-                                     -1.0 / 1307674368000.0, 1.0 / 355687428096000.0};   // sin(n) / n - 1 in n^2
-__device__ __forceinline__ void quat_plus_tab(const double* x, const double* d, double* out) {
-  const double n2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-  if (n2 == 0.0) { out[0] = x[0]; out[1] = x[1]; out[2] = x[2]; out[3] = x[3]; return; }
-  double s, a0;
-  if (n2 < 0.0625) {
-    const double* c = kPlusCoef;
-    asm volatile("" : "+s"(c));
-    a0 = 1.0 + n2 * (c[0] + n2 * (c[1] + n2 * (c[2] + n2 * (c[3] + n2 * (c[4] + n2 * (c[5] + n2 * (c[6] + n2 * c[7])))))));
-    s = 1.0 + n2 * (c[8] + n2 * (c[9] + n2 * (c[10] + n2 * (c[11] + n2 * (c[12] + n2 * (c[13] + n2 * (c[14] + n2 * c[15])))))));
-  } else {
-    const double nd = sqrt(n2);
-    s = sin(nd) / nd;
-    a0 = cos(nd);
-  }
-  const double a1 = s * d[0], a2 = s * d[1], a3 = s * d[2];
-  out[0] = a0 * x[0] - a1 * x[1] - a2 * x[2] - a3 * x[3];
-  out[1] = a0 * x[1] + a1 * x[0] + a2 * x[3] - a3 * x[2];
-  out[2] = a0 * x[2] - a1 * x[3] + a2 * x[0] + a3 * x[1];
-  out[3] = a0 * x[3] + a1 * x[2] - a2 * x[1] + a3 * x[0];
-}
-
-// cc::pose_grad_proj_max (cc_common.hpp: same values, same order, same bits -- 1 - cos n is the negated Horner sum of the
-// negated coefficients) with the series read from the same table, for the same reason
-__device__ __forceinline__ double pose_grad_proj_max_tab(const double* q, const double* g) {
-  const double gt = fmax(fmax(fabs(g[3]), fabs(g[4])), fabs(g[5]));
-  const double n2 = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
-  if (!(n2 < 0.0625)) return fmax(gt, fmax(fmax(fabs(g[0]), fabs(g[1])), fabs(g[2])));
-  const double* c = kPlusCoef;
-  asm volatile("" : "+s"(c));
-  const double c1 = -(n2 * (c[0] + n2 * (c[1] + n2 * (c[2] + n2 * (c[3] + n2 * (c[4] + n2 * (c[5] + n2 * (c[6] + n2 * c[7]))))))));
-  const double s = 1.0 + n2 * (c[8] + n2 * (c[9] + n2 * (c[10] + n2 * (c[11] + n2 * (c[12] + n2 * (c[13] + n2 * (c[14] + n2 * c[15])))))));
-  const double w = q[0], v0 = q[1], v1 = q[2], v2 = q[3];
-  const double dw = c1 * w - s * (g[0] * v0 + g[1] * v1 + g[2] * v2);
-  const double d0 = c1 * v0 + s * (w * g[0] + (g[1] * v2 - g[2] * v1));
-  const double d1 = c1 * v1 + s * (w * g[1] + (g[2] * v0 - g[0] * v2));
-  const double d2 = c1 * v2 + s * (w * g[2] + (g[0] * v1 - g[1] * v0));
-  return fmax(fmax(gt, fabs(dw)), fmax(fmax(fabs(d0), fabs(d1)), fabs(d2)));
-}
-
 // Control workgroup, all 1024 threads: column sums (maximum for column `maxcol`) of the G rows of a box whose words
 // carry `tag`. Thread -> (column, row group): rows grp, grp + NG, ... are polled BATCH at a time (all 2 BATCH loads in
 // flight, unconditional from clamped rows; BATCH = what sixteen rows need where there are never more) and added in that order; the NG group sums are then added in group order.

@@ -3587,7 +3587,7 @@ __global__ __launch_bounds__(TEAMS * 256) void k_rig_persist_w(RigDev P, RigPers
 #pragma unroll
               for (int i = 0; i < 6; ++i) dp[i] = -u[i] * tm[RPW_SP + i];
               double qn[4];
-              quat_plus(q, dp, qn);
+              quat_plus_tab(q, dp, qn);   // (series coefficients from a table: as literals they are hoisted out of the round loop and spilled)
 #pragma unroll
               for (int i = 0; i < 4; ++i) { const double d = qn[i] - q[i]; step2 += d * d; q[i] = qn[i]; }
 #pragma unroll
@@ -3728,7 +3728,7 @@ __global__ __launch_bounds__(TEAMS * 256) void k_rig_persist_w(RigDev P, RigPers
           double q4[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) q4[i] = tm[RPW_POSE + cur_e * 8 + i];
-          gmaxp = pose_grad_proj_max(q4, gf);
+          gmaxp = pose_grad_proj_max_tab(q4, gf);
         }
         // the factor is the same in every lane: scalar registers from here on
 #pragma unroll
