@@ -3148,6 +3148,19 @@ __device__ __forceinline__ void rig_persist_control(const RigDev& P, const RigPe
     double* vl = smem + (size_t)S * ((S + 1) | 1) + 5 * 128;   // [PC + 32] the reduced row in the layout rig_solve_block reads, behind its own LDS
     if (tid == 0) s_ctl = *P.ctl;   // (zeros: rig_begin)
     for (int i = tid; i < P.PC + 32; i += 256) vl[i] = 0.0;   // entries the compact rows never touch stay zero
+    // the solve step's destination tables, copied to LDS once: rig_solve_block walks them every round, and here nothing
+    // but this workgroup's latency is on the critical path (flat loads of LDS addresses through the same RigDev fields)
+    RigDev Pc = P;
+    {
+      int32_t* t_tile = reinterpret_cast<int32_t*>(vl + P.PC + 32);
+      int32_t* t_dd = t_tile + P.nT * 256;
+      int32_t* t_dn = t_dd + P.ND;
+      int16_t* t_sa = reinterpret_cast<int16_t*>(t_dn + P.ND);
+      int16_t* t_sb = t_sa + P.ND;
+      for (int i = tid; i < P.nT * 256; i += 256) t_tile[i] = P.tile_dst[i];
+      for (int i = tid; i < P.ND; i += 256) { t_dd[i] = P.dir_dst[i]; t_dn[i] = P.dir_next[i]; t_sa[i] = P.dir_sa[i]; t_sb[i] = P.dir_sb[i]; }
+      Pc.tile_dst = t_tile; Pc.dir_dst = t_dd; Pc.dir_next = t_dn; Pc.dir_sa = t_sa; Pc.dir_sb = t_sb;
+    }
     __syncthreads();
     {   // records of the starting point (k_rig_records) -> broadcast B of round 0
       double a, b;
@@ -3277,7 +3290,7 @@ __device__ __forceinline__ void rig_persist_control(const RigDev& P, const RigPe
       RPC_MARK(4);
       if (tid == 0) { *P.ctl = s_ctl; *P.ctl_next = s_ctl; }   // (rig_solve_block finishes the record of this round in P.log)
       __syncthreads();
-      rig_solve_block<3>(P, smem, &s_ctl, vl);
+      rig_solve_block<3>(Pc, smem, &s_ctl, vl);
       __syncthreads();
       RPC_MARK(5);
       if (tid == 0) s_ctl = *P.ctl;   // as the solve step left it (this workgroup wrote it)
@@ -3897,6 +3910,11 @@ void comm_destroy(Comm* c);
 int comm_allreduce_sum(Comm* c, double* buf, int n, hipStream_t stream);
 }  // namespace cc
 
+// dynamic LDS of the persistent kernels' control workgroup: the solve step's, the reduced row, the destination tables
+static size_t rig_persist_ctl_lds(size_t solve_lds, const cc::RigDev& d) {
+  return solve_lds + (size_t)(d.PC + 32) * 8 + (((size_t)4 * (d.nT * 256 + 2 * d.ND) + (size_t)4 * d.ND + 7) & ~(size_t)7);
+}
+
 struct cc_rig {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -4226,7 +4244,7 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
     q.sbox = base; q.abox = q.sbox + n_s; q.rbox = q.abox + n_a; q.cbox = q.rbox + n_r; q.ybox = q.cbox + n_c;
     q.pbox = q.ybox + n_y; q.pcbox = q.pbox + n_r;
     h->p_epoch = 0;
-    const size_t pl = std::max(h->elim_lds, h->solve_lds + (size_t)(d.PC + 32) * 8);
+    const size_t pl = std::max(h->elim_lds, rig_persist_ctl_lds(h->solve_lds, d));
     const bool small = d.ND <= 8 * 64;
     int per_cu = 0, cus = 0;
     hipError_t e1 = small ? hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_persist<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl)
@@ -4246,7 +4264,7 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
       const void* kw = h->p_teams == 1 ? reinterpret_cast<const void*>(k_rig_persist_w<1>) : h->p_teams == 2 ? reinterpret_cast<const void*>(k_rig_persist_w<2>)
                                                                                            : reinterpret_cast<const void*>(k_rig_persist_w<4>);
       hipError_t e2 = hipFuncSetAttribute(kw, hipFuncAttributeMaxDynamicSharedMemorySize, lb);
-      if (e2 == hipSuccess) e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_persist_ctl), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(h->solve_lds + (size_t)(d.PC + 32) * 8));
+      if (e2 == hipSuccess) e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_persist_ctl), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rig_persist_ctl_lds(h->solve_lds, d));
       if (e2 == hipSuccess)
         e2 = h->p_teams == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&pw, k_rig_persist_w<1>, 256, (size_t)lb)
            : h->p_teams == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&pw, k_rig_persist_w<2>, 512, (size_t)lb)
@@ -4810,7 +4828,7 @@ static int rig_launch(cc_rig* h, RigRun* r, int chunk) {
       CC_HIP(hipStreamWaitEvent(h->stream2, h->ev_begin, 0));
       static const bool drop_control = getenv("CC_RIG_PERSIST_TEST_NO_CONTROL") && atoi(getenv("CC_RIG_PERSIST_TEST_NO_CONTROL")) != 0;   // (test hook: the workers' first wait gives up)
       if (!drop_control)
-        hipLaunchKernelGGL(k_rig_persist_ctl, dim3((unsigned)(q.G % 8) + 1u), dim3(256), h->solve_lds + (size_t)(h->d.PC + 32) * 8, h->stream2, h->d, q);
+        hipLaunchKernelGGL(k_rig_persist_ctl, dim3((unsigned)(q.G % 8) + 1u), dim3(256), rig_persist_ctl_lds(h->solve_lds, h->d), h->stream2, h->d, q);
 
       const size_t lb = (size_t)rpw_lds_doubles(h->p_teams) * 8;
       if (h->p_teams == 1) hipLaunchKernelGGL(k_rig_persist_w<1>, dim3((unsigned)q.G), dim3(256), lb, h->stream, h->d, q);
@@ -4819,7 +4837,7 @@ static int rig_launch(cc_rig* h, RigRun* r, int chunk) {
     } else {
       q.G = (int32_t)((h->F + 3) / 4);
       q.pbox = nullptr; q.pcbox = nullptr;   // (its workers wait for every decision)
-      const size_t pl = std::max(h->elim_lds, h->solve_lds + (size_t)(h->d.PC + 32) * 8);
+      const size_t pl = std::max(h->elim_lds, rig_persist_ctl_lds(h->solve_lds, h->d));
       const dim3 grid((unsigned)q.G + 1u);
       if (h->d.ND <= 8 * 64) hipLaunchKernelGGL(k_rig_persist<8>, grid, dim3(256), pl, h->stream, h->d, q);
       else hipLaunchKernelGGL(k_rig_persist<kRigDirectPerLane>, grid, dim3(256), pl, h->stream, h->d, q);
