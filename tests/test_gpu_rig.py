@@ -308,6 +308,36 @@ def test_plain_kernels_pass_the_rig_suites_on_problems_the_tuned_kernels_solve()
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_small_rigs_match_the_oracle(seed):
+    """Random small rigs -- 1 to 4 cameras, 1 to 70 frames (1, 2 or 4 of them per workgroup of the lean persistent kernel,
+    a last workgroup that is not full), 1 to 90 points, random drop-outs, sometimes a camera that sees nothing, an empty
+    frame, a second frozen camera, the robust loss on or off -- against the oracle: same trajectory, same minimiser."""
+    rng = np.random.default_rng(1000 + seed)
+    cams = int(rng.integers(1, 5))
+    frames = int(rng.integers(1, 71))
+    pts = int(rng.integers(1, 91))
+    sc = po.rig_scenario(cams, frames, pts)
+    keep = rng.uniform(size=len(sc["obs_cam"])) > rng.choice([0.0, 0.2, 0.5])
+    if cams >= 3 and rng.uniform() < 0.4:
+        keep &= sc["obs_cam"] != cams - 1                       # the last camera sees nothing
+    off0 = sc["frame_offsets"]
+    if frames >= 3 and rng.uniform() < 0.5:
+        f_empty = int(rng.integers(0, frames))
+        keep[off0[f_empty]:off0[f_empty + 1]] = False           # a frame without observations
+    if not keep.any():
+        keep[0] = True
+    counts = [np.count_nonzero(keep[off0[f]:off0[f + 1]]) for f in range(frames)]
+    sc2 = dict(sc, obs_cam=sc["obs_cam"][keep], obs_world=sc["obs_world"][keep], obs_uv=sc["obs_uv"][keep],
+               frame_offsets=np.concatenate([[0], np.cumsum(counts)]).astype(np.int64))
+    frozen = np.array(sc["cam_frozen"], dtype=np.uint8).copy()
+    if cams >= 3 and rng.uniform() < 0.3:
+        frozen[1] = 1
+    huber = capi.HUBER_A if rng.uniform() < 0.7 else 1e6
+    g, o = _both(sc2, cams, huber_a=huber, frozen=frozen)
+    _assert_same(g, o)
+
+
 def _form_of(cams, frames, pts, env):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import sys; sys.path.insert(0, %r)\n"
