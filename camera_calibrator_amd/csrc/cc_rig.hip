@@ -3440,7 +3440,7 @@ __global__ __launch_bounds__(256) void k_rig_persist(RigDev P, RigPersistDev Q) 
 }
 
 // ---------------------------------------------------------------------------------------------
-// The LEAN workers of the persistent rig solve (k_rig_persist_w; small rigs: at most 4 observed cameras, 18 shared
+// The LEAN workers of the persistent rig solve (k_rig_persist_w; small rigs: at most 4 observed cameras, 24 shared
 // coordinates) with the control workgroup as a launch of its own beside them (k_rig_persist_ctl: rig_persist_control, on a
 // second stream -- it needs 230 registers a thread, the workers must stay under 128 to put SIXTEEN waves on a compute
 // unit). Same seams, same rows, same control as k_rig_persist; what differs is where a worker keeps its four frames:
@@ -3449,12 +3449,16 @@ __global__ __launch_bounds__(256) void k_rig_persist(RigDev P, RigPersistDev Q) 
 // the other), sixteen lanes per frame in the pose update, one wave per frame in the elimination, which builds the
 // compact row straight from a slot table (cc_intrinsics_persist.hip's way) instead of going through the partial-row layout.
 // ---------------------------------------------------------------------------------------------
-constexpr int kRpwYS = 20;          // row stride of Y / Z (S + 1 <= 19 columns)
-constexpr int kRpwMaxK = 320;       // compact row entries
-enum { RPW_Y = 0, RPW_Z = 120, RPW_POSE = 240, RPW_FREC = 256, RPW_SP = 288, RPW_A = 296, RPW_GST = 328, RPW_FST = 336, RPW_HD0 = 338, RPW_ROW = 384,
-       RPW_TEAM = RPW_ROW + kRpwMaxK };   // per-team scratch (doubles)
-enum { RPW_BC = 0, RPW_AB = 160, RPW_SS = 184, RPW_SROW = 208, RPW_SLOT = 232 /* int[320] */, RPW_S16 = 392, RPW_INFO = 408 /* int[24] colinfo, int[16] group of (team, slot) */,
-       RPW_COLS = 428 /* int[8] */, RPW_WG = 440 };   // workgroup scratch (doubles)
+constexpr int kRpwMaxS = 24;        // shared coordinates: four optimised cameras (none of them frozen)
+constexpr int kRpwYS = 28;          // row stride of Y / Z (S + 1 <= 25 columns)
+constexpr int kRpwMaxK = 448;       // compact row entries (S = 24: 325 Schur + 108 direct + 2)
+constexpr int kRpwInfoG = 32;       // s_info: [0..31] colinfo of the shared columns, [32..47] group of (team, slot)
+enum { RPW_Y = 0, RPW_Z = 6 * kRpwYS, RPW_POSE = 12 * kRpwYS, RPW_FREC = RPW_POSE + 16, RPW_SP = RPW_FREC + 32, RPW_A = RPW_SP + 8, RPW_GST = RPW_A + 32,
+       RPW_FST = RPW_GST + 8, RPW_HD0 = RPW_FST + 2, RPW_ROW = ((RPW_HD0 + 32 + 7) / 8) * 8, RPW_TEAM = RPW_ROW + kRpwMaxK };   // per-team scratch (doubles)
+// workgroup scratch (doubles): broadcast B (2 + S + 32 cameras: kRigPersistMaxNB), broadcast A, Jacobi scales, statistics row, slot table, ...
+enum { RPW_BC = 0, RPW_AB = 344, RPW_SS = 376, RPW_SROW = 408, RPW_SLOT = 440 /* int[kRpwMaxK] */, RPW_S16 = RPW_SLOT + kRpwMaxK / 2, RPW_INFO = RPW_S16 + 16 /* int[48] */,
+       RPW_COLS = RPW_INFO + 24 /* int[8], int good */, RPW_WG = RPW_COLS + 8 };
+static_assert(kRigPersistMaxNB <= RPW_AB - RPW_BC, "broadcast B must fit its LDS slot");
 constexpr int rpw_lds_doubles(int teams) { return teams * (2048 + 512 + 1024 + RPW_TEAM) + RPW_WG; }
 
 // column sums over the G rows of a box, for a workgroup of NW waves (cf. rig_gather_cols; thread t < G polls row t)
@@ -3535,7 +3539,7 @@ __global__ __launch_bounds__(TEAMS * 256) void k_rig_persist_w(RigDev P, RigPers
   double* s_row = s_wg + RPW_SROW;
   int* s_slot = reinterpret_cast<int*>(s_wg + RPW_SLOT);
   double* s16 = s_wg + RPW_S16;
-  int* s_info = reinterpret_cast<int*>(s_wg + RPW_INFO);   // [0..23] colinfo, [24..39] group of (team, slot)
+  int* s_info = reinterpret_cast<int*>(s_wg + RPW_INFO);   // [0..31] colinfo, [32..47] group of (team, slot)
   int* s_cols = reinterpret_cast<int*>(s_wg + RPW_COLS);
   int* s_good = s_cols + 8;
   // ---- start of the solve: poses of the workgroup's frames (buffer 0 holds the starting point: rig_begin), tables
@@ -3546,7 +3550,7 @@ __global__ __launch_bounds__(TEAMS * 256) void k_rig_persist_w(RigDev P, RigPers
   if (tid0 >= 64 && tid0 < 64 + 4 * TEAMS) {
     const int t = (tid0 - 64) >> 2, j = (tid0 - 64) & 3;
     const int64_t ff = (int64_t)blockIdx.x * TEAMS + t;
-    s_info[24 + t * 4 + j] = (ff < P.F && j < CO) ? P.fslot[ff * CO + j] : -1;
+    s_info[kRpwInfoG + t * 4 + j] = (ff < P.F && j < CO) ? P.fslot[ff * CO + j] : -1;
   }
   __syncthreads();
   if (has_frame && twave == 0 && lane < 8) {
@@ -3588,7 +3592,7 @@ __global__ __launch_bounds__(TEAMS * 256) void k_rig_persist_w(RigDev P, RigPers
         }
         if (lane == 0) {
           bool active = false;
-          for (int j = 0; j < 4; ++j) active = active || s_info[24 + team * 4 + j] >= 0;
+          for (int j = 0; j < 4; ++j) active = active || s_info[kRpwInfoG + team * 4 + j] >= 0;
           double q[4], t[3], dp[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
           for (int i = 0; i < 4; ++i) q[i] = tm[RPW_POSE + cur * 8 + i];
@@ -3643,7 +3647,7 @@ __global__ __launch_bounds__(TEAMS * 256) void k_rig_persist_w(RigDev P, RigPers
         if (swept) {
           for (int t = 0; t < TEAMS; ++t) {
             for (int j = 0; j < 4; ++j)
-              if (s_info[24 + t * 4 + j] >= 0) { a0 += s_tm[t * RPW_TEAM + RPW_GST + 2 * j]; a1 += s_tm[t * RPW_TEAM + RPW_GST + 2 * j + 1]; }
+              if (s_info[kRpwInfoG + t * 4 + j] >= 0) { a0 += s_tm[t * RPW_TEAM + RPW_GST + 2 * j]; a1 += s_tm[t * RPW_TEAM + RPW_GST + 2 * j + 1]; }
             if ((int64_t)blockIdx.x * TEAMS + t < P.F) { a2 += s_tm[t * RPW_TEAM + RPW_FST]; a3 += s_tm[t * RPW_TEAM + RPW_FST + 1]; }
           }
         }
@@ -3653,7 +3657,7 @@ __global__ __launch_bounds__(TEAMS * 256) void k_rig_persist_w(RigDev P, RigPers
         const int k = tid - 64, info = s_info[k], j = info >> 8, comp = info & 15;
         double d = 0.0;
         for (int t = 0; t < TEAMS; ++t)
-          if (s_info[24 + t * 4 + j] >= 0) d += s_tm[t * RPW_TEAM + RPW_HD0 + 8 * j + comp];
+          if (s_info[kRpwInfoG + t * 4 + j] >= 0) d += s_tm[t * RPW_TEAM + RPW_HD0 + 8 * j + comp];
         s_row[4 + k] = d;
       }
       __syncthreads();
@@ -3674,7 +3678,7 @@ __global__ __launch_bounds__(TEAMS * 256) void k_rig_persist_w(RigDev P, RigPers
       double* rowt = tm + RPW_ROW;
       bool exists[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) exists[j] = has_frame && s_info[24 + team * 4 + j] >= 0;
+      for (int j = 0; j < 4; ++j) exists[j] = has_frame && s_info[kRpwInfoG + team * 4 + j] >= 0;
       const bool live = exists[0] || exists[1] || exists[2] || exists[3];
       const double* T0 = s_tile + ((team * 4) * 2 + cur_e) * 256;   // slot j: T0 + j * 512
       bool ok = true;
@@ -3956,7 +3960,7 @@ struct cc_rig {
   double* d_cam_backup = nullptr;   // [C][8] cameras of the starting point (the lean persistent solve may be run again in the three-kernel form)
   bool persist_ok = false;      // k_rig_persist can run this problem (poses only, <= 4 frames per compute unit, everything resident)
   int p_teams = 4;              // frames per workgroup of the lean form
-  bool persist_w_ok = false;    // ... and so can its lean form (k_rig_persist_w + k_rig_persist_ctl: <= 4 observed cameras, <= 18 shared coordinates)
+  bool persist_w_ok = false;    // ... and so can its lean form (k_rig_persist_w + k_rig_persist_ctl: <= 4 observed cameras, <= 24 shared coordinates)
   hipStream_t stream2 = nullptr;   // the control workgroup's launch of the lean form
   hipEvent_t ev_begin = nullptr;
   cc::RigPersistDev pq{};
@@ -4213,7 +4217,7 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
     q.G = (int32_t)((F + 3) / 4); q.K = (int32_t)comp.size(); q.KS = 4 + S; q.NB = 2 + S + 32 * (int32_t)C;
     // the lean form (k_rig_persist_w) takes the fewest frames per workgroup that still leave every XCD a compute unit for the
     // control workgroup: fewer frames per compute unit = more of the chip in the sweep
-    const bool lean_shape = CO <= 4 && S <= 18 && (int)comp.size() <= kRpwMaxK;
+    const bool lean_shape = CO <= 4 && S <= kRpwMaxS && (int)comp.size() <= kRpwMaxK;
     h->p_teams = 4;
     if (lean_shape) {
       for (int t : {1, 2, 4}) if ((F + t - 1) / t <= 255) { h->p_teams = t; break; }   // (G = 256 would fill every XCD: no compute unit for the control)

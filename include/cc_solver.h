@@ -229,7 +229,7 @@ int cc_rig_reset(cc_rig* h);
 int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary);
 /* Which form cc_rig_solve runs (without profiling):
  *   2 -- the whole solve as ONE launch of the lean persistent kernel (+ its control workgroup's launch): poses only, at most 4
- *        observed cameras, 18 shared coordinates, ~1020 frames, the device to itself; the default where it fits. If its
+ *        observed cameras, 24 shared coordinates, ~1020 frames, the device to itself; the default where it fits. If its
  *        workgroups cannot all be resident the solve is run again in form 0 (same result, 1.3 s late, once per handle);
  *   0 -- three kernels per LM iteration (sweep, decision + elimination, reduce + solve step + pose update): any size, any
  *        exchange; CC_RIG_PERSIST=0 forces it;

@@ -338,6 +338,24 @@ def test_random_small_rigs_match_the_oracle(seed):
     _assert_same(g, o)
 
 
+def test_rig_with_no_camera_held_constant_runs_the_lean_form_at_24_shared_coordinates():
+    """Four cameras, none frozen: 24 shared coordinates, the most the lean persistent form takes. The problem has a gauge
+    freedom (the damping makes every step well defined); the trajectory is compared with the oracle's over the first
+    iterations, where both are far from the flat directions' noise."""
+    sc = po.rig_scenario(4, 30, 20)
+    frozen = np.zeros(4, dtype=np.uint8)
+    cq, ct, fq, ft = _inputs(sc)
+    prob = capi.RigProblem(4, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"], sc["world_xyz"], frozen)
+    if not any(os.environ.get(k) for k in ("CC_RIG_PERSIST", "CC_RIG_FORCE_BIG")):
+        assert prob.solver_form() == 2
+    prob.close()
+    g, o = _both(sc, 4, frozen=frozen)
+    n = min(6, len(g[5]["log"]), len(o[5]["log"]))
+    assert [l["accepted"] for l in g[5]["log"][:n]] == [l["accepted"] for l in o[5]["log"][:n]]
+    assert np.allclose([l["cost"] for l in g[5]["log"][:n]], [l["cost"] for l in o[5]["log"][:n]], rtol=1e-8)
+    assert np.isclose(g[5]["final_cost"], o[5]["final_cost"], rtol=1e-6)
+
+
 def _form_of(cams, frames, pts, env):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import sys; sys.path.insert(0, %r)\n"
@@ -356,7 +374,7 @@ _NESTED = any(os.environ.get(k) for k in ("CC_RIG_PERSIST", "CC_RIG_FORCE_BIG"))
 @pytest.mark.skipif(_NESTED, reason="a forced solver form is already in the environment")
 @pytest.mark.parametrize("persist", ["0", "1"])
 def test_the_rig_suite_in_every_form_of_the_solver(persist):
-    """A small rig (at most 4 observed cameras, 18 shared coordinates, ~1020 frames) is solved by ONE launch of the lean
+    """A small rig (at most 4 observed cameras, 24 shared coordinates, ~1020 frames) is solved by ONE launch of the lean
     persistent kernel (k_rig_persist_w + k_rig_persist_ctl) by default -- which is what every other test in this file then
     exercises. CC_RIG_PERSIST=0: the three kernels per LM iteration on everything; CC_RIG_PERSIST=1: additionally the glued
     persistent kernel (k_rig_persist, an experiment that is slower than the three kernels) where the lean one does not
