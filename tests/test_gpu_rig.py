@@ -338,6 +338,25 @@ def test_random_small_rigs_match_the_oracle(seed):
     _assert_same(g, o)
 
 
+def test_small_rig_among_more_cameras_than_it_observes():
+    """Seven cameras, four of them observed: the lean persistent form takes it (its limits count OBSERVED cameras), and the
+    control workgroup's broadcast carries the records of all seven (the slot it lands in once held four)."""
+    sc = po.rig_scenario(7, 24, 12)
+    keep = sc["obs_cam"] < 4
+    off0 = sc["frame_offsets"]
+    counts = [np.count_nonzero(keep[off0[f]:off0[f + 1]]) for f in range(24)]
+    sc2 = dict(sc, obs_cam=sc["obs_cam"][keep], obs_world=sc["obs_world"][keep], obs_uv=sc["obs_uv"][keep],
+               frame_offsets=np.concatenate([[0], np.cumsum(counts)]).astype(np.int64))
+    if not any(os.environ.get(k) for k in ("CC_RIG_PERSIST", "CC_RIG_FORCE_BIG")):
+        prob = capi.RigProblem(7, sc2["frame_offsets"], sc2["obs_cam"], sc2["obs_world"], sc2["obs_uv"], sc2["world_xyz"], sc2["cam_frozen"])
+        assert prob.solver_form() == 2
+        prob.close()
+    g, o = _both(sc2, 7)
+    _assert_same(g, o)
+    cq, ct, fq, ft = _inputs(sc)
+    assert all(np.array_equal(g[0][c], cq[c]) and np.array_equal(g[1][c], ct[c]) for c in (4, 5, 6))   # unobserved: untouched
+
+
 def test_rig_with_no_camera_held_constant_runs_the_lean_form_at_24_shared_coordinates():
     """Four cameras, none frozen: 24 shared coordinates, the most the lean persistent form takes. The problem has a gauge
     freedom (the damping makes every step well defined); the trajectory is compared with the oracle's over the first
