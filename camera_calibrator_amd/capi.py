@@ -78,10 +78,10 @@ EXPORTED_SYMBOLS = [
     "cc_options_init", "cc_last_error", "cc_version", "cc_device_count",
     "cc_intrinsics_create", "cc_intrinsics_destroy", "cc_intrinsics_set_state",
     "cc_intrinsics_reset", "cc_intrinsics_get_state", "cc_intrinsics_eval",
-    "cc_intrinsics_solve", "cc_intrinsics_solver_form", "cc_intrinsics_profile_sweep", "cc_intrinsics_profile_solve", "cc_intrinsics_optimize", "cc_intrinsics_estimate", "cc_comm_get_unique_id",
+    "cc_intrinsics_solve", "cc_intrinsics_solver_form", "cc_intrinsics_solver_status", "cc_intrinsics_profile_sweep", "cc_intrinsics_profile_solve", "cc_intrinsics_optimize", "cc_intrinsics_estimate", "cc_comm_get_unique_id",
     "cc_intrinsics_comm_init", "cc_intrinsics_exchange_export", "cc_intrinsics_exchange_attach", "cc_partition_frames", "cc_distort", "cc_undistort",
     "cc_rig_create", "cc_rig_destroy", "cc_rig_set_state", "cc_rig_reset", "cc_rig_solve",
-    "cc_rig_get_state", "cc_rig_solver_form", "cc_rig_eval", "cc_rig_optimize", "cc_rig_comm_init", "cc_rig_exchange_export", "cc_rig_exchange_attach", "cc_rigk_create",
+    "cc_rig_get_state", "cc_rig_solver_form", "cc_rig_solver_status", "cc_rig_eval", "cc_rig_optimize", "cc_rig_comm_init", "cc_rig_exchange_export", "cc_rig_exchange_attach", "cc_rigk_create",
     "cc_rigk_set_intrinsics", "cc_rigk_get_intrinsics", "cc_rigk_create_per_camera", "cc_rigk_set_camera_intrinsics",
     "cc_rigk_get_camera_intrinsics", "cc_zhang_init", "cc_intrinsics_optimize_multi", "cc_rig_optimize_multi",
 ]
@@ -238,6 +238,13 @@ class IntrinsicsProblem:
     def solver_form(self):
         """0: two kernels per LM iteration; 1, 2, 4: the persistent per-solve kernel with that many frames per workgroup."""
         return int(lib().cc_intrinsics_solver_form(self._h))
+
+    def solver_status(self):
+        """(form, reruns, note): cc_intrinsics_solver_status -- persistent solves that gave up and were run again, and why."""
+        form, reruns = C.c_int32(), C.c_int32()
+        note = C.create_string_buffer(2048)
+        _check(lib().cc_intrinsics_solver_status(self._h, C.byref(form), C.byref(reruns), note, 2048))
+        return form.value, reruns.value, note.value.decode()
 
     def profile_solve(self, options=None, n=20):
         """Persistent form: (average ms per launch = per complete solve, evaluations per launch), hipEvents on the solver's stream."""
@@ -405,8 +412,15 @@ class RigProblem:
         return cq, ct, fq, ft, cost
 
     def solver_form(self):
-        """1: the whole solve as one persistent kernel launch; 0: three kernels per LM iteration."""
+        """2: the whole solve as one launch of the lean persistent kernel; 0: three kernels per LM iteration."""
         return int(lib().cc_rig_solver_form(self._h))
+
+    def solver_status(self):
+        """(form, reruns, note): cc_rig_solver_status -- lean persistent solves that gave up and were run again, and why."""
+        form, reruns = C.c_int32(), C.c_int32()
+        note = C.create_string_buffer(1024)
+        _check(lib().cc_rig_solver_status(self._h, C.byref(form), C.byref(reruns), note, 1024))
+        return form.value, reruns.value, note.value.decode()
 
     def eval(self):
         c = C.c_double()

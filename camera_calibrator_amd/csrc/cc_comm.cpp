@@ -5,6 +5,7 @@
 
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "cc_common.hpp"
 
@@ -184,6 +185,39 @@ int mailbox_attach(Mailbox* m, int rank, int nranks, const uint8_t* handles, P2p
   out->sw[1] = m->sw[1];
   out->on = 1;
   return CC_OK;
+}
+
+// After a wait on the mailboxes gave up: where every rank's posts stand in THIS rank's mailbox, per kind -- the link of
+// the chain that stalled is the rank whose words for the epoch last waited for are not there. The slot of an epoch e holds
+// e (posted), e - 2 (the previous use of that parity: not posted yet) or a mix (a post in flight). Synchronous copies
+// out of the (uncached) mailbox; the caller has drained its stream.
+std::string mailbox_describe(const Mailbox* m, int rank, int nranks) {
+  if (!m->local || !m->seq) return "no mailbox";
+  unsigned long long seq[2] = {0, 0};
+  if (hipMemcpy(seq, m->seq, sizeof(seq), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return "mailbox unreadable"; }
+  char buf[160];
+  std::string out;
+  std::snprintf(buf, sizeof(buf), "mailbox of rank %d of %d:", rank, nranks);
+  out += buf;
+  for (int kind = 0; kind < 2; ++kind) {
+    const unsigned long long e = seq[kind];
+    std::snprintf(buf, sizeof(buf), " %s, last epoch waited for %llu -", kind == 0 ? "reduced sums (kind 0)" : "; statistics (kind 1)", e);
+    out += buf;
+    const size_t base = kind == 0 ? 0 : (size_t)2 * kP2pMaxRanks * (size_t)m->sw[0];
+    for (int r = 0; r < nranks; ++r) {
+      const size_t off = base + ((size_t)(e & 1ull) * kP2pMaxRanks + (size_t)r) * (size_t)m->sw[kind];
+      std::vector<unsigned long long> w((size_t)m->sw[kind]);
+      if (hipMemcpy(w.data(), m->local + off, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return out + " unreadable"; }
+      size_t have = 0, older = 0;
+      for (unsigned long long x : w) { have += (x >> 32) == (e & 0xffffffffull) ? 1 : 0; older += (x >> 32) != (e & 0xffffffffull) && x != 0ull ? 1 : 0; }
+      if (have && !older) std::snprintf(buf, sizeof(buf), " rank %d posted (%zu words)", r, have);
+      else if (have) std::snprintf(buf, sizeof(buf), " rank %d PARTLY posted (%zu words of this epoch, %zu of an older one)", r, have, older);
+      else std::snprintf(buf, sizeof(buf), " rank %d MISSING (first word carries epoch %llu)", r, w.empty() ? 0ull : (w[0] >> 32));
+      out += buf;
+      out += r + 1 < nranks ? "," : "";
+    }
+  }
+  return out;
 }
 
 }  // namespace cc

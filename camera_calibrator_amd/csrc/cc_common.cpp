@@ -13,7 +13,7 @@ std::string& last_error() {
 }
 
 int fail(int code, const char* fmt, ...) {
-  char buf[1024];
+  char buf[4096];   // (a stalled exchange describes every rank's mailbox slots)
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(buf, sizeof(buf), fmt, ap);

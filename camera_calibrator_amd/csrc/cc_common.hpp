@@ -73,6 +73,7 @@ int mailbox_attach(Mailbox* m, int rank, int nranks, const uint8_t* handles, P2p
 // and device.
 int mailbox_wire_local(Mailbox* m, int rank, int nranks, Mailbox* const* all, const int* devices, P2pDev* out);
 void mailbox_release(Mailbox* m);
+std::string mailbox_describe(const Mailbox* m, int rank, int nranks);   // diagnostics after a timed-out wait
 
 // ---------------------------------------------------------------------------------------------
 // Device-resident LM state machine.  All control decisions (step acceptance, radius update,

@@ -1044,6 +1044,8 @@ struct cc_intrinsics {
   std::vector<hipEvent_t> events;
   std::vector<int> event_kind;
   // persistent per-solve kernel (cc_intrinsics_persist.hip): usable when every frame gets a team of a resident workgroup
+  int form_reruns = 0;          // persistent solves that gave up and were run again in the two-kernel form (cc_intrinsics_solver_status)
+  std::string form_note;        // why
   bool persist_ok = false;      // ... on a device of its own
   bool persist_x_ok = false;    // ... as one rank of an exchange: every rank fits next to the ranks it shares its device with,
                                 // and every rank said so (cc_intrinsics_exchange_attach / cc_intrinsics_optimize_multi agree on it)
@@ -1306,12 +1308,14 @@ int intr_create_impl(cc_intrinsics* h, const int64_t* off, const float* uv, cons
     for (int t = 1; t <= kPMaxTeams && !p_teams; t *= 2) {
       int resident = 0;
       if (int rc = persist_resident_workgroups(h->device, t, &resident)) return rc;
-      if ((F + t - 1) / t + 1 <= resident) { p_teams = t; h->p_resident = resident; }
+      // (kPMaxWorkers: the control's statistics gather reads one row per four threads, gather_stats4 -- a device with more
+      // than 257 compute units must not get a grid whose last rows would be dropped from the sums)
+      if ((F + t - 1) / t + 1 <= resident && (F + t - 1) / t <= kPMaxWorkers) { p_teams = t; h->p_resident = resident; }
     }
     if (const char* e = getenv("CC_INTR_PERSIST_TEAMS")) {   // (A/B: force a shape that fits)
       const int t = atoi(e);
       int resident = 0;
-      if ((t == 1 || t == 2 || t == 4) && !persist_resident_workgroups(h->device, t, &resident) && (F + t - 1) / t + 1 <= resident) { p_teams = t; h->p_resident = resident; }
+      if ((t == 1 || t == 2 || t == 4) && !persist_resident_workgroups(h->device, t, &resident) && (F + t - 1) / t + 1 <= resident && (F + t - 1) / t <= kPMaxWorkers) { p_teams = t; h->p_resident = resident; }
     }
   }
   const int64_t PG = p_teams ? (F + p_teams - 1) / p_teams : 1;
@@ -1619,8 +1623,11 @@ static int solve_launch(cc_intrinsics* h, SolveRun* r, int chunk) {
 static int solve_wait(cc_intrinsics* h, SolveRun* r) {
   CC_HIP(hipSetDevice(h->device));
   if (int rc = r->host_word ? wait_published(h, &r->st) : read_ctl(h, &r->st)) return rc;
-  if (r->st.done && r->st.term == CC_FAILURE_EXCHANGE)
-    return fail(CC_ERR_COMM, "mailbox exchange timed out: a peer rank did not post within 10 s (iteration %d)", r->st.iter);
+  if (r->st.done && r->st.term == CC_FAILURE_EXCHANGE) {
+    (void)hipStreamSynchronize(h->stream);
+    const std::string where = h->exchange ? mailbox_describe(&h->mailbox, h->d.rank, h->d.nranks) : std::string();
+    return fail(CC_ERR_COMM, "mailbox exchange timed out: a peer rank did not post within 10 s (iteration %d). %s", r->st.iter, where.c_str());
+  }
   if (!r->st.done && r->launched > r->o.max_iterations + 2 * r->o.check_interval + 2)
     return fail(CC_ERR_STATE, "LM loop did not terminate (iter=%d)", r->st.iter);
   return 0;
@@ -1659,8 +1666,10 @@ static int persistent_wait(cc_intrinsics* h, SolveRun* r) {
   if (int rc = wait_published(h, &r->st)) return rc;
   if (r->st.done && r->st.term == CC_FAILURE_EXCHANGE) {
     CC_HIP(hipMemsetAsync(h->pq.fail, 0, sizeof(unsigned), h->stream));
+    (void)hipStreamSynchronize(h->stream);
+    const std::string where = h->exchange ? mailbox_describe(&h->mailbox, h->d.rank, h->d.nranks) : std::string();
     return fail(CC_ERR_COMM, "persistent solve: a wait inside the kernel timed out (iteration %d): its %d workgroups were not all "
-                "resident, or a peer rank did not post within 10 s", r->st.iter, h->pq.G + 1);
+                "resident, or a peer rank did not post within 10 s. %s", r->st.iter, h->pq.G + 1, where.c_str());
   }
   if (!r->st.done) {
     // the control workgroup never published: did the workers give up waiting for it?
@@ -1734,6 +1743,8 @@ int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* sum
     // a compute-unit mask). Nothing was written back, so the solve is run again -- and this handle keeps to -- the
     // two-kernel form, which needs no co-residency. (Another GPU form of the same arithmetic, not a fallback off the GPU.)
     h->persist_ok = false;
+    h->form_reruns++;   // (not silently: cc_intrinsics_solver_status reports the demotion and what the kernel said)
+    h->form_note = last_error() + "; the solve was run again with two kernels per iteration and the handle stays on that form";
     CC_HIP(hipStreamSynchronize(h->stream));
     CC_HIP(hipMemsetAsync(h->pq.fail, 0, sizeof(unsigned), h->stream));
     if (was_restart) {
@@ -1852,6 +1863,15 @@ int cc_intrinsics_debug_fetch(cc_intrinsics* h, const char* name, double* out, i
 int cc_intrinsics_solver_form(cc_intrinsics* h) {
   if (!h || h->comm) return 0;
   return (h->exchange ? h->persist_x_ok : h->persist_ok) ? h->pq.teams : 0;
+}
+
+int cc_intrinsics_solver_status(cc_intrinsics* h, int32_t* form, int32_t* reruns, char* note, int32_t note_capacity) {
+  using namespace cc;
+  if (!h) return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_solver_status: NULL handle");
+  if (form) *form = cc_intrinsics_solver_form(h);
+  if (reruns) *reruns = h->form_reruns;
+  if (note && note_capacity > 0) std::snprintf(note, (size_t)note_capacity, "%s", h->form_note.c_str());
+  return CC_OK;
 }
 
 int cc_intrinsics_profile_solve(cc_intrinsics* h, const cc_options* opt, int32_t n, double* avg_launch_ms, int32_t* sweeps_per_launch) {

@@ -59,6 +59,13 @@ enum { WG_INTR = 0 /* [2][16] */, WG_X = 64 /* the control's last broadcast: fla
        // source entry of the Gram block, the two columns of Z whose product is subtracted (| 1 << 16: there is one)
        WG_TGI = 416 /* int[80] */, WG_TZ = 456 /* int[80] */ };
 
+static_assert(TM_POSE - TM_Y >= 6 * 10 && TM_SP - TM_POSE >= 2 * 8 && TM_STEP - TM_SP >= 6 && TM_R - TM_STEP >= 15 && TM_T - TM_R >= 9 && TM_KC - TM_T >= 3 &&
+              TM_STEP2 - TM_KC >= 9 && TM_QW - TM_XN2 >= 1 && TM_STAT - TM_QW >= 4 && TM_STAT + 4 + 9 <= 192,
+              "per-team scratch: Y (6 x 10), two poses, pose scale, step (9 + 6), R, t, intrinsics, scalars, statistics row -- inside the 192 doubles persist_lds_doubles gives a team");
+static_assert(WG_X - WG_INTR >= 2 * 16 && WG_DS - WG_X >= 2 && WG_SS - WG_DS >= 9 && WG_R0 - WG_SS >= 9 && WG_OPT - WG_R0 >= 1 && WG_TAB - WG_OPT >= 4 &&
+              WG_TZ - WG_TGI >= 80 / 2 && WG_TZ + 80 / 2 <= 512,
+              "workgroup scratch: both intrinsics, broadcast (2 + 9), scales, options, tables of the 80-slot row -- inside the 512 doubles of persist_lds_doubles");
+
 // Control workgroup, all 1024 threads: column sums (maximum for column `maxcol`) of the G rows of a box whose words
 // carry `tag`. Thread -> (column, row group): rows grp, grp + NG, ... are polled BATCH at a time (all 2 BATCH loads in
 // flight, unconditional from clamped rows; BATCH = what sixteen rows need where there are never more) and added in that order; the NG group sums are then added in group order.
@@ -118,6 +125,7 @@ __device__ __forceinline__ void gather_rows(const u64* box, int G, unsigned tag,
 template <int THREADS>
 __device__ __forceinline__ void gather_stats4(const u64* box, int G, unsigned tag, double* s_part, double* out, unsigned* fail, int* s_ok, int tshift) {
   constexpr int RPT = 1024 / THREADS;   // rows per thread
+  static_assert(THREADS / 4 * RPT == kPMaxWorkers, "one statistics row per four threads: the host caps the worker grid at kPMaxWorkers");
   const int tid = threadIdx.x, col = tid & 3, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) *s_ok = 1;
   __syncthreads();
@@ -219,6 +227,10 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
       const double* kc0 = s_intr + (c.cur ? 16 : 0);   // accepted intrinsics
       const double* kc1 = s_intr + (c.cur ? 0 : 16);   // candidate
       if (!s_int[0]) {
+        // (a gather that gave up ends the solve AS A FAILURE for everybody: the failure word stops the workers from writing
+        // their poses back and this workgroup from writing the intrinsics, so that the host's rerun in the two-kernel form
+        // starts from the untouched starting point -- ADVICE round 3: only a worker's own timed-out wait used to set it)
+        __hip_atomic_store(Q.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         c.done = 1; c.term = CC_FAILURE_EXCHANGE;
       } else if (phase0) {
         double xn2 = s_tot[ST_XNORM2];
@@ -372,7 +384,7 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
       const bool ok = ((int)s_bc[0] & 2) != 0;
       cc_iteration* e = s_int[1] ? s_log : nullptr;
       if (e && e->accepted) e->gradient_max_norm = gmax;
-      if (!s_int[0]) { s_ctl->done = 1; s_ctl->term = CC_FAILURE_EXCHANGE; }
+      if (!s_int[0]) { __hip_atomic_store(Q.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_ctl->done = 1; s_ctl->term = CC_FAILURE_EXCHANGE; }
       else if (lm_finalize(*s_ctl, o, gmax)) { s_ctl->step_valid = ok ? 1 : 0; s_ctl->cand_pending = 1; }
       if (e && s_ctl->log_len <= P.log_cap) P.log[s_ctl->log_len - 1] = *e;
     }
@@ -822,7 +834,8 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
                                                         Q.fail, s_lok, Q.timeout_shift);
       PW_MARK(11);
       CC_FRESH_TID(tid);
-      // (rows that did not arrive: nothing is posted, the control's own wait gives up and ends the solve)
+      // (rows that did not arrive: nothing is posted, the control's own wait gives up and ends the solve -- as a failure)
+      if (!*s_lok && tid == 0) __hip_atomic_store(Q.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (*s_lok && tid < 2 * kPartialCols) ag_st(Q.lbox + (size_t)(g0 / kPLeaderRows) * (2 * kPartialCols) + tid, granule(tag, lout[tid >> 1], tid & 1));
     }
     };
@@ -865,7 +878,7 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
     step_valid = (fl & 2) != 0;
   }
   // ---- the solve is over: the frame's accepted pose goes back to HBM (cc_intrinsics_get_state, the next solve)
-  if (!failed && has_frame && (tid0 & 255) < 7) P.pose[((size_t)cur * P.F + f) * 8 + (tid0 & 255)] = sm[TM_POSE + cur * 8 + (tid0 & 255)];
+  if (!failed && ag_ld32(Q.fail) == 0u && has_frame && (tid0 & 255) < 7) P.pose[((size_t)cur * P.F + f) * 8 + (tid0 & 255)] = sm[TM_POSE + cur * 8 + (tid0 & 255)];
   asm volatile("" ::"v"(nm.x), "v"(nX0), "v"(nX1), "v"(nX2));   // (the last prefetch has no consumer)
 }
 

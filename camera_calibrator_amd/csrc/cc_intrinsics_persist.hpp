@@ -8,6 +8,7 @@ namespace cc {
 constexpr int kPMaxTeams = 4;                     // frames (teams of four waves) per worker workgroup: 1, 2 or 4
 constexpr int kPStatCols = 16;                    // doubles per statistics row (4 sums; + 9 diagonal sums in the first round)
 constexpr int kPBcastWords = 64;                  // words per broadcast box
+constexpr int kPMaxWorkers = 256;                 // worker workgroups: the control polls one statistics row per four of its 1024 threads (gather_stats4)
 constexpr int kPLeaderRows = 16;                  // elimination rows a leader workgroup adds up before the control sees them
 
 // Seam mailboxes of one handle: self-validating 8-byte words {epoch32 : half of a double}, agent-scope stores and

@@ -135,6 +135,13 @@ struct RigDev {
   double* ghdk;       // [NG][16] diag of the intrinsics block of each group at the initial point
 };
 
+// Progress words of a solve (zeroed with the control block, read by the host only after a wait gave up): launches of each
+// kind that have STARTED -- with the mailbox epochs this names the link of a stalled chain (rig_describe_stall).
+enum { RIG_PROG_SWEEP = 0, RIG_PROG_STATS, RIG_PROG_INIT, RIG_PROG_ELIM, RIG_PROG_REDUCE, RIG_PROG_SOLVE, RIG_PROG_UPDATE, RIG_PROG_COUNT };
+__device__ __forceinline__ void rig_progress(const RigDev& P, int kind) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(P.arrive + 4 + kind, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (no return value: nothing waits)
+}
+
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
@@ -297,6 +304,7 @@ __device__ __forceinline__ int rigk_out_source(int t, int i, int j, int& e) {
 // many half-size workgroups are all resident at once and split the chunks 3 + 2 instead of 2 + 1 + 1 + 1).
 template <bool HK, int NW>
 __global__ __launch_bounds__(NW * 64, HK ? 3 : CC_RIG_SWEEP_WAVES) void k_rig_sweep(RigDev P) {
+  rig_progress(P, RIG_PROG_SWEEP);
   static_assert(NW == 4 || ((NW == 2 || NW == 1) && !HK), "small workgroups exist for the poses-only sweep");
   constexpr int NT = NW * 64;      // threads
   constexpr int EPT = 256 / NT;    // block entries per thread
@@ -827,6 +835,7 @@ __device__ __forceinline__ void rig_sweep_adj_body(const RigDev& P, const int64_
 
 template <int NW>
 __global__ __launch_bounds__(NW * 64, NW == 1 ? CC_RIG_ADJ_WAVES : 3) void k_rig_sweep_adj(RigDev P) {   // (NW > 1: few, large groups -- registers rather than residency)
+  rig_progress(P, RIG_PROG_SWEEP);
   __shared__ double s_lds[kRigSweepAdjLds(NW)];
   const LmCtl* ctl = P.ctl;
   const int done = ctl->done, phase = ctl->phase, step_valid = ctl->step_valid, cur = ctl->cur;
@@ -851,6 +860,7 @@ constexpr int kRigCompK = 320;   // doubles per group and buffer of the compact 
 // cross-lane epilogue and the assembly over all passes of its group and there is no cross-wave reduction), four otherwise.
 template <int NW>
 __global__ __launch_bounds__(NW * 64, CC_RIG_ADJK_WAVES) void k_rig_sweep_adjk(RigDev P) {
+  rig_progress(P, RIG_PROG_SWEEP);
   constexpr int NT = NW * 64, EPT = 256 / NT;
   __shared__ __attribute__((aligned(16))) double s_stage[NW * kStageDoublesPerWave];   // per wave 64 x 16; then the partial products
   __shared__ double sm[96];        // camera record, frame record, intrinsics record (candidate [0..8], step [16..24])
@@ -1193,6 +1203,7 @@ __device__ __forceinline__ void rig_update_body(const RigDev& P, int phase, int 
 }
 
 __global__ __launch_bounds__(256) void k_rig_update(RigDev P) {
+  rig_progress(P, RIG_PROG_UPDATE);
   const LmCtl* ctl = P.ctl;
   if (ctl->done) return;
   const int phase = ctl->phase;
@@ -1310,6 +1321,7 @@ __device__ __forceinline__ void rig_diag_sums(const RigDev& P, double* s4, doubl
 // column k over this rank's groups (Jacobi scaling of the shared block).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rig_stats(RigDev P) {
+  rig_progress(P, RIG_PROG_STATS);
   __shared__ double s4[4];
   __shared__ double s16[16];
   __shared__ double s_out[4];
@@ -1366,6 +1378,7 @@ __global__ __launch_bounds__(128) void k_rig_flag_exchange(RigDev P, const doubl
 // init (one block, first evaluation only): Jacobi scale of the shared block, trust-region state
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rig_init(RigDev P) {
+  rig_progress(P, RIG_PROG_INIT);
   __shared__ double s4[4];
   __shared__ double s16[16];
   __shared__ double s_out[4];
@@ -1827,6 +1840,7 @@ __device__ __forceinline__ void rig_elim_body(const RigDev& P, char* smem_raw, c
 
 template <bool HK, int NR>
 __global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
+  rig_progress(P, RIG_PROG_ELIM);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   rig_elim_body<HK, NR, false>(P, smem_raw, 0, 1.0, false, nullptr);
 }
@@ -2369,16 +2383,43 @@ __device__ void rig_solve_block(const RigDev& P, double* smem, const LmCtl* cn_i
   RIG_MARK(6);
 }
 
-// RCCL route: the solve step as a kernel of its own (after the all-reduce of P.vec)
-__global__ __launch_bounds__(256) void k_rig_solve(RigDev P) {
+// Hands the control block (and the failure word of the in-kernel waits) to the host without a copy engine in the way:
+// payload first, then the sequence word the host spins on (system-scope stores into pinned host memory; one thread).
+// Last reduce launch of a host chunk only (cf. publish_to_host, cc_intrinsics_dev.hpp).
+__device__ __forceinline__ void rig_publish(const RigDev& P, const LmCtl& c) {
+  if (!P.host_pub) return;
+  const unsigned long long* w = reinterpret_cast<const unsigned long long*>(&c);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(LmCtl) / 8); ++i)
+    __hip_atomic_store(P.host_pub + 2 + i, w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const unsigned failed = __hip_atomic_load(P.arrive + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(P.host_pub + 2 + sizeof(LmCtl) / 8, (unsigned long long)failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const unsigned long long seq = *P.pub_seq + 1ull;
+  *P.pub_seq = seq;
+  __hip_atomic_store(P.host_pub, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// The solve step as a kernel of its own.
+//   SRC 0 (RCCL route): after the all-reduce of P.vec.
+//   SRC 2 (mailbox exchange on a device this rank SHARES with other shards or processes: rig_enqueue_round): this ONE
+//          block collects every rank's posts (k_rig_reduce<4> made ours) in rank order inside rig_solve_block, and -- last
+//          launch of a host chunk but for the pose update -- publishes the control block to the host. No block of any
+//          launch of this form waits for another block: the only waits are this block's polls of its own mailbox.
+template <int SRC>
+__global__ __launch_bounds__(256) void k_rig_solve(RigDev P, int publish) {
+  rig_progress(P, RIG_PROG_SOLVE);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const LmCtl* cn = P.ctl_next;
   if (cn->done) {
-    if (threadIdx.x == 0) *P.ctl = *cn;
+    if (threadIdx.x == 0) { *P.ctl = *cn; if (SRC == 2 && publish) rig_publish(P, *cn); }
     return;
   }
   if (cn->phase == 0) return;
-  rig_solve_block<0>(P, reinterpret_cast<double*>(smem_raw));
+  rig_solve_block<SRC>(P, reinterpret_cast<double*>(smem_raw));
+  if (SRC == 2 && publish) {
+    __syncthreads();
+    if (threadIdx.x == 0) rig_publish(P, *P.ctl);   // (written by this very thread a moment ago)
+  }
 }
 
 // first launch of a solve: camera / intrinsics records of the starting point (what the first sweep reads)
@@ -2396,44 +2437,33 @@ __global__ __launch_bounds__(256) void k_rig_records(RigDev P) {
 // to arrive runs the solve step on them (sc1 loads, no fence: MI355X guide, valid hand-off forms).
 // MODE 3 (mailbox exchange): every block posts its sums straight into all ranks' mailboxes; the last block
 // to arrive collects them in rank order inside the solve step. MODE 2 (RCCL): sums -> P.vec, nothing else.
+// MODE 4 (mailbox exchange on a SHARED device): sums -> every rank's mailbox, nothing else -- the solve step and the pose
+// update are launches of their own (k_rig_solve<2>, k_rig_update), so no block waits for another one.
 // MODES 0 and 3 then run the POSE UPDATE in the same launch: the grid is at most one block per CU (all of them
 // resident), the blocks that are not last wait for a flag word the solver stores (epoch | done | step_valid | cur,
 // sc1, behind its drained sc1 stores of the shared step) and every block updates its share of the frames. The wait is
 // bounded (10 s of the wall clock) like the mailbox polls.
 // ---------------------------------------------------------------------------------------------
-// Hands the control block (and the failure word of the in-kernel waits) to the host without a copy engine in the way:
-// payload first, then the sequence word the host spins on (system-scope stores into pinned host memory; one thread).
-// Last reduce launch of a host chunk only (cf. publish_to_host, cc_intrinsics_dev.hpp).
-__device__ __forceinline__ void rig_publish(const RigDev& P, const LmCtl& c) {
-  if (!P.host_pub) return;
-  const unsigned long long* w = reinterpret_cast<const unsigned long long*>(&c);
-#pragma unroll
-  for (int i = 0; i < (int)(sizeof(LmCtl) / 8); ++i)
-    __hip_atomic_store(P.host_pub + 2 + i, w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  const unsigned failed = __hip_atomic_load(P.arrive + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(P.host_pub + 2 + sizeof(LmCtl) / 8, (unsigned long long)failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  const unsigned long long seq = *P.pub_seq + 1ull;
-  *P.pub_seq = seq;
-  __hip_atomic_store(P.host_pub, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P, int publish) {
+  rig_progress(P, RIG_PROG_REDUCE);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   __shared__ double s_r[16][16];
   __shared__ double s_post[48];
   __shared__ double s_tail;
   __shared__ int s_last;
   __shared__ unsigned s_flag;
+  constexpr bool FUSED = MODE == 0 || MODE == 3;   // solve step + pose update in this launch (its blocks wait for each other)
   const LmCtl* cn = P.ctl_next;
   if (cn->done) {
-    if (MODE != 2 && blockIdx.x == 0 && threadIdx.x == 0) { *P.ctl = *cn; if (publish) rig_publish(P, *cn); }
+    if (FUSED && blockIdx.x == 0 && threadIdx.x == 0) { *P.ctl = *cn; if (publish) rig_publish(P, *cn); }
     return;
   }
   if (cn->phase == 0) return;
   // an earlier launch of this solve gave up waiting (below): the state is half updated, the host will report it
   // (rig_wait); do not wait another ten seconds per remaining round of the chunk
-  if (MODE != 2 && __hip_atomic_load(P.arrive + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+  if (FUSED && __hip_atomic_load(P.arrive + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
     if (publish && blockIdx.x == 0 && threadIdx.x == 0) rig_publish(P, *cn);
     return;
   }
@@ -2442,7 +2472,7 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P, int publish) {
   const long long t_entry = wall_clock64();
 #endif
   unsigned epoch0 = 0;
-  if (MODE != 2) epoch0 = __hip_atomic_load(P.arrive + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 3;   // before we arrive
+  if (FUSED) epoch0 = __hip_atomic_load(P.arrive + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 3;   // before we arrive
   for (int first = blockIdx.x * 16; first < P.PC; first += gridDim.x * 16) {
     const int o = first + c;
     const bool is_max = o == P.pc_gmax;
@@ -2482,7 +2512,7 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P, int publish) {
       else P.vec[o] = r;
       s_post[c] = r;
     }
-    if (MODE == 3) {
+    if (MODE == 3 || MODE == 4) {
       // mailbox exchange (kind 0): the block that owns the max column also posts the 32 per-rank max slots
       // (ours set, the others zero). The epoch is stable here: only the solve step advances it.
       __syncthreads();
@@ -2496,7 +2526,7 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P, int publish) {
       }
     }
   }
-  if (MODE == 2) return;
+  if (!FUSED) return;
 #ifdef CC_RIG_TIMING
   const long long t_sums = wall_clock64();
 #endif
@@ -2584,6 +2614,7 @@ __host__ __device__ constexpr int big_tile(int a, int b) { return a * 16 - a * (
 
 template <bool HK>
 __global__ __launch_bounds__(256) void k_rig_elim_big(RigDev P) {
+  rig_progress(P, RIG_PROG_ELIM);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* s_Z = reinterpret_cast<double*>(smem_raw);   // [6][256] staged Z rows of the block's current frame
   double* s_d = s_Z + 6 * 256;                          // [ND] direct sums of the block
@@ -2792,6 +2823,7 @@ struct BigA {
 
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_rig_solve_big(RigDev P, double* Aglobal) {
+  rig_progress(P, RIG_PROG_SOLVE);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const LmCtl* cn = P.ctl_next;
   if (cn->done) {
@@ -3031,12 +3063,15 @@ struct RigPersistDev {
                         //     camera c's block; -1: failed factorisations; -2: gradient maximum
   int32_t G, K, KS, NB;
   unsigned epoch0;      // tags: epoch0 + round + 1 (boxes are zeroed when they would wrap)
+  unsigned* claim;      // [1] the control candidate that exchanges epoch0 + 1 in first is the control workgroup (k_rig_persist_ctl)
+  unsigned* gate;       // signal word the control launch waits for at the command processor (hipStreamWaitValue32): the worker that
+                        //   finds all G workers started stores epoch0 + 1 into it; null: no gate (the candidates run when they run)
   int32_t max_rounds, timeout_shift;
 };
 
 constexpr int kRigPersistMaxS = 48;     // shared coordinates (8 optimised cameras)
 constexpr int kRigPersistMaxC = 9;      // cameras (records travel in broadcast B)
-constexpr int kRigPersistMaxNB = 2 + kRigPersistMaxS + 32 * kRigPersistMaxC;
+constexpr int kRigPersistMaxNB = 2 + kRigPersistMaxS + 32 * kRigPersistMaxC;   // (the control workgroup's own copies are sized for 48 coordinates; the workers take kRpwMaxS)
 
 // One wave waits until the n doubles of a broadcast box carry `tag` and leaves them in dst[0..n) (LDS). false: gave up.
 __device__ __forceinline__ bool rig_bcast_wait(const u64* box, unsigned tag, int n, double* dst, unsigned* fail, int tshift) {
@@ -3311,134 +3346,6 @@ __device__ __forceinline__ void rig_persist_control(const RigDev& P, const RigPe
     }
 }
 
-template <int NR>
-__global__ __launch_bounds__(256) void k_rig_persist(RigDev P, RigPersistDev Q) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  __shared__ double s_bc[kRigPersistMaxNB];     // broadcast B of this round: flags, radius, step, camera records
-  __shared__ double s_a[2 + kRigPersistMaxS];   // broadcast A
-  __shared__ double s_ss[kRigPersistMaxS + 1];
-  __shared__ double s_row[4 + kRigPersistMaxS];
-  __shared__ double s4[4];
-  __shared__ int s_cols[16];
-  __shared__ int s_flag;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int S = P.S, C = P.C, G = Q.G, K = Q.K, KS = Q.KS, NB = Q.NB;
-  unsigned* fail = P.arrive + 3;
-
-  if ((int)blockIdx.x == G) { rig_persist_control(P, Q, smem_raw); return; }
-
-  // ============================================================================= worker workgroup
-  const int64_t fbase = (int64_t)blockIdx.x * 4;
-  const int64_t fw = fbase + wave;                              // this wave's frame
-  const int64_t g0 = P.fgoff[fbase < P.F ? fbase : P.F];
-  const int64_t g1 = P.fgoff[fbase + 4 < P.F ? fbase + 4 : P.F];   // groups of the workgroup: [g0, g1)
-  const int64_t nf = P.F - fbase < 4 ? P.F - fbase : 4;
-  double* wlds = reinterpret_cast<double*>(smem_raw) + wave * 256;   // the wave's sweep scratch (the elimination's LDS, idle then)
-  int cur = 0;
-  double radius = 1.0;
-  for (int round = 0; round < Q.max_rounds; ++round) {
-    const unsigned e = Q.epoch0 + (unsigned)round + 1u;
-    const bool phase0 = round == 0;
-    // ---- broadcast B: the step to apply and the camera records of the point to evaluate
-    RPW_MARK(0);
-    if (wave == 0 && !rig_bcast_wait(Q.ybox, e, NB, s_bc, fail, Q.timeout_shift)) s_bc[0] = 1.0;
-    __syncthreads();
-    const int flb = (int)s_bc[0];
-    RPW_MARK(1);
-    if (flb & 1) break;
-    cur = (flb >> 3) & 1;
-    const bool swept = (flb & 2) != 0;
-    if (swept) {
-      // pose update of the workgroup's frames (sixteen lanes per frame), records of the candidate
-      {
-        RigUpdPre none;
-        const int64_t fu = tid < 64 ? fbase + (tid >> 4) : P.F;
-        rig_update_body<false, false>(P, phase0 ? 0 : 1, cur, fu, none, s_bc + 2);
-      }
-      __syncthreads();
-      RPW_MARK(2);
-      if (fw < P.F)
-        for (int64_t g = P.fgoff[fw]; g < P.fgoff[fw + 1]; ++g)
-          {
-            RigSweepIO io = rig_sweep_io_global(P, g, cur, phase0 ? cur : (cur ^ 1));
-            io.camrec = s_bc + 2 + S;
-            rig_sweep_adj_body<1, true>(P, g, phase0 ? 0 : 1, cur, wlds, io);
-          }
-      __syncthreads();
-      RPW_MARK(3);
-    }
-    // ---- statistics row of the workgroup
-    {
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-      if (swept) {
-        for (int64_t g = g0 + tid; g < g1; g += 256) { a0 += P.gstats[g * 2]; a1 += P.gstats[g * 2 + 1]; }
-        if (tid < nf) { a2 = P.fstats[(fbase + tid) * 2]; a3 = P.fstats[(fbase + tid) * 2 + 1]; }
-      }
-      a0 = block_sum256(a0, s4);
-      a1 = block_sum256(a1, s4);
-      a2 = block_sum256(a2, s4);
-      a3 = block_sum256(a3, s4);
-      if (tid == 0) { s_row[0] = a0; s_row[1] = a1; s_row[2] = a2; s_row[3] = a3; }
-      if (phase0 && tid < S) {   // diagonal of H_cc of the workgroup's groups, per shared column (Jacobi scaling, k_rig_init)
-        double d = 0.0;
-        for (int64_t g = g0; g < g1; ++g) {
-          const int p0 = P.pcol[P.gcam[g]];
-          if (p0 >= 0 && tid >= p0 && tid < p0 + 6) d += P.ghd0[g * 8 + (tid - p0)];
-        }
-        s_row[4 + tid] = d;
-      }
-      __syncthreads();
-      const int nst = phase0 ? KS : 4;
-      for (int w = tid; w < 2 * nst; w += 256) ag_st(Q.sbox + ((size_t)blockIdx.x * KS) * 2 + w, granule(e, s_row[w >> 1], w & 1));
-    }
-    RPW_MARK(4);
-    // ---- broadcast A: the decision
-    if (wave == 0 && !rig_bcast_wait(Q.abox, e, 2 + S, s_a, fail, Q.timeout_shift)) s_a[0] = 1.0;
-    __syncthreads();
-    const int fla = (int)s_a[0];
-    RPW_MARK(5);
-    if (fla & 1) break;
-    cur = (fla >> 3) & 1;
-    radius = s_a[1];
-    if (phase0 && tid < S) s_ss[tid] = s_a[2 + tid];
-    __syncthreads();
-    // ---- elimination of the workgroup's frames -> partial row (global, this workgroup's own) -> compact row
-    rig_elim_body<false, NR, true>(P, smem_raw, cur, radius, phase0, s_ss);
-    __syncthreads();
-    RPW_MARK(6);
-    {
-      const double* prow = P.partial + (size_t)blockIdx.x * P.PC;
-      for (int k = tid; k < K; k += 256) {
-        const double v = prow[Q.comp[k]];
-        u64* q = Q.rbox + ((size_t)blockIdx.x * K + k) * 2;
-        ag_st(q, granule(e, v, 0));
-        ag_st(q + 1, granule(e, v, 1));
-      }
-    }
-    RPW_MARK(7);
-    // ---- this workgroup's share of the column sums: columns b, b + G, ...
-    for (int c0 = (int)blockIdx.x; c0 < K; c0 += 8 * G) {
-      if (tid < 8) s_cols[tid] = c0 + tid * G < K ? c0 + tid * G : c0;
-      __syncthreads();
-      int nc = 0;
-      for (int j = 0; j < 8; ++j) nc += c0 + j * G < K ? 1 : 0;
-      double out8[8];
-      const bool ok = rig_gather_cols<8>(Q.rbox, G, K, s_cols, nc, K - 1, e, s4, out8, fail, Q.timeout_shift);
-      if (!ok) { if (tid == 0) __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-      if (ok && tid < 2 * nc) {
-        const int j = tid >> 1;
-        double v = 0.0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v = j == u ? out8[u] : v;
-        ag_st(Q.cbox + (size_t)s_cols[j] * 2 + (tid & 1), granule(e, v, tid & 1));
-      }
-      __syncthreads();
-    }
-    RPW_MARK(8);
-  }
-  (void)lane; (void)radius;
-}
-
 // ---------------------------------------------------------------------------------------------
 // The LEAN workers of the persistent rig solve (k_rig_persist_w; small rigs: at most 4 observed cameras, 24 shared
 // coordinates) with the control workgroup as a launch of its own beside them (k_rig_persist_ctl: rig_persist_control, on a
@@ -3450,15 +3357,45 @@ __global__ __launch_bounds__(256) void k_rig_persist(RigDev P, RigPersistDev Q) 
 // compact row straight from a slot table (cc_intrinsics_persist.hip's way) instead of going through the partial-row layout.
 // ---------------------------------------------------------------------------------------------
 constexpr int kRpwMaxS = 24;        // shared coordinates: four optimised cameras (none of them frozen)
+constexpr int kRpwMaxCO = 4;        // observed cameras = groups of a frame = sweep waves of a team
 constexpr int kRpwYS = 28;          // row stride of Y / Z (S + 1 <= 25 columns)
 constexpr int kRpwMaxK = 448;       // compact row entries (S = 24: 325 Schur + 108 direct + 2)
 constexpr int kRpwInfoG = 32;       // s_info: [0..31] colinfo of the shared columns, [32..47] group of (team, slot)
-enum { RPW_Y = 0, RPW_Z = 6 * kRpwYS, RPW_POSE = 12 * kRpwYS, RPW_FREC = RPW_POSE + 16, RPW_SP = RPW_FREC + 32, RPW_A = RPW_SP + 8, RPW_GST = RPW_A + 32,
-       RPW_FST = RPW_GST + 8, RPW_HD0 = RPW_FST + 2, RPW_ROW = ((RPW_HD0 + 32 + 7) / 8) * 8, RPW_TEAM = RPW_ROW + kRpwMaxK };   // per-team scratch (doubles)
-// workgroup scratch (doubles): broadcast B (2 + S + 32 cameras: kRigPersistMaxNB), broadcast A, Jacobi scales, statistics row, slot table, ...
-enum { RPW_BC = 0, RPW_AB = 344, RPW_SS = 376, RPW_SROW = 408, RPW_SLOT = 440 /* int[kRpwMaxK] */, RPW_S16 = RPW_SLOT + kRpwMaxK / 2, RPW_INFO = RPW_S16 + 16 /* int[48] */,
-       RPW_COLS = RPW_INFO + 24 /* int[8], int good */, RPW_WG = RPW_COLS + 8 };
-static_assert(kRigPersistMaxNB <= RPW_AB - RPW_BC, "broadcast B must fit its LDS slot");
+// Per-team scratch (doubles). Every region is placed from the SIZE of the one before it, and the sizes from the capacities
+// above: a capacity cannot be raised without the layout following (round 3: a slot sized by hand overflowed beyond four
+// cameras in all and was found late -- c533722).
+enum { RPW_Y = 0,                                  // [6][kRpwYS]   Y
+       RPW_Z = RPW_Y + 6 * kRpwYS,                 // [6][kRpwYS]   Z
+       RPW_POSE = RPW_Z + 6 * kRpwYS,              // [2][8]        the frame's pose, both buffers
+       RPW_FREC = RPW_POSE + 2 * 8,                // [32]          frame record: R(9) t(3) step(6)
+       RPW_SP = RPW_FREC + 32,                     // [8]           Jacobi scale of the pose block (6)
+       RPW_A = RPW_SP + 8,                         // [32]          damped frame block (21) + its gradient (6)
+       RPW_GST = RPW_A + 32,                       // [kRpwMaxCO][2] group statistics
+       RPW_FST = RPW_GST + 2 * kRpwMaxCO,          // [2]           frame statistics
+       RPW_HD0 = RPW_FST + 2,                      // [kRpwMaxCO][8] diagonals of the camera blocks (first round)
+       RPW_ROW = ((RPW_HD0 + 8 * kRpwMaxCO + 7) / 8) * 8,   // [kRpwMaxK] the frame's compact row
+       RPW_TEAM = RPW_ROW + kRpwMaxK };
+// Workgroup scratch (doubles): broadcast B (flags, radius, step[S], records of ALL C cameras), broadcast A (flags, radius, S
+// scales), Jacobi scales (S + 1), statistics row (4 + S), slot table int[kRpwMaxK], sums, s_info int[kRpwInfoG + 4 teams x
+// kRpwMaxCO], column list int[8] + good flag.
+constexpr int kRpwBcDoubles = ((2 + kRpwMaxS + 32 * kRigPersistMaxC + 7) / 8) * 8 + 24;   // (+ 24: round 3's slot was 344 for nine cameras; kept)
+enum { RPW_BC = 0,
+       RPW_AB = RPW_BC + kRpwBcDoubles,
+       RPW_SS = RPW_AB + 32,
+       RPW_SROW = RPW_SS + 32,
+       RPW_SLOT = RPW_SROW + 32,                   // int[kRpwMaxK]
+       RPW_S16 = RPW_SLOT + kRpwMaxK / 2,
+       RPW_INFO = RPW_S16 + 16,                    // int[kRpwInfoG + 16]
+       RPW_COLS = RPW_INFO + (kRpwInfoG + 4 * kRpwMaxCO) / 2,   // int[8], int good
+       RPW_WG = RPW_COLS + 8 };
+static_assert(kRpwYS >= kRpwMaxS + 1, "a row of Y / Z holds the S shared columns and the right-hand side");
+static_assert(kRpwInfoG >= kRpwMaxS + 1, "s_info[0..kRpwInfoG) holds colinfo of the S + 1 columns");
+static_assert(kRpwMaxK % 2 == 0 && kRpwMaxK >= (kRpwMaxS + 1) * (kRpwMaxS + 2) / 2 + kRpwMaxCO * kDE0 + 2, "compact row: Schur entries of S + 1 columns, 27 direct entries per observed camera, failures, gradient maximum");
+static_assert(2 + kRpwMaxS + 32 * kRigPersistMaxC <= RPW_AB - RPW_BC, "broadcast B (step + records of every camera) must fit its LDS slot");
+static_assert(2 + kRpwMaxS <= RPW_SS - RPW_AB && kRpwMaxS + 1 <= RPW_SROW - RPW_SS && 4 + kRpwMaxS <= RPW_SLOT - RPW_SROW, "broadcast A, scales and statistics row must fit their LDS slots");
+static_assert(27 <= RPW_GST - RPW_A && 6 <= RPW_A - RPW_SP && 18 <= RPW_SP - RPW_FREC, "frame block + gradient, pose scale and frame record must fit their LDS slots");
+static_assert(RPW_AB == 344 && RPW_SS == 376 && RPW_SROW == 408 && RPW_SLOT == 440 && RPW_TEAM == ((12 * kRpwYS + 16 + 32 + 8 + 32 + 8 + 2 + 32 + 7) / 8) * 8 + kRpwMaxK,
+              "layout as measured in round 3 (profiles/r03/rig_persist_marks.jsonl); a change of capacity moves it knowingly");
 constexpr int rpw_lds_doubles(int teams) { return teams * (2048 + 512 + 1024 + RPW_TEAM) + RPW_WG; }
 
 // column sums over the G rows of a box, for a workgroup of NW waves (cf. rig_gather_cols; thread t < G polls row t)
@@ -3508,12 +3445,30 @@ __device__ __forceinline__ bool rig_gather_cols_w(const u64* box, int G, int row
   return *s_good != 0;
 }
 
-// (workgroups of a launch go round the eight XCDs, and a workgroup never moves: with G = 250 workers XCDs 0 and 1 hold 32 of
-// them -- every compute unit -- so the control workgroup must be one that lands on another XCD: the LAST block of this
-// launch of (G mod 8) + 1 blocks; the others leave at once)
+// The control workgroup FINDS its compute unit (round 4). Workgroups of a launch are dealt round-robin over the eight XCDs and
+// never move; with G = 250 workers two XCDs hold 32 of them -- every compute unit -- and WHICH two is not fixed (the XCD
+// block 0 of a launch goes to varies: MI355X guide, workgroup dispatch), so no block index can be told in advance to land
+// next to a free compute unit (round 3 launched (G mod 8) + 1 blocks and let the last one work: right only when both
+// launches start their round on the same XCD). This launch has kRigCtlCandidates blocks -- two per XCD -- and the FIRST one
+// that gets to run claims the solve (one exchange on a word tagged with the solve's epoch) and is the control; the others
+// leave as soon as they run (those queued on a full XCD: when the workers are gone). A claim needs a free compute unit
+// somewhere, which G <= 255 leaves; the XCD that gave it is recorded (arrive[12]) for the host's diagnostics.
+constexpr int kRigCtlCandidates = 16;
 __global__ __launch_bounds__(256) void k_rig_persist_ctl(RigDev P, RigPersistDev Q) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (blockIdx.x + 1 != gridDim.x) return;
+  __shared__ int s_mine;
+  if (threadIdx.x == 0) {
+    const unsigned tag = Q.epoch0 + 1u;
+    const unsigned prev = __hip_atomic_exchange(Q.claim, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_mine = prev != tag;
+    if (prev != tag) {
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+      __hip_atomic_store(P.arrive + 12, ((unsigned)blockIdx.x << 8) | (xcc + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  if (!s_mine) return;
   rig_persist_control(P, Q, smem_raw);
 }
 
@@ -3542,6 +3497,12 @@ __global__ __launch_bounds__(TEAMS * 256) void k_rig_persist_w(RigDev P, RigPers
   int* s_info = reinterpret_cast<int*>(s_wg + RPW_INFO);   // [0..31] colinfo, [32..47] group of (team, slot)
   int* s_cols = reinterpret_cast<int*>(s_wg + RPW_COLS);
   int* s_good = s_cols + 8;
+  // ---- every worker is RESIDENT once all G have passed this point: the last one opens the gate of the control launch, whose
+  // candidates therefore only ever run on compute units the workers left free (k_rig_persist_ctl)
+  if (Q.gate && tid0 == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(P.arrive + 13, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev + 1u == (unsigned)G) __hip_atomic_store(Q.gate, Q.epoch0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   // ---- start of the solve: poses of the workgroup's frames (buffer 0 holds the starting point: rig_begin), tables
   for (int i = tid0; i < TEAMS * (2048 + 512); i += NT) s_tile[i] = 0.0;
   for (int i = tid0; i < TEAMS * RPW_TEAM; i += NT) s_tm[i] = 0.0;
@@ -3863,6 +3824,8 @@ __global__ __launch_bounds__(TEAMS * 256) void k_rig_persist_w(RigDev P, RigPers
   // ---- the solve is over: the frame's accepted pose goes back to global memory (cc_rig_get_state, the next solve)
   __syncthreads();
   if (ag_ld32(fail) == 0u && has_frame && twave == 0 && lane < 7) P.pose[((size_t)cur * P.F + f) * 8 + lane] = tm[RPW_POSE + cur * 8 + lane];
+  // (a solve that gave up -- not every worker resident -- still opens the gate: the control launch must not wait for ever)
+  if (Q.gate && tid0 == 0 && ag_ld32(fail) != 0u) __hip_atomic_store(Q.gate, Q.epoch0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // creation: world point of every observation
@@ -3954,13 +3917,15 @@ struct cc_rig {
   std::vector<int64_t> fgoff_h;
   size_t elim_lds = 0, solve_lds = 0;
   bool big = false;             // 128 <= S <= 255: the plain kernels (k_rig_elim_big, k_rig_solve_big), no exchange
-  bool persist_allowed = false; // CC_RIG_PERSIST=1: also the GLUED persistent kernel (k_rig_persist) where the lean one does not fit -- an experiment: slower
-                                //   than the three kernels; CC_RIG_PERSIST=0: no persistent kernel at all (the lean form is on by default)
-  bool persist_lean_allowed = true;
+  bool persist_lean_allowed = true;   // CC_RIG_PERSIST=0: three kernels per iteration always
   double* d_cam_backup = nullptr;   // [C][8] cameras of the starting point (the lean persistent solve may be run again in the three-kernel form)
-  bool persist_ok = false;      // k_rig_persist can run this problem (poses only, <= 4 frames per compute unit, everything resident)
   int p_teams = 4;              // frames per workgroup of the lean form
   bool persist_w_ok = false;    // ... and so can its lean form (k_rig_persist_w + k_rig_persist_ctl: <= 4 observed cameras, <= 24 shared coordinates)
+  int form_reruns = 0;             // lean persistent solves that gave up and were run again in the three-kernel form
+  std::string form_note;           // why (cc_rig_solver_status)
+  bool gate_tried = false;
+  unsigned gate_tag = 0;           // tag the control launch of the last lean solve waits for
+  unsigned* d_gate = nullptr;      // signal memory (hipMallocSignalMemory) the control launch waits on; null: device without stream wait values
   hipStream_t stream2 = nullptr;   // the control workgroup's launch of the lean form
   hipEvent_t ev_begin = nullptr;
   cc::RigPersistDev pq{};
@@ -4037,7 +4002,7 @@ struct RigProbe {  // optional hipEvent bracket around one launch
 // them. Called by create (with the locally observed cameras) and again by the multi-GPU attach calls when
 // another rank observes a camera this one does not.
 static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
-  if (const char* e = getenv("CC_RIG_PERSIST")) { h->persist_allowed = atoi(e) != 0; h->persist_lean_allowed = atoi(e) != 0; }
+  if (const char* e = getenv("CC_RIG_PERSIST")) h->persist_lean_allowed = atoi(e) != 0;
   RigDev& d = h->d;
   const int64_t C = h->C, F = h->F;
   const int kmode = h->kmode;
@@ -4204,10 +4169,14 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<true, kRigDirectPerLane>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_reduce<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_reduce<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
-  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
-  // ---- the persistent per-solve kernel (k_rig_persist): poses only, four frames per compute unit, every workgroup resident
-  h->persist_ok = false;
-  if (!kmode && (h->persist_allowed || h->persist_lean_allowed) && S >= 1 && S <= kRigPersistMaxS && C <= kRigPersistMaxC && F <= 4 * 256) {
+  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_solve<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
+  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_solve<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
+  // ---- the persistent per-solve form (k_rig_persist_w + k_rig_persist_ctl): poses only, at most four frames per compute
+  // unit, every workgroup resident. (Round 3 also kept a GLUED form, k_rig_persist -- the three kernels' bodies in one
+  // launch, 444 registers a thread, 81 us per iteration where the three kernels take 47: retired in round 4, no
+  // configuration was found where it won; profiles/r03/rig_persist_marks.jsonl has its timeline.)
+  h->persist_w_ok = false;
+  if (!kmode && h->persist_lean_allowed && S >= 1 && S <= kRpwMaxS && CO <= kRpwMaxCO && C <= kRigPersistMaxC && F <= 4 * 256) {
     std::vector<int32_t> comp;
     for (size_t i = 0; i < tile_dst.size(); ++i) if (tile_dst[i] != -1) comp.push_back((int32_t)i);
     for (int e = 0; e < d.ND; ++e) if (dir_dst[(size_t)e] != -1) comp.push_back(d.pc_dir + e);
@@ -4217,12 +4186,10 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
     q.G = (int32_t)((F + 3) / 4); q.K = (int32_t)comp.size(); q.KS = 4 + S; q.NB = 2 + S + 32 * (int32_t)C;
     // the lean form (k_rig_persist_w) takes the fewest frames per workgroup that still leave every XCD a compute unit for the
     // control workgroup: fewer frames per compute unit = more of the chip in the sweep
-    const bool lean_shape = CO <= 4 && S <= kRpwMaxS && (int)comp.size() <= kRpwMaxK;
+    const bool lean_shape = (int)comp.size() <= kRpwMaxK;
     h->p_teams = 4;
-    if (lean_shape) {
-      for (int t : {1, 2, 4}) if ((F + t - 1) / t <= 255) { h->p_teams = t; break; }   // (G = 256 would fill every XCD: no compute unit for the control)
-      q.G = (int32_t)((F + h->p_teams - 1) / h->p_teams);
-    }
+    for (int t : {1, 2, 4}) if ((F + t - 1) / t <= 255) { h->p_teams = t; break; }   // (G = 256 would fill every XCD: no compute unit for the control)
+    q.G = (int32_t)((F + h->p_teams - 1) / h->p_teams);
     if (int rc = dev_upload(h, &q.comp, comp)) return rc;
     {   // the same entries as the lean workers build them (k_rig_persist_w)
       std::vector<int32_t> slots(comp.size());
@@ -4240,26 +4207,18 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
       slots[comp.size() - 1] = -2;
       if (int rc = dev_upload(h, &q.slots, slots)) return rc;
     }
-    const int Gmax = (int)std::max<int64_t>(q.G, (F + 3) / 4);   // (the glued form always has four frames per workgroup)
+    const int Gmax = q.G;
     const size_t n_s = (size_t)Gmax * q.KS * 2, n_a = (size_t)(2 + S) * 2, n_r = (size_t)Gmax * q.K * 2, n_c = (size_t)q.K * 2, n_y = (size_t)q.NB * 2;
     u64* base = nullptr;
-    h->p_box_words = n_s + n_a + 2 * n_r + 2 * n_c + n_y;
+    h->p_box_words = n_s + n_a + 2 * n_r + 2 * n_c + n_y + 1;
     if (int rc = dev_zeroed(h, &base, h->p_box_words)) return rc;
     q.sbox = base; q.abox = q.sbox + n_s; q.rbox = q.abox + n_a; q.cbox = q.rbox + n_r; q.ybox = q.cbox + n_c;
     q.pbox = q.ybox + n_y; q.pcbox = q.pbox + n_r;
+    q.claim = reinterpret_cast<unsigned*>(q.pcbox + n_c);
     h->p_epoch = 0;
-    const size_t pl = std::max(h->elim_lds, rig_persist_ctl_lds(h->solve_lds, d));
-    const bool small = d.ND <= 8 * 64;
-    int per_cu = 0, cus = 0;
-    hipError_t e1 = small ? hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_persist<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl)
-                          : hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_persist<kRigDirectPerLane>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl);
-    if (e1 == hipSuccess)
-      e1 = small ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rig_persist<8>, 256, pl)
-                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rig_persist<kRigDirectPerLane>, 256, pl);
-    if (e1 == hipSuccess) e1 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+    int cus = 0;
+    hipError_t e1 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
     if (e1 != hipSuccess) (void)hipGetLastError();
-    // one workgroup per compute unit is what the kernel is built for (its elimination uses most of a CU's registers)
-    h->persist_ok = h->persist_allowed && e1 == hipSuccess && per_cu >= 1 && (F + 3) / 4 + 1 <= cus;
     if (!h->d_cam_backup) { if (int rc = dev_zeroed(h, &h->d_cam_backup, (size_t)C * 8)) return rc; }
     h->persist_w_ok = false;
     if (e1 == hipSuccess && lean_shape && q.G <= 255 && cus >= 256) {
@@ -4274,9 +4233,8 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
            : h->p_teams == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&pw, k_rig_persist_w<2>, 512, (size_t)lb)
                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&pw, k_rig_persist_w<4>, 1024, (size_t)lb);
       if (e2 != hipSuccess) (void)hipGetLastError();
-      h->persist_w_ok = h->persist_lean_allowed && e2 == hipSuccess && pw >= 1;
+      h->persist_w_ok = e2 == hipSuccess && pw >= 1;
     }
-    if (!h->persist_w_ok) q.G = (int32_t)((F + 3) / 4);
   }
   rig_drop_graphs(h);
   return 0;
@@ -4304,14 +4262,32 @@ static void rig_exchange_bounds(const cc_rig* h, int* doubles_kind0, int* double
 // hand where several fit (the query reads one high for kernels with 81..112 SGPRs: MI355X guide, residency). The column
 // sums and the pose update loop over chunks, so any grid >= 1 is correct; 128 blocks are the most that ever paid
 // (2000 frames: 124.4 us per iteration with 128, 127.2 with 64; CC_RIG_REDUCE_BLOCKS for A/B).
-static int rig_size_reduce_grid(cc_rig* h) {
+// Launches of this rank that share the device with other shards of the same solve (cc_rig_optimize_multi with a repeated
+// device id) or with other processes' ranks (cc_rig_exchange_attach with more ranks than visible devices).
+static int rig_co_resident(const cc_rig* h) {
   static const int env_co = getenv("CC_RIG_CO_RESIDENT") ? std::max(1, atoi(getenv("CC_RIG_CO_RESIDENT"))) : 0;
+  return env_co ? env_co : std::max(1, h->co_resident);
+}
+// The mailbox exchange on a SHARED device runs UNFUSED: column sums + posts (k_rig_reduce<4>), the solve step as ONE block
+// (k_rig_solve<2>), the pose update (k_rig_update). In the fused launch every block but one spins until the solving block
+// has run, and the solving block meanwhile polls the PEERS' posts -- a dependency chain across processes through blocks
+// that must all stay resident (rank A's spinners <- A's solving block <- B's posts <- B's reduce launch <- B's sweep and
+// elimination finding room next to A's and C's spinners). Three ranks x 74 blocks of 110 KB of LDS stalled for 10 s on
+// that chain inside longer sessions (round 3, tests/test_gpu_exchange.py); margins on the grid (64 -> 128 -> occupancy
+// query -> 7/8 of it) only moved the point where it happened. Unfused, no block of any launch waits for another block
+// and exactly one block per rank polls, which is what the intrinsics path does and what survived the same sessions.
+// The fused launch stays for a device this rank has to itself (it saves two launch boundaries per iteration).
+static bool rig_unfused_exchange(const cc_rig* h) { return h->exchange && !h->big && rig_co_resident(h) > 1; }
+
+static int rig_size_reduce_grid(cc_rig* h) {
   static const int rcap = getenv("CC_RIG_REDUCE_BLOCKS") ? std::max(1, atoi(getenv("CC_RIG_REDUCE_BLOCKS"))) : 128;
-  const int co = env_co ? env_co : std::max(1, h->co_resident);
+  const int co = rig_co_resident(h);
   const size_t key = (h->solve_lds << 8) ^ ((size_t)co << 1) ^ (h->exchange ? 1u : 0u) ^ ((size_t)h->d.PC << 40) ^ ((size_t)h->F << 20);
   if (key == h->reduce_key && h->reduce_blocks > 0) return 0;
-  if (h->big) {   // column sums only (k_rig_reduce<2>): nothing waits inside that launch
-    h->reduce_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(rcap, (h->d.PC + 15) / 16));
+  if (h->big || rig_unfused_exchange(h)) {   // column sums only (k_rig_reduce<2> / <4>): nothing waits inside that launch
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(rcap, (h->d.PC + 15) / 16));
+    if (blocks != h->reduce_blocks) rig_drop_graphs(h);
+    h->reduce_blocks = blocks;
     h->reduce_key = key;
     return 0;
   }
@@ -4322,9 +4298,9 @@ static int rig_size_reduce_grid(cc_rig* h) {
   if (per_cu < 1 || cus < 1) return fail(CC_ERR_HIP, "k_rig_reduce does not fit a compute unit (%zu bytes of LDS)", h->solve_lds);
   if (per_cu > 1) per_cu -= 1;
   per_cu = std::min(per_cu, 8);
-  // ... and an eighth of the chip stays free: the kernels of the OTHER ranks that run before their own reduce launches
-  // (sweep, elimination) need somewhere to go while this rank's blocks spin, and a grid that needs every last compute
-  // unit hangs on the first one that is not available (three ranks x 85 blocks of 110 KB on 256 units did, round 3)
+  // ... and an eighth of the chip stays free (another tenant's kernels; a grid that needs every last compute unit hangs on
+  // the first one that is not available). co > 1 does not get here with an exchange (rig_unfused_exchange); it still
+  // divides the bound for CC_RIG_CO_RESIDENT set by hand on a single-rank handle.
   const int64_t resident = std::max<int64_t>(1, (int64_t)per_cu * cus * 7 / 8 / co);
   const int64_t want = std::max<int64_t>((h->d.PC + 15) / 16, (h->F + 15) / 16);
   const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(rcap, want), resident));
@@ -4376,7 +4352,11 @@ static int rig_enqueue_round(cc_rig* h, bool initial, bool profile, bool publish
   if (h->comm) {
     { RigProbe p(h, CC_K_REDUCE, profile); hipLaunchKernelGGL(k_rig_reduce<2>, dim3(rblocks), dim3(256), 0, h->stream, d, 0); }
     { RigProbe p(h, CC_K_ALLREDUCE, profile); if (int rc = comm_allreduce_sum(h->comm, d.vec, d.PC + 32, h->stream)) return rc; }
-    { RigProbe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_rig_solve, dim3(1), dim3(256), h->solve_lds, h->stream, d); }
+    { RigProbe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_rig_solve<0>, dim3(1), dim3(256), h->solve_lds, h->stream, d, 0); }
+    { RigProbe p(h, CC_K_UPDATE, profile); hipLaunchKernelGGL(k_rig_update, dim3((unsigned)((h->F + 15) / 16)), dim3(256), 0, h->stream, d); }
+  } else if (rig_unfused_exchange(h)) {   // shared device: nobody waits for a block of its own launch (see rig_unfused_exchange)
+    { RigProbe p(h, CC_K_REDUCE, profile); hipLaunchKernelGGL(k_rig_reduce<4>, dim3(rblocks), dim3(256), 0, h->stream, d, 0); }
+    { RigProbe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_rig_solve<2>, dim3(1), dim3(256), h->solve_lds, h->stream, d, publish ? 1 : 0); }
     { RigProbe p(h, CC_K_UPDATE, profile); hipLaunchKernelGGL(k_rig_update, dim3((unsigned)((h->F + 15) / 16)), dim3(256), 0, h->stream, d); }
   } else {   // reduce + solve step + pose update in one launch
     RigProbe p(h, CC_K_SOLVE, profile);
@@ -4409,12 +4389,18 @@ static int rig_read_ctl(cc_rig* h, LmCtl* c, bool* wait_failed = nullptr) {
 // Waits for the chunk just enqueued: spins on the sequence word its last reduce launch stores into pinned host memory
 // (no copy engine, no stream synchronisation on the way), then takes the control block and the failure word from next
 // to it. A stream that has gone idle without the word showing up (a kernel fault) falls back to a copy.
-static int rig_wait_published(cc_rig* h, LmCtl* c, bool* wait_failed) {
+// `lean`: the chunk is a lean persistent solve -- its ONLY publisher is the control workgroup on h->stream2, and the workers
+// on h->stream leave as soon as they have seen `done` in their boxes, a few microseconds BEFORE the control has written the
+// control block and the sequence word. The fallback is therefore taken only when BOTH streams are idle (ADVICE round 3:
+// with h->stream alone the host could re-synchronise its count and read a half-written control block while the control
+// workgroup was still publishing, and the late publication then satisfied the NEXT solve's wait at once).
+static int rig_wait_published(cc_rig* h, LmCtl* c, bool* wait_failed, bool lean = false) {
   const unsigned long long want = ++h->pub_count;
   for (unsigned spins = 0;; ++spins) {
     if (__atomic_load_n(const_cast<const unsigned long long*>(h->host_pub), __ATOMIC_ACQUIRE) == want) break;
     if ((spins & 0xfffu) == 0xfffu) {
-      const hipError_t q = hipStreamQuery(h->stream);
+      hipError_t q = hipStreamQuery(h->stream);
+      if (q == hipSuccess && lean && h->stream2) q = hipStreamQuery(h->stream2);
       if (q == hipSuccess) {
         if (__atomic_load_n(const_cast<const unsigned long long*>(h->host_pub), __ATOMIC_ACQUIRE) == want) break;
         h->pub_count = __atomic_load_n(const_cast<const unsigned long long*>(h->host_pub), __ATOMIC_ACQUIRE);
@@ -4684,7 +4670,14 @@ void cc_rig_destroy(cc_rig* h) {
   hipSetDevice(h->device);
   bool stream_ok = true;
   if (h->stream) stream_ok = hipStreamSynchronize(h->stream) == hipSuccess;
-  if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
+  if (h->stream2) {
+    // (a control launch still held at its gate -- the workers never ran -- is let through: it finds the solve's failure word
+    // or claim and leaves)
+    if (h->d_gate && h->gate_tag) (void)hipStreamWriteValue32(h->stream, h->d_gate, h->gate_tag, 0);
+    hipStreamSynchronize(h->stream2);
+    hipStreamDestroy(h->stream2);
+  }
+  if (h->d_gate) (void)hipFree(h->d_gate);
   if (h->ev_begin) hipEventDestroy(h->ev_begin);
   cc::rig_drop_graphs(h);
   for (auto e : h->events) hipEventDestroy(e);
@@ -4810,42 +4803,48 @@ static int rig_begin(cc_rig* h, const cc_options* opt, RigRun* r) {
 
 static int rig_launch(cc_rig* h, RigRun* r, int chunk) {
   CC_HIP(hipSetDevice(h->device));
-  if (chunk == 0 && !r->no_persist && (h->persist_ok || h->persist_w_ok) && h->sweep_adjoint && !r->profile && !h->comm && !h->exchange && !h->big && h->co_resident <= 1) {
+  if (chunk == 0 && !r->no_persist && h->persist_w_ok && h->sweep_adjoint && !r->profile && !h->comm && !h->exchange && !h->big && h->co_resident <= 1) {
     // the whole solve in one launch (k_rig_persist); the control workgroup publishes when it is over
     RigPersistDev q = h->pq;
     q.max_rounds = r->o.max_iterations + 2;
     q.timeout_shift = 27;   // 1.3 s of the 100 MHz wall clock
     if (h->p_epoch > 0x7fff0000u - (unsigned)q.max_rounds) {   // the 32-bit tags would wrap: start over on zeroed boxes
-      CC_HIP(hipMemsetAsync(h->pq.sbox, 0, h->p_box_words * sizeof(unsigned long long), h->stream));
+      CC_HIP(hipMemsetAsync(h->pq.sbox, 0, h->p_box_words * sizeof(unsigned long long), h->stream));   // (the claim word is its last)
       h->p_epoch = 0;
     }
     q.epoch0 = h->p_epoch;
     h->p_epoch += (unsigned)q.max_rounds + 2u;
-    static const bool lean = !(getenv("CC_RIG_PERSIST_LEAN") && atoi(getenv("CC_RIG_PERSIST_LEAN")) == 0);
-    if (h->persist_w_ok && lean) {
-      // lean workers (sixteen waves a compute unit) + the control workgroup as a launch of its own on a second stream, behind
-      // everything rig_begin put on the first
-      CC_HIP(hipMemcpyAsync(h->d_cam_backup, h->d.cam, (size_t)h->C * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-      if (!h->stream2) CC_HIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-      if (!h->ev_begin) CC_HIP(hipEventCreateWithFlags(&h->ev_begin, hipEventDisableTiming));
-      CC_HIP(hipEventRecord(h->ev_begin, h->stream));
-      CC_HIP(hipStreamWaitEvent(h->stream2, h->ev_begin, 0));
-      static const bool drop_control = getenv("CC_RIG_PERSIST_TEST_NO_CONTROL") && atoi(getenv("CC_RIG_PERSIST_TEST_NO_CONTROL")) != 0;   // (test hook: the workers' first wait gives up)
-      if (!drop_control)
-        hipLaunchKernelGGL(k_rig_persist_ctl, dim3((unsigned)(q.G % 8) + 1u), dim3(256), rig_persist_ctl_lds(h->solve_lds, h->d), h->stream2, h->d, q);
-
-      const size_t lb = (size_t)rpw_lds_doubles(h->p_teams) * 8;
-      if (h->p_teams == 1) hipLaunchKernelGGL(k_rig_persist_w<1>, dim3((unsigned)q.G), dim3(256), lb, h->stream, h->d, q);
-      else if (h->p_teams == 2) hipLaunchKernelGGL(k_rig_persist_w<2>, dim3((unsigned)q.G), dim3(512), lb, h->stream, h->d, q);
-      else hipLaunchKernelGGL(k_rig_persist_w<4>, dim3((unsigned)q.G), dim3(1024), lb, h->stream, h->d, q);
-    } else {
-      q.G = (int32_t)((h->F + 3) / 4);
-      q.pbox = nullptr; q.pcbox = nullptr;   // (its workers wait for every decision)
-      const size_t pl = std::max(h->elim_lds, rig_persist_ctl_lds(h->solve_lds, h->d));
-      const dim3 grid((unsigned)q.G + 1u);
-      if (h->d.ND <= 8 * 64) hipLaunchKernelGGL(k_rig_persist<8>, grid, dim3(256), pl, h->stream, h->d, q);
-      else hipLaunchKernelGGL(k_rig_persist<kRigDirectPerLane>, grid, dim3(256), pl, h->stream, h->d, q);
+    // lean workers (sixteen waves a compute unit) + the control workgroup as a launch of its own on a second stream, behind
+    // everything rig_begin put on the first
+    CC_HIP(hipMemcpyAsync(h->d_cam_backup, h->d.cam, (size_t)h->C * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    if (!h->stream2) CC_HIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    if (!h->ev_begin) CC_HIP(hipEventCreateWithFlags(&h->ev_begin, hipEventDisableTiming));
+    CC_HIP(hipEventRecord(h->ev_begin, h->stream));
+    CC_HIP(hipStreamWaitEvent(h->stream2, h->ev_begin, 0));
+    static const bool drop_control = getenv("CC_RIG_PERSIST_TEST_NO_CONTROL") && atoi(getenv("CC_RIG_PERSIST_TEST_NO_CONTROL")) != 0;   // (test hook: the workers' first wait gives up)
+    // the control launch is held at the command processor until every worker is resident (the last worker to start stores the
+    // solve's tag into the signal word), so that whichever candidate runs first sits on a compute unit no worker needs
+    static const bool use_gate = !(getenv("CC_RIG_CTL_GATE") && atoi(getenv("CC_RIG_CTL_GATE")) == 0);
+    if (use_gate && !h->d_gate && !h->gate_tried) {
+      h->gate_tried = true;
+      int can = 0;
+      if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, h->device) != hipSuccess) { can = 0; (void)hipGetLastError(); }
+      if (can && hipExtMallocWithFlags((void**)&h->d_gate, 8, hipMallocSignalMemory) != hipSuccess) { h->d_gate = nullptr; (void)hipGetLastError(); }
+      if (h->d_gate) CC_HIP(hipMemsetAsync(h->d_gate, 0, 8, h->stream));
     }
+    q.gate = use_gate ? h->d_gate : nullptr;
+    if (q.gate && !drop_control && hipStreamWaitValue32(h->stream2, q.gate, q.epoch0 + 1u, hipStreamWaitValueEq, 0xffffffffu) != hipSuccess) {
+      (void)hipGetLastError();
+      q.gate = nullptr;   // (no gate on this stack: the candidates claim as they come)
+    }
+    h->gate_tag = q.gate ? q.epoch0 + 1u : 0u;
+    if (!drop_control)
+      hipLaunchKernelGGL(k_rig_persist_ctl, dim3((unsigned)kRigCtlCandidates), dim3(256), rig_persist_ctl_lds(h->solve_lds, h->d), h->stream2, h->d, q);
+
+    const size_t lb = (size_t)rpw_lds_doubles(h->p_teams) * 8;
+    if (h->p_teams == 1) hipLaunchKernelGGL(k_rig_persist_w<1>, dim3((unsigned)q.G), dim3(256), lb, h->stream, h->d, q);
+    else if (h->p_teams == 2) hipLaunchKernelGGL(k_rig_persist_w<2>, dim3((unsigned)q.G), dim3(512), lb, h->stream, h->d, q);
+    else hipLaunchKernelGGL(k_rig_persist_w<4>, dim3((unsigned)q.G), dim3(1024), lb, h->stream, h->d, q);
     CC_HIP(hipGetLastError());
     r->persist = true;
     r->launched += q.max_rounds;
@@ -4867,24 +4866,59 @@ static int rig_launch(cc_rig* h, RigRun* r, int chunk) {
   return 0;
 }
 
+// After a wait inside the kernels gave up: this rank's position, in words -- launches of each kind started in this solve,
+// the synchronisation words, and what its mailbox holds of every rank's posts. Every rank that gives up prints its own;
+// together they name the stalled link (whose reduce launch never started, or whose post never arrived).
+static std::string rig_describe_stall(cc_rig* h) {
+  (void)hipStreamSynchronize(h->stream);   // (every later launch of the chunk returns at once: done / failure word)
+  struct { LmCtl c; unsigned w[16]; } snap{};
+  if (hipMemcpy(&snap, h->d.ctl_next, sizeof(snap), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return "state unreadable"; }
+  static const char* names[RIG_PROG_COUNT] = {"sweep", "stats", "init", "elim", "reduce", "solve", "update"};
+  char buf[256];
+  std::string out = "launches started this solve:";
+  for (int k = 0; k < RIG_PROG_COUNT; ++k) { std::snprintf(buf, sizeof(buf), " %s %u", names[k], snap.w[4 + k]); out += buf; }
+  std::snprintf(buf, sizeof(buf), "; %s form, reduce grid %d, co-resident %d; reduce blocks arrived %u, flag word epoch %u (done %u, step %u, cur %u), failure word %u; ",
+                rig_unfused_exchange(h) ? "unfused (reduce / solve / update as three launches)" : "fused reduce + solve + update",
+                h->reduce_blocks, rig_co_resident(h), snap.w[0], snap.w[1] >> 3, (snap.w[1] >> 2) & 1u, (snap.w[1] >> 1) & 1u, snap.w[1] & 1u, snap.w[3]);
+  out += buf;
+  if (h->exchange) out += mailbox_describe(&h->mailbox, h->d.rank, h->d.nranks);
+  return out;
+}
+
 static int rig_wait(cc_rig* h, RigRun* r) {
   CC_HIP(hipSetDevice(h->device));
   bool wait_failed = false;
-  if (int rc = ((h->comm || h->big) ? rig_read_ctl(h, &r->st, &wait_failed) : rig_wait_published(h, &r->st, &wait_failed))) return rc;
+  const bool lean_run = r->persist && h->persist_w_ok && h->stream2 != nullptr;   // (what rig_launch put on two streams)
+  if (int rc = ((h->comm || h->big) ? rig_read_ctl(h, &r->st, &wait_failed) : rig_wait_published(h, &r->st, &wait_failed, lean_run))) return rc;
   if (r->st.done) { h->last_st = r->st; h->st_known = true; }
   if (wait_failed && r->persist) {
-    const bool was_lean = h->persist_w_ok;
-    h->persist_ok = false;   // (this handle runs the three-kernel form from now on)
+    // The lean form keeps the starting point intact: cc_rig_solve runs the solve again, three kernels per iteration, and this
+    // handle stays on that form. NOT silently (ADVICE / review of round 3): the demotion is counted and its reason kept for
+    // cc_rig_solver_status -- launches started, where the control workgroup ran (or that it never did), the round reached.
     h->persist_w_ok = false;
-    if (was_lean) { r->rerun = true; return 0; }   // (the lean form keeps the starting point intact: cc_rig_solve runs the solve again)
-    return fail(CC_ERR_COMM, "k_rig_persist: a workgroup waited 1.3 s for another one (round %d): the launch was not fully resident "
-                "(%d workgroups; a device shared with another process?). The handle now runs the three-kernel form", r->st.iter, h->pq.G + 1);
+    h->form_reruns++;
+    unsigned w[16] = {};
+    (void)hipStreamSynchronize(h->stream);
+    if (hipMemcpy(w, h->d.arrive, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) (void)hipGetLastError();
+    char note[512];
+    std::snprintf(note, sizeof(note), "lean persistent solve gave up in round %d after a 1.3 s wait (%d worker workgroups of %d threads + control): "
+                  "%u workers had started, control workgroup %s (candidate %u, XCD %d)%s; the solve was run again with three kernels per "
+                  "iteration and the handle stays on that form (kernel-serialising tools, a CU mask or another tenant on the device cause this)",
+                  r->st.iter, h->pq.G, h->p_teams * 256, w[13], w[12] ? "claimed a compute unit" : "NEVER RAN", w[12] >> 8, (int)(w[12] & 0xffu) - 1,
+                  h->gate_tag ? "" : ", no command-processor gate");
+    h->form_note = note;
+    r->rerun = true;
+    return 0;
   }
-  if (wait_failed)
+  if (wait_failed) {
+    const std::string where = rig_describe_stall(h);
     return fail(CC_ERR_COMM, "k_rig_reduce: the solving block did not publish within 10 s (iteration %d): its launch was not fully "
-                "resident (%d blocks; shards or processes sharing the device? CC_RIG_CO_RESIDENT) or a peer rank stalled", r->st.iter, h->reduce_blocks);
-  if (r->st.done && r->st.term == CC_FAILURE_EXCHANGE)
-    return fail(CC_ERR_COMM, "mailbox exchange timed out: a peer rank did not post within 10 s (iteration %d)", r->st.iter);
+                "resident (%d blocks; shards or processes sharing the device? CC_RIG_CO_RESIDENT) or a peer rank stalled. %s", r->st.iter, h->reduce_blocks, where.c_str());
+  }
+  if (r->st.done && r->st.term == CC_FAILURE_EXCHANGE) {
+    const std::string where = rig_describe_stall(h);
+    return fail(CC_ERR_COMM, "mailbox exchange timed out: a peer rank did not post within 10 s (iteration %d). %s", r->st.iter, where.c_str());
+  }
   if (!r->st.done && r->launched > r->o.max_iterations + 2 * r->o.check_interval + 2)
     return fail(CC_ERR_STATE, "rig LM loop did not terminate (iter=%d)", r->st.iter);
   return 0;
@@ -4941,6 +4975,7 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
       // global memory only at the end of a solve that did not fail, and the cameras of the starting point were put
       // aside: restore them and run the solve again, three kernels per iteration (no co-residency needed).
       CC_HIP(hipStreamSynchronize(h->stream));
+      if (h->d_gate && h->gate_tag) (void)hipStreamWriteValue32(h->stream, h->d_gate, h->gate_tag, 0);   // (the failing workers opened it; belt and braces)
       if (h->stream2) CC_HIP(hipStreamSynchronize(h->stream2));
       CC_HIP(hipMemcpyAsync(h->d.cam, h->d_cam_backup, (size_t)h->C * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
       h->last_st = LmCtl{};   // (buffer 0 holds the starting point)
@@ -4961,8 +4996,17 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
 int cc_rig_solver_form(cc_rig* h) {
   using namespace cc;
   if (!h) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_solver_form: NULL handle");
-  if (!((h->persist_ok || h->persist_w_ok) && h->sweep_adjoint && !h->comm && !h->exchange && !h->big && h->co_resident <= 1)) return 0;
-  return h->persist_w_ok ? 2 : 1;
+  if (!(h->persist_w_ok && h->sweep_adjoint && !h->comm && !h->exchange && !h->big && h->co_resident <= 1)) return 0;
+  return 2;
+}
+
+int cc_rig_solver_status(cc_rig* h, int32_t* form, int32_t* reruns, char* note, int32_t note_capacity) {
+  using namespace cc;
+  if (!h) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_solver_status: NULL handle");
+  if (form) *form = cc_rig_solver_form(h);
+  if (reruns) *reruns = h->form_reruns;
+  if (note && note_capacity > 0) std::snprintf(note, (size_t)note_capacity, "%s", h->form_note.c_str());
+  return CC_OK;
 }
 
 int cc_rig_get_state(cc_rig* h, double* cam_q, double* cam_t, double* frame_q, double* frame_t, double* obs_cost) {

@@ -139,6 +139,10 @@ int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* sum
 /* 0: two kernels per iteration; 1, 2, 4: the persistent kernel with that many frames per workgroup. With an exchange
  * attached the answer is what the ranks agreed on (cc_intrinsics_exchange_attach). */
 int cc_intrinsics_solver_form(cc_intrinsics* h);
+/* The same, with the history of the handle: *reruns = persistent solves that gave up (a wait inside the kernel timed out:
+ * not every workgroup resident) and were run again in the two-kernel form, which the handle then keeps; note = what the
+ * last one reported (NUL-terminated, truncated to note_capacity). Any output may be NULL. */
+int cc_intrinsics_solver_status(cc_intrinsics* h, int32_t* form, int32_t* reruns, char* note, int32_t note_capacity);
 
 /* Measurement aid: launches `n` steady-state Jacobian sweeps (candidate step + sweep, exactly the
  * kernel an LM iteration runs) back to back on the solver's stream between two hipEvents and
@@ -230,12 +234,16 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary);
 /* Which form cc_rig_solve runs (without profiling):
  *   2 -- the whole solve as ONE launch of the lean persistent kernel (+ its control workgroup's launch): poses only, at most 4
  *        observed cameras, 24 shared coordinates, ~1020 frames, the device to itself; the default where it fits. If its
- *        workgroups cannot all be resident the solve is run again in form 0 (same result, 1.3 s late, once per handle);
+ *        workgroups cannot all be resident the solve is run again in form 0 (same result, 1.3 s late, once per handle:
+ *        the handle stays on form 0 -- cc_rig_solver_status says so and why);
  *   0 -- three kernels per LM iteration (sweep, decision + elimination, reduce + solve step + pose update): any size, any
- *        exchange; CC_RIG_PERSIST=0 forces it;
- *   1 -- the glued persistent kernel (poses only, <= 1024 frames, 48 shared coordinates, 9 cameras): an experiment enabled by
- *        CC_RIG_PERSIST=1 where form 2 does not fit; correct but slower than form 0. */
+ *        exchange; CC_RIG_PERSIST=0 forces it.
+ * (Round 3's form 1, a glued persistent kernel behind CC_RIG_PERSIST=1, was slower than form 0 everywhere and is gone.) */
 int cc_rig_solver_form(cc_rig* h);
+/* The same, with the history of the handle: *reruns = lean persistent solves that gave up (not every workgroup resident)
+ * and were run again in form 0; note (NUL-terminated, truncated to note_capacity) = the reason of the last one -- round
+ * reached, workers started, whether and where the control workgroup ran. Any output may be NULL. */
+int cc_rig_solver_status(cc_rig* h, int32_t* form, int32_t* reruns, char* note, int32_t note_capacity);
 /* Any output may be NULL. obs_cost[k] = 1/2 rho(|r_k|^2) at the current point, in the caller's
  * observation order (extrinsics_calibrator.cpp:219-225). */
 int cc_rig_get_state(cc_rig* h, double* cam_q, double* cam_t, double* frame_q, double* frame_t,

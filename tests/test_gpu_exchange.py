@@ -130,11 +130,12 @@ def test_sharded_rig_solve_over_the_mailbox_exchange(world, cams, frames, pts, t
             assert str(r[name + "_termname"]) == ref[5]["termination"] and int(r[name + "_iters"]) == ref[5]["iterations"]
             assert list(r[name + "_acc"]) == [l["accepted"] for l in ref[5]["log"]]
             assert np.allclose(r[name + "_costs"], [l["cost"] for l in ref[5]["log"]], rtol=1e-9)
-            assert np.abs(r[name + "_cam_q"] - ref[0]).max() < 1e-9 and np.abs(r[name + "_cam_t"] - ref[1]).max() < 1e-9
             f0, f1, o0, o1 = int(r["f0"]), int(r["f1"]), int(r["o0"]), int(r["o1"])
-            assert np.abs(r[name + "_frame_q"] - ref[2][f0:f1]).max() < 1e-8
-            assert np.abs(r[name + "_frame_t"] - ref[3][f0:f1]).max() < 1e-8
-            assert np.allclose(r[name + "_cost"], ref[4][o0:o1], rtol=1e-6, atol=1e-13)
+            dev = dict(cam_q=np.abs(r[name + "_cam_q"] - ref[0]).max(), cam_t=np.abs(r[name + "_cam_t"] - ref[1]).max(),
+                       frame_q=np.abs(r[name + "_frame_q"] - ref[2][f0:f1]).max(), frame_t=np.abs(r[name + "_frame_t"] - ref[3][f0:f1]).max())
+            assert max(dev.values()) < 1e-11, dev   # (summation order only; was 1e-9 / 1e-8)
+            # per-observation costs 1/2 rho(|r|^2) of residuals ~1e-3 formed from O(1) numbers: relative floor ~1e3 eps per residual
+            assert np.allclose(r[name + "_cost"], ref[4][o0:o1], rtol=1e-8, atol=1e-16), np.abs(r[name + "_cost"] / np.maximum(ref[4][o0:o1], 1e-300) - 1).max()
         assert np.array_equal(ranks[0]["default_cam_t"], ranks[0]["nograph_cam_t"])
 
 
@@ -157,31 +158,25 @@ def test_sharded_rig_with_intrinsics_over_the_mailbox_exchange(world, cams, fram
             assert np.array_equal(r[name + "_intr"], ranks[0][name + "_intr"]) and np.array_equal(r[name + "_cam_t"], ranks[0][name + "_cam_t"])
             assert str(r[name + "_termname"]) == s["termination"] and int(r[name + "_iters"]) == s["iterations"]
             assert np.allclose(r[name + "_costs"], [l["cost"] for l in s["log"]], rtol=1e-9)
-            assert np.allclose(r[name + "_intr"][:4], intr[:4], rtol=1e-9) and np.allclose(r[name + "_intr"][4:], intr[4:], atol=1e-8)
-            assert np.abs(r[name + "_cam_t"] - ref[1]).max() < 1e-8
+            # sharded against one GPU: the same arithmetic with the sums split by rank -- a different summation order, nothing
+            # else (measured floor of that: <= 8e-14, profiles/r03/rigk_deviation.jsonl). Was 1e-9 / 1e-8 / 1e-7.
             f0, f1 = int(r["f0"]), int(r["f1"])
-            assert np.abs(r[name + "_frame_t"] - ref[3][f0:f1]).max() < 1e-7
+            dev = dict(f=np.abs(r[name + "_intr"][:4] / intr[:4] - 1).max(), dist=np.abs(r[name + "_intr"][4:] - intr[4:]).max(),
+                       cam_t=np.abs(r[name + "_cam_t"] - ref[1]).max(), frame_t=np.abs(r[name + "_frame_t"] - ref[3][f0:f1]).max())
+            assert max(dev.values()) < 1e-11, dev
 
 
 def test_three_ranks_with_per_camera_intrinsics_share_one_gpu_without_starving_each_other(tmp_path):
-    """Round 2's hang, as a test: the fused reduce + solve + update launch of the rig path keeps its blocks spinning until
-    the launch's solving block has run, and with 114 shared coordinates (8 cameras with intrinsics of their own) that
-    launch holds 110 KB of LDS per block -- one block per CU. Three ranks on one GPU asking for 128 blocks each do not
-    fit 256 CUs: the spinning blocks of one rank kept another rank's solving block off the chip and the solve ended in
-    a 10 s timeout. The grid is now sized from the occupancy query and the ranks sharing the device
-    (rig_size_reduce_grid); a wait that does time out is reported as CC_ERR_COMM instead of being passed over."""
+    """Rounds 2 and 3's stall, as a test. With 114 shared coordinates (8 cameras with intrinsics of their own) the FUSED
+    reduce + solve + update launch of the rig path holds 110 KB of LDS per block -- one block per CU -- and keeps every block
+    but one spinning until the launch's solving block has run, which in turn polls the PEERS' posts: three ranks on one GPU
+    formed a wait chain across processes through blocks that all had to stay resident, and inside a long session it timed
+    out after 10 s (round 3 hid that behind a skip). Ranks that share a device now run the solve step UNFUSED
+    (rig_unfused_exchange, cc_rig.hip: k_rig_reduce<4> -> k_rig_solve<2> -> k_rig_update): no block waits for a block of its
+    own launch, one block per rank polls. No skip: the ranks must agree with the single-GPU solve."""
     from tests.helpers import rigk_case
     world, cams, frames, pts = 3, 8, 45, 12
-    try:
-        ranks = _run_ranks(world, frames, pts, tmp_path, extra=(f"rigkpc:{cams}",))
-    except RanksFailed as e:
-        # Three PROCESSES spinning on each other's posts on one GPU are at the mercy of how the box schedules them (seen on the
-        # MI355X pool: the same three ranks pass on their own and stall for > 10 s inside a longer test session). What the
-        # library owes in that case is what round 2 lacked: no hang, no half-applied update passed off as an iteration --
-        # every rank must come back with CC_ERR_COMM and say which wait gave up. Anything else is a failure.
-        for log in e.logs:
-            assert "cc error -4" in log and ("did not publish within 10 s" in log or "did not post within 10 s" in log), str(e)
-        pytest.skip("the three ranks were not co-scheduled on this box; every rank reported the timed-out wait (CC_ERR_COMM)")
+    ranks = _run_ranks(world, frames, pts, tmp_path, extra=(f"rigkpc:{cams}",))
     k = rigk_case(cams, frames, pts, per_camera=True)
     prob = capi.RigProblem(cams, k["frame_offsets"], k["obs_cam"], k["obs_world"], k["obs_uv_pix"], k["world_xyz"], k["cam_frozen"],
                            huber_a=0.0, with_intrinsics="per_camera")
@@ -197,7 +192,7 @@ def test_three_ranks_with_per_camera_intrinsics_share_one_gpu_without_starving_e
             assert np.array_equal(r[name + "_intr"], ranks[0][name + "_intr"]) and np.array_equal(r[name + "_cam_t"], ranks[0][name + "_cam_t"])
             assert str(r[name + "_termname"]) == s["termination"] and int(r[name + "_iters"]) == s["iterations"]
             assert np.allclose(r[name + "_costs"], [l["cost"] for l in s["log"]], rtol=1e-9)
-            assert np.allclose(r[name + "_intr"][:, :4], intr[:, :4], rtol=1e-8) and np.allclose(r[name + "_intr"][:, 4:], intr[:, 4:], atol=1e-7)
-            assert np.abs(r[name + "_cam_t"] - ref[1]).max() < 1e-7
-            f0, f1 = int(r["f0"]), int(r["f1"])
-            assert np.abs(r[name + "_frame_t"] - ref[3][f0:f1]).max() < 1e-7
+            f0, f1 = int(r["f0"]), int(r["f1"])   # (tolerances: see the shared-intrinsics test above; were 1e-8 / 1e-7)
+            dev = dict(f=np.abs(r[name + "_intr"][:, :4] / intr[:, :4] - 1).max(), dist=np.abs(r[name + "_intr"][:, 4:] - intr[:, 4:]).max(),
+                       cam_t=np.abs(r[name + "_cam_t"] - ref[1]).max(), frame_t=np.abs(r[name + "_frame_t"] - ref[3][f0:f1]).max())
+            assert max(dev.values()) < 1e-11, dev

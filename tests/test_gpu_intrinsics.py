@@ -234,6 +234,8 @@ def test_persistent_solve_that_cannot_get_its_grid_is_rerun_in_the_two_kernel_fo
         s = prob.solve(capi.default_options())
         dt = time.time() - t0
         assert prob.solver_form() == 0 and dt > 1.0, (prob.solver_form(), dt)
+        form, reruns, note = prob.solver_status()        # the demotion is visible, with the kernel's own words
+        assert (form, reruns) == (0, 1) and "two kernels" in note and "never ran" in note, (form, reruns, note)
         ig, qg, tg = prob.get_state()
         s2 = prob.solve(capi.default_options())          # continues from the accepted point, two-kernel form, no stall
         prob.close()

@@ -391,17 +391,16 @@ _NESTED = any(os.environ.get(k) for k in ("CC_RIG_PERSIST", "CC_RIG_FORCE_BIG"))
 
 
 @pytest.mark.skipif(_NESTED, reason="a forced solver form is already in the environment")
-@pytest.mark.parametrize("persist", ["0", "1"])
-def test_the_rig_suite_in_every_form_of_the_solver(persist):
+def test_the_rig_suite_in_every_form_of_the_solver():
     """A small rig (at most 4 observed cameras, 24 shared coordinates, ~1020 frames) is solved by ONE launch of the lean
     persistent kernel (k_rig_persist_w + k_rig_persist_ctl) by default -- which is what every other test in this file then
-    exercises. CC_RIG_PERSIST=0: the three kernels per LM iteration on everything; CC_RIG_PERSIST=1: additionally the glued
-    persistent kernel (k_rig_persist, an experiment that is slower than the three kernels) where the lean one does not
-    fit. The rig suite again, in both."""
-    env = dict(os.environ, CC_RIG_PERSIST=persist)
+    exercises. CC_RIG_PERSIST=0: the three kernels per LM iteration on everything. The rig suite again, in that form.
+    (Round 3's third form, the glued persistent kernel behind CC_RIG_PERSIST=1, is gone: CC_RIG_PERSIST=1 is the default.)"""
+    env = dict(os.environ, CC_RIG_PERSIST="0")
     assert _form_of(3, 40, 20, dict(os.environ)) == 2
-    assert _form_of(3, 40, 20, env) == (2 if persist == "1" else 0)
-    assert _form_of(8, 30, 10, env) == (1 if persist == "1" else 0)      # 42 shared coordinates: not the lean form's
+    assert _form_of(3, 40, 20, dict(os.environ, CC_RIG_PERSIST="1")) == 2
+    assert _form_of(3, 40, 20, env) == 0
+    assert _form_of(8, 30, 10, dict(os.environ)) == 0      # 42 shared coordinates: not the lean form's
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_rig.py", "-q", "-m", "gpu", "-x",
                         "-k", "not rccl and not exchange and not plain_kernels and not every_form and not ranks and not rerun", "-p", "no:cacheprovider"],
@@ -427,11 +426,13 @@ def test_lean_persistent_solve_that_cannot_get_its_grid_is_rerun_in_the_three_ke
             "assert p.solver_form() == 2\n"
             "t0 = time.time(); s = p.solve(); dt = time.time() - t0\n"
             "assert p.solver_form() == 0 and dt > 1.0, (p.solver_form(), dt)\n"
+            "form, reruns, note = p.solver_status()\n"
+            "assert (form, reruns) == (0, 1) and 'NEVER RAN' in note and 'three kernels' in note, (form, reruns, note)\n"
             "g = p.get_state()\n"
             "o = po.rig_solve(*args, cq, ct, sc['cam_frozen'], fq, ft, options=po.default_options(max_iterations=1000))\n"
             "assert s['iterations'] == o[5]['iterations'] and s['termination'] == o[5]['termination']\n"
             "assert all(np.abs(g[k] - o[k]).max() < 1e-9 for k in range(4))\n"
-            "s2 = p.solve(); assert s2['iterations'] <= 2\n"
+            "s2 = p.solve(); assert s2['iterations'] <= 2 and p.solver_status()[1] == 1\n"
             "print('rerun ok', dt)\n") % root
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CC_RIG_PERSIST_TEST_NO_CONTROL="1"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "rerun ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

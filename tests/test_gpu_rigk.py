@@ -33,7 +33,9 @@ def _assert_same(g, o):
     assert np.allclose(g[0][:4], o[0][:4], rtol=1e-11) and np.allclose(g[0][4:], o[0][4:], atol=1e-11)   # (measured <= 5e-14: profiles/r03/rigk_deviation.jsonl)
     for a in range(1, 5):
         assert np.abs(g[a] - o[a]).max() < 1e-11
-    assert np.allclose(g[5], o[5], rtol=1e-6, atol=1e-12)
+    # per-observation costs: 1/2 |r|^2 of ~0.3 px residuals formed as differences of ~1e3 px numbers -- relative floor measured
+    # <= 4.7e-10 (profiles/r03/rigk_deviation.jsonl), asserted at 1e-8 (was 1e-6)
+    assert np.allclose(g[5], o[5], rtol=1e-8, atol=1e-12), np.abs(g[5] / np.maximum(o[5], 1e-300) - 1).max()
 
 
 @pytest.mark.parametrize("cams,frames,pts", [(2, 50, 8), (4, 60, 30), (3, 20, 300), (8, 25, 70), (1, 40, 20)])
