@@ -137,6 +137,9 @@ struct RigDev {
 
 // Progress words of a solve (zeroed with the control block, read by the host only after a wait gave up): launches of each
 // kind that have STARTED -- with the mailbox epochs this names the link of a stalled chain (rig_describe_stall).
+// NOT in the sweep kernels: one scalar branch and an atomic at the top of k_rig_sweep_adj<1> moved its register allocation
+// from 126 VGPRs / 87 SGPRs without spills to 128 / 66 with ten spilled registers -- 56.8 -> 82.2 us per launch at BASELINE
+// configs[4] (gpurun_out/r4g, same box A/B against the round-3 library). The statistics / elimination counters bracket the sweep.
 enum { RIG_PROG_SWEEP = 0, RIG_PROG_STATS, RIG_PROG_INIT, RIG_PROG_ELIM, RIG_PROG_REDUCE, RIG_PROG_SOLVE, RIG_PROG_UPDATE, RIG_PROG_COUNT };
 __device__ __forceinline__ void rig_progress(const RigDev& P, int kind) {
   if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(P.arrive + 4 + kind, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (no return value: nothing waits)
@@ -304,7 +307,6 @@ __device__ __forceinline__ int rigk_out_source(int t, int i, int j, int& e) {
 // many half-size workgroups are all resident at once and split the chunks 3 + 2 instead of 2 + 1 + 1 + 1).
 template <bool HK, int NW>
 __global__ __launch_bounds__(NW * 64, HK ? 3 : CC_RIG_SWEEP_WAVES) void k_rig_sweep(RigDev P) {
-  rig_progress(P, RIG_PROG_SWEEP);
   static_assert(NW == 4 || ((NW == 2 || NW == 1) && !HK), "small workgroups exist for the poses-only sweep");
   constexpr int NT = NW * 64;      // threads
   constexpr int EPT = 256 / NT;    // block entries per thread
@@ -835,7 +837,6 @@ __device__ __forceinline__ void rig_sweep_adj_body(const RigDev& P, const int64_
 
 template <int NW>
 __global__ __launch_bounds__(NW * 64, NW == 1 ? CC_RIG_ADJ_WAVES : 3) void k_rig_sweep_adj(RigDev P) {   // (NW > 1: few, large groups -- registers rather than residency)
-  rig_progress(P, RIG_PROG_SWEEP);
   __shared__ double s_lds[kRigSweepAdjLds(NW)];
   const LmCtl* ctl = P.ctl;
   const int done = ctl->done, phase = ctl->phase, step_valid = ctl->step_valid, cur = ctl->cur;
@@ -860,7 +861,6 @@ constexpr int kRigCompK = 320;   // doubles per group and buffer of the compact 
 // cross-lane epilogue and the assembly over all passes of its group and there is no cross-wave reduction), four otherwise.
 template <int NW>
 __global__ __launch_bounds__(NW * 64, CC_RIG_ADJK_WAVES) void k_rig_sweep_adjk(RigDev P) {
-  rig_progress(P, RIG_PROG_SWEEP);
   constexpr int NT = NW * 64, EPT = 256 / NT;
   __shared__ __attribute__((aligned(16))) double s_stage[NW * kStageDoublesPerWave];   // per wave 64 x 16; then the partial products
   __shared__ double sm[96];        // camera record, frame record, intrinsics record (candidate [0..8], step [16..24])
@@ -1864,6 +1864,15 @@ __device__ __forceinline__ double readlane_d(double x, int l) {
 }
 
 
+// 1 / sqrt(d) for a Cholesky pivot: the hardware estimate and the library's third-order correction WITHOUT its special-case
+// selects (zero, infinity, NaN: the caller tests d > 0 && isfinite(d) and discards the step) -- three dependent
+// instructions fewer on a chain that is nothing but dependent instructions. Same bits as rsqrt() for every d it is kept for.
+__device__ __forceinline__ double rsqrt_pos(double d) {
+  const double y0 = __builtin_amdgcn_rsq(d);
+  const double e = fma(y0 * -d, y0, 1.0);
+  return fma(y0 * e, fma(e, 0.375, 0.5), y0);
+}
+
 // shared step: write-through, so that workgroups of the same launch can read it behind a flag (sc1 loads)
 __device__ __forceinline__ void store_ds(double* p, double v) {
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2042,6 +2051,223 @@ __device__ __forceinline__ void chol_backward(const double* A, int S, int LD, do
   if (TWO) b1 *= v1;
 }
 
+// Trailing update A[t0.., t0..] -= P P^T (P = the panel's nc <= 4 KS columns from j0, rows t0..S-1) ON THE MATRIX PIPE: the
+// lower 16 x 16 tiles of the trailing triangle are dealt to the four waves, KS v_mfma_f64_16x16x4_f64 per tile; per element 3
+// LDS operations instead of the 18 of the element-wise form (S = 114: the trailing updates were a third of the solve
+// step). Two tiles per round: every LDS read of both (operands and the elements to update) is issued before the first
+// matrix instruction -- one LDS round trip and one matrix-pipe latency per pair instead of per tile. All 256 threads call.
+// RE: one past the last ROW updated -- S, or S + 1 when the right-hand side rides along as row S of the matrix (chol_block4).
+template <int KS>
+__device__ __forceinline__ void chol_trail_mfma(double* A, int S, int LD, int j0, int nc, int t0, int RE) {
+  const int tid = threadIdx.x;
+  const int nt = RE - t0, n16 = (nt + 15) >> 4, ntile = n16 * (n16 + 1) / 2;
+  const int wv = tid >> 6, ln = tid & 63, kq = ln >> 4, c16 = ln & 15;
+  for (int tb = wv; tb < ntile; tb += 8) {
+    double am[2][KS], bm[2][KS], old[2][4];
+    int at[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = tb + 4 * u;
+      const bool live = t < ntile;
+      const int tc = live ? t : 0;
+      int ti = (int)((sqrtf(8.0f * (float)tc + 1.0f) - 1.0f) * 0.5f);
+      ti = ti * (ti + 1) / 2 > tc ? ti - 1 : ti;
+      ti = (ti + 1) * (ti + 2) / 2 <= tc ? ti + 1 : ti;
+      const int tj = tc - ti * (ti + 1) / 2;
+      const int R = t0 + 16 * ti, Cc = t0 + 16 * tj;
+      const bool ina = live && R + c16 < RE, inb = live && Cc + c16 < S;
+      const int ra = ina ? R + c16 : S - 1, rb = inb ? Cc + c16 : S - 1;      // (unconditional loads, then selects)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int kc = 4 * ks + kq;                                            // panel column of this lane in k-step ks
+        const int cc = j0 + kc < S ? j0 + kc : S - 1;                          // (stays inside the LDS block; selected away)
+        const double xa = A[(size_t)ra * LD + cc], xb = A[(size_t)rb * LD + cc];
+        am[u][ks] = (ina && kc < nc) ? xa : 0.0;
+        bm[u][ks] = (inb && kc < nc) ? xb : 0.0;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = R + kq + 4 * r, col = Cc + c16;
+        at[u][r] = (live && row < RE && col < S && col <= row) ? row * LD + col : -1;
+        old[u][r] = A[at[u][r] >= 0 ? at[u][r] : 0];
+      }
+    }
+    d4 T0 = {0.0, 0.0, 0.0, 0.0}, T1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      T0 = __builtin_amdgcn_mfma_f64_16x16x4f64(am[0][ks], bm[0][ks], T0, 0, 0, 0);
+      T1 = __builtin_amdgcn_mfma_f64_16x16x4f64(am[1][ks], bm[1][ks], T1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (at[0][r] >= 0) A[at[0][r]] = old[0][r] - T0[r];
+      if (at[1][r] >= 0) A[at[1][r]] = old[1][r] - T1[r];
+    }
+  }
+}
+
+// Cholesky of the damped reduced system FOUR columns at a time with LOOK-AHEAD (round 4; medium systems, 24 < S <= 63:
+// BASELINE configs[4] is S = 42), the right-hand side riding along as row S of the matrix. One barrier per block of four:
+//   wave 0 owns the serial chain. Lane l holds the four entries of row j0 + l in the block's columns, fully updated; a
+//     column is pivot (lane read) -> rsqrt -> scale -> up to three updates of (lane read + FMA) -- no LDS round trip and
+//     no barrier on the chain. It stores the panel, and behind the barrier applies THIS panel's rank-4 update to the NEXT
+//     block's four columns itself (sixteen FMAs per row, multipliers by uniform LDS reads) and goes straight on factoring;
+//   waves 1..3 meanwhile give the REST of the trailing matrix (columns beyond the next block, the right-hand side's row
+//     included) the same rank-4 update on the matrix pipe: one v_mfma_f64_16x16x4_f64 per 16 x 16 tile, operands straight
+//     from LDS, tiles fixed for the whole factorisation (addresses and validity computed once per lane).
+// What was measured on the way (scripts/time_chol.py, one workgroup, hot, S = 42, shader cycles at 2.41 GHz): round 3's
+// eight-column panels on wave 0 + trailing updates 32.2 k (13.4 us; in the solving block 9.0 + 4.8 us); sixteen-column
+// register-row panels with lane reads 13.0 + 3.0 us in the solving block (360 dependent lane-read / FMA triples per panel
+// on one wave); four-column blocks with the 4 x 4 diagonal block in closed form on every thread, two barriers and the
+// trailing update on all four waves 38.1 k, of which the trailing update 20 k (tiles re-anchored per step) / 15 k (fixed
+// tiles) -- a dependent fp64 instruction costs ~20 cycles when a SIMD has one wave to run, so what counts is the LENGTH of
+// the dependent chain (~12 instructions per column: 42 x 240 cycles = 4.2 us is the floor), and everything that can
+// leave the chain's wave must. s_inv[j] receives 1 / L_jj (backward substitution). All 256 threads call; returns whether
+// every pivot was positive and finite (valid in every thread).
+#ifdef CC_RIG_TIMING
+#define B4_MARK(k) do { if (marks) { const long long t_ = wall_clock64(); b4t[k] += t_ - b4last; b4last = t_; } } while (0)
+#else
+#define B4_MARK(k) do { } while (0)
+#endif
+__device__ __forceinline__ bool chol_block4(double* A, int S, int LD, double* s_inv, double* marks = nullptr, int ablate = 0) {
+  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63, kq = ln >> 4, c16 = ln & 15;
+  __shared__ int s_okb;
+  if (tid == 0) s_okb = 1;
+#ifdef CC_RIG_TIMING
+  long long b4t[6] = {0, 0, 0, 0, 0, 0}, b4last = wall_clock64();
+#endif
+  // ---- waves 1..3: the tiles of the trailing update, dealt round robin; fixed rows / columns 16 ti.. / 16 tj.. (ti >= tj)
+  const int n16 = (S + 1 + 15) >> 4, ntile = n16 * (n16 + 1) / 2;
+  constexpr int kMaxT = 4;   // tiles per wave: ntile <= 10 over three waves (S <= 63)
+  int ra[kMaxT], rb[kMaxT], rowmin[kMaxT], colmin[kMaxT], e0[kMaxT];
+  bool ina[kMaxT], inb[kMaxT], live[kMaxT];
+#pragma unroll
+  for (int u = 0; u < kMaxT; ++u) {
+    const int t = (wv - 1) + 3 * u;
+    live[u] = wv > 0 && t < ntile;
+    const int tc = live[u] ? t : 0;
+    int ti = (int)((sqrtf(8.0f * (float)tc + 1.0f) - 1.0f) * 0.5f);
+    ti = ti * (ti + 1) / 2 > tc ? ti - 1 : ti;
+    ti = (ti + 1) * (ti + 2) / 2 <= tc ? ti + 1 : ti;
+    const int tj = tc - ti * (ti + 1) / 2;
+    const int R = 16 * ti, Cc = 16 * tj;
+    ina[u] = live[u] && R + c16 <= S;
+    inb[u] = live[u] && Cc + c16 < S;
+    ra[u] = (ina[u] ? R + c16 : S) * LD;
+    rb[u] = (inb[u] ? Cc + c16 : S - 1) * LD;
+    rowmin[u] = R;                        // tile rows R + kq + 4 r, column Cc + c16
+    colmin[u] = Cc + c16;
+    e0[u] = (R + kq) * LD + Cc + c16;     // element r of this lane: e0 + 4 r LD
+  }
+  // ---- wave 0: lane l is ROW l of the matrix for the whole factorisation (row S: the right-hand side); x = its entries in the
+  // current block's columns, fully updated
+  double x[4] = {0.0, 0.0, 0.0, 0.0};
+  bool ok = true;
+  const double* Row = A + (size_t)(ln <= S ? ln : S) * LD;
+  if (wv == 0) {
+    const int nb0 = S < 4 ? S : 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const double v = Row[c < nb0 ? c : 0];
+      x[c] = (ln <= S && c < nb0 && c <= ln) ? v : 0.0;
+    }
+  }
+  for (int j0 = 0; j0 < S; j0 += 4) {
+    const int nb = S - j0 < 4 ? S - j0 : 4, t0 = j0 + nb;
+    const int nbn = S - t0 < 4 ? S - t0 : 4;   // width of the next block (<= 0: there is none)
+    if (wv == 0) {
+      // ---- the block's columns, one after the other
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (c < nb) {   // (uniform)
+          const double d = readlane_d(x[c], j0 + c);
+          ok = ok && (d > 0.0) && isfinite(d);
+          const double inv = rsqrt_pos(d);
+          const double y = x[c] * inv;            // lane j0 + c: d * inv = L_cc; lanes above it: not part of the column
+          x[c] = y;
+          if (ln == j0 + c) s_inv[j0 + c] = inv;
+#pragma unroll
+          for (int c2 = c + 1; c2 < 4; ++c2) x[c2] = fma(-y, readlane_d(y, (j0 + c2) & 63), x[c2]);
+        }
+      }
+      B4_MARK(0);
+      if (ln <= S) {
+        double* W = A + (size_t)ln * LD + j0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < nb && j0 + c <= ln) W[c] = x[c];
+      }
+    }
+    __syncthreads();   // panel j0 is in LDS; waves 1..3 have finished the previous block's trailing update
+    B4_MARK(1);
+    if (t0 >= S) break;
+    if (wv == 0) {
+      // ---- look-ahead: this panel's update of the NEXT block's columns. The row's entries there (final but for this
+      // panel: the barrier) and the sixteen multipliers L[t0 + c][j0 + k] (uniform addresses) come in ONE LDS round trip; the
+      // row's own panel entries are the registers x[] (lane = row for the whole factorisation). (Multipliers by lane reads
+      // instead, with the products under the round trip of the four entries: 21.4 k cycles against 19.9 k -- a lane read
+      // into a scalar register followed by its use costs more than a broadcast LDS read.)
+      double xn[4], m[4][4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) xn[c] = Row[(c < nbn ? t0 + c : 0)];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[c][k] = A[(size_t)(t0 + (c < nbn ? c : 0)) * LD + j0 + (k < nb ? k : 0)];   // L[t0 + c][j0 + k]: uniform address, one round trip for all twenty
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        double a = xn[c];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a = fma(-(k < nb ? x[k] : 0.0), m[c][k], a);
+        xn[c] = a;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) x[c] = (ln <= S && c < nbn && t0 + c <= ln) ? xn[c] : 0.0;
+      B4_MARK(2);
+    } else if (t0 + 4 < S && !(ablate & 1)) {
+      // ---- waves 1..3: rank-nb update of the rest, columns >= t0 + 4 (the next block's are wave 0's), rows up to S
+      const int kc = j0 + (kq < nb ? kq : 0);   // the lane's panel column (one k-step: column kq)
+#pragma unroll
+      for (int u0 = 0; u0 < kMaxT; u0 += 2) {
+        if ((live[u0] && rowmin[u0] + 15 >= t0 + 4) || (u0 + 1 < kMaxT && live[u0 + 1] && rowmin[u0 + 1] + 15 >= t0 + 4)) {   // (uniform; tiles wholly above the corner are finished)
+          double am[2], bm[2], old[2][4];
+#pragma unroll
+          for (int v = 0; v < 2; ++v) {
+            const int u = u0 + v;
+            const double xa = A[ra[u] + kc], xb = A[rb[u] + kc];
+            am[v] = (ina[u] && kq < nb) ? xa : 0.0;
+            bm[v] = (inb[u] && kq < nb) ? xb : 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int e = e0[u] + 4 * r * LD;
+              old[v][r] = A[(live[u] && e < (S + 1) * LD) ? e : 0];
+            }
+          }
+          d4 T0 = {0.0, 0.0, 0.0, 0.0}, T1 = {0.0, 0.0, 0.0, 0.0};
+          T0 = __builtin_amdgcn_mfma_f64_16x16x4f64(am[0], bm[0], T0, 0, 0, 0);
+          T1 = __builtin_amdgcn_mfma_f64_16x16x4f64(am[1], bm[1], T1, 0, 0, 0);
+#pragma unroll
+          for (int v = 0; v < 2; ++v) {
+            const int u = u0 + v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = rowmin[u] + kq + 4 * r, col = colmin[u];
+              if (live[u] && col >= t0 + 4 && col < S && row <= S && col <= row) A[e0[u] + 4 * r * LD] = old[v][r] - (v == 0 ? T0[r] : T1[r]);
+            }
+          }
+        }
+      }
+      B4_MARK(3);
+    }
+  }
+  if (wv == 0 && ln == 0 && !ok) s_okb = 0;
+  __syncthreads();
+#ifdef CC_RIG_TIMING
+  if (marks && tid == 0) { for (int k = 0; k < 5; ++k) marks[k] = (double)b4t[k]; }
+#endif
+  return s_okb != 0;
+}
+
 // Timing-only builds (-DCC_RIG_TIMING, scripts/time_rig_reduce.py): the solving block leaves wall-clock marks
 // (100 MHz) in shared_stats[8..]; the product build compiles them away.
 #ifdef CC_RIG_TIMING
@@ -2214,6 +2440,34 @@ __device__ void rig_solve_block(const RigDev& P, double* smem, const LmCtl* cn_i
       if (lane == 0) s_stepok = step_ok ? 1 : 0;
     }
     __syncthreads();
+#ifndef CC_RIG_PANEL8
+  } else if (s_go && S <= 63) {   // (chol_block4: the right-hand side is row S on lane S of wave 0)
+    // ---- medium systems: four columns at a time on all four waves, right-hand side as row S (chol_block4)
+#ifdef CC_RIG_TIMING
+    const long long tf0 = wall_clock64();
+    const long long cy0 = clock64();
+#endif
+    const bool okb = chol_block4(A, S, LD, s_inv, P.shared_stats + 48);
+#ifdef CC_RIG_TIMING
+    if (tid == 0) { P.shared_stats[16] = (double)(wall_clock64() - tf0); P.shared_stats[17] = 0.0; P.shared_stats[18] = (double)wall_clock64();
+                    P.shared_stats[54] = (double)(clock64() - cy0); P.shared_stats[55] = (double)(wall_clock64() - tf0); }   // shader cycles / 100 MHz ticks: the clock the solving block runs at
+#endif
+    if (tid < 64) {
+      const int i0 = lane;
+      double b0 = i0 < S ? s_b[i0] : 0.0, b1 = 0.0;          // y = L^-1 b (row S of the matrix)
+      const double v0 = i0 < S ? s_inv[i0] : 0.0;
+      chol_backward<false>(A, S, LD, b0, b1, v0, 0.0);
+      const bool fin = i0 >= S || isfinite(b0);
+      const bool step_ok = s_cholok != 0 && okb && __all(fin);
+      if (i0 < S) { s_b[i0] = b0; if (SRC != 3) store_ds(P.ds + i0, -b0); }
+      if (SRC != 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the update blocks of this launch read ds behind a flag
+      if (lane == 0) s_stepok = step_ok ? 1 : 0;
+    }
+    __syncthreads();
+#ifdef CC_RIG_TIMING
+    if (tid == 0) P.shared_stats[19] = (double)wall_clock64();
+#endif
+#endif
   } else if (s_go) {
     // ---- Cholesky of the damped reduced system in LDS, eight columns at a time (S <= 127):
     //   panel:    wave 0 (chol_panel), forward substitution included;
@@ -2244,51 +2498,7 @@ __device__ void rig_solve_block(const RigDev& P, double* smem, const LmCtl* cn_i
       if (t0 < S && S > 64) {
         // (large systems only -- cameras with their own intrinsics; for S <= 64 the element-wise form below is as fast
         // or faster: S = 18, 48.7 vs 49.6 us per iteration)
-        // trailing update A[t0.., t0..] -= P P^T (P = the panel's columns, rows t0..S-1) ON THE MATRIX PIPE: the lower
-        // 16 x 16 tiles of the trailing triangle are dealt to the four waves, two v_mfma_f64_16x16x4_f64 per tile (k = 8
-        // panel columns); per element 3 LDS operations instead of the 18 of the element-wise form below (S = 114: the
-        // trailing updates were a third of the solve step).
-        const int nt = S - t0, n16 = (nt + 15) >> 4, ntile = n16 * (n16 + 1) / 2;
-        const int wv = tid >> 6, ln = tid & 63, kq = ln >> 4, c16 = ln & 15;
-        // two tiles per round: every LDS read of both (operands and the elements to update) is issued before the first
-        // matrix instruction -- one LDS round trip and one matrix-pipe latency per pair instead of per tile
-        for (int tb = wv; tb < ntile; tb += 8) {
-          double a0[2], a1[2], b0m[2], b1m[2], old[2][4];
-          int at[2][4];
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int t = tb + 4 * u;
-            const bool live = t < ntile;
-            const int tc = live ? t : 0;
-            int ti = (int)((sqrtf(8.0f * (float)tc + 1.0f) - 1.0f) * 0.5f);
-            ti = ti * (ti + 1) / 2 > tc ? ti - 1 : ti;
-            ti = (ti + 1) * (ti + 2) / 2 <= tc ? ti + 1 : ti;
-            const int tj = tc - ti * (ti + 1) / 2;
-            const int R = t0 + 16 * ti, Cc = t0 + 16 * tj;
-            const bool ina = live && R + c16 < S, inb = live && Cc + c16 < S;
-            const int ra = ina ? R + c16 : S - 1, rb = inb ? Cc + c16 : S - 1;      // (unconditional loads, then selects)
-            const double xa0 = A[(size_t)ra * LD + j0 + kq], xa1 = A[(size_t)ra * LD + j0 + 4 + kq];
-            const double xb0 = A[(size_t)rb * LD + j0 + kq], xb1 = A[(size_t)rb * LD + j0 + 4 + kq];
-            a0[u] = (ina && kq < nc) ? xa0 : 0.0; a1[u] = (ina && 4 + kq < nc) ? xa1 : 0.0;
-            b0m[u] = (inb && kq < nc) ? xb0 : 0.0; b1m[u] = (inb && 4 + kq < nc) ? xb1 : 0.0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int row = R + kq + 4 * r, col = Cc + c16;
-              at[u][r] = (live && row < S && col <= row) ? row * LD + col : -1;
-              old[u][r] = A[at[u][r] >= 0 ? at[u][r] : 0];
-            }
-          }
-          d4 T0 = {0.0, 0.0, 0.0, 0.0}, T1 = {0.0, 0.0, 0.0, 0.0};
-          T0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], b0m[0], T0, 0, 0, 0);
-          T1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], b0m[1], T1, 0, 0, 0);
-          T0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[0], b1m[0], T0, 0, 0, 0);
-          T1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[1], b1m[1], T1, 0, 0, 0);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (at[0][r] >= 0) A[at[0][r]] = old[0][r] - T0[r];
-            if (at[1][r] >= 0) A[at[1][r]] = old[1][r] - T1[r];
-          }
-        }
+        chol_trail_mfma<2>(A, S, LD, j0, nc, t0, S);
       } else if (t0 < S) {
 #else
       if (t0 < S) {
@@ -3064,8 +3274,8 @@ struct RigPersistDev {
   int32_t G, K, KS, NB;
   unsigned epoch0;      // tags: epoch0 + round + 1 (boxes are zeroed when they would wrap)
   unsigned* claim;      // [1] the control candidate that exchanges epoch0 + 1 in first is the control workgroup (k_rig_persist_ctl)
-  unsigned* gate;       // signal word the control launch waits for at the command processor (hipStreamWaitValue32): the worker that
-                        //   finds all G workers started stores epoch0 + 1 into it; null: no gate (the candidates run when they run)
+  unsigned long long* gate;   // pinned host word: the worker that finds all G workers started stores epoch0 + 1 into it and the HOST then
+                              //   launches the control (rig_launch); null: no gate (the candidates run when they run)
   int32_t max_rounds, timeout_shift;
 };
 
@@ -3497,11 +3707,11 @@ __global__ __launch_bounds__(TEAMS * 256) void k_rig_persist_w(RigDev P, RigPers
   int* s_info = reinterpret_cast<int*>(s_wg + RPW_INFO);   // [0..31] colinfo, [32..47] group of (team, slot)
   int* s_cols = reinterpret_cast<int*>(s_wg + RPW_COLS);
   int* s_good = s_cols + 8;
-  // ---- every worker is RESIDENT once all G have passed this point: the last one opens the gate of the control launch, whose
-  // candidates therefore only ever run on compute units the workers left free (k_rig_persist_ctl)
+  // ---- every worker is RESIDENT once all G have passed this point: the last one tells the host, which launches the control
+  // only then -- its candidates therefore only ever run on compute units the workers left free (k_rig_persist_ctl)
   if (Q.gate && tid0 == 0) {
     const unsigned prev = __hip_atomic_fetch_add(P.arrive + 13, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev + 1u == (unsigned)G) __hip_atomic_store(Q.gate, Q.epoch0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (prev + 1u == (unsigned)G) __hip_atomic_store(Q.gate, (unsigned long long)(Q.epoch0 + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   // ---- start of the solve: poses of the workgroup's frames (buffer 0 holds the starting point: rig_begin), tables
   for (int i = tid0; i < TEAMS * (2048 + 512); i += NT) s_tile[i] = 0.0;
@@ -3824,9 +4034,46 @@ __global__ __launch_bounds__(TEAMS * 256) void k_rig_persist_w(RigDev P, RigPers
   // ---- the solve is over: the frame's accepted pose goes back to global memory (cc_rig_get_state, the next solve)
   __syncthreads();
   if (ag_ld32(fail) == 0u && has_frame && twave == 0 && lane < 7) P.pose[((size_t)cur * P.F + f) * 8 + lane] = tm[RPW_POSE + cur * 8 + lane];
-  // (a solve that gave up -- not every worker resident -- still opens the gate: the control launch must not wait for ever)
-  if (Q.gate && tid0 == 0 && ag_ld32(fail) != 0u) __hip_atomic_store(Q.gate, Q.epoch0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+
+#ifdef CC_RIG_TIMING
+// Timing-only: the factorisation routines alone, hot, on one workgroup (scripts/time_chol.py): `reps` factorisations of the same
+// S x S matrix (+ right-hand side) from global memory; out[0] = 100 MHz ticks per factorisation, out[1] = shader cycles.
+__global__ __launch_bounds__(256) void k_chol_bench(const double* Ain, int S, int reps, int which, double* out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* A = reinterpret_cast<double*>(smem_raw);
+  const int LD = (S + 1) | 1, tid = threadIdx.x, lane = tid & 63;
+  double* s_b = A + (size_t)S * LD;
+  double* s_inv = s_b + 128;
+  long long ticks = 0, cyc = 0;
+  double chk = 0.0;
+  for (int r = 0; r < reps; ++r) {
+    for (int i = tid; i < (S + 1) * LD; i += 256) A[i] = Ain[i];
+    __syncthreads();
+    const long long t0 = wall_clock64(), c0 = clock64();
+    if (which == 0 || which >= 2) {
+      chol_block4(A, S, LD, s_inv, nullptr, which == 2 ? 1 : 0);
+    } else {
+      double b0 = 0.0, b1 = 0.0, v0 = 0.0, v1 = 0.0;
+      bool okw = true;
+      if (tid < 64) b0 = lane < S ? s_b[lane] : 0.0;
+      for (int j0 = 0; j0 < S; j0 += 8) {
+        const int nc = S - j0 < 8 ? S - j0 : 8;
+        if (tid < 64) chol_panel<false>(A, S, LD, j0, nc, s_inv, b0, b1, v0, v1, okw);
+        __syncthreads();
+        const int t0c = j0 + nc;
+        if (t0c < S) chol_trail_mfma<2>(A, S, LD, j0, nc, t0c, S);
+        __syncthreads();
+      }
+      if (tid < 64 && lane < S) s_b[lane] = b0;
+    }
+    __syncthreads();
+    ticks += wall_clock64() - t0; cyc += clock64() - c0;
+    chk += s_b[S - 1];
+  }
+  if (tid == 0) { out[0] = (double)ticks / reps; out[1] = (double)cyc / reps; out[2] = chk; }
+}
+#endif
 
 // creation: world point of every observation
 __global__ void k_rig_expand_xyz(int64_t n, const int32_t* widx, const float* wxyz, float* oxyz) {
@@ -3923,9 +4170,7 @@ struct cc_rig {
   bool persist_w_ok = false;    // ... and so can its lean form (k_rig_persist_w + k_rig_persist_ctl: <= 4 observed cameras, <= 24 shared coordinates)
   int form_reruns = 0;             // lean persistent solves that gave up and were run again in the three-kernel form
   std::string form_note;           // why (cc_rig_solver_status)
-  bool gate_tried = false;
-  unsigned gate_tag = 0;           // tag the control launch of the last lean solve waits for
-  unsigned* d_gate = nullptr;      // signal memory (hipMallocSignalMemory) the control launch waits on; null: device without stream wait values
+  bool gated = false;              // the last lean solve launched its control behind the workers' residency word
   hipStream_t stream2 = nullptr;   // the control workgroup's launch of the lean form
   hipEvent_t ev_begin = nullptr;
   cc::RigPersistDev pq{};
@@ -4561,7 +4806,7 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   if (int rc = dev_zeroed(h, &d.sp, (size_t)F * 8)) return rc;
   if (int rc = dev_zeroed(h, &d.ss, (size_t)256)) return rc;
   if (int rc = dev_zeroed(h, &d.ds, (size_t)256)) return rc;
-  if (int rc = dev_zeroed(h, &d.shared_stats, (size_t)48)) return rc;   // [0..3] statistics, [8..] timing marks (CC_RIG_TIMING builds)
+  if (int rc = dev_zeroed(h, &d.shared_stats, (size_t)64)) return rc;   // [0..3] statistics, [8..] timing marks (CC_RIG_TIMING builds)
   // one piece: control block | its copy for the host (ctl_next) | 16 synchronisation words (RigDev::arrive) | publication
   // counter -- a solve starts by zeroing the first three with ONE fill (rig_begin)
   if (int rc = dev_zeroed(h, &d.ctl, (size_t)4)) return rc;
@@ -4585,6 +4830,7 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
     h->h_ctl = reinterpret_cast<LmCtl*>(pin + 192);
     static_assert(16 + sizeof(LmCtl) + 8 <= 192 && 192 + sizeof(LmCtl) + 16 <= 512, "pinned block layout");
     h->host_pub[0] = 0ull;   // (a recycled block may carry an old sequence number; the device counter starts at 0)
+    h->host_pub[22] = 0ull;  // residency word of the lean persistent form (rig_launch)
     h->pub_count = 0;
     void* dev_view = nullptr;
     CC_HIP(hipHostGetDevicePointer(&dev_view, pin, 0));
@@ -4671,13 +4917,10 @@ void cc_rig_destroy(cc_rig* h) {
   bool stream_ok = true;
   if (h->stream) stream_ok = hipStreamSynchronize(h->stream) == hipSuccess;
   if (h->stream2) {
-    // (a control launch still held at its gate -- the workers never ran -- is let through: it finds the solve's failure word
-    // or claim and leaves)
-    if (h->d_gate && h->gate_tag) (void)hipStreamWriteValue32(h->stream, h->d_gate, h->gate_tag, 0);
     hipStreamSynchronize(h->stream2);
     hipStreamDestroy(h->stream2);
   }
-  if (h->d_gate) (void)hipFree(h->d_gate);
+
   if (h->ev_begin) hipEventDestroy(h->ev_begin);
   cc::rig_drop_graphs(h);
   for (auto e : h->events) hipEventDestroy(e);
@@ -4811,6 +5054,7 @@ static int rig_launch(cc_rig* h, RigRun* r, int chunk) {
     if (h->p_epoch > 0x7fff0000u - (unsigned)q.max_rounds) {   // the 32-bit tags would wrap: start over on zeroed boxes
       CC_HIP(hipMemsetAsync(h->pq.sbox, 0, h->p_box_words * sizeof(unsigned long long), h->stream));   // (the claim word is its last)
       h->p_epoch = 0;
+      h->host_pub[22] = 0ull;   // (no launch of this handle is in flight: rig_begin synchronised both streams' predecessors)
     }
     q.epoch0 = h->p_epoch;
     h->p_epoch += (unsigned)q.max_rounds + 2u;
@@ -4822,29 +5066,28 @@ static int rig_launch(cc_rig* h, RigRun* r, int chunk) {
     CC_HIP(hipEventRecord(h->ev_begin, h->stream));
     CC_HIP(hipStreamWaitEvent(h->stream2, h->ev_begin, 0));
     static const bool drop_control = getenv("CC_RIG_PERSIST_TEST_NO_CONTROL") && atoi(getenv("CC_RIG_PERSIST_TEST_NO_CONTROL")) != 0;   // (test hook: the workers' first wait gives up)
-    // the control launch is held at the command processor until every worker is resident (the last worker to start stores the
-    // solve's tag into the signal word), so that whichever candidate runs first sits on a compute unit no worker needs
+    // Workers first; the control's candidates are launched when every worker is RESIDENT (the last worker to start stores the
+    // solve's tag into a pinned word this thread spins on: ~10 us, once per solve), so that whichever candidate runs first sits
+    // on a compute unit no worker needs. (First version of the round: hipStreamWaitValue32 on signal memory -- right, but a
+    // command processor that finds the value not there yet goes to sleep: +154 us per solve at 250 workgroups of 1024
+    // threads. Without any gate a candidate that starts BEFORE the workers can claim the last compute unit of an XCD that
+    // 32 workers need: seen at once on the first box tried, CC_RIG_CTL_GATE=0.)
     static const bool use_gate = !(getenv("CC_RIG_CTL_GATE") && atoi(getenv("CC_RIG_CTL_GATE")) == 0);
-    if (use_gate && !h->d_gate && !h->gate_tried) {
-      h->gate_tried = true;
-      int can = 0;
-      if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, h->device) != hipSuccess) { can = 0; (void)hipGetLastError(); }
-      if (can && hipExtMallocWithFlags((void**)&h->d_gate, 8, hipMallocSignalMemory) != hipSuccess) { h->d_gate = nullptr; (void)hipGetLastError(); }
-      if (h->d_gate) CC_HIP(hipMemsetAsync(h->d_gate, 0, 8, h->stream));
-    }
-    q.gate = use_gate ? h->d_gate : nullptr;
-    if (q.gate && !drop_control && hipStreamWaitValue32(h->stream2, q.gate, q.epoch0 + 1u, hipStreamWaitValueEq, 0xffffffffu) != hipSuccess) {
-      (void)hipGetLastError();
-      q.gate = nullptr;   // (no gate on this stack: the candidates claim as they come)
-    }
-    h->gate_tag = q.gate ? q.epoch0 + 1u : 0u;
-    if (!drop_control)
-      hipLaunchKernelGGL(k_rig_persist_ctl, dim3((unsigned)kRigCtlCandidates), dim3(256), rig_persist_ctl_lds(h->solve_lds, h->d), h->stream2, h->d, q);
-
+    q.gate = use_gate ? const_cast<unsigned long long*>(h->host_pub) + 22 : nullptr;
+    h->gated = q.gate != nullptr;
     const size_t lb = (size_t)rpw_lds_doubles(h->p_teams) * 8;
     if (h->p_teams == 1) hipLaunchKernelGGL(k_rig_persist_w<1>, dim3((unsigned)q.G), dim3(256), lb, h->stream, h->d, q);
     else if (h->p_teams == 2) hipLaunchKernelGGL(k_rig_persist_w<2>, dim3((unsigned)q.G), dim3(512), lb, h->stream, h->d, q);
     else hipLaunchKernelGGL(k_rig_persist_w<4>, dim3((unsigned)q.G), dim3(1024), lb, h->stream, h->d, q);
+    CC_HIP(hipGetLastError());
+    if (q.gate) {
+      const auto tg = std::chrono::steady_clock::now();
+      const unsigned long long want = (unsigned long long)(q.epoch0 + 1u);
+      for (unsigned spins = 0; __atomic_load_n(const_cast<const unsigned long long*>(q.gate), __ATOMIC_ACQUIRE) != want; ++spins)
+        if ((spins & 0x3ffu) == 0x3ffu && std::chrono::steady_clock::now() - tg > std::chrono::milliseconds(5)) break;   // (not all resident: the workers will give up and the solve is rerun)
+    }
+    if (!drop_control)
+      hipLaunchKernelGGL(k_rig_persist_ctl, dim3((unsigned)kRigCtlCandidates), dim3(256), rig_persist_ctl_lds(h->solve_lds, h->d), h->stream2, h->d, q);
     CC_HIP(hipGetLastError());
     r->persist = true;
     r->launched += q.max_rounds;
@@ -4873,7 +5116,7 @@ static std::string rig_describe_stall(cc_rig* h) {
   (void)hipStreamSynchronize(h->stream);   // (every later launch of the chunk returns at once: done / failure word)
   struct { LmCtl c; unsigned w[16]; } snap{};
   if (hipMemcpy(&snap, h->d.ctl_next, sizeof(snap), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return "state unreadable"; }
-  static const char* names[RIG_PROG_COUNT] = {"sweep", "stats", "init", "elim", "reduce", "solve", "update"};
+  static const char* names[RIG_PROG_COUNT] = {"sweep (not counted)", "stats", "init", "elim", "reduce", "solve", "update"};
   char buf[256];
   std::string out = "launches started this solve:";
   for (int k = 0; k < RIG_PROG_COUNT; ++k) { std::snprintf(buf, sizeof(buf), " %s %u", names[k], snap.w[4 + k]); out += buf; }
@@ -4905,7 +5148,7 @@ static int rig_wait(cc_rig* h, RigRun* r) {
                   "%u workers had started, control workgroup %s (candidate %u, XCD %d)%s; the solve was run again with three kernels per "
                   "iteration and the handle stays on that form (kernel-serialising tools, a CU mask or another tenant on the device cause this)",
                   r->st.iter, h->pq.G, h->p_teams * 256, w[13], w[12] ? "claimed a compute unit" : "NEVER RAN", w[12] >> 8, (int)(w[12] & 0xffu) - 1,
-                  h->gate_tag ? "" : ", no command-processor gate");
+                  h->gated ? "" : ", control launched without waiting for the workers (CC_RIG_CTL_GATE=0)");
     h->form_note = note;
     r->rerun = true;
     return 0;
@@ -4975,7 +5218,6 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
       // global memory only at the end of a solve that did not fail, and the cameras of the starting point were put
       // aside: restore them and run the solve again, three kernels per iteration (no co-residency needed).
       CC_HIP(hipStreamSynchronize(h->stream));
-      if (h->d_gate && h->gate_tag) (void)hipStreamWriteValue32(h->stream, h->d_gate, h->gate_tag, 0);   // (the failing workers opened it; belt and braces)
       if (h->stream2) CC_HIP(hipStreamSynchronize(h->stream2));
       CC_HIP(hipMemcpyAsync(h->d.cam, h->d_cam_backup, (size_t)h->C * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
       h->last_st = LmCtl{};   // (buffer 0 holds the starting point)
@@ -5150,6 +5392,30 @@ int cc_rig_exchange_attach(cc_rig* h, int32_t rank, int32_t nranks, const uint8_
   if (!ok) return fail(CC_ERR_COMM, "cc_rig_exchange_attach: a peer rank did not attach within 10 s");
   return rig_adopt_global_cameras(h, flags);
 }
+
+#ifdef CC_RIG_TIMING
+// timing-only builds: out[0..2] = ticks (100 MHz) and shader cycles per factorisation of a random SPD S x S system, checksum
+int cc_rig_debug_chol_bench(int32_t S, int32_t reps, int32_t which, double* out) {
+  using namespace cc;
+  const int LD = (S + 1) | 1;
+  std::vector<double> A((size_t)(S + 1) * LD + 256, 0.0);
+  for (int i = 0; i < S; ++i) {
+    for (int j = 0; j <= i; ++j) A[(size_t)i * LD + j] = i == j ? S + 1.0 : 1.0 / (1 + i + j);
+    A[(size_t)S * LD + i] = 1.0 + i;
+  }
+  double *dA = nullptr, *dout = nullptr;
+  CC_HIP(hipMalloc(&dA, A.size() * 8));
+  CC_HIP(hipMalloc(&dout, 64));
+  CC_HIP(hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice));
+  const size_t lds = ((size_t)(S + 1) * LD + 5 * 128) * 8;
+  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_bench), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_chol_bench, dim3(1), dim3(256), lds, 0, dA, S, reps, which, dout);
+  CC_HIP(hipDeviceSynchronize());
+  CC_HIP(hipMemcpy(out, dout, 24, hipMemcpyDeviceToHost));
+  hipFree(dA); hipFree(dout);
+  return CC_OK;
+}
+#endif
 
 // Debug/test aid (not declared in the public header): copies a named device buffer to the host.
 int cc_rig_debug_fetch(cc_rig* h, const char* name, double* out, int64_t n) {

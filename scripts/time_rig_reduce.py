@@ -30,8 +30,10 @@ rows, erows, swrows = [], [], []
 for _ in range(5):
     prob.reset()
     s = prob.solve(capi.default_options(max_iterations=12), log_capacity=0)
-    buf = np.zeros(48)
-    capi._check(capi.lib().cc_rig_debug_fetch(prob._h, b"shared_stats", buf.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(48)))
+    buf = np.zeros(64)
+    capi._check(capi.lib().cc_rig_debug_fetch(prob._h, b"shared_stats", buf.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(64)))
+    b4 = buf[48:53] / 100.0
+    sclk_mhz = buf[54] / max(buf[55], 1.0) * 100.0
     t = buf[8:16] / 100.0   # 100 MHz ticks -> us
     rows.append(np.concatenate([np.diff(t), [buf[16] / 100.0, buf[17] / 100.0, (buf[19] - buf[18]) / 100.0]]))
     e = buf[20:30] / 100.0
@@ -50,4 +52,8 @@ print(json.dumps({"kernel": "k_rig_sweep (middle workgroup, from the records bar
                   **{n: round(float(v), 2) for n, v in zip(["model-cost term + rotation setup", "first pass", "remaining passes", "cross-wave reduction + block store"], swd)}}))
 print(json.dumps({"kernel": "k_rig_elim (block 0)", "cams": Cc, "frames": F, "pts": M, "total_us": float(ed.sum()),
                   **{n: round(float(v), 2) for n, v in zip(enames, ed)}}))
+if b4.sum() > 0:
+    print(json.dumps({"kernel": "chol_block4 (thread 0, summed over the blocks of four columns, last solve)", **{n: round(float(v), 2) for n, v in zip(
+        ["LDS reads of the diagonal block + row", "4 x 4 factor + row solve", "row store + barrier", "trailing update (MFMA)", "barrier"], b4)},
+        "shader_clock_mhz_during_the_factorisation": round(float(sclk_mhz), 1)}))
 print(json.dumps({"kernel": "k_rig_reduce (solving block)", "cams": Cc, "frames": F, "pts": M, "intrinsics": K, "total_us": float(d[:7].sum()), **{n: round(float(v), 2) for n, v in zip(names, d)}}))
