@@ -104,7 +104,12 @@ struct RigDev {
   double* fstats;   // [F][2] step^2, |x|^2
   double* ghd0;     // [NG][8] diag of H_cc at the initial point
   double* gcomp;    // compact record per group and buffer for the next sweep's model-cost term: [2][NG][64] 7-column Gram (28),
-                    // M (36) (k_rig_sweep_adj); with intrinsics [2][NG][320] 16-column Gram (256), M (36) (k_rig_sweep_adjk)
+                    // M (36) (k_rig_sweep_adj); with intrinsics [2][NG][320] 16-column Gram (256), M (36) (k_rig_sweep_adjk).
+                    // FRAME form (fmode, k_rig_sweep_frame): [2][NG][64] 7-column Gram G7 (28) and T = G_cc M (36) -- ALL the
+                    // elimination reads of a group (direct sums: G7; coupling columns: T); no 16 x 16 tile is written
+  double* fsum;     // FRAME form: [2][F][32] per frame H_ff (21, packed lower triangle) and g_f (6), summed over its groups
+  int32_t fmode;    // 1: the sweep is k_rig_sweep_frame (one workgroup per FRAME); gstats then holds one row per frame
+  int32_t pad_fm;
   double* sp;       // [F][8]
   double* ss;       // [128]
   double* ds;       // [128] scaled shared step
@@ -126,6 +131,8 @@ struct RigDev {
   unsigned long long* pub_seq;   // [1] device: chunks published so far
   unsigned long long* host_pub;  // pinned host memory: [0] sequence word the host spins on, [2..19] control block, [20] failure word
   double huber_a;
+  double huber_b, huber_2a, huber_ha;   // a^2, 2 a, a / 2 as KERNEL ARGUMENTS: scalar registers from the start (computed in the kernel they
+                                        // are vector results the compiler keeps -- and, in k_rig_sweep_frame, spills -- across the passes)
   // EXTENSION: intrinsics in the shared block, pixel observations. kmode 0: off.
   int32_t kmode, gstride;
   int32_t init_slices;   // blocks of k_rig_init that share the diagonal sums of a set of intrinsics common to all cameras
@@ -846,6 +853,300 @@ __global__ __launch_bounds__(NW * 64, NW == 1 ? CC_RIG_ADJ_WAVES : 3) void k_rig
 }
 
 // ---------------------------------------------------------------------------------------------
+// FRAME form of the poses-only sweep (round 4; the default of the three-kernel path): one workgroup per FRAME, its NWF waves
+// deal the frame's (frame, camera) groups among themselves and sweep them one after the other with the main loop of
+// k_rig_sweep_adj (7-column Gram per group, plain FMAs). What changes is everything AROUND that loop:
+//   * the frame record is read once per wave, not per group; a wave requests its NEXT group's first observations before it
+//     reduces the current one;
+//   * nothing but the 28 numbers of G7 leaves the group: the 16 x 16 tile N^T G7 N of k_rig_sweep_adj (four matrix
+//     instructions behind ~150 instructions of operand set-up per group, 2 KB written per group and read back by the
+//     elimination) is never formed. Wave 0 ends the frame with ONE assembly for all its groups, eight lanes per group:
+//     T = G_cc M (the 6 x 6 coupling block the elimination's camera columns are made of), the group's share M^T T of the frame
+//     block and M^T g_c of its gradient, added over the groups by lane exchanges. A group's record is [G7 (28) | T (36)],
+//     the frame's [H_ff (21) | g_f (6)]: 64 + 32/CO doubles per group where the tile form wrote 256 + 64;
+//   * the model-cost term of the step needs no adjoint of the accepted point any more: with the OLD records
+//     q = sum_g (1/2 dc' G_cc dc + dc' g_c + dc' T df) + 1/2 df' H_ff df + df' g_f   (dc = 0 for a camera held constant);
+//   * cost and model-cost term are ONE row per frame (gstats[f]): the elimination's statistics pass reads F rows instead
+//     of NG (BASELINE configs[4]: 2000 instead of 16000 in each of its 256 blocks).
+// Arithmetic of a row and of G7: k_rig_sweep_adj's, instruction for instruction (same sums in the same order per lane, same
+// butterfly). LDS (dynamic): per group slot 32 doubles (G7, cost), staging 64 per group of an assembly pass, small scratch.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRigFrameLdsDoubles(int CO) { return CO * 32 + 8 * 64 + 64; }
+// ONE: every wave sweeps at most ONE group (a frame has no more groups than the workgroup has waves: rigs of up to eight
+// observed cameras) -- no loop over groups, and the kernel fits the 128 registers of four waves per SIMD like k_rig_sweep_adj<1>
+// does; with the loop (more groups than waves) the passes spill 12 - 19 registers at 128, so that variant is compiled for
+// three waves per SIMD (141 registers).
+template <int NWF, bool ONE>
+__global__ __launch_bounds__(NWF * 64, ONE ? 4 : (NWF <= 4 ? 3 : 2)) void k_rig_sweep_frame(RigDev P) {
+  extern __shared__ __attribute__((aligned(16))) double sf_lds[];
+  double* s_G = sf_lds;                     // [CO][32]  G7 (28), cost (28) of every group of the frame
+  double* s_rec = s_G + (size_t)P.CO * 32;  // [8][64]   records of an assembly pass, staged for one coalesced store
+  double* s_fr = s_rec + 8 * 64;            // [64]      frame record of the evaluated point (32), then scratch
+  const LmCtl* ctl = P.ctl;
+  const int done = ctl->done, phase = ctl->phase, step_valid = ctl->step_valid, cur = ctl->cur;
+  if (done) return;
+  if (phase != 0 && !step_valid) return;
+  const int dst = phase == 0 ? cur : (cur ^ 1);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t f = blockIdx.x;
+  const int64_t g0 = P.fgoff[f], g1 = P.fgoff[f + 1];
+  const int ng = (int)(g1 - g0);            // groups of this frame (0: no observation)
+  const double* fr = P.frec + (size_t)f * 32;
+  const double ha = P.huber_a;
+  const double hb = P.huber_b, h2a = P.huber_2a, hha = P.huber_ha;
+  struct F3 { float x, y, z; };
+  struct ObsRaw { float2 m; F3 X; };
+  struct ObsD { double u, v, X0, X1, X2; };
+  auto widen = [](const ObsRaw& r, ObsD& d) { d.u = (double)r.m.x; d.v = (double)r.m.y; d.X0 = (double)r.X.x; d.X1 = (double)r.X.y; d.X2 = (double)r.X.z; };
+  // ---- the wave's groups, one after the other
+  ObsRaw oa, ob;
+  {
+    const int64_t gq = g0 + (wave < ng ? wave : 0);
+    const int64_t s0 = P.goff[gq < P.NG ? gq : 0], s1 = P.goff[(gq < P.NG ? gq : 0) + 1];
+    const int n = (int)(s1 - s0);
+    const float2* uvg = reinterpret_cast<const float2*>(P.uv) + s0;
+    const F3* xg = reinterpret_cast<const F3*>(P.oxyz) + s0;
+    const int k0 = lane < n ? lane : 0, k1 = lane + 64 < n ? lane + 64 : 0;
+    oa.m = uvg[k0]; oa.X = xg[k0];
+    ob.m = uvg[k1]; ob.X = xg[k1];
+  }
+  auto sweep_group = [&](const int j) {
+    const int64_t g = g0 + j;
+    const int c = __builtin_amdgcn_readfirstlane(P.gcam[g]);   // (uniform, and the compiler must know it: the camera record then comes by scalar loads)
+    const int64_t s0 = P.goff[g], s1 = P.goff[g + 1];
+    const int n = (int)(s1 - s0);
+    const int npass = (n + 63) >> 6;
+    const float2* uvg = reinterpret_cast<const float2*>(P.uv) + s0;
+    const F3* xg = reinterpret_cast<const F3*>(P.oxyz) + s0;
+    auto fetch = [&](int k, ObsRaw& r) {
+      const int kc = k < n ? k : 0;
+      r.m = uvg[kc];
+      r.X = xg[kc];
+    };
+    // the chain of both poses as one: a = Rc (Rf X + tf) = Rca X + tca. Uniform addresses: scalar loads, values in SGPRs.
+    double Rca[9], tca[3], tcs[3];
+    {
+      const double* cr = P.camrec + (size_t)c * 32;
+      // (the frame record is re-read -- scalar loads, twelve values -- for every group: read once above the loop, the copies
+      // the products need in vector registers stay alive across the whole loop and are spilled: 28 registers of scratch)
+      const double* frl = fr;
+      asm volatile("" : "+s"(frl));
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Rca[3 * i + k] = rfl(cr[3 * i] * frl[k] + cr[3 * i + 1] * frl[3 + k] + cr[3 * i + 2] * frl[6 + k]);
+        tca[i] = rfl(cr[3 * i] * frl[9] + cr[3 * i + 1] * frl[10] + cr[3 * i + 2] * frl[11]);
+        tcs[i] = rfl(cr[9 + i]);
+      }
+    }
+    double acc[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) acc[e] = 0.0;
+    auto pass = [&](int k, const ObsD& r) {
+      const bool valid = k < n;
+      const double X0 = r.X0, X1 = r.X1, X2 = r.X2;
+      RigObs o;
+      o.a0 = Rca[0] * X0 + Rca[1] * X1 + Rca[2] * X2 + tca[0];
+      o.a1 = Rca[3] * X0 + Rca[4] * X1 + Rca[5] * X2 + tca[1];
+      o.a2 = Rca[6] * X0 + Rca[7] * X1 + Rca[8] * X2 + tca[2];
+      o.iz = recip_depth(o.a2 + tcs[2]);
+      o.x = (o.a0 + tcs[0]) * o.iz;
+      o.y = (o.a1 + tcs[1]) * o.iz;
+      o.ru = o.x - r.u;
+      o.rv = o.y - r.v;
+      double rho, sr;
+      {
+        const double ss = o.ru * o.ru + o.rv * o.rv;
+        if (ss > hb) {
+          const double rr = sqrt(ss);
+          rho = h2a * (rr - hha);
+          sr = sqrt(fmax(2.2250738585072014e-308, ha / rr));
+        } else { rho = ss; sr = 1.0; }
+      }
+      if (valid) acc[28] += 0.5 * rho;
+      if (!valid) sr = 0.0;
+      const double pz = sr * o.iz, qu = -(pz * o.x), qv = -(pz * o.y);
+      const double pz2 = pz + pz, qu2 = qu + qu, qv2 = qv + qv;
+      double w[7];
+      w[0] = qu2 * o.a1; w[1] = pz2 * o.a2 - qu2 * o.a0; w[2] = -(pz2 * o.a1);
+      w[3] = pz; w[4] = 0.0; w[5] = qu; w[6] = sr * o.ru;
+      adj_accumulate<4>(w, acc);
+      w[0] = qv2 * o.a1 - pz2 * o.a2; w[1] = -(qv2 * o.a0); w[2] = pz2 * o.a0;
+      w[3] = 0.0; w[4] = pz; w[5] = qv; w[6] = sr * o.rv;
+      adj_accumulate<3>(w, acc);
+    };
+    int p = 0;
+    for (; p + 1 < npass; p += 2) {
+      const int k = p * 64 + lane;
+      ObsD d;
+      widen(oa, d);
+      fetch(k + 128, oa);
+      pass(k, d);
+      widen(ob, d);
+      fetch(k + 192, ob);
+      pass(k + 64, d);
+    }
+    if (p < npass) {
+      ObsD d;
+      widen(oa, d);
+      pass(p * 64 + lane, d);
+    }
+    reduce_scatter32(acc, lane);   // value e in lanes 2e, 2e + 1
+    if ((lane & 1) == 0 && (lane >> 1) < 29) s_G[j * 32 + (lane >> 1)] = acc[0];
+    // (loop form only) the NEXT group's first two passes (requested behind the reduction: held across it, the ten registers of the two sets
+    // push the butterfly over the kernel's 128 and spill)
+    if (!ONE) {
+      const int jn = j + NWF < ng ? j + NWF : j;
+      const int64_t gn = g0 + jn;
+      const int64_t t0 = P.goff[gn], t1 = P.goff[gn + 1];
+      const int nn = (int)(t1 - t0);
+      const float2* uvn = reinterpret_cast<const float2*>(P.uv) + t0;
+      const F3* xn = reinterpret_cast<const F3*>(P.oxyz) + t0;
+      const int k0 = lane < nn ? lane : 0, k1 = lane + 64 < nn ? lane + 64 : 0;
+      oa.m = uvn[k0]; oa.X = xn[k0];
+      ob.m = uvn[k1]; ob.X = xn[k1];
+    }
+  };
+  // (ONE: straight-line code -- as a loop, even one that runs once, the compiler hoists the Huber constants and lane
+  // predicates out of it and keeps them in registers across the passes: sixteen spilled at 128)
+  if (ONE) { if (wave < ng) sweep_group(wave); }
+  else for (int j = wave; j < ng; j += NWF) sweep_group(j);
+  if (tid < 32) s_fr[tid] = fr[tid];
+  if (NWF > 1) __syncthreads(); else wave_lds_fence();
+  if (wave != 0) return;
+  // ---- the frame's assembly: eight lanes per group, eight groups per pass. Lane (gi, l): l < 6 owns column l of T and of the
+  // group's share of H_ff; l == 6 the gradient column (g_c -> M^T g_c); l == 7 idles.
+  // (every per-lane index below comes from a LAUNDERED copy of the lane id: derived from the original they are hoisted above
+  // the group loop and kept alive -- spilled -- across its passes)
+  int lane_a = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane_a));
+  const int gi = lane_a >> 3, l = lane_a & 7;
+  const double tf0 = s_fr[9], tf1 = s_fr[10], tf2 = s_fr[11];
+  double hsum[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // column l of H_ff (l < 6) / g_f (l == 6), over this lane's groups
+  double cost = 0.0, qm = 0.0;
+  const double* comp_cur = P.gcomp + (size_t)cur * P.NG * 64;
+  double* comp_dst = P.gcomp + (size_t)dst * P.NG * 64;
+  for (int jb = 0; jb < ng; jb += 8) {
+    const int j = jb + gi;
+    const bool live = j < ng;
+    const int64_t g = g0 + (live ? j : 0);
+    const int c = P.gcam[g];
+    const bool fixed = P.cam_fixed[c] != 0;
+    const double* cr = P.camrec + (size_t)c * 32;
+    // model-cost term of the group from its OLD record (lanes l < 6: row a = l): 1/2 dc_a (G_cc dc)_a + dc_a g_c,a + dc_a (T df)_a
+    // (first, on its own: nothing of it stays in registers across the assembly below)
+    if (phase != 0) {
+      const int a = l < 6 ? l : 0;
+      const double* old = comp_cur + (size_t)g * 64;
+      double gd = 0.0, td = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int hi = a > k ? a : k, lo = a > k ? k : a;
+        gd = fma(old[hi * (hi + 1) / 2 + lo], fixed ? 0.0 : cr[12 + k], gd);
+        td = fma(old[28 + a * 6 + k], s_fr[12 + k], td);
+      }
+      const double dca = fixed ? 0.0 : cr[12 + a];
+      if (live && l < 6) qm += dca * (0.5 * gd + old[21 + a] + td);
+    }
+    double Rc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rc[i] = cr[i];
+    const double* G = s_G + (size_t)(live ? j : 0) * 32;
+    // K[i][b] = 2 (Rc_i x tf)_b: the rotation block of the adjoint's lower left
+    double K[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      K[3 * i + 0] = 2.0 * (Rc[3 * i + 1] * tf2 - Rc[3 * i + 2] * tf1);
+      K[3 * i + 1] = 2.0 * (Rc[3 * i + 2] * tf0 - Rc[3 * i + 0] * tf2);
+      K[3 * i + 2] = 2.0 * (Rc[3 * i + 0] * tf1 - Rc[3 * i + 1] * tf0);
+    }
+    // column l of M: M = [Rc 0; K Rc]
+    double mc[6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int b3 = l < 3 ? l : (l < 6 ? l - 3 : 0);
+      const double rv = b3 == 0 ? Rc[3 * k] : (b3 == 1 ? Rc[3 * k + 1] : Rc[3 * k + 2]);
+      const double kv = b3 == 0 ? K[3 * k] : (b3 == 1 ? K[3 * k + 1] : K[3 * k + 2]);
+      mc[k] = l < 3 ? rv : 0.0;
+      mc[3 + k] = l < 3 ? kv : rv;
+    }
+    // tcol = column l of T = G_cc M (l < 6), or g_c (l == 6)
+    double tcol[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int hi = r > k ? r : k, lo = r > k ? k : r;
+        t = fma(G[hi * (hi + 1) / 2 + lo], mc[k], t);
+      }
+      tcol[r] = l < 6 ? t : G[21 + r];
+    }
+    // u = M^T tcol: u[a'] = sum_k M[k][a'] tcol[k]
+    double u[6];
+#pragma unroll
+    for (int ap = 0; ap < 3; ++ap) {
+      u[ap] = Rc[ap] * tcol[0] + Rc[3 + ap] * tcol[1] + Rc[6 + ap] * tcol[2] + K[ap] * tcol[3] + K[3 + ap] * tcol[4] + K[6 + ap] * tcol[5];
+      u[3 + ap] = Rc[ap] * tcol[3] + Rc[3 + ap] * tcol[4] + Rc[6 + ap] * tcol[5];
+    }
+    if (live && l < 7) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) hsum[r] += u[r];
+    }
+    if (live && l == 7) cost += G[28];
+    // stage the record [G7 | T] of the pass's groups, then one coalesced store per group
+    if (l < 6) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) s_rec[gi * 64 + 28 + r * 6 + l] = tcol[r];
+    }
+    for (int e = l; e < 28; e += 8) s_rec[gi * 64 + e] = G[e];
+    wave_lds_fence();
+    {
+      const int nb = ng - jb < 8 ? ng - jb : 8;
+      double* out = comp_dst + (size_t)(g0 + jb) * 64;
+      for (int e = lane_a; e < nb * 64; e += 64) out[e] = s_rec[e];
+      if (phase == 0 && live && l < 6) P.ghd0[g * 8 + l] = fixed ? 0.0 : G[l * (l + 1) / 2 + l];
+    }
+    wave_lds_fence();
+  }
+  // ---- sums over the lanes that share l (the groups of the frame): lane bits 3, 4, 5
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    hsum[r] += __shfl_xor(hsum[r], 8, 64);
+    hsum[r] += __shfl_xor(hsum[r], 16, 64);
+    hsum[r] += __shfl_xor(hsum[r], 32, 64);
+  }
+  // frame record of the evaluated point: H_ff (packed lower triangle: entry (r, l), r >= l, from column l) and g_f
+  double* fs = P.fsum + ((size_t)dst * P.F + f) * 32;
+  if (gi == 0 && l < 6) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+      if (r >= l) fs[r * (r + 1) / 2 + l] = hsum[r];
+  }
+  if (gi == 0 && l == 6) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) fs[21 + r] = hsum[r];
+  }
+  // model-cost term of the frame's own block at the accepted point
+  if (phase != 0 && gi == 0 && l < 6 && ng > 0) {
+    const double* fo = P.fsum + ((size_t)cur * P.F + f) * 32;
+    double hd = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int hi = l > k ? l : k, lo = l > k ? k : l;
+      hd = fma(fo[hi * (hi + 1) / 2 + lo], s_fr[12 + k], hd);
+    }
+    qm += s_fr[12 + l] * (0.5 * hd + fo[21 + l]);
+  }
+  cost = wave_sum(cost);
+  qm = wave_sum(qm);
+  if (lane_a == 0) {
+    P.gstats[f * 2] = cost;
+    P.gstats[f * 2 + 1] = qm;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // EXTENSION (pixel observations through the camera's intrinsics): the same idea with the matrix pipe. A row's 22 columns
 // [J_cam(6) J_frame(6) r | J_k(9)] carry only SIXTEEN independent ones, X = [J_cam(6) r J_k(9)]: one 16 x 16 product
 // per row set instead of the two of k_rig_sweep<true> (gram_rows_p2), one staged tile instead of two, no frame columns to
@@ -1230,10 +1531,11 @@ __device__ __forceinline__ void rig_reduce_stats(const RigDev& P, bool want, dou
     const d2* fs2 = reinterpret_cast<const d2*>(P.fstats);
     // up to sixteen loads in flight per thread: one round trip per 4096 groups instead of one per 256 (the plain loop waited
     // for every load: 20 us for the 16000 groups of BASELINE configs[4], in every block of the elimination)
-    for (int64_t i0 = 0; i0 < P.NG; i0 += 16 * 256) {
+    const int64_t nrows = P.fmode ? P.F : P.NG;   // (frame form: one row of cost / model-cost term per FRAME)
+    for (int64_t i0 = 0; i0 < nrows; i0 += 16 * 256) {
       d2 v[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) { const int64_t i = i0 + u * 256 + tid; v[u] = i < P.NG ? gs2[i] : d2{0.0, 0.0}; }
+      for (int u = 0; u < 16; ++u) { const int64_t i = i0 + u * 256 + tid; v[u] = i < nrows ? gs2[i] : d2{0.0, 0.0}; }
 #pragma unroll
       for (int u = 0; u < 16; ++u) { a[0] += v[u].x; a[1] += v[u].y; }
     }
@@ -1489,9 +1791,11 @@ __global__ __launch_bounds__(256) void k_rig_init(RigDev P) {
 // The elimination as a function: k_rig_elim (a launch of its own: trust-region decision, then the elimination) and the
 // persistent per-solve kernel (PS: the decision is the control workgroup's -- which buffer holds the point to eliminate,
 // the radius, whether this is the first elimination, and the Jacobi scales of the shared columns come as arguments).
-template <bool HK, int NR, bool PS>
+// FM: the sweep was k_rig_sweep_frame -- a group's record is [G7 (28) | T (36)] (P.gcomp), the frame block comes summed (P.fsum).
+template <bool HK, int NR, bool PS, bool FM = false>
 __device__ __forceinline__ void rig_elim_body(const RigDev& P, char* smem_raw, const int ps_cur, const double ps_radius, const bool ps_first,
                                               const double* ps_ss) {
+  static_assert(!(HK && FM), "the frame form is the poses-only sweep's");
   double* s_Z = reinterpret_cast<double*>(smem_raw);         // [24][ZS] staged Z rows of the four frames
   double* s_A = s_Z + 24 * P.ZS;                             // [4][32] frame block broadcast, per wave
   double* s_red = s_A + 4 * 32;                              // [4][1024] cross-wave reduction scratch
@@ -1605,8 +1909,8 @@ __device__ __forceinline__ void rig_elim_body(const RigDev& P, char* smem_raw, c
   const bool first_elim = PS ? ps_first : (ctl->phase == 1 && s_ctl.iter == 0 && !pending);   // Jacobi scale of the frame blocks
   const bool jac = P.opts->jacobi_scaling != 0;
   const int SW = P.SW, S = P.S, ZS = P.ZS;
-  const size_t gs = (size_t)P.gstride;
-  const double* blocks = P.gblocks + (size_t)cur * P.NG * gs;
+  const size_t gs = FM ? (size_t)64 : (size_t)P.gstride;
+  const double* blocks = FM ? P.gcomp + (size_t)cur * P.NG * 64 : P.gblocks + (size_t)cur * P.NG * gs;
 
   double c_ss[2];
 #pragma unroll
@@ -1642,14 +1946,19 @@ __device__ __forceinline__ void rig_elim_body(const RigDev& P, char* smem_raw, c
       const double fq0 = fqp[0], fq1 = fqp[1], fq2 = fqp[2], fq3 = fqp[3];
       // ---- loads: frame block entries (lanes < 27, summed over the groups), column data, direct entries
       double a_e = 0.0;
-      for (int j0 = 0; j0 < CO; j0 += 8) {
-        double v[8];
+      if (FM) {
+        a_e = P.fsum[((size_t)cur * P.F + f) * 32 + (lane < 27 ? lane : 0)];   // (the sweep summed the frame's groups)
+        if (lane >= 27) a_e = 0.0;
+      } else {
+        for (int j0 = 0; j0 < CO; j0 += 8) {
+          double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int g = j0 + u < CO ? __builtin_amdgcn_readlane(gj, j0 + u) : -1;
-          v[u] = (g >= 0 && lane < 27) ? blocks[(size_t)g * gs + a_off] : 0.0;
+          for (int u = 0; u < 8; ++u) {
+            const int g = j0 + u < CO ? __builtin_amdgcn_readlane(gj, j0 + u) : -1;
+            v[u] = (g >= 0 && lane < 27) ? blocks[(size_t)g * gs + a_off] : 0.0;
+          }
+          a_e += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
         }
-        a_e += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
       }
       double w[2][6];
 #pragma unroll
@@ -1661,7 +1970,7 @@ __device__ __forceinline__ void rig_elim_body(const RigDev& P, char* smem_raw, c
           const double* G = blocks + (size_t)gsel * gs;
 #pragma unroll
           for (int i = 0; i < 6; ++i)
-            w[h][i] = c_kind[h] == 0 ? G[c_comp[h] * 16 + 6 + i] : G[256 + (6 + i) * 16 + c_comp[h]];
+            w[h][i] = FM ? G[28 + c_comp[h] * 6 + i] : (c_kind[h] == 0 ? G[c_comp[h] * 16 + 6 + i] : G[256 + (6 + i) * 16 + c_comp[h]]);
         }
       }
       if (HK && P.kmode == RIG_K_SHARED) {
@@ -1838,11 +2147,11 @@ __device__ __forceinline__ void rig_elim_body(const RigDev& P, char* smem_raw, c
   ELIM_MARK(9);
 }
 
-template <bool HK, int NR>
+template <bool HK, int NR, bool FM = false>
 __global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
   rig_progress(P, RIG_PROG_ELIM);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  rig_elim_body<HK, NR, false>(P, smem_raw, 0, 1.0, false, nullptr);
+  rig_elim_body<HK, NR, false, FM>(P, smem_raw, 0, 1.0, false, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -4137,6 +4446,8 @@ struct cc_rig {
   int n_runs = 0;            // runs of shared columns (one per optimised camera, one per intrinsics set): blocks of k_rig_init
   int n_shared_runs = 0;     // of which sets of intrinsics common to all cameras (summed by init_slices blocks each)
   int sweep_waves = 4;       // waves per workgroup of the poses-only sweep (2: small groups that outnumber the slots)
+  bool frame_allowed = true; // poses-only, three-kernel path: the FRAME form of the sweep (k_rig_sweep_frame); CC_RIG_SWEEP_FRAME=0: one workgroup per group (k_rig_sweep_adj)
+  int frame_waves = 2;       // waves per frame workgroup of the frame form
   bool sweep_adjoint = true; // poses-only sweep: 7-column Gram + per-group assembly (k_rig_sweep_adj); CC_RIG_SWEEP_MFMA=1: the 13-column matrix-pipe sweep
   int kmode = 0;
   std::vector<int64_t> perm;  // sorted position -> caller's observation index
@@ -4292,6 +4603,9 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
   // (k_rig_elim_big, k_rig_solve_big), single GPU only
   h->big = S > kRigMaxS || CO * DE > 64 * kRigDirectPerLane;
   if (const char* e = getenv("CC_RIG_FORCE_BIG")) h->big = h->big || (atoi(e) != 0 && !h->comm && !h->exchange);   // (test knob: the plain kernels on any problem)
+  // the frame form of the sweep feeds the tuned elimination only (the plain large-rig kernels read the 16 x 16 tiles)
+  d.fmode = (!kmode && h->sweep_adjoint && h->frame_allowed && S <= kRigMaxS && CO * DE <= 64 * kRigDirectPerLane &&
+             !(getenv("CC_RIG_FORCE_BIG") && atoi(getenv("CC_RIG_FORCE_BIG")) != 0)) ? 1 : 0;
   if (h->big && (h->comm || h->exchange))
     return fail(CC_ERR_BAD_ARGUMENT, "%d shared coordinates, %d observed cameras%s: more than %d coordinates or %d cameras are not supported across several GPUs",
                 S, CO, kmode ? " with intrinsics" : "", kRigMaxS, 64 * kRigDirectPerLane / DE);
@@ -4373,8 +4687,11 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
   if (int rc = dev_upload(h, &d.colinfo, colinfo)) return rc;
   if (int rc = dev_upload(h, &d.dmap, dmap)) return rc;
   {
+    // (frame form of the sweep: a group's record is the packed G7, whose index of direct entry e -- H_cc (i, j) at i (i + 1) / 2
+    // + j, g_c,i at 21 + i -- IS e)
+    const bool fm = !kmode && h->sweep_adjoint && h->frame_allowed && !(S > kRigMaxS || CO * DE > 64 * kRigDirectPerLane || (getenv("CC_RIG_FORCE_BIG") && atoi(getenv("CC_RIG_FORCE_BIG")) != 0));
     std::vector<int32_t> dent((size_t)CO * DE);
-    for (int c = 0; c < CO; ++c) for (int e = 0; e < DE; ++e) dent[(size_t)c * DE + e] = (c << 16) | (int)(uint16_t)dmap[(size_t)e];
+    for (int c = 0; c < CO; ++c) for (int e = 0; e < DE; ++e) dent[(size_t)c * DE + e] = (c << 16) | (fm ? e : (int)(uint16_t)dmap[(size_t)e]);
     if (int rc = dev_upload(h, &d.dent, dent)) return rc;
   }
   if (int rc = dev_upload(h, &d.tile_i, ti)) return rc;
@@ -4409,6 +4726,8 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
     return 0;
   }
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
+  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<false, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
+  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<false, kRigDirectPerLane, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<false, kRigDirectPerLane>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<true, kRigDirectPerLane>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
@@ -4564,6 +4883,18 @@ static int rig_enqueue_round(cc_rig* h, bool initial, bool profile, bool publish
     if (d.kmode && h->sweep_adjoint && h->sweep_waves == 1) hipLaunchKernelGGL(k_rig_sweep_adjk<1>, dim3((unsigned)h->NG), dim3(64), 0, h->stream, d);
     else if (d.kmode && h->sweep_adjoint) hipLaunchKernelGGL(k_rig_sweep_adjk<4>, dim3((unsigned)h->NG), dim3(256), 0, h->stream, d);
     else if (d.kmode) hipLaunchKernelGGL((k_rig_sweep<true, 4>), dim3((unsigned)h->NG), dim3(kRigThreads), kRigSweepLdsBytesK, h->stream, d);
+    else if (d.fmode) {
+      const size_t fl = (size_t)kRigFrameLdsDoubles(d.CO) * 8;
+      const bool one = d.CO <= h->frame_waves;   // a wave per group: no loop over groups in the kernel
+      if (h->frame_waves == 1 && one) hipLaunchKernelGGL((k_rig_sweep_frame<1, true>), dim3((unsigned)h->F), dim3(64), fl, h->stream, d);
+      else if (h->frame_waves == 1) hipLaunchKernelGGL((k_rig_sweep_frame<1, false>), dim3((unsigned)h->F), dim3(64), fl, h->stream, d);
+      else if (h->frame_waves == 2 && one) hipLaunchKernelGGL((k_rig_sweep_frame<2, true>), dim3((unsigned)h->F), dim3(128), fl, h->stream, d);
+      else if (h->frame_waves == 2) hipLaunchKernelGGL((k_rig_sweep_frame<2, false>), dim3((unsigned)h->F), dim3(128), fl, h->stream, d);
+      else if (h->frame_waves == 4 && one) hipLaunchKernelGGL((k_rig_sweep_frame<4, true>), dim3((unsigned)h->F), dim3(256), fl, h->stream, d);
+      else if (h->frame_waves == 4) hipLaunchKernelGGL((k_rig_sweep_frame<4, false>), dim3((unsigned)h->F), dim3(256), fl, h->stream, d);
+      else if (one) hipLaunchKernelGGL((k_rig_sweep_frame<8, true>), dim3((unsigned)h->F), dim3(512), fl, h->stream, d);
+      else hipLaunchKernelGGL((k_rig_sweep_frame<8, false>), dim3((unsigned)h->F), dim3(512), fl, h->stream, d);
+    }
     else if (h->sweep_adjoint && h->sweep_waves == 4) hipLaunchKernelGGL((k_rig_sweep_adj<4>), dim3((unsigned)h->NG), dim3(256), 0, h->stream, d);
     else if (h->sweep_adjoint && h->sweep_waves == 2) hipLaunchKernelGGL((k_rig_sweep_adj<2>), dim3((unsigned)h->NG), dim3(128), 0, h->stream, d);
     else if (h->sweep_adjoint) hipLaunchKernelGGL((k_rig_sweep_adj<1>), dim3((unsigned)h->NG), dim3(64), 0, h->stream, d);
@@ -4590,6 +4921,8 @@ static int rig_enqueue_round(cc_rig* h, bool initial, bool profile, bool publish
     const bool small = d.ND <= 8 * 64;
     if (d.kmode && small) hipLaunchKernelGGL((k_rig_elim<true, 8>), dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d);
     else if (d.kmode) hipLaunchKernelGGL((k_rig_elim<true, kRigDirectPerLane>), dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d);
+    else if (d.fmode && small) hipLaunchKernelGGL((k_rig_elim<false, 8, true>), dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d);
+    else if (d.fmode) hipLaunchKernelGGL((k_rig_elim<false, kRigDirectPerLane, true>), dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d);
     else if (small) hipLaunchKernelGGL((k_rig_elim<false, 8>), dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d);
     else hipLaunchKernelGGL((k_rig_elim<false, kRigDirectPerLane>), dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d); }
   // (every block of the fused launch must be resident at once: its grid comes from rig_size_reduce_grid, rig_begin)
@@ -4750,6 +5083,7 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   RigDev& d = h->d;
   d.F = F; d.N = N; d.NG = NG;
   d.huber_a = (kmode && !(huber_a > 0.0)) ? 1e300 : huber_a;   // extension: a <= 0 switches the loss off
+  d.huber_b = d.huber_a * d.huber_a; d.huber_2a = d.huber_a + d.huber_a; d.huber_ha = 0.5 * d.huber_a;
   d.comm = 0; d.rank = 0; d.nranks = 1;
   d.kmode = kmode; d.gstride = kmode ? 768 : 256;
   d.init_slices = (int32_t)std::min<int64_t>(16, std::max<int64_t>(1, (NG + 511) / 512));
@@ -4772,7 +5106,22 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   if (int rc = dev_upload(h, &d.fgoff, h->fgoff_h)) return rc;
   if (int rc = dev_upload(h, &d.cam_goff, cam_goff)) return rc;
   if (int rc = dev_upload(h, &d.cam_glist, cam_glist)) return rc;
+  if (const char* e = getenv("CC_RIG_SWEEP_MFMA")) h->sweep_adjoint = atoi(e) == 0;      // (before the layout: it decides the form of the records)
+  if (const char* e = getenv("CC_RIG_SWEEP_FRAME")) h->frame_allowed = atoi(e) != 0;
   if (int rc = rig_layout(h, seen)) return rc;
+  {
+    // frame form: waves per frame workgroup -- enough workgroups x waves to fill the chip's 4096 wave slots, never more waves
+    // than a frame has groups (each wave sweeps whole groups)
+    int nw = 1;
+    while (nw < 8 && (int64_t)F * nw < 4096) nw *= 2;
+    while (nw > 1 && nw / 2 >= d.CO) nw /= 2;
+    // ... and a wave PER group when the rig has at most eight observed cameras and the frames alone do not fill the chip twice
+    // over: that kernel has no loop over groups and runs four waves per SIMD (three with the loop)
+    if (d.CO <= 8 && (int64_t)F * nw < 2 * 4096) { nw = 1; while (nw < d.CO) nw *= 2; }
+    h->frame_waves = nw;
+    if (const char* e = getenv("CC_RIG_FRAME_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) h->frame_waves = v; }
+  }
+  if (int rc = dev_zeroed(h, &d.fsum, (size_t)2 * F * 32)) return rc;
   const size_t CKn = (size_t)std::max(d.CK, 1);
   if (int rc = dev_zeroed(h, &d.cam, (size_t)2 * C * 8)) return rc;
   if (int rc = dev_zeroed(h, &d.pose, (size_t)2 * F * 8)) return rc;
@@ -4799,7 +5148,7 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   if (int rc = dev_zeroed(h, &h->init_intr, CKn * 16)) return rc;
   if (int rc = dev_zeroed(h, &h->d_kmask, CKn)) return rc;
   d.kmask = h->d_kmask;
-  if (int rc = dev_zeroed(h, &d.gstats, (size_t)NG * 2)) return rc;
+  if (int rc = dev_zeroed(h, &d.gstats, (size_t)std::max<int64_t>(NG, F) * 2)) return rc;   // (frame form: one row per frame)
   if (int rc = dev_zeroed(h, &d.fstats, (size_t)F * 2)) return rc;
   if (int rc = dev_zeroed(h, &d.ghd0, (size_t)NG * 8)) return rc;
   if (int rc = dev_zeroed(h, &d.gcomp, (size_t)2 * NG * (kmode ? kRigCompK : 64))) return rc;
@@ -5428,6 +5777,7 @@ int cc_rig_debug_fetch(cc_rig* h, const char* name, double* out, int64_t n) {
   const RigDev& d = h->d;
   if (k == "ss") src = d.ss; else if (k == "sp") src = d.sp; else if (k == "ds") src = d.ds;
   else if (k == "Y") src = d.Y; else if (k == "partial") src = d.partial; else if (k == "gblocks") src = d.gblocks;
+  else if (k == "gcomp") src = d.gcomp; else if (k == "fsum") src = d.fsum;
   else if (k == "camrec") src = d.camrec; else if (k == "frec") src = d.frec; else if (k == "gstats") src = d.gstats;
   else if (k == "fstats") src = d.fstats; else if (k == "shared_stats") src = d.shared_stats; else if (k == "cam") src = d.cam; else if (k == "pose") src = d.pose;
   else if (k == "vec") src = d.vec; else if (k == "vec_stats") src = d.vec_stats;

@@ -31,6 +31,7 @@ def _group_count(sc_or_k, cams):
 
 def _blocks_poses_only(monkeypatch, mfma, sc, cams, frozen, huber_a):
     monkeypatch.setenv("CC_RIG_SWEEP_MFMA", str(mfma))
+    monkeypatch.setenv("CC_RIG_SWEEP_FRAME", "0")   # (the 16 x 16 tiles: the frame form of the sweep never writes them, see below)
     monkeypatch.setenv("CC_RIG_PERSIST", "0")    # (the group blocks are read back from global memory: the lean persistent kernel keeps them in LDS)
     cq, ct = po.affine_to_qt(sc["cam_T"])
     fq, ft = po.affine_to_qt(sc["frame_T"])
@@ -64,10 +65,61 @@ def test_group_blocks_of_both_sweeps_agree(monkeypatch, cams, frames, pts, huber
     assert np.all(np.diagonal(b0[zero_cam][:, 6:12, 6:12], axis1=1, axis2=2) > 0)
 
 
+@pytest.mark.parametrize("nw", [1, 2, 4, 8])
+@pytest.mark.parametrize("cams,frames,pts,huber_a", [(3, 30, 150, capi.HUBER_A), (4, 25, 70, 0.0), (2, 40, 5, capi.HUBER_A), (11, 12, 20, capi.HUBER_A)])
+def test_frame_form_records_equal_the_tiles(monkeypatch, nw, cams, frames, pts, huber_a):
+    """The FRAME form of the sweep (k_rig_sweep_frame, the default of the three-kernel path since round 4) writes per group
+    [G7 (28) | T = G_cc M (36)] and per frame [H_ff (21) | g_f (6)] instead of the 16 x 16 tile N^T G7 N: every one of these
+    numbers is an entry (or, for the frame record, a sum over the frame's groups of entries) of the tile the group form
+    writes -- compared here entry by entry, with every wave count of the frame workgroup (more groups per frame than one
+    assembly pass of eight in the last shape), together with the frame's cost row."""
+    sc = po.rig_scenario(cams, frames, pts)
+    frozen = np.array(sc["cam_frozen"], dtype=np.uint8).copy()
+    c0, b0 = _blocks_poses_only(monkeypatch, 0, sc, cams, frozen, huber_a)
+    monkeypatch.setenv("CC_RIG_SWEEP_FRAME", "1")
+    monkeypatch.setenv("CC_RIG_FRAME_WAVES", str(nw))
+    cq, ct = po.affine_to_qt(sc["cam_T"])
+    fq, ft = po.affine_to_qt(sc["frame_T"])
+    prob = capi.RigProblem(cams, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"], sc["world_xyz"], frozen, huber_a=huber_a)
+    prob.set_state(cq, ct, fq, ft)
+    c1 = prob.solve(capi.default_options(max_iterations=1))["initial_cost"]
+    ng = _group_count(sc, cams)
+    rec = _fetch(prob, "gcomp", ng * 64).reshape(ng, 64)
+    fsum = _fetch(prob, "fsum", frames * 32).reshape(frames, 32)
+    prob.close()
+    assert np.isclose(c0, c1, rtol=1e-13)
+    off, cam = np.asarray(sc["frame_offsets"]), np.asarray(sc["obs_cam"])
+    gframe = np.concatenate([[f] * len(np.unique(cam[off[f]:off[f + 1]])) for f in range(frames)])
+    gcam = np.concatenate([np.unique(cam[off[f]:off[f + 1]]) for f in range(frames)])
+    idx7 = [0, 1, 2, 3, 4, 5, 12]
+    tri = [(i, j) for i in range(7) for j in range(i + 1)]
+    tri6 = [(i, j) for i in range(6) for j in range(i + 1)]
+    for g in range(ng):
+        tile = b0[g]
+        scale = np.abs(tile).max()
+        if not frozen[gcam[g]]:   # (a camera held constant: the tile form zeroes its rows, the record keeps G7 -- nobody reads it)
+            g7 = np.array([tile[idx7[i], idx7[j]] for i, j in tri])
+            assert np.abs(rec[g, :28] - g7).max() < 1e-11 * scale
+            assert np.abs(rec[g, 28:].reshape(6, 6) - tile[0:6, 6:12]).max() < 1e-11 * scale
+    for f in range(frames):
+        sel = gframe == f
+        if not sel.any():
+            continue
+        hff = b0[sel][:, 6:12, 6:12].sum(axis=0)
+        gf = b0[sel][:, 6:12, 12].sum(axis=0)
+        scale = np.abs(hff).max()
+        assert np.abs(fsum[f, :21] - np.array([hff[i, j] for i, j in tri6])).max() < 1e-11 * scale
+        assert np.abs(fsum[f, 21:27] - gf).max() < 1e-11 * max(scale, np.abs(gf).max())
+
+
+@pytest.mark.parametrize("frame", [0, 1])
 @pytest.mark.parametrize("mfma", [0, 1])
 @pytest.mark.parametrize("cams,frames,pts", [(3, 30, 150), (4, 40, 30), (2, 300, 4)])
-def test_rig_solve_matches_the_oracle_under_either_sweep(monkeypatch, mfma, cams, frames, pts):
+def test_rig_solve_matches_the_oracle_under_either_sweep(monkeypatch, mfma, frame, cams, frames, pts):
     monkeypatch.setenv("CC_RIG_SWEEP_MFMA", str(mfma))
+    monkeypatch.setenv("CC_RIG_SWEEP_FRAME", str(frame))
+    if frame:
+        monkeypatch.setenv("CC_RIG_PERSIST", "0")   # (small rigs run the lean persistent form by default: the frame form is the three-kernel path's)
     sc = po.rig_scenario(cams, frames, pts)
     g, o = _both(sc, cams)
     _assert_same(g, o)

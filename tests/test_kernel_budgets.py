@@ -33,8 +33,17 @@ def test_rig_sweeps_keep_their_register_allocation():
     assert t["k_rig_sweep_adj<1>"]["vgpr"] <= 128, t["k_rig_sweep_adj<1>"]      # four waves per SIMD
     for k in ("k_rig_sweep_adjk<1>", "k_rig_sweep_adjk<4>"):
         assert t[k]["vspill"] == 0 and t[k]["vgpr"] <= 168, (k, t[k])            # three waves per SIMD
-    for k in ("k_rig_elim<false, 8>", "k_rig_elim<false, 24>", "k_rig_elim<true, 8>", "k_rig_elim<true, 24>"):
+    elims = [k for k in t if k.startswith("k_rig_elim<")]
+    assert len(elims) == 6, elims
+    for k in elims:
         assert t[k]["vspill"] == 0 and t[k]["scratch"] == 0, (k, t[k])            # (sits at the 512-register limit by design)
+    # frame form of the sweep: a wave per group (ONE) at four waves per SIMD -- its few spills are in the once-per-frame assembly,
+    # none in the passes (checked on the ISA in round 4: every scratch access lies behind the kernel's barrier); the loop form
+    # is compiled for three waves per SIMD and must not spill at all
+    for nw in (1, 2, 4, 8):
+        one, loop = t["k_rig_sweep_frame<%d, true>" % nw], t["k_rig_sweep_frame<%d, false>" % nw]
+        assert one["vgpr"] <= 128 and one["vspill"] <= 3, (nw, one)
+        assert loop["vgpr"] <= 168 and loop["vspill"] == 0 and loop["scratch"] == 0, (nw, loop)
     for k in ("k_rig_persist_w<1>", "k_rig_persist_w<2>"):
         assert t[k]["vspill"] == 0 and t[k]["scratch"] == 0, (k, t[k])
     assert t["k_rig_persist_w<4>"]["vgpr"] <= 128 and t["k_rig_persist_w<4>"]["vspill"] <= 20, t["k_rig_persist_w<4>"]   # (1024 threads; the spills are outside the sweep loop, as in round 3)
