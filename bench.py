@@ -101,6 +101,22 @@ def peer_access(torch, world):
         return f"query failed: {e}"
 
 
+def class_surface(frames, points):
+    """What a drop-in user of the C++ class pays per call: Calibrator::Estimate at this size through the class (packing of the
+    vector<Points2D> / vector<Points3D> arguments included), measured by the native program tests/cpp/test_dropin
+    (--class-surface), a fresh Calibrator per call as the reference's workflow makes one. None when the program is not built."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "test_dropin")
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe, "--class-surface", str(frames), str(points), "20"], capture_output=True, text=True, timeout=300)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        return json.loads(line[-1]) if r.returncode == 0 and line else {"error": (r.stdout + r.stderr)[-400:]}
+    except Exception as e:   # (reported, never fatal)
+        return {"error": str(e)}
+
+
 def usable_cores():
     """Host cores this process may actually use: affinity mask and cgroup CPU quota, not the node's count."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -404,14 +420,23 @@ def main():
         sleg = Leg(FRAMES_PER_GPU)
         s_elapsed, s_solves = sleg.timed(args.steps, args.warmup)
         s_sweep_ms = sleg.prob.profile_sweep(100)
+        s_forms = [None] * world
+        dist.all_gather_object(s_forms, {"rank": rank, "device": local_rank, "solver_form": sleg.prob.solver_form(), "exchange": sleg.exchange,
+                                         "frames": sleg.f1 - sleg.f0, "solver_status": list(sleg.prob.solver_status())})
         strong = {
             "workload": f"fixed {FRAMES_PER_GPU} frames x {args.points} pts split over {world} GPUs",
+            "ranks": s_forms,   # per rank: the form of the solver it ran (0 two kernels, 1 / 2 / 4 persistent) and the route of its exchange
             "value": 2.0 * sleg.n_obs_total * args.steps / s_elapsed, "unit": "residuals/s",
             "ms_per_step": s_elapsed / args.steps * 1e3, "lm_iterations_per_sec": args.steps / s_elapsed,
             "frames_per_gpu": sleg.f1 - sleg.f0, "exchange": sleg.exchange, "sweep_ms_rank0": s_sweep_ms,
         }
         sleg.close()
 
+    rank_forms = None
+    if world > 1:   # so that the first run on real hardware explains itself: every rank's solver form and exchange route
+        rank_forms = [None] * world
+        dist.all_gather_object(rank_forms, {"rank": rank, "device": local_rank, "solver_form": form, "exchange": leg.exchange,
+                                            "frames": leg.f1 - leg.f0, "solver_status": list(prob.solver_status())})
     result = None
     if rank == 0:
         n_obs_total = leg.n_obs_total
@@ -437,6 +462,7 @@ def main():
                 "frames_total": leg.F_total, "points_per_frame": args.points,
                 "observations_total": n_obs_total, "parallelism": (f"independent replicas x{world}" if world > 1 and leg.exchange.startswith("none") else f"frame-sharded x{world}"),
                 "exchange": leg.exchange,
+                "ranks": rank_forms,
                 "exchange_errors": leg.exchange_errors,
                 "exchange_validation_us_per_iteration": leg.validation_us_per_iteration,
                 "peer_access": peer_access(torch, world),
@@ -447,6 +473,7 @@ def main():
             "time_to_converge_ms": conv_ms,
             "observations_per_sec": n_obs_total * args.steps / elapsed,
             "one_shot_ms_including_upload": e2e_ms,
+            "class_surface": class_surface(args.frames, args.points) if world == 1 else None,
             "per_solve_us_per_iteration": {"n_solves": len(per_iter_us), "median": float(np.median(per_iter_us)),
                                            "min": float(np.min(per_iter_us)), "max": float(np.max(per_iter_us))},
             "converged": {"termination": conv["termination"], "final_cost": conv["final_cost"],
@@ -570,7 +597,7 @@ def rig_configs(capi, device):
             sweeps = s["iterations"] + 1
             sweep_ms = p["kernel_ms"]["sweep"] / sweeps
             ab = algorithmic_bytes_rig_sweep(n_obs, n_world, F, C_)
-            sweep_name = "k_rig_sweep_adj" if variant == "poses" else "k_rig_sweep_adjk"
+            sweep_name = "k_rig_sweep_frame (one workgroup per frame, a wave per (frame, camera) group)" if variant == "poses" else "k_rig_sweep_adjk"
             names = {"sweep": sweep_name, "decide": "k_rig_init", "elim": "k_rig_elim", "solve": "k_rig_reduce (column sums + reduced solve + pose update)",
                      "update": "k_rig_update", "reduce": "k_rig_reduce<2>", "allreduce": "ncclAllReduce"}
             # the kernel that takes the largest share of the profiled solve's kernel time -- NOT assumed to be the sweep: at
@@ -584,7 +611,7 @@ def rig_configs(capi, device):
             else:
                 dominant.update(bound="latency", note="a chain of dependent steps on one workgroup (column sums, assembly, Cholesky of the "
                                 "reduced system, pose update behind a flag): no bandwidth or flop roofline applies; stage times in "
-                                "profiles/r03/rig_stage_marks.jsonl")
+                                "profiles/r04/rig_stage_marks.jsonl")
             if form:
                 # the timed solves ran as ONE launch (lean persistent kernel + its control workgroup's launch); the per-kernel
                 # figures below are the three-kernel form's, which is what a profiled solve runs
@@ -599,16 +626,16 @@ def rig_configs(capi, device):
                 "observations": n_obs, "iterations": s["iterations"], "termination": s["termination"],
                 "solve_ms": t_solve * 1e3, "ms_per_iteration": t_solve * 1e3 / max(1, s["iterations"]),
                 "residuals_per_sec": 2.0 * n_obs * s["iterations"] / t_solve,
-                "solver_form": {0: "three kernels per LM iteration", 1: "persistent kernel (glued form)", 2: "lean persistent kernel: one launch per solve"}[form],
+                "solver_form": {0: "three kernels per LM iteration", 2: "lean persistent kernel: one launch per solve"}[form],
                 "dominant_kernel": dominant,
                 "sweep_kernel": {"kernel": sweep_name, "ms_per_launch": sweep_ms,
                                  "hbm_frac": ab / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  "fp64_frac": RIG_FLOP_PER_OBS[variant] * n_obs / (sweep_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                                  "algorithmic_bytes_per_launch": ab, "traffic": load_rig_traffic(C_, F, M, variant)},
                 "kernel_ms_per_launch_eager": per_launch,
-                "kernel_ms_labels": "(the THREE-KERNEL form: what profile_kernels = 1 runs) sweep = k_rig_sweep_adj / k_rig_sweep_adjk (per group the columns [J_cam r (J_k)] only, frame blocks "
-                                    "through the group's adjoint), decide = k_rig_init (once per solve), elim = k_rig_elim, "
-                                    "solve = k_rig_reduce (column sums + reduced solve + pose update in one launch)",
+                "kernel_ms_labels": "(the THREE-KERNEL form: what profile_kernels = 1 runs) sweep = k_rig_sweep_frame (poses: per group the 7-column Gram of [J_cam r], per frame ONE "
+                                    "assembly of the coupling blocks and the frame block through the groups' adjoints) / k_rig_sweep_adjk (with intrinsics), decide = k_rig_init "
+                                    "(once per solve), elim = k_rig_elim, solve = k_rig_reduce (column sums + reduced solve + pose update in one launch)",
                 "final_cost": s["final_cost"],
             }
     return out

@@ -2,7 +2,9 @@
 #include "calibrator.hh"
 
 #include <cassert>
+#include <chrono>
 #include <cstdint>
+#include <cstring>
 #include <stdexcept>
 
 #include "../../include/cc_solver.h"
@@ -13,6 +15,49 @@ namespace calibrator {
 namespace {
 // parameter order of the shared block, identical to the reference's enum (calibrator.cpp:168-179)
 enum Intrinsic { FX, FY, PX, PY, K1, K2, P1, P2, K3, kNumIntrinsics };
+
+// The reference copies every point into Ceres parameter blocks (calibrator.cpp:261-292); here the views are packed into the
+// flat arrays of the C ABI -- ONE memcpy per view (a Points2D / Points3D is a contiguous array of two / three floats per
+// point, with Eigen as with mini_eigen.hh) straight into pinned host memory that is cached between calls
+// (cc_host_staging_acquire): the upload then runs at the full PCIe rate and no per-point loop, push_back or pageable
+// bounce buffer is left on the path of a caller that re-estimates as images arrive (cam_calibration.py:290-322).
+static_assert(sizeof(Point2D) == 2 * sizeof(float) && sizeof(Point3D) == 3 * sizeof(float), "points are packed float arrays");
+struct PackedViews {
+  void* block = nullptr;
+  int64_t* offsets = nullptr;
+  float* uv = nullptr;
+  float* xyz = nullptr;
+  int64_t n_obs = 0;
+  double pack_ms = 0.0;
+  PackedViews(const std::vector<Points2D>& pix, const std::vector<Points3D>& pts) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t n_img = pix.size();
+    size_t n = 0;
+    for (size_t i = 0; i < n_img; ++i) n += pix[i].size();
+    const size_t b_off = ((n_img + 1) * sizeof(int64_t) + 255) & ~(size_t)255, b_uv = (n * 2 * sizeof(float) + 255) & ~(size_t)255;
+    block = cc_host_staging_acquire(b_off + b_uv + n * 3 * sizeof(float) + 256);
+    if (!block) throw std::runtime_error("Calibrator: pinned staging memory could not be allocated");
+    offsets = static_cast<int64_t*>(block);
+    uv = reinterpret_cast<float*>(static_cast<char*>(block) + b_off);
+    xyz = reinterpret_cast<float*>(static_cast<char*>(block) + b_off + b_uv);
+    offsets[0] = 0;
+    for (size_t i = 0; i < n_img; ++i) {
+      assert(pix[i].size() == pts[i].size());
+      const size_t k = (size_t)offsets[i], m = pix[i].size();
+      if (m) {
+        std::memcpy(uv + 2 * k, pix[i].data(), m * sizeof(Point2D));
+        std::memcpy(xyz + 3 * k, pts[i].data(), m * sizeof(Point3D));
+      }
+      offsets[i + 1] = (int64_t)(k + m);
+    }
+    n_obs = (int64_t)n;
+    pack_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+  void release() { cc_host_staging_release(block); block = nullptr; }   // (before another packing of the same thread: the cache holds one block)
+  ~PackedViews() { if (block) cc_host_staging_release(block); }
+  PackedViews(const PackedViews&) = delete;
+  PackedViews& operator=(const PackedViews&) = delete;
+};
 }  // namespace
 
 Calibrator::Calibrator(const int image_width, const int image_height) : image_w_(image_width), image_h_(image_height) {}
@@ -27,16 +72,12 @@ void Calibrator::Estimate(const std::vector<Points2D>& pixels_per_view, const st
   assert(pixels_per_view.size() == board_points_per_view.size());
   const size_t n_img = pixels_per_view.size();
   // Zhang initialisation on the device (cc_zhang_init): homographies -> K -> poses
-  std::vector<int64_t> offsets(n_img + 1, 0);
-  for (size_t i = 0; i < n_img; ++i) offsets[i + 1] = offsets[i] + (int64_t)pixels_per_view[i].size();
-  std::vector<float> uv((size_t)offsets[n_img] * 2), xyz((size_t)offsets[n_img] * 3);
-  for (size_t i = 0; i < n_img; ++i) {
-    size_t k = (size_t)offsets[i];
-    for (size_t j = 0; j < pixels_per_view[i].size(); ++j, ++k) {
-      uv[2 * k] = pixels_per_view[i][j].x(); uv[2 * k + 1] = pixels_per_view[i][j].y();
-      xyz[3 * k] = board_points_per_view[i][j].x(); xyz[3 * k + 1] = board_points_per_view[i][j].y(); xyz[3 * k + 2] = board_points_per_view[i][j].z();
-    }
-  }
+  const auto t_call = std::chrono::steady_clock::now();
+  PackedViews pv(pixels_per_view, board_points_per_view);
+  const int64_t* offsets_p = pv.offsets;
+  const float *uv_p = pv.uv, *xyz_p = pv.xyz;
+  for (double& v : last_timing_ms_) v = 0.0;
+  last_timing_ms_[0] = pv.pack_ms;
   float K9[9];
   if (devices_.size() <= 1) {
     // one device: the fused entry point (one upload of the observations for initialisation and solve together);
@@ -50,8 +91,9 @@ void Calibrator::Estimate(const std::vector<Points2D>& pixels_per_view, const st
     cc_options options;
     cc_options_init(&options);  // non-monotonic steps, 100 iterations: calibrator.cpp:314-321
     cc_summary summary{};
-    last_status_ = cc_intrinsics_estimate(&options, device_, (int64_t)n_img, offsets.data(), uv.data(), xyz.data(), dist5, frozen,
+    last_status_ = cc_intrinsics_estimate(&options, device_, (int64_t)n_img, offsets_p, uv_p, xyz_p, dist5, frozen,
                                           K9, intr, qd.data(), td.data(), &summary);
+    cc_last_call_timing(&last_timing_ms_[1]);
     // Same contract as the two-step path below: environment errors (no device, HIP, exchange) and the Zhang
     // preconditions (cc_zhang_init's CC_ERR_BAD_ARGUMENT: < 3 frames, < 4 points in a frame) throw; a solver-level
     // status (CC_ERR_STATE: the LM loop gave up) does not -- it goes to LastStatus() as Optimize() documents, and the
@@ -71,18 +113,20 @@ void Calibrator::Estimate(const std::vector<Points2D>& pixels_per_view, const st
     distortion_(2) = static_cast<float>(intr[P1]);
     distortion_(3) = static_cast<float>(intr[P2]);
     distortion_(4) = static_cast<float>(intr[K3]);
+    last_timing_ms_[6] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
     return;
   }
   std::vector<float> q(4 * n_img), t(3 * n_img);
-  const int rc = cc_zhang_init(device_, (int64_t)n_img, offsets.data(), uv.data(), xyz.data(), K9, q.data(), t.data(), nullptr);
+  const int rc = cc_zhang_init(device_, (int64_t)n_img, offsets_p, uv_p, xyz_p, K9, q.data(), t.data(), nullptr);
   if (rc != 0) throw std::runtime_error(std::string("Calibrator::Estimate: ") + cc_last_error());
   for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) camera_matrix_(r, c) = K9[r * 3 + c];
-  std::vector<Quaternion> qs;
-  std::vector<Point3D> ts;
+  std::vector<Quaternion> qs(n_img);
+  std::vector<Point3D> ts(n_img);
   for (size_t i = 0; i < n_img; ++i) {
-    qs.emplace_back(q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]);
-    ts.emplace_back(t[3 * i], t[3 * i + 1], t[3 * i + 2]);
+    qs[i] = Quaternion(q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]);
+    ts[i] = Point3D(t[3 * i], t[3 * i + 1], t[3 * i + 2]);
   }
+  pv.release();
   Optimize(pixels_per_view, board_points_per_view, qs, ts);
 }
 
@@ -90,23 +134,15 @@ void Calibrator::Optimize(const std::vector<Points2D>& pixels_per_view, const st
                           std::vector<Quaternion>& qs, std::vector<Point3D>& ts) {
   const size_t n_img = pixels_per_view.size();
   assert(n_img == board_points_per_view.size() && n_img == qs.size() && n_img == ts.size());
-  // CSR layout of the ragged frames + fp64 parameter arrays
-  std::vector<int64_t> offsets(n_img + 1, 0);
-  for (size_t i = 0; i < n_img; ++i) {
-    assert(pixels_per_view[i].size() == board_points_per_view[i].size());
-    offsets[i + 1] = offsets[i] + (int64_t)pixels_per_view[i].size();
-  }
-  std::vector<float> uv((size_t)offsets[n_img] * 2), xyz((size_t)offsets[n_img] * 3);
+  // CSR layout of the ragged frames (packed into cached pinned memory, one memcpy per view) + fp64 parameter arrays
+  const auto t_call = std::chrono::steady_clock::now();
+  PackedViews pv(pixels_per_view, board_points_per_view);
+  const int64_t* offsets_p = pv.offsets;
+  const float *uv_p = pv.uv, *xyz_p = pv.xyz;
+  for (double& v : last_timing_ms_) v = 0.0;
+  last_timing_ms_[0] = pv.pack_ms;
   std::vector<double> q(4 * n_img), t(3 * n_img);
   for (size_t i = 0; i < n_img; ++i) {
-    size_t k = (size_t)offsets[i];
-    for (size_t j = 0; j < pixels_per_view[i].size(); ++j, ++k) {
-      uv[2 * k] = pixels_per_view[i][j].x();
-      uv[2 * k + 1] = pixels_per_view[i][j].y();
-      xyz[3 * k] = board_points_per_view[i][j].x();
-      xyz[3 * k + 1] = board_points_per_view[i][j].y();
-      xyz[3 * k + 2] = board_points_per_view[i][j].z();
-    }
     q[4 * i] = qs[i].w(); q[4 * i + 1] = qs[i].x(); q[4 * i + 2] = qs[i].y(); q[4 * i + 3] = qs[i].z();
     t[3 * i] = ts[i].x(); t[3 * i + 1] = ts[i].y(); t[3 * i + 2] = ts[i].z();
   }
@@ -124,11 +160,12 @@ void Calibrator::Optimize(const std::vector<Points2D>& pixels_per_view, const st
     last_status_ = 0;
   } else if (devices_.size() > 1) {
     std::vector<int32_t> devs(devices_.begin(), devices_.end());
-    last_status_ = cc_intrinsics_optimize_multi(&options, (int32_t)devs.size(), devs.data(), (int64_t)n_img, offsets.data(), uv.data(),
-                                                xyz.data(), intr, frozen, q.data(), t.data(), &summary);
+    last_status_ = cc_intrinsics_optimize_multi(&options, (int32_t)devs.size(), devs.data(), (int64_t)n_img, offsets_p, uv_p,
+                                                xyz_p, intr, frozen, q.data(), t.data(), &summary);
   } else {
-    last_status_ = cc_intrinsics_optimize(&options, device_, (int64_t)n_img, offsets.data(), uv.data(), xyz.data(),
+    last_status_ = cc_intrinsics_optimize(&options, device_, (int64_t)n_img, offsets_p, uv_p, xyz_p,
                                           intr, frozen, q.data(), t.data(), &summary);
+    cc_last_call_timing(&last_timing_ms_[1]);
   }
   last_iterations_ = summary.iterations;
   last_final_cost_ = summary.final_cost;
@@ -144,6 +181,7 @@ void Calibrator::Optimize(const std::vector<Points2D>& pixels_per_view, const st
   distortion_(2) = static_cast<float>(intr[P1]);
   distortion_(3) = static_cast<float>(intr[P2]);
   distortion_(4) = static_cast<float>(intr[K3]);
+  last_timing_ms_[6] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
 }
 
 void Calibrator::ForceDistortionToConstant(const int coefficient) {

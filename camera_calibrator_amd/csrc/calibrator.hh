@@ -53,6 +53,10 @@ class Calibrator {
   int LastStatus() const { return last_status_; }
   int LastIterations() const { return last_iterations_; }
   double LastFinalCost() const { return last_final_cost_; }
+  /// Wall milliseconds of the last Estimate / Optimize on one device: [0] packing the views into (cached, pinned) flat arrays,
+  /// [1] solver handle + device arena (cached), [2] upload, [3] Zhang initialisation (Estimate), [4] solve, [5] read-back +
+  /// teardown, [6] the whole call.
+  const double* LastTimingMs() const { return last_timing_ms_; }
 
  private:
   int image_w_;
@@ -62,6 +66,7 @@ class Calibrator {
   int last_status_{0};
   int last_iterations_{0};
   double last_final_cost_{0.0};
+  double last_timing_ms_[7]{0, 0, 0, 0, 0, 0, 0};
   Matrix3 camera_matrix_{Matrix3::Identity()};
   DynamicVector distortion_{DynamicVector::Zero(5)};
   std::set<int> frozen_intrinsics_;

@@ -12,6 +12,11 @@ std::string& last_error() {
   return s;
 }
 
+double* last_timing() {
+  static thread_local double t[5] = {0, 0, 0, 0, 0};
+  return t;
+}
+
 int fail(int code, const char* fmt, ...) {
   char buf[4096];   // (a stalled exchange describes every rank's mailbox slots)
   va_list ap;
@@ -120,6 +125,80 @@ void scratch_put(int device, void* p, size_t, bool cached) {
   hipFree(p);
 }
 
+// ---- device arena of a solver handle and pinned host staging of the class surface: ONE cached piece each (per device /
+// per process), grow-only, handed to one owner at a time -- a caller that re-estimates as images arrive (the reference's
+// workflow builds a fresh Calibrator per call: cam_calibration.py:290-322) pays hipMalloc / hipHostMalloc once, not per call.
+namespace {
+struct Piece { void* p = nullptr; size_t bytes = 0; bool busy = false; };
+std::vector<Piece> g_arena;     // per device
+Piece g_staging;                // pinned host memory
+constexpr size_t kArenaKeep = (size_t)1 << 30, kStagingKeep = (size_t)1 << 30;
+}  // namespace
+
+int arena_get(int device, size_t bytes, void** out, bool* cached) {
+  *cached = false;
+  if (bytes <= kArenaKeep) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    if ((int)g_arena.size() <= device) g_arena.resize((size_t)device + 1);
+    Piece& a = g_arena[(size_t)device];
+    if (!a.busy) {
+      if (a.bytes < bytes) {
+        if (a.p) hipFree(a.p);
+        a.p = nullptr; a.bytes = 0;
+        const size_t want = bytes + bytes / 4;   // (room for a problem that grows by a few frames per call)
+        if (hipMalloc(&a.p, want) != hipSuccess) { (void)hipGetLastError(); a.p = nullptr; return fail(CC_ERR_HIP, "hipMalloc(%zu) failed", want); }
+        a.bytes = want;
+      }
+      a.busy = true;
+      *out = a.p;
+      *cached = true;
+      return CC_OK;
+    }
+  }
+  CC_HIP(hipMalloc(out, bytes));
+  return CC_OK;
+}
+
+void arena_put(int device, void* p, bool cached) {
+  if (!p) return;
+  if (cached) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    if ((int)g_arena.size() > device && g_arena[(size_t)device].p == p) { g_arena[(size_t)device].busy = false; return; }
+  }
+  hipFree(p);
+}
+
+void* staging_get(size_t bytes, bool* cached) {
+  *cached = false;
+  if (bytes <= kStagingKeep) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    if (!g_staging.busy) {
+      if (g_staging.bytes < bytes) {
+        if (g_staging.p) hipHostFree(g_staging.p);
+        g_staging.p = nullptr; g_staging.bytes = 0;
+        const size_t want = bytes + bytes / 4;
+        if (hipHostMalloc(&g_staging.p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); g_staging.p = nullptr; return nullptr; }
+        g_staging.bytes = want;
+      }
+      g_staging.busy = true;
+      *cached = true;
+      return g_staging.p;
+    }
+  }
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+
+void staging_put(void* p) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    if (g_staging.p == p) { g_staging.busy = false; return; }
+  }
+  hipHostFree(p);
+}
+
 void stream_put(int device, hipStream_t s) {
   if (!s) return;
   std::lock_guard<std::mutex> lk(g_cache_mu);
@@ -152,6 +231,22 @@ void cc_options_init(cc_options* o) {
 }
 
 const char* cc_last_error(void) { return cc::last_error().c_str(); }
+
+// Pinned host memory for a caller that packs its inputs itself (the C++ classes: one memcpy per frame straight into memory
+// hipMemcpyAsync reads at full PCIe rate, cached between calls). Not needed for correctness: every entry point takes any
+// host pointer.
+void* cc_host_staging_acquire(size_t bytes) {
+  bool cached = false;
+  return cc::staging_get(bytes ? bytes : 1, &cached);
+}
+void cc_host_staging_release(void* p) { cc::staging_put(p); }
+
+// Phases of the last cc_intrinsics_estimate / cc_intrinsics_optimize of this thread, wall milliseconds:
+// [0] handle + device arena, [1] upload (enqueue + wait), [2] Zhang initialisation incl. its read-back, [3] solve,
+// [4] read-back + teardown.
+void cc_last_call_timing(double out_ms[5]) {
+  for (int i = 0; i < 5; ++i) out_ms[i] = cc::last_timing()[i];
+}
 const char* cc_version(void) { return "camera_calibrator_amd 0.1 (gfx950, HIP)"; }
 
 int cc_device_count(void) {

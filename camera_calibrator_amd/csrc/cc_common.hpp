@@ -41,6 +41,11 @@ void stream_put(int device, hipStream_t s);
 // One reusable scratch buffer per device for the point kernels (Distort / Undistort are called once per frame by the
 // Python workflow): grows to the largest request (<= 64 MiB kept), handed out to one caller at a time; a second
 // concurrent caller simply gets a fresh allocation. scratch_put frees what was not taken from / cannot go back to the cache.
+int arena_get(int device, size_t bytes, void** out, bool* cached);    // device arena of a solver handle (one cached, grow-only)
+void arena_put(int device, void* p, bool cached);
+void* staging_get(size_t bytes, bool* cached);                       // pinned host staging (one cached, grow-only)
+void staging_put(void* p);
+double* last_timing();                                               // [5] phases of this thread's last one-shot call (ms)
 int scratch_get(int device, size_t bytes, void** out, bool* cached);
 void scratch_put(int device, void* p, size_t bytes, bool cached);
 

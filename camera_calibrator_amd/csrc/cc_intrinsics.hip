@@ -1019,7 +1019,11 @@ struct cc_intrinsics {
   cc::IntrDev d{};
   int64_t F = 0, N = 0;
   int elim_blocks = 1;
-  void* arena = nullptr;        // every device buffer of the handle lives in this one allocation
+  void* arena = nullptr;        // every device buffer of the handle lives in this one allocation (cc::arena_get: cached between handles)
+  bool arena_cached = false;
+  size_t extra_bytes = 0;       // set before creation: scratch appended to the arena (cc_intrinsics_estimate's initialisation)
+  char* extra = nullptr;
+  bool one_shot = false;        // the creator keeps uv / xyz alive until it has synchronised: no wait at the end of create
   double* init_intr = nullptr;  // [16]
   double* init_pose = nullptr;  // [F][8]
   bool have_state = false;
@@ -1168,6 +1172,15 @@ static int wait_published(cc_intrinsics* h, LmCtl* c) {
 
 namespace cc {
 int intr_create_impl(cc_intrinsics* h, const int64_t* off, const float* uv, const float* xyz);
+// (how the one-shot entry points -- cc_intrinsics_optimize / _estimate -- ask cc_intrinsics_create for a handle of their own
+// kind: the upload is not waited for, `extra` bytes of scratch ride in the same arena)
+static thread_local bool g_create_one_shot = false;
+static thread_local size_t g_create_extra = 0;
+struct OneShotCreate {
+  OneShotCreate(size_t extra) { g_create_one_shot = true; g_create_extra = extra; }
+  ~OneShotCreate() { g_create_one_shot = false; g_create_extra = 0; }
+};
+static double ms_since(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 }
 
 extern "C" {
@@ -1188,6 +1201,8 @@ int cc_intrinsics_create(int32_t device, int64_t F, const int64_t* off, const fl
   if (int rc = select_device(device)) return rc;
   cc_intrinsics* h = new cc_intrinsics();
   h->device = device; h->F = F; h->N = N;
+  h->one_shot = cc::g_create_one_shot;
+  h->extra_bytes = cc::g_create_extra;
   const int rc_init = cc::intr_create_impl(h, off, uv, xyz);
   if (rc_init != CC_OK) {  // release whatever was allocated before the failure
     cc_intrinsics_destroy(h);
@@ -1334,15 +1349,17 @@ int intr_create_impl(cc_intrinsics* h, const int64_t* off, const float* uv, cons
   const size_t o_uv = take(n1 * 2 * sizeof(float));
   const size_t o_xyz = take(n1 * 3 * sizeof(float));
   const size_t o_off = take((size_t)(F + 1) * sizeof(int64_t));
-  CC_HIP(hipMalloc(&h->arena, cursor));
+  const size_t o_extra = take(h->extra_bytes);
+  if (int rc = arena_get(h->device, cursor, &h->arena, &h->arena_cached)) return rc;
   char* base = static_cast<char*>(h->arena);
+  h->extra = h->extra_bytes ? base + o_extra : nullptr;
   CC_HIP(hipMemsetAsync(base, 0, zeroed, h->stream));
   if (N > 0) {
     CC_HIP(hipMemcpyAsync(base + o_uv, uv, (size_t)N * 2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
     CC_HIP(hipMemcpyAsync(base + o_xyz, xyz, (size_t)N * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
   }
   CC_HIP(hipMemcpyAsync(base + o_off, off, (size_t)(F + 1) * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
-  CC_HIP(hipStreamSynchronize(h->stream));            // the caller's arrays may go away after create
+  if (!h->one_shot) CC_HIP(hipStreamSynchronize(h->stream));            // the caller's arrays may go away after create
   d.uv = reinterpret_cast<const float*>(base + o_uv);
   d.xyz = reinterpret_cast<const float*>(base + o_xyz);
   d.off = reinterpret_cast<const int64_t*>(base + o_off);
@@ -1420,7 +1437,7 @@ void cc_intrinsics_destroy(cc_intrinsics* h) {
   for (auto e : h->events) hipEventDestroy(e);
   if (h->comm) cc::comm_destroy(h->comm);
   cc::exchange_release(h);
-  if (h->arena) hipFree(h->arena);
+  if (h->arena) cc::arena_put(h->device, h->arena, h->arena_cached);   // (the stream was synchronised above: nothing of this handle is in flight)
   cc::pinned_block_put(h->pinned);
   if (stream_ok) cc::stream_put(h->device, h->stream);   // idle and reusable
   else if (h->stream) hipStreamDestroy(h->stream);      // never hand a failed / capturing stream to the next handle
@@ -1983,15 +2000,24 @@ int cc_intrinsics_optimize(const cc_options* opt, int32_t device, int64_t F, con
                            const float* uv, const float* xyz, double* intr9, uint32_t mask,
                            double* q, double* t, cc_summary* summary) {
   cc_intrinsics* h = nullptr;
-  int rc = cc_intrinsics_create(device, F, off, uv, xyz, &h);
+  double* tm = cc::last_timing();
+  for (int i = 0; i < 5; ++i) tm[i] = 0.0;
+  auto t0 = std::chrono::steady_clock::now();
+  int rc;
+  { cc::OneShotCreate os(0); rc = cc_intrinsics_create(device, F, off, uv, xyz, &h); }
   if (rc) return rc;
-  rc = cc_intrinsics_set_state(h, intr9, mask, q, t);
+  tm[0] = cc::ms_since(t0); t0 = std::chrono::steady_clock::now();
+  if (hipStreamSynchronize(h->stream) != hipSuccess) { (void)hipGetLastError(); rc = cc::fail(CC_ERR_HIP, "upload failed"); }   // (uv / xyz are the caller's)
+  tm[1] = cc::ms_since(t0); t0 = std::chrono::steady_clock::now();
+  if (!rc) rc = cc_intrinsics_set_state(h, intr9, mask, q, t);
   cc_options o;
   if (opt) o = *opt; else cc_options_init(&o);
   o.use_graph = 0;   // one solve per handle: capturing and instantiating a graph cannot pay off
   if (!rc) rc = cc_intrinsics_solve(h, &o, summary);
+  tm[3] = cc::ms_since(t0); t0 = std::chrono::steady_clock::now();
   if (!rc) rc = cc_intrinsics_get_state(h, intr9, q, t);
   cc_intrinsics_destroy(h);
+  tm[4] = cc::ms_since(t0);
   return rc;
 }
 
@@ -2007,29 +2033,45 @@ int cc_intrinsics_estimate(const cc_options* opt, int32_t device, int64_t F, con
     return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_estimate: needs >= 3 frames and non-NULL arrays");
   for (int64_t f = 0; f < F; ++f)
     if (off[f + 1] - off[f] < 4) return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_estimate: frame %lld has fewer than 4 points", (long long)f);
-  cc_intrinsics* h = nullptr;
-  int rc = cc_intrinsics_create(device, F, off, uv, xyz, &h);
-  if (rc) return rc;
-  struct Guard { cc_intrinsics* h; void* scratch; ~Guard() { if (scratch) hipFree(scratch); cc_intrinsics_destroy(h); } } guard{h, nullptr};
-  // scratch of the initialisation: gram double[F][256] | H float[9F] | K float[9] | q float[4F] | t float[3F]
+  // scratch of the initialisation, appended to the handle's arena: gram double[F][256] | H float[9F] | K float[9] | q float[4F] | t float[3F]
   size_t cursor = 0;
   auto take = [&](size_t bytes) { const size_t at = cursor; cursor += (bytes + 255) & ~(size_t)255; return at; };
   const size_t o_gram = take((size_t)F * 256 * sizeof(double)), o_H = take((size_t)F * 9 * sizeof(float)), o_K = take(9 * sizeof(float));
   const size_t o_q = take((size_t)F * 4 * sizeof(float)), o_t = take((size_t)F * 3 * sizeof(float));
-  CC_HIP(hipMalloc(&guard.scratch, cursor));
-  char* sc = static_cast<char*>(guard.scratch);
+  double* tm = last_timing();
+  for (int i = 0; i < 5; ++i) tm[i] = 0.0;
+  auto t0 = std::chrono::steady_clock::now();
+  cc_intrinsics* h = nullptr;
+  int rc;
+  { OneShotCreate os(cursor); rc = cc_intrinsics_create(device, F, off, uv, xyz, &h); }
+  if (rc) return rc;
+  struct Guard { cc_intrinsics* h; ~Guard() { cc_intrinsics_destroy(h); } } guard{h};
+  tm[0] = ms_since(t0); t0 = std::chrono::steady_clock::now();
+  char* sc = h->extra;
   float* dK = reinterpret_cast<float*>(sc + o_K);
   float* dq = reinterpret_cast<float*>(sc + o_q);
   float* dt = reinterpret_cast<float*>(sc + o_t);
+  // (the initialisation's kernels are enqueued behind the upload; the wait below covers both -- the split of the two in
+  // cc_last_call_timing comes from an event between them)
+  hipEvent_t ev_up = nullptr;
+  if (hipEventCreate(&ev_up) == hipSuccess) (void)hipEventRecord(ev_up, h->stream); else { ev_up = nullptr; (void)hipGetLastError(); }
   if ((rc = zhang_on_device(h->stream, F, h->d.off, h->d.uv, h->d.xyz, reinterpret_cast<double*>(sc + o_gram),
-                            reinterpret_cast<float*>(sc + o_H), dK, dq, dt)))
+                            reinterpret_cast<float*>(sc + o_H), dK, dq, dt))) {
+    if (ev_up) hipEventDestroy(ev_up);
     return rc;
+  }
   float K9[9];
   std::vector<float> qf((size_t)F * 4), tf((size_t)F * 3);
   CC_HIP(hipMemcpyAsync(K9, dK, sizeof(K9), hipMemcpyDeviceToHost, h->stream));
   CC_HIP(hipMemcpyAsync(qf.data(), dq, qf.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   CC_HIP(hipMemcpyAsync(tf.data(), dt, tf.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  if (ev_up) {
+    (void)hipEventSynchronize(ev_up);
+    tm[1] = ms_since(t0); t0 = std::chrono::steady_clock::now();
+    hipEventDestroy(ev_up);
+  }
   CC_HIP(hipStreamSynchronize(h->stream));
+  tm[2] = ms_since(t0); t0 = std::chrono::steady_clock::now();
   if (K_init9) std::memcpy(K_init9, K9, sizeof(K9));
   // intrinsics order fx fy px py k1 k2 p1 p2 k3 (calibrator.cpp:168-179); the distortion starts from the caller's
   intr9[0] = K9[0]; intr9[1] = K9[4]; intr9[2] = K9[2]; intr9[3] = K9[5];
@@ -2041,7 +2083,10 @@ int cc_intrinsics_estimate(const cc_options* opt, int32_t device, int64_t F, con
   if (opt) o = *opt; else cc_options_init(&o);
   o.use_graph = 0;   // one solve per handle: capturing and instantiating a graph cannot pay off
   if ((rc = cc_intrinsics_solve(h, &o, summary))) return rc;
-  return cc_intrinsics_get_state(h, intr9, q, t);
+  tm[3] = ms_since(t0); t0 = std::chrono::steady_clock::now();
+  rc = cc_intrinsics_get_state(h, intr9, q, t);
+  tm[4] = ms_since(t0);   // (+ the handle's teardown, a few microseconds with the cached arena, after this function returns)
+  return rc;
 }
 
 int cc_intrinsics_comm_init(cc_intrinsics* h, const uint8_t id[128], int32_t rank, int32_t nranks) {

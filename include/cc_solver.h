@@ -20,6 +20,7 @@
  */
 #ifndef CC_SOLVER_H
 #define CC_SOLVER_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -100,6 +101,14 @@ typedef struct cc_summary {
 
 void cc_options_init(cc_options* o);
 const char* cc_last_error(void);
+/* Pinned host memory, cached between calls, for a caller that packs its inputs itself (the C++ classes do: one memcpy per frame
+ * of the reference's vector<Points2D> / vector<Points3D> arguments, calibrator.cpp:261-292). Optional: every entry point takes
+ * any host pointer. Returns NULL when the allocation fails. */
+void* cc_host_staging_acquire(size_t bytes);
+void cc_host_staging_release(void* p);
+/* Wall milliseconds of the phases of this thread's last cc_intrinsics_estimate / cc_intrinsics_optimize:
+ * [0] handle + device arena, [1] upload, [2] Zhang initialisation (estimate only), [3] solve, [4] read-back + teardown. */
+void cc_last_call_timing(double out_ms[5]);
 const char* cc_version(void);
 /* Number of usable HIP devices (0 if none); never touches the oracle or a CPU path. */
 int cc_device_count(void);
