@@ -1644,13 +1644,12 @@ __global__ __launch_bounds__(256) void k_rig_stats(RigDev P) {
     __shared__ double s_post[4 + 256];
     __shared__ int s_ok;
     __syncthreads();
-    const int n = 4 + P.S;
-    if (tid < n) s_post[tid] = P.vec_stats[tid];
+    const int n = 4 + P.S;   // (up to 259: large rigs)
+    for (int k = tid; k < n; k += 256) s_post[k] = P.vec_stats[k];
     __syncthreads();
     const unsigned long long epoch = P.x.seq[1] + 1ull;
     p2p_post(P.x, 1, epoch, P.rank, P.nranks, s_post, n);
-    const double a = p2p_collect(P.x, 1, epoch, P.rank, P.nranks, n, &s_ok);
-    if (tid < n) P.vec_stats[tid] = a;
+    p2p_collect_to(P.x, 1, epoch, P.rank, P.nranks, n, P.vec_stats, &s_ok);
     if (tid == 0) {
       P.x.seq[1] = epoch;
       if (s_ok == 0) {
@@ -2941,6 +2940,24 @@ __global__ __launch_bounds__(256) void k_rig_solve(RigDev P, int publish) {
   }
 }
 
+// Large rigs on the mailbox exchange: k_rig_reduce<4> posted this rank's column sums into every mailbox; ONE block collects
+// all ranks' posts in rank order into P.vec, which k_rig_solve_big then reads as it does after an all-reduce.
+__global__ __launch_bounds__(256) void k_rig_collect(RigDev P) {
+  __shared__ int s_ok;
+  const LmCtl* cn = P.ctl_next;
+  if (cn->done || cn->phase == 0) return;
+  const unsigned long long epoch = P.x.seq[0] + 1ull;
+  p2p_collect_to(P.x, 0, epoch, P.rank, P.nranks, P.PC + 32, P.vec, &s_ok);
+  if (threadIdx.x == 0) {
+    P.x.seq[0] = epoch;
+    if (s_ok == 0) {
+      LmCtl c = *cn;
+      c.done = 1; c.term = CC_FAILURE_EXCHANGE;
+      *P.ctl = c; *P.ctl_next = c;
+    }
+  }
+}
+
 // first launch of a solve: camera / intrinsics records of the starting point (what the first sweep reads)
 __global__ __launch_bounds__(256) void k_rig_records(RigDev P) {
   const LmCtl* ctl = P.ctl;
@@ -3149,7 +3166,12 @@ __global__ __launch_bounds__(256) void k_rig_elim_big(RigDev P) {
   if (ctl->done || ctl->phase == 0) return;
   // ---- trust-region decision: every block, same answer; block 0 publishes it (as in k_rig_elim)
   const bool pending = ctl->cand_pending != 0;
-  rig_reduce_stats(P, pending && ctl->step_valid, s16, s_tot);
+  if (P.comm) {   // (sharded: k_rig_stats exchanged them)
+    if (tid < 4) s_tot[tid] = P.vec_stats[tid];
+    __syncthreads();
+  } else {
+    rig_reduce_stats(P, pending && ctl->step_valid, s16, s_tot);
+  }
   if (tid == 0) {
     LmCtl c = *ctl;
     const LmOpts o = *P.opts;
@@ -3326,15 +3348,16 @@ __global__ __launch_bounds__(256) void k_rig_elim_big(RigDev P) {
 }
 
 // accessor of the reduced system's lower triangle (rows 0..S, row S = right-hand side; S columns). In LDS: packed by
-// rows -- thread i owns row i, a batch of its entries is one base address plus immediates (packed by columns, free of
-// bank conflicts on paper, measured slower: 302 against 214 us at S = 132). In global memory: COLUMN-major with a stride,
-// so that at a fixed column the 64 lanes of a wave touch consecutive addresses (one 512-byte transaction instead of 64)
-// and the pivot row's entry is one address for the wave.
+// rows -- thread i owns row i, a batch of its entries is one base address plus immediates. In global memory (L2-resident:
+// 0.5 MB at S = 255): ROW-major with the stride the host's destination tables use -- a thread's sixteen panel entries are
+// 128 contiguous bytes, the sixteen columns of a trailing tile's row one transaction (round 3 kept it column-major for its
+// left-looking factorisation, one row per thread).
+constexpr int kRigBigPanelDoubles = 256 * 17 + 64;
 template <bool PACKED>
 struct BigA {
   double* p; int LD;
   __device__ __forceinline__ double& at(int i, int k) const {   // k <= i <= S, k < S
-    return PACKED ? p[i * (i + 1) / 2 + k] : p[(size_t)k * LD + i];
+    return PACKED ? p[i * (i + 1) / 2 + k] : p[(size_t)i * LD + k];
   }
   // host-built destinations are row * LD + col (rig_layout)
   __device__ __forceinline__ double& at_dst(int dst) const { const int i = dst / LD, k = dst - i * LD; return at(i, k); }
@@ -3357,7 +3380,8 @@ __global__ __launch_bounds__(256) void k_rig_solve_big(RigDev P, double* Aglobal
   double* s_hd = s_gs + 256;          // [256] diagonal of the scaled H_ss
   double* s_inv = s_hd + 256;         // [256] 1 / L_jj
   double* s_ss = s_inv + 256;         // [256]
-  BigA<PACKED> A{PACKED ? s_ss + 256 : Aglobal, LD};
+  double* s_pan = s_ss + 256;         // [256][17] the factorisation's panel, then [64] micro-block words
+  BigA<PACKED> A{PACKED ? s_pan + kRigBigPanelDoubles : Aglobal, LD};
   __shared__ int s_cholok, s_stepok, s_go;
   __shared__ double s4[4];
   __shared__ double s8[8];
@@ -3375,28 +3399,51 @@ __global__ __launch_bounds__(256) void k_rig_solve_big(RigDev P, double* Aglobal
   const bool pinned = pin >= 0 && ((P.kmask[pin >> 4] >> (pin & 15)) & 1u) != 0;
   __syncthreads();
   // ---- assembly from the column sums (P.vec): direct sums, then minus the Schur products. An element gets at most one
-  // contribution of each kind; the two loops are separated by a barrier, so plain read-modify-write is safe.
-  for (int e = tid; e < P.ND; e += 256) {
-    const int d = P.dir_dst[e];
-    if (d == -1) continue;
-    double acc = P.vec[P.pc_dir + e];
-    for (int n = P.dir_next[e]; n >= 0; n = P.dir_next[n]) acc += P.vec[P.pc_dir + n];
-    if (d >= 0) {
-      const int sa = P.dir_sa[e], sb = P.dir_sb[e];
-      const double x = s_ss[sa] * acc * s_ss[sb];
-      A.at_dst(d) += x;
-      if (sa == sb) s_hd[sa] = x;
-    } else {
-      s_gs[-2 - d] = acc;
+  // contribution of each kind; the two loops are separated by a barrier, so plain read-modify-write is safe. Loads are
+  // batched eight deep (table entry and value together, then the eight elements): 30720 tile entries at S = 234 were 120
+  // dependent round trips per thread one at a time -- the largest piece of the launch once the factorisation was blocked.
+  for (int e0 = 0; e0 < P.ND; e0 += 8 * 256) {
+    int d[8], sa[8], sb[8];
+    double acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * 256 + tid, ec = e < P.ND ? e : 0;
+      d[u] = P.dir_dst[ec]; sa[u] = P.dir_sa[ec]; sb[u] = P.dir_sb[ec];
+      acc[u] = P.vec[P.pc_dir + ec];
+      if (e >= P.ND) d[u] = -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (d[u] == -1) continue;
+      const int e = e0 + u * 256 + tid;
+      for (int n = P.dir_next[e]; n >= 0; n = P.dir_next[n]) acc[u] += P.vec[P.pc_dir + n];
+      if (d[u] >= 0) {
+        const double x = s_ss[sa[u]] * acc[u] * s_ss[sb[u]];
+        A.at_dst(d[u]) = x;          // (zeroed above, one direct contribution at most: a plain store)
+        if (sa[u] == sb[u]) s_hd[sa[u]] = x;
+      } else {
+        s_gs[-2 - d[u]] = acc[u];
+      }
     }
   }
   __syncthreads();
-  for (int i = tid; i < P.nT * 256; i += 256) {
-    const int d = P.tile_dst[i];
-    if (d == -1) continue;
-    const double v = P.vec[i];
-    if (d >= 0) A.at_dst(d) -= v;
-    else s_b[-2 - d] = -v;
+  for (int i0 = 0; i0 < P.nT * 256; i0 += 8 * 256) {
+    int d[8];
+    double v[8], old[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 256 + tid, ic = i < P.nT * 256 ? i : 0;
+      d[u] = P.tile_dst[ic];
+      v[u] = P.vec[ic];
+      if (i >= P.nT * 256) d[u] = -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) old[u] = A.at_dst(d[u] >= 0 ? d[u] : 0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (d[u] >= 0) A.at_dst(d[u]) = old[u] - v[u];
+      else if (d[u] <= -2) s_b[-2 - d[u]] = -v[u];
+    }
   }
   const double fail = P.vec[P.pc_fail];
   const double gm_r = (tid < P.nranks && tid < 32) ? P.vec[P.PC + tid] : 0.0;
@@ -3441,70 +3488,199 @@ __global__ __launch_bounds__(256) void k_rig_solve_big(RigDev P, double* Aglobal
   }
   __syncthreads();
   if (s_go) {
-    // ---- left-looking Cholesky, thread i owns row i. The right-hand side is ROW S of the matrix (thread S): its forward
-    // substitution y_j = (b_j - sum_m L_jm y_m) / L_jj is the same dot product and the same scaling as every other row
-    // (carried by the pivot thread on its own it was a serial chain of j dependent loads per column: 2/3 of the step).
+    // ---- blocked right-looking Cholesky (round 4), sixteen columns per panel, all 256 threads; the right-hand side is ROW S
+    // of the matrix, so its forward substitution is what every other row undergoes. Per panel:
+    //   thread i = row i holds the panel's sixteen entries of its row in registers; the panel is factored four columns at a
+    //   time: the 4 x 4 diagonal block is published (sixteen LDS words), factored in closed form by every thread, every row
+    //   below solves its four entries against it and takes the rank-4 update of its remaining panel entries with the
+    //   multipliers the block's rows publish -- two barriers per FOUR columns, no dot product over finished columns;
+    //   the panel goes back to the matrix and into an LDS tile [rows][17], and the trailing matrix takes its rank-16 update
+    //   on the matrix pipe: 16 x 16 tiles dealt to the four waves, four at a time (every load of the four -- operands from
+    //   the LDS panel, the elements themselves from LDS / L2 -- is issued before the first product).
+    // Round 3's left-looking form, one row per thread and a dot product over all finished columns per entry, two barriers
+    // per COLUMN: S = 234, 971 us per launch (profiles/r03/rig_big.jsonl).
     const int i = tid;
     if (tid < S) A.at(S, tid) = s_b[tid];
     __syncthreads();
-    for (int j = 0; j < S; ++j) {
-      double a = 0.0;
-      if (i >= j && i <= S) {
-        // dot product of rows i and j over the finished columns, sixteen columns per round trip: all loads of a batch
-        // are issued before its first FMA (written naively the loop waits for every single load)
-        a = A.at(i, j);
-        int m = 0;
-        for (; m + 16 <= j; m += 16) {
-          double x[16], y[16];
+    double* Pn = s_pan;        // [256][17] the panel, rows by matrix row
+    double* s_d = s_pan + 256 * 17;   // [16] diagonal block of a micro-block, [16 + 12 * 4] multipliers of the panel's later rows
+    bool ok = true;
+    for (int j0 = 0; j0 < S; j0 += 16) {
+      const int nc = S - j0 < 16 ? S - j0 : 16;
+      const bool row_in = i >= j0 && i <= S;
+      double pv[16];
 #pragma unroll
-          for (int u = 0; u < 16; ++u) { x[u] = A.at(i, m + u); y[u] = A.at(j, m + u); }
+      for (int c = 0; c < 16; ++c) {
+        const int col = j0 + (c < nc ? c : 0);
+        const double x = A.at(row_in ? i : S, col <= (row_in ? i : S) ? col : 0);
+        pv[c] = (row_in && c < nc && (j0 + c <= i || i == S)) ? x : 0.0;
+      }
 #pragma unroll
-          for (int u = 0; u < 16; ++u) a -= x[u] * y[u];
-        }
-        {   // tail: loads from clamped columns, selected away
-          double x[16], y[16];
+      for (int mb = 0; mb < 4; ++mb) {
+        const int c0 = 4 * mb;
+        if (c0 < nc) {   // (uniform)
+          const int nb = nc - c0 < 4 ? nc - c0 : 4;
+          const int rb = i - (j0 + c0);   // row inside the micro-block: 0 .. nb - 1
+          if (rb >= 0 && rb < nb) {
 #pragma unroll
-          for (int u = 0; u < 16; ++u) { const int c = m + u < j ? m + u : j; x[u] = A.at(i, c); y[u] = A.at(j, c); }
+            for (int c = 0; c < 4; ++c) s_d[rb * 4 + c] = pv[c0 + c];
+          }
+          __syncthreads();
+          double a00 = s_d[0], a10 = s_d[4], a11 = s_d[5], a20 = s_d[8], a21 = s_d[9], a22 = s_d[10], a30 = s_d[12], a31 = s_d[13], a32 = s_d[14], a33 = s_d[15];
+          if (nb < 2) { a10 = 0.0; a11 = 1.0; }
+          if (nb < 3) { a20 = 0.0; a21 = 0.0; a22 = 1.0; }
+          if (nb < 4) { a30 = 0.0; a31 = 0.0; a32 = 0.0; a33 = 1.0; }
+          const double i0 = rsqrt_pos(a00);
+          ok = ok && (a00 > 0.0) && isfinite(a00);
+          const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+          const double d1 = fma(-l10, l10, a11);
+          const double i1 = rsqrt_pos(d1);
+          ok = ok && (d1 > 0.0) && isfinite(d1);
+          const double l21 = fma(-l20, l10, a21) * i1, l31 = fma(-l30, l10, a31) * i1;
+          const double d2 = fma(-l21, l21, fma(-l20, l20, a22));
+          const double i2 = rsqrt_pos(d2);
+          ok = ok && (d2 > 0.0) && isfinite(d2);
+          const double l32 = fma(-l31, l21, fma(-l30, l20, a32)) * i2;
+          const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, a33)));
+          const double i3 = rsqrt_pos(d3);
+          ok = ok && (d3 > 0.0) && isfinite(d3);
+          if (i == 0) { s_inv[j0 + c0] = i0; if (nb > 1) s_inv[j0 + c0 + 1] = i1; if (nb > 2) s_inv[j0 + c0 + 2] = i2; if (nb > 3) s_inv[j0 + c0 + 3] = i3; }
+          // the row's four entries against the block (rows inside the block get their own row of L: the same recurrence
+          // stopped at the diagonal)
+          {
+            const double x0 = pv[c0], x1 = nb > 1 ? pv[c0 + 1] : 0.0, x2 = nb > 2 ? pv[c0 + 2] : 0.0, x3 = nb > 3 ? pv[c0 + 3] : 0.0;
+            const double y0 = x0 * i0;
+            const double y1 = fma(-y0, l10, x1) * i1;
+            const double y2 = fma(-y1, l21, fma(-y0, l20, x2)) * i2;
+            const double y3 = fma(-y2, l32, fma(-y1, l31, fma(-y0, l30, x3))) * i3;
+            const bool below = rb >= nb || (i == S);   // (row S: the right-hand side, below everything)
+            // inside the block: row rb of L = entries up to the diagonal (y_c for c < rb is L[rb][c]; the diagonal is d * inv)
+            pv[c0] = below ? y0 : (rb == 0 ? a00 * i0 : (rb > 0 ? y0 : pv[c0]));
+            if (nb > 1) pv[c0 + 1] = below ? y1 : (rb == 1 ? d1 * i1 : (rb > 1 ? y1 : pv[c0 + 1]));
+            if (nb > 2) pv[c0 + 2] = below ? y2 : (rb == 2 ? d2 * i2 : (rb > 2 ? y2 : pv[c0 + 2]));
+            if (nb > 3) pv[c0 + 3] = below ? y3 : (rb == 3 ? d3 * i3 : pv[c0 + 3]);
+          }
+          // multipliers of the panel's later columns: rows j0 + c2 (c2 >= c0 + 4) publish their four new entries
+          const int rl = i - j0;   // row inside the panel
+          if (rl >= c0 + 4 && rl < 16 && rl < nc) {
 #pragma unroll
-          for (int u = 0; u < 16; ++u) a -= m + u < j ? x[u] * y[u] : 0.0;
+            for (int c = 0; c < 4; ++c) s_d[16 + (rl - 4) * 4 + c] = pv[c0 + c];
+          }
+          __syncthreads();
+#pragma unroll
+          for (int c2 = c0 + 4; c2 < 16; ++c2) {
+            if (c2 < nc) {   // (uniform)
+              double acc = pv[c2];
+#pragma unroll
+              for (int c = 0; c < 4; ++c) acc = fma(-(c < nb ? pv[c0 + c] : 0.0), s_d[16 + (c2 - 4) * 4 + c], acc);
+              pv[c2] = (row_in && (j0 + c2 <= i || i == S)) ? acc : 0.0;
+            }
+          }
         }
       }
-      if (i == j) {
-        const bool ok = (a > 0.0) && isfinite(a);
-        if (!ok) s_cholok = 0;
-        const double r = rsqrt(a);
-        s_r = r;
-        s_inv[j] = r;
-        A.at(j, j) = a * r;
+      // the panel: back to the matrix, and into its LDS tile for the trailing update
+      if (row_in) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+          if (c < nc && (j0 + c <= i || i == S)) A.at(i, j0 + c) = pv[c];
       }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) Pn[i * 17 + c] = (row_in && c < nc && i >= j0 + nc) ? pv[c] : 0.0;   // (rows below the panel: the update's operands)
       __syncthreads();
-      if (i > j && i <= S) A.at(i, j) = a * s_r;
+      // ---- trailing update: rows t0..S (right-hand side included), columns t0..S-1, 16 x 16 tiles at multiples of 16
+      const int t0 = j0 + nc;
+      if (t0 < S) {
+        const int wv = tid >> 6, ln = tid & 63, kq = ln >> 4, c16 = ln & 15;
+        const int tlo = t0 >> 4, n16 = (S + 1 + 15) >> 4;
+        // tiles (ti, tj), tlo <= tj <= ti < n16, numbered row by row; wave w takes numbers w, w + 4, ...: four per round
+        const int nrow = n16 - tlo, ntile = nrow * (nrow + 1) / 2;
+        for (int tb = wv; tb < ntile; tb += 16) {
+          double am[4][4], bm[4][4], old[4][4];
+          int at_i[4][4], at_k[4][4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int t = tb + 4 * u;
+            const bool live = t < ntile;
+            const int tc = live ? t : 0;
+            int tr = (int)((sqrtf(8.0f * (float)tc + 1.0f) - 1.0f) * 0.5f);
+            tr = tr * (tr + 1) / 2 > tc ? tr - 1 : tr;
+            tr = (tr + 1) * (tr + 2) / 2 <= tc ? tr + 1 : tr;
+            const int tq = tc - tr * (tr + 1) / 2;
+            const int R = 16 * (tlo + tr), Cc = 16 * (tlo + tq);
+            const int ra = R + c16 <= S ? R + c16 : S, rb2 = Cc + c16 < S ? Cc + c16 : S - 1;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+              const double xa = Pn[ra * 17 + 4 * ks + kq], xb = Pn[rb2 * 17 + 4 * ks + kq];
+              am[u][ks] = (live && R + c16 <= S) ? xa : 0.0;
+              bm[u][ks] = (live && Cc + c16 < S) ? xb : 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = R + kq + 4 * r, col = Cc + c16;
+              const bool v = live && row >= t0 && row <= S && col >= t0 && col < S && (col <= row);
+              at_i[u][r] = v ? row : -1;
+              at_k[u][r] = v ? col : 0;
+              old[u][r] = A.at(v ? row : S, v ? col : 0);
+            }
+          }
+          d4 T[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) T[u] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) T[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[u][ks], bm[u][ks], T[u], 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (at_i[u][r] >= 0) A.at(at_i[u][r], at_k[u][r]) = old[u][r] - T[u][r];
+        }
+      }
       __syncthreads();
     }
+    if (!ok && tid == 0) s_cholok = 0;
     if (tid < S) s_b[tid] = A.at(S, tid);
     __syncthreads();
-    // ---- backward substitution L^T x = y, column-oriented: x_k is published, every row above subtracts its share
-    // (thread i touches only its own entry between the barriers, so one barrier per step is enough; the multipliers of
-    // eight steps are fetched in one round trip, from clamped addresses, ahead of the steps that use them)
+    // ---- backward substitution L^T x = y in blocks of sixteen unknowns, from the last: wave 0 solves the block's triangle
+    // (lane j holds y_j and column j of the block; sixteen steps of lane read + FMA, no barrier), publishes x, and every
+    // row above the block subtracts its sixteen products at once -- two barriers per SIXTEEN unknowns (round 3: one per
+    // unknown, each behind a dependent load)
     {
-      const int ic = i < S ? i : S - 1;
-      for (int k0 = S - 1; k0 >= 0; k0 -= 8) {
-        double l[8];
+      double* s_x = s_pan;   // [16] the block's solution
+      for (int kb = ((S - 1) >> 4) << 4; kb >= 0; kb -= 16) {
+        const int nbk = S - kb < 16 ? S - kb : 16;
+        if (tid < 64) {
+          const int j = lane < nbk ? lane : 0;
+          double bj = s_b[kb + j];
+          double lcol[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int kk = k0 - u > 0 ? k0 - u : 0;
-          l[u] = A.at(kk > ic ? kk : ic, ic);
-        }
+          for (int k = 0; k < 16; ++k) {
+            const int kr = kb + (k < nbk ? k : 0);
+            const double x = A.at(kr > kb + j ? kr : kb + j, kb + j);   // L[kb + k][kb + j] for k > j
+            lcol[k] = (k < nbk && k > j) ? x : 0.0;
+          }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int kk = k0 - u;
-          if (kk < 0) break;   // (uniform)
-          if (i == kk) s_b[kk] = s_b[kk] * s_inv[kk];
-          __syncthreads();
-          if (i < kk) s_b[i] -= l[u] * s_b[kk];
+          for (int k = 15; k >= 0; --k) {
+            if (k < nbk) {   // (uniform)
+              const double xk = readlane_d(bj, k) * s_inv[kb + k];
+              bj = lane == k ? xk : fma(-lcol[k], xk, bj);
+            }
+          }
+          if (lane < nbk) { s_b[kb + lane] = bj; s_x[lane] = bj; }
         }
+        __syncthreads();
+        if (i < kb) {
+          double acc = s_b[i];
+          double l[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) l[k] = A.at(kb + (k < nbk ? k : 0), i);
+#pragma unroll
+          for (int k = 0; k < 16; ++k) acc = fma(-(k < nbk ? l[k] : 0.0), s_x[k], acc);
+          s_b[i] = acc;
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
     if (tid < 64) {
       bool fin = true;
@@ -4602,7 +4778,7 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
   // beyond what the tuned kernels are built around (S <= 127 shared coordinates, 1536 direct sums): the plain ones
   // (k_rig_elim_big, k_rig_solve_big), single GPU only
   h->big = S > kRigMaxS || CO * DE > 64 * kRigDirectPerLane;
-  if (const char* e = getenv("CC_RIG_FORCE_BIG")) h->big = h->big || (atoi(e) != 0 && !h->comm && !h->exchange);   // (test knob: the plain kernels on any problem)
+  if (const char* e = getenv("CC_RIG_FORCE_BIG")) h->big = h->big || atoi(e) != 0;   // (test knob: the plain kernels on any problem, sharded or not)
   // the frame form of the sweep feeds the tuned elimination only (the plain large-rig kernels read the 16 x 16 tiles)
   d.fmode = (!kmode && h->sweep_adjoint && h->frame_allowed && S <= kRigMaxS && CO * DE <= 64 * kRigDirectPerLane &&
              !(getenv("CC_RIG_FORCE_BIG") && atoi(getenv("CC_RIG_FORCE_BIG")) != 0)) ? 1 : 0;
@@ -4713,11 +4889,12 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
   h->solve_lds = ((size_t)S * ((S + 1) | 1) + 5 * 128) * sizeof(double);
   if (h->big) {
     h->elim_lds = ((size_t)6 * 256 + d.ND) * sizeof(double);
-    const size_t packed = ((size_t)5 * 256 + (size_t)(S + 1) * (S + 2) / 2) * sizeof(double);   // (rows 0..S: the right-hand side is row S)
+    const size_t fixed_lds = ((size_t)5 * 256 + kRigBigPanelDoubles) * sizeof(double);
+    const size_t packed = fixed_lds + (size_t)(S + 1) * (S + 2) / 2 * sizeof(double);   // (rows 0..S: the right-hand side is row S)
     h->big_packed = packed + 2048 <= 160 * 1024;
-    h->solve_lds = h->big_packed ? packed : (size_t)5 * 256 * sizeof(double);
+    h->solve_lds = h->big_packed ? packed : fixed_lds;
     if (!h->big_packed)
-      if (int rc = dev_zeroed(h, &h->bigA, (size_t)S * ((S + 1) | 1))) return rc;
+      if (int rc = dev_zeroed(h, &h->bigA, (size_t)(S + 2) * ((S + 1) | 1))) return rc;
     CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim_big<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
     CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim_big<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
     CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_solve_big<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
@@ -4811,7 +4988,7 @@ static void rig_exchange_bounds(const cc_rig* h, int* doubles_kind0, int* double
   for (int64_t c = 0; c < h->C; ++c) if (!h->frozen[(size_t)c]) S += 6;
   if (h->kmode == RIG_K_SHARED) S += kRigK;
   if (h->kmode == RIG_K_PER_CAMERA) S += kRigK * (int)h->C;
-  S = std::min(S, kRigMaxS);
+  S = std::min(S, kRigBigMaxS);
   CO = std::min(CO, 64);
   const int T = (S + 1 + 15) / 16;
   *doubles_kind0 = T * (T + 1) / 2 * 256 + CO * (h->kmode ? kDEK : kDE0) + 2 + 32;
@@ -4910,7 +5087,13 @@ static int rig_enqueue_round(cc_rig* h, bool initial, bool profile, bool publish
     { RigProbe p(h, CC_K_ELIM, profile);
       if (d.kmode) hipLaunchKernelGGL(k_rig_elim_big<true>, dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d);
       else hipLaunchKernelGGL(k_rig_elim_big<false>, dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d); }
-    { RigProbe p(h, CC_K_REDUCE, profile); hipLaunchKernelGGL(k_rig_reduce<2>, dim3((unsigned)std::max(1, h->reduce_blocks)), dim3(256), 0, h->stream, d, 0); }
+    if (h->exchange) {   // sharded over the mailboxes: posts, then one collecting block (nothing waits inside a launch of many blocks)
+      { RigProbe p(h, CC_K_REDUCE, profile); hipLaunchKernelGGL(k_rig_reduce<4>, dim3((unsigned)std::max(1, h->reduce_blocks)), dim3(256), 0, h->stream, d, 0); }
+      { RigProbe p(h, CC_K_ALLREDUCE, profile); hipLaunchKernelGGL(k_rig_collect, dim3(1), dim3(256), 0, h->stream, d); }
+    } else {
+      { RigProbe p(h, CC_K_REDUCE, profile); hipLaunchKernelGGL(k_rig_reduce<2>, dim3((unsigned)std::max(1, h->reduce_blocks)), dim3(256), 0, h->stream, d, 0); }
+      if (h->comm) { RigProbe p(h, CC_K_ALLREDUCE, profile); if (int rc = comm_allreduce_sum(h->comm, d.vec, d.PC + 32, h->stream)) return rc; }
+    }
     { RigProbe p(h, CC_K_SOLVE, profile);
       if (h->big_packed) hipLaunchKernelGGL(k_rig_solve_big<true>, dim3(1), dim3(256), h->solve_lds, h->stream, d, h->bigA);
       else hipLaunchKernelGGL(k_rig_solve_big<false>, dim3(1), dim3(256), h->solve_lds, h->stream, d, h->bigA); }
@@ -5666,7 +5849,6 @@ int cc_rig_comm_init(cc_rig* h, const uint8_t id[128], int32_t rank, int32_t nra
   using namespace cc;
   if (!h || !id || rank < 0 || nranks < 1 || rank >= nranks || nranks > 32)
     return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_comm_init: bad arguments (nranks must be 1..32)");
-  if (h->big) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_comm_init: %d shared coordinates, %d observed cameras: problems beyond %d coordinates or %d direct sums run on one GPU only", h->d.S, h->d.CO, kRigMaxS, 64 * kRigDirectPerLane);
   CC_HIP(hipSetDevice(h->device));
   if (h->comm) { comm_destroy(h->comm); h->comm = nullptr; }
   rig_drop_graphs(h);
@@ -5709,7 +5891,6 @@ int cc_rig_exchange_attach(cc_rig* h, int32_t rank, int32_t nranks, const uint8_
   if (!h->mailbox.local) return fail(CC_ERR_STATE, "cc_rig_exchange_attach: call cc_rig_exchange_export first");
   if (h->comm) return fail(CC_ERR_STATE, "cc_rig_exchange_attach: an RCCL communicator is already attached");
   if (h->C > 128) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_exchange_attach: at most 128 cameras with the mailbox exchange");
-  if (h->big) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_exchange_attach: %d shared coordinates, %d observed cameras: problems beyond %d coordinates or %d direct sums run on one GPU only", h->d.S, h->d.CO, kRigMaxS, 64 * kRigDirectPerLane);
   CC_HIP(hipSetDevice(h->device));
   rig_drop_graphs(h);
   if (int rc = mailbox_attach(&h->mailbox, rank, nranks, handles, &h->d.x)) return rc;

@@ -227,7 +227,9 @@ int cc_partition_frames(int64_t n_frames, const int64_t* frame_offsets, int32_t 
  * cameras / frames without observations are left untouched (they never enter the problem).
  * Any number of cameras: only cameras that are observed and not frozen own columns of the reduced system
  * (6 each, at most 255 in all, i.e. 42 optimised cameras; at most 64 observed cameras). Up to 127 coordinates the
- * tuned kernels run; beyond, plain ones on a single GPU (cc_rig_comm_init / cc_rig_exchange_attach then refuse).
+ * tuned kernels run; beyond, plainer ones with a blocked factorisation of the reduced system (sixteen-column panels, trailing
+ * updates on the matrix pipe); both take either exchange (since round 4 the large ones too: column sums posted / all-reduced,
+ * one solving block).
  * ------------------------------------------------------------------------------------------- */
 typedef struct cc_rig cc_rig;
 
@@ -276,7 +278,7 @@ int cc_rig_exchange_attach(cc_rig* h, int32_t rank, int32_t nranks, const uint8_
  * ReprojectionErrorExtrinsics (extrinsics_calibrator.cpp:51-84) and DistortNormalized/DistortPixels
  * (calibrator.cpp:70-95). huber_a is in pixels, <= 0 switches the loss off. 6 columns per optimised camera + 9
  * must stay <= 255. Multi-GPU through cc_rig_exchange_* / cc_rig_comm_init like the plain rig problem (intrinsics
- * replicated) while the columns stay <= 127 and at most 11 cameras are observed; larger problems run on one GPU.
+ * replicated), at every supported size.
  * The handle is a cc_rig: set_state / reset / solve / get_state / eval / destroy are the cc_rig_* calls;
  * cc_rigk_set_intrinsics must be called once before the first solve (const_mask bit i freezes intrinsic i). */
 int cc_rigk_create(int32_t device, int64_t n_cams, int64_t n_frames, int64_t n_world,

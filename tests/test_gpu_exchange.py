@@ -113,8 +113,10 @@ def test_single_rank_exchange_equals_plain_solve():
     assert np.allclose(intr, ref[0], rtol=1e-12, atol=1e-14)
 
 
-@pytest.mark.parametrize("world,cams,frames,pts", [(2, 3, 30, 12), (3, 4, 45, 30), (2, 8, 40, 20)])
+@pytest.mark.parametrize("world,cams,frames,pts", [(2, 3, 30, 12), (3, 4, 45, 30), (2, 8, 40, 20), (2, 23, 24, 8)])
 def test_sharded_rig_solve_over_the_mailbox_exchange(world, cams, frames, pts, tmp_path):
+    # (the last shape: 22 optimised cameras, 132 shared coordinates -- the plain large-rig kernels, which take an exchange
+    # since round 4: column sums posted by k_rig_reduce<4>, collected by one block, k_rig_solve_big on the sums)
     from oracle import pyoracle as po
     ranks = _run_ranks(world, frames, pts, tmp_path, extra=(f"rig:{cams}",))
     sc = po.rig_scenario(cams, frames, pts)
