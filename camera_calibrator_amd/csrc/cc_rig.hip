@@ -3219,6 +3219,18 @@ __global__ __launch_bounds__(256) void k_rig_elim_big(RigDev P) {
   // (failure count and gradient maximum of the block live in LDS, s_fg[0] / s_fg[1]: thread 0 alone touches them)
   if (tid == 0) { s_fg[0] = 0.0; s_fg[1] = 0.0; }
   const int tr = tid >> 4, tc = tid & 15;
+#ifdef CC_EXP_ELIMBIG_TABLES
+  // FORENSICS ONLY (round 4): round 3's first version of this kernel, reconstructed from its description in DESIGN.md --
+  // the (a, b) of every tile pair read from the host tables ONCE into scalar registers (136 of them live across the frame
+  // loop) and the block's failure count / gradient maximum carried in registers. See DESIGN.md (rig item 7) for what its ISA shows.
+  int t_ab[kRigBigTiles];
+#pragma unroll
+  for (int t = 0; t < kRigBigTiles; ++t) {
+    const int tc2 = t < P.nT ? t : 0;
+    t_ab[t] = __builtin_amdgcn_readfirstlane((int)P.tile_i[tc2] | ((int)P.tile_j[tc2] << 8));
+  }
+  double nfail_r = 0.0, gmax_r = 0.0;
+#endif
   for (int64_t f = blockIdx.x; f < P.F; f += gridDim.x) {
     if (tid < 64) s_g[tid] = tid < CO ? P.fslot[f * CO + tid] : -1;
     __syncthreads();
@@ -3262,12 +3274,21 @@ __global__ __launch_bounds__(256) void k_rig_elim_big(RigDev P) {
           L[tri(i, j)] = a * inv;
         }
       }
+#ifdef CC_EXP_ELIMBIG_TABLES
+      {
+        if (!ok) nfail_r += 1.0;
+        const double* fqp = P.pose + ((size_t)cur * P.F + f) * 8;
+        const double q4[4] = {fqp[0], fqp[1], fqp[2], fqp[3]};
+        gmax_r = fmax(gmax_r, pose_grad_proj_max(q4, &A[21]));
+      }
+#else
       if (tid == 0) {
         if (!ok) s_fg[0] += 1.0;
         const double* fqp = P.pose + ((size_t)cur * P.F + f) * 8;
         const double q4[4] = {fqp[0], fqp[1], fqp[2], fqp[3]};
         s_fg[1] = fmax(s_fg[1], pose_grad_proj_max(q4, &A[21]));   // Ceres' gradient_max_norm (cc_common.hpp)
       }
+#endif
       if (tid < SW) {
         double w[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         if (c_kind == 0 || c_kind == 1) {
@@ -3316,6 +3337,18 @@ __global__ __launch_bounds__(256) void k_rig_elim_big(RigDev P) {
       // Schur products of this frame: entry (tr, tc) of every upper tile pair (a, b), a <= b < T. The loops run over the
       // largest tile grid with compile-time accumulator indices (no tables: 136 pairs of table entries in scalar registers
       // spilled hundreds of them); which pairs exist is a uniform test.
+#ifdef CC_EXP_ELIMBIG_TABLES
+#pragma unroll
+      for (int t = 0; t < kRigBigTiles; ++t) {
+        if (t < P.nT) {
+          const int a = t_ab[t] & 255, b = t_ab[t] >> 8;
+          double x = acc[t];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) x = fma(s_Z[i * 256 + 16 * a + tr], s_Z[i * 256 + 16 * b + tc], x);
+          acc[t] = x;
+        }
+      }
+#else
 #pragma unroll
       for (int a = 0; a < 16; ++a) {
         if (a < T) {
@@ -3333,11 +3366,19 @@ __global__ __launch_bounds__(256) void k_rig_elim_big(RigDev P) {
           }
         }
       }
+#endif
     }
     __syncthreads();
   }
   double* prow = P.partial + (size_t)blockIdx.x * P.PC;
   // (the partial row numbers the pairs of the T x T grid in the same order: a, then b)
+#ifdef CC_EXP_ELIMBIG_TABLES
+#pragma unroll
+  for (int t = 0; t < kRigBigTiles; ++t)
+    if (t < P.nT) prow[(size_t)t * 256 + tid] = acc[t];
+  for (int e = tid; e < P.ND; e += 256) prow[P.pc_dir + e] = s_d[e];
+  if (tid == 0) { prow[P.pc_fail] = nfail_r; prow[P.pc_gmax] = gmax_r; }
+#else
 #pragma unroll
   for (int a = 0; a < 16; ++a)
 #pragma unroll
@@ -3345,6 +3386,7 @@ __global__ __launch_bounds__(256) void k_rig_elim_big(RigDev P) {
       if (b < T) prow[(size_t)(a * T - a * (a - 1) / 2 + (b - a)) * 256 + tid] = acc[big_tile(a, b)];
   for (int e = tid; e < P.ND; e += 256) prow[P.pc_dir + e] = s_d[e];
   if (tid == 0) { prow[P.pc_fail] = s_fg[0]; prow[P.pc_gmax] = s_fg[1]; }
+#endif
 }
 
 // accessor of the reduced system's lower triangle (rows 0..S, row S = right-hand side; S columns). In LDS: packed by

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch  # noqa: F401
 from camera_calibrator_amd import capi
-for S in (30, 42, 63):
+for S in (18, 30, 42, 51, 63):
     for which in (0, 1, 2):
         if which == 1 and S > 64:
             continue
