@@ -78,7 +78,7 @@ EXPORTED_SYMBOLS = [
     "cc_options_init", "cc_last_error", "cc_version", "cc_device_count",
     "cc_intrinsics_create", "cc_intrinsics_destroy", "cc_intrinsics_set_state",
     "cc_intrinsics_reset", "cc_intrinsics_get_state", "cc_intrinsics_eval",
-    "cc_intrinsics_solve", "cc_intrinsics_solver_form", "cc_intrinsics_solver_status", "cc_intrinsics_profile_sweep", "cc_intrinsics_profile_solve", "cc_intrinsics_optimize", "cc_intrinsics_estimate", "cc_comm_get_unique_id",
+    "cc_intrinsics_solve", "cc_intrinsics_solver_form", "cc_intrinsics_solver_status", "cc_intrinsics_profile_sweep", "cc_intrinsics_profile_solve", "cc_intrinsics_optimize", "cc_intrinsics_estimate", "cc_intrinsics_estimate_views", "cc_intrinsics_optimize_views", "cc_host_staging_acquire", "cc_host_staging_release", "cc_last_call_timing", "cc_comm_get_unique_id",
     "cc_intrinsics_comm_init", "cc_intrinsics_exchange_export", "cc_intrinsics_exchange_attach", "cc_partition_frames", "cc_distort", "cc_undistort",
     "cc_rig_create", "cc_rig_destroy", "cc_rig_set_state", "cc_rig_reset", "cc_rig_solve",
     "cc_rig_get_state", "cc_rig_solver_form", "cc_rig_solver_status", "cc_rig_eval", "cc_rig_optimize", "cc_rig_comm_init", "cc_rig_exchange_export", "cc_rig_exchange_attach", "cc_rigk_create",
@@ -277,10 +277,23 @@ def comm_get_unique_id():
     return bytes(buf)
 
 
+def _views(off, uv, xyz):
+    """(uv_views, xyz_views, counts, keep-alive) for the *_views entry points: one pointer per view, each view its own
+    array (as a vector<Points2D> holds them), not slices of one block."""
+    F = len(off) - 1
+    parts_uv = [np.array(uv.reshape(-1, 2)[off[f]:off[f + 1]], dtype=np.float32, order="C") for f in range(F)]
+    parts_xyz = [np.array(xyz.reshape(-1, 3)[off[f]:off[f + 1]], dtype=np.float32, order="C") for f in range(F)]
+    fp = C.POINTER(C.c_float)
+    uv_views = (fp * F)(*[a.ctypes.data_as(fp) for a in parts_uv])
+    xyz_views = (fp * F)(*[a.ctypes.data_as(fp) for a in parts_xyz])
+    counts = np.ascontiguousarray(np.diff(off), dtype=np.int64)
+    return uv_views, xyz_views, counts, (parts_uv, parts_xyz)
+
+
 def intrinsics_optimize(frame_offsets, uv, xyz, intr, q, t, const_mask=0, options=None, device=0,
-                        log_capacity=1024, devices=None):
+                        log_capacity=1024, devices=None, views=False):
     """One-shot cc_intrinsics_optimize (devices=[...]: cc_intrinsics_optimize_multi, one host thread driving several
-    devices). Returns (intr, q, t, summary)."""
+    devices; views=True: cc_intrinsics_optimize_views, every view handed over as its own array). Returns (intr, q, t, summary)."""
     off = np.ascontiguousarray(frame_offsets, dtype=np.int64)
     F = len(off) - 1
     uv, xyz = _f32(uv), _f32(xyz)
@@ -297,6 +310,12 @@ def intrinsics_optimize(frame_offsets, uv, xyz, intr, q, t, const_mask=0, option
                                                   _p(intr, C.c_double), C.c_uint32(const_mask),
                                                   _p(q, C.c_double), _p(t, C.c_double), C.byref(s)))
         return intr, q, t, _summary_dict(s, log)
+    if views:
+        uv_views, xyz_views, counts, _keep = _views(off, uv, xyz)
+        _check(lib().cc_intrinsics_optimize_views(C.byref(opt), C.c_int32(device), C.c_int64(F), uv_views, xyz_views,
+                                                  _p(counts, C.c_int64), _p(intr, C.c_double), C.c_uint32(const_mask),
+                                                  _p(q, C.c_double), _p(t, C.c_double), C.byref(s)))
+        return intr, q, t, _summary_dict(s, log)
     _check(lib().cc_intrinsics_optimize(C.byref(opt), C.c_int32(device), C.c_int64(F),
                                         _p(off, C.c_int64), _p(uv, C.c_float), _p(xyz, C.c_float),
                                         _p(intr, C.c_double), C.c_uint32(const_mask),
@@ -304,8 +323,10 @@ def intrinsics_optimize(frame_offsets, uv, xyz, intr, q, t, const_mask=0, option
     return intr, q, t, _summary_dict(s, log)
 
 
-def intrinsics_estimate(frame_offsets, uv, xyz, distortion5=None, const_mask=0, options=None, device=0, log_capacity=1024):
-    """cc_intrinsics_estimate (= Calibrator::Estimate: Zhang initialisation + solve, one upload).
+def intrinsics_estimate(frame_offsets, uv, xyz, distortion5=None, const_mask=0, options=None, device=0, log_capacity=1024,
+                        views=False):
+    """cc_intrinsics_estimate (= Calibrator::Estimate: Zhang initialisation + solve, one upload; views=True:
+    cc_intrinsics_estimate_views, every view handed over as its own array and packed by the library under its upload).
     Returns (K_init float32 3x3, intr, q, t, summary)."""
     off = np.ascontiguousarray(frame_offsets, dtype=np.int64)
     F = len(off) - 1
@@ -318,6 +339,13 @@ def intrinsics_estimate(frame_offsets, uv, xyz, distortion5=None, const_mask=0, 
     K = np.zeros(9, dtype=np.float32)
     intr, q, t = np.zeros(9), np.zeros((F, 4)), np.zeros((F, 3))
     d5 = _f64(distortion5) if distortion5 is not None else None
+    if views:
+        uv_views, xyz_views, counts, _keep = _views(off, uv, xyz)
+        _check(lib().cc_intrinsics_estimate_views(C.byref(opt), C.c_int32(device), C.c_int64(F), uv_views, xyz_views,
+                                                  _p(counts, C.c_int64), _p(d5, C.c_double) if d5 is not None else None,
+                                                  C.c_uint32(const_mask), _p(K, C.c_float), _p(intr, C.c_double),
+                                                  _p(q, C.c_double), _p(t, C.c_double), C.byref(s)))
+        return K.reshape(3, 3), intr, q, t, _summary_dict(s, log)
     _check(lib().cc_intrinsics_estimate(C.byref(opt), C.c_int32(device), C.c_int64(F), _p(off, C.c_int64), _p(uv, C.c_float),
                                         _p(xyz, C.c_float), _p(d5, C.c_double) if d5 is not None else None,
                                         C.c_uint32(const_mask), _p(K, C.c_float), _p(intr, C.c_double), _p(q, C.c_double),

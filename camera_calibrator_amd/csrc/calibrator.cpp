@@ -73,26 +73,31 @@ void Calibrator::Estimate(const std::vector<Points2D>& pixels_per_view, const st
   const size_t n_img = pixels_per_view.size();
   // Zhang initialisation on the device (cc_zhang_init): homographies -> K -> poses
   const auto t_call = std::chrono::steady_clock::now();
-  PackedViews pv(pixels_per_view, board_points_per_view);
-  const int64_t* offsets_p = pv.offsets;
-  const float *uv_p = pv.uv, *xyz_p = pv.xyz;
   for (double& v : last_timing_ms_) v = 0.0;
-  last_timing_ms_[0] = pv.pack_ms;
   float K9[9];
   if (devices_.size() <= 1) {
     // one device: the fused entry point (one upload of the observations for initialisation and solve together);
-    // same numbers as the two calls below exchange through camera_matrix_ and the float poses
+    // same numbers as the two calls below exchange through camera_matrix_ and the float poses. The views go over as they
+    // are (one pointer per view): the library packs them into pinned memory piece by piece under the upload.
     double intr[kNumIntrinsics], dist5[5];
     for (int i = 0; i < 5; ++i) dist5[i] = distortion_(i);
     uint32_t frozen = 0;
     for (int idx : frozen_intrinsics_)
       if (idx >= 0 && idx < kNumIntrinsics) frozen |= 1u << idx;
     std::vector<double> qd(4 * n_img), td(3 * n_img);
+    std::vector<const float*> uv_views(n_img), xyz_views(n_img);
+    std::vector<int64_t> counts(n_img);
+    for (size_t i = 0; i < n_img; ++i) {
+      assert(pixels_per_view[i].size() == board_points_per_view[i].size());
+      uv_views[i] = reinterpret_cast<const float*>(pixels_per_view[i].data());
+      xyz_views[i] = reinterpret_cast<const float*>(board_points_per_view[i].data());
+      counts[i] = (int64_t)pixels_per_view[i].size();
+    }
     cc_options options;
     cc_options_init(&options);  // non-monotonic steps, 100 iterations: calibrator.cpp:314-321
     cc_summary summary{};
-    last_status_ = cc_intrinsics_estimate(&options, device_, (int64_t)n_img, offsets_p, uv_p, xyz_p, dist5, frozen,
-                                          K9, intr, qd.data(), td.data(), &summary);
+    last_status_ = cc_intrinsics_estimate_views(&options, device_, (int64_t)n_img, uv_views.data(), xyz_views.data(), counts.data(),
+                                                dist5, frozen, K9, intr, qd.data(), td.data(), &summary);
     cc_last_call_timing(&last_timing_ms_[1]);
     // Same contract as the two-step path below: environment errors (no device, HIP, exchange) and the Zhang
     // preconditions (cc_zhang_init's CC_ERR_BAD_ARGUMENT: < 3 frames, < 4 points in a frame) throw; a solver-level
@@ -116,6 +121,10 @@ void Calibrator::Estimate(const std::vector<Points2D>& pixels_per_view, const st
     last_timing_ms_[6] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
     return;
   }
+  PackedViews pv(pixels_per_view, board_points_per_view);
+  const int64_t* offsets_p = pv.offsets;
+  const float *uv_p = pv.uv, *xyz_p = pv.xyz;
+  last_timing_ms_[0] = pv.pack_ms;
   std::vector<float> q(4 * n_img), t(3 * n_img);
   const int rc = cc_zhang_init(device_, (int64_t)n_img, offsets_p, uv_p, xyz_p, K9, q.data(), t.data(), nullptr);
   if (rc != 0) throw std::runtime_error(std::string("Calibrator::Estimate: ") + cc_last_error());
@@ -134,13 +143,10 @@ void Calibrator::Optimize(const std::vector<Points2D>& pixels_per_view, const st
                           std::vector<Quaternion>& qs, std::vector<Point3D>& ts) {
   const size_t n_img = pixels_per_view.size();
   assert(n_img == board_points_per_view.size() && n_img == qs.size() && n_img == ts.size());
-  // CSR layout of the ragged frames (packed into cached pinned memory, one memcpy per view) + fp64 parameter arrays
+  // fp64 parameter arrays; the ragged views go over as they are on one device (the library packs them under its upload),
+  // as one CSR layout in cached pinned memory (one memcpy per view) for several devices
   const auto t_call = std::chrono::steady_clock::now();
-  PackedViews pv(pixels_per_view, board_points_per_view);
-  const int64_t* offsets_p = pv.offsets;
-  const float *uv_p = pv.uv, *xyz_p = pv.xyz;
   for (double& v : last_timing_ms_) v = 0.0;
-  last_timing_ms_[0] = pv.pack_ms;
   std::vector<double> q(4 * n_img), t(3 * n_img);
   for (size_t i = 0; i < n_img; ++i) {
     q[4 * i] = qs[i].w(); q[4 * i + 1] = qs[i].x(); q[4 * i + 2] = qs[i].y(); q[4 * i + 3] = qs[i].z();
@@ -159,12 +165,22 @@ void Calibrator::Optimize(const std::vector<Points2D>& pixels_per_view, const st
   if (n_img == 0) {
     last_status_ = 0;
   } else if (devices_.size() > 1) {
+    PackedViews pv(pixels_per_view, board_points_per_view);
+    last_timing_ms_[0] = pv.pack_ms;
     std::vector<int32_t> devs(devices_.begin(), devices_.end());
-    last_status_ = cc_intrinsics_optimize_multi(&options, (int32_t)devs.size(), devs.data(), (int64_t)n_img, offsets_p, uv_p,
-                                                xyz_p, intr, frozen, q.data(), t.data(), &summary);
+    last_status_ = cc_intrinsics_optimize_multi(&options, (int32_t)devs.size(), devs.data(), (int64_t)n_img, pv.offsets, pv.uv,
+                                                pv.xyz, intr, frozen, q.data(), t.data(), &summary);
   } else {
-    last_status_ = cc_intrinsics_optimize(&options, device_, (int64_t)n_img, offsets_p, uv_p, xyz_p,
-                                          intr, frozen, q.data(), t.data(), &summary);
+    std::vector<const float*> uv_views(n_img), xyz_views(n_img);
+    std::vector<int64_t> counts(n_img);
+    for (size_t i = 0; i < n_img; ++i) {
+      assert(pixels_per_view[i].size() == board_points_per_view[i].size());
+      uv_views[i] = reinterpret_cast<const float*>(pixels_per_view[i].data());
+      xyz_views[i] = reinterpret_cast<const float*>(board_points_per_view[i].data());
+      counts[i] = (int64_t)pixels_per_view[i].size();
+    }
+    last_status_ = cc_intrinsics_optimize_views(&options, device_, (int64_t)n_img, uv_views.data(), xyz_views.data(), counts.data(),
+                                                intr, frozen, q.data(), t.data(), &summary);
     cc_last_call_timing(&last_timing_ms_[1]);
   }
   last_iterations_ = summary.iterations;

@@ -53,9 +53,10 @@ class Calibrator {
   int LastStatus() const { return last_status_; }
   int LastIterations() const { return last_iterations_; }
   double LastFinalCost() const { return last_final_cost_; }
-  /// Wall milliseconds of the last Estimate / Optimize on one device: [0] packing the views into (cached, pinned) flat arrays,
-  /// [1] solver handle + device arena (cached), [2] upload, [3] Zhang initialisation (Estimate), [4] solve, [5] read-back +
-  /// teardown, [6] the whole call.
+  /// Wall milliseconds of the last Estimate / Optimize: [0] packing the views into (cached, pinned) flat arrays when the
+  /// class does it (several devices; on one device the library packs piece by piece under its upload and the time is
+  /// part of [2]), [1] solver handle + device arena (cached), [2] pack + upload, [3] Zhang initialisation (Estimate),
+  /// [4] solve, [5] read-back + teardown, [6] the whole call.
   const double* LastTimingMs() const { return last_timing_ms_; }
 
  private:

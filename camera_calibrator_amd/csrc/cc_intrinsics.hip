@@ -1024,6 +1024,7 @@ struct cc_intrinsics {
   size_t extra_bytes = 0;       // set before creation: scratch appended to the arena (cc_intrinsics_estimate's initialisation)
   char* extra = nullptr;
   bool one_shot = false;        // the creator keeps uv / xyz alive until it has synchronised: no wait at the end of create
+  bool no_obs_upload = false;   // ... and uploads the observations itself
   double* init_intr = nullptr;  // [16]
   double* init_pose = nullptr;  // [F][8]
   bool have_state = false;
@@ -1175,10 +1176,11 @@ int intr_create_impl(cc_intrinsics* h, const int64_t* off, const float* uv, cons
 // (how the one-shot entry points -- cc_intrinsics_optimize / _estimate -- ask cc_intrinsics_create for a handle of their own
 // kind: the upload is not waited for, `extra` bytes of scratch ride in the same arena)
 static thread_local bool g_create_one_shot = false;
+static thread_local bool g_create_no_obs = false;   // the creator uploads uv / xyz itself (in pieces, as it packs them)
 static thread_local size_t g_create_extra = 0;
 struct OneShotCreate {
-  OneShotCreate(size_t extra) { g_create_one_shot = true; g_create_extra = extra; }
-  ~OneShotCreate() { g_create_one_shot = false; g_create_extra = 0; }
+  OneShotCreate(size_t extra, bool no_obs = false) { g_create_one_shot = true; g_create_extra = extra; g_create_no_obs = no_obs; }
+  ~OneShotCreate() { g_create_one_shot = false; g_create_extra = 0; g_create_no_obs = false; }
 };
 static double ms_since(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 }
@@ -1197,11 +1199,12 @@ int cc_intrinsics_create(int32_t device, int64_t F, const int64_t* off, const fl
   const int64_t N = off[F];
   if (F >= ((int64_t)1 << 28) || N >= ((int64_t)1 << 40))   // launch grids are 32-bit (F * tiles workgroups)
     return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_create: problem too large (frames < 2^28, observations < 2^40)");
-  if (N > 0 && (!uv || !xyz)) return fail(CC_ERR_BAD_ARGUMENT, "uv/xyz are NULL");
+  if (N > 0 && (!uv || !xyz) && !cc::g_create_no_obs) return fail(CC_ERR_BAD_ARGUMENT, "uv/xyz are NULL");
   if (int rc = select_device(device)) return rc;
   cc_intrinsics* h = new cc_intrinsics();
   h->device = device; h->F = F; h->N = N;
   h->one_shot = cc::g_create_one_shot;
+  h->no_obs_upload = cc::g_create_no_obs;
   h->extra_bytes = cc::g_create_extra;
   const int rc_init = cc::intr_create_impl(h, off, uv, xyz);
   if (rc_init != CC_OK) {  // release whatever was allocated before the failure
@@ -1354,7 +1357,7 @@ int intr_create_impl(cc_intrinsics* h, const int64_t* off, const float* uv, cons
   char* base = static_cast<char*>(h->arena);
   h->extra = h->extra_bytes ? base + o_extra : nullptr;
   CC_HIP(hipMemsetAsync(base, 0, zeroed, h->stream));
-  if (N > 0) {
+  if (N > 0 && !h->no_obs_upload) {
     CC_HIP(hipMemcpyAsync(base + o_uv, uv, (size_t)N * 2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
     CC_HIP(hipMemcpyAsync(base + o_xyz, xyz, (size_t)N * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
   }
@@ -2025,38 +2028,34 @@ int cc_intrinsics_optimize(const cc_options* opt, int32_t device, int64_t F, con
 // (calibrator.cpp:47-66) runs on the handle's own device arrays, its K and poses -- rounded to float exactly as the
 // two-step path cc_zhang_init -> cc_intrinsics_optimize hands them over -- start the solve. Same results as the two
 // calls, one 20-byte-per-observation upload, one allocation and one pair of host packing loops less.
-int cc_intrinsics_estimate(const cc_options* opt, int32_t device, int64_t F, const int64_t* off, const float* uv,
-                           const float* xyz, const double* distortion5, uint32_t mask, float* K_init9, double* intr9,
-                           double* q, double* t, cc_summary* summary) {
-  using namespace cc;
-  if (F < 3 || !off || !uv || !xyz || !intr9 || !q || !t)
-    return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_estimate: needs >= 3 frames and non-NULL arrays");
-  for (int64_t f = 0; f < F; ++f)
-    if (off[f + 1] - off[f] < 4) return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_estimate: frame %lld has fewer than 4 points", (long long)f);
-  // scratch of the initialisation, appended to the handle's arena: gram double[F][256] | H float[9F] | K float[9] | q float[4F] | t float[3F]
-  size_t cursor = 0;
-  auto take = [&](size_t bytes) { const size_t at = cursor; cursor += (bytes + 255) & ~(size_t)255; return at; };
-  const size_t o_gram = take((size_t)F * 256 * sizeof(double)), o_H = take((size_t)F * 9 * sizeof(float)), o_K = take(9 * sizeof(float));
-  const size_t o_q = take((size_t)F * 4 * sizeof(float)), o_t = take((size_t)F * 3 * sizeof(float));
+namespace cc {
+// scratch of the Zhang initialisation, appended to the handle's arena: gram double[F][256] | H float[9F] | K float[9] | q float[4F] | t float[3F]
+struct ZhangScratch {
+  size_t o_gram, o_H, o_K, o_q, o_t, bytes;
+  explicit ZhangScratch(int64_t F) {
+    size_t cursor = 0;
+    auto take = [&](size_t b) { const size_t at = cursor; cursor += (b + 255) & ~(size_t)255; return at; };
+    o_gram = take((size_t)F * 256 * sizeof(double)); o_H = take((size_t)F * 9 * sizeof(float)); o_K = take(9 * sizeof(float));
+    o_q = take((size_t)F * 4 * sizeof(float)); o_t = take((size_t)F * 3 * sizeof(float));
+    bytes = cursor;
+  }
+};
+// Everything of cc_intrinsics_estimate behind the handle and its upload (enqueued on h->stream, not waited for): Zhang on the
+// device arrays, its K and poses rounded to float as the two-call path hands them over, the solve, the read-back.
+static int estimate_on_handle(cc_intrinsics* h, const ZhangScratch& zs, const cc_options* opt, int64_t F, const double* distortion5, uint32_t mask,
+                              float* K_init9, double* intr9, double* q, double* t, cc_summary* summary, std::chrono::steady_clock::time_point t0) {
   double* tm = last_timing();
-  for (int i = 0; i < 5; ++i) tm[i] = 0.0;
-  auto t0 = std::chrono::steady_clock::now();
-  cc_intrinsics* h = nullptr;
-  int rc;
-  { OneShotCreate os(cursor); rc = cc_intrinsics_create(device, F, off, uv, xyz, &h); }
-  if (rc) return rc;
-  struct Guard { cc_intrinsics* h; ~Guard() { cc_intrinsics_destroy(h); } } guard{h};
-  tm[0] = ms_since(t0); t0 = std::chrono::steady_clock::now();
   char* sc = h->extra;
-  float* dK = reinterpret_cast<float*>(sc + o_K);
-  float* dq = reinterpret_cast<float*>(sc + o_q);
-  float* dt = reinterpret_cast<float*>(sc + o_t);
+  float* dK = reinterpret_cast<float*>(sc + zs.o_K);
+  float* dq = reinterpret_cast<float*>(sc + zs.o_q);
+  float* dt = reinterpret_cast<float*>(sc + zs.o_t);
   // (the initialisation's kernels are enqueued behind the upload; the wait below covers both -- the split of the two in
   // cc_last_call_timing comes from an event between them)
   hipEvent_t ev_up = nullptr;
   if (hipEventCreate(&ev_up) == hipSuccess) (void)hipEventRecord(ev_up, h->stream); else { ev_up = nullptr; (void)hipGetLastError(); }
-  if ((rc = zhang_on_device(h->stream, F, h->d.off, h->d.uv, h->d.xyz, reinterpret_cast<double*>(sc + o_gram),
-                            reinterpret_cast<float*>(sc + o_H), dK, dq, dt))) {
+  int rc;
+  if ((rc = zhang_on_device(h->stream, F, h->d.off, h->d.uv, h->d.xyz, reinterpret_cast<double*>(sc + zs.o_gram),
+                            reinterpret_cast<float*>(sc + zs.o_H), dK, dq, dt))) {
     if (ev_up) hipEventDestroy(ev_up);
     return rc;
   }
@@ -2067,7 +2066,7 @@ int cc_intrinsics_estimate(const cc_options* opt, int32_t device, int64_t F, con
   CC_HIP(hipMemcpyAsync(tf.data(), dt, tf.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   if (ev_up) {
     (void)hipEventSynchronize(ev_up);
-    tm[1] = ms_since(t0); t0 = std::chrono::steady_clock::now();
+    tm[1] += ms_since(t0); t0 = std::chrono::steady_clock::now();
     hipEventDestroy(ev_up);
   }
   CC_HIP(hipStreamSynchronize(h->stream));
@@ -2086,6 +2085,134 @@ int cc_intrinsics_estimate(const cc_options* opt, int32_t device, int64_t F, con
   tm[3] = ms_since(t0); t0 = std::chrono::steady_clock::now();
   rc = cc_intrinsics_get_state(h, intr9, q, t);
   tm[4] = ms_since(t0);   // (+ the handle's teardown, a few microseconds with the cached arena, after this function returns)
+  return rc;
+}
+}  // namespace cc
+
+int cc_intrinsics_estimate(const cc_options* opt, int32_t device, int64_t F, const int64_t* off, const float* uv,
+                           const float* xyz, const double* distortion5, uint32_t mask, float* K_init9, double* intr9,
+                           double* q, double* t, cc_summary* summary) {
+  using namespace cc;
+  if (F < 3 || !off || !uv || !xyz || !intr9 || !q || !t)
+    return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_estimate: needs >= 3 frames and non-NULL arrays");
+  for (int64_t f = 0; f < F; ++f)
+    if (off[f + 1] - off[f] < 4) return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_estimate: frame %lld has fewer than 4 points", (long long)f);
+  const ZhangScratch zs(F);
+  double* tm = last_timing();
+  for (int i = 0; i < 5; ++i) tm[i] = 0.0;
+  auto t0 = std::chrono::steady_clock::now();
+  cc_intrinsics* h = nullptr;
+  int rc;
+  { OneShotCreate os(zs.bytes); rc = cc_intrinsics_create(device, F, off, uv, xyz, &h); }
+  if (rc) return rc;
+  struct Guard { cc_intrinsics* h; ~Guard() { cc_intrinsics_destroy(h); } } guard{h};
+  tm[0] = ms_since(t0); t0 = std::chrono::steady_clock::now();
+  return estimate_on_handle(h, zs, opt, F, distortion5, mask, K_init9, intr9, q, t, summary, t0);
+}
+
+// The same for a caller whose views are separate arrays (the reference's vector<Points2D> / vector<Points3D> arguments,
+// calibrator.cpp:47-68): view i has counts[i] points at uv_views[i] (2 floats each) and xyz_views[i] (3 floats each). The
+// library packs them into its cached pinned staging block IN PIECES and uploads every piece as soon as it is packed: the
+// copy of piece k over PCIe runs under the packing of piece k + 1, and the first kernels behind the last one.
+namespace cc {
+struct ViewsUpload {
+  void* staging = nullptr;
+  cc_intrinsics* h = nullptr;
+  ~ViewsUpload() { if (h) cc_intrinsics_destroy(h); staging_put(staging); }   // (the handle's stream is idle by then: every path below waits on it)
+  int open(const char* who, int32_t device, int64_t F, const float* const* uv_views, const float* const* xyz_views,
+           const int64_t* counts, int64_t min_points, size_t extra_bytes) {
+    int64_t N = 0;
+    for (int64_t f = 0; f < F; ++f) {
+      if (counts[f] < min_points || (counts[f] > 0 && (!uv_views[f] || !xyz_views[f])))
+        return fail(CC_ERR_BAD_ARGUMENT, "%s: view %lld has %lld points (needs >= %lld, non-NULL)", who, (long long)f, (long long)counts[f], (long long)min_points);
+      N += counts[f];
+    }
+    double* tm = last_timing();
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t b_off = ((size_t)(F + 1) * sizeof(int64_t) + 255) & ~(size_t)255, b_uv = ((size_t)N * 2 * sizeof(float) + 255) & ~(size_t)255;
+    bool st_cached = false;
+    staging = staging_get(b_off + b_uv + (size_t)N * 3 * sizeof(float) + 256, &st_cached);
+    if (!staging) return fail(CC_ERR_HIP, "%s: pinned staging memory could not be allocated", who);
+    char* st = static_cast<char*>(staging);
+    int64_t* off = reinterpret_cast<int64_t*>(st);
+    float* uv = reinterpret_cast<float*>(st + b_off);
+    float* xyz = reinterpret_cast<float*>(st + b_off + b_uv);
+    off[0] = 0;
+    for (int64_t f = 0; f < F; ++f) off[f + 1] = off[f] + counts[f];
+    int rc;
+    { OneShotCreate os(extra_bytes, true); rc = cc_intrinsics_create(device, F, off, nullptr, nullptr, &h); }
+    if (rc) return rc;
+    tm[0] = ms_since(t0);
+    const auto t1 = std::chrono::steady_clock::now();
+    // THREE pieces of a large problem (none below 32k observations = 640 KB): every hipMemcpyAsync costs about 7.5 us of host
+    // time and the link moves ~36 GB/s either way, so more pieces lose what the overlap gains (measured at 500k observations,
+    // pack + upload: 1 piece 0.47-0.49 ms, 2: 0.39-0.40, 3: 0.38-0.39, 4: 0.45, 8: 0.51, 32: 0.92; a second stream for xyz
+    // or a kernel that pulls the pinned block over PCIe itself made no difference beyond box-to-box noise)
+    const int64_t piece = std::max<int64_t>(32768, N / 3 + 1);
+    float* duv = const_cast<float*>(h->d.uv);
+    float* dxyz = const_cast<float*>(h->d.xyz);
+    int64_t f0 = 0;
+    while (f0 < F) {
+      int64_t f1 = f0;
+      while (f1 < F && off[f1] - off[f0] < piece) ++f1;
+      for (int64_t f = f0; f < f1; ++f) {
+        if (!counts[f]) continue;
+        std::memcpy(uv + 2 * off[f], uv_views[f], (size_t)counts[f] * 2 * sizeof(float));
+        std::memcpy(xyz + 3 * off[f], xyz_views[f], (size_t)counts[f] * 3 * sizeof(float));
+      }
+      const size_t n = (size_t)(off[f1] - off[f0]);
+      if (n) {
+        CC_HIP(hipMemcpyAsync(duv + 2 * off[f0], uv + 2 * off[f0], n * 2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        CC_HIP(hipMemcpyAsync(dxyz + 3 * off[f0], xyz + 3 * off[f0], n * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+      }
+      f0 = f1;
+    }
+    tm[1] = ms_since(t1);   // packing + enqueueing; the callers add their wait for the last piece
+    return CC_OK;
+  }
+};
+}  // namespace cc
+
+int cc_intrinsics_estimate_views(const cc_options* opt, int32_t device, int64_t F, const float* const* uv_views,
+                                 const float* const* xyz_views, const int64_t* counts, const double* distortion5, uint32_t mask,
+                                 float* K_init9, double* intr9, double* q, double* t, cc_summary* summary) {
+  using namespace cc;
+  if (F < 3 || !uv_views || !xyz_views || !counts || !intr9 || !q || !t)
+    return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_estimate_views: needs >= 3 views and non-NULL arrays");
+  const ZhangScratch zs(F);
+  double* tm = last_timing();
+  for (int i = 0; i < 5; ++i) tm[i] = 0.0;
+  ViewsUpload up;
+  if (int rc = up.open("cc_intrinsics_estimate_views", device, F, uv_views, xyz_views, counts, 4, zs.bytes)) return rc;
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = estimate_on_handle(up.h, zs, opt, F, distortion5, mask, K_init9, intr9, q, t, summary, t0);
+  if (rc) (void)hipStreamSynchronize(up.h->stream);   // (an early return may have left copies from the staging block in flight)
+  return rc;
+}
+
+// cc_intrinsics_optimize for views given as separate arrays (Calibrator::Optimize's arguments, calibrator.cpp:70-74).
+int cc_intrinsics_optimize_views(const cc_options* opt, int32_t device, int64_t F, const float* const* uv_views,
+                                 const float* const* xyz_views, const int64_t* counts, double* intr9, uint32_t mask,
+                                 double* q, double* t, cc_summary* summary) {
+  using namespace cc;
+  if (F < 1 || !uv_views || !xyz_views || !counts || !intr9 || !q || !t)
+    return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_optimize_views: needs >= 1 view and non-NULL arrays");
+  double* tm = last_timing();
+  for (int i = 0; i < 5; ++i) tm[i] = 0.0;
+  ViewsUpload up;
+  if (int rc = up.open("cc_intrinsics_optimize_views", device, F, uv_views, xyz_views, counts, 0, 0)) return rc;
+  auto t0 = std::chrono::steady_clock::now();
+  int rc = CC_OK;
+  if (hipStreamSynchronize(up.h->stream) != hipSuccess) { (void)hipGetLastError(); rc = fail(CC_ERR_HIP, "upload failed"); }
+  tm[1] += ms_since(t0); t0 = std::chrono::steady_clock::now();
+  if (!rc) rc = cc_intrinsics_set_state(up.h, intr9, mask, q, t);
+  cc_options o;
+  if (opt) o = *opt; else cc_options_init(&o);
+  o.use_graph = 0;
+  if (!rc) rc = cc_intrinsics_solve(up.h, &o, summary);
+  tm[3] = ms_since(t0); t0 = std::chrono::steady_clock::now();
+  if (!rc) rc = cc_intrinsics_get_state(up.h, intr9, q, t);
+  tm[4] = ms_since(t0);
   return rc;
 }
 

@@ -180,6 +180,17 @@ int cc_intrinsics_optimize(const cc_options* opt, int32_t device, int64_t n_fram
 int cc_intrinsics_estimate(const cc_options* opt, int32_t device, int64_t n_frames, const int64_t* frame_offsets,
                            const float* uv, const float* xyz, const double* distortion5, uint32_t const_mask,
                            float* K_init9, double* intr9, double* q_wxyz, double* t_xyz, cc_summary* summary);
+/* The same for views given as separate arrays, the shape of the reference's arguments (vector<Points2D> / vector<Points3D>,
+ * calibrator.cpp:47-68): view i has counts[i] points, uv_views[i] = 2 floats per point, xyz_views[i] = 3. The library packs
+ * the views into cached pinned memory in pieces and uploads each piece while it packs the next. */
+int cc_intrinsics_estimate_views(const cc_options* opt, int32_t device, int64_t n_frames, const float* const* uv_views,
+                                 const float* const* xyz_views, const int64_t* counts, const double* distortion5,
+                                 uint32_t const_mask, float* K_init9, double* intr9, double* q_wxyz, double* t_xyz,
+                                 cc_summary* summary);
+/* cc_intrinsics_optimize for views given as separate arrays (Calibrator::Optimize's arguments, calibrator.cpp:70-74). */
+int cc_intrinsics_optimize_views(const cc_options* opt, int32_t device, int64_t n_frames, const float* const* uv_views,
+                                 const float* const* xyz_views, const int64_t* counts, double* intr9, uint32_t const_mask,
+                                 double* q_wxyz, double* t_xyz, cc_summary* summary);
 
 /* Multi-GPU inside ONE process, ONE host thread (SURVEY.md 8(b) thread model): the one-shot call over several
  * devices. Frames are sharded contiguously by observation count (cc_partition_frames), one handle + stream per

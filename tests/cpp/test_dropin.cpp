@@ -227,8 +227,8 @@ static int class_surface(int frames, int pts, int reps) {
   }
   auto median = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
   std::printf("{\"call\": \"Calibrator::Estimate through the C++ class (fresh object per call)\", \"frames\": %d, \"pts\": %d, \"observations\": %d, "
-              "\"lm_iterations\": %d, \"calls\": %d, \"first_call_ms\": %.4f, \"wall_ms_median\": %.4f, \"pack_ms\": %.4f, \"handle_and_arena_ms\": %.4f, "
-              "\"upload_ms\": %.4f, \"zhang_ms\": %.4f, \"solve_ms\": %.4f, \"readback_ms\": %.4f}\n",
+              "\"lm_iterations\": %d, \"calls\": %d, \"first_call_ms\": %.4f, \"wall_ms_median\": %.4f, \"class_side_pack_ms\": %.4f, \"handle_and_arena_ms\": %.4f, "
+              "\"pack_and_upload_ms\": %.4f, \"zhang_ms\": %.4f, \"solve_ms\": %.4f, \"readback_ms\": %.4f}\n",
               frames, pts, frames * pts, iters, reps, first_ms, median(total), median(parts[0]), median(parts[1]), median(parts[2]),
               median(parts[3]), median(parts[4]), median(parts[5]));
   return 0;

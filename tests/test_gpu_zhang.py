@@ -88,3 +88,29 @@ def test_estimate_in_one_call_equals_initialisation_plus_optimize(frames, pts, m
     assert s1["iterations"] == s2["iterations"] and s1["termination"] == s2["termination"]
     assert np.array_equal(i1, i2) and np.array_equal(q1, q2) and np.array_equal(t1, t2)
     assert s1["final_cost"] == s2["final_cost"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frames,pts", [(20, 88), (7, [30, 4, 500, 12, 64, 65, 9]), (400, 300)])
+def test_views_entry_points_equal_the_flat_ones(frames, pts):
+    """cc_intrinsics_estimate_views / cc_intrinsics_optimize_views (views as separate arrays, packed by the library piece by
+    piece under its upload -- three pieces at 400 x 300) give the bits of the flat entry points."""
+    off, uv, xyz = capi.make_intrinsics_problem(frames, pts)
+    K0, i0, q0, t0, s0 = capi.intrinsics_estimate(off, uv, xyz)
+    K1, i1, q1, t1, s1 = capi.intrinsics_estimate(off, uv, xyz, views=True)
+    assert np.array_equal(K0, K1) and np.array_equal(i0, i1) and np.array_equal(q0, q1) and np.array_equal(t0, t1)
+    assert s0["iterations"] == s1["iterations"] and s0["final_cost"] == s1["final_cost"]
+    Kz, qz, tz = capi.zhang_init(off, uv, xyz)
+    intr = np.array([Kz[0, 0], Kz[1, 1], Kz[0, 2], Kz[1, 2], 0, 0, 0, 0, 0], dtype=np.float64)
+    a = capi.intrinsics_optimize(off, uv, xyz, intr, qz.astype(np.float64), tz.astype(np.float64))
+    b = capi.intrinsics_optimize(off, uv, xyz, intr, qz.astype(np.float64), tz.astype(np.float64), views=True)
+    for x, y in zip(a[:3], b[:3]):
+        assert np.array_equal(x, y)
+    assert a[3]["final_cost"] == b[3]["final_cost"]
+
+
+@pytest.mark.gpu
+def test_views_entry_points_refuse_short_views():
+    off, uv, xyz = capi.make_intrinsics_problem(4, [10, 3, 10, 10])
+    with pytest.raises(capi.CcError):
+        capi.intrinsics_estimate(off, uv, xyz, views=True)   # a homography needs >= 4 points
