@@ -72,6 +72,9 @@ struct RigDev {
   const int32_t* gframe;  // [NG]
   const int32_t* gcam;    // [NG]
   const int64_t* fgoff;   // [F+1] group range of each frame
+  const int4* fwave;      // [F][8] (frames of at most eight groups: k_rig_sweep_frame<.., true>) group j of frame f in ONE
+                          // 16-byte record {first observation (lo, hi), observations, camera}: the wave that sweeps it reads this
+                          // and nothing else before its observations (fgoff -> goff / gcam -> observations was three loads deep)
   const int32_t* cam_goff;   // [C+1]
   const int32_t* cam_glist;  // [NG] groups of each camera
   const uint8_t* cam_fixed;  // [C] pose held constant (frozen, or unobserved by every rank)
@@ -882,15 +885,8 @@ __global__ __launch_bounds__(NWF * 64, ONE ? 4 : (NWF <= 4 ? 3 : 2)) void k_rig_
   double* s_G = sf_lds;                     // [CO][32]  G7 (28), cost (28) of every group of the frame
   double* s_rec = s_G + (size_t)P.CO * 32;  // [8][64]   records of an assembly pass, staged for one coalesced store
   double* s_fr = s_rec + 8 * 64;            // [64]      frame record of the evaluated point (32), then scratch
-  const LmCtl* ctl = P.ctl;
-  const int done = ctl->done, phase = ctl->phase, step_valid = ctl->step_valid, cur = ctl->cur;
-  if (done) return;
-  if (phase != 0 && !step_valid) return;
-  const int dst = phase == 0 ? cur : (cur ^ 1);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t f = blockIdx.x;
-  const int64_t g0 = P.fgoff[f], g1 = P.fgoff[f + 1];
-  const int ng = (int)(g1 - g0);            // groups of this frame (0: no observation)
   const double* fr = P.frec + (size_t)f * 32;
   const double ha = P.huber_a;
   const double hb = P.huber_b, h2a = P.huber_2a, hha = P.huber_ha;
@@ -898,9 +894,32 @@ __global__ __launch_bounds__(NWF * 64, ONE ? 4 : (NWF <= 4 ? 3 : 2)) void k_rig_
   struct ObsRaw { float2 m; F3 X; };
   struct ObsD { double u, v, X0, X1, X2; };
   auto widen = [](const ObsRaw& r, ObsD& d) { d.u = (double)r.m.x; d.v = (double)r.m.y; d.X0 = (double)r.X.x; d.X1 = (double)r.X.y; d.X2 = (double)r.X.z; };
-  // ---- the wave's groups, one after the other
+  // ---- the wave's groups, one after the other. The first two passes' observations are requested BEFORE the control block
+  // is looked at: a launch that returns at once wastes two loads per lane, every other one starts its longest chain
+  // (slot record -> observations) with the kernel.
   ObsRaw oa, ob;
-  {
+  int64_t g0, s0_one = 0;
+  int ng, n_one = 0, c_one = 0;
+#ifdef CC_RIG_NO_FWAVE
+  constexpr bool FW = false;   // (A/B build: the three-loads-deep chain of round 4's first frame form)
+#else
+  constexpr bool FW = ONE;
+#endif
+  if (FW) {
+    const int4 sl = P.fwave[f * 8 + wave];
+    s0_one = (int64_t)(((unsigned long long)(unsigned)sl.y << 32) | (unsigned)sl.x);
+    n_one = __builtin_amdgcn_readfirstlane(sl.z);
+    c_one = __builtin_amdgcn_readfirstlane(sl.w);
+    const float2* uvg = reinterpret_cast<const float2*>(P.uv) + s0_one;
+    const F3* xg = reinterpret_cast<const F3*>(P.oxyz) + s0_one;
+    const int k0 = lane < n_one ? lane : 0, k1 = lane + 64 < n_one ? lane + 64 : 0;
+    oa.m = uvg[k0]; oa.X = xg[k0];
+    ob.m = uvg[k1]; ob.X = xg[k1];
+    g0 = P.fgoff[f];
+    ng = (int)(P.fgoff[f + 1] - g0);            // groups of this frame (0: no observation)
+  } else {
+    g0 = P.fgoff[f];
+    ng = (int)(P.fgoff[f + 1] - g0);
     const int64_t gq = g0 + (wave < ng ? wave : 0);
     const int64_t s0 = P.goff[gq < P.NG ? gq : 0], s1 = P.goff[(gq < P.NG ? gq : 0) + 1];
     const int n = (int)(s1 - s0);
@@ -910,12 +929,22 @@ __global__ __launch_bounds__(NWF * 64, ONE ? 4 : (NWF <= 4 ? 3 : 2)) void k_rig_
     oa.m = uvg[k0]; oa.X = xg[k0];
     ob.m = uvg[k1]; ob.X = xg[k1];
   }
+  const LmCtl* ctl = P.ctl;
+  const int done = ctl->done, phase = ctl->phase, step_valid = ctl->step_valid, cur = ctl->cur;
+  if (done) return;
+  if (phase != 0 && !step_valid) return;
+  const int dst = phase == 0 ? cur : (cur ^ 1);
   auto sweep_group = [&](const int j) {
     const int64_t g = g0 + j;
-    const int c = __builtin_amdgcn_readfirstlane(P.gcam[g]);   // (uniform, and the compiler must know it: the camera record then comes by scalar loads)
-    const int64_t s0 = P.goff[g], s1 = P.goff[g + 1];
-    const int n = (int)(s1 - s0);
+    // (the camera index is uniform, and the compiler must know it: the camera record then comes by scalar loads)
+    const int c = FW ? c_one : __builtin_amdgcn_readfirstlane(P.gcam[g]);
+    const int64_t s0 = FW ? s0_one : P.goff[g];
+    const int n = FW ? n_one : (int)(P.goff[g + 1] - s0);
+#ifdef CC_ABL_NO_PASS
+    const int npass = n < 0 ? 1 : 0;
+#else
     const int npass = (n + 63) >> 6;
+#endif
     const float2* uvg = reinterpret_cast<const float2*>(P.uv) + s0;
     const F3* xg = reinterpret_cast<const F3*>(P.oxyz) + s0;
     auto fetch = [&](int k, ObsRaw& r) {
@@ -991,7 +1020,9 @@ __global__ __launch_bounds__(NWF * 64, ONE ? 4 : (NWF <= 4 ? 3 : 2)) void k_rig_
       widen(oa, d);
       pass(p * 64 + lane, d);
     }
+#ifndef CC_ABL_NO_RS
     reduce_scatter32(acc, lane);   // value e in lanes 2e, 2e + 1
+#endif
     if ((lane & 1) == 0 && (lane >> 1) < 29) s_G[j * 32 + (lane >> 1)] = acc[0];
     // (loop form only) the NEXT group's first two passes (requested behind the reduction: held across it, the ten registers of the two sets
     // push the butterfly over the kernel's 128 and spill)
@@ -1026,7 +1057,11 @@ __global__ __launch_bounds__(NWF * 64, ONE ? 4 : (NWF <= 4 ? 3 : 2)) void k_rig_
   double cost = 0.0, qm = 0.0;
   const double* comp_cur = P.gcomp + (size_t)cur * P.NG * 64;
   double* comp_dst = P.gcomp + (size_t)dst * P.NG * 64;
+#ifdef CC_ABL_NO_ASM
+  for (int jb = ng; jb < ng; jb += 8) {
+#else
   for (int jb = 0; jb < ng; jb += 8) {
+#endif
     const int j = jb + gi;
     const bool live = j < ng;
     const int64_t g = g0 + (live ? j : 0);
@@ -5329,6 +5364,21 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   if (int rc = dev_upload(h, &d.gframe, gframe)) return rc;
   if (int rc = dev_upload(h, &d.gcam, gcam)) return rc;
   if (int rc = dev_upload(h, &d.fgoff, h->fgoff_h)) return rc;
+  {
+    // slot records of the frame form (read only by its one-group-per-wave variant: frames of at most eight groups)
+    std::vector<int4> fslot((size_t)F * 8, int4{0, 0, 0, 0});
+    for (int64_t f = 0; f < F; ++f) {
+      const int64_t a = h->fgoff_h[(size_t)f], b = h->fgoff_h[(size_t)f + 1];
+      for (int64_t g = a; g < b && g - a < 8; ++g) {
+        int4& sl = fslot[(size_t)f * 8 + (size_t)(g - a)];
+        sl.x = (int)(unsigned)((unsigned long long)goff[(size_t)g] & 0xffffffffull);
+        sl.y = (int)(unsigned)((unsigned long long)goff[(size_t)g] >> 32);
+        sl.z = (int)(goff[(size_t)g + 1] - goff[(size_t)g]);
+        sl.w = gcam[(size_t)g];
+      }
+    }
+    if (int rc = dev_upload(h, &d.fwave, fslot)) return rc;
+  }
   if (int rc = dev_upload(h, &d.cam_goff, cam_goff)) return rc;
   if (int rc = dev_upload(h, &d.cam_glist, cam_glist)) return rc;
   if (const char* e = getenv("CC_RIG_SWEEP_MFMA")) h->sweep_adjoint = atoi(e) == 0;      // (before the layout: it decides the form of the records)
