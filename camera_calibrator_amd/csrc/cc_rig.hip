@@ -161,13 +161,38 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
-// ceres::HuberLoss(a) + Corrector (rho'' <= 0): residual and Jacobian scaled by sqrt(rho')
+// 1 / sqrt(d) for a Cholesky pivot: the hardware estimate and the library's third-order correction WITHOUT its special-case
+// selects (zero, infinity, NaN: the caller tests d > 0 && isfinite(d) and discards the step) -- three dependent
+// instructions fewer on a chain that is nothing but dependent instructions. Same bits as rsqrt() for every d it is kept for.
+__device__ __forceinline__ double rsqrt_pos(double d) {
+  const double y0 = __builtin_amdgcn_rsq(d);
+  const double e = fma(y0 * -d, y0, 1.0);
+  return fma(y0 * e, fma(e, 0.375, 0.5), y0);
+}
+
+// ceres::HuberLoss(a) + Corrector (rho'' <= 0): residual and Jacobian scaled by sqrt(rho').
+// Outlier rows: |r| = s y and sqrt(a / |r|) = q rsqrt(q), q = a y, from two refined reciprocal square roots y = rsqrt(s)
+// (each within an ulp or two: 17 instructions). The correctly rounded sqrt, divide, sqrt sequence is 34 with its scaling and
+// special-case selects, and the WHOLE wave executes it whenever one of its 64 rows is an outlier -- with the reference's
+// threshold of three pixels that is most waves of a noisy scenario: 56.3 -> 50.5 us per launch of the frame sweep at
+// 8 x 2000 x 500. -DCC_RIG_EXACT_HUBER restores the library calls (A/B and parity forensics).
+__device__ __forceinline__ void huber_outlier(double a, double s, double& r, double& sr) {
+#ifdef CC_RIG_EXACT_HUBER
+  r = sqrt(s);
+  sr = sqrt(fmax(2.2250738585072014e-308, a / r));
+#else
+  const double y = rsqrt_pos(s);
+  r = s * y;
+  const double q = fmax(2.2250738585072014e-308, a * y);   // (a = 0: the same tiny weight the guarded divide gives)
+  sr = q * rsqrt_pos(q);
+#endif
+}
 __device__ __forceinline__ void huber(double a, double s, double& rho, double& sr) {
   const double b = a * a;
   if (s > b) {
-    const double r = sqrt(s);
+    double r;
+    huber_outlier(a, s, r, sr);
     rho = 2.0 * a * r - b;
-    sr = sqrt(fmax(2.2250738585072014e-308, a / r));
   } else {
     rho = s;
     sr = 1.0;
@@ -987,9 +1012,9 @@ __global__ __launch_bounds__(NWF * 64, ONE ? 4 : (NWF <= 4 ? 3 : 2)) void k_rig_
       {
         const double ss = o.ru * o.ru + o.rv * o.rv;
         if (ss > hb) {
-          const double rr = sqrt(ss);
+          double rr;
+          huber_outlier(ha, ss, rr, sr);
           rho = h2a * (rr - hha);
-          sr = sqrt(fmax(2.2250738585072014e-308, ha / rr));
         } else { rho = ss; sr = 1.0; }
       }
       if (valid) acc[28] += 0.5 * rho;
@@ -2207,14 +2232,6 @@ __device__ __forceinline__ double readlane_d(double x, int l) {
 }
 
 
-// 1 / sqrt(d) for a Cholesky pivot: the hardware estimate and the library's third-order correction WITHOUT its special-case
-// selects (zero, infinity, NaN: the caller tests d > 0 && isfinite(d) and discards the step) -- three dependent
-// instructions fewer on a chain that is nothing but dependent instructions. Same bits as rsqrt() for every d it is kept for.
-__device__ __forceinline__ double rsqrt_pos(double d) {
-  const double y0 = __builtin_amdgcn_rsq(d);
-  const double e = fma(y0 * -d, y0, 1.0);
-  return fma(y0 * e, fma(e, 0.375, 0.5), y0);
-}
 
 // shared step: write-through, so that workgroups of the same launch can read it behind a flag (sc1 loads)
 __device__ __forceinline__ void store_ds(double* p, double v) {
