@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 namespace cc {
@@ -197,6 +198,69 @@ void staging_put(void* p) {
     if (g_staging.p == p) { g_staging.busy = false; return; }
   }
   hipHostFree(p);
+}
+
+namespace {
+struct PoolBlock { void* p; size_t bytes; };
+std::vector<std::vector<PoolBlock>> g_pool;   // per device, guarded by g_cache_mu
+std::vector<size_t> g_pool_bytes;
+constexpr size_t kPoolKeep = (size_t)8 << 30;
+}  // namespace
+
+int pool_alloc(int device, size_t bytes, void** out, size_t* got) {
+  {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    if ((int)g_pool.size() > device) {
+      auto& v = g_pool[(size_t)device];
+      int best = -1;
+      for (int i = 0; i < (int)v.size(); ++i)
+        if (v[(size_t)i].bytes >= bytes && v[(size_t)i].bytes <= bytes + bytes / 4 + ((size_t)1 << 20) && (best < 0 || v[(size_t)i].bytes < v[(size_t)best].bytes)) best = i;
+      if (best >= 0) {
+        *out = v[(size_t)best].p; *got = v[(size_t)best].bytes;
+        g_pool_bytes[(size_t)device] -= v[(size_t)best].bytes;
+        v.erase(v.begin() + best);
+        return CC_OK;
+      }
+    }
+  }
+  CC_HIP(hipMalloc(out, bytes));
+  *got = bytes;
+  return CC_OK;
+}
+
+void pool_free(int device, void* p, size_t bytes) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    if ((int)g_pool.size() <= device) { g_pool.resize((size_t)device + 1); g_pool_bytes.resize((size_t)device + 1, 0); }
+    if (g_pool_bytes[(size_t)device] + bytes <= kPoolKeep && g_pool[(size_t)device].size() < 256) {
+      g_pool[(size_t)device].push_back(PoolBlock{p, bytes});
+      g_pool_bytes[(size_t)device] += bytes;
+      return;
+    }
+  }
+  (void)hipFree(p);
+}
+
+int parallel_parts(int64_t n, int64_t min_per_part) {
+  if (n < 2 * min_per_part) return 1;
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int64_t cap = std::min<int64_t>(16, hw ? (int64_t)hw : 4);
+  return (int)std::max<int64_t>(1, std::min<int64_t>(cap, n / min_per_part));
+}
+
+void parallel_tasks(int parts, const std::function<void(int)>& fn) {
+  if (parts <= 1) { fn(0); return; }
+  std::vector<std::thread> th;
+  th.reserve((size_t)parts - 1);
+  for (int t = 1; t < parts; ++t) th.emplace_back([&fn, t] { fn(t); });
+  fn(0);
+  for (auto& x : th) x.join();
+}
+
+void parallel_ranges(int64_t n, int64_t min_per_part, const std::function<void(int, int64_t, int64_t)>& fn) {
+  const int parts = parallel_parts(n, min_per_part);
+  parallel_tasks(parts, [&](int t) { fn(t, n * t / parts, n * (t + 1) / parts); });
 }
 
 void stream_put(int device, hipStream_t s) {

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <functional>
 #include <string>
 
 #include "../../include/cc_solver.h"
@@ -44,6 +45,16 @@ void stream_put(int device, hipStream_t s);
 int arena_get(int device, size_t bytes, void** out, bool* cached);    // device arena of a solver handle (one cached, grow-only)
 void arena_put(int device, void* p, bool cached);
 void* staging_get(size_t bytes, bool* cached);                       // pinned host staging (one cached, grow-only)
+// Device blocks of handles that allocate piece by piece (the rig path): a destroyed handle's blocks wait here (per device, at
+// most kPoolKeep bytes in all) for the next handle that asks for the same size -- a caller that optimises again with a few more
+// frames pays hipMalloc / hipFree for the difference only.
+int pool_alloc(int device, size_t bytes, void** out, size_t* got);
+void pool_free(int device, void* p, size_t bytes);
+// fn(part, begin, end) over [0, n) cut into contiguous parts, one host thread each (at most 16, one when n < 2 min_per_part);
+// returns after all parts. parallel_parts gives the number of parts fn will see.
+int parallel_parts(int64_t n, int64_t min_per_part);
+void parallel_tasks(int parts, const std::function<void(int)>& fn);   // fn(0 .. parts-1), one host thread each
+void parallel_ranges(int64_t n, int64_t min_per_part, const std::function<void(int, int64_t, int64_t)>& fn);
 void staging_put(void* p);
 double* last_timing();                                               // [5] phases of this thread's last one-shot call (ms)
 int scratch_get(int device, size_t bytes, void** out, bool* cached);

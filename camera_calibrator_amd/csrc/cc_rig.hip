@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "cc_common.hpp"
+#include <mutex>
 #include "cc_device.hpp"
 #include "cc_persist_dev.hpp"
 
@@ -4721,7 +4722,7 @@ struct cc_rig {
   bool sweep_adjoint = true; // poses-only sweep: 7-column Gram + per-group assembly (k_rig_sweep_adj); CC_RIG_SWEEP_MFMA=1: the 13-column matrix-pipe sweep
   int kmode = 0;
   std::vector<int64_t> perm;  // sorted position -> caller's observation index
-  std::vector<void*> allocs;    // the chunks dev_alloc carves buffers from
+  std::vector<std::pair<void*, size_t>> allocs;   // the chunks dev_alloc carves buffers from (cc::pool_alloc: recycled between handles)
   char* chunk_cur = nullptr;
   size_t chunk_left = 0;
   double* init_cam = nullptr;
@@ -4783,10 +4784,11 @@ static int dev_alloc(cc_rig* h, T** p, size_t n) {
   if (h->chunk_left < bytes) {
     const size_t sz = std::max<size_t>(bytes, (size_t)16 << 20);
     void* c = nullptr;
-    CC_HIP(hipMalloc(&c, sz));
-    h->allocs.push_back(c);
+    size_t got = 0;
+    if (int rc = pool_alloc(h->device, sz, &c, &got)) return rc;
+    h->allocs.emplace_back(c, got);
     h->chunk_cur = static_cast<char*>(c);
-    h->chunk_left = sz;
+    h->chunk_left = got;
   }
   *p = reinterpret_cast<T*>(h->chunk_cur);
   h->chunk_cur += bytes;
@@ -5274,6 +5276,19 @@ static int rig_wait_published(cc_rig* h, LmCtl* c, bool* wait_failed, bool lean 
 extern "C" void cc_rig_destroy(cc_rig* h);
 
 namespace cc {
+static std::mutex g_perm_mu;
+static std::vector<int64_t> g_perm_cache;   // storage of the last destroyed handle's permutation (cc_rig_create takes it over)
+struct HostPhases {   // CC_RIG_HOST_TIMING=1: wall milliseconds of the host-side phases of a call, to stderr
+  const char* who; bool on; std::chrono::steady_clock::time_point t; std::string line;
+  explicit HostPhases(const char* w) : who(w), on(getenv("CC_RIG_HOST_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+  void mark(const char* name) {
+    if (!on) return;
+    const auto n = std::chrono::steady_clock::now();
+    char b[96]; snprintf(b, sizeof(b), " %s %.3f", name, std::chrono::duration<double, std::milli>(n - t).count());
+    line += b; t = n;
+  }
+  ~HostPhases() { if (on) fprintf(stderr, "[%s]%s\n", who, line.c_str()); }
+};
 struct RigCreateGuard {  // releases a half-built handle on every early return
   cc_rig* h;
   bool ok = false;
@@ -5287,6 +5302,7 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
                            const uint32_t* obs_cam, const uint64_t* obs_world, const float* obs_uv,
                            const float* world_xyz, const uint8_t* cam_frozen, double huber_a, int kmode, cc_rig** out) {
   using namespace cc;
+  HostPhases hp("cc_rig_create");
   if (!out || !off || C < 1 || F < 1 || n_world < 0) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: bad arguments");
   if (off[0] != 0) return fail(CC_ERR_BAD_ARGUMENT, "obs_frame_offsets[0] must be 0");
   const int64_t N = off[F];
@@ -5296,55 +5312,101 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   if (C > (1 << 20) || F >= INT32_MAX || n_world >= INT32_MAX || N >= ((int64_t)1 << 40))
     return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: problem too large (cameras < 2^20, frames and world points < 2^31)");
   if (N > 0 && (!obs_cam || !obs_world || !obs_uv || !world_xyz)) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: NULL arrays");
-  for (int64_t k = 0; k < N; ++k) {
-    if (obs_cam[k] >= (uint32_t)C) return fail(CC_ERR_BAD_ARGUMENT, "observation %lld: camera id out of range", (long long)k);
-    if (obs_world[k] >= (uint64_t)n_world) return fail(CC_ERR_BAD_ARGUMENT, "observation %lld: world point id out of range", (long long)k);
-  }
+  hp.mark("checks");   // (camera and world point ids: inside the regrouping pass)
   if (int rc = select_device(device)) return rc;
   cc_rig* h = new cc_rig();
   RigCreateGuard guard{h};
   h->device = device; h->C = C; h->F = F; h->N = N; h->P = n_world; h->kmode = kmode;
-  // ---- regroup: within each frame, stable sort by camera -> (frame, camera) groups
-  h->perm.resize((size_t)N);
+  // ---- regroup: within each frame, stable sort by camera -> (frame, camera) groups. ONE pass over the caller's arrays, cut
+  // into contiguous frame ranges of equal observation counts for up to 16 host threads: ids checked, groups listed, the
+  // permutation kept (per-observation costs go back in the caller's order) and the regrouped pixel / world-index arrays written
+  // straight into the cached pinned staging block the uploads below read (8 M observations: 55 ms on one thread through three
+  // freshly allocated vectors -- more than the whole solve -- before round 4's end)
+  {
+    std::lock_guard<std::mutex> lk(g_perm_mu);
+    h->perm.swap(g_perm_cache);          // (an earlier handle's storage: already faulted in; never shrunk, h->N is the length)
+  }
+  if ((int64_t)h->perm.size() < N) h->perm.resize((size_t)N);
+  const size_t b_uv = ((size_t)N * 2 * sizeof(float) + 255) & ~(size_t)255;
+  bool st_cached = false;
+  char* st = static_cast<char*>(staging_get(b_uv + (size_t)N * sizeof(int32_t) + 256, &st_cached));
+  if (!st) return fail(CC_ERR_HIP, "cc_rig_create: pinned staging memory could not be allocated");
+  struct StGuard {   // the uploads read the block until the handle's stream has drained
+    void* p; cc_rig* h;
+    ~StGuard() { if (h->stream) (void)hipStreamSynchronize(h->stream); staging_put(p); }
+  } stg{st, h};
+  float* uv_s = reinterpret_cast<float*>(st);
+  int32_t* widx_s = reinterpret_cast<int32_t*>(st + b_uv);
   std::vector<int64_t> goff{0};
   h->fgoff_h.assign((size_t)F + 1, 0);
   std::vector<int32_t>& gframe = h->gframe_h;
   std::vector<int32_t>& gcam = h->gcam_h;
   std::vector<uint8_t> seen((size_t)C, 0);
   {
-    // counting sort by camera inside each frame (stable: observation order is kept within a group); only the
-    // cameras that occur in the frame are visited, so thousands of idle cameras cost nothing
-    int64_t pos = 0;
-    std::vector<int64_t> cnt((size_t)C, 0), start((size_t)C, 0);
-    std::vector<uint32_t> present;
-    for (int64_t f = 0; f < F; ++f) {
-      present.clear();
-      for (int64_t k = off[f]; k < off[f + 1]; ++k) if (cnt[obs_cam[k]]++ == 0) present.push_back(obs_cam[k]);
-      std::sort(present.begin(), present.end());
-      for (uint32_t c : present) {
-        start[c] = pos;
-        gframe.push_back((int32_t)f);
-        gcam.push_back((int32_t)c);
-        seen[c] = 1;
-        pos += cnt[c];
-        goff.push_back(pos);
+    // (per-thread tables of C entries: one thread when the camera ids are sparse in a huge range)
+    const int parts = C <= 65536 ? parallel_parts(N, (int64_t)1 << 17) : 1;
+    std::vector<int64_t> pf((size_t)parts + 1, 0);
+    if (int rc = cc_partition_frames(F, off, parts, pf.data())) return rc;
+    struct Part { std::vector<int32_t> gframe, gcam, per_frame; std::vector<int64_t> gend; int64_t bad = -1; int bad_kind = 0; };
+    std::vector<Part> part((size_t)parts);
+    int64_t* perm = h->perm.data();
+    uint8_t* seen_p = seen.data();
+    parallel_tasks(parts, [&](int t) {
+      Part& L = part[(size_t)t];
+      // counting sort by camera inside each frame (stable: observation order is kept within a group); only the
+      // cameras that occur in the frame are visited, so thousands of idle cameras cost nothing
+      std::vector<int64_t> cnt((size_t)C, 0), start((size_t)C, 0);
+      std::vector<uint32_t> present;
+      for (int64_t f = pf[(size_t)t]; f < pf[(size_t)t + 1]; ++f) {
+        present.clear();
+        for (int64_t k = off[f]; k < off[f + 1]; ++k) {
+          const uint32_t c = obs_cam[k];
+          if (c >= (uint32_t)C) { L.bad = k; L.bad_kind = 0; return; }
+          if (obs_world[k] >= (uint64_t)n_world) { L.bad = k; L.bad_kind = 1; return; }
+          if (cnt[c]++ == 0) present.push_back(c);
+        }
+        std::sort(present.begin(), present.end());
+        int64_t pos = off[f];
+        for (uint32_t c : present) {
+          start[c] = pos;
+          L.gframe.push_back((int32_t)f);
+          L.gcam.push_back((int32_t)c);
+          __atomic_store_n(seen_p + c, (uint8_t)1, __ATOMIC_RELAXED);
+          pos += cnt[c];
+          L.gend.push_back(pos);
+        }
+        L.per_frame.push_back((int32_t)present.size());
+        for (int64_t k = off[f]; k < off[f + 1]; ++k) {
+          const int64_t dst = start[obs_cam[k]]++;
+          perm[dst] = k;
+          uv_s[2 * dst] = obs_uv[2 * k]; uv_s[2 * dst + 1] = obs_uv[2 * k + 1];
+          widx_s[dst] = (int32_t)obs_world[k];
+        }
+        for (uint32_t c : present) cnt[c] = 0;
       }
-      for (int64_t k = off[f]; k < off[f + 1]; ++k) h->perm[(size_t)start[obs_cam[k]]++] = k;
-      for (uint32_t c : present) cnt[c] = 0;
-      h->fgoff_h[(size_t)f + 1] = (int64_t)gframe.size();
+    });
+    for (const Part& L : part)   // (parts are in frame order: the first one with a bad id holds the first bad observation)
+      if (L.bad >= 0)
+        return fail(CC_ERR_BAD_ARGUMENT, L.bad_kind == 0 ? "observation %lld: camera id out of range" : "observation %lld: world point id out of range", (long long)L.bad);
+    size_t ng_total = 0;
+    for (const Part& L : part) ng_total += L.gframe.size();
+    gframe.reserve(ng_total); gcam.reserve(ng_total); goff.reserve(ng_total + 1);
+    for (int t = 0; t < parts; ++t) {
+      const Part& L = part[(size_t)t];
+      gframe.insert(gframe.end(), L.gframe.begin(), L.gframe.end());
+      gcam.insert(gcam.end(), L.gcam.begin(), L.gcam.end());
+      goff.insert(goff.end(), L.gend.begin(), L.gend.end());
+      for (size_t i = 0; i < L.per_frame.size(); ++i) {
+        const int64_t f = pf[(size_t)t] + (int64_t)i;
+        h->fgoff_h[(size_t)f + 1] = h->fgoff_h[(size_t)f] + L.per_frame[i];
+      }
     }
   }
+  hp.mark("regroup");
   const int64_t NG = (int64_t)gframe.size();
   h->NG = NG;
   if (NG == 0) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: no observations");
   if (NG >= INT32_MAX) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: too many (frame, camera) groups");
-  std::vector<float> uv((size_t)N * 2);
-  std::vector<int32_t> widx((size_t)N);
-  for (int64_t i = 0; i < N; ++i) {
-    const int64_t k = h->perm[(size_t)i];
-    uv[2 * i] = obs_uv[2 * k]; uv[2 * i + 1] = obs_uv[2 * k + 1];
-    widx[(size_t)i] = (int32_t)obs_world[k];
-  }
   std::vector<int32_t> cam_goff((size_t)C + 1, 0), cam_glist((size_t)NG);
   for (int64_t g = 0; g < NG; ++g) cam_goff[(size_t)gcam[g] + 1]++;
   for (int64_t c = 0; c < C; ++c) cam_goff[c + 1] += cam_goff[c];
@@ -5355,6 +5417,7 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   h->frozen.assign((size_t)C, 0);
   if (cam_frozen) for (int64_t c = 0; c < C; ++c) h->frozen[(size_t)c] = cam_frozen[c] ? 1 : 0;
   h->seen = seen;
+  hp.mark("gather");
 
   if (int rc = stream_get(device, &h->stream)) return rc;
   RigDev& d = h->d;
@@ -5364,8 +5427,17 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   d.comm = 0; d.rank = 0; d.nranks = 1;
   d.kmode = kmode; d.gstride = kmode ? 768 : 256;
   d.init_slices = (int32_t)std::min<int64_t>(16, std::max<int64_t>(1, (NG + 511) / 512));
-  { const float* p; if (int rc = dev_upload(h, &p, uv)) return rc; d.uv = p; }
-  if (int rc = dev_upload(h, &d.widx, widx)) return rc;
+  {
+    float* duv = nullptr;
+    int32_t* dw = nullptr;
+    if (int rc = dev_alloc(h, &duv, (size_t)N * 2)) return rc;
+    if (int rc = dev_alloc(h, &dw, (size_t)N)) return rc;
+    if (N > 0) {
+      CC_HIP(hipMemcpyAsync(duv, uv_s, (size_t)N * 2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+      CC_HIP(hipMemcpyAsync(dw, widx_s, (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    }
+    d.uv = duv; d.widx = dw;
+  }
   {
     float* w = nullptr;
     if (int rc = dev_alloc(h, &w, (size_t)n_world * 3)) return rc;
@@ -5377,6 +5449,7 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
     CC_HIP(hipGetLastError());
     d.oxyz = ox;
   }
+  hp.mark("upload_obs");
   if (int rc = dev_upload(h, &d.goff, goff)) return rc;
   if (int rc = dev_upload(h, &d.gframe, gframe)) return rc;
   if (int rc = dev_upload(h, &d.gcam, gcam)) return rc;
@@ -5400,7 +5473,9 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   if (int rc = dev_upload(h, &d.cam_glist, cam_glist)) return rc;
   if (const char* e = getenv("CC_RIG_SWEEP_MFMA")) h->sweep_adjoint = atoi(e) == 0;      // (before the layout: it decides the form of the records)
   if (const char* e = getenv("CC_RIG_SWEEP_FRAME")) h->frame_allowed = atoi(e) != 0;
+  hp.mark("upload_idx");
   if (int rc = rig_layout(h, seen)) return rc;
+  hp.mark("layout");
   {
     // frame form: waves per frame workgroup -- enough workgroups x waves to fill the chip's 4096 wave slots, never more waves
     // than a frame has groups (each wave sweeps whole groups)
@@ -5481,6 +5556,8 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_sweep<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kRigSweepLdsBytes2));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_sweep<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kRigSweepLdsBytes1));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_sweep<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kRigSweepLdsBytesK));
+  CC_HIP(hipStreamSynchronize(h->stream));   // the observations are up (the staging block goes back to the cache)
+  hp.mark("alloc_rest");
   guard.ok = true;
   *out = h;
   return CC_OK;
@@ -5554,6 +5631,7 @@ int cc_rigk_get_intrinsics(cc_rig* h, double* intr9) { return cc_rigk_get_camera
 
 void cc_rig_destroy(cc_rig* h) {
   if (!h) return;
+  cc::HostPhases hp("cc_rig_destroy");
   hipSetDevice(h->device);
   bool stream_ok = true;
   if (h->stream) stream_ok = hipStreamSynchronize(h->stream) == hipSuccess;
@@ -5562,12 +5640,19 @@ void cc_rig_destroy(cc_rig* h) {
     hipStreamDestroy(h->stream2);
   }
 
+  hp.mark("sync");
   if (h->ev_begin) hipEventDestroy(h->ev_begin);
   cc::rig_drop_graphs(h);
   for (auto e : h->events) hipEventDestroy(e);
   if (h->comm) cc::comm_destroy(h->comm);
   cc::mailbox_release(&h->mailbox);
-  for (void* p : h->allocs) hipFree(p);
+  hp.mark("graphs_events");
+  for (auto& a : h->allocs) cc::pool_free(h->device, a.first, a.second);
+  hp.mark("free");
+  {
+    std::lock_guard<std::mutex> lk(cc::g_perm_mu);
+    if (h->perm.size() > cc::g_perm_cache.size() && h->perm.size() <= ((size_t)1 << 28)) h->perm.swap(cc::g_perm_cache);
+  }
   cc::pinned_block_put(h->pinned);
   if (stream_ok) cc::stream_put(h->device, h->stream);   // idle and reusable
   else if (h->stream) hipStreamDestroy(h->stream);      // never hand a failed stream to the next handle
@@ -5918,10 +6003,18 @@ int cc_rig_get_state(cc_rig* h, double* cam_q, double* cam_t, double* frame_q, d
   if (obs_cost && h->N > 0) {
     hipLaunchKernelGGL(k_rig_obs_cost, dim3((unsigned)h->NG), dim3(256), 0, h->stream, h->d, cur, h->d_cost);
     CC_HIP(hipGetLastError());
-    std::vector<double> sorted((size_t)h->N);
-    CC_HIP(hipMemcpyAsync(sorted.data(), h->d_cost, sorted.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    // through the cached pinned block (full PCIe rate, no fresh 8N-byte vector to fault in), back into the caller's order on
+    // several host threads
+    bool st_cached = false;
+    double* sorted = static_cast<double*>(staging_get((size_t)h->N * sizeof(double), &st_cached));
+    if (!sorted) return fail(CC_ERR_HIP, "cc_rig_get_state: pinned staging memory could not be allocated");
+    struct StGuard { void* p; hipStream_t s; ~StGuard() { (void)hipStreamSynchronize(s); staging_put(p); } } stg{sorted, h->stream};
+    CC_HIP(hipMemcpyAsync(sorted, h->d_cost, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     CC_HIP(hipStreamSynchronize(h->stream));
-    for (int64_t i = 0; i < h->N; ++i) obs_cost[h->perm[(size_t)i]] = sorted[(size_t)i];
+    const int64_t* perm = h->perm.data();
+    parallel_ranges(h->N, (int64_t)1 << 18, [&](int, int64_t a, int64_t b) {
+      for (int64_t i = a; i < b; ++i) obs_cost[perm[i]] = sorted[i];
+    });
   }
   return CC_OK;
 }
@@ -6082,15 +6175,21 @@ int cc_rig_optimize(const cc_options* opt, int32_t device, int64_t C, int64_t F,
                     const uint8_t* cam_frozen, double* frame_q, double* frame_t, double huber_a,
                     double* obs_cost, cc_summary* summary) {
   cc_rig* h = nullptr;
+  cc::HostPhases hp("cc_rig_optimize");
   int rc = cc_rig_create(device, C, F, n_world, off, obs_cam, obs_world, obs_uv, world_xyz, cam_frozen, huber_a, &h);
   if (rc) return rc;
+  hp.mark("create");
   rc = cc_rig_set_state(h, cam_q, cam_t, frame_q, frame_t);
+  hp.mark("set_state");
   cc_options o;
   if (opt) o = *opt; else { cc_options_init(&o); o.max_iterations = 1000; }  // extrinsics_calibrator.cpp:211
   o.use_graph = 0;   // one solve per handle: capturing and instantiating a graph cannot pay off
   if (!rc) rc = cc_rig_solve(h, &o, summary);
+  hp.mark("solve");
   if (!rc) rc = cc_rig_get_state(h, cam_q, cam_t, frame_q, frame_t, obs_cost);
+  hp.mark("get_state");
   cc_rig_destroy(h);
+  hp.mark("destroy");
   return rc;
 }
 

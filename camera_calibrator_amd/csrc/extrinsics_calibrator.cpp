@@ -2,13 +2,16 @@
 #include "extrinsics_calibrator.hh"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <fstream>
 #include <functional>
 #include <limits>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
+#include <thread>
 
 #include "../../include/cc_solver.h"
 #include "geometry.hh"
@@ -64,7 +67,25 @@ void ExtrinsicsCalibrator::GetObservation(size_t frame_id, size_t k, size_t* cam
 
 // ---- the solve -----------------------------------------------------------------------------------
 
+namespace {
+// flat observation arrays of the last ExtrinsicsCalibrator that was destroyed (one set per process, at most 2^27 observations):
+// the next object's first Optimize() starts with memory that is already faulted in
+std::mutex g_flat_mu;
+std::vector<uint32_t> g_flat_cam;
+std::vector<uint64_t> g_flat_world;
+std::vector<float> g_flat_uv;
+std::vector<double> g_flat_rho;
+}  // namespace
+
+ExtrinsicsCalibrator::FlatArrays::~FlatArrays() {
+  std::lock_guard<std::mutex> lk(g_flat_mu);
+  if (cam.size() > g_flat_cam.size() && cam.size() <= ((size_t)1 << 27)) {
+    cam.swap(g_flat_cam); world.swap(g_flat_world); uv.swap(g_flat_uv); rho.swap(g_flat_rho);
+  }
+}
+
 void ExtrinsicsCalibrator::Optimize() {
+  const auto t_call = std::chrono::steady_clock::now();
   const size_t C = cameras_.size(), F = frames_.size(), Pn = point_refs_.size();
   // fp64 parameter arrays exactly as the reference fills them (extrinsics_calibrator.cpp:116-137)
   std::vector<double> cam_q(4 * C), cam_t(3 * C), frame_q(4 * F), frame_t(3 * F);
@@ -79,20 +100,48 @@ void ExtrinsicsCalibrator::Optimize() {
   std::vector<int64_t> offsets(F + 1, 0);
   for (size_t f = 0; f < F; ++f) offsets[f + 1] = offsets[f] + (int64_t)frames_[f].sightings.size();
   const size_t N = (size_t)offsets[F];
-  std::vector<uint32_t> obs_cam(N);
-  std::vector<uint64_t> obs_world(N);
-  std::vector<float> obs_uv(2 * N);
-  for (size_t f = 0, k = 0; f < F; ++f)
-    for (const auto& o : frames_[f].sightings) {
-      obs_cam[k] = (uint32_t)o.camera;
-      obs_world[k] = (uint64_t)o.point_global;
-      obs_uv[2 * k] = o.normalised.x();
-      obs_uv[2 * k + 1] = o.normalised.y();
-      ++k;
+  if (flat_.cam.size() < N) {
+    // a fresh object (the reference's workflow may build one per call): take over the arrays the last object left behind
+    std::lock_guard<std::mutex> lk(g_flat_mu);
+    if (g_flat_cam.size() > flat_.cam.size()) { flat_.cam.swap(g_flat_cam); flat_.world.swap(g_flat_world); flat_.uv.swap(g_flat_uv); flat_.rho.swap(g_flat_rho); }
+  }
+  if (flat_.cam.size() < N) { flat_.cam.resize(N); flat_.world.resize(N); flat_.uv.resize(2 * N); flat_.rho.resize(N); }
+  uint32_t* obs_cam = flat_.cam.data();
+  uint64_t* obs_world = flat_.world.data();
+  float* obs_uv = flat_.uv.data();
+  double* half_rho = flat_.rho.data();   // (cc_rig_optimize writes every entry)
+  // frames in contiguous ranges of about equal observation counts, one host thread each
+  std::vector<size_t> part_first{0};
+  {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t parts = N < ((size_t)1 << 18) ? 1 : std::min<size_t>({(size_t)16, hw ? (size_t)hw : 4, N >> 17});
+    for (size_t t = 1; t < parts; ++t)
+      part_first.push_back((size_t)(std::lower_bound(offsets.begin(), offsets.end(), (int64_t)(N * t / parts)) - offsets.begin()));
+    part_first.push_back(F);
+    for (size_t t = 1; t < part_first.size(); ++t) part_first[t] = std::min(F, std::max(part_first[t], part_first[t - 1]));
+  }
+  auto over_frames = [&](const std::function<void(size_t, size_t)>& fn) {
+    std::vector<std::thread> th;
+    for (size_t t = 1; t + 1 < part_first.size(); ++t) th.emplace_back([&, t] { fn(part_first[t], part_first[t + 1]); });
+    fn(part_first[0], part_first[1]);
+    for (auto& x : th) x.join();
+  };
+  over_frames([&](size_t f0, size_t f1) {
+    for (size_t f = f0; f < f1; ++f) {
+      size_t k = (size_t)offsets[f];
+      for (const auto& o : frames_[f].sightings) {
+        obs_cam[k] = (uint32_t)o.camera;
+        obs_world[k] = (uint64_t)o.point_global;
+        obs_uv[2 * k] = o.normalised.x();
+        obs_uv[2 * k + 1] = o.normalised.y();
+        ++k;
+      }
     }
+  });
   std::vector<uint8_t> frozen(C, 0);
   for (size_t id : frozen_) if (id < C) frozen[id] = 1;
-  std::vector<double> half_rho(N, 0.0);
+  last_timing_ms_[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
+  const auto t_lib = std::chrono::steady_clock::now();
 
   cc_options options;
   cc_options_init(&options);
@@ -107,12 +156,12 @@ void ExtrinsicsCalibrator::Optimize() {
     if (devices_.size() > 1) {
       std::vector<int32_t> devs(devices_.begin(), devices_.end());
       last_status_ = cc_rig_optimize_multi(&options, (int32_t)devs.size(), devs.data(), (int64_t)C, (int64_t)F, (int64_t)Pn, offsets.data(),
-                                           obs_cam.data(), obs_world.data(), obs_uv.data(), world.data(), cam_q.data(), cam_t.data(),
-                                           frozen.data(), frame_q.data(), frame_t.data(), huber_a, half_rho.data(), &summary);
+                                           obs_cam, obs_world, obs_uv, world.data(), cam_q.data(), cam_t.data(),
+                                           frozen.data(), frame_q.data(), frame_t.data(), huber_a, half_rho, &summary);
     } else {
-      last_status_ = cc_rig_optimize(&options, device_, (int64_t)C, (int64_t)F, (int64_t)Pn, offsets.data(), obs_cam.data(),
-                                     obs_world.data(), obs_uv.data(), world.data(), cam_q.data(), cam_t.data(), frozen.data(),
-                                     frame_q.data(), frame_t.data(), huber_a, half_rho.data(), &summary);
+      last_status_ = cc_rig_optimize(&options, device_, (int64_t)C, (int64_t)F, (int64_t)Pn, offsets.data(), obs_cam,
+                                     obs_world, obs_uv, world.data(), cam_q.data(), cam_t.data(), frozen.data(),
+                                     frame_q.data(), frame_t.data(), huber_a, half_rho, &summary);
     }
     if (last_status_ == CC_ERR_NO_DEVICE || last_status_ == CC_ERR_HIP || last_status_ == CC_ERR_BAD_ARGUMENT || last_status_ == CC_ERR_COMM)
       throw std::runtime_error(std::string("ExtrinsicsCalibrator::Optimize: ") + cc_last_error());  // no silent CPU path
@@ -126,12 +175,22 @@ void ExtrinsicsCalibrator::Optimize() {
       std::printf("%4d %.6e %11.2e %10.2e %10.2e %9.2e %9.2e\n", i + 1, log[i].cost, log[i].cost_change, log[i].gradient_max_norm,
                   log[i].step_norm, log[i].relative_decrease, log[i].radius);
   }
+  last_timing_ms_[1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lib).count();
+  const auto t_back = std::chrono::steady_clock::now();
   // per-observation robustified half_rho (extrinsics_calibrator.cpp:219-225)
-  for (size_t f = 0, k = 0; f < F; ++f)
-    for (auto& o : frames_[f].sightings) o.half_rho = half_rho[k++];
+  if (N > 0 && C > 0 && F > 0)
+    over_frames([&](size_t f0, size_t f1) {
+      for (size_t f = f0; f < f1; ++f) {
+        size_t k = (size_t)offsets[f];
+        for (auto& o : frames_[f].sightings) o.half_rho = half_rho[k++];
+      }
+    });
   // poses back through float (extrinsics_calibrator.cpp:228-256)
   for (size_t i = 0; i < C; ++i) cameras_[i] = QuaternionTranslationToAffine(&cam_q[4 * i], &cam_t[3 * i]);
   for (size_t i = 0; i < F; ++i) frames_[i].pose = QuaternionTranslationToAffine(&frame_q[4 * i], &frame_t[3 * i]);
+  const auto t_end = std::chrono::steady_clock::now();
+  last_timing_ms_[2] = std::chrono::duration<double, std::milli>(t_end - t_back).count();
+  last_timing_ms_[3] = std::chrono::duration<double, std::milli>(t_end - t_call).count();
 }
 
 // ---- JSON wire format (reference: extrinsics_calibrator.cpp:268-413) -----------------------------

@@ -2,6 +2,7 @@
 // reference's calibrator::ExtrinsicsCalibrator (src/extrinsics_calibrator.hh:8-70). Optimize runs on
 // the GPU through cc_rig_optimize (include/cc_solver.h) instead of Ceres.
 #pragma once
+#include <cstdint>
 #include <set>
 #include <string>
 #include <vector>
@@ -45,6 +46,9 @@ class ExtrinsicsCalibrator {
   int LastStatus() const { return last_status_; }
   int LastIterations() const { return last_iterations_; }
   double LastFinalCost() const { return last_final_cost_; }
+  /// Wall milliseconds of the last Optimize(): [0] flattening the frames into the C ABI's arrays, [1] cc_rig_optimize
+  /// (regrouping, upload, solve, per-observation costs, read-back), [2] writing costs and poses back, [3] the whole call.
+  const double* LastTimingMs() const { return last_timing_ms_; }
   /// Bookkeeping introspection used by the tests (ids are what the reference's private members hold).
   size_t NumCameras() const { return cameras_.size(); }
   size_t NumObservationFrames() const { return frames_.size(); }
@@ -84,6 +88,21 @@ class ExtrinsicsCalibrator {
   int last_status_{0};
   int last_iterations_{0};
   double last_final_cost_{0.0};
+  // flat copies of the observations for the C ABI, kept between calls (grow-only: a caller that optimises again after adding
+  // frames -- the reference's workflow -- does not fault in 200 MB of fresh vectors per call at BASELINE configs[4] size)
+  // (not copied with the object; handed to the next object when this one goes: extrinsics_calibrator.cpp)
+  struct FlatArrays {
+    std::vector<uint32_t> cam;
+    std::vector<uint64_t> world;
+    std::vector<float> uv;
+    std::vector<double> rho;
+    FlatArrays() = default;
+    FlatArrays(const FlatArrays&) {}
+    FlatArrays& operator=(const FlatArrays&) { return *this; }
+    ~FlatArrays();
+  };
+  FlatArrays flat_;
+  double last_timing_ms_[4]{0, 0, 0, 0};
 };
 
 }  // namespace calibrator

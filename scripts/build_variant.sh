@@ -11,5 +11,5 @@ objs=""
 for o in cc_intrinsics.o cc_intrinsics_persist.o cc_rig.o cc_zhang.o cc_points.o cc_common.o cc_comm.o data_generator.o rig_scenario.o geometry.o; do
   if [ "$o" = "${file%.hip}.o" ]; then objs="$objs /tmp/cc_variant_$name.o"; else objs="$objs $o"; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../scripts/ablate_build/libcc_$name.so $objs -ldl -Wl,-rpath,/opt/rocm/lib
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../scripts/ablate_build/libcc_$name.so $objs -ldl -pthread -Wl,-rpath,/opt/rocm/lib
 echo scripts/ablate_build/libcc_$name.so

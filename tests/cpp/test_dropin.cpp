@@ -15,6 +15,7 @@
 #include "calibrator.hh"
 #include "data_generator.hh"
 #include "extrinsics_calibrator.hh"
+#include "cc_harness.h"
 
 using namespace calibrator;
 
@@ -234,7 +235,52 @@ static int class_surface(int frames, int pts, int reps) {
   return 0;
 }
 
+// ---- 4. the same for the rig: ExtrinsicsCalibrator::Optimize, every camera sees every point (--class-surface-rig C F M REPS) ----
+static int class_surface_rig(int num_cams, int num_frames, int pts_per_frame, int reps) {
+  // the product harness's scenario (include/cc_harness.h: the reference's rig test at any size) -- what bench.py's `configs` solve
+  const size_t C = (size_t)num_cams, F = (size_t)num_frames, M = (size_t)pts_per_frame, N = C * F * M;
+  std::vector<float> cam_T(16 * C), cam_T_true(16 * C), frame_T(16 * F), world(3 * F * M), uv(2 * N);
+  std::vector<uint32_t> obs_cam(N);
+  std::vector<uint64_t> obs_world(N);
+  cc_rig_scenario(num_cams, num_frames, pts_per_frame, 0u, cam_T.data(), cam_T_true.data(), frame_T.data(), world.data(), obs_cam.data(),
+                  obs_world.data(), uv.data());
+  auto affine = [](const float* T16) { Eigen::Affine3f T; for (int i = 0; i < 16; ++i) T.matrix()(i % 4, i / 4) = T16[i]; return T; };
+  ExtrinsicsCalibrator base;
+  base.SetVerbose(false);
+  for (size_t c = 0; c < C; ++c) base.AddCameraTRig(affine(&cam_T[16 * c]), c == 0);
+  for (size_t f = 0, k = 0; f < F; ++f) {
+    const size_t fid = base.AddObservationFrame(affine(&frame_T[16 * f]));
+    for (size_t j = 0; j < M; ++j) base.AddWorldPoint(fid, Point3D(world[3 * (f * M + j)], world[3 * (f * M + j) + 1], world[3 * (f * M + j) + 2]));
+    for (size_t j = 0; j < M * C; ++j, ++k) base.AddObservation(obs_cam[k], (size_t)obs_world[k], Point2D(uv[2 * k], uv[2 * k + 1]));
+  }
+  auto median = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
+  std::vector<double> parts[4], again[4];
+  int iters = 0, iters_again = 0;
+  double first_ms = 0.0;
+  for (int r = 0; r < reps + 1; ++r) {
+    ExtrinsicsCalibrator c = base;   // (a copy of the starting state; the copy is outside the clock)
+    c.Optimize();
+    if (r == 0) { first_ms = c.LastTimingMs()[3]; continue; }   // (first call: allocations, code object load)
+    iters = c.LastIterations();
+    for (int k = 0; k < 4; ++k) parts[k].push_back(c.LastTimingMs()[k]);
+    c.Optimize();                    // the same object again: its flat arrays are warm, the solve starts at its optimum
+    iters_again = c.LastIterations();
+    for (int k = 0; k < 4; ++k) again[k].push_back(c.LastTimingMs()[k]);
+  }
+  std::printf("{\"call\": \"ExtrinsicsCalibrator::Optimize through the C++ class\", \"cams\": %d, \"frames\": %d, \"pts\": %d, \"observations\": %lld, "
+              "\"calls\": %d, \"first_call_ms\": %.3f, "
+              "\"fresh_object\": {\"lm_iterations\": %d, \"wall_ms_median\": %.3f, \"flatten_ms\": %.3f, \"cc_rig_optimize_ms\": %.3f, \"write_back_ms\": %.3f}, "
+              "\"same_object_again\": {\"lm_iterations\": %d, \"wall_ms_median\": %.3f, \"flatten_ms\": %.3f, \"cc_rig_optimize_ms\": %.3f, \"write_back_ms\": %.3f}}\n",
+              num_cams, num_frames, pts_per_frame, (long long)num_cams * num_frames * pts_per_frame, reps, first_ms,
+              iters, median(parts[3]), median(parts[0]), median(parts[1]), median(parts[2]),
+              iters_again, median(again[3]), median(again[0]), median(again[1]), median(again[2]));
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc >= 2 && std::strcmp(argv[1], "--class-surface-rig") == 0)
+    return class_surface_rig(argc > 2 ? std::atoi(argv[2]) : 4, argc > 3 ? std::atoi(argv[3]) : 400, argc > 4 ? std::atoi(argv[4]) : 300,
+                             argc > 5 ? std::atoi(argv[5]) : 5);
   if (argc >= 2 && std::strcmp(argv[1], "--class-surface") == 0)
     return class_surface(argc > 2 ? std::atoi(argv[2]) : 1000, argc > 3 ? std::atoi(argv[3]) : 500, argc > 4 ? std::atoi(argv[4]) : 20);
   single_camera();
