@@ -117,6 +117,21 @@ def class_surface(frames, points):
         return {"error": str(e)}
 
 
+def class_surface_rig(cams, frames, points):
+    """The same for the rig: ExtrinsicsCalibrator::Optimize at BASELINE configs[3] size through the class (flattening of the
+    per-frame observation lists, cc_rig_optimize with its regrouping / upload / solve / per-observation costs, write-back)."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "test_dropin")
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe, "--class-surface-rig", str(cams), str(frames), str(points), "8"], capture_output=True, text=True, timeout=300)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        return json.loads(line[-1]) if r.returncode == 0 and line else {"error": (r.stdout + r.stderr)[-400:]}
+    except Exception as e:   # (reported, never fatal)
+        return {"error": str(e)}
+
+
 def usable_cores():
     """Host cores this process may actually use: affinity mask and cgroup CPU quota, not the node's count."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -474,6 +489,7 @@ def main():
             "observations_per_sec": n_obs_total * args.steps / elapsed,
             "one_shot_ms_including_upload": e2e_ms,
             "class_surface": class_surface(args.frames, args.points) if world == 1 else None,
+            "class_surface_rig": class_surface_rig(4, 400, 300) if world == 1 and not args.no_configs else None,
             "per_solve_us_per_iteration": {"n_solves": len(per_iter_us), "median": float(np.median(per_iter_us)),
                                            "min": float(np.min(per_iter_us)), "max": float(np.max(per_iter_us))},
             "converged": {"termination": conv["termination"], "final_cost": conv["final_cost"],

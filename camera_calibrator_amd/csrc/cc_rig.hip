@@ -5635,9 +5635,9 @@ void cc_rig_destroy(cc_rig* h) {
   hipSetDevice(h->device);
   bool stream_ok = true;
   if (h->stream) stream_ok = hipStreamSynchronize(h->stream) == hipSuccess;
-  if (h->stream2) {
-    hipStreamSynchronize(h->stream2);
-    hipStreamDestroy(h->stream2);
+  if (h->stream2) {   // (back to the process's stream cache like h->stream: creating and destroying one per handle cost 1.3 ms of every one-shot call)
+    if (hipStreamSynchronize(h->stream2) == hipSuccess) cc::stream_put(h->device, h->stream2);
+    else hipStreamDestroy(h->stream2);
   }
 
   hp.mark("sync");
@@ -5787,7 +5787,7 @@ static int rig_launch(cc_rig* h, RigRun* r, int chunk) {
     // lean workers (sixteen waves a compute unit) + the control workgroup as a launch of its own on a second stream, behind
     // everything rig_begin put on the first
     CC_HIP(hipMemcpyAsync(h->d_cam_backup, h->d.cam, (size_t)h->C * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    if (!h->stream2) CC_HIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    if (!h->stream2) { if (int rc = stream_get(h->device, &h->stream2)) return rc; }
     if (!h->ev_begin) CC_HIP(hipEventCreateWithFlags(&h->ev_begin, hipEventDisableTiming));
     CC_HIP(hipEventRecord(h->ev_begin, h->stream));
     CC_HIP(hipStreamWaitEvent(h->stream2, h->ev_begin, 0));
@@ -5934,10 +5934,14 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
   if (!h || !h->have_state) return fail(CC_ERR_STATE, "cc_rig_solve: no state set");
   if (h->d.kmode && !h->have_intr) return fail(CC_ERR_STATE, "cc_rig_solve: cc_rigk_set_intrinsics has not been called");
   RigRun r;
+  HostPhases hp("cc_rig_solve");
   if (int rc = rig_begin(h, opt, &r)) return rc;
+  hp.mark("begin");
   for (int chunk = 0;; ++chunk) {
     if (int rc = rig_launch(h, &r, chunk)) return rc;
+    if (chunk == 0) hp.mark("launch0");
     if (int rc = rig_wait(h, &r)) return rc;
+    if (chunk == 0) hp.mark("wait0");
     if (r.rerun) {
       // The lean persistent launch could not get every workgroup resident (a device shared with another process, or the
       // control launch not scheduled next to the workers): a wait inside it gave up after 1.3 s. Frame poses go back to
@@ -5958,7 +5962,10 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
     }
     if (r.st.done) break;
   }
-  return rig_finish(h, &r, summary);
+  hp.mark("chunks");
+  const int rc_fin = rig_finish(h, &r, summary);
+  hp.mark("finish");
+  return rc_fin;
 }
 
 int cc_rig_solver_form(cc_rig* h) {

@@ -39,7 +39,13 @@ python scripts/time_big_rig.py 2>/dev/null | grep "^{" > $OUT/rig_big.jsonl
 python scripts/time_rig_sweep_scaling.py 2>/dev/null | grep "^{" > $OUT/rig_sweep_scaling.jsonl
 CC_RIG_SWEEP_FRAME=0 python scripts/time_rig_sweep_scaling.py 2>/dev/null | grep "^{" >> $OUT/rig_sweep_scaling.jsonl
 tests/cpp/test_dropin --class-surface 1000 500 20 > $OUT/class_surface.jsonl
-tests/cpp/test_dropin --class-surface 200 200 20 >> $OUT/class_surface.jsonl
+tests/cpp/test_dropin --class-surface 1000 500 20 >> $OUT/class_surface.jsonl
+tests/cpp/test_dropin --class-surface 200 500 20 >> $OUT/class_surface.jsonl
+tests/cpp/test_dropin --class-surface-rig 4 400 300 8 > $OUT/class_surface_rig.jsonl
+tests/cpp/test_dropin --class-surface-rig 8 2000 500 4 >> $OUT/class_surface_rig.jsonl
+export CC_RIG_HOST_TIMING=1
+(REPS=6 python scripts/time_rig_oneshot.py; REPS=6 C=8 F=2000 M=500 python scripts/time_rig_oneshot.py) 2> $OUT/rig_oneshot_phases.txt | grep "^{" > $OUT/rig_oneshot.jsonl
+unset CC_RIG_HOST_TIMING
 echo "big / scaling / class surface done"
 # stage breakdowns from the timing-only build (wall-clock marks inside the kernels)
 bash scripts/build_variant.sh rigtime cc_rig.hip -DCC_RIG_TIMING > /dev/null 2>&1
