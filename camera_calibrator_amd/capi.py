@@ -83,7 +83,7 @@ EXPORTED_SYMBOLS = [
     "cc_rig_create", "cc_rig_destroy", "cc_rig_set_state", "cc_rig_reset", "cc_rig_solve",
     "cc_rig_get_state", "cc_rig_solver_form", "cc_rig_solver_status", "cc_rig_eval", "cc_rig_optimize", "cc_rig_comm_init", "cc_rig_exchange_export", "cc_rig_exchange_attach", "cc_rigk_create",
     "cc_rigk_set_intrinsics", "cc_rigk_get_intrinsics", "cc_rigk_create_per_camera", "cc_rigk_set_camera_intrinsics",
-    "cc_rigk_get_camera_intrinsics", "cc_zhang_init", "cc_intrinsics_optimize_multi", "cc_rig_optimize_multi",
+    "cc_rigk_get_camera_intrinsics", "cc_zhang_init", "cc_intrinsics_optimize_multi", "cc_rig_optimize_multi", "cc_rig_optimize_frames",
 ]
 # every symbol include/cc_harness.h declares (synthetic-input harness, host code)
 HARNESS_SYMBOLS = [
@@ -354,6 +354,54 @@ def intrinsics_estimate(frame_offsets, uv, xyz, distortion5=None, const_mask=0, 
 
 
 HUBER_A = float(np.float32(3.0) / np.float32(500.0))  # extrinsics_calibrator.cpp:176
+
+
+class ObsLayout(C.Structure):
+    _fields_ = [("stride", C.c_int64), ("camera_offset", C.c_int64), ("world_offset", C.c_int64), ("uv_offset", C.c_int64),
+                ("cost_offset", C.c_int64)]
+
+
+# one sighting as ExtrinsicsCalibrator keeps it (camera, point in frame, global point, normalised image point, cost)
+SIGHTING = np.dtype([("camera", "<u8"), ("point_in_frame", "<u8"), ("world", "<u8"), ("uv", "<f4", (2,)), ("cost", "<f8")])
+
+
+def rig_optimize_frames(n_cams, frame_offsets, obs_cam, obs_world, obs_uv, world_xyz, cam_q, cam_t, cam_frozen,
+                        frame_q, frame_t, huber_a=HUBER_A, options=None, device=0, log_capacity=2048):
+    """cc_rig_optimize_frames: the observations handed over frame by frame as arrays of SIGHTING records (one numpy array per
+    frame, as the C++ class holds one vector per frame); the costs come back inside the records.
+    Returns (cam_q, cam_t, frame_q, frame_t, obs_cost, summary) like rig_optimize."""
+    off = np.ascontiguousarray(frame_offsets, dtype=np.int64)
+    F = len(off) - 1
+    obs_cam, obs_world = np.asarray(obs_cam), np.asarray(obs_world)
+    uv = _f32(obs_uv).reshape(-1, 2)
+    world_xyz = _f32(world_xyz)
+    frames = []
+    for f in range(F):
+        a = np.zeros(int(off[f + 1] - off[f]), dtype=SIGHTING)
+        a["camera"] = obs_cam[off[f]:off[f + 1]]
+        a["world"] = obs_world[off[f]:off[f + 1]]
+        a["uv"] = uv[off[f]:off[f + 1]]
+        a["cost"] = -1.0
+        frames.append(a)
+    ptrs = (C.c_void_p * F)(*[a.ctypes.data if len(a) else None for a in frames])
+    counts = np.ascontiguousarray(np.diff(off), dtype=np.int64)
+    lay = ObsLayout(SIGHTING.itemsize, SIGHTING.fields["camera"][1], SIGHTING.fields["world"][1], SIGHTING.fields["uv"][1],
+                    SIGHTING.fields["cost"][1])
+    frozen = np.ascontiguousarray(cam_frozen, dtype=np.uint8)
+    cam_q, cam_t = _f64(cam_q).copy(), _f64(cam_t).copy()
+    frame_q, frame_t = _f64(frame_q).copy(), _f64(frame_t).copy()
+    opt = options if options is not None else default_options(max_iterations=1000)
+    log = (Iteration * max(1, log_capacity))()
+    s = Summary()
+    s.log = C.cast(log, C.POINTER(Iteration))
+    s.log_capacity = log_capacity
+    _check(lib().cc_rig_optimize_frames(C.byref(opt), C.c_int32(device), C.c_int64(n_cams), C.c_int64(F),
+                                        C.c_int64(world_xyz.size // 3), ptrs, _p(counts, C.c_int64), C.byref(lay),
+                                        _p(world_xyz, C.c_float), _p(cam_q, C.c_double), _p(cam_t, C.c_double),
+                                        _p(frozen, C.c_uint8), _p(frame_q, C.c_double), _p(frame_t, C.c_double),
+                                        C.c_double(huber_a), C.byref(s)))
+    cost = np.concatenate([a["cost"] for a in frames]) if F else np.zeros(0)
+    return cam_q, cam_t, frame_q, frame_t, cost, _summary_dict(s, log)
 
 
 class RigProblem:

@@ -4722,6 +4722,7 @@ struct cc_rig {
   bool sweep_adjoint = true; // poses-only sweep: 7-column Gram + per-group assembly (k_rig_sweep_adj); CC_RIG_SWEEP_MFMA=1: the 13-column matrix-pipe sweep
   int kmode = 0;
   std::vector<int64_t> perm;  // sorted position -> caller's observation index
+  bool perm_inverse = false;   // perm[k] = regrouped position of the caller's observation k (records) instead of perm[i] = caller's index of position i
   std::vector<std::pair<void*, size_t>> allocs;   // the chunks dev_alloc carves buffers from (cc::pool_alloc: recycled between handles)
   char* chunk_cur = nullptr;
   size_t chunk_left = 0;
@@ -5298,8 +5299,77 @@ struct RigCreateGuard {  // releases a half-built handle on every early return
 
 extern "C" {
 
+}  // extern "C"
+
+namespace cc {
+// Where cc_rig_create reads the observations: three flat arrays (cc_rig_create), or records the caller keeps frame by frame
+// (cc_rig_optimize_frames: ExtrinsicsCalibrator's per-frame lists, read in place).
+struct RigObsSource {
+  const uint32_t* cam = nullptr; const uint64_t* world = nullptr; const float* uv = nullptr;
+  const void* const* frames = nullptr; cc_obs_layout lay{};
+};
+struct RigFlatFrame {
+  const uint32_t* cam; const uint64_t* world; const float* uv;
+  RigFlatFrame(const RigObsSource& s, int64_t, int64_t base) : cam(s.cam + base), world(s.world + base), uv(s.uv + 2 * base) {}
+  uint64_t camera(int64_t i) const { return cam[i]; }
+  uint64_t point(int64_t i) const { return world[i]; }
+  void pixel(int64_t i, float* o) const { o[0] = uv[2 * i]; o[1] = uv[2 * i + 1]; }
+};
+struct RigRecordFrame {
+  const unsigned char* p; int64_t stride, oc, ow, ou;
+  RigRecordFrame(const RigObsSource& s, int64_t f, int64_t)
+      : p(static_cast<const unsigned char*>(s.frames[f])), stride(s.lay.stride), oc(s.lay.camera_offset), ow(s.lay.world_offset), ou(s.lay.uv_offset) {}
+  uint64_t camera(int64_t i) const { uint64_t v; std::memcpy(&v, p + i * stride + oc, 8); return v; }
+  uint64_t point(int64_t i) const { uint64_t v; std::memcpy(&v, p + i * stride + ow, 8); return v; }
+  void pixel(int64_t i, float* o) const { std::memcpy(o, p + i * stride + ou, 8); }
+};
+struct RigRegroupPart { std::vector<int32_t> gframe, gcam, per_frame; std::vector<int64_t> gend; int64_t bad = -1; int bad_kind = 0; };
+
+// frames [f0, f1) of the regrouping pass (one host thread): counting sort by camera inside each frame (stable: observation
+// order is kept within a group); only the cameras that occur in the frame are visited, so thousands of idle cameras cost
+// nothing. Ids are checked on the way; the regrouped pixels / world indices go straight into the staging block.
+template <class Frame, bool INV>
+static void rig_regroup_part(const RigObsSource& src, int64_t C, int64_t n_world, const int64_t* off, int64_t f0, int64_t f1,
+                             int64_t* perm, float* uv_s, int32_t* widx_s, uint8_t* seen_p, RigRegroupPart& L) {
+  std::vector<int64_t> cnt((size_t)C, 0), start((size_t)C, 0);
+  std::vector<uint32_t> present;
+  for (int64_t f = f0; f < f1; ++f) {
+    const int64_t base = off[f], n = off[f + 1] - off[f];
+    if (n == 0) { L.per_frame.push_back(0); continue; }
+    const Frame fr(src, f, base);
+    present.clear();
+    for (int64_t i = 0; i < n; ++i) {
+      const uint64_t c = fr.camera(i);
+      if (c >= (uint64_t)C) { L.bad = base + i; L.bad_kind = 0; return; }
+      if (fr.point(i) >= (uint64_t)n_world) { L.bad = base + i; L.bad_kind = 1; return; }
+      if (cnt[c]++ == 0) present.push_back((uint32_t)c);
+    }
+    std::sort(present.begin(), present.end());
+    int64_t pos = base;
+    for (uint32_t c : present) {
+      start[c] = pos;
+      L.gframe.push_back((int32_t)f);
+      L.gcam.push_back((int32_t)c);
+      __atomic_store_n(seen_p + c, (uint8_t)1, __ATOMIC_RELAXED);
+      pos += cnt[c];
+      L.gend.push_back(pos);
+    }
+    L.per_frame.push_back((int32_t)present.size());
+    for (int64_t i = 0; i < n; ++i) {
+      const int64_t dst = start[fr.camera(i)]++;
+      if (INV) perm[base + i] = dst; else perm[dst] = base + i;   // (records: where observation i of the frame went -- the costs are written record by record)
+      fr.pixel(i, uv_s + 2 * dst);
+      widx_s[dst] = (int32_t)fr.point(i);
+    }
+    for (uint32_t c : present) cnt[c] = 0;
+  }
+}
+}  // namespace cc
+
+extern "C" {
+
 static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world, const int64_t* off,
-                           const uint32_t* obs_cam, const uint64_t* obs_world, const float* obs_uv,
+                           const cc::RigObsSource& src,
                            const float* world_xyz, const uint8_t* cam_frozen, double huber_a, int kmode, cc_rig** out) {
   using namespace cc;
   HostPhases hp("cc_rig_create");
@@ -5311,7 +5381,15 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   // device-side indices are 32-bit (world point, group, camera) and launch grids are unsigned
   if (C > (1 << 20) || F >= INT32_MAX || n_world >= INT32_MAX || N >= ((int64_t)1 << 40))
     return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: problem too large (cameras < 2^20, frames and world points < 2^31)");
-  if (N > 0 && (!obs_cam || !obs_world || !obs_uv || !world_xyz)) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: NULL arrays");
+  if (N > 0 && ((!src.frames && (!src.cam || !src.world || !src.uv)) || !world_xyz)) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: NULL arrays");
+  if (src.frames) {
+    const cc_obs_layout& l = src.lay;
+    if (l.stride < 8 || l.camera_offset < 0 || l.world_offset < 0 || l.uv_offset < 0 || l.camera_offset + 8 > l.stride ||
+        l.world_offset + 8 > l.stride || l.uv_offset + 8 > l.stride || (l.cost_offset >= 0 && l.cost_offset + 8 > l.stride))
+      return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_optimize_frames: record layout does not fit its stride");
+    for (int64_t f = 0; f < F; ++f)
+      if (off[f + 1] > off[f] && !src.frames[f]) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_optimize_frames: frame %lld has no records", (long long)f);
+  }
   hp.mark("checks");   // (camera and world point ids: inside the regrouping pass)
   if (int rc = select_device(device)) return rc;
   cc_rig* h = new cc_rig();
@@ -5347,43 +5425,14 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
     const int parts = C <= 65536 ? parallel_parts(N, (int64_t)1 << 17) : 1;
     std::vector<int64_t> pf((size_t)parts + 1, 0);
     if (int rc = cc_partition_frames(F, off, parts, pf.data())) return rc;
-    struct Part { std::vector<int32_t> gframe, gcam, per_frame; std::vector<int64_t> gend; int64_t bad = -1; int bad_kind = 0; };
+    using Part = RigRegroupPart;
     std::vector<Part> part((size_t)parts);
     int64_t* perm = h->perm.data();
+    h->perm_inverse = src.frames != nullptr;
     uint8_t* seen_p = seen.data();
     parallel_tasks(parts, [&](int t) {
-      Part& L = part[(size_t)t];
-      // counting sort by camera inside each frame (stable: observation order is kept within a group); only the
-      // cameras that occur in the frame are visited, so thousands of idle cameras cost nothing
-      std::vector<int64_t> cnt((size_t)C, 0), start((size_t)C, 0);
-      std::vector<uint32_t> present;
-      for (int64_t f = pf[(size_t)t]; f < pf[(size_t)t + 1]; ++f) {
-        present.clear();
-        for (int64_t k = off[f]; k < off[f + 1]; ++k) {
-          const uint32_t c = obs_cam[k];
-          if (c >= (uint32_t)C) { L.bad = k; L.bad_kind = 0; return; }
-          if (obs_world[k] >= (uint64_t)n_world) { L.bad = k; L.bad_kind = 1; return; }
-          if (cnt[c]++ == 0) present.push_back(c);
-        }
-        std::sort(present.begin(), present.end());
-        int64_t pos = off[f];
-        for (uint32_t c : present) {
-          start[c] = pos;
-          L.gframe.push_back((int32_t)f);
-          L.gcam.push_back((int32_t)c);
-          __atomic_store_n(seen_p + c, (uint8_t)1, __ATOMIC_RELAXED);
-          pos += cnt[c];
-          L.gend.push_back(pos);
-        }
-        L.per_frame.push_back((int32_t)present.size());
-        for (int64_t k = off[f]; k < off[f + 1]; ++k) {
-          const int64_t dst = start[obs_cam[k]]++;
-          perm[dst] = k;
-          uv_s[2 * dst] = obs_uv[2 * k]; uv_s[2 * dst + 1] = obs_uv[2 * k + 1];
-          widx_s[dst] = (int32_t)obs_world[k];
-        }
-        for (uint32_t c : present) cnt[c] = 0;
-      }
+      if (src.frames) rig_regroup_part<RigRecordFrame, true>(src, C, n_world, off, pf[(size_t)t], pf[(size_t)t + 1], perm, uv_s, widx_s, seen_p, part[(size_t)t]);
+      else rig_regroup_part<RigFlatFrame, false>(src, C, n_world, off, pf[(size_t)t], pf[(size_t)t + 1], perm, uv_s, widx_s, seen_p, part[(size_t)t]);
     });
     for (const Part& L : part)   // (parts are in frame order: the first one with a bad id holds the first bad observation)
       if (L.bad >= 0)
@@ -5566,23 +5615,27 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
 int cc_rig_create(int32_t device, int64_t C, int64_t F, int64_t n_world, const int64_t* off,
                   const uint32_t* obs_cam, const uint64_t* obs_world, const float* obs_uv,
                   const float* world_xyz, const uint8_t* cam_frozen, double huber_a, cc_rig** out) {
-  return rig_create_impl(device, C, F, n_world, off, obs_cam, obs_world, obs_uv, world_xyz, cam_frozen, huber_a, cc::RIG_K_NONE, out);
+  cc::RigObsSource src;
+  src.cam = obs_cam; src.world = obs_world; src.uv = obs_uv;
+  return rig_create_impl(device, C, F, n_world, off, src, world_xyz, cam_frozen, huber_a, cc::RIG_K_NONE, out);
 }
 
 // EXTENSION: the same handle with 9 intrinsics shared by all cameras; obs_uv in pixels
 int cc_rigk_create(int32_t device, int64_t C, int64_t F, int64_t n_world, const int64_t* off,
                    const uint32_t* obs_cam, const uint64_t* obs_world, const float* obs_uv_pixels,
                    const float* world_xyz, const uint8_t* cam_frozen, double huber_a, cc_rig** out) {
-  return rig_create_impl(device, C, F, n_world, off, obs_cam, obs_world, obs_uv_pixels, world_xyz, cam_frozen, huber_a,
-                         cc::RIG_K_SHARED, out);
+  cc::RigObsSource src;
+  src.cam = obs_cam; src.world = obs_world; src.uv = obs_uv_pixels;
+  return rig_create_impl(device, C, F, n_world, off, src, world_xyz, cam_frozen, huber_a, cc::RIG_K_SHARED, out);
 }
 
 // EXTENSION: one set of 9 intrinsics PER CAMERA (BASELINE.json configs[4]: "full intrinsics+extrinsics co-optimisation")
 int cc_rigk_create_per_camera(int32_t device, int64_t C, int64_t F, int64_t n_world, const int64_t* off,
                               const uint32_t* obs_cam, const uint64_t* obs_world, const float* obs_uv_pixels,
                               const float* world_xyz, const uint8_t* cam_frozen, double huber_a, cc_rig** out) {
-  return rig_create_impl(device, C, F, n_world, off, obs_cam, obs_world, obs_uv_pixels, world_xyz, cam_frozen, huber_a,
-                         cc::RIG_K_PER_CAMERA, out);
+  cc::RigObsSource src;
+  src.cam = obs_cam; src.world = obs_world; src.uv = obs_uv_pixels;
+  return rig_create_impl(device, C, F, n_world, off, src, world_xyz, cam_frozen, huber_a, cc::RIG_K_PER_CAMERA, out);
 }
 
 // camera < 0: every set (the one shared set, or all per-camera sets)
@@ -6020,7 +6073,8 @@ int cc_rig_get_state(cc_rig* h, double* cam_q, double* cam_t, double* frame_q, d
     CC_HIP(hipStreamSynchronize(h->stream));
     const int64_t* perm = h->perm.data();
     parallel_ranges(h->N, (int64_t)1 << 18, [&](int, int64_t a, int64_t b) {
-      for (int64_t i = a; i < b; ++i) obs_cost[perm[i]] = sorted[i];
+      if (h->perm_inverse) { for (int64_t i = a; i < b; ++i) obs_cost[i] = sorted[perm[i]]; }
+      else { for (int64_t i = a; i < b; ++i) obs_cost[perm[i]] = sorted[i]; }
     });
   }
   return CC_OK;
@@ -6204,6 +6258,67 @@ int cc_rig_optimize(const cc_options* opt, int32_t device, int64_t C, int64_t F,
 // Multi-device rig solve driven by ONE host thread (SURVEY.md 8(b) thread model; cf. cc_intrinsics_optimize_multi):
 // frames sharded contiguously by observation count, cameras and world points replicated, mailboxes wired inside the
 // process, every device's chunk enqueued before any is waited for. A device id may appear several times.
+int cc_rig_optimize_frames(const cc_options* opt, int32_t device, int64_t C, int64_t F, int64_t n_world,
+                           void* const* frame_records, const int64_t* counts, const cc_obs_layout* layout,
+                           const float* world_xyz, double* cam_q, double* cam_t, const uint8_t* cam_frozen,
+                           double* frame_q, double* frame_t, double huber_a, cc_summary* summary) {
+  using namespace cc;
+  if (F < 1 || !frame_records || !counts || !layout) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_optimize_frames: bad arguments");
+  HostPhases hp("cc_rig_optimize_frames");
+  std::vector<int64_t> off((size_t)F + 1, 0);
+  for (int64_t f = 0; f < F; ++f) {
+    if (counts[f] < 0) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_optimize_frames: negative count");
+    off[(size_t)f + 1] = off[(size_t)f] + counts[f];
+  }
+  RigObsSource src;
+  src.frames = const_cast<const void* const*>(frame_records);
+  src.lay = *layout;
+  cc_rig* h = nullptr;
+  int rc = rig_create_impl(device, C, F, n_world, off.data(), src, world_xyz, cam_frozen, huber_a, RIG_K_NONE, &h);
+  if (rc) return rc;
+  hp.mark("create");
+  rc = cc_rig_set_state(h, cam_q, cam_t, frame_q, frame_t);
+  cc_options o;
+  if (opt) o = *opt; else { cc_options_init(&o); o.max_iterations = 1000; }  // extrinsics_calibrator.cpp:211
+  o.use_graph = 0;
+  if (!rc) rc = cc_rig_solve(h, &o, summary);
+  hp.mark("solve");
+  if (!rc) rc = cc_rig_get_state(h, cam_q, cam_t, frame_q, frame_t, nullptr);
+  if (!rc && layout->cost_offset >= 0 && h->N > 0) {
+    // per-observation costs (extrinsics_calibrator.cpp:219-225) through the pinned block, then into the caller's records on
+    // several host threads (a frame's observations stay inside the frame's range of the regrouped order)
+    rc = [&]() -> int {
+      LmCtl c;
+      if (int r2 = rig_read_ctl(h, &c)) return r2;
+      hipLaunchKernelGGL(k_rig_obs_cost, dim3((unsigned)h->NG), dim3(256), 0, h->stream, h->d, c.cur & 1, h->d_cost);
+      CC_HIP(hipGetLastError());
+      bool st_cached = false;
+      double* sorted = static_cast<double*>(staging_get((size_t)h->N * sizeof(double), &st_cached));
+      if (!sorted) return fail(CC_ERR_HIP, "cc_rig_optimize_frames: pinned staging memory could not be allocated");
+      struct StGuard { void* p; hipStream_t s; ~StGuard() { (void)hipStreamSynchronize(s); staging_put(p); } } stg{sorted, h->stream};
+      CC_HIP(hipMemcpyAsync(sorted, h->d_cost, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      CC_HIP(hipStreamSynchronize(h->stream));
+      const int64_t* perm = h->perm.data();
+      const int parts = parallel_parts(h->N, (int64_t)1 << 17);
+      std::vector<int64_t> pf((size_t)parts + 1, 0);
+      if (int r2 = cc_partition_frames(F, off.data(), parts, pf.data())) return r2;
+      const int64_t stride = layout->stride, oc = layout->cost_offset;
+      parallel_tasks(parts, [&](int t) {
+        // record after record (the inverse permutation: sequential stores, the reads stay inside the frame's range of `sorted`)
+        for (int64_t f = pf[(size_t)t]; f < pf[(size_t)t + 1]; ++f) {
+          unsigned char* rec = static_cast<unsigned char*>(frame_records[f]) + oc;
+          for (int64_t k = off[(size_t)f]; k < off[(size_t)f + 1]; ++k, rec += stride) std::memcpy(rec, &sorted[perm[k]], sizeof(double));
+        }
+      });
+      return CC_OK;
+    }();
+  }
+  hp.mark("get_state");
+  cc_rig_destroy(h);
+  hp.mark("destroy");
+  return rc;
+}
+
 int cc_rig_optimize_multi(const cc_options* opt, int32_t n_devices, const int32_t* devices, int64_t C, int64_t F,
                           int64_t n_world, const int64_t* off, const uint32_t* obs_cam, const uint64_t* obs_world,
                           const float* obs_uv, const float* world_xyz, double* cam_q, double* cam_t,

@@ -92,25 +92,26 @@ void ExtrinsicsCalibrator::Optimize() {
   for (size_t i = 0; i < C; ++i) AffineToQuaternionTranslation(cameras_[i], &cam_q[4 * i], &cam_t[3 * i]);
   for (size_t i = 0; i < F; ++i) AffineToQuaternionTranslation(frames_[i].pose, &frame_q[4 * i], &frame_t[3 * i]);
   std::vector<float> world(3 * Pn);
-  for (size_t i = 0; i < Pn; ++i) {
-    const PointRef& info = point_refs_[i];
-    const Point3D& p = frames_[info.frame].points[info.point_in_frame];
-    world[3 * i] = p.x(); world[3 * i + 1] = p.y(); world[3 * i + 2] = p.z();
+  {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t parts = Pn < ((size_t)1 << 17) ? 1 : std::min<size_t>({(size_t)16, hw ? (size_t)hw : 4, Pn >> 16});
+    auto fill = [&](size_t a, size_t b) {
+      for (size_t i = a; i < b; ++i) {
+        const PointRef& info = point_refs_[i];
+        const Point3D& p = frames_[info.frame].points[info.point_in_frame];
+        world[3 * i] = p.x(); world[3 * i + 1] = p.y(); world[3 * i + 2] = p.z();
+      }
+    };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < parts; ++t) th.emplace_back(fill, Pn * t / parts, Pn * (t + 1) / parts);
+    fill(0, Pn / parts);
+    for (auto& x : th) x.join();
   }
   std::vector<int64_t> offsets(F + 1, 0);
   for (size_t f = 0; f < F; ++f) offsets[f + 1] = offsets[f] + (int64_t)frames_[f].sightings.size();
   const size_t N = (size_t)offsets[F];
-  if (flat_.cam.size() < N) {
-    // a fresh object (the reference's workflow may build one per call): take over the arrays the last object left behind
-    std::lock_guard<std::mutex> lk(g_flat_mu);
-    if (g_flat_cam.size() > flat_.cam.size()) { flat_.cam.swap(g_flat_cam); flat_.world.swap(g_flat_world); flat_.uv.swap(g_flat_uv); flat_.rho.swap(g_flat_rho); }
-  }
-  if (flat_.cam.size() < N) { flat_.cam.resize(N); flat_.world.resize(N); flat_.uv.resize(2 * N); flat_.rho.resize(N); }
-  uint32_t* obs_cam = flat_.cam.data();
-  uint64_t* obs_world = flat_.world.data();
-  float* obs_uv = flat_.uv.data();
-  double* half_rho = flat_.rho.data();   // (cc_rig_optimize writes every entry)
-  // frames in contiguous ranges of about equal observation counts, one host thread each
+  const bool several = devices_.size() > 1;
+  // frames in contiguous ranges of about equal observation counts, one host thread each (flattening for several devices)
   std::vector<size_t> part_first{0};
   {
     const unsigned hw = std::thread::hardware_concurrency();
@@ -126,18 +127,35 @@ void ExtrinsicsCalibrator::Optimize() {
     fn(part_first[0], part_first[1]);
     for (auto& x : th) x.join();
   };
-  over_frames([&](size_t f0, size_t f1) {
-    for (size_t f = f0; f < f1; ++f) {
-      size_t k = (size_t)offsets[f];
-      for (const auto& o : frames_[f].sightings) {
-        obs_cam[k] = (uint32_t)o.camera;
-        obs_world[k] = (uint64_t)o.point_global;
-        obs_uv[2 * k] = o.normalised.x();
-        obs_uv[2 * k + 1] = o.normalised.y();
-        ++k;
-      }
+  uint32_t* obs_cam = nullptr;
+  uint64_t* obs_world = nullptr;
+  float* obs_uv = nullptr;
+  double* half_rho = nullptr;
+  if (several) {
+    // several devices: flat copies of the observations for cc_rig_optimize_multi, kept between calls
+    if (flat_.cam.size() < N) {
+      // a fresh object (the reference's workflow may build one per call): take over the arrays the last object left behind
+      std::lock_guard<std::mutex> lk(g_flat_mu);
+      if (g_flat_cam.size() > flat_.cam.size()) { flat_.cam.swap(g_flat_cam); flat_.world.swap(g_flat_world); flat_.uv.swap(g_flat_uv); flat_.rho.swap(g_flat_rho); }
     }
-  });
+    if (flat_.cam.size() < N) { flat_.cam.resize(N); flat_.world.resize(N); flat_.uv.resize(2 * N); flat_.rho.resize(N); }
+    obs_cam = flat_.cam.data();
+    obs_world = flat_.world.data();
+    obs_uv = flat_.uv.data();
+    half_rho = flat_.rho.data();   // (cc_rig_optimize_multi writes every entry)
+    over_frames([&](size_t f0, size_t f1) {
+      for (size_t f = f0; f < f1; ++f) {
+        size_t k = (size_t)offsets[f];
+        for (const auto& o : frames_[f].sightings) {
+          obs_cam[k] = (uint32_t)o.camera;
+          obs_world[k] = (uint64_t)o.point_global;
+          obs_uv[2 * k] = o.normalised.x();
+          obs_uv[2 * k + 1] = o.normalised.y();
+          ++k;
+        }
+      }
+    });
+  }
   std::vector<uint8_t> frozen(C, 0);
   for (size_t id : frozen_) if (id < C) frozen[id] = 1;
   last_timing_ms_[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
@@ -159,9 +177,24 @@ void ExtrinsicsCalibrator::Optimize() {
                                            obs_cam, obs_world, obs_uv, world.data(), cam_q.data(), cam_t.data(),
                                            frozen.data(), frame_q.data(), frame_t.data(), huber_a, half_rho, &summary);
     } else {
-      last_status_ = cc_rig_optimize(&options, device_, (int64_t)C, (int64_t)F, (int64_t)Pn, offsets.data(), obs_cam,
-                                     obs_world, obs_uv, world.data(), cam_q.data(), cam_t.data(), frozen.data(),
-                                     frame_q.data(), frame_t.data(), huber_a, half_rho, &summary);
+      // one device: the library reads the per-frame lists of sightings where they are and writes the costs into them
+      // (cc_rig_optimize_frames) -- no flat copies, no write-back loop on this side
+      using Sighting = Frame::Sighting;
+      static_assert(sizeof(size_t) == 8 && sizeof(Point2D) == 2 * sizeof(float), "record fields as cc_obs_layout reads them");
+      std::vector<void*> records(F);
+      std::vector<int64_t> counts(F);
+      for (size_t f = 0; f < F; ++f) { records[f] = frames_[f].sightings.data(); counts[f] = (int64_t)frames_[f].sightings.size(); }
+      Sighting probe{};
+      const char* p0 = reinterpret_cast<const char*>(&probe);
+      cc_obs_layout lay;
+      lay.stride = (int64_t)sizeof(Sighting);
+      lay.camera_offset = reinterpret_cast<const char*>(&probe.camera) - p0;
+      lay.world_offset = reinterpret_cast<const char*>(&probe.point_global) - p0;
+      lay.uv_offset = reinterpret_cast<const char*>(&probe.normalised) - p0;
+      lay.cost_offset = reinterpret_cast<const char*>(&probe.half_rho) - p0;
+      last_status_ = cc_rig_optimize_frames(&options, device_, (int64_t)C, (int64_t)F, (int64_t)Pn, records.data(), counts.data(), &lay,
+                                            world.data(), cam_q.data(), cam_t.data(), frozen.data(), frame_q.data(), frame_t.data(),
+                                            huber_a, &summary);
     }
     if (last_status_ == CC_ERR_NO_DEVICE || last_status_ == CC_ERR_HIP || last_status_ == CC_ERR_BAD_ARGUMENT || last_status_ == CC_ERR_COMM)
       throw std::runtime_error(std::string("ExtrinsicsCalibrator::Optimize: ") + cc_last_error());  // no silent CPU path
@@ -178,7 +211,7 @@ void ExtrinsicsCalibrator::Optimize() {
   last_timing_ms_[1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lib).count();
   const auto t_back = std::chrono::steady_clock::now();
   // per-observation robustified half_rho (extrinsics_calibrator.cpp:219-225)
-  if (N > 0 && C > 0 && F > 0)
+  if (several && N > 0 && C > 0 && F > 0)
     over_frames([&](size_t f0, size_t f1) {
       for (size_t f = f0; f < f1; ++f) {
         size_t k = (size_t)offsets[f];

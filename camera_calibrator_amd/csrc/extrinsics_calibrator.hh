@@ -46,7 +46,7 @@ class ExtrinsicsCalibrator {
   int LastStatus() const { return last_status_; }
   int LastIterations() const { return last_iterations_; }
   double LastFinalCost() const { return last_final_cost_; }
-  /// Wall milliseconds of the last Optimize(): [0] flattening the frames into the C ABI's arrays, [1] cc_rig_optimize
+  /// Wall milliseconds of the last Optimize(): [0] preparing the arguments (several devices: flattening the frames), [1] cc_rig_optimize_frames
   /// (regrouping, upload, solve, per-observation costs, read-back), [2] writing costs and poses back, [3] the whole call.
   const double* LastTimingMs() const { return last_timing_ms_; }
   /// Bookkeeping introspection used by the tests (ids are what the reference's private members hold).

@@ -318,6 +318,20 @@ int cc_rig_optimize(const cc_options* opt, int32_t device, int64_t n_cams, int64
                     double* cam_q, double* cam_t, const uint8_t* cam_frozen, double* frame_q,
                     double* frame_t, double huber_a, double* obs_cost, cc_summary* summary);
 
+/* The same for observations the caller keeps FRAME BY FRAME as arrays of records (ExtrinsicsCalibrator's per-frame lists of
+ * sightings -- camera id, point id, normalised image point, cost -- extrinsics_calibrator.cpp:33-49 fills them): frame f has
+ * counts[f] records starting at frame_records[f], `stride` bytes apart; in a record the camera id and the global world point
+ * id are 64-bit unsigned integers at camera_offset / world_offset, the normalised image point two floats at uv_offset, and
+ * the robustified cost 0.5 rho(||r||^2) is WRITTEN as a double at cost_offset (negative: not written). The library reads the
+ * records in place (no flat copies on the caller's side) and writes the costs back into them. */
+typedef struct cc_obs_layout {
+  int64_t stride, camera_offset, world_offset, uv_offset, cost_offset;
+} cc_obs_layout;
+int cc_rig_optimize_frames(const cc_options* opt, int32_t device, int64_t n_cams, int64_t n_frames, int64_t n_world,
+                           void* const* frame_records, const int64_t* counts, const cc_obs_layout* layout,
+                           const float* world_xyz, double* cam_q, double* cam_t, const uint8_t* cam_frozen,
+                           double* frame_q, double* frame_t, double huber_a, cc_summary* summary);
+
 /* The same over several devices from one host thread (cf. cc_intrinsics_optimize_multi): frames sharded, cameras and
  * world points replicated; ExtrinsicsCalibrator::SetDevices selects it behind the class surface. */
 int cc_rig_optimize_multi(const cc_options* opt, int32_t n_devices, const int32_t* devices, int64_t n_cams,

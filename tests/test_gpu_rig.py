@@ -436,3 +436,36 @@ def test_lean_persistent_solve_that_cannot_get_its_grid_is_rerun_in_the_three_ke
             "print('rerun ok', dt)\n") % root
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CC_RIG_PERSIST_TEST_NO_CONTROL="1"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "rerun ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("cams,frames,pts,ragged", [(2, 50, 4, False), (4, 40, 30, True), (8, 2200, 70, False)])
+def test_frame_by_frame_records_give_the_bits_of_the_flat_arrays(cams, frames, pts, ragged):
+    """cc_rig_optimize_frames (what ExtrinsicsCalibrator::Optimize calls on one device: its per-frame lists of sightings read in
+    place, the costs written back into them) against cc_rig_optimize on the flattened arrays: same regrouping, same bits --
+    also with frames that lost observations (some empty) and with enough observations for several host threads."""
+    sc = po.rig_scenario(cams, frames, pts)
+    cq, ct, fq, ft = _inputs(sc)
+    off, cam, world, uv = sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"]
+    if ragged:
+        rng = np.random.default_rng(3)
+        keep = rng.random(len(cam)) < 0.8
+        keep[off[5]:off[6]] = False          # an empty frame
+        counts = np.array([keep[off[f]:off[f + 1]].sum() for f in range(frames)])
+        off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        cam, world, uv = cam[keep], world[keep], np.asarray(uv).reshape(-1, 2)[keep]
+    args = (cams, off, cam, world, uv, sc["world_xyz"], cq, ct, sc["cam_frozen"], fq, ft)
+    opts = capi.default_options(max_iterations=30)
+    a = capi.rig_optimize(*args, options=opts)
+    b = capi.rig_optimize_frames(*args, options=opts)
+    assert a[5]["iterations"] == b[5]["iterations"] and a[5]["final_cost"] == b[5]["final_cost"]
+    for k in range(5):
+        assert np.array_equal(a[k], b[k])
+
+
+def test_frame_by_frame_records_with_a_bad_id_are_refused():
+    sc = po.rig_scenario(2, 10, 4)
+    cq, ct, fq, ft = _inputs(sc)
+    cam = sc["obs_cam"].copy()
+    cam[17] = 9
+    with pytest.raises(capi.CcError, match="observation 17: camera id out of range"):
+        capi.rig_optimize_frames(2, sc["frame_offsets"], cam, sc["obs_world"], sc["obs_uv"], sc["world_xyz"], cq, ct, sc["cam_frozen"], fq, ft)
