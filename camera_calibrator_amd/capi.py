@@ -75,7 +75,7 @@ class Summary(C.Structure):
 
 # every symbol include/cc_solver.h declares
 EXPORTED_SYMBOLS = [
-    "cc_options_init", "cc_last_error", "cc_version", "cc_device_count",
+    "cc_options_init", "cc_last_error", "cc_version", "cc_device_count", "cc_release_caches",
     "cc_intrinsics_create", "cc_intrinsics_destroy", "cc_intrinsics_set_state",
     "cc_intrinsics_reset", "cc_intrinsics_get_state", "cc_intrinsics_eval",
     "cc_intrinsics_solve", "cc_intrinsics_solver_form", "cc_intrinsics_solver_status", "cc_intrinsics_profile_sweep", "cc_intrinsics_profile_solve", "cc_intrinsics_optimize", "cc_intrinsics_estimate", "cc_intrinsics_estimate_views", "cc_intrinsics_optimize_views", "cc_host_staging_acquire", "cc_host_staging_release", "cc_last_call_timing", "cc_comm_get_unique_id",
@@ -354,6 +354,12 @@ def intrinsics_estimate(frame_offsets, uv, xyz, distortion5=None, const_mask=0, 
 
 
 HUBER_A = float(np.float32(3.0) / np.float32(500.0))  # extrinsics_calibrator.cpp:176
+
+
+def release_caches():
+    """cc_release_caches: hand the library's cached device / pinned memory back (idle pieces only)."""
+    lib().cc_release_caches.restype = None
+    lib().cc_release_caches()
 
 
 class ObsLayout(C.Structure):

@@ -311,6 +311,33 @@ void cc_host_staging_release(void* p) { cc::staging_put(p); }
 void cc_last_call_timing(double out_ms[5]) {
   for (int i = 0; i < 5; ++i) out_ms[i] = cc::last_timing()[i];
 }
+// Gives back what the library keeps between calls for the next one: pooled device blocks, the idle device arena and scratch
+// piece of every device, the idle pinned staging block (cached streams and the 512-byte control blocks stay: they cost
+// nothing). Safe at any time -- a piece a live handle is using is not touched; the next call allocates again.
+void cc_release_caches(void) {
+  std::vector<std::pair<int, void*>> dev;
+  void* pinned = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(cc::g_cache_mu);
+    for (size_t d = 0; d < cc::g_pool.size(); ++d) {
+      for (auto& b : cc::g_pool[d]) dev.emplace_back((int)d, b.p);
+      cc::g_pool[d].clear();
+      cc::g_pool_bytes[d] = 0;
+    }
+    for (size_t d = 0; d < cc::g_arena.size(); ++d)
+      if (!cc::g_arena[d].busy && cc::g_arena[d].p) { dev.emplace_back((int)d, cc::g_arena[d].p); cc::g_arena[d] = {}; }
+    for (size_t d = 0; d < cc::g_scratch.size(); ++d)
+      if (!cc::g_scratch[d].busy && cc::g_scratch[d].p) { dev.emplace_back((int)d, cc::g_scratch[d].p); cc::g_scratch[d] = {}; }
+    if (!cc::g_staging.busy && cc::g_staging.p) { pinned = cc::g_staging.p; cc::g_staging = {}; }
+  }
+  int cur = -1;
+  (void)hipGetDevice(&cur);
+  for (auto& e : dev) { if (hipSetDevice(e.first) == hipSuccess) (void)hipFree(e.second); }
+  if (cur >= 0) (void)hipSetDevice(cur);
+  if (pinned) (void)hipHostFree(pinned);
+  (void)hipGetLastError();
+  cc::rig_release_host_caches();
+}
 const char* cc_version(void) { return "camera_calibrator_amd 0.1 (gfx950, HIP)"; }
 
 int cc_device_count(void) {

@@ -52,6 +52,7 @@ int pool_alloc(int device, size_t bytes, void** out, size_t* got);
 void pool_free(int device, void* p, size_t bytes);
 // fn(part, begin, end) over [0, n) cut into contiguous parts, one host thread each (at most 16, one when n < 2 min_per_part);
 // returns after all parts. parallel_parts gives the number of parts fn will see.
+void rig_release_host_caches();   // (cc_rig.hip: the permutation storage kept for the next rig handle; part of cc_release_caches)
 int parallel_parts(int64_t n, int64_t min_per_part);
 void parallel_tasks(int parts, const std::function<void(int)>& fn);   // fn(0 .. parts-1), one host thread each
 void parallel_ranges(int64_t n, int64_t min_per_part, const std::function<void(int, int64_t, int64_t)>& fn);

@@ -1584,10 +1584,18 @@ __device__ __forceinline__ double block_sum256(double v, double* s4) {
 }
 
 // column sums of gstats[NG][2] and fstats[F][2] -> out[0..3] = cost, q, step2, xnorm2 (all threads after return)
-__device__ __forceinline__ void rig_reduce_stats(const RigDev& P, bool want, double* s16, double* out) {
+// pre_g / pre_f (optional): the rows i = u * 256 + tid, u < 8, of gstats / fstats requested by the caller at kernel start
+// (at most 2048 rows each: the frame form's one row per frame) -- same sums in the same order, one round trip earlier
+__device__ __forceinline__ void rig_reduce_stats(const RigDev& P, bool want, double* s16, double* out, const d2* pre_g = nullptr,
+                                                 const d2* pre_f = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double a[4] = {0, 0, 0, 0};
-  if (want) {
+  if (want && pre_g) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a[0] += pre_g[u].x; a[1] += pre_g[u].y; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a[2] += pre_f[u].x; a[3] += pre_f[u].y; }
+  } else if (want) {
     const d2* gs2 = reinterpret_cast<const d2*>(P.gstats);
     const d2* fs2 = reinterpret_cast<const d2*>(P.fstats);
     // up to sixteen loads in flight per thread: one round trip per 4096 groups instead of one per 256 (the plain loop waited
@@ -1882,6 +1890,23 @@ __device__ __forceinline__ void rig_elim_body(const RigDev& P, char* smem_raw, c
   LmOpts o_in;
   double sh0 = 0.0, sh1 = 0.0;
   if constexpr (!PS) { c_in = *ctl; o_in = *P.opts; sh0 = P.shared_stats[0]; sh1 = P.shared_stats[1]; }
+  // ... and, frame form, the statistics rows themselves (one per frame: eight per thread up to 2048 frames): requested next
+  // to the control block instead of behind it
+  constexpr bool kPre = FM && !PS;
+  d2 pre_g[kPre ? 8 : 1], pre_f[kPre ? 8 : 1];
+  const bool pre = kPre && P.fmode && P.F <= 2048 && !P.comm;
+  if constexpr (kPre) {
+    if (pre) {
+      const d2* gs2 = reinterpret_cast<const d2*>(P.gstats);
+      const d2* fs2 = reinterpret_cast<const d2*>(P.fstats);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t i = u * 256 + tid;
+        pre_g[u] = i < P.F ? gs2[i] : d2{0.0, 0.0};
+        pre_f[u] = i < P.F ? fs2[i] : d2{0.0, 0.0};
+      }
+    }
+  }
   // ---- loads that do not depend on the trust-region decision go out first, under the statistics round trip: the
   // lane's static tables and the group slots of the block's first four frames
   const int CO = P.CO;
@@ -1939,7 +1964,8 @@ __device__ __forceinline__ void rig_elim_body(const RigDev& P, char* smem_raw, c
     if (tid < 4) s_tot[tid] = P.vec_stats[tid];
     __syncthreads();
   } else {
-    rig_reduce_stats(P, pending && ctl->step_valid, s16, s_tot);
+    if (kPre && pre) rig_reduce_stats(P, pending && ctl->step_valid, s16, s_tot, pre_g, pre_f);
+    else rig_reduce_stats(P, pending && ctl->step_valid, s16, s_tot);
   }
   if (tid == 0) {
     LmCtl c = c_in;
@@ -5279,6 +5305,10 @@ extern "C" void cc_rig_destroy(cc_rig* h);
 namespace cc {
 static std::mutex g_perm_mu;
 static std::vector<int64_t> g_perm_cache;   // storage of the last destroyed handle's permutation (cc_rig_create takes it over)
+void rig_release_host_caches() {
+  std::lock_guard<std::mutex> lk(g_perm_mu);
+  std::vector<int64_t>().swap(g_perm_cache);
+}
 struct HostPhases {   // CC_RIG_HOST_TIMING=1: wall milliseconds of the host-side phases of a call, to stderr
   const char* who; bool on; std::chrono::steady_clock::time_point t; std::string line;
   explicit HostPhases(const char* w) : who(w), on(getenv("CC_RIG_HOST_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}

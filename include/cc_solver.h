@@ -110,6 +110,11 @@ void cc_host_staging_release(void* p);
  * [0] handle + device arena, [1] upload, [2] Zhang initialisation (estimate only), [3] solve, [4] read-back + teardown. */
 void cc_last_call_timing(double out_ms[5]);
 const char* cc_version(void);
+/* The library keeps a few things between calls so that a caller that re-estimates as images arrive (the reference's workflow
+ * builds a fresh solver per call: cam_calibration.py:290-322) does not pay for allocation every time: the device arena /
+ * pooled device blocks of the last handles (at most 8 GB per device), one pinned host staging block, streams. This gives the
+ * memory back (idle pieces only; safe at any time, the next call allocates again). */
+void cc_release_caches(void);
 /* Number of usable HIP devices (0 if none); never touches the oracle or a CPU path. */
 int cc_device_count(void);
 

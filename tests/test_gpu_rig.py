@@ -469,3 +469,21 @@ def test_frame_by_frame_records_with_a_bad_id_are_refused():
     cam[17] = 9
     with pytest.raises(capi.CcError, match="observation 17: camera id out of range"):
         capi.rig_optimize_frames(2, sc["frame_offsets"], cam, sc["obs_world"], sc["obs_uv"], sc["world_xyz"], cq, ct, sc["cam_frozen"], fq, ft)
+
+
+def test_releasing_the_caches_between_calls_changes_nothing():
+    """cc_release_caches hands the pooled device blocks, the arena and the pinned staging block back; the next call allocates
+    again and gives the same bits (also for the intrinsics path, which keeps its arena in the same cache)."""
+    sc = po.rig_scenario(3, 30, 20)
+    cq, ct, fq, ft = _inputs(sc)
+    args = (3, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"], sc["world_xyz"], cq, ct, sc["cam_frozen"], fq, ft)
+    a = capi.rig_optimize(*args)
+    off, uv, xyz = capi.make_intrinsics_problem(12, 40)
+    e0 = capi.intrinsics_estimate(off, uv, xyz)
+    capi.release_caches()
+    capi.release_caches()          # (nothing left: a no-op)
+    b = capi.rig_optimize(*args)
+    e1 = capi.intrinsics_estimate(off, uv, xyz, views=True)
+    for k in range(5):
+        assert np.array_equal(a[k], b[k])
+    assert np.array_equal(e0[1], e1[1]) and np.array_equal(e0[2], e1[2])
