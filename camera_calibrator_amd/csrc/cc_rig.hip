@@ -4758,7 +4758,7 @@ struct cc_rig {
   bool have_state = false;
   cc::LmCtl* h_ctl = nullptr;
   void* pinned = nullptr;       // the pinned block h_ctl and host_pub live in
-  hipGraphExec_t graph[2] = {nullptr, nullptr};
+  hipGraphExec_t graph[3] = {nullptr, nullptr, nullptr};   // first chunk (with the preparation) | chunk of check_interval rounds | of twice as many
   int graph_iters = 0;
   cc::Comm* comm = nullptr;
   cc::Mailbox mailbox;          // mailbox exchange (cc_rig_exchange_export / _attach)
@@ -5902,9 +5902,13 @@ static int rig_launch(cc_rig* h, RigRun* r, int chunk) {
     r->launched += q.max_rounds;
     return 0;
   }
-  const int n = r->o.check_interval + (chunk == 0 ? 1 : 0);
+  // Rounds per chunk: check_interval, and twice that from the third chunk on -- a solve that has not ended after two looks
+  // is a long one, and every look costs the host's round trip (publication seen + launch: 2 us per iteration at configs[4]
+  // size with chunks of four, measured by varying check_interval) against the rounds that return at once after the solve
+  // has ended (three kernels of ~4 us each per round, (n - 1) / 2 rounds on average).
+  const int n = r->o.check_interval * (chunk >= 2 ? 2 : 1) + (chunk == 0 ? 1 : 0);
   if (r->use_graph) {
-    const int which = chunk == 0 ? 0 : 1;
+    const int which = chunk == 0 ? 0 : (chunk >= 2 ? 2 : 1);
     if (!h->graph[which])
       if (int rc = rig_capture(h, which == 0, n, &h->graph[which])) { rig_drop_graphs(h); return rc; }
     CC_HIP(hipGraphLaunch(h->graph[which], h->stream));
@@ -5971,7 +5975,7 @@ static int rig_wait(cc_rig* h, RigRun* r) {
     const std::string where = rig_describe_stall(h);
     return fail(CC_ERR_COMM, "mailbox exchange timed out: a peer rank did not post within 10 s (iteration %d). %s", r->st.iter, where.c_str());
   }
-  if (!r->st.done && r->launched > r->o.max_iterations + 2 * r->o.check_interval + 2)
+  if (!r->st.done && r->launched > r->o.max_iterations + 4 * r->o.check_interval + 2)
     return fail(CC_ERR_STATE, "rig LM loop did not terminate (iter=%d)", r->st.iter);
   return 0;
 }

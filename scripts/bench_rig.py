@@ -37,7 +37,7 @@ else:
         for c in range(C):
             prob.set_camera_intrinsics(c, k["intr0"][c], 0)
 prob.set_state(cq, ct, fq, ft)
-o = capi.default_options(max_iterations=1000)
+o = capi.default_options(max_iterations=1000, use_graph=int(os.environ.get("GRAPH", 1)), check_interval=int(os.environ.get("CHECK", 4)))
 s = prob.solve(o, log_capacity=0)
 ts = []
 for _ in range(REPS):
