@@ -70,11 +70,12 @@ void ExtrinsicsCalibrator::GetObservation(size_t frame_id, size_t k, size_t* cam
 namespace {
 // flat observation arrays of the last ExtrinsicsCalibrator that was destroyed (one set per process, at most 2^27 observations):
 // the next object's first Optimize() starts with memory that is already faulted in
-std::mutex g_flat_mu;
-std::vector<uint32_t> g_flat_cam;
-std::vector<uint64_t> g_flat_world;
-std::vector<float> g_flat_uv;
-std::vector<double> g_flat_rho;
+// (never destroyed: an ExtrinsicsCalibrator with static storage in another translation unit may go after this one's statics)
+std::mutex& g_flat_mu = *new std::mutex;
+std::vector<uint32_t>& g_flat_cam = *new std::vector<uint32_t>;
+std::vector<uint64_t>& g_flat_world = *new std::vector<uint64_t>;
+std::vector<float>& g_flat_uv = *new std::vector<float>;
+std::vector<double>& g_flat_rho = *new std::vector<double>;
 }  // namespace
 
 ExtrinsicsCalibrator::FlatArrays::~FlatArrays() {
