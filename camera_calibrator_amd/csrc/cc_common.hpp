@@ -284,9 +284,22 @@ __device__ inline double rfl(double x) {  // wave-uniform value -> SGPR pair
   return __hiloint2double(hi, lo);
 }
 
+// 1 / sqrt(d), d > 0 and finite: the hardware estimate with the library's third-order correction, without the library's
+// special-case selects (four dependent instructions; sqrt followed by a division is twenty-five, each waiting ~20 cycles
+// for the one before it on a wave that has its SIMD to itself)
+__device__ __forceinline__ double rsqrt_pos(double d) {
+  const double y0 = __builtin_amdgcn_rsq(d);
+  const double e = fma(y0 * -d, y0, 1.0);
+  return fma(y0 * e, fma(e, 0.375, 0.5), y0);
+}
+
 // Rotation matrix of q/|q| (ceres::QuaternionRotatePoint normalises; calibrator.cpp:201)
 __device__ inline void quat_to_R(const double* q, double* R) {
+#ifdef CC_EXACT_QUAT_NORM
   const double n = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+#else
+  const double n = rsqrt_pos(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);   // (a pose's quaternion is never zero)
+#endif
   const double w = q[0] * n, x = q[1] * n, y = q[2] * n, z = q[3] * n;
   R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z);     R[2] = 2 * (x * z + w * y);
   R[3] = 2 * (x * y + w * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);

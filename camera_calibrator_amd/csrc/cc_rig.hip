@@ -162,14 +162,7 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
-// 1 / sqrt(d) for a Cholesky pivot: the hardware estimate and the library's third-order correction WITHOUT its special-case
-// selects (zero, infinity, NaN: the caller tests d > 0 && isfinite(d) and discards the step) -- three dependent
-// instructions fewer on a chain that is nothing but dependent instructions. Same bits as rsqrt() for every d it is kept for.
-__device__ __forceinline__ double rsqrt_pos(double d) {
-  const double y0 = __builtin_amdgcn_rsq(d);
-  const double e = fma(y0 * -d, y0, 1.0);
-  return fma(y0 * e, fma(e, 0.375, 0.5), y0);
-}
+// (rsqrt_pos -- 1 / sqrt(d) for a Cholesky pivot or a Huber weight: cc_common.hpp; the caller tests d > 0 && isfinite(d))
 
 // ceres::HuberLoss(a) + Corrector (rho'' <= 0): residual and Jacobian scaled by sqrt(rho').
 // Outlier rows: |r| = s y and sqrt(a / |r|) = q rsqrt(q), q = a y, from two refined reciprocal square roots y = rsqrt(s)
