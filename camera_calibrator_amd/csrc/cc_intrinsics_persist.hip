@@ -717,7 +717,7 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
 #pragma unroll
         for (int k = 0; k < j; ++k) d -= L[tri(j, k)] * L[tri(j, k)];
         ok = ok && (d > 0.0) && isfinite(d);
-        const double inv = rsqrt(d);
+        const double inv = rsqrt_pos(d);   // (same bits as rsqrt for d > 0 finite; the step is discarded otherwise)
         L[tri(j, j)] = d * inv;
         Li[j] = inv;
 #pragma unroll
