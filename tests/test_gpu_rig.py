@@ -487,3 +487,44 @@ def test_releasing_the_caches_between_calls_changes_nothing():
     for k in range(5):
         assert np.array_equal(a[k], b[k])
     assert np.array_equal(e0[1], e1[1]) and np.array_equal(e0[2], e1[2])
+
+
+def test_one_shot_calls_from_two_host_threads_at_once():
+    """The process-wide caches behind the one-shot calls (pinned staging block, device block pool, permutation storage, streams)
+    are handed to one owner at a time: two host threads calling cc_rig_optimize / cc_rig_optimize_frames / cc_intrinsics_estimate
+    concurrently get the bits of the same calls made one after the other."""
+    import threading
+    scs = [po.rig_scenario(3, 60, 40), po.rig_scenario(4, 45, 25)]
+    args = []
+    for sc, cams in zip(scs, (3, 4)):
+        cq, ct, fq, ft = _inputs(sc)
+        args.append((cams, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"], sc["world_xyz"], cq, ct, sc["cam_frozen"], fq, ft))
+    off, uv, xyz = capi.make_intrinsics_problem(30, 80)
+    ref = [capi.rig_optimize(*args[0]), capi.rig_optimize_frames(*args[1]), capi.intrinsics_estimate(off, uv, xyz, views=True)]
+    out = [[None] * 4 for _ in range(3)]
+    err = []
+
+    def work(which):
+        try:
+            for rep in range(4):
+                if which == 0:
+                    out[0][rep] = capi.rig_optimize(*args[0])
+                elif which == 1:
+                    out[1][rep] = capi.rig_optimize_frames(*args[1])
+                else:
+                    out[2][rep] = capi.intrinsics_estimate(off, uv, xyz, views=True)
+        except Exception as e:   # (reported below: an exception in a thread would otherwise pass silently)
+            err.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(w,)) for w in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not err, err
+    for w in range(3):
+        for rep in range(4):
+            got = out[w][rep]
+            n = 5 if w < 2 else 4
+            for k in range(n):
+                assert np.array_equal(np.asarray(got[k]), np.asarray(ref[w][k])), (w, rep, k)
