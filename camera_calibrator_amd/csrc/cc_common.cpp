@@ -126,14 +126,33 @@ void scratch_put(int device, void* p, size_t, bool cached) {
   hipFree(p);
 }
 
-// ---- device arena of a solver handle and pinned host staging of the class surface: ONE cached piece each (per device /
+// ---- device arena of a solver handle and pinned host staging of the one-shot calls: a few cached pieces each (per device /
 // per process), grow-only, handed to one owner at a time -- a caller that re-estimates as images arrive (the reference's
-// workflow builds a fresh Calibrator per call: cam_calibration.py:290-322) pays hipMalloc / hipHostMalloc once, not per call.
+// workflow builds a fresh Calibrator per call: cam_calibration.py:290-322) pays hipMalloc / hipHostMalloc once, not per call,
+// and so do up to four host threads calling at once (hipFree / hipHostFree wait for the whole device: from a second thread
+// they can stall behind another thread's persistent solve).
 namespace {
 struct Piece { void* p = nullptr; size_t bytes = 0; bool busy = false; };
-std::vector<Piece> g_arena;     // per device
-Piece g_staging;                // pinned host memory
+constexpr int kPiecesKept = 4;
+std::vector<std::vector<Piece>> g_arena;   // per device
+std::vector<Piece> g_staging;              // pinned host memory
 constexpr size_t kArenaKeep = (size_t)1 << 30, kStagingKeep = (size_t)1 << 30;
+
+// an idle piece for `bytes`: the smallest one that is large enough, else the largest idle one (grown by the caller), else
+// a new slot while fewer than kPiecesKept exist; nullptr: all busy (the caller allocates a piece of its own)
+Piece* pick_piece(std::vector<Piece>& v, size_t bytes) {
+  Piece* fit = nullptr;
+  Piece* grow = nullptr;
+  for (Piece& x : v) {
+    if (x.busy) continue;
+    if (x.bytes >= bytes) { if (!fit || x.bytes < fit->bytes) fit = &x; }
+    else if (!grow || x.bytes > grow->bytes) grow = &x;
+  }
+  if (fit) return fit;
+  if (grow) return grow;
+  if ((int)v.size() < kPiecesKept) { v.emplace_back(); return &v.back(); }
+  return nullptr;
+}
 }  // namespace
 
 int arena_get(int device, size_t bytes, void** out, bool* cached) {
@@ -141,17 +160,17 @@ int arena_get(int device, size_t bytes, void** out, bool* cached) {
   if (bytes <= kArenaKeep) {
     std::lock_guard<std::mutex> lk(g_cache_mu);
     if ((int)g_arena.size() <= device) g_arena.resize((size_t)device + 1);
-    Piece& a = g_arena[(size_t)device];
-    if (!a.busy) {
-      if (a.bytes < bytes) {
-        if (a.p) hipFree(a.p);
-        a.p = nullptr; a.bytes = 0;
+    if (g_arena[(size_t)device].capacity() < (size_t)kPiecesKept) g_arena[(size_t)device].reserve(kPiecesKept);   // (pointers into it stay valid)
+    if (Piece* a = pick_piece(g_arena[(size_t)device], bytes)) {
+      if (a->bytes < bytes) {
+        if (a->p) (void)hipFree(a->p);
+        a->p = nullptr; a->bytes = 0;
         const size_t want = bytes + bytes / 4;   // (room for a problem that grows by a few frames per call)
-        if (hipMalloc(&a.p, want) != hipSuccess) { (void)hipGetLastError(); a.p = nullptr; return fail(CC_ERR_HIP, "hipMalloc(%zu) failed", want); }
-        a.bytes = want;
+        if (hipMalloc(&a->p, want) != hipSuccess) { (void)hipGetLastError(); a->p = nullptr; return fail(CC_ERR_HIP, "hipMalloc(%zu) failed", want); }
+        a->bytes = want;
       }
-      a.busy = true;
-      *out = a.p;
+      a->busy = true;
+      *out = a->p;
       *cached = true;
       return CC_OK;
     }
@@ -164,26 +183,29 @@ void arena_put(int device, void* p, bool cached) {
   if (!p) return;
   if (cached) {
     std::lock_guard<std::mutex> lk(g_cache_mu);
-    if ((int)g_arena.size() > device && g_arena[(size_t)device].p == p) { g_arena[(size_t)device].busy = false; return; }
+    if ((int)g_arena.size() > device)
+      for (Piece& a : g_arena[(size_t)device])
+        if (a.p == p) { a.busy = false; return; }
   }
-  hipFree(p);
+  (void)hipFree(p);
 }
 
 void* staging_get(size_t bytes, bool* cached) {
   *cached = false;
   if (bytes <= kStagingKeep) {
     std::lock_guard<std::mutex> lk(g_cache_mu);
-    if (!g_staging.busy) {
-      if (g_staging.bytes < bytes) {
-        if (g_staging.p) hipHostFree(g_staging.p);
-        g_staging.p = nullptr; g_staging.bytes = 0;
+    if (g_staging.capacity() < (size_t)kPiecesKept) g_staging.reserve(kPiecesKept);
+    if (Piece* st = pick_piece(g_staging, bytes)) {
+      if (st->bytes < bytes) {
+        if (st->p) (void)hipHostFree(st->p);
+        st->p = nullptr; st->bytes = 0;
         const size_t want = bytes + bytes / 4;
-        if (hipHostMalloc(&g_staging.p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); g_staging.p = nullptr; return nullptr; }
-        g_staging.bytes = want;
+        if (hipHostMalloc(&st->p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); st->p = nullptr; return nullptr; }
+        st->bytes = want;
       }
-      g_staging.busy = true;
+      st->busy = true;
       *cached = true;
-      return g_staging.p;
+      return st->p;
     }
   }
   void* p = nullptr;
@@ -195,9 +217,10 @@ void staging_put(void* p) {
   if (!p) return;
   {
     std::lock_guard<std::mutex> lk(g_cache_mu);
-    if (g_staging.p == p) { g_staging.busy = false; return; }
+    for (Piece& st : g_staging)
+      if (st.p == p) { st.busy = false; return; }
   }
-  hipHostFree(p);
+  (void)hipHostFree(p);
 }
 
 namespace {
@@ -240,6 +263,11 @@ void pool_free(int device, void* p, size_t bytes) {
     }
   }
   (void)hipFree(p);
+}
+
+std::mutex& persist_mutex(int device) {
+  static std::mutex table[64];
+  return table[device >= 0 && device < 64 ? device : 0];
 }
 
 int parallel_parts(int64_t n, int64_t min_per_part) {
@@ -316,7 +344,7 @@ void cc_last_call_timing(double out_ms[5]) {
 // nothing). Safe at any time -- a piece a live handle is using is not touched; the next call allocates again.
 void cc_release_caches(void) {
   std::vector<std::pair<int, void*>> dev;
-  void* pinned = nullptr;
+  std::vector<void*> pinned;
   {
     std::lock_guard<std::mutex> lk(cc::g_cache_mu);
     for (size_t d = 0; d < cc::g_pool.size(); ++d) {
@@ -325,16 +353,18 @@ void cc_release_caches(void) {
       cc::g_pool_bytes[d] = 0;
     }
     for (size_t d = 0; d < cc::g_arena.size(); ++d)
-      if (!cc::g_arena[d].busy && cc::g_arena[d].p) { dev.emplace_back((int)d, cc::g_arena[d].p); cc::g_arena[d] = {}; }
+      for (auto& a : cc::g_arena[d])
+        if (!a.busy && a.p) { dev.emplace_back((int)d, a.p); a = {}; }
     for (size_t d = 0; d < cc::g_scratch.size(); ++d)
       if (!cc::g_scratch[d].busy && cc::g_scratch[d].p) { dev.emplace_back((int)d, cc::g_scratch[d].p); cc::g_scratch[d] = {}; }
-    if (!cc::g_staging.busy && cc::g_staging.p) { pinned = cc::g_staging.p; cc::g_staging = {}; }
+    for (auto& st : cc::g_staging)
+      if (!st.busy && st.p) { pinned.push_back(st.p); st = {}; }
   }
   int cur = -1;
   (void)hipGetDevice(&cur);
   for (auto& e : dev) { if (hipSetDevice(e.first) == hipSuccess) (void)hipFree(e.second); }
   if (cur >= 0) (void)hipSetDevice(cur);
-  if (pinned) (void)hipHostFree(pinned);
+  for (void* q : pinned) (void)hipHostFree(q);
   (void)hipGetLastError();
   cc::rig_release_host_caches();
 }

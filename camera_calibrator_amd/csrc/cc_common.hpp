@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <functional>
+#include <mutex>
 #include <string>
 
 #include "../../include/cc_solver.h"
@@ -52,6 +53,11 @@ int pool_alloc(int device, size_t bytes, void** out, size_t* got);
 void pool_free(int device, void* p, size_t bytes);
 // fn(part, begin, end) over [0, n) cut into contiguous parts, one host thread each (at most 16, one when n < 2 min_per_part);
 // returns after all parts. parallel_parts gives the number of parts fn will see.
+// One persistent launch at a time per device and process: a persistent solve (the intrinsics kernel, the lean rig form's two
+// launches) waits INSIDE its kernels for workgroups of its own grid, so two of them in flight from two host threads can hold
+// each other's compute units or hardware queues (a process has four; streams share them) until both give up after 1.3 s.
+// The second caller waits here instead. Not taken by the sharded forms (their ranks must run together by construction).
+std::mutex& persist_mutex(int device);
 void rig_release_host_caches();   // (cc_rig.hip: the permutation storage kept for the next rig handle; part of cc_release_caches)
 int parallel_parts(int64_t n, int64_t min_per_part);
 void parallel_tasks(int parts, const std::function<void(int)>& fn);   // fn(0 .. parts-1), one host thread each

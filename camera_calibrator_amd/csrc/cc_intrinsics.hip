@@ -1708,6 +1708,10 @@ static int persistent_wait(cc_intrinsics* h, SolveRun* r) {
 // The whole solve as one launch of the persistent kernel. Starts from buffer 0 (solve_begin moved a continued solve's
 // accepted point there) or, after set_state / reset, from the initial-state arrays.
 static int solve_persistent(cc_intrinsics* h, SolveRun* r) {
+  // (one persistent launch per device and process at a time: persist_mutex, cc_common.hpp; the exchanging forms -- several
+  // ranks that must run together -- go through cc_intrinsics_optimize_multi's own loop or one process per rank)
+  std::unique_lock<std::mutex> lk(persist_mutex(h->device), std::defer_lock);
+  if (!h->exchange && !h->comm) lk.lock();
   if (int rc = persistent_launch(h, r)) return rc;
   return persistent_wait(h, r);
 }

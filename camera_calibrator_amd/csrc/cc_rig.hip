@@ -2115,7 +2115,7 @@ __device__ __forceinline__ void rig_elim_body(const RigDev& P, char* smem_raw, c
 #pragma unroll
         for (int k = 0; k < j; ++k) d -= L[tri(j, k)] * L[tri(j, k)];
         ok = ok && (d > 0.0) && isfinite(d);
-        const double inv = rsqrt(d);
+        const double inv = rsqrt_pos(d);
         L[tri(j, j)] = d * inv;
         Li[j] = inv;
 #pragma unroll
@@ -2355,7 +2355,7 @@ __device__ __forceinline__ void chol_panel(double* A, int S, int LD, int j0, int
   // operation the update performs on that entry, so the value is the same bit for bit): its reciprocal square root is
   // then computed while the LDS round trip of the multipliers is in flight instead of behind it.
   double d = (!TWO || j0 < 64) ? readlane_d(p0[0], j0 & 63) : readlane_d(p1[0], j0 & 63);
-  double inv = rsqrt(d);
+  double inv = rsqrt_pos(d);
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     if (c < nc) {   // (uniform)
@@ -2374,7 +2374,7 @@ __device__ __forceinline__ void chol_panel(double* A, int S, int LD, int j0, int
         const double ln = (!TWO || cn < 64) ? readlane_d(l0, cn & 63) : readlane_d(l1, cn & 63);          // L[cn][col]
         const double pn = (!TWO || cn < 64) ? readlane_d(p0[c + 1], cn & 63) : readlane_d(p1[c + 1], cn & 63);
         d = fma(-ln, ln, pn);
-        inv = rsqrt(d);
+        inv = rsqrt_pos(d);
       }
       // (no test against nc here: columns beyond the panel's end are computed on whatever colbuf holds and never
       // stored -- a uniform branch per column would put every LDS read behind its own wait)
@@ -3335,7 +3335,7 @@ __global__ __launch_bounds__(256) void k_rig_elim_big(RigDev P) {
 #pragma unroll
         for (int k = 0; k < j; ++k) d -= L[tri(j, k)] * L[tri(j, k)];
         ok = ok && (d > 0.0) && isfinite(d);
-        const double inv = rsqrt(d);
+        const double inv = rsqrt_pos(d);
         L[tri(j, j)] = d * inv;
         Li[j] = inv;
 #pragma unroll
@@ -3875,7 +3875,7 @@ struct RigPersistDev {
   unsigned* claim;      // [1] the control candidate that exchanges epoch0 + 1 in first is the control workgroup (k_rig_persist_ctl)
   unsigned long long* gate;   // pinned host word: the worker that finds all G workers started stores epoch0 + 1 into it and the HOST then
                               //   launches the control (rig_launch); null: no gate (the candidates run when they run)
-  int32_t max_rounds, timeout_shift;
+  int32_t max_rounds, timeout_shift, first_shift;   // (first_shift: the workers' wait for the control's FIRST broadcast)
 };
 
 constexpr int kRigPersistMaxS = 48;     // shared coordinates (8 optimised cameras)
@@ -4336,7 +4336,7 @@ __global__ __launch_bounds__(TEAMS * 256) void k_rig_persist_w(RigDev P, RigPers
     const bool phase0 = round == 0;
     // ---- broadcast B: step and camera records
     RPW_MARK(0);
-    if (wave == 0 && !rig_bcast_wait(Q.ybox, e, NB, s_bc, fail, Q.timeout_shift)) s_bc[0] = 1.0;
+    if (wave == 0 && !rig_bcast_wait(Q.ybox, e, NB, s_bc, fail, phase0 ? Q.first_shift : Q.timeout_shift)) s_bc[0] = 1.0;
     __syncthreads();
     const int flb = (int)s_bc[0];
     RPW_MARK(1);
@@ -4500,7 +4500,7 @@ __global__ __launch_bounds__(TEAMS * 256) void k_rig_persist_w(RigDev P, RigPers
 #pragma unroll
           for (int k = 0; k < j; ++k) d -= L[tri(j, k)] * L[tri(j, k)];
           ok = ok && (d > 0.0) && isfinite(d);
-          const double inv = rsqrt(d);
+          const double inv = rsqrt_pos(d);
           L[tri(j, j)] = d * inv;
           Li[j] = inv;
 #pragma unroll
@@ -4771,6 +4771,7 @@ struct cc_rig {
   int p_teams = 4;              // frames per workgroup of the lean form
   bool persist_w_ok = false;    // ... and so can its lean form (k_rig_persist_w + k_rig_persist_ctl: <= 4 observed cameras, <= 24 shared coordinates)
   int form_reruns = 0;             // lean persistent solves that gave up and were run again in the three-kernel form
+  int lean_strikes = 0;            // ... of them in the first round, in a row (two demote the handle)
   std::string form_note;           // why (cc_rig_solver_status)
   bool gated = false;              // the last lean solve launched its control behind the workers' residency word
   hipStream_t stream2 = nullptr;   // the control workgroup's launch of the lean form
@@ -5853,6 +5854,11 @@ static int rig_launch(cc_rig* h, RigRun* r, int chunk) {
     RigPersistDev q = h->pq;
     q.max_rounds = r->o.max_iterations + 2;
     q.timeout_shift = 27;   // 1.3 s of the 100 MHz wall clock
+    // ... and 42 ms for the control workgroup to appear at all (its launch follows the workers' residency word by microseconds):
+    // when another host thread sits in a call that waits for the whole device (hipFree, hipHostFree) while holding the
+    // runtime's lock, THIS thread's control launch waits behind it and the device never goes idle under the spinning workers --
+    // seen with three threads making one-shot calls at once: 1.3 s per collision before, the solve's rerun 42 ms late now
+    q.first_shift = 22;
     if (h->p_epoch > 0x7fff0000u - (unsigned)q.max_rounds) {   // the 32-bit tags would wrap: start over on zeroed boxes
       CC_HIP(hipMemsetAsync(h->pq.sbox, 0, h->p_box_words * sizeof(unsigned long long), h->stream));   // (the claim word is its last)
       h->p_epoch = 0;
@@ -5939,22 +5945,27 @@ static int rig_wait(cc_rig* h, RigRun* r) {
   bool wait_failed = false;
   const bool lean_run = r->persist && h->persist_w_ok && h->stream2 != nullptr;   // (what rig_launch put on two streams)
   if (int rc = ((h->comm || h->big) ? rig_read_ctl(h, &r->st, &wait_failed) : rig_wait_published(h, &r->st, &wait_failed, lean_run))) return rc;
-  if (r->st.done) { h->last_st = r->st; h->st_known = true; }
+  if (r->st.done) { h->last_st = r->st; h->st_known = true; if (r->persist && !wait_failed) h->lean_strikes = 0; }
   if (wait_failed && r->persist) {
     // The lean form keeps the starting point intact: cc_rig_solve runs the solve again, three kernels per iteration, and this
     // handle stays on that form. NOT silently (ADVICE / review of round 3): the demotion is counted and its reason kept for
     // cc_rig_solver_status -- launches started, where the control workgroup ran (or that it never did), the round reached.
-    h->persist_w_ok = false;
+    // (a give-up in the very first round -- the control never showed up within 42 ms -- demotes the handle only the second
+    // time in a row: a host thread that lost its time slice between the two launches is not a property of the device)
+    const bool first_round = r->st.iter == 0 && !r->st.done;
+    if (!first_round || ++h->lean_strikes >= 2) h->persist_w_ok = false;
     h->form_reruns++;
     unsigned w[16] = {};
     (void)hipStreamSynchronize(h->stream);
     if (hipMemcpy(w, h->d.arrive, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) (void)hipGetLastError();
     char note[512];
-    std::snprintf(note, sizeof(note), "lean persistent solve gave up in round %d after a 1.3 s wait (%d worker workgroups of %d threads + control): "
+    std::snprintf(note, sizeof(note), "lean persistent solve gave up in round %d after a %s wait (%d worker workgroups of %d threads + control): "
                   "%u workers had started, control workgroup %s (candidate %u, XCD %d)%s; the solve was run again with three kernels per "
-                  "iteration and the handle stays on that form (kernel-serialising tools, a CU mask or another tenant on the device cause this)",
-                  r->st.iter, h->pq.G, h->p_teams * 256, w[13], w[12] ? "claimed a compute unit" : "NEVER RAN", w[12] >> 8, (int)(w[12] & 0xffu) - 1,
-                  h->gated ? "" : ", control launched without waiting for the workers (CC_RIG_CTL_GATE=0)");
+                  "iteration and the handle %s (kernel-serialising tools, a CU mask, another tenant on the device or another host thread "
+                  "in a call that waits for the device cause this)",
+                  r->st.iter, first_round ? "42 ms" : "1.3 s", h->pq.G, h->p_teams * 256, w[13], w[12] ? "claimed a compute unit" : "NEVER RAN", w[12] >> 8,
+                  (int)(w[12] & 0xffu) - 1, h->gated ? "" : ", control launched without waiting for the workers (CC_RIG_CTL_GATE=0)",
+                  h->persist_w_ok ? "tries the lean form again next time" : "stays on that form");
     h->form_note = note;
     r->rerun = true;
     return 0;
@@ -6017,10 +6028,16 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
   HostPhases hp("cc_rig_solve");
   if (int rc = rig_begin(h, opt, &r)) return rc;
   hp.mark("begin");
+  // (the lean form is two launches that wait for each other inside their kernels: one such solve at a time per device and
+  // process -- persist_mutex, cc_common.hpp; a second host thread waits here instead of inside a kernel for 1.3 s)
+  std::unique_lock<std::mutex> lean_lock(persist_mutex(h->device), std::defer_lock);
   for (int chunk = 0;; ++chunk) {
+    if (chunk == 0 && !r.no_persist && h->persist_w_ok && h->sweep_adjoint && !r.profile && !h->comm && !h->exchange && !h->big && h->co_resident <= 1)
+      lean_lock.lock();
     if (int rc = rig_launch(h, &r, chunk)) return rc;
     if (chunk == 0) hp.mark("launch0");
     if (int rc = rig_wait(h, &r)) return rc;
+    if (lean_lock.owns_lock()) lean_lock.unlock();
     if (chunk == 0) hp.mark("wait0");
     if (r.rerun) {
       // The lean persistent launch could not get every workgroup resident (a device shared with another process, or the

@@ -411,10 +411,11 @@ def test_the_rig_suite_in_every_form_of_the_solver():
 @pytest.mark.skipif(_NESTED, reason="a forced solver form is already in the environment")
 def test_lean_persistent_solve_that_cannot_get_its_grid_is_rerun_in_the_three_kernel_form():
     """The lean persistent form needs its workers AND the control workgroup's launch resident at once. When a wait inside
-    it gives up (1.3 s) nothing has been written back -- frame poses return to global memory only at the end of a solve that
-    did not fail, the cameras of the starting point were put aside -- and cc_rig_solve runs the solve again, three kernels
-    per iteration; the handle stays with that form. Forced by not launching the control workgroup
-    (CC_RIG_PERSIST_TEST_NO_CONTROL, read once per process: a process of its own)."""
+    it gives up (42 ms for the control to appear at all, 1.3 s afterwards) nothing has been written back -- frame poses return
+    to global memory only at the end of a solve that did not fail, the cameras of the starting point were put aside -- and
+    cc_rig_solve runs the solve again, three kernels per iteration. A give-up in the first round demotes the handle the
+    second time in a row (a host thread that lost its time slice between the two launches says nothing about the device).
+    Forced by not launching the control workgroup (CC_RIG_PERSIST_TEST_NO_CONTROL, read once per process: a process of its own)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import sys, time; sys.path.insert(0, %r)\n"
             "import numpy as np\nfrom camera_calibrator_amd import capi\nfrom oracle import pyoracle as po\n"
@@ -425,14 +426,19 @@ def test_lean_persistent_solve_that_cannot_get_its_grid_is_rerun_in_the_three_ke
             "p.set_state(cq, ct, fq, ft)\n"
             "assert p.solver_form() == 2\n"
             "t0 = time.time(); s = p.solve(); dt = time.time() - t0\n"
-            "assert p.solver_form() == 0 and dt > 1.0, (p.solver_form(), dt)\n"
+            "assert 0.03 < dt < 1.0, dt\n"
             "form, reruns, note = p.solver_status()\n"
-            "assert (form, reruns) == (0, 1) and 'NEVER RAN' in note and 'three kernels' in note, (form, reruns, note)\n"
+            "assert (form, reruns) == (2, 1) and 'NEVER RAN' in note and 'three kernels' in note and 'again next time' in note, (form, reruns, note)\n"
             "g = p.get_state()\n"
             "o = po.rig_solve(*args, cq, ct, sc['cam_frozen'], fq, ft, options=po.default_options(max_iterations=1000))\n"
             "assert s['iterations'] == o[5]['iterations'] and s['termination'] == o[5]['termination']\n"
             "assert all(np.abs(g[k] - o[k]).max() < 1e-9 for k in range(4))\n"
-            "s2 = p.solve(); assert s2['iterations'] <= 2 and p.solver_status()[1] == 1\n"
+            "p.set_state(cq, ct, fq, ft)\n"
+            "s1 = p.solve()\n"
+            "form, reruns, note = p.solver_status()\n"
+            "assert (form, reruns) == (0, 2) and 'stays on that form' in note, (form, reruns, note)\n"
+            "assert s1['iterations'] == s['iterations'] and s1['final_cost'] == s['final_cost']\n"
+            "s2 = p.solve(); assert s2['iterations'] <= 2 and p.solver_status()[1] == 2\n"
             "print('rerun ok', dt)\n") % root
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CC_RIG_PERSIST_TEST_NO_CONTROL="1"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "rerun ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
@@ -491,8 +497,10 @@ def test_releasing_the_caches_between_calls_changes_nothing():
 
 def test_one_shot_calls_from_two_host_threads_at_once():
     """The process-wide caches behind the one-shot calls (pinned staging block, device block pool, permutation storage, streams)
-    are handed to one owner at a time: two host threads calling cc_rig_optimize / cc_rig_optimize_frames / cc_intrinsics_estimate
-    concurrently get the bits of the same calls made one after the other."""
+    are handed to one owner at a time: host threads calling cc_rig_optimize / cc_rig_optimize_frames / cc_intrinsics_estimate
+    concurrently get the results of the same calls made one after the other -- the intrinsics path bit for bit; the rig path to
+    the rounding by which its two solver forms differ, because a lean persistent solve whose control launch got stuck behind
+    another thread's device-wide wait is rerun with three kernels per iteration (42 ms late, not 1.3 s)."""
     import threading
     scs = [po.rig_scenario(3, 60, 40), po.rig_scenario(4, 45, 25)]
     args = []
@@ -527,4 +535,7 @@ def test_one_shot_calls_from_two_host_threads_at_once():
             got = out[w][rep]
             n = 5 if w < 2 else 4
             for k in range(n):
-                assert np.array_equal(np.asarray(got[k]), np.asarray(ref[w][k])), (w, rep, k)
+                if w == 2:
+                    assert np.array_equal(np.asarray(got[k]), np.asarray(ref[w][k])), (w, rep, k)
+                else:
+                    assert np.allclose(np.asarray(got[k]), np.asarray(ref[w][k]), rtol=1e-9, atol=1e-12), (w, rep, k)
