@@ -249,3 +249,34 @@ def test_persistent_solve_that_cannot_get_its_grid_is_rerun_in_the_two_kernel_fo
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CC_INTR_PERSIST_TEST_NO_CONTROL="1"),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
     assert r.returncode == 0 and "rerun ok" in r.stdout, r.stdout[-3000:]
+
+
+@pytest.mark.gpu
+def test_persistent_solves_from_two_host_threads_do_not_hold_each_other():
+    """Two host threads, each with a problem whose persistent kernel wants most of the chip (600 frames: 150 workgroups of 1024
+    threads + control), solving at once: the library runs one persistent solve at a time per device (persist_mutex) instead of
+    letting two half-resident grids wait 1.3 s for workgroups that cannot start. Same bits as one after the other, no stall."""
+    import threading, time
+    off, uv, xyz = capi.make_intrinsics_problem(600, 120)
+    ref = capi.intrinsics_estimate(off, uv, xyz)
+    out, err = {}, []
+
+    def work(w):
+        try:
+            out[w] = [capi.intrinsics_estimate(off, uv, xyz, views=bool(w)) for _ in range(4)]
+        except Exception as e:
+            err.append(repr(e))
+
+    t0 = time.time()
+    th = [threading.Thread(target=work, args=(w,)) for w in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.time() - t0
+    assert not err, err
+    for w in range(2):
+        for got in out[w]:
+            for k in range(4):
+                assert np.array_equal(np.asarray(got[k]), np.asarray(ref[k]))
+    assert dt < 1.0, dt
