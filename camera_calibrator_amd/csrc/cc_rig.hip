@@ -1444,8 +1444,8 @@ __global__ __launch_bounds__(NW * 64, CC_RIG_ADJK_WAVES) void k_rig_sweep_adjk(R
 // What the update of a frame needs besides the shared step: fetched by the blocks of k_rig_reduce WHILE they wait for
 // the solving block's flag (SW <= 32: two Y columns per lane), so that only the step itself is read behind the flag.
 // Everything unconditional (all sixteen lanes of a frame fetch the frame's scalars: same addresses, one transaction).
-struct RigUpdPre {
-  double y[2][6], p0[7], p1[7], sp[6];
+struct RigUpdPre {   // (y: columns l, l + 16, l + 32, l + 48 of the frame's six rows of Y -- up to 64 shared columns)
+  double y[4][6], p0[7], p1[7], sp[6];
   int g0, g1;
 };
 __device__ __forceinline__ void rig_update_prefetch(const RigDev& P, int64_t f, RigUpdPre& x) {   // f: frame of this thread's sixteen lanes
@@ -1453,10 +1453,15 @@ __device__ __forceinline__ void rig_update_prefetch(const RigDev& P, int64_t f, 
   const int64_t fc = f < P.F ? f : 0;
   const double* Yf = P.Y + (size_t)fc * 6 * P.SW;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < 4; ++h) {
     const int k = l + 16 * h, kc = k < P.SW ? k : 0;
+    if (16 * h < P.SW) {   // (uniform)
 #pragma unroll
-    for (int i = 0; i < 6; ++i) x.y[h][i] = Yf[i * P.SW + kc];
+      for (int i = 0; i < 6; ++i) x.y[h][i] = Yf[i * P.SW + kc];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) x.y[h][i] = 0.0;
+    }
   }
 #pragma unroll
   for (int i = 0; i < 7; ++i) { x.p0[i] = P.pose[(size_t)fc * 8 + i]; x.p1[i] = P.pose[((size_t)P.F + fc) * 8 + i]; }
@@ -1477,8 +1482,9 @@ __device__ __forceinline__ void rig_update_body(const RigDev& P, int phase, int 
   double u[6] = {0, 0, 0, 0, 0, 0};
   if (phase != 0 && PRE) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < 4; ++h) {
       const int k = l + 16 * h;
+      if (16 * h >= P.SW) continue;   // (uniform)
       double d = 1.0;   // (column S is the right-hand side)
       const double dk = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(P.ds) + (k < P.S ? k : 0),
                                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -3149,7 +3155,7 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P, int publish) {
   // every block -- the solving one included -- requests what the update of its first sixteen frames needs NOW, before it
   // waits (or solves): behind the flag only the shared step is still to be read
   RigUpdPre pre;
-  const bool use_pre = P.SW <= 32 && (int64_t)blockIdx.x * 16 < P.F;
+  const bool use_pre = P.SW <= 64 && (int64_t)blockIdx.x * 16 < P.F;
   rig_update_prefetch(P, (int64_t)blockIdx.x * 16 + (tid >> 4), pre);   // (unconditional: loads inside an `if` would be waited for at its end)
   if (s_last) {
     if (tid == 0) __hip_atomic_store(P.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
