@@ -2663,7 +2663,7 @@ __device__ __forceinline__ bool chol_block4(double* A, int S, int LD, double* s_
 #endif
 
 template <int SRC>
-__device__ void rig_solve_block(const RigDev& P, double* smem, const LmCtl* cn_in = nullptr, const double* vec_lds = nullptr) {   // cn_in: the persistent kernels' control block (LDS); vec_lds: their reduced row (SRC 3)
+__device__ void rig_solve_block(const RigDev& P, double* smem, const LmCtl* cn_in = nullptr, const double* vec_lds = nullptr, unsigned flag_epoch = 0u) {   // cn_in: the persistent kernels' control block (LDS); vec_lds: their reduced row (SRC 3)
   const int S = P.S, LD = (S + 1) | 1;   // odd row stride: a column walks all LDS banks
   double* A = smem;                       // [S][LD] lower triangle of the reduced system
   double* s_b = A + (size_t)S * LD;       // [128] right-hand side, then the solution x
@@ -2952,9 +2952,18 @@ __device__ void rig_solve_block(const RigDev& P, double* smem, const LmCtl* cn_i
 #endif
   }
   RIG_MARK(5);
+  const bool have_step = s_go != 0 && s_stepok != 0;
+  // Fused launch (k_rig_reduce<0>, flag_epoch != 0): the blocks waiting to update their frames need the shared step -- stored
+  // and drained above -- and three bits of the control block that are final by now (done and cur do not change below,
+  // step_valid is have_step): the flag goes up HERE, and the frame updates run under the camera candidates, block sums and
+  // control block below instead of behind them (2.8 us at BASELINE configs[4] size). The next kernel reads the control block;
+  // this one is not over before it is written.
+  if (flag_epoch != 0u && tid == 0) {
+    const unsigned fl = (flag_epoch << 3) | (s_c.done ? 4u : 0u) | ((s_go ? have_step : (s_c.step_valid != 0)) ? 2u : 0u) | (unsigned)(s_c.cur & 1);
+    __hip_atomic_store(P.arrive + 1, fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   // ---- camera / intrinsics candidates and records (nothing moves unless a valid step exists)
   double st2 = 0.0, xs2 = 0.0;
-  const bool have_step = s_go != 0 && s_stepok != 0;
   if (have_step) rig_candidates(P, s_b, s_ss, true, cur, dst, st2, xs2);
   {   // both block sums behind one pair of barriers
     const double a = wave_sum(st2), b2 = wave_sum(xs2);
@@ -3163,7 +3172,7 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P, int publish) {
     if (tid == 0) { P.shared_stats[8] = (double)t_entry; P.shared_stats[9] = (double)t_sums; }
 #endif
     RIG_MARK(2);
-    rig_solve_block<MODE == 0 ? 1 : 2>(P, reinterpret_cast<double*>(smem_raw));
+    rig_solve_block<MODE == 0 ? 1 : 2>(P, reinterpret_cast<double*>(smem_raw), nullptr, nullptr, MODE == 0 ? epoch0 + 1u : 0u);   // (MODE 0: raises the flag itself, early)
     // the shared step (sc1 stores of wave 0) has been drained inside; hand the outcome to the waiting blocks
     __syncthreads();
     if (tid == 0) {
