@@ -5369,10 +5369,21 @@ struct RigRegroupPart { std::vector<int32_t> gframe, gcam, per_frame; std::vecto
 // nothing. Ids are checked on the way; the regrouped pixels / world indices go straight into the staging block.
 template <class Frame, bool INV>
 static void rig_regroup_part(const RigObsSource& src, int64_t C, int64_t n_world, const int64_t* off, int64_t f0, int64_t f1,
-                             int64_t* perm, float* uv_s, int32_t* widx_s, uint8_t* seen_p, RigRegroupPart& L) {
+                             int64_t* perm, float* uv_s, int32_t* widx_s, uint8_t* seen_p, RigRegroupPart& L,
+                             const std::function<bool(int64_t, int64_t)>& flush) {
   std::vector<int64_t> cnt((size_t)C, 0), start((size_t)C, 0);
   std::vector<uint32_t> present;
+  // the regrouped arrays go up in (at most) four pieces per thread, each as soon as it is written: the transfers of the
+  // first three run under the regrouping of what follows
+  const int64_t n_part = off[f1] - off[f0];
+  const int64_t piece = n_part >= ((int64_t)1 << 18) ? (n_part + 3) / 4 : n_part + 1;   // (small ranges: one piece -- a copy costs the host 7.5 us)
+  int64_t f_sent = f0, next_flush = off[f0] + piece;
   for (int64_t f = f0; f < f1; ++f) {
+    if (off[f] >= next_flush && f > f_sent) {
+      if (!flush(f_sent, f)) { L.bad = off[f_sent]; L.bad_kind = 2; return; }
+      f_sent = f;
+      next_flush = off[f] + piece;
+    }
     const int64_t base = off[f], n = off[f + 1] - off[f];
     if (n == 0) { L.per_frame.push_back(0); continue; }
     const Frame fr(src, f, base);
@@ -5402,6 +5413,7 @@ static void rig_regroup_part(const RigObsSource& src, int64_t C, int64_t n_world
     }
     for (uint32_t c : present) cnt[c] = 0;
   }
+  if (f1 > f_sent && !flush(f_sent, f1)) { L.bad = off[f_sent]; L.bad_kind = 2; }
 }
 }  // namespace cc
 
@@ -5454,6 +5466,19 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   } stg{st, h};
   float* uv_s = reinterpret_cast<float*>(st);
   int32_t* widx_s = reinterpret_cast<int32_t*>(st + b_uv);
+  if (int rc = stream_get(device, &h->stream)) return rc;
+  float* duv = nullptr;
+  int32_t* dw = nullptr;
+  if (int rc = dev_alloc(h, &duv, (size_t)N * 2)) return rc;
+  if (int rc = dev_alloc(h, &dw, (size_t)N)) return rc;
+  // (called by the regrouping threads, each for the frames it has just written)
+  const auto flush = [&](int64_t fa, int64_t fb) -> bool {
+    const int64_t a = off[fa], n = off[fb] - off[fa];
+    if (n <= 0) return true;
+    if (hipSetDevice(device) != hipSuccess) return false;
+    return hipMemcpyAsync(duv + 2 * a, uv_s + 2 * a, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, h->stream) == hipSuccess &&
+           hipMemcpyAsync(dw + a, widx_s + a, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream) == hipSuccess;
+  };
   std::vector<int64_t> goff{0};
   h->fgoff_h.assign((size_t)F + 1, 0);
   std::vector<int32_t>& gframe = h->gframe_h;
@@ -5470,12 +5495,13 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
     h->perm_inverse = src.frames != nullptr;
     uint8_t* seen_p = seen.data();
     parallel_tasks(parts, [&](int t) {
-      if (src.frames) rig_regroup_part<RigRecordFrame, true>(src, C, n_world, off, pf[(size_t)t], pf[(size_t)t + 1], perm, uv_s, widx_s, seen_p, part[(size_t)t]);
-      else rig_regroup_part<RigFlatFrame, false>(src, C, n_world, off, pf[(size_t)t], pf[(size_t)t + 1], perm, uv_s, widx_s, seen_p, part[(size_t)t]);
+      if (src.frames) rig_regroup_part<RigRecordFrame, true>(src, C, n_world, off, pf[(size_t)t], pf[(size_t)t + 1], perm, uv_s, widx_s, seen_p, part[(size_t)t], flush);
+      else rig_regroup_part<RigFlatFrame, false>(src, C, n_world, off, pf[(size_t)t], pf[(size_t)t + 1], perm, uv_s, widx_s, seen_p, part[(size_t)t], flush);
     });
     for (const Part& L : part)   // (parts are in frame order: the first one with a bad id holds the first bad observation)
       if (L.bad >= 0)
-        return fail(CC_ERR_BAD_ARGUMENT, L.bad_kind == 0 ? "observation %lld: camera id out of range" : "observation %lld: world point id out of range", (long long)L.bad);
+        return L.bad_kind == 2 ? fail(CC_ERR_HIP, "cc_rig_create: upload of the regrouped observations failed: %s", hipGetErrorString(hipGetLastError()))
+                               : fail(CC_ERR_BAD_ARGUMENT, L.bad_kind == 0 ? "observation %lld: camera id out of range" : "observation %lld: world point id out of range", (long long)L.bad);
     size_t ng_total = 0;
     for (const Part& L : part) ng_total += L.gframe.size();
     gframe.reserve(ng_total); gcam.reserve(ng_total); goff.reserve(ng_total + 1);
@@ -5507,7 +5533,6 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   h->seen = seen;
   hp.mark("gather");
 
-  if (int rc = stream_get(device, &h->stream)) return rc;
   RigDev& d = h->d;
   d.F = F; d.N = N; d.NG = NG;
   d.huber_a = (kmode && !(huber_a > 0.0)) ? 1e300 : huber_a;   // extension: a <= 0 switches the loss off
@@ -5515,17 +5540,7 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   d.comm = 0; d.rank = 0; d.nranks = 1;
   d.kmode = kmode; d.gstride = kmode ? 768 : 256;
   d.init_slices = (int32_t)std::min<int64_t>(16, std::max<int64_t>(1, (NG + 511) / 512));
-  {
-    float* duv = nullptr;
-    int32_t* dw = nullptr;
-    if (int rc = dev_alloc(h, &duv, (size_t)N * 2)) return rc;
-    if (int rc = dev_alloc(h, &dw, (size_t)N)) return rc;
-    if (N > 0) {
-      CC_HIP(hipMemcpyAsync(duv, uv_s, (size_t)N * 2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
-      CC_HIP(hipMemcpyAsync(dw, widx_s, (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-    }
-    d.uv = duv; d.widx = dw;
-  }
+  d.uv = duv; d.widx = dw;   // (uploaded piece by piece by the regrouping threads, above)
   {
     float* w = nullptr;
     if (int rc = dev_alloc(h, &w, (size_t)n_world * 3)) return rc;
@@ -6355,20 +6370,32 @@ int cc_rig_optimize_frames(const cc_options* opt, int32_t device, int64_t C, int
       double* sorted = static_cast<double*>(staging_get((size_t)h->N * sizeof(double), &st_cached));
       if (!sorted) return fail(CC_ERR_HIP, "cc_rig_optimize_frames: pinned staging memory could not be allocated");
       struct StGuard { void* p; hipStream_t s; ~StGuard() { (void)hipStreamSynchronize(s); staging_put(p); } } stg{sorted, h->stream};
-      CC_HIP(hipMemcpyAsync(sorted, h->d_cost, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-      CC_HIP(hipStreamSynchronize(h->stream));
       const int64_t* perm = h->perm.data();
       const int parts = parallel_parts(h->N, (int64_t)1 << 17);
       std::vector<int64_t> pf((size_t)parts + 1, 0);
       if (int r2 = cc_partition_frames(F, off.data(), parts, pf.data())) return r2;
+      // one transfer and one event per thread's range of frames: a thread writes its range into the records as soon as it has
+      // arrived, under the transfers of the ranges behind it
+      std::vector<hipEvent_t> ev((size_t)parts, nullptr);
+      struct EvGuard { std::vector<hipEvent_t>& e; ~EvGuard() { for (auto x : e) if (x) (void)hipEventDestroy(x); } } evg{ev};
+      for (int t = 0; t < parts; ++t) {
+        const int64_t a = off[(size_t)pf[(size_t)t]], n = off[(size_t)pf[(size_t)t + 1]] - a;
+        if (n > 0) CC_HIP(hipMemcpyAsync(sorted + a, h->d_cost + a, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        CC_HIP(hipEventCreateWithFlags(&ev[(size_t)t], hipEventDisableTiming));
+        CC_HIP(hipEventRecord(ev[(size_t)t], h->stream));
+      }
       const int64_t stride = layout->stride, oc = layout->cost_offset;
+      std::vector<char> bad((size_t)parts, 0);
       parallel_tasks(parts, [&](int t) {
+        if (hipSetDevice(h->device) != hipSuccess || hipEventSynchronize(ev[(size_t)t]) != hipSuccess) { bad[(size_t)t] = 1; return; }
         // record after record (the inverse permutation: sequential stores, the reads stay inside the frame's range of `sorted`)
         for (int64_t f = pf[(size_t)t]; f < pf[(size_t)t + 1]; ++f) {
           unsigned char* rec = static_cast<unsigned char*>(frame_records[f]) + oc;
           for (int64_t k = off[(size_t)f]; k < off[(size_t)f + 1]; ++k, rec += stride) std::memcpy(rec, &sorted[perm[k]], sizeof(double));
         }
       });
+      CC_HIP(hipStreamSynchronize(h->stream));
+      for (char b : bad) if (b) return fail(CC_ERR_HIP, "cc_rig_optimize_frames: the read-back of the costs failed");
       return CC_OK;
     }();
   }
