@@ -2,7 +2,8 @@
 """bench.py -- LM iterations/sec and residuals/sec of the HIP intrinsics bundle-adjustment path.
 
 Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N>1 launched through
-torch.distributed.run, one rank per GPU.  A "step" is one Levenberg-Marquardt iteration (elimination
+torch.distributed.run, one rank per GPU -- or bare: `python bench.py --gpus N` without WORLD_SIZE in the environment starts
+its N ranks itself (launch_ranks) before anything touches the GPU.  A "step" is one Levenberg-Marquardt iteration (elimination
 + reduced solve + Jacobian sweep at the candidate + trust-region decision) of the single-camera
 intrinsics problem of BASELINE.json configs[2] (1000 frames x 500 points) on synthetic
 data_generator-style input already resident in HBM.  Steps are produced by complete solves from the
@@ -144,6 +145,49 @@ def usable_cores():
     return max(1, n)
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process becomes the launcher. It starts
+    N fresh children of this same file, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, the
+    environment torch.distributed.run would give them), relays rank 0's JSON line and exits non-zero if any child does.
+    The launcher never imports torch and never touches the GPU: the children are ordinary fresh processes, no exec from a
+    process that has initialised HIP."""
+    import socket
+    import subprocess
+    assert "torch" not in sys.modules, "the launcher must not load the GPU runtime"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    import tempfile
+    procs = []
+    with tempfile.TemporaryFile(mode="w+") as out0:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what hipIpc / RCCL need on this driver
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=None))
+        # one rank that dies leaves its peers inside a rendezvous or a barrier: end them (exact PIDs) instead of waiting it out
+        failed_at = None
+        while any(q.poll() is None for q in procs):
+            if failed_at is None and any(q.poll() not in (None, 0) for q in procs):
+                failed_at = time.monotonic()
+            if failed_at is not None and time.monotonic() - failed_at > 10.0:
+                for q in procs:
+                    if q.poll() is None:
+                        q.kill()
+            time.sleep(0.1)
+        codes = [q.wait() for q in procs]
+        out0.seek(0)
+        out0 = out0.read()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    lines = [l for l in (out0 or "").splitlines() if l.startswith("{")]
+    if bad or len(lines) != 1:
+        sys.stderr.write(f"bench.py launcher: ranks failed (rank, exit code): {bad}; rank 0 printed {len(lines)} JSON line(s)\n")
+        return next((c for _, c in bad if c), 1) or 1
+    print(lines[0])
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,7 +198,11 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the rig configurations (configs[3], configs[4])")
+    ap.add_argument("--no-class-surface", action="store_true", help="skip the class-surface legs (they run as child processes of "
+                    "their own: a rocprofv3 trace of this command then holds the bench loop's process only)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -164,7 +212,7 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
-        raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE=1")
 
     import torch  # device/runtime plumbing: loads the ROCm runtime the library binds to
 
@@ -488,8 +536,8 @@ def main():
             "time_to_converge_ms": conv_ms,
             "observations_per_sec": n_obs_total * args.steps / elapsed,
             "one_shot_ms_including_upload": e2e_ms,
-            "class_surface": class_surface(args.frames, args.points) if world == 1 else None,
-            "class_surface_rig": class_surface_rig(4, 400, 300) if world == 1 and not args.no_configs else None,
+            "class_surface": class_surface(args.frames, args.points) if world == 1 and not args.no_class_surface else None,
+            "class_surface_rig": class_surface_rig(4, 400, 300) if world == 1 and not args.no_configs and not args.no_class_surface else None,
             "per_solve_us_per_iteration": {"n_solves": len(per_iter_us), "median": float(np.median(per_iter_us)),
                                            "min": float(np.min(per_iter_us)), "max": float(np.max(per_iter_us))},
             "converged": {"termination": conv["termination"], "final_cost": conv["final_cost"],
@@ -608,10 +656,10 @@ def rig_configs(capi, device):
             p = prob.solve(capi.default_options(max_iterations=1000, profile_kernels=1), log_capacity=0)
             prob.close()
             t_solve = float(np.median(ts))
-            # the profile counts every launch of a chunk; the ones after the terminating iteration return at once
+            # per kernel ONE number: the mean over the launches that did work (the library keeps the launches of the last chunk
+            # that return at once after the terminating decision apart: kernel_idle_*, cc_solver.h)
             per_launch = {k: (p["kernel_ms"][k] / p["kernel_launches"][k] if p["kernel_launches"][k] else None) for k in p["kernel_ms"]}
-            sweeps = s["iterations"] + 1
-            sweep_ms = p["kernel_ms"]["sweep"] / sweeps
+            sweep_ms = per_launch["sweep"]
             ab = algorithmic_bytes_rig_sweep(n_obs, n_world, F, C_)
             sweep_name = "k_rig_sweep_frame (one workgroup per frame, a wave per (frame, camera) group)" if variant == "poses" else "k_rig_sweep_adjk"
             names = {"sweep": sweep_name, "decide": "k_rig_init", "elim": "k_rig_elim", "solve": "k_rig_reduce (column sums + reduced solve + pose update)",
@@ -620,7 +668,7 @@ def rig_configs(capi, device):
             # configs[3] the latency-bound reduce + solve + update launch is
             total_ms = sum(v for v in p["kernel_ms"].values() if v)
             dom = max((k for k in p["kernel_ms"] if p["kernel_launches"][k]), key=lambda k: p["kernel_ms"][k])
-            dominant = {"kernel": names.get(dom, dom), "ms_per_launch": per_launch[dom], "share_of_kernel_time": p["kernel_ms"][dom] / total_ms}
+            dominant = {"kernel": names.get(dom, dom), "ms_per_full_launch": per_launch[dom], "share_of_kernel_time": p["kernel_ms"][dom] / total_ms}
             if dom == "sweep":
                 dominant.update(bound="fp64 issue / hbm", hbm_frac=ab / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 fp64_frac=RIG_FLOP_PER_OBS[variant] * n_obs / (sweep_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS)
@@ -632,7 +680,7 @@ def rig_configs(capi, device):
                 # the timed solves ran as ONE launch (lean persistent kernel + its control workgroup's launch); the per-kernel
                 # figures below are the three-kernel form's, which is what a profiled solve runs
                 dominant = {"kernel": "k_rig_persist_w (the whole solve in one launch; control workgroup: k_rig_persist_ctl)",
-                            "ms_per_launch": t_solve * 1e3, "share_of_kernel_time": 1.0, "bound": "latency",
+                            "ms_per_full_launch": t_solve * 1e3, "share_of_kernel_time": 1.0, "bound": "latency",
                             "note": "a round is a chain of dependent steps across workgroups (broadcast, pose update, sweep, elimination, "
                                     "column sums, reduced solve): no bandwidth or flop roofline applies; round timeline in "
                                     "profiles/r03/rig_persist_marks.jsonl"}
@@ -644,11 +692,12 @@ def rig_configs(capi, device):
                 "residuals_per_sec": 2.0 * n_obs * s["iterations"] / t_solve,
                 "solver_form": {0: "three kernels per LM iteration", 2: "lean persistent kernel: one launch per solve"}[form],
                 "dominant_kernel": dominant,
-                "sweep_kernel": {"kernel": sweep_name, "ms_per_launch": sweep_ms,
+                "sweep_kernel": {"kernel": sweep_name, "ms_per_full_launch": sweep_ms,
                                  "hbm_frac": ab / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  "fp64_frac": RIG_FLOP_PER_OBS[variant] * n_obs / (sweep_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                                  "algorithmic_bytes_per_launch": ab, "traffic": load_rig_traffic(C_, F, M, variant)},
-                "kernel_ms_per_launch_eager": per_launch,
+                "kernel_ms_per_full_launch_eager": per_launch,
+                "idle_launches_of_the_profiled_solve": {k: v for k, v in p["kernel_idle_launches"].items() if v},
                 "kernel_ms_labels": "(the THREE-KERNEL form: what profile_kernels = 1 runs) sweep = k_rig_sweep_frame (poses: per group the 7-column Gram of [J_cam r], per frame ONE "
                                     "assembly of the coupling blocks and the frame block through the groups' adjoints) / k_rig_sweep_adjk (with intrinsics), decide = k_rig_init "
                                     "(once per solve), elim = k_rig_elim, solve = k_rig_reduce (column sums + reduced solve + pose update in one launch)",

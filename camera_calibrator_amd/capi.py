@@ -70,6 +70,8 @@ class Summary(C.Structure):
         ("sweeps", C.c_int32),
         ("kernel_ms", C.c_double * 8),
         ("kernel_launches", C.c_int32 * 8),
+        ("kernel_idle_ms", C.c_double * 8),
+        ("kernel_idle_launches", C.c_int32 * 8),
     ]
 
 
@@ -157,6 +159,8 @@ def _summary_dict(s, log):
         "sweeps": s.sweeps,
         "kernel_ms": {K_NAMES[i]: s.kernel_ms[i] for i in range(len(K_NAMES))},
         "kernel_launches": {K_NAMES[i]: s.kernel_launches[i] for i in range(len(K_NAMES))},
+        "kernel_idle_ms": {K_NAMES[i]: s.kernel_idle_ms[i] for i in range(len(K_NAMES))},
+        "kernel_idle_launches": {K_NAMES[i]: s.kernel_idle_launches[i] for i in range(len(K_NAMES))},
         "log": [{k: getattr(log[i], k) for k in names} for i in range(s.log_len)],
     }
 

@@ -145,6 +145,23 @@ __host__ inline void opts_from_public(const cc_options& o, LmOpts* d) {
   d->max_lm_diagonal = o.max_lm_diagonal;
 }
 
+// profile_kernels = 1: event pairs of a solve -> per-kind totals. Rounds are enqueued a chunk at a time, so the launches after
+// the terminating decision (made in round `iter`) return at once: they go to kernel_idle_*, not into the per-launch averages.
+// A launch of round r did work if r < iter, or r == iter for the kinds ahead of the decision (sweep, statistics).
+template <class Event, class Elapsed>
+inline void summarise_probes(const std::vector<Event>& events, const std::vector<int>& kinds, const std::vector<int>& rounds, int iter,
+                             cc_summary* s, Elapsed elapsed_ms) {
+  for (int i = 0; i < CC_K_COUNT; ++i) { s->kernel_ms[i] = s->kernel_idle_ms[i] = 0.0; s->kernel_launches[i] = s->kernel_idle_launches[i] = 0; }
+  for (size_t i = 0; i < kinds.size(); ++i) {
+    float ms = 0.f;
+    if (!elapsed_ms(&ms, events[2 * i], events[2 * i + 1])) continue;
+    const int k = kinds[i], r = i < rounds.size() ? rounds[i] : 0;
+    const bool worked = r < iter || (r == iter && (k == CC_K_SWEEP || k == CC_K_DECIDE));
+    if (worked) { s->kernel_ms[k] += ms; s->kernel_launches[k]++; }
+    else { s->kernel_idle_ms[k] += ms; s->kernel_idle_launches[k]++; }
+  }
+}
+
 #if defined(__HIPCC__)
 
 // One log record per LM iteration. lm_decide fills `e` (when the caller passes one); the caller stores it at

@@ -1048,6 +1048,8 @@ struct cc_intrinsics {
   bool exchange = false;
   std::vector<hipEvent_t> events;
   std::vector<int> event_kind;
+  std::vector<int> event_round;   // round of the solve a probed launch belongs to (summarise_probes)
+  int enq_round = 0;
   // persistent per-solve kernel (cc_intrinsics_persist.hip): usable when every frame gets a team of a resident workgroup
   int form_reruns = 0;          // persistent solves that gave up and were run again in the two-kernel form (cc_intrinsics_solver_status)
   std::string form_note;        // why
@@ -1074,12 +1076,12 @@ static void exchange_release(cc_intrinsics* h) {
 }
 
 struct Probe {  // optional hipEvent bracket around one launch
-  cc_intrinsics* h; int kind; bool on; hipEvent_t e0 = nullptr, e1 = nullptr;
-  Probe(cc_intrinsics* h_, int kind_, bool on_) : h(h_), kind(kind_), on(on_) {
+  cc_intrinsics* h; int kind; bool on; int round_shift; hipEvent_t e0 = nullptr, e1 = nullptr;
+  Probe(cc_intrinsics* h_, int kind_, bool on_, int round_shift_ = 0) : h(h_), kind(kind_), on(on_), round_shift(round_shift_) {
     if (on) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, h->stream); }
   }
   ~Probe() {
-    if (on) { hipEventRecord(e1, h->stream); h->events.push_back(e0); h->events.push_back(e1); h->event_kind.push_back(kind); }
+    if (on) { hipEventRecord(e1, h->stream); h->events.push_back(e0); h->events.push_back(e1); h->event_kind.push_back(kind); h->event_round.push_back(h->enq_round + round_shift); }
   }
 };
 
@@ -1106,11 +1108,12 @@ static void launch_reset(cc_intrinsics* h) {
 static int enqueue_round(cc_intrinsics* h, bool profile, bool initial, bool publish, bool restart = false) {
   const int pub = (publish ? 1 : 0) | (restart ? 4 : 0);
   const int sweep_flags = 1 | (restart ? 2 : 0);
+  struct RoundCount { cc_intrinsics* h; ~RoundCount() { h->enq_round++; } } count_round{h};
   if (h->comm) {
-    if (!initial) {
-      { Probe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_intr_solve<1>, dim3(1), dim3(kSolveThreads), 0, h->stream, h->d, h->elim_blocks, 0); }
-      { Probe p(h, CC_K_ALLREDUCE, profile); if (int rc = comm_allreduce_sum(h->comm, h->d.vec_solve, kVecSolve, h->stream)) return rc; }
-      { Probe p(h, CC_K_SOLVE, profile); hipLaunchKernelGGL(k_intr_solve<2>, dim3(1), dim3(kSolveThreads), 0, h->stream, h->d, h->elim_blocks, 0); }
+    if (!initial) {   // (the solve step at the head of round r belongs to the iteration decided in round r - 1)
+      { Probe p(h, CC_K_SOLVE, profile, -1); hipLaunchKernelGGL(k_intr_solve<1>, dim3(1), dim3(kSolveThreads), 0, h->stream, h->d, h->elim_blocks, 0); }
+      { Probe p(h, CC_K_ALLREDUCE, profile, -1); if (int rc = comm_allreduce_sum(h->comm, h->d.vec_solve, kVecSolve, h->stream)) return rc; }
+      { Probe p(h, CC_K_SOLVE, profile, -1); hipLaunchKernelGGL(k_intr_solve<2>, dim3(1), dim3(kSolveThreads), 0, h->stream, h->d, h->elim_blocks, 0); }
     }
     launch_sweep(h, profile, 1);
     { Probe p(h, CC_K_DECIDE, profile); hipLaunchKernelGGL(k_intr_stats_reduce, dim3(1), dim3(256), 0, h->stream, h->d); }
@@ -1611,6 +1614,8 @@ static int solve_begin(cc_intrinsics* h, const cc_options* opt, SolveRun* r) {
   for (auto e : h->events) hipEventDestroy(e);
   h->events.clear();
   h->event_kind.clear();
+  h->event_round.clear();
+  h->enq_round = 0;
   if (r->use_graph && h->graph_iters != o.check_interval) { drop_graphs(h); h->graph_iters = o.check_interval; }
   return 0;
 }
@@ -1731,21 +1736,14 @@ static int solve_finish(cc_intrinsics* h, SolveRun* r, cc_summary* summary) {
     const int n = user_log ? std::min(std::min(st.log_len, cap), h->d.log_cap) : 0;
     summary->log_len = n;
     if (n > 0) CC_HIP(hipMemcpy(user_log, h->d.log, (size_t)n * sizeof(cc_iteration), hipMemcpyDeviceToHost));
-    for (int i = 0; i < CC_K_COUNT; ++i) { summary->kernel_ms[i] = 0.0; summary->kernel_launches[i] = 0; }
-    if (r->profile) {
-      for (size_t i = 0; i < h->event_kind.size(); ++i) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, h->events[2 * i], h->events[2 * i + 1]) == hipSuccess) {
-          summary->kernel_ms[h->event_kind[i]] += ms;
-          summary->kernel_launches[h->event_kind[i]]++;
-        }
-      }
-    }
+    summarise_probes(h->events, r->profile ? h->event_kind : std::vector<int>(), h->event_round, st.iter, summary,
+                     [](float* ms, hipEvent_t a, hipEvent_t b) { return hipEventElapsedTime(ms, a, b) == hipSuccess; });
     summary->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - r->t0).count();
   }
   for (auto e : h->events) hipEventDestroy(e);
   h->events.clear();
   h->event_kind.clear();
+  h->event_round.clear();
   return CC_OK;
 }
 }  // namespace cc

@@ -4830,6 +4830,8 @@ struct cc_rig {
   size_t reduce_key = ~(size_t)0;
   std::vector<hipEvent_t> events;
   std::vector<int> event_kind;
+  std::vector<int> event_round;   // round of the solve a probed launch belongs to (summarise_probes)
+  int enq_round = 0;
 };
 
 namespace cc {
@@ -4874,12 +4876,12 @@ static void rig_drop_graphs(cc_rig* h) {
 }
 
 struct RigProbe {  // optional hipEvent bracket around one launch
-  cc_rig* h; int kind; bool on; hipEvent_t e0 = nullptr, e1 = nullptr;
-  RigProbe(cc_rig* h_, int kind_, bool on_) : h(h_), kind(kind_), on(on_) {
+  cc_rig* h; int kind; bool on; int round_shift; hipEvent_t e0 = nullptr, e1 = nullptr;
+  RigProbe(cc_rig* h_, int kind_, bool on_, int round_shift_ = 0) : h(h_), kind(kind_), on(on_), round_shift(round_shift_) {
     if (on) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, h->stream); }
   }
   ~RigProbe() {
-    if (on) { hipEventRecord(e1, h->stream); h->events.push_back(e0); h->events.push_back(e1); h->event_kind.push_back(kind); }
+    if (on) { hipEventRecord(e1, h->stream); h->events.push_back(e0); h->events.push_back(e1); h->event_kind.push_back(kind); h->event_round.push_back(h->enq_round + round_shift); }
   }
 };
 
@@ -4930,15 +4932,13 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
   if (CO > 64) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: %d observed cameras; at most 64", CO);
   const int DE = kmode ? kDEK : kDE0;
   // beyond what the tuned kernels are built around (S <= 127 shared coordinates, 1536 direct sums): the plain ones
-  // (k_rig_elim_big, k_rig_solve_big), single GPU only
+  // (k_rig_elim_big, k_rig_solve_big) -- on one GPU or sharded, over either exchange (this function runs again from the attach
+  // calls when a peer observes a camera this rank does not: the layout below is then the large-rig one for the GLOBAL cameras)
   h->big = S > kRigMaxS || CO * DE > 64 * kRigDirectPerLane;
   if (const char* e = getenv("CC_RIG_FORCE_BIG")) h->big = h->big || atoi(e) != 0;   // (test knob: the plain kernels on any problem, sharded or not)
   // the frame form of the sweep feeds the tuned elimination only (the plain large-rig kernels read the 16 x 16 tiles)
   d.fmode = (!kmode && h->sweep_adjoint && h->frame_allowed && S <= kRigMaxS && CO * DE <= 64 * kRigDirectPerLane &&
              !(getenv("CC_RIG_FORCE_BIG") && atoi(getenv("CC_RIG_FORCE_BIG")) != 0)) ? 1 : 0;
-  if (h->big && (h->comm || h->exchange))
-    return fail(CC_ERR_BAD_ARGUMENT, "%d shared coordinates, %d observed cameras%s: more than %d coordinates or %d cameras are not supported across several GPUs",
-                S, CO, kmode ? " with intrinsics" : "", kRigMaxS, 64 * kRigDirectPerLane / DE);
   d.C = (int32_t)C; d.CO = CO; d.CK = CK; d.S = S; d.SW = S + 1;
   d.T = (d.SW + 15) / 16; d.nT = d.T * (d.T + 1) / 2; d.ZS = 16 * d.T + ((d.T & 1) ? 0 : 16);
   d.DE = DE; d.ND = CO * DE;
@@ -5210,6 +5210,7 @@ static int rig_size_reduce_grid(cc_rig* h) {
 // the initial evaluation.
 static int rig_enqueue_round(cc_rig* h, bool initial, bool profile, bool publish = false) {
   const RigDev& d = h->d;
+  struct RoundCount { cc_rig* h; ~RoundCount() { h->enq_round++; } } count_round{h};
   { RigProbe p(h, CC_K_SWEEP, profile);
     if (d.kmode && h->sweep_adjoint && h->sweep_waves == 1) hipLaunchKernelGGL(k_rig_sweep_adjk<1>, dim3((unsigned)h->NG), dim3(64), 0, h->stream, d);
     else if (d.kmode && h->sweep_adjoint) hipLaunchKernelGGL(k_rig_sweep_adjk<4>, dim3((unsigned)h->NG), dim3(256), 0, h->stream, d);
@@ -5895,6 +5896,8 @@ static int rig_begin(cc_rig* h, const cc_options* opt, RigRun* r) {
   for (auto e : h->events) hipEventDestroy(e);
   h->events.clear();
   h->event_kind.clear();
+  h->event_round.clear();
+  h->enq_round = 0;
   if (r->use_graph && h->graph_iters != o.check_interval) { rig_drop_graphs(h); h->graph_iters = o.check_interval; }
   return 0;
 }
@@ -6051,21 +6054,14 @@ static int rig_finish(cc_rig* h, RigRun* r, cc_summary* summary) {
     const int n = user_log ? std::min(std::min(st.log_len, cap), h->d.log_cap) : 0;
     summary->log_len = n;
     if (n > 0) CC_HIP(hipMemcpy(user_log, h->d.log, (size_t)n * sizeof(cc_iteration), hipMemcpyDeviceToHost));
-    for (int i = 0; i < CC_K_COUNT; ++i) { summary->kernel_ms[i] = 0.0; summary->kernel_launches[i] = 0; }
-    if (r->profile) {
-      for (size_t i = 0; i < h->event_kind.size(); ++i) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, h->events[2 * i], h->events[2 * i + 1]) == hipSuccess) {
-          summary->kernel_ms[h->event_kind[i]] += ms;
-          summary->kernel_launches[h->event_kind[i]]++;
-        }
-      }
-    }
+    summarise_probes(h->events, r->profile ? h->event_kind : std::vector<int>(), h->event_round, st.iter, summary,
+                     [](float* ms, hipEvent_t a, hipEvent_t b) { return hipEventElapsedTime(ms, a, b) == hipSuccess; });
     summary->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - r->t0).count();
   }
   for (auto e : h->events) hipEventDestroy(e);
   h->events.clear();
   h->event_kind.clear();
+  h->event_round.clear();
   return CC_OK;
 }
 }  // namespace cc
@@ -6089,15 +6085,20 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
     if (int rc = rig_launch(h, &r, chunk)) return rc;
     if (chunk == 0) hp.mark("launch0");
     if (int rc = rig_wait(h, &r)) return rc;
-    if (lean_lock.owns_lock()) lean_lock.unlock();
+    // (a lean solve that gave up: its control launch on the second stream may still be queued or spinning -- the lock is kept
+    // until both streams have drained below, or another thread's lean solve would start next to that late control workgroup)
+    if (lean_lock.owns_lock() && !r.rerun) lean_lock.unlock();
     if (chunk == 0) hp.mark("wait0");
     if (r.rerun) {
       // The lean persistent launch could not get every workgroup resident (a device shared with another process, or the
       // control launch not scheduled next to the workers): a wait inside it gave up after 1.3 s. Frame poses go back to
       // global memory only at the end of a solve that did not fail, and the cameras of the starting point were put
       // aside: restore them and run the solve again, three kernels per iteration (no co-residency needed).
-      CC_HIP(hipStreamSynchronize(h->stream));
-      if (h->stream2) CC_HIP(hipStreamSynchronize(h->stream2));
+      const hipError_t e_s1 = hipStreamSynchronize(h->stream);
+      const hipError_t e_s2 = h->stream2 ? hipStreamSynchronize(h->stream2) : hipSuccess;
+      if (lean_lock.owns_lock()) lean_lock.unlock();
+      CC_HIP(e_s1);
+      CC_HIP(e_s2);
       CC_HIP(hipMemcpyAsync(h->d.cam, h->d_cam_backup, (size_t)h->C * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
       h->last_st = LmCtl{};   // (buffer 0 holds the starting point)
       h->st_known = true;

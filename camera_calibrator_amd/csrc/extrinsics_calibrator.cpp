@@ -212,7 +212,13 @@ void ExtrinsicsCalibrator::Optimize() {
   last_timing_ms_[1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lib).count();
   const auto t_back = std::chrono::steady_clock::now();
   // per-observation robustified half_rho (extrinsics_calibrator.cpp:219-225)
-  if (several && N > 0 && C > 0 && F > 0)
+  // A call that failed without throwing (CC_ERR_STATE, ...) leaves no costs of ANOTHER problem behind: flat_.rho may be storage
+  // recycled from an earlier object, and on one device the library skips its write-back -- zeros in both cases.
+  if (last_status_ != 0 && N > 0)
+    over_frames([&](size_t f0, size_t f1) {
+      for (size_t f = f0; f < f1; ++f) for (auto& o : frames_[f].sightings) o.half_rho = 0.0;
+    });
+  else if (several && N > 0 && C > 0 && F > 0)
     over_frames([&](size_t f0, size_t f1) {
       for (size_t f = f0; f < f1; ++f) {
         size_t k = (size_t)offsets[f];

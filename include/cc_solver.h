@@ -95,8 +95,12 @@ typedef struct cc_summary {
   int32_t log_capacity;
   int32_t sweeps;            /* Jacobian sweeps launched (1 initial + 1 per valid LM iteration) */
   /* profile_kernels=1 only: per-kernel device time from hipEvents on the solver's stream */
-  double kernel_ms[CC_K_COUNT];      /* total ms per kernel kind */
+  double kernel_ms[CC_K_COUNT];      /* total ms per kernel kind, over the launches that DID WORK (see kernel_idle_*) */
   int32_t kernel_launches[CC_K_COUNT];
+  /* the launches of the last chunk that came after the terminating decision and returned at once (rounds are enqueued
+   * check_interval at a time): kept apart so that kernel_ms / kernel_launches is the time of a launch that does work */
+  double kernel_idle_ms[CC_K_COUNT];
+  int32_t kernel_idle_launches[CC_K_COUNT];
 } cc_summary;
 
 void cc_options_init(cc_options* o);

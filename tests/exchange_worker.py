@@ -11,7 +11,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def rig_main(rank, world, frames, pts, out, dist, capi):
     """argv[7] = "rig:<cams>" (the reference's rig problem), "rigk:<cams>" (extension: + shared intrinsics) or
-    "rigkpc:<cams>" (extension: + one set of intrinsics per camera)."""
+    "rigkpc:<cams>" (extension: + one set of intrinsics per camera); "rigdrop:<cams>": the rig problem with the last camera
+    unobserved in rank 0's shard."""
     from oracle import pyoracle as po      # scenario generator only (test input)
     with_k = sys.argv[7].startswith("rigk")
     per_cam = sys.argv[7].startswith("rigkpc")
@@ -23,11 +24,17 @@ def rig_main(rank, world, frames, pts, out, dist, capi):
                   world_xyz=k["world_xyz"], cam_frozen=k["cam_frozen"])
         cq, ct, fq, ft = k["cam_q0"], k["cam_t0"], k["frame_q0"], k["frame_t0"]
     else:
-        sc = po.rig_scenario(cams, frames, pts)
+        first = None
+        if sys.argv[7].startswith("rigdrop"):   # rank 0's shard does not observe the last camera
+            from tests.helpers import rig_case_with_a_camera_missing_from_shard0
+            sc, first = rig_case_with_a_camera_missing_from_shard0(cams, frames, pts, world)
+        else:
+            sc = po.rig_scenario(cams, frames, pts)
         cq, ct = po.affine_to_qt(sc["cam_T"])
         fq, ft = po.affine_to_qt(sc["frame_T"])
     off = sc["frame_offsets"]
-    first = capi.partition_frames(off, world)
+    if with_k or first is None:
+        first = capi.partition_frames(off, world)
     f0, f1 = int(first[rank]), int(first[rank + 1])
     o0, o1 = int(off[f0]), int(off[f1])
     prob = capi.RigProblem(cams, off[f0:f1 + 1] - o0, sc["obs_cam"][o0:o1], sc["obs_world"][o0:o1], sc["obs_uv"][o0:o1],

@@ -43,3 +43,20 @@ def rig_outlier_case(cams, frames, pts, frac=0.10, seed=1, lo=0.02, hi=0.06):
     sc["cam_q0"], sc["cam_t0"] = po.affine_to_qt(sc["cam_T"])
     sc["frame_q0"], sc["frame_t0"] = po.affine_to_qt(sc["frame_T"])
     return sc
+
+
+def rig_case_with_a_camera_missing_from_shard0(cams, frames, pts, world):
+    """The reference's rig scenario with every observation of the LAST camera removed from the frames of rank 0's shard (the
+    shard boundaries `first` are fixed BEFORE the removal and returned with the case): rank 0 then does not observe a camera
+    its peers do, so the attach call has to lay its shared block out again for the global camera set."""
+    from camera_calibrator_amd import capi
+    sc = po.rig_scenario(cams, frames, pts)
+    off = np.asarray(sc["frame_offsets"], dtype=np.int64)
+    first = capi.partition_frames(off, world)
+    frame_of = np.repeat(np.arange(frames), np.diff(off))
+    keep = ~((np.asarray(sc["obs_cam"]) == cams - 1) & (frame_of < first[1]))
+    out = dict(sc)
+    for k in ("obs_cam", "obs_world", "obs_uv"):
+        out[k] = np.ascontiguousarray(np.asarray(sc[k])[keep])
+    out["frame_offsets"] = np.concatenate([[0], np.cumsum(np.bincount(frame_of[keep], minlength=frames))]).astype(np.int64)
+    return out, first

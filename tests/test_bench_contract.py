@@ -44,3 +44,57 @@ def test_bench_refuses_to_run_without_a_gpu():
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert r.returncode != 0 and "needs a GPU" in (r.stderr + r.stdout)
     assert r.stdout.strip() == ""          # no JSON line from a run that measured nothing
+
+
+def test_bare_multi_gpu_command_starts_its_ranks_before_any_gpu_call():
+    """`python bench.py --gpus N` without WORLD_SIZE (what the driver's one-GPU command looks like with N = 8) must start N
+    fresh rank processes itself -- with the environment torch.distributed.run would give them -- before torch or the HIP
+    runtime is loaded in the launching process."""
+    code = r"""
+import json, os, sys
+sys.argv = ["bench.py", "--gpus", "3", "--steps", "7", "--warmup", "2"]
+os.environ.pop("WORLD_SIZE", None)
+import subprocess
+started = []
+class FakePopen:
+    def __init__(self, cmd, env=None, stdout=None, **kw):
+        assert "torch" not in sys.modules and "camera_calibrator_amd.capi" not in sys.modules
+        started.append((cmd, {k: env[k] for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}))
+        if env["RANK"] == "0":
+            stdout.write(json.dumps({"metric": "x", "n_gpus": 3}) + chr(10)); stdout.flush()
+        self.returncode = 0
+    def poll(self): return 0
+    def wait(self, timeout=None): return 0
+    def kill(self): pass
+subprocess.Popen = FakePopen
+import bench
+try:
+    bench.main()
+except SystemExit as e:
+    rc = e.code
+assert "torch" not in sys.modules, "launcher imported torch"
+print(json.dumps({"rc": rc, "started": started}))
+"""
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert json.loads(lines[0]) == {"metric": "x", "n_gpus": 3}          # rank 0's line, relayed
+    rep = json.loads(lines[1])
+    assert rep["rc"] == 0 and len(rep["started"]) == 3
+    ports = set()
+    for rank, (cmd, env) in enumerate(rep["started"]):
+        assert cmd[1].endswith("bench.py") and cmd[2:] == ["--gpus", "3", "--steps", "7", "--warmup", "2"]
+        assert env["RANK"] == env["LOCAL_RANK"] == str(rank) and env["WORLD_SIZE"] == "3" and env["MASTER_ADDR"] == "127.0.0.1"
+        ports.add(env["MASTER_PORT"])
+    assert len(ports) == 1
+
+
+def test_bare_multi_gpu_command_fails_loudly_when_a_rank_fails():
+    import torch
+    if torch.cuda.is_available():
+        return   # (on a GPU box the ranks would run: tests/test_gpu_bench_ranks.py covers that)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and "needs a GPU" in r.stderr and "ranks failed" in r.stderr
+    assert r.stdout.strip() == ""

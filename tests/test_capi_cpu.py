@@ -72,7 +72,7 @@ def test_struct_layouts_match_header():
     import ctypes as C
     assert C.sizeof(capi.Options) == 6 * 4 + 9 * 8 + 2 * 4
     assert C.sizeof(capi.Iteration) == 7 * 8 + 2 * 4
-    assert C.sizeof(capi.Summary) == 4 * 4 + 3 * 8 + 8 + 2 * 4 + 8 * 8 + 8 * 4
+    assert C.sizeof(capi.Summary) == 4 * 4 + 3 * 8 + 8 + 2 * 4 + 2 * (8 * 8 + 8 * 4)
 
 
 @pytest.mark.parametrize("nranks", [1, 2, 3, 4, 8])

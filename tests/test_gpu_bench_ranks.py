@@ -18,12 +18,17 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(extra_env, frames):
+def _run(extra_env, frames, bare=False):
     env = dict(os.environ, CC_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0",
                GPU_MAX_HW_QUEUES="8", **extra_env)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "4",
-           "--frames", str(frames), "--points", "120"]
+    bench = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "4", "--frames", str(frames), "--points", "120"]
+    if bare:   # the driver's one-GPU command shape with N = 2: no launcher in front, no WORLD_SIZE -- bench.py starts its ranks itself
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+            env.pop(k, None)
+        cmd = [sys.executable] + bench
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + bench
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -48,3 +53,10 @@ def test_two_rank_bench_line_as_independent_replicas():
     d = _run({"CC_EXCHANGE": "replicas"}, 40)
     assert d["n_gpus"] == 2 and d["config"]["exchange"].startswith("none: independent replicas")
     assert d["config"]["parallelism"] == "independent replicas x2" and d["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bare_command_starts_two_ranks_by_itself():
+    d = _run({"CC_EXCHANGE": "mailbox"}, 40, bare=True)
+    assert d["n_gpus"] == 2 and d["steps"] == 8 and d["config"]["exchange"] == "mailbox" and d["config"]["frames_total"] == 80
+    assert [r["rank"] for r in d["config"]["ranks"]] == [0, 1] and d["value"] > 0 and d["strong_scaling"]["value"] > 0

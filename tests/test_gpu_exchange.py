@@ -141,6 +141,37 @@ def test_sharded_rig_solve_over_the_mailbox_exchange(world, cams, frames, pts, t
         assert np.array_equal(ranks[0]["default_cam_t"], ranks[0]["nograph_cam_t"])
 
 
+@pytest.mark.parametrize("cams,force_big", [(23, False), (5, False), (5, True)])
+def test_sharded_rig_where_one_shard_does_not_observe_a_camera(cams, force_big, tmp_path, monkeypatch):
+    """rank 0's shard holds no observation of the last camera, so cc_rig_exchange_attach lays the shared block
+    out again for the global camera set (rig_adopt_global_cameras -> rig_layout) with the exchange already attached -- for a
+    large rig (23 cameras: 132 shared coordinates, plain large-rig kernels; or any rig under CC_RIG_FORCE_BIG) that second
+    layout used to be refused ("not supported across several GPUs"), a rejection left over from before the large-rig kernels
+    took exchanges. The sharded result must equal the one-GPU solve of the same (reduced) problem."""
+    from oracle import pyoracle as po
+    from tests.helpers import rig_case_with_a_camera_missing_from_shard0
+    world, frames, pts = 2, 24, 8
+    if force_big:
+        monkeypatch.setenv("CC_RIG_FORCE_BIG", "1")   # (inherited by the rank processes)
+    ranks = _run_ranks(world, frames, pts, tmp_path, extra=(f"rigdrop:{cams}",))
+    sc, first = rig_case_with_a_camera_missing_from_shard0(cams, frames, pts, world)
+    assert not np.any(sc["obs_cam"][:sc["frame_offsets"][first[1]]] == cams - 1) and np.any(sc["obs_cam"] == cams - 1)
+    cq, ct = po.affine_to_qt(sc["cam_T"])
+    fq, ft = po.affine_to_qt(sc["frame_T"])
+    ref = capi.rig_optimize(cams, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"], sc["world_xyz"],
+                            cq, ct, sc["cam_frozen"], fq, ft, options=capi.default_options(max_iterations=1000))
+    for name in ("default", "nograph"):
+        for r in ranks:
+            assert np.array_equal(r[name + "_cam_q"], ranks[0][name + "_cam_q"]) and np.array_equal(r[name + "_cam_t"], ranks[0][name + "_cam_t"])
+            assert str(r[name + "_termname"]) == ref[5]["termination"] and int(r[name + "_iters"]) == ref[5]["iterations"]
+            assert np.allclose(r[name + "_costs"], [l["cost"] for l in ref[5]["log"]], rtol=1e-9)
+            f0, f1 = int(r["f0"]), int(r["f1"])
+            assert (f0, f1) == (int(first[int(f0 != 0)]), int(first[int(f0 != 0) + 1]))
+            dev = dict(cam_q=np.abs(r[name + "_cam_q"] - ref[0]).max(), cam_t=np.abs(r[name + "_cam_t"] - ref[1]).max(),
+                       frame_q=np.abs(r[name + "_frame_q"] - ref[2][f0:f1]).max(), frame_t=np.abs(r[name + "_frame_t"] - ref[3][f0:f1]).max())
+            assert max(dev.values()) < 1e-11, dev
+
+
 @pytest.mark.parametrize("world,cams,frames,pts", [(2, 3, 30, 20), (3, 6, 45, 12)])
 def test_sharded_rig_with_intrinsics_over_the_mailbox_exchange(world, cams, frames, pts, tmp_path):
     """The extension (cc_rigk_*) sharded over ranks: intrinsics replicated, bit-identical on every rank."""
