@@ -113,7 +113,7 @@ struct RigDev {
                     // elimination reads of a group (direct sums: G7; coupling columns: T); no 16 x 16 tile is written
   double* fsum;     // FRAME form: [2][F][32] per frame H_ff (21, packed lower triangle) and g_f (6), summed over its groups
   int32_t fmode;    // 1: the sweep is k_rig_sweep_frame (one workgroup per FRAME); gstats then holds one row per frame
-  int32_t pad_fm;
+  int32_t kcm;      // 1: (with intrinsics) the sweep is k_rig_sweep_k2: compact records of kRigRecK doubles in gcomp, no tiles
   double* sp;       // [F][8]
   double* ss;       // [128]
   double* ds;       // [128] scaled shared step
@@ -1437,6 +1437,327 @@ __global__ __launch_bounds__(NW * 64, CC_RIG_ADJK_WAVES) void k_rig_sweep_adjk(R
 }
 
 // ---------------------------------------------------------------------------------------------
+// EXTENSION, round 5: the sweep with intrinsics WITHOUT the matrix pipe, and with compact records (k_rig_sweep_k2).
+// On gfx950 v_mfma_f64_16x16x4_f64 runs at the rate of v_fma_f64 (32 flop per clock and SIMD) and the two share one datapath
+// (profiles/r01/microbench_f64.txt), so the 16 x 16 product of k_rig_sweep_adjk pays 2 x 256 multiply-adds per observation
+// for 2 x 136 useful ones, plus a staging round trip through LDS per row set. Here the 16-column Gram of
+// X = [J_cam(6) r J_k(9)] is accumulated by plain FMAs on its lower triangle, skipping the structural zeros of the pixel
+// model (d u / d (fy, py) = d v / d (fx, px) = 0: 105 products per row instead of 256): 210 FMAs per observation.
+// 132 accumulators do not fit one lane's 256 registers next to the projection, so a group is swept by TWO waves that split
+// the pairs (kK2 below, 66 each) and show each other their rows through LDS: per pass each wave evaluates 64 observations,
+// leaves the 28 non-zero row entries of each in LDS, and accumulates ITS pairs over both waves' 128 observations.
+// What leaves the group is ONE record of 256 doubles (P.gcomp) -- everything the elimination reads of a group:
+//   [0..134]   the direct sums in dmap order: G_cc (21) g_c (6) H_ck (54) H_kk (45) g_k (9)      [135] r^2
+//   [136..171] T = G_cc M (camera columns of the frame's coupling)   [172..225] H_fk = M^T H_ck (its intrinsics columns)
+//   [226..246] the group's share M^T G_cc M of the frame block       [247..252] its share M^T g_c of the frame gradient
+// instead of three 16 x 16 tiles and a 320-double compact record (8.5 KB per group and buffer -> 2 KB). The model-cost term of
+// a step is a weighted sum of the OLD record's entries (weights: products of the step's components, k2_qcoef).
+// ---------------------------------------------------------------------------------------------
+constexpr int kRigRecK = 256;
+constexpr int kRkR2 = 135, kRkT = 136, kRkFK = 172, kRkHff = 226, kRkGf = 247, kRkEnd = 253;
+constexpr bool k2_in_u(int c) { return c != 8 && c != 10; }   // columns with a non-zero entry in the u row / the v row
+constexpr bool k2_in_v(int c) { return c != 7 && c != 9; }
+struct K2Split {
+  signed char owner[136];   // wave that accumulates pair p = tri(i, j); -1: structurally zero
+  unsigned char slot[136];  // its accumulator: 0..63 summed by the butterfly (the sum ends in lane `slot`), 64.. by wave_sum
+  unsigned char inv[2][64]; // pair of butterfly slot s of wave w (255: none)
+  unsigned char dir[136];   // direct entry e (dmap order, [135] = r^2) -> pair
+  int n[2];
+};
+constexpr K2Split k2_make_split() {
+  K2Split s{};
+  int cost[2] = {0, 0};
+  s.n[0] = s.n[1] = 0;
+  for (int w = 0; w < 2; ++w) for (int k = 0; k < 64; ++k) s.inv[w][k] = 255;
+  for (int i = 0; i < 16; ++i)
+    for (int j = 0; j <= i; ++j) {
+      const int p = i * (i + 1) / 2 + j;
+      const int c = ((k2_in_u(i) && k2_in_u(j)) ? 1 : 0) + ((k2_in_v(i) && k2_in_v(j)) ? 1 : 0);
+      if (c == 0) { s.owner[p] = -1; s.slot[p] = 0; continue; }
+      const int w = cost[0] <= cost[1] ? 0 : 1;
+      s.owner[p] = (signed char)w;
+      s.slot[p] = (unsigned char)s.n[w];
+      if (s.n[w] < 64) s.inv[w][s.n[w]] = (unsigned char)p;
+      s.n[w]++;
+      cost[w] += c;
+    }
+  // direct entries: columns 0..5 camera, 6 residual, 7..15 intrinsics
+  int e = 0;
+  for (int i = 0; i < 6; ++i) for (int j = 0; j <= i; ++j) s.dir[e++] = (unsigned char)(i * (i + 1) / 2 + j);
+  for (int i = 0; i < 6; ++i) s.dir[e++] = (unsigned char)(6 * 7 / 2 + i);
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < 9; ++j) s.dir[e++] = (unsigned char)((7 + j) * (8 + j) / 2 + i);
+  for (int i = 0; i < 9; ++i) for (int j = 0; j <= i; ++j) s.dir[e++] = (unsigned char)((7 + i) * (8 + i) / 2 + 7 + j);
+  for (int j = 0; j < 9; ++j) s.dir[e++] = (unsigned char)((7 + j) * (8 + j) / 2 + 6);
+  s.dir[e++] = (unsigned char)(6 * 7 / 2 + 6);
+  return s;
+}
+constexpr K2Split kK2 = k2_make_split();
+static_assert(kK2.n[0] <= 68 && kK2.n[1] <= 68 && kK2.n[0] + kK2.n[1] == 132, "pairs per wave");
+__device__ const K2Split kK2Dev = k2_make_split();   // (the same tables where a lane indexes them at run time)
+constexpr int kK2Acc = 68;
+
+template <int W>
+__device__ __forceinline__ void k2_accumulate(const double* wu, const double* wv, double* acc) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      const int p = i * (i + 1) / 2 + j;
+      if (kK2.owner[p] == W) {
+        const int s = kK2.slot[p];
+        if (k2_in_u(i) && k2_in_u(j)) acc[s] = fma(wu[i], wu[j], acc[s]);
+        if (k2_in_v(i) && k2_in_v(j)) acc[s] = fma(wv[i], wv[j], acc[s]);
+      }
+    }
+  }
+}
+// 64 per-lane values -> their 64-lane sums, value e in lane e (reduce_scatter32 with one more halving in front and the last
+// step a halving too)
+__device__ __forceinline__ void reduce_scatter64(double* p, int lane) {
+  reduce_swap32<32>(p);
+  reduce_swap16<16>(p);
+  reduce_dpp<8, 0x128, 8>(p, lane);   // row_ror:8
+  reduce_dpp<4, 0x141, 4>(p, lane);   // row_half_mirror
+  reduce_dpp<2, 0x4E, 2>(p, lane);    // quad_perm:[2,3,0,1]
+  reduce_dpp<1, 0xB1, 1>(p, lane);    // quad_perm:[1,0,3,2]
+}
+// weight of entry e of a group's OLD record in the model-cost term q = g^T d + 1/2 d^T H d of the step d = (dc, df, dk)
+__device__ __forceinline__ double k2_qcoef(int e, const double* dc, const double* df, const double* dk) {
+  auto tri_ij = [](int idx, int& i, int& j) { i = 0; while ((i + 1) * (i + 2) / 2 <= idx) ++i; j = idx - i * (i + 1) / 2; };
+  int i, j;
+  if (e < 21) { tri_ij(e, i, j); return (i == j ? 0.5 : 1.0) * dc[i] * dc[j]; }
+  if (e < 27) return dc[e - 21];
+  if (e < 81) { i = (e - 27) / 9; j = (e - 27) - 9 * i; return dc[i] * dk[j]; }
+  if (e < 126) { tri_ij(e - 81, i, j); return (i == j ? 0.5 : 1.0) * dk[i] * dk[j]; }
+  if (e < 135) return dk[e - 126];
+  if (e < kRkT) return 0.0;
+  if (e < kRkFK) { i = (e - kRkT) / 6; j = (e - kRkT) - 6 * i; return dc[i] * df[j]; }
+  if (e < kRkHff) { i = (e - kRkFK) / 9; j = (e - kRkFK) - 9 * i; return df[i] * dk[j]; }
+  if (e < kRkGf) { tri_ij(e - kRkHff, i, j); return (i == j ? 0.5 : 1.0) * df[i] * df[j]; }
+  if (e < kRkEnd) return df[e - kRkGf];
+  return 0.0;
+}
+
+#ifndef CC_RIG_K2_WAVES
+#define CC_RIG_K2_WAVES 2   // waves per SIMD the kernel is compiled for (256 registers)
+#endif
+__global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P) {
+  __shared__ __attribute__((aligned(16))) d2 s_rows[2 * 14 * 64];   // [wave][q][lane]: u row entries (q < 7), v row entries
+  __shared__ double sm[96];        // camera record, frame record, intrinsics record (candidate [0..8], step [16..24])
+  __shared__ double s_G[144];      // lower triangle of G by pair, [136] cost of wave 0, [137] of wave 1, [138..139] model-cost sums
+  __shared__ double s_m[36];       // M
+  __shared__ double s_T[128];      // T (36) | H_fk (54) | g_f share (6) | H_ff share (21)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t g = blockIdx.x;
+  const int f = P.gframe[g], c = P.gcam[g];
+  const int64_t s0 = P.goff[g], s1 = P.goff[g + 1];
+  const LmCtl* ctl = P.ctl;
+  const int done = ctl->done, phase = ctl->phase, step_valid = ctl->step_valid, cur = ctl->cur;
+  if (done) return;
+  if (phase != 0 && !step_valid) return;
+  const int dst = phase == 0 ? cur : (cur ^ 1);
+  const bool fixed = P.cam_fixed[c] != 0;
+  const int ks = P.kset[c];
+  const int n = (int)(s1 - s0);
+  const int npass = (n + 127) >> 7;      // (the same for both waves: they meet at two barriers per pass)
+  const float2* uvg = reinterpret_cast<const float2*>(P.uv) + s0;
+  struct F3 { float x, y, z; };
+  const F3* xg = reinterpret_cast<const F3*>(P.oxyz) + s0;
+  struct ObsRaw { float2 m; F3 X; };
+  auto fetch = [&](int k, ObsRaw& r) {
+    const int kc = k < n ? k : 0;
+    r.m = uvg[kc];
+    r.X = xg[kc];
+  };
+  ObsRaw oa, ob;
+  fetch(tid, oa);
+  fetch(tid + 128, ob);
+  const double* rec_old = P.gcomp + ((size_t)cur * P.NG + g) * kRigRecK;
+  const double old0 = rec_old[tid], old1 = rec_old[tid + 128];
+  {
+    const double r0 = tid < 32 ? P.camrec[c * 32 + tid] : (tid < 64 ? P.frec[(size_t)f * 32 + (tid - 32)] : P.krec[ks * 32 + ((tid - 64) & 31)]);
+    if (tid < 96) sm[tid] = r0;
+  }
+  __syncthreads();
+  double Rca[9], tca[3], tcs[3], kk[9];
+  {
+    const double* cr = P.camrec + (size_t)c * 32;
+    const double* fr = P.frec + (size_t)f * 32;
+    const double* kr = P.krec + (size_t)ks * 32;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Rca[3 * i + j] = rfl(cr[3 * i] * fr[j] + cr[3 * i + 1] * fr[3 + j] + cr[3 * i + 2] * fr[6 + j]);
+      tca[i] = rfl(cr[3 * i] * fr[9] + cr[3 * i + 1] * fr[10] + cr[3 * i + 2] * fr[11]);
+      tcs[i] = cr[9 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) kk[i] = kr[i];
+  }
+  if (tid < 48) {   // M[a][b], a = tid >> 3, b = tid & 7 < 6 (see k_rig_sweep_adj)
+    const int a = tid >> 3, b = tid & 7;
+    const int a3 = a < 3 ? a : a - 3, b3 = b < 3 ? b : b - 3;
+    const int b1 = b3 == 2 ? 0 : b3 + 1, b2 = b3 == 0 ? 2 : b3 - 1;
+    const double diag = sm[3 * a3 + (b3 < 3 ? b3 : 0)];
+    const double cross = 2.0 * (sm[3 * a3 + b1] * sm[32 + 9 + b2] - sm[3 * a3 + b2] * sm[32 + 9 + b1]);
+    const double v = (a < 3) == (b < 3) ? diag : (a >= 3 ? cross : 0.0);
+    if (b < 6) s_m[a * 6 + b] = v;
+  }
+  // model-cost term of the step at the accepted point, from the group's old record (two entries per thread)
+  double qterm = 0.0;
+  if (phase != 0) {
+    double dc[6], df[6], dk[9];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { dc[i] = fixed ? 0.0 : sm[12 + i]; df[i] = sm[32 + 12 + i]; }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) dk[i] = sm[64 + 16 + i];
+    qterm = k2_qcoef(tid, dc, df, dk) * old0 + k2_qcoef(tid + 128, dc, df, dk) * old1;
+  }
+  const double ha = P.huber_a;
+  const uint32_t kmask = P.kmask[ks];
+  double acc[kK2Acc];
+#pragma unroll
+  for (int e = 0; e < kK2Acc; ++e) acc[e] = 0.0;
+  double cost = 0.0;
+  struct ObsD { double u, v, X0, X1, X2; };
+  auto widen = [](const ObsRaw& r, ObsD& d) { d.u = (double)r.m.x; d.v = (double)r.m.y; d.X0 = (double)r.X.x; d.X1 = (double)r.X.y; d.X2 = (double)r.X.z; };
+  d2* mine = s_rows + (size_t)wave * 14 * 64 + lane;
+  const d2* theirs = s_rows + (size_t)(wave ^ 1) * 14 * 64 + lane;
+  auto pass = [&](int k, const ObsD& r) {
+    const bool valid = k < n;
+    RigObs o;
+    o.a0 = Rca[0] * r.X0 + Rca[1] * r.X1 + Rca[2] * r.X2 + tca[0];
+    o.a1 = Rca[3] * r.X0 + Rca[4] * r.X1 + Rca[5] * r.X2 + tca[1];
+    o.a2 = Rca[6] * r.X0 + Rca[7] * r.X1 + Rca[8] * r.X2 + tca[2];
+    o.iz = recip_depth(o.a2 + tcs[2]);
+    o.x = (o.a0 + tcs[0]) * o.iz;
+    o.y = (o.a1 + tcs[1]) * o.iz;
+    RigKObs ko;
+    rigk_obs(kk, o, r.u, r.v, ko);
+    double rho, sr;
+    huber(ha, ko.ru * ko.ru + ko.rv * ko.rv, rho, sr);
+    if (valid) cost += 0.5 * rho;
+    if (!valid) sr = 0.0;
+    double wu[16], wv[16];
+    wu[0] = sr * (2.0 * (ko.Bu2 * o.a1 - ko.Bu1 * o.a2)); wu[1] = sr * (2.0 * (ko.Bu0 * o.a2 - ko.Bu2 * o.a0)); wu[2] = sr * (2.0 * (ko.Bu1 * o.a0 - ko.Bu0 * o.a1));
+    wu[3] = sr * ko.Bu0; wu[4] = sr * ko.Bu1; wu[5] = sr * ko.Bu2; wu[6] = sr * ko.ru;
+    wv[0] = sr * (2.0 * (ko.Bv2 * o.a1 - ko.Bv1 * o.a2)); wv[1] = sr * (2.0 * (ko.Bv0 * o.a2 - ko.Bv2 * o.a0)); wv[2] = sr * (2.0 * (ko.Bv1 * o.a0 - ko.Bv0 * o.a1));
+    wv[3] = sr * ko.Bv0; wv[4] = sr * ko.Bv1; wv[5] = sr * ko.Bv2; wv[6] = sr * ko.rv;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const bool off = (kmask & (1u << q)) != 0;
+      wu[7 + q] = off ? 0.0 : sr * ko.ju[q];
+      wv[7 + q] = off ? 0.0 : sr * ko.jv[q];
+    }
+    // the 14 non-zero entries of each row for the other wave: u skips columns 8 and 10, v columns 7 and 9
+    mine[0 * 64] = d2{wu[0], wu[1]}; mine[1 * 64] = d2{wu[2], wu[3]}; mine[2 * 64] = d2{wu[4], wu[5]}; mine[3 * 64] = d2{wu[6], wu[7]};
+    mine[4 * 64] = d2{wu[9], wu[11]}; mine[5 * 64] = d2{wu[12], wu[13]}; mine[6 * 64] = d2{wu[14], wu[15]};
+    mine[7 * 64] = d2{wv[0], wv[1]}; mine[8 * 64] = d2{wv[2], wv[3]}; mine[9 * 64] = d2{wv[4], wv[5]}; mine[10 * 64] = d2{wv[6], wv[8]};
+    mine[11 * 64] = d2{wv[10], wv[11]}; mine[12 * 64] = d2{wv[12], wv[13]}; mine[13 * 64] = d2{wv[14], wv[15]};
+    __syncthreads();
+    if (wave == 0) k2_accumulate<0>(wu, wv, acc); else k2_accumulate<1>(wu, wv, acc);
+    {
+      d2 t;
+      t = theirs[0 * 64]; wu[0] = t.x; wu[1] = t.y;  t = theirs[1 * 64]; wu[2] = t.x; wu[3] = t.y;
+      t = theirs[2 * 64]; wu[4] = t.x; wu[5] = t.y;  t = theirs[3 * 64]; wu[6] = t.x; wu[7] = t.y;
+      t = theirs[4 * 64]; wu[9] = t.x; wu[11] = t.y; t = theirs[5 * 64]; wu[12] = t.x; wu[13] = t.y;
+      t = theirs[6 * 64]; wu[14] = t.x; wu[15] = t.y;
+      t = theirs[7 * 64]; wv[0] = t.x; wv[1] = t.y;  t = theirs[8 * 64]; wv[2] = t.x; wv[3] = t.y;
+      t = theirs[9 * 64]; wv[4] = t.x; wv[5] = t.y;  t = theirs[10 * 64]; wv[6] = t.x; wv[8] = t.y;
+      t = theirs[11 * 64]; wv[10] = t.x; wv[11] = t.y; t = theirs[12 * 64]; wv[12] = t.x; wv[13] = t.y;
+      t = theirs[13 * 64]; wv[14] = t.x; wv[15] = t.y;
+    }
+    __syncthreads();   // (both waves have read: the rows may be overwritten by the next pass)
+    if (wave == 0) k2_accumulate<0>(wu, wv, acc); else k2_accumulate<1>(wu, wv, acc);
+  };
+  int p = 0;
+  for (; p + 1 < npass; p += 2) {
+    const int k = p * 128 + tid;
+    ObsD d;
+    widen(oa, d);
+    fetch(k + 256, oa);
+    pass(k, d);
+    widen(ob, d);
+    fetch(k + 384, ob);
+    pass(k + 128, d);
+  }
+  if (p < npass) {
+    ObsD d;
+    widen(oa, d);
+    pass(p * 128 + tid, d);
+  }
+  // ---- sums over the lanes: 64 accumulators by the butterfly (value s ends in lane s), the others and the scalars by wave_sum
+  reduce_scatter64(acc, lane);
+  {
+    const int pr = kK2Dev.inv[wave][lane];
+    if (pr != 255) s_G[pr] = acc[0];
+  }
+#pragma unroll
+  for (int x = 64; x < kK2Acc; ++x) {
+    const double t = wave_sum(acc[x]);
+    // (pair of the extra slot x of this wave: compile-time search, two candidates)
+#pragma unroll
+    for (int pr = 0; pr < 136; ++pr)
+      if (kK2.slot[pr] == x && kK2.owner[pr] >= 0) { if (lane == 0 && wave == kK2.owner[pr]) s_G[pr] = t; }
+  }
+  {
+    const double cw = wave_sum(cost), qw = wave_sum(qterm);
+    if (lane == 0) { s_G[136 + wave] = cw; s_G[138 + wave] = qw; }
+  }
+  if (tid < 4) s_G[tid == 0 ? 43 : (tid == 1 ? 62 : (tid == 2 ? 53 : 64))] = 0.0;   // the structurally zero pairs (fy, fx) (py, fx) (px, fy) (py, px)
+  __syncthreads();
+  auto G = [&](int i, int j) { const int hi = i > j ? i : j, lo = i > j ? j : i; return s_G[hi * (hi + 1) / 2 + lo]; };
+  // ---- the frame's couplings through the group's adjoint: T = G_cc M, H_fk = M^T H_ck, g_f = M^T g_c
+  if (tid < 96) {
+    double t = 0.0;
+    if (tid < 36) {
+      const int r = tid / 6, l = tid - 6 * r;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) t = fma(G(r, k), s_m[k * 6 + l], t);
+    } else if (tid < 90) {
+      const int a = (tid - 36) / 9, j = (tid - 36) - 9 * a;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) t = fma(s_m[k * 6 + a], G(k, 7 + j), t);
+    } else {
+      const int a = tid - 90;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) t = fma(s_m[k * 6 + a], G(k, 6), t);
+    }
+    s_T[tid] = t;
+  }
+  __syncthreads();
+  if (tid < 21) {   // share of the frame block: (M^T T)[i][j], i >= j
+    int i = 0;
+    while ((i + 1) * (i + 2) / 2 <= tid) ++i;
+    const int j = tid - i * (i + 1) / 2;
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) t = fma(s_m[k * 6 + i], s_T[k * 6 + j], t);
+    s_T[96 + tid] = t;
+  }
+  __syncthreads();
+  double* rec = P.gcomp + ((size_t)dst * P.NG + g) * kRigRecK;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int e = tid + 128 * h;
+    double v = 0.0;
+    if (e <= kRkR2) v = s_G[kK2Dev.dir[e]];
+    else if (e < kRkHff) v = s_T[e - kRkT];
+    else if (e < kRkGf) v = s_T[96 + (e - kRkHff)];
+    else if (e < kRkEnd) v = s_T[90 + (e - kRkGf)];
+    rec[e] = v;
+  }
+  if (phase == 0) {
+    if (tid < 6) P.ghd0[g * 8 + tid] = fixed ? 0.0 : G(tid, tid);
+    else if (tid >= 64 && tid < 73) P.ghdk[g * 16 + (tid - 64)] = G(7 + (tid - 64), 7 + (tid - 64));
+  }
+  if (tid == 0) {
+    P.gstats[g * 2] = s_G[136] + s_G[137];
+    P.gstats[g * 2 + 1] = s_G[138] + s_G[139];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // update: per frame, back-substitute the pose step and form the candidate pose. 16 lanes/frame, 16 frames per
 // 256-thread block (`fblk` = which sixteen). SC1: the shared step `ds` was written by another workgroup of the
 // SAME launch (fused into k_rig_reduce): read it with sc1 loads.
@@ -1859,10 +2180,12 @@ __global__ __launch_bounds__(256) void k_rig_init(RigDev P) {
 // persistent per-solve kernel (PS: the decision is the control workgroup's -- which buffer holds the point to eliminate,
 // the radius, whether this is the first elimination, and the Jacobi scales of the shared columns come as arguments).
 // FM: the sweep was k_rig_sweep_frame -- a group's record is [G7 (28) | T (36)] (P.gcomp), the frame block comes summed (P.fsum).
-template <bool HK, int NR, bool PS, bool FM = false>
+// KC: the sweep was k_rig_sweep_k2 (intrinsics, compact records of kRigRecK doubles in P.gcomp: offsets kRk*).
+template <bool HK, int NR, bool PS, bool FM = false, bool KC = false>
 __device__ __forceinline__ void rig_elim_body(const RigDev& P, char* smem_raw, const int ps_cur, const double ps_radius, const bool ps_first,
                                               const double* ps_ss) {
   static_assert(!(HK && FM), "the frame form is the poses-only sweep's");
+  static_assert(!KC || HK, "compact K records belong to the sweep with intrinsics");
   double* s_Z = reinterpret_cast<double*>(smem_raw);         // [24][ZS] staged Z rows of the four frames
   double* s_A = s_Z + 24 * P.ZS;                             // [4][32] frame block broadcast, per wave
   double* s_red = s_A + 4 * 32;                              // [4][1024] cross-wave reduction scratch
@@ -1919,10 +2242,10 @@ __device__ __forceinline__ void rig_elim_body(const RigDev& P, char* smem_raw, c
     int i = 0;
     while (tri(i + 1, 0) <= lane) ++i;
     const int j = lane - tri(i, 0);
-    a_off = (6 + i) * 16 + 6 + j;
+    a_off = KC ? kRkHff + lane : (6 + i) * 16 + 6 + j;
     if (i == j) sp_i = i;
   } else if (lane < 27) {
-    a_off = (6 + (lane - 21)) * 16 + 12;
+    a_off = KC ? kRkHff + lane : (6 + (lane - 21)) * 16 + 12;
   }
   // shared columns of this lane: k = lane and lane + 64
   int c_kind[2], c_co[2], c_comp[2];
@@ -1994,8 +2317,8 @@ __device__ __forceinline__ void rig_elim_body(const RigDev& P, char* smem_raw, c
   const bool first_elim = PS ? ps_first : (ctl->phase == 1 && s_ctl.iter == 0 && !pending);   // Jacobi scale of the frame blocks
   const bool jac = P.opts->jacobi_scaling != 0;
   const int SW = P.SW, S = P.S, ZS = P.ZS;
-  const size_t gs = FM ? (size_t)64 : (size_t)P.gstride;
-  const double* blocks = FM ? P.gcomp + (size_t)cur * P.NG * 64 : P.gblocks + (size_t)cur * P.NG * gs;
+  const size_t gs = FM ? (size_t)64 : (KC ? (size_t)kRigRecK : (size_t)P.gstride);
+  const double* blocks = (FM || KC) ? P.gcomp + (size_t)cur * P.NG * gs : P.gblocks + (size_t)cur * P.NG * gs;
 
   double c_ss[2];
 #pragma unroll
@@ -2055,7 +2378,9 @@ __device__ __forceinline__ void rig_elim_body(const RigDev& P, char* smem_raw, c
           const double* G = blocks + (size_t)gsel * gs;
 #pragma unroll
           for (int i = 0; i < 6; ++i)
-            w[h][i] = FM ? G[28 + c_comp[h] * 6 + i] : (c_kind[h] == 0 ? G[c_comp[h] * 16 + 6 + i] : G[256 + (6 + i) * 16 + c_comp[h]]);
+            w[h][i] = FM ? G[28 + c_comp[h] * 6 + i]
+                    : KC ? (c_kind[h] == 0 ? G[kRkT + c_comp[h] * 6 + i] : G[kRkFK + i * 9 + c_comp[h]])
+                         : (c_kind[h] == 0 ? G[c_comp[h] * 16 + 6 + i] : G[256 + (6 + i) * 16 + c_comp[h]]);
         }
       }
       if (HK && P.kmode == RIG_K_SHARED) {
@@ -2063,12 +2388,12 @@ __device__ __forceinline__ void rig_elim_body(const RigDev& P, char* smem_raw, c
         for (int j = 0; j < CO; ++j) {
           const int g = __builtin_amdgcn_readlane(gj, j);
           if (g < 0) continue;
-          const double* G = blocks + (size_t)g * gs + 256;
+          const double* G = blocks + (size_t)g * gs + (KC ? kRkFK : 256);
 #pragma unroll
           for (int h = 0; h < 2; ++h)
             if (c_kind[h] == 2) {
 #pragma unroll
-              for (int i = 0; i < 6; ++i) w[h][i] += G[(6 + i) * 16 + c_comp[h]];
+              for (int i = 0; i < 6; ++i) w[h][i] += KC ? G[i * 9 + c_comp[h]] : G[(6 + i) * 16 + c_comp[h]];
             }
         }
       }
@@ -2232,11 +2557,11 @@ __device__ __forceinline__ void rig_elim_body(const RigDev& P, char* smem_raw, c
   ELIM_MARK(9);
 }
 
-template <bool HK, int NR, bool FM = false>
+template <bool HK, int NR, bool FM = false, bool KC = false>
 __global__ __launch_bounds__(256) void k_rig_elim(RigDev P) {
   rig_progress(P, RIG_PROG_ELIM);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  rig_elim_body<HK, NR, false, FM>(P, smem_raw, 0, 1.0, false, nullptr);
+  rig_elim_body<HK, NR, false, FM, KC>(P, smem_raw, 0, 1.0, false, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -4939,6 +5264,9 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
   // the frame form of the sweep feeds the tuned elimination only (the plain large-rig kernels read the 16 x 16 tiles)
   d.fmode = (!kmode && h->sweep_adjoint && h->frame_allowed && S <= kRigMaxS && CO * DE <= 64 * kRigDirectPerLane &&
              !(getenv("CC_RIG_FORCE_BIG") && atoi(getenv("CC_RIG_FORCE_BIG")) != 0)) ? 1 : 0;
+  // with intrinsics: compact records + the FMA sweep (k_rig_sweep_k2) feed the tuned elimination; the plain large-rig kernels
+  // read the three tiles of k_rig_sweep_adjk. CC_RIG_K_COMPACT=0 keeps the tile form for A/B and the record-against-tile test.
+  d.kcm = (kmode && h->sweep_adjoint && !h->big && !(getenv("CC_RIG_K_COMPACT") && atoi(getenv("CC_RIG_K_COMPACT")) == 0)) ? 1 : 0;
   d.C = (int32_t)C; d.CO = CO; d.CK = CK; d.S = S; d.SW = S + 1;
   d.T = (d.SW + 15) / 16; d.nT = d.T * (d.T + 1) / 2; d.ZS = 16 * d.T + ((d.T & 1) ? 0 : 16);
   d.DE = DE; d.ND = CO * DE;
@@ -5021,7 +5349,7 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
     // + j, g_c,i at 21 + i -- IS e)
     const bool fm = !kmode && h->sweep_adjoint && h->frame_allowed && !(S > kRigMaxS || CO * DE > 64 * kRigDirectPerLane || (getenv("CC_RIG_FORCE_BIG") && atoi(getenv("CC_RIG_FORCE_BIG")) != 0));
     std::vector<int32_t> dent((size_t)CO * DE);
-    for (int c = 0; c < CO; ++c) for (int e = 0; e < DE; ++e) dent[(size_t)c * DE + e] = (c << 16) | (fm ? e : (int)(uint16_t)dmap[(size_t)e]);
+    for (int c = 0; c < CO; ++c) for (int e = 0; e < DE; ++e) dent[(size_t)c * DE + e] = (c << 16) | ((fm || d.kcm) ? e : (int)(uint16_t)dmap[(size_t)e]);   // (k_rig_sweep_k2's record starts with the direct entries in this order)
     if (int rc = dev_upload(h, &d.dent, dent)) return rc;
   }
   if (int rc = dev_upload(h, &d.tile_i, ti)) return rc;
@@ -5062,6 +5390,8 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<false, kRigDirectPerLane>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<true, kRigDirectPerLane>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
+  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<true, 8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
+  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<true, kRigDirectPerLane, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_reduce<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_reduce<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
   CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_solve<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
@@ -5212,7 +5542,8 @@ static int rig_enqueue_round(cc_rig* h, bool initial, bool profile, bool publish
   const RigDev& d = h->d;
   struct RoundCount { cc_rig* h; ~RoundCount() { h->enq_round++; } } count_round{h};
   { RigProbe p(h, CC_K_SWEEP, profile);
-    if (d.kmode && h->sweep_adjoint && h->sweep_waves == 1) hipLaunchKernelGGL(k_rig_sweep_adjk<1>, dim3((unsigned)h->NG), dim3(64), 0, h->stream, d);
+    if (d.kcm) hipLaunchKernelGGL(k_rig_sweep_k2, dim3((unsigned)h->NG), dim3(128), 0, h->stream, d);
+    else if (d.kmode && h->sweep_adjoint && h->sweep_waves == 1) hipLaunchKernelGGL(k_rig_sweep_adjk<1>, dim3((unsigned)h->NG), dim3(64), 0, h->stream, d);
     else if (d.kmode && h->sweep_adjoint) hipLaunchKernelGGL(k_rig_sweep_adjk<4>, dim3((unsigned)h->NG), dim3(256), 0, h->stream, d);
     else if (d.kmode) hipLaunchKernelGGL((k_rig_sweep<true, 4>), dim3((unsigned)h->NG), dim3(kRigThreads), kRigSweepLdsBytesK, h->stream, d);
     else if (d.fmode) {
@@ -5257,7 +5588,9 @@ static int rig_enqueue_round(cc_rig* h, bool initial, bool profile, bool publish
   }
   { RigProbe p(h, CC_K_ELIM, profile);
     const bool small = d.ND <= 8 * 64;
-    if (d.kmode && small) hipLaunchKernelGGL((k_rig_elim<true, 8>), dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d);
+    if (d.kcm && small) hipLaunchKernelGGL((k_rig_elim<true, 8, false, true>), dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d);
+    else if (d.kcm) hipLaunchKernelGGL((k_rig_elim<true, kRigDirectPerLane, false, true>), dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d);
+    else if (d.kmode && small) hipLaunchKernelGGL((k_rig_elim<true, 8>), dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d);
     else if (d.kmode) hipLaunchKernelGGL((k_rig_elim<true, kRigDirectPerLane>), dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d);
     else if (d.fmode && small) hipLaunchKernelGGL((k_rig_elim<false, 8, true>), dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d);
     else if (d.fmode) hipLaunchKernelGGL((k_rig_elim<false, kRigDirectPerLane, true>), dim3(d.nblk), dim3(256), h->elim_lds, h->stream, d);

@@ -172,3 +172,62 @@ def test_rigk_sweep_workgroup_sizes_give_the_same_solve(monkeypatch, waves, per_
         else:
             g, o = _both_k(k, const_mask=1 << 5, huber_a=1.5)
             _assert_same_k(g, o)
+
+
+@pytest.mark.parametrize("per_camera", [False, True])
+@pytest.mark.parametrize("cams,frames,pts,mask,huber_a", [(3, 24, 90, 1 << 7, 2.0), (2, 12, 300, 0, 0.0), (4, 10, 131, 1 << 8, 1.5), (2, 30, 5, 0, 2.0)])
+def test_compact_k_records_equal_the_tiles(monkeypatch, per_camera, cams, frames, pts, mask, huber_a):
+    """Round 5: the sweep with intrinsics (k_rig_sweep_k2: plain FMAs on the lower triangle of the 16-column Gram, two waves
+    per group that split the pairs) writes ONE record of 256 doubles per group -- direct sums, coupling columns T = G_cc M and
+    H_fk = M^T H_ck, the group's share of the frame block and gradient -- where k_rig_sweep_adjk (matrix pipe,
+    CC_RIG_K_COMPACT=0) writes three 16 x 16 tiles. Every record entry is an entry of those tiles: compared one by one,
+    ragged groups (pts not a multiple of 128, fewer observations than a wave) and a constant intrinsic included."""
+    k = rigk_case(cams, frames, pts, per_camera=per_camera)
+    ng = _group_count(k, cams)
+    out = []
+    for compact in (0, 1):
+        monkeypatch.setenv("CC_RIG_K_COMPACT", str(compact))
+        prob = capi.RigProblem(cams, k["frame_offsets"], k["obs_cam"], k["obs_world"], k["obs_uv_pix"], k["world_xyz"], k["cam_frozen"],
+                               huber_a=huber_a, with_intrinsics="per_camera" if per_camera else True)
+        if per_camera:
+            for c in range(cams):
+                prob.set_camera_intrinsics(c, k["intr0"][c], mask)
+        else:
+            prob.set_intrinsics(k["intr0"], mask)
+        prob.set_state(k["cam_q0"], k["cam_t0"], k["frame_q0"], k["frame_t0"])
+        cost = prob.solve(capi.default_options(max_iterations=1))["initial_cost"]
+        data = _fetch(prob, "gcomp", ng * 256).reshape(ng, 256) if compact else _fetch(prob, "gblocks", ng * 768).reshape(ng, 3, 16, 16)
+        prob.close()
+        out.append((cost, data))
+    (c0, tiles), (c1, rec) = out
+    assert np.isclose(c0, c1, rtol=1e-13)
+    off, cam = np.asarray(k["frame_offsets"]), np.asarray(k["obs_cam"])
+    gcam = np.concatenate([np.unique(cam[off[f]:off[f + 1]]) for f in range(frames)])
+    tri6 = [(i, j) for i in range(6) for j in range(i + 1)]
+    tri9 = [(i, j) for i in range(9) for j in range(i + 1)]
+    worst = 0.0
+    for g in range(ng):
+        AA, AB, BB = tiles[g]
+        scale = max(np.abs(AA).max(), np.abs(AB).max(), np.abs(BB).max())
+        want = {}
+        if not k["cam_frozen"][gcam[g]]:   # (a camera held constant: the tiles zero its rows, the record keeps the sums -- nobody reads them)
+            want[(0, 21)] = [AA[i, j] for i, j in tri6]
+            want[(21, 27)] = AA[0:6, 12]
+            want[(27, 81)] = AB[0:6, 0:9].ravel()
+            want[(136, 172)] = AA[0:6, 6:12].ravel()
+        want[(81, 126)] = [BB[i, j] for i, j in tri9]
+        want[(126, 135)] = AB[12, 0:9]
+        want[(135, 136)] = [AA[12, 12]]
+        want[(172, 226)] = AB[6:12, 0:9].ravel()
+        want[(226, 247)] = [AA[6 + i, 6 + j] for i, j in tri6]
+        want[(247, 253)] = AA[6:12, 12]
+        for (a, b), w in want.items():
+            # per kind of entry against the largest entry of that kind in the group (the tiles mix pixel^2 and O(1) numbers)
+            sc = max(np.abs(np.asarray(w)).max(), 1e-300)
+            worst = max(worst, np.abs(rec[g, a:b] - np.asarray(w)).max() / sc)
+        assert np.array_equal(rec[g, 253:], np.zeros(3))
+        assert scale > 0
+    assert worst < 1e-11, worst
+    if mask:
+        q = int(np.log2(mask))   # the intrinsic held constant has no column
+        assert np.abs(rec[:, 27:81].reshape(ng, 6, 9)[:, :, q]).max() == 0 and np.abs(rec[:, 172:226].reshape(ng, 6, 9)[:, :, q]).max() == 0
