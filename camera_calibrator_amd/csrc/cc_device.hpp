@@ -114,6 +114,13 @@ __device__ __forceinline__ bool chol_solve_rows(double (&a)[S], double b, double
   return ok;
 }
 
+// Workgroup barrier for data handed over through LDS ONLY: waits for this wave's LDS operations, not for its global loads.
+// __syncthreads() is a workgroup fence + s_barrier, and the fence drains EVERY outstanding memory operation (s_waitcnt vmcnt(0)):
+// a prefetch of the next pass's observations issued above it is then waited for at the barrier, its whole latency exposed in
+// every pass (k_rig_sweep_k2: 201 -> ... us at 8 x 2000 x 500). The "memory" clobber keeps the compiler from moving LDS accesses
+// across it; registers a pending global load writes are still tracked (the wait comes at their first use).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // LDS accesses of one wave execute in order; the fence only stops the compiler from moving
 // the staged-row reads above the writes of other lanes (no instruction is emitted).
 __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }

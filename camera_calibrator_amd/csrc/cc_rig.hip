@@ -1462,6 +1462,7 @@ struct K2Split {
   unsigned char slot[136];  // its accumulator: 0..63 summed by the butterfly (the sum ends in lane `slot`), 64.. by wave_sum
   unsigned char inv[2][64]; // pair of butterfly slot s of wave w (255: none)
   unsigned char dir[136];   // direct entry e (dmap order, [135] = r^2) -> pair
+  unsigned char extra[2][4];   // pair of accumulator 64 + x of wave w (255: none)
   int n[2];
 };
 constexpr K2Split k2_make_split() {
@@ -1469,6 +1470,7 @@ constexpr K2Split k2_make_split() {
   int cost[2] = {0, 0};
   s.n[0] = s.n[1] = 0;
   for (int w = 0; w < 2; ++w) for (int k = 0; k < 64; ++k) s.inv[w][k] = 255;
+  for (int w = 0; w < 2; ++w) for (int k = 0; k < 4; ++k) s.extra[w][k] = 255;
   for (int i = 0; i < 16; ++i)
     for (int j = 0; j <= i; ++j) {
       const int p = i * (i + 1) / 2 + j;
@@ -1477,7 +1479,7 @@ constexpr K2Split k2_make_split() {
       const int w = cost[0] <= cost[1] ? 0 : 1;
       s.owner[p] = (signed char)w;
       s.slot[p] = (unsigned char)s.n[w];
-      if (s.n[w] < 64) s.inv[w][s.n[w]] = (unsigned char)p;
+      if (s.n[w] < 64) s.inv[w][s.n[w]] = (unsigned char)p; else s.extra[w][s.n[w] - 64] = (unsigned char)p;
       s.n[w]++;
       cost[w] += c;
     }
@@ -1496,8 +1498,9 @@ static_assert(kK2.n[0] <= 68 && kK2.n[1] <= 68 && kK2.n[0] + kK2.n[1] == 132, "p
 __device__ const K2Split kK2Dev = k2_make_split();   // (the same tables where a lane indexes them at run time)
 constexpr int kK2Acc = 68;
 
-template <int W>
-__device__ __forceinline__ void k2_accumulate(const double* wu, const double* wv, double* acc) {
+// the products of ONE row (ROW 0: u, 1: v) that wave W accumulates
+template <int W, int ROW>
+__device__ __forceinline__ void k2_accumulate(const double* w, double* acc) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
 #pragma unroll
@@ -1505,8 +1508,7 @@ __device__ __forceinline__ void k2_accumulate(const double* wu, const double* wv
       const int p = i * (i + 1) / 2 + j;
       if (kK2.owner[p] == W) {
         const int s = kK2.slot[p];
-        if (k2_in_u(i) && k2_in_u(j)) acc[s] = fma(wu[i], wu[j], acc[s]);
-        if (k2_in_v(i) && k2_in_v(j)) acc[s] = fma(wv[i], wv[j], acc[s]);
+        if (ROW == 0 ? (k2_in_u(i) && k2_in_u(j)) : (k2_in_v(i) && k2_in_v(j))) acc[s] = fma(w[i], w[j], acc[s]);
       }
     }
   }
@@ -1521,26 +1523,46 @@ __device__ __forceinline__ void reduce_scatter64(double* p, int lane) {
   reduce_dpp<2, 0x4E, 2>(p, lane);    // quad_perm:[2,3,0,1]
   reduce_dpp<1, 0xB1, 1>(p, lane);    // quad_perm:[1,0,3,2]
 }
-// weight of entry e of a group's OLD record in the model-cost term q = g^T d + 1/2 d^T H d of the step d = (dc, df, dk)
-__device__ __forceinline__ double k2_qcoef(int e, const double* dc, const double* df, const double* dk) {
+// weight of entry e of a group's OLD record in the model-cost term q = g^T d + 1/2 d^T H d of the step d = (dc, df, dk);
+// the steps are read where the records lie in LDS (sm: camera [12..17], frame [44..49], intrinsics [80..88]) -- indexed by a
+// lane-dependent entry, register arrays become chains of selects (300 instructions per group)
+__device__ __forceinline__ double k2_qcoef(int e, const double* sm, double cam_on) {
   auto tri_ij = [](int idx, int& i, int& j) { i = 0; while ((i + 1) * (i + 2) / 2 <= idx) ++i; j = idx - i * (i + 1) / 2; };
+  // entry -> (kind of first factor, index, kind of second factor, index, weight); kinds: 0 one, 1 dc, 2 df, 3 dk
+  int ka = 0, ia = 0, kb = 0, ib = 0;
+  double wgt = 1.0;
   int i, j;
-  if (e < 21) { tri_ij(e, i, j); return (i == j ? 0.5 : 1.0) * dc[i] * dc[j]; }
-  if (e < 27) return dc[e - 21];
-  if (e < 81) { i = (e - 27) / 9; j = (e - 27) - 9 * i; return dc[i] * dk[j]; }
-  if (e < 126) { tri_ij(e - 81, i, j); return (i == j ? 0.5 : 1.0) * dk[i] * dk[j]; }
-  if (e < 135) return dk[e - 126];
-  if (e < kRkT) return 0.0;
-  if (e < kRkFK) { i = (e - kRkT) / 6; j = (e - kRkT) - 6 * i; return dc[i] * df[j]; }
-  if (e < kRkHff) { i = (e - kRkFK) / 9; j = (e - kRkFK) - 9 * i; return df[i] * dk[j]; }
-  if (e < kRkGf) { tri_ij(e - kRkHff, i, j); return (i == j ? 0.5 : 1.0) * df[i] * df[j]; }
-  if (e < kRkEnd) return df[e - kRkGf];
-  return 0.0;
+  if (e < 21) { tri_ij(e, i, j); ka = 1; ia = i; kb = 1; ib = j; wgt = i == j ? 0.5 : 1.0; }
+  else if (e < 27) { ka = 1; ia = e - 21; }
+  else if (e < 81) { i = (e - 27) / 9; j = (e - 27) - 9 * i; ka = 1; ia = i; kb = 3; ib = j; }
+  else if (e < 126) { tri_ij(e - 81, i, j); ka = 3; ia = i; kb = 3; ib = j; wgt = i == j ? 0.5 : 1.0; }
+  else if (e < 135) { ka = 3; ia = e - 126; }
+  else if (e < kRkT) { wgt = 0.0; }
+  else if (e < kRkFK) { i = (e - kRkT) / 6; j = (e - kRkT) - 6 * i; ka = 1; ia = i; kb = 2; ib = j; }
+  else if (e < kRkHff) { i = (e - kRkFK) / 9; j = (e - kRkFK) - 9 * i; ka = 2; ia = i; kb = 3; ib = j; }
+  else if (e < kRkGf) { tri_ij(e - kRkHff, i, j); ka = 2; ia = i; kb = 2; ib = j; wgt = i == j ? 0.5 : 1.0; }
+  else if (e < kRkEnd) { ka = 2; ia = e - kRkGf; }
+  else wgt = 0.0;
+  auto factor = [&](int k, int idx) {
+    const double v = sm[(k == 1 ? 12 : (k == 2 ? 44 : 80)) + idx];   // (k == 0: reads sm[80 + 0], discarded)
+    return k == 0 ? 1.0 : (k == 1 ? v * cam_on : v);
+  };
+  return wgt * factor(ka, ia) * factor(kb, ib);
 }
 
 #ifndef CC_RIG_K2_WAVES
 #define CC_RIG_K2_WAVES 2   // waves per SIMD the kernel is compiled for (256 registers)
 #endif
+// A workgroup (two waves) sweeps groups blockIdx.x, blockIdx.x + gridDim.x, ... one after the other (the grid is four workgroups
+// per compute unit: what fits next to the 248 registers). What a group needs before its first pass -- its indices, then its
+// records, old record and first observations: two dependent round trips of ~2 us each under load, a third of a workgroup's life
+// at 500 observations per group when every group was a workgroup of its own (profiles/r05/k2_stage_marks.jsonl) -- is requested
+// during the PREVIOUS group: the indices at its start, the rest right behind its main loop, under its lane sums and assembly.
+struct K2Group {   // what is known about a group before its sweep starts
+  int f, c, ks, n, fixed;
+  int64_t s0;
+  uint32_t kmask;
+};
 __global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P) {
   __shared__ __attribute__((aligned(16))) d2 s_rows[2 * 14 * 64];   // [wave][q][lane]: u row entries (q < 7), v row entries
   __shared__ double sm[96];        // camera record, frame record, intrinsics record (candidate [0..8], step [16..24])
@@ -1548,213 +1570,310 @@ __global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P)
   __shared__ double s_m[36];       // M
   __shared__ double s_T[128];      // T (36) | H_fk (54) | g_f share (6) | H_ff share (21)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t g = blockIdx.x;
-  const int f = P.gframe[g], c = P.gcam[g];
-  const int64_t s0 = P.goff[g], s1 = P.goff[g + 1];
   const LmCtl* ctl = P.ctl;
   const int done = ctl->done, phase = ctl->phase, step_valid = ctl->step_valid, cur = ctl->cur;
   if (done) return;
   if (phase != 0 && !step_valid) return;
   const int dst = phase == 0 ? cur : (cur ^ 1);
-  const bool fixed = P.cam_fixed[c] != 0;
-  const int ks = P.kset[c];
-  const int n = (int)(s1 - s0);
-  const int npass = (n + 127) >> 7;      // (the same for both waves: they meet at two barriers per pass)
-  const float2* uvg = reinterpret_cast<const float2*>(P.uv) + s0;
+  const int64_t NG = P.NG, stride = gridDim.x;
+#ifdef CC_RIG_K2_TIMING   // (timing-only build: shader-clock cycles per phase, summed over the groups and passes of wave 0 of the middle workgroup -> shared_stats[40..])
+  long long k2t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long k2last = clock64();
+  const long long k2wall0 = wall_clock64();
+  int k2groups = 0;
+#define K2_T(i) do { const long long now_ = clock64(); k2t[i] += now_ - k2last; k2last = now_; } while (0)
+#else
+#define K2_T(i) do { } while (0)
+#endif
   struct F3 { float x, y, z; };
-  const F3* xg = reinterpret_cast<const F3*>(P.oxyz) + s0;
   struct ObsRaw { float2 m; F3 X; };
-  auto fetch = [&](int k, ObsRaw& r) {
-    const int kc = k < n ? k : 0;
-    r.m = uvg[kc];
-    r.X = xg[kc];
+  struct ObsD { double u, v, X0, X1, X2; };
+  auto widen = [](const ObsRaw& r, ObsD& d) { d.u = (double)r.m.x; d.v = (double)r.m.y; d.X0 = (double)r.X.x; d.X1 = (double)r.X.y; d.X2 = (double)r.X.z; };
+  auto group_indices = [&](int64_t g, K2Group& q) {   // scalar loads: first round trip (group), second (its camera's flags)
+    const int64_t gc = g < NG ? g : 0;
+    q.f = P.gframe[gc]; q.c = P.gcam[gc];
+    q.s0 = P.goff[gc];
+    q.n = (int)(P.goff[gc + 1] - q.s0);
+    q.fixed = P.cam_fixed[q.c];
+    q.ks = P.kset[q.c];
+    q.kmask = P.kmask[q.ks];
   };
-  ObsRaw oa, ob;
-  fetch(tid, oa);
-  fetch(tid + 128, ob);
-  const double* rec_old = P.gcomp + ((size_t)cur * P.NG + g) * kRigRecK;
-  const double old0 = rec_old[tid], old1 = rec_old[tid + 128];
-  {
-    const double r0 = tid < 32 ? P.camrec[c * 32 + tid] : (tid < 64 ? P.frec[(size_t)f * 32 + (tid - 32)] : P.krec[ks * 32 + ((tid - 64) & 31)]);
-    if (tid < 96) sm[tid] = r0;
-  }
-  __syncthreads();
-  double Rca[9], tca[3], tcs[3], kk[9];
-  {
-    const double* cr = P.camrec + (size_t)c * 32;
-    const double* fr = P.frec + (size_t)f * 32;
-    const double* kr = P.krec + (size_t)ks * 32;
+  // vector loads of a group: the lane's first observation, one value of the three records, two of the group's old record
+  auto group_loads = [&](int64_t g, const K2Group& q, ObsRaw& o0, double& recv, double& old0, double& old1) {
+    const float2* uvg = reinterpret_cast<const float2*>(P.uv) + q.s0;
+    const F3* xg = reinterpret_cast<const F3*>(P.oxyz) + q.s0;
+    const int kc = tid < q.n ? tid : 0;
+    o0.m = uvg[kc];
+    o0.X = xg[kc];
+    recv = tid < 32 ? P.camrec[q.c * 32 + tid] : (tid < 64 ? P.frec[(size_t)q.f * 32 + (tid - 32)] : P.krec[q.ks * 32 + ((tid - 64) & 31)]);
+    const double* rec_old = P.gcomp + ((size_t)cur * NG + (g < NG ? g : 0)) * kRigRecK;
+    old0 = rec_old[tid];
+    old1 = rec_old[tid + 128];
+  };
+  const double ha = P.huber_a;
+  // ONE branch on the wave for the whole loop over groups (each arm its own register allocation: with a branch per row the arms
+  // met four times a pass, ~90 register moves each to reconcile them)
+  auto sweep = [&](auto wtag) {
+  constexpr int W = decltype(wtag)::value;
+  int64_t g = blockIdx.x;
+  K2Group q;
+  group_indices(g, q);
+  ObsRaw oa;
+  double recv, old0, old1;
+  group_loads(g, q, oa, recv, old0, old1);
+  d2* mine = s_rows + (size_t)W * 14 * 64 + lane;
+  const d2* theirs = s_rows + (size_t)(W ^ 1) * 14 * 64 + lane;
+  while (g < NG) {
+    // ---- the group's records into LDS; indices of the NEXT group requested
+    // (every per-lane index of the group's head and tail comes from a LAUNDERED copy of the thread id: derived from the original
+    // they are hoisted out of the loop over groups and kept alive -- spilled -- across its passes)
+    int tid_h = threadIdx.x;
+    asm volatile("" : "+v"(tid_h));
+    if (tid_h < 96) sm[tid_h] = recv;
+    K2Group qn = q;
+    const bool more = g + stride < NG;   // (uniform)
+    if (more) group_indices(g + stride, qn);
+    __syncthreads();
+    const int n = q.n, npass = (n + 127) >> 7;      // (the same for both waves: they meet at two barriers per pass)
+    const bool fixed = q.fixed != 0;
+    const uint32_t kmask = q.kmask;
+    const float2* uvg = reinterpret_cast<const float2*>(P.uv) + q.s0;
+    const F3* xg = reinterpret_cast<const F3*>(P.oxyz) + q.s0;
+    auto fetch = [&](int k, ObsRaw& r) {
+      const int kc = k < n ? k : 0;
+      r.m = uvg[kc];
+      r.X = xg[kc];
+    };
+    // the chain of both poses as one (k_rig_sweep_adj), from the records in LDS (uniform addresses), values in scalar registers
+    double Rca[9], tca[3], tcs[3], kk[9];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) Rca[3 * i + j] = rfl(cr[3 * i] * fr[j] + cr[3 * i + 1] * fr[3 + j] + cr[3 * i + 2] * fr[6 + j]);
-      tca[i] = rfl(cr[3 * i] * fr[9] + cr[3 * i + 1] * fr[10] + cr[3 * i + 2] * fr[11]);
-      tcs[i] = cr[9 + i];
+      for (int j = 0; j < 3; ++j) Rca[3 * i + j] = rfl(sm[3 * i] * sm[32 + j] + sm[3 * i + 1] * sm[32 + 3 + j] + sm[3 * i + 2] * sm[32 + 6 + j]);
+      tca[i] = rfl(sm[3 * i] * sm[32 + 9] + sm[3 * i + 1] * sm[32 + 10] + sm[3 * i + 2] * sm[32 + 11]);
+      tcs[i] = rfl(sm[9 + i]);
     }
 #pragma unroll
-    for (int i = 0; i < 9; ++i) kk[i] = kr[i];
-  }
-  if (tid < 48) {   // M[a][b], a = tid >> 3, b = tid & 7 < 6 (see k_rig_sweep_adj)
-    const int a = tid >> 3, b = tid & 7;
-    const int a3 = a < 3 ? a : a - 3, b3 = b < 3 ? b : b - 3;
-    const int b1 = b3 == 2 ? 0 : b3 + 1, b2 = b3 == 0 ? 2 : b3 - 1;
-    const double diag = sm[3 * a3 + (b3 < 3 ? b3 : 0)];
-    const double cross = 2.0 * (sm[3 * a3 + b1] * sm[32 + 9 + b2] - sm[3 * a3 + b2] * sm[32 + 9 + b1]);
-    const double v = (a < 3) == (b < 3) ? diag : (a >= 3 ? cross : 0.0);
-    if (b < 6) s_m[a * 6 + b] = v;
-  }
-  // model-cost term of the step at the accepted point, from the group's old record (two entries per thread)
-  double qterm = 0.0;
-  if (phase != 0) {
-    double dc[6], df[6], dk[9];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { dc[i] = fixed ? 0.0 : sm[12 + i]; df[i] = sm[32 + 12 + i]; }
-#pragma unroll
-    for (int i = 0; i < 9; ++i) dk[i] = sm[64 + 16 + i];
-    qterm = k2_qcoef(tid, dc, df, dk) * old0 + k2_qcoef(tid + 128, dc, df, dk) * old1;
-  }
-  const double ha = P.huber_a;
-  const uint32_t kmask = P.kmask[ks];
-  double acc[kK2Acc];
-#pragma unroll
-  for (int e = 0; e < kK2Acc; ++e) acc[e] = 0.0;
-  double cost = 0.0;
-  struct ObsD { double u, v, X0, X1, X2; };
-  auto widen = [](const ObsRaw& r, ObsD& d) { d.u = (double)r.m.x; d.v = (double)r.m.y; d.X0 = (double)r.X.x; d.X1 = (double)r.X.y; d.X2 = (double)r.X.z; };
-  d2* mine = s_rows + (size_t)wave * 14 * 64 + lane;
-  const d2* theirs = s_rows + (size_t)(wave ^ 1) * 14 * 64 + lane;
-  auto pass = [&](int k, const ObsD& r) {
-    const bool valid = k < n;
-    RigObs o;
-    o.a0 = Rca[0] * r.X0 + Rca[1] * r.X1 + Rca[2] * r.X2 + tca[0];
-    o.a1 = Rca[3] * r.X0 + Rca[4] * r.X1 + Rca[5] * r.X2 + tca[1];
-    o.a2 = Rca[6] * r.X0 + Rca[7] * r.X1 + Rca[8] * r.X2 + tca[2];
-    o.iz = recip_depth(o.a2 + tcs[2]);
-    o.x = (o.a0 + tcs[0]) * o.iz;
-    o.y = (o.a1 + tcs[1]) * o.iz;
-    RigKObs ko;
-    rigk_obs(kk, o, r.u, r.v, ko);
-    double rho, sr;
-    huber(ha, ko.ru * ko.ru + ko.rv * ko.rv, rho, sr);
-    if (valid) cost += 0.5 * rho;
-    if (!valid) sr = 0.0;
-    double wu[16], wv[16];
-    wu[0] = sr * (2.0 * (ko.Bu2 * o.a1 - ko.Bu1 * o.a2)); wu[1] = sr * (2.0 * (ko.Bu0 * o.a2 - ko.Bu2 * o.a0)); wu[2] = sr * (2.0 * (ko.Bu1 * o.a0 - ko.Bu0 * o.a1));
-    wu[3] = sr * ko.Bu0; wu[4] = sr * ko.Bu1; wu[5] = sr * ko.Bu2; wu[6] = sr * ko.ru;
-    wv[0] = sr * (2.0 * (ko.Bv2 * o.a1 - ko.Bv1 * o.a2)); wv[1] = sr * (2.0 * (ko.Bv0 * o.a2 - ko.Bv2 * o.a0)); wv[2] = sr * (2.0 * (ko.Bv1 * o.a0 - ko.Bv0 * o.a1));
-    wv[3] = sr * ko.Bv0; wv[4] = sr * ko.Bv1; wv[5] = sr * ko.Bv2; wv[6] = sr * ko.rv;
-#pragma unroll
-    for (int q = 0; q < 9; ++q) {
-      const bool off = (kmask & (1u << q)) != 0;
-      wu[7 + q] = off ? 0.0 : sr * ko.ju[q];
-      wv[7 + q] = off ? 0.0 : sr * ko.jv[q];
+    for (int i = 0; i < 9; ++i) kk[i] = rfl(sm[64 + i]);
+    if (tid_h < 48) {   // M[a][b], a = tid >> 3, b = tid & 7 < 6 (see k_rig_sweep_adj)
+      const int a = tid_h >> 3, b = tid_h & 7;
+      const int a3 = a < 3 ? a : a - 3, b3 = b < 3 ? b : b - 3;
+      const int b1 = b3 == 2 ? 0 : b3 + 1, b2 = b3 == 0 ? 2 : b3 - 1;
+      const double diag = sm[3 * a3 + (b3 < 3 ? b3 : 0)];
+      const double cross = 2.0 * (sm[3 * a3 + b1] * sm[32 + 9 + b2] - sm[3 * a3 + b2] * sm[32 + 9 + b1]);
+      const double v = (a < 3) == (b < 3) ? diag : (a >= 3 ? cross : 0.0);
+      if (b < 6) s_m[a * 6 + b] = v;
     }
-    // the 14 non-zero entries of each row for the other wave: u skips columns 8 and 10, v columns 7 and 9
-    mine[0 * 64] = d2{wu[0], wu[1]}; mine[1 * 64] = d2{wu[2], wu[3]}; mine[2 * 64] = d2{wu[4], wu[5]}; mine[3 * 64] = d2{wu[6], wu[7]};
-    mine[4 * 64] = d2{wu[9], wu[11]}; mine[5 * 64] = d2{wu[12], wu[13]}; mine[6 * 64] = d2{wu[14], wu[15]};
-    mine[7 * 64] = d2{wv[0], wv[1]}; mine[8 * 64] = d2{wv[2], wv[3]}; mine[9 * 64] = d2{wv[4], wv[5]}; mine[10 * 64] = d2{wv[6], wv[8]};
-    mine[11 * 64] = d2{wv[10], wv[11]}; mine[12 * 64] = d2{wv[12], wv[13]}; mine[13 * 64] = d2{wv[14], wv[15]};
-    __syncthreads();
-    if (wave == 0) k2_accumulate<0>(wu, wv, acc); else k2_accumulate<1>(wu, wv, acc);
+    // model-cost term of the step at the accepted point, from the group's old record (two entries per thread)
+    double qterm = 0.0;
+    if (phase != 0) qterm = k2_qcoef(tid_h, sm, fixed ? 0.0 : 1.0) * old0 + k2_qcoef(tid_h + 128, sm, fixed ? 0.0 : 1.0) * old1;
+    K2_T(0);
+    double acc[kK2Acc];
+#pragma unroll
+    for (int e = 0; e < kK2Acc; ++e) acc[e] = 0.0;
+    double cost = 0.0;
+    auto pass = [&](int k, const ObsD& r) {
+      const bool valid = k < n;
+#ifdef CC_RIG_K2_TIMING
+      { double t_ = r.u + r.X0; asm volatile("" : "+v"(t_)); K2_T(5); }   // (the wait for this pass's observations, on its own)
+#endif
+      RigObs o;
+      o.a0 = Rca[0] * r.X0 + Rca[1] * r.X1 + Rca[2] * r.X2 + tca[0];
+      o.a1 = Rca[3] * r.X0 + Rca[4] * r.X1 + Rca[5] * r.X2 + tca[1];
+      o.a2 = Rca[6] * r.X0 + Rca[7] * r.X1 + Rca[8] * r.X2 + tca[2];
+      o.iz = recip_depth(o.a2 + tcs[2]);
+      o.x = (o.a0 + tcs[0]) * o.iz;
+      o.y = (o.a1 + tcs[1]) * o.iz;
+      // pixel model (rigk_obs, DistortNormalized / DistortPixels of calibrator.cpp:70-95) with the Huber weight folded into
+      // the factors every row entry carries anyway (sr fx, sr fy, sr fx / z, sr fy / z): an entry costs one instruction
+      const double x = o.x, y = o.y;
+      const double x2 = x * x, y2 = y * y, xy = x * y;
+      const double r2 = x2 + y2, r4 = r2 * r2, r6 = r4 * r2;
+      const double m = 1.0 + kk[4] * r2 + kk[5] * r4 + kk[8] * r6;
+      const double ax = r2 + 2.0 * x2, ay = r2 + 2.0 * y2;
+      const double xd = x * m + 2.0 * kk[6] * xy + kk[7] * ax;
+      const double yd = y * m + 2.0 * kk[7] * xy + kk[6] * ay;
+      const double ru = kk[0] * xd + kk[2] - r.u, rv = kk[1] * yd + kk[3] - r.v;
+      const double mp = kk[4] + 2.0 * kk[5] * r2 + 3.0 * kk[8] * r4;
+      const double dxx = m + 2.0 * mp * x2 + 2.0 * kk[6] * y + 6.0 * kk[7] * x;
+      const double dxy = 2.0 * mp * xy + 2.0 * kk[6] * x + 2.0 * kk[7] * y;
+      const double dyy = m + 2.0 * mp * y2 + 2.0 * kk[7] * x + 6.0 * kk[6] * y;
+      double rho, sr;
+      huber(ha, ru * ru + rv * rv, rho, sr);
+      if (valid) cost += 0.5 * rho;
+      if (!valid) sr = 0.0;
+      const double sfx = sr * kk[0], sfy = sr * kk[1];
+      const double a0d = o.a0 + o.a0, a1d = o.a1 + o.a1, a2d = o.a2 + o.a2;   // (2 a: the rotation columns are 2 a x B)
+      // Row by row, each used up at once: formed, left in LDS for the other wave (its 14 non-zero entries: u skips columns 8 and
+      // 10, v columns 7 and 9), accumulated -- so that only one row of 14 is alive next to the accumulators at any time.
+      {
+        double w[16];
+        const double gz = sfx * o.iz;
+        const double B0 = gz * dxx, B1 = gz * dxy, B2 = -(B0 * x + B1 * y);
+        w[0] = B2 * a1d - B1 * a2d; w[1] = B0 * a2d - B2 * a0d; w[2] = B1 * a0d - B0 * a1d;
+        w[3] = B0; w[4] = B1; w[5] = B2; w[6] = sr * ru;
+        const double tx = sfx * x;
+        w[7] = sr * xd; w[8] = 0.0; w[9] = sr; w[10] = 0.0;
+        w[11] = tx * r2; w[12] = tx * r4; w[13] = tx * (y + y); w[14] = sfx * ax; w[15] = tx * r6;
+        if (kmask != 0u) {   // (uniform: intrinsics held constant have no column)
+#pragma unroll
+          for (int qq = 0; qq < 9; ++qq) w[7 + qq] = (kmask & (1u << qq)) ? 0.0 : w[7 + qq];
+        }
+        mine[0 * 64] = d2{w[0], w[1]}; mine[1 * 64] = d2{w[2], w[3]}; mine[2 * 64] = d2{w[4], w[5]}; mine[3 * 64] = d2{w[6], w[7]};
+        mine[4 * 64] = d2{w[9], w[11]}; mine[5 * 64] = d2{w[12], w[13]}; mine[6 * 64] = d2{w[14], w[15]};
+        k2_accumulate<W, 0>(w, acc);
+      }
+      {
+        double w[16];
+        const double gz = sfy * o.iz;
+        const double B0 = gz * dxy, B1 = gz * dyy, B2 = -(B0 * x + B1 * y);
+        w[0] = B2 * a1d - B1 * a2d; w[1] = B0 * a2d - B2 * a0d; w[2] = B1 * a0d - B0 * a1d;
+        w[3] = B0; w[4] = B1; w[5] = B2; w[6] = sr * rv;
+        const double ty = sfy * y;
+        w[7] = 0.0; w[8] = sr * yd; w[9] = 0.0; w[10] = sr;
+        w[11] = ty * r2; w[12] = ty * r4; w[13] = sfy * ay; w[14] = ty * (x + x); w[15] = ty * r6;
+        if (kmask != 0u) {
+#pragma unroll
+          for (int qq = 0; qq < 9; ++qq) w[7 + qq] = (kmask & (1u << qq)) ? 0.0 : w[7 + qq];
+        }
+        mine[7 * 64] = d2{w[0], w[1]}; mine[8 * 64] = d2{w[2], w[3]}; mine[9 * 64] = d2{w[4], w[5]}; mine[10 * 64] = d2{w[6], w[8]};
+        mine[11 * 64] = d2{w[10], w[11]}; mine[12 * 64] = d2{w[12], w[13]}; mine[13 * 64] = d2{w[14], w[15]};
+        k2_accumulate<W, 1>(w, acc);
+      }
+      K2_T(1);
+      lds_barrier();
+      K2_T(2);
+      {
+        double w[16];
+        d2 t;
+        t = theirs[0 * 64]; w[0] = t.x; w[1] = t.y;  t = theirs[1 * 64]; w[2] = t.x; w[3] = t.y;
+        t = theirs[2 * 64]; w[4] = t.x; w[5] = t.y;  t = theirs[3 * 64]; w[6] = t.x; w[7] = t.y;
+        t = theirs[4 * 64]; w[9] = t.x; w[11] = t.y; t = theirs[5 * 64]; w[12] = t.x; w[13] = t.y;
+        t = theirs[6 * 64]; w[14] = t.x; w[15] = t.y;
+        w[8] = 0.0; w[10] = 0.0;
+        k2_accumulate<W, 0>(w, acc);
+      }
+      {
+        double w[16];
+        d2 t;
+        t = theirs[7 * 64]; w[0] = t.x; w[1] = t.y;  t = theirs[8 * 64]; w[2] = t.x; w[3] = t.y;
+        t = theirs[9 * 64]; w[4] = t.x; w[5] = t.y;  t = theirs[10 * 64]; w[6] = t.x; w[8] = t.y;
+        t = theirs[11 * 64]; w[10] = t.x; w[11] = t.y; t = theirs[12 * 64]; w[12] = t.x; w[13] = t.y;
+        t = theirs[13 * 64]; w[14] = t.x; w[15] = t.y;
+        w[7] = 0.0; w[9] = 0.0;
+        k2_accumulate<W, 1>(w, acc);
+      }
+      K2_T(3);
+      lds_barrier();   // (both waves have read: the rows may be overwritten by the next pass)
+      K2_T(4);
+    };
+    // one register set, observations one pass ahead (two sets -- the pair of passes unrolled -- spill: 607 us against 209 at 8 x 2000 x 500)
+    for (int p = 0; p < npass; ++p) {
+      const int k = p * 128 + tid;
+      ObsD d;
+      widen(oa, d);
+      fetch(k + 128, oa);
+      pass(k, d);
+    }
+    // ---- the NEXT group's loads go out now: they travel under this group's lane sums and assembly
+    if (more) group_loads(g + stride, qn, oa, recv, old0, old1);
+    // ---- sums over the lanes: 64 accumulators by the butterfly (value s ends in lane s), the others and the scalars by wave_sum
+    int tid_t = threadIdx.x;
+    asm volatile("" : "+v"(tid_t));
+    const int lane_t = tid_t & 63;
+    reduce_scatter64(acc, lane_t);
     {
-      d2 t;
-      t = theirs[0 * 64]; wu[0] = t.x; wu[1] = t.y;  t = theirs[1 * 64]; wu[2] = t.x; wu[3] = t.y;
-      t = theirs[2 * 64]; wu[4] = t.x; wu[5] = t.y;  t = theirs[3 * 64]; wu[6] = t.x; wu[7] = t.y;
-      t = theirs[4 * 64]; wu[9] = t.x; wu[11] = t.y; t = theirs[5 * 64]; wu[12] = t.x; wu[13] = t.y;
-      t = theirs[6 * 64]; wu[14] = t.x; wu[15] = t.y;
-      t = theirs[7 * 64]; wv[0] = t.x; wv[1] = t.y;  t = theirs[8 * 64]; wv[2] = t.x; wv[3] = t.y;
-      t = theirs[9 * 64]; wv[4] = t.x; wv[5] = t.y;  t = theirs[10 * 64]; wv[6] = t.x; wv[8] = t.y;
-      t = theirs[11 * 64]; wv[10] = t.x; wv[11] = t.y; t = theirs[12 * 64]; wv[12] = t.x; wv[13] = t.y;
-      t = theirs[13 * 64]; wv[14] = t.x; wv[15] = t.y;
+      const int pr = kK2Dev.inv[W][lane_t];
+      if (pr != 255) s_G[pr] = acc[0];
     }
-    __syncthreads();   // (both waves have read: the rows may be overwritten by the next pass)
-    if (wave == 0) k2_accumulate<0>(wu, wv, acc); else k2_accumulate<1>(wu, wv, acc);
+    {
+      // the (at most four) accumulators beyond the butterfly, the cost and the model-cost term: eight values through three halving
+      // steps and three plain ones (value e in lanes with bits 5, 4, 3 = e), instead of six full wave sums
+      double v8[8] = {acc[64], acc[65], acc[66], acc[67], cost, qterm, 0.0, 0.0};
+      reduce_swap32<4>(v8);
+      reduce_swap16<2>(v8);
+      reduce_dpp<1, 0x128, 8>(v8, lane_t);   // row_ror:8
+      double t = v8[0];
+      t += dpp_f64<0x141>(t);                // row_half_mirror (partner l ^ 7: stays inside the eight lanes that share bits 5, 4, 3)
+      t += dpp_f64<0x4E>(t);                 // quad_perm:[2,3,0,1]
+      t += dpp_f64<0xB1>(t);                 // quad_perm:[1,0,3,2]
+      const int e8 = ((lane_t >> 5) & 1) * 4 + ((lane_t >> 4) & 1) * 2 + ((lane_t >> 3) & 1);
+      if ((lane_t & 7) == 0) {
+        if (e8 < 4) { const int pr = kK2Dev.extra[W][e8]; if (pr != 255) s_G[pr] = t; }
+        else if (e8 == 4) s_G[136 + W] = t;
+        else if (e8 == 5) s_G[138 + W] = t;
+      }
+    }
+    K2_T(6);
+    if (tid_t < 4) s_G[tid_t == 0 ? 43 : (tid_t == 1 ? 62 : (tid_t == 2 ? 53 : 64))] = 0.0;   // the structurally zero pairs (fy, fx) (py, fx) (px, fy) (py, px)
+    lds_barrier();
+    auto G = [&](int i, int j) { const int hi = i > j ? i : j, lo = i > j ? j : i; return s_G[hi * (hi + 1) / 2 + lo]; };
+    // ---- the frame's couplings through the group's adjoint: T = G_cc M, H_fk = M^T H_ck, g_f = M^T g_c
+    if (tid_t < 96) {
+      double t = 0.0;
+      if (tid_t < 36) {
+        const int r = tid_t / 6, l = tid_t - 6 * r;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t = fma(G(r, k), s_m[k * 6 + l], t);
+      } else if (tid_t < 90) {
+        const int a = (tid_t - 36) / 9, j = (tid_t - 36) - 9 * a;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t = fma(s_m[k * 6 + a], G(k, 7 + j), t);
+      } else {
+        const int a = tid_t - 90;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t = fma(s_m[k * 6 + a], G(k, 6), t);
+      }
+      s_T[tid_t] = t;
+    }
+    lds_barrier();
+    if (tid_t < 21) {   // share of the frame block: (M^T T)[i][j], i >= j
+      int i = 0;
+      while ((i + 1) * (i + 2) / 2 <= tid_t) ++i;
+      const int j = tid_t - i * (i + 1) / 2;
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) t = fma(s_m[k * 6 + i], s_T[k * 6 + j], t);
+      s_T[96 + tid_t] = t;
+    }
+    lds_barrier();
+    double* rec = P.gcomp + ((size_t)dst * NG + g) * kRigRecK;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int e = tid_t + 128 * h;
+      double v = 0.0;
+      if (e <= kRkR2) v = s_G[kK2Dev.dir[e]];
+      else if (e < kRkHff) v = s_T[e - kRkT];
+      else if (e < kRkGf) v = s_T[96 + (e - kRkHff)];
+      else if (e < kRkEnd) v = s_T[90 + (e - kRkGf)];
+      rec[e] = v;
+    }
+    if (phase == 0) {
+      if (tid_t < 6) P.ghd0[g * 8 + tid_t] = fixed ? 0.0 : G(tid_t, tid_t);
+      else if (tid_t >= 64 && tid_t < 73) P.ghdk[g * 16 + (tid_t - 64)] = G(7 + (tid_t - 64), 7 + (tid_t - 64));
+    }
+    if (tid_t == 0) {
+      P.gstats[g * 2] = s_G[136] + s_G[137];
+      P.gstats[g * 2 + 1] = s_G[138] + s_G[139];
+    }
+    K2_T(7);
+#ifdef CC_RIG_K2_TIMING
+    ++k2groups;
+#endif
+    g += stride;
+    q = qn;
+    // (the next group's first barrier -- behind its store of the records into sm -- separates this group's last reads of s_G, s_T
+    // and s_m from the writes that follow)
+  }
+#ifdef CC_RIG_K2_TIMING
+  if (blockIdx.x == gridDim.x / 2 && tid == 0) {
+    for (int qq = 0; qq < 8; ++qq) P.shared_stats[40 + qq] = (double)k2t[qq];
+    P.shared_stats[48] = (double)(wall_clock64() - k2wall0);
+    P.shared_stats[49] = (double)k2groups;
+  }
+#endif
   };
-  int p = 0;
-  for (; p + 1 < npass; p += 2) {
-    const int k = p * 128 + tid;
-    ObsD d;
-    widen(oa, d);
-    fetch(k + 256, oa);
-    pass(k, d);
-    widen(ob, d);
-    fetch(k + 384, ob);
-    pass(k + 128, d);
-  }
-  if (p < npass) {
-    ObsD d;
-    widen(oa, d);
-    pass(p * 128 + tid, d);
-  }
-  // ---- sums over the lanes: 64 accumulators by the butterfly (value s ends in lane s), the others and the scalars by wave_sum
-  reduce_scatter64(acc, lane);
-  {
-    const int pr = kK2Dev.inv[wave][lane];
-    if (pr != 255) s_G[pr] = acc[0];
-  }
-#pragma unroll
-  for (int x = 64; x < kK2Acc; ++x) {
-    const double t = wave_sum(acc[x]);
-    // (pair of the extra slot x of this wave: compile-time search, two candidates)
-#pragma unroll
-    for (int pr = 0; pr < 136; ++pr)
-      if (kK2.slot[pr] == x && kK2.owner[pr] >= 0) { if (lane == 0 && wave == kK2.owner[pr]) s_G[pr] = t; }
-  }
-  {
-    const double cw = wave_sum(cost), qw = wave_sum(qterm);
-    if (lane == 0) { s_G[136 + wave] = cw; s_G[138 + wave] = qw; }
-  }
-  if (tid < 4) s_G[tid == 0 ? 43 : (tid == 1 ? 62 : (tid == 2 ? 53 : 64))] = 0.0;   // the structurally zero pairs (fy, fx) (py, fx) (px, fy) (py, px)
-  __syncthreads();
-  auto G = [&](int i, int j) { const int hi = i > j ? i : j, lo = i > j ? j : i; return s_G[hi * (hi + 1) / 2 + lo]; };
-  // ---- the frame's couplings through the group's adjoint: T = G_cc M, H_fk = M^T H_ck, g_f = M^T g_c
-  if (tid < 96) {
-    double t = 0.0;
-    if (tid < 36) {
-      const int r = tid / 6, l = tid - 6 * r;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) t = fma(G(r, k), s_m[k * 6 + l], t);
-    } else if (tid < 90) {
-      const int a = (tid - 36) / 9, j = (tid - 36) - 9 * a;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) t = fma(s_m[k * 6 + a], G(k, 7 + j), t);
-    } else {
-      const int a = tid - 90;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) t = fma(s_m[k * 6 + a], G(k, 6), t);
-    }
-    s_T[tid] = t;
-  }
-  __syncthreads();
-  if (tid < 21) {   // share of the frame block: (M^T T)[i][j], i >= j
-    int i = 0;
-    while ((i + 1) * (i + 2) / 2 <= tid) ++i;
-    const int j = tid - i * (i + 1) / 2;
-    double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) t = fma(s_m[k * 6 + i], s_T[k * 6 + j], t);
-    s_T[96 + tid] = t;
-  }
-  __syncthreads();
-  double* rec = P.gcomp + ((size_t)dst * P.NG + g) * kRigRecK;
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int e = tid + 128 * h;
-    double v = 0.0;
-    if (e <= kRkR2) v = s_G[kK2Dev.dir[e]];
-    else if (e < kRkHff) v = s_T[e - kRkT];
-    else if (e < kRkGf) v = s_T[96 + (e - kRkHff)];
-    else if (e < kRkEnd) v = s_T[90 + (e - kRkGf)];
-    rec[e] = v;
-  }
-  if (phase == 0) {
-    if (tid < 6) P.ghd0[g * 8 + tid] = fixed ? 0.0 : G(tid, tid);
-    else if (tid >= 64 && tid < 73) P.ghdk[g * 16 + (tid - 64)] = G(7 + (tid - 64), 7 + (tid - 64));
-  }
-  if (tid == 0) {
-    P.gstats[g * 2] = s_G[136] + s_G[137];
-    P.gstats[g * 2 + 1] = s_G[138] + s_G[139];
-  }
+  if (wave == 0) sweep(std::integral_constant<int, 0>{}); else sweep(std::integral_constant<int, 1>{});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -5154,6 +5273,7 @@ struct cc_rig {
   int reduce_blocks = 0;       // grid of the fused reduce + solve + update launch (rig_size_reduce_grid)
   size_t reduce_key = ~(size_t)0;
   std::vector<hipEvent_t> events;
+  int k2_grid = 1024;          // workgroups of k_rig_sweep_k2: four per compute unit (rig_layout)
   std::vector<int> event_kind;
   std::vector<int> event_round;   // round of the solve a probed launch belongs to (summarise_probes)
   int enq_round = 0;
@@ -5267,6 +5387,16 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
   // with intrinsics: compact records + the FMA sweep (k_rig_sweep_k2) feed the tuned elimination; the plain large-rig kernels
   // read the three tiles of k_rig_sweep_adjk. CC_RIG_K_COMPACT=0 keeps the tile form for A/B and the record-against-tile test.
   d.kcm = (kmode && h->sweep_adjoint && !h->big && !(getenv("CC_RIG_K_COMPACT") && atoi(getenv("CC_RIG_K_COMPACT")) == 0)) ? 1 : 0;
+  if (d.kcm) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus < 1) { (void)hipGetLastError(); cus = 256; }
+    // a workgroup per group by default: the persistent form (CC_RIG_K2_GRID=1024: four workgroups per compute unit, each looping over
+    // groups with the next group's loads under the current one's tail) measured SLOWER, 241 against 201 us at 8 x 2000 x 500 --
+    // what a group costs beyond its passes is instructions (lane sums, assembly), not latency, and other workgroups already cover the latency
+    (void)cus;
+    h->k2_grid = INT32_MAX;
+    if (const char* e = getenv("CC_RIG_K2_GRID")) { const int v = atoi(e); if (v >= 1) h->k2_grid = v; }   // (A/B; any grid is correct)
+  }
   d.C = (int32_t)C; d.CO = CO; d.CK = CK; d.S = S; d.SW = S + 1;
   d.T = (d.SW + 15) / 16; d.nT = d.T * (d.T + 1) / 2; d.ZS = 16 * d.T + ((d.T & 1) ? 0 : 16);
   d.DE = DE; d.ND = CO * DE;
@@ -5542,7 +5672,7 @@ static int rig_enqueue_round(cc_rig* h, bool initial, bool profile, bool publish
   const RigDev& d = h->d;
   struct RoundCount { cc_rig* h; ~RoundCount() { h->enq_round++; } } count_round{h};
   { RigProbe p(h, CC_K_SWEEP, profile);
-    if (d.kcm) hipLaunchKernelGGL(k_rig_sweep_k2, dim3((unsigned)h->NG), dim3(128), 0, h->stream, d);
+    if (d.kcm) hipLaunchKernelGGL(k_rig_sweep_k2, dim3((unsigned)std::min<int64_t>(h->NG, h->k2_grid)), dim3(128), 0, h->stream, d);   // (each workgroup loops over groups)
     else if (d.kmode && h->sweep_adjoint && h->sweep_waves == 1) hipLaunchKernelGGL(k_rig_sweep_adjk<1>, dim3((unsigned)h->NG), dim3(64), 0, h->stream, d);
     else if (d.kmode && h->sweep_adjoint) hipLaunchKernelGGL(k_rig_sweep_adjk<4>, dim3((unsigned)h->NG), dim3(256), 0, h->stream, d);
     else if (d.kmode) hipLaunchKernelGGL((k_rig_sweep<true, 4>), dim3((unsigned)h->NG), dim3(kRigThreads), kRigSweepLdsBytesK, h->stream, d);

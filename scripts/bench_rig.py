@@ -45,7 +45,12 @@ for _ in range(REPS):
     t0 = time.perf_counter()
     s = prob.solve(o, log_capacity=0)
     ts.append(time.perf_counter() - t0)
-print(json.dumps(dict(cams=C, frames=F, pts=M, intrinsics=K, observations=n_obs, iterations=s["iterations"], termination=s["termination"],
+per_kernel = None
+if os.environ.get("PROFILE"):   # one more solve with hipEvents around every launch: mean over the launches that did work (us)
+    prob.reset()
+    sp = prob.solve(capi.default_options(max_iterations=1000, profile_kernels=1), log_capacity=0)
+    per_kernel = {k: round(1e3 * v / sp["kernel_launches"][k], 1) for k, v in sp["kernel_ms"].items() if sp["kernel_launches"].get(k)}
+print(json.dumps(dict(cams=C, frames=F, pts=M, intrinsics=K, kernel_us_per_full_launch=per_kernel, observations=n_obs, iterations=s["iterations"], termination=s["termination"],
                       gpu_solve_ms=float(np.median(ts) * 1e3), gpu_us_per_iteration=float(np.median(ts) * 1e6 / max(1, s["iterations"])),
                       gpu_residuals_per_s=2.0 * n_obs * s["iterations"] / float(np.median(ts)), final_cost=s["final_cost"])))
 prob.close()
