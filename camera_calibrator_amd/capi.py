@@ -77,7 +77,7 @@ class Summary(C.Structure):
 
 # every symbol include/cc_solver.h declares
 EXPORTED_SYMBOLS = [
-    "cc_options_init", "cc_last_error", "cc_version", "cc_device_count", "cc_release_caches",
+    "cc_options_init", "cc_last_error", "cc_version", "cc_device_count", "cc_release_caches", "cc_parallel_for", "cc_parallel_parts", "cc_host_pool_threads", "cc_last_call_solver_status",
     "cc_intrinsics_create", "cc_intrinsics_destroy", "cc_intrinsics_set_state",
     "cc_intrinsics_reset", "cc_intrinsics_get_state", "cc_intrinsics_eval",
     "cc_intrinsics_solve", "cc_intrinsics_solver_form", "cc_intrinsics_solver_status", "cc_intrinsics_profile_sweep", "cc_intrinsics_profile_solve", "cc_intrinsics_optimize", "cc_intrinsics_estimate", "cc_intrinsics_estimate_views", "cc_intrinsics_optimize_views", "cc_host_staging_acquire", "cc_host_staging_release", "cc_last_call_timing", "cc_comm_get_unique_id",

@@ -152,6 +152,8 @@ PYBIND11_MODULE(pycalibrator, m) {
       .def("SetDevices", &Calibrator::SetDevices, py::arg("devices"))
       .def("LastStatus", &Calibrator::LastStatus)
       .def("LastIterations", &Calibrator::LastIterations)
+      .def("LastSolverReruns", &Calibrator::LastSolverReruns)
+      .def("LastSolverNote", &Calibrator::LastSolverNote)
       .def("LastFinalCost", &Calibrator::LastFinalCost);
 
   py::class_<ExtrinsicsCalibrator>(m, "ExtrinsicsCalibrator")
@@ -173,6 +175,8 @@ PYBIND11_MODULE(pycalibrator, m) {
       .def("SetVerbose", &ExtrinsicsCalibrator::SetVerbose, py::arg("verbose"))
       .def("LastStatus", &ExtrinsicsCalibrator::LastStatus)
       .def("LastIterations", &ExtrinsicsCalibrator::LastIterations)
+      .def("LastSolverReruns", &ExtrinsicsCalibrator::LastSolverReruns)
+      .def("LastSolverNote", &ExtrinsicsCalibrator::LastSolverNote)
       .def("LastFinalCost", &ExtrinsicsCalibrator::LastFinalCost)
       .def("NumCameras", &ExtrinsicsCalibrator::NumCameras)
       .def("NumObservationFrames", &ExtrinsicsCalibrator::NumObservationFrames)

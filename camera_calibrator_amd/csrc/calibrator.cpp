@@ -107,6 +107,20 @@ void Calibrator::Estimate(const std::vector<Points2D>& pixels_per_view, const st
     if (last_status_ == CC_ERR_NO_DEVICE || last_status_ == CC_ERR_HIP || last_status_ == CC_ERR_COMM || last_status_ == CC_ERR_BAD_ARGUMENT)
       throw std::runtime_error(std::string("Calibrator::Estimate: ") + cc_last_error());
     last_iterations_ = summary.iterations;
+  {
+    char note[640] = "";
+    int32_t form = 0, reruns = 0;
+    cc_last_call_solver_status(&form, &reruns, note, (int32_t)sizeof(note));
+    last_solver_reruns_ = reruns;
+    last_solver_note_ = note;
+  }
+    {
+      char note[640] = "";
+      int32_t form = 0, reruns = 0;
+      cc_last_call_solver_status(&form, &reruns, note, (int32_t)sizeof(note));
+      last_solver_reruns_ = reruns;
+      last_solver_note_ = note;
+    }
     last_final_cost_ = summary.final_cost;
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) camera_matrix_(r, c) = K9[r * 3 + c];
     camera_matrix_(0, 0) = static_cast<float>(intr[FX]);

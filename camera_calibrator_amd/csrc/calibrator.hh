@@ -3,6 +3,7 @@
 // the GPU through the C ABI of include/cc_solver.h instead of Ceres.
 #pragma once
 #include <set>
+#include <string>
 #include <vector>
 
 #include "types.hh"
@@ -52,6 +53,12 @@ class Calibrator {
   /// (ceres' summary is discarded), so Optimize itself never throws on solver failure.
   int LastStatus() const { return last_status_; }
   int LastIterations() const { return last_iterations_; }
+  /// Did the last call's solve have to be run AGAIN in another form of the solver (cc_last_call_solver_status: the persistent
+  /// one-launch kernel gave up because its workgroups were not resident together -- another tenant on the GPU, a tool that
+  /// serialises kernels, another host thread inside a device-wide runtime call)? > 0: that many times; the call was late by 42 ms
+  /// to 1.3 s each and its result equals the usual one to rounding only. LastSolverNote() says what the kernel reported.
+  int LastSolverReruns() const { return last_solver_reruns_; }
+  const std::string& LastSolverNote() const { return last_solver_note_; }
   double LastFinalCost() const { return last_final_cost_; }
   /// Wall milliseconds of the last Estimate / Optimize: [0] packing the views into (cached, pinned) flat arrays when the
   /// class does it (several devices; on one device the library packs piece by piece under its upload and the time is
@@ -66,6 +73,8 @@ class Calibrator {
   std::vector<int> devices_;
   int last_status_{0};
   int last_iterations_{0};
+  int last_solver_reruns_{0};
+  std::string last_solver_note_;
   double last_final_cost_{0.0};
   double last_timing_ms_[7]{0, 0, 0, 0, 0, 0, 0};
   Matrix3 camera_matrix_{Matrix3::Identity()};

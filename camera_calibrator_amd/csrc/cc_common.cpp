@@ -2,7 +2,10 @@
 #include "cc_common.hpp"
 
 #include <algorithm>
+#include <cstdio>
+#include <condition_variable>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -270,6 +273,19 @@ std::mutex& persist_mutex(int device) {
   return table[device >= 0 && device < 64 ? device : 0];
 }
 
+// Solver form / reruns of the handles this thread's last one-shot call worked with (the call destroys them before it returns:
+// cc_last_call_solver_status is how its caller -- the C++ classes included -- learns that a persistent solve gave up and was run
+// again in the several-kernel form: 42 ms to 1.3 s late, results equal to rounding only).
+namespace {
+thread_local int t_last_form = 0, t_last_reruns = 0;
+thread_local std::string t_last_note;
+}  // namespace
+void last_call_status_reset() { t_last_form = 0; t_last_reruns = 0; t_last_note.clear(); }
+void last_call_status_record(int form, int reruns, const std::string& note) {
+  if (reruns > 0 || t_last_reruns == 0) { t_last_form = form; if (reruns > 0) t_last_note = note; }
+  t_last_reruns += reruns;
+}
+
 int parallel_parts(int64_t n, int64_t min_per_part) {
   if (n < 2 * min_per_part) return 1;
   const unsigned hw = std::thread::hardware_concurrency();
@@ -277,13 +293,87 @@ int parallel_parts(int64_t n, int64_t min_per_part) {
   return (int)std::max<int64_t>(1, std::min<int64_t>(cap, n / min_per_part));
 }
 
+// ---- host worker pool (round 5). Every parallel phase of the library (regrouping of the observations, per-observation cost
+// scatter) and of the C++ classes (cc_parallel_for: ExtrinsicsCalibrator::Optimize's fills) runs on ONE set of threads that
+// lives as long as the process: created at first use, grown to the largest part count asked for (at most 15 workers + the
+// caller), joined by cc_release_caches. Before, each phase created and joined its own std::threads -- up to 16, two or three
+// times per Optimize(). One job at a time (a second host thread waits its turn; the phases are memory-bound copies, running
+// two at once on the same cores gains nothing). Task 0 runs on the calling thread, which also helps with the rest.
+namespace {
+struct WorkerPool {
+  std::mutex job_mu;                 // one job at a time
+  std::mutex mu;
+  std::condition_variable cv_work, cv_done;
+  std::vector<std::thread> th;
+  const std::function<void(int)>* fn = nullptr;
+  int parts = 0, next = 0, pending = 0;
+  unsigned long long gen = 0;
+  bool stop = false;
+  void worker() {
+    unsigned long long seen = 0;
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv_work.wait(lk, [&] { return stop || (gen != seen && next < parts); });
+      if (stop) return;
+      seen = gen;
+      while (next < parts) {
+        const int t = next++;
+        const std::function<void(int)>* f = fn;
+        lk.unlock();
+        (*f)(t);
+        lk.lock();
+        if (--pending == 0) cv_done.notify_all();
+      }
+    }
+  }
+};
+WorkerPool& pool() { static WorkerPool* p = new WorkerPool; return *p; }   // (never destroyed: see g_flat_* in extrinsics_calibrator.cpp)
+}  // namespace
+
 void parallel_tasks(int parts, const std::function<void(int)>& fn) {
   if (parts <= 1) { fn(0); return; }
-  std::vector<std::thread> th;
-  th.reserve((size_t)parts - 1);
-  for (int t = 1; t < parts; ++t) th.emplace_back([&fn, t] { fn(t); });
+  WorkerPool& P = pool();
+  std::lock_guard<std::mutex> job(P.job_mu);
+  {
+    std::unique_lock<std::mutex> lk(P.mu);
+    P.stop = false;
+    while ((int)P.th.size() < parts - 1 && P.th.size() < 15) P.th.emplace_back([&P] { P.worker(); });
+    P.fn = &fn; P.parts = parts; P.next = 1; P.pending = parts - 1;
+    ++P.gen;
+  }
+  P.cv_work.notify_all();
   fn(0);
-  for (auto& x : th) x.join();
+  std::unique_lock<std::mutex> lk(P.mu);
+  while (P.next < P.parts) {   // (the caller takes what no worker has started yet)
+    const int t = P.next++;
+    lk.unlock();
+    fn(t);
+    lk.lock();
+    --P.pending;
+  }
+  P.cv_done.wait(lk, [&] { return P.pending == 0; });
+  P.fn = nullptr; P.parts = 0; P.next = 0;
+}
+
+void parallel_pool_release() {
+  WorkerPool& P = pool();
+  std::lock_guard<std::mutex> job(P.job_mu);
+  std::vector<std::thread> th;
+  {
+    std::lock_guard<std::mutex> lk(P.mu);
+    P.stop = true;
+    th.swap(P.th);
+  }
+  P.cv_work.notify_all();
+  for (auto& t : th) t.join();
+  std::lock_guard<std::mutex> lk(P.mu);
+  P.stop = false;
+}
+
+int parallel_pool_threads() {
+  WorkerPool& P = pool();
+  std::lock_guard<std::mutex> lk(P.mu);
+  return (int)P.th.size();
 }
 
 void parallel_ranges(int64_t n, int64_t min_per_part, const std::function<void(int, int64_t, int64_t)>& fn) {
@@ -367,6 +457,21 @@ void cc_release_caches(void) {
   for (void* q : pinned) (void)hipHostFree(q);
   (void)hipGetLastError();
   cc::rig_release_host_caches();
+  cc::parallel_pool_release();   // (the host worker threads: the next parallel phase starts them again)
+}
+
+void cc_parallel_for(int32_t parts, void (*fn)(void* ctx, int32_t part), void* ctx) {
+  if (!fn || parts < 1) return;
+  cc::parallel_tasks(parts, [fn, ctx](int t) { fn(ctx, (int32_t)t); });
+}
+int32_t cc_parallel_parts(int64_t n, int64_t min_per_part) { return cc::parallel_parts(n, min_per_part < 1 ? 1 : min_per_part); }
+int32_t cc_host_pool_threads(void) { return cc::parallel_pool_threads(); }
+
+int cc_last_call_solver_status(int32_t* form, int32_t* reruns, char* note, int32_t note_capacity) {
+  if (form) *form = cc::t_last_form;
+  if (reruns) *reruns = cc::t_last_reruns;
+  if (note && note_capacity > 0) std::snprintf(note, (size_t)note_capacity, "%s", cc::t_last_note.c_str());
+  return CC_OK;
 }
 const char* cc_version(void) { return "camera_calibrator_amd 0.1 (gfx950, HIP)"; }
 

@@ -62,6 +62,10 @@ void rig_release_host_caches();   // (cc_rig.hip: the permutation storage kept f
 int parallel_parts(int64_t n, int64_t min_per_part);
 void parallel_tasks(int parts, const std::function<void(int)>& fn);   // fn(0 .. parts-1), one host thread each
 void parallel_ranges(int64_t n, int64_t min_per_part, const std::function<void(int, int64_t, int64_t)>& fn);
+void last_call_status_reset();                                                   // one-shot entry points: at their start
+void last_call_status_record(int form, int reruns, const std::string& note);    // ... and for every handle they destroy
+void parallel_pool_release();   // joins the pool's threads (cc_release_caches); the next parallel_tasks starts them again
+int parallel_pool_threads();
 void staging_put(void* p);
 double* last_timing();                                               // [5] phases of this thread's last one-shot call (ms)
 int scratch_get(int device, size_t bytes, void** out, bool* cached);

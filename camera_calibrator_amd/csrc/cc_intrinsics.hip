@@ -1430,6 +1430,7 @@ int intr_create_impl(cc_intrinsics* h, const int64_t* off, const float* uv, cons
 extern "C" {
 
 void cc_intrinsics_destroy(cc_intrinsics* h) {
+  if (h) cc::last_call_status_record(cc_intrinsics_solver_form(h), h->form_reruns, h->form_note);   // (what a one-shot call's caller can still ask for)
   if (!h) return;
   hipSetDevice(h->device);
   bool stream_ok = true;
@@ -1795,6 +1796,7 @@ int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* sum
 int cc_intrinsics_optimize_multi(const cc_options* opt, int32_t n_devices, const int32_t* devices, int64_t F,
                                  const int64_t* off, const float* uv, const float* xyz, double* intr9, uint32_t mask,
                                  double* q, double* t, cc_summary* summary) {
+  cc::last_call_status_reset();
   using namespace cc;
   if (n_devices < 1 || !devices || n_devices > kP2pMaxRanks)
     return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_optimize_multi: 1..%d devices", kP2pMaxRanks);
@@ -2004,6 +2006,7 @@ int cc_intrinsics_profile_kernel(cc_intrinsics* h, int32_t which, int32_t n, dou
 int cc_intrinsics_optimize(const cc_options* opt, int32_t device, int64_t F, const int64_t* off,
                            const float* uv, const float* xyz, double* intr9, uint32_t mask,
                            double* q, double* t, cc_summary* summary) {
+  cc::last_call_status_reset();
   cc_intrinsics* h = nullptr;
   double* tm = cc::last_timing();
   for (int i = 0; i < 5; ++i) tm[i] = 0.0;
@@ -2094,6 +2097,7 @@ static int estimate_on_handle(cc_intrinsics* h, const ZhangScratch& zs, const cc
 int cc_intrinsics_estimate(const cc_options* opt, int32_t device, int64_t F, const int64_t* off, const float* uv,
                            const float* xyz, const double* distortion5, uint32_t mask, float* K_init9, double* intr9,
                            double* q, double* t, cc_summary* summary) {
+  cc::last_call_status_reset();
   using namespace cc;
   if (F < 3 || !off || !uv || !xyz || !intr9 || !q || !t)
     return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_estimate: needs >= 3 frames and non-NULL arrays");
@@ -2178,6 +2182,7 @@ struct ViewsUpload {
 int cc_intrinsics_estimate_views(const cc_options* opt, int32_t device, int64_t F, const float* const* uv_views,
                                  const float* const* xyz_views, const int64_t* counts, const double* distortion5, uint32_t mask,
                                  float* K_init9, double* intr9, double* q, double* t, cc_summary* summary) {
+  cc::last_call_status_reset();
   using namespace cc;
   if (F < 3 || !uv_views || !xyz_views || !counts || !intr9 || !q || !t)
     return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_estimate_views: needs >= 3 views and non-NULL arrays");
@@ -2196,6 +2201,7 @@ int cc_intrinsics_estimate_views(const cc_options* opt, int32_t device, int64_t 
 int cc_intrinsics_optimize_views(const cc_options* opt, int32_t device, int64_t F, const float* const* uv_views,
                                  const float* const* xyz_views, const int64_t* counts, double* intr9, uint32_t mask,
                                  double* q, double* t, cc_summary* summary) {
+  cc::last_call_status_reset();
   using namespace cc;
   if (F < 1 || !uv_views || !xyz_views || !counts || !intr9 || !q || !t)
     return fail(CC_ERR_BAD_ARGUMENT, "cc_intrinsics_optimize_views: needs >= 1 view and non-NULL arrays");

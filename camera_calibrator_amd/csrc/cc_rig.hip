@@ -5,12 +5,19 @@
 // (camera_T_rig), one 6-dof pose per observation frame (rig_T_world), constant world points,
 // residuals in normalised coordinates, ceres::HuberLoss(3/500).
 //
-// Observations are regrouped on the host into (frame, camera) groups; one workgroup sweeps one
-// group and produces its 16x16 Gram block of [J_cam(6) J_frame(6) r 0 0 0] rows with the same
-// LDS-staged v_mfma_f64_16x16x4_f64 contraction as the intrinsics problem. Only cameras that are
+// Observations are regrouped on the host into (frame, camera) groups. Inside a group both poses are constants and a row's
+// frame columns are one 6 x 6 matrix applied to its camera columns (J_frame = J_cam M), so a group's sweep accumulates the Gram
+// of [J_cam(6) r] only -- 28 sums on plain FMAs -- and the frame blocks follow from the group's adjoint M. The sweeps:
+//   k_rig_sweep_frame  one workgroup per FRAME, a wave per group, compact records [G7 | G_cc M], per-frame sums (the default)
+//   k_rig_sweep_adj    one workgroup per group, 16 x 16 tile per group (large rigs: the plain kernels read tiles; tests)
+//   k_rig_persist_w    the whole solve in one launch for rigs of at most four observed cameras (lean persistent form)
+//   k_rig_sweep_k2     extension (intrinsics): 16-column Gram on plain FMAs, two waves per group, compact records
+//   k_rig_sweep_adjk   extension, tiles (large rigs; CC_RIG_K_COMPACT=0)
+// (The first formulation -- every row's 13 / 22 columns through the matrix pipe, k_rig_sweep -- lost to the adjoint forms in
+// round 2 and was deleted in round 5; git history has it.) Only cameras that are
 // observed AND not frozen own columns of the reduced system (any number of frozen / unobserved cameras
 // costs nothing, cf. the Parse-keeps-cameras quirk of extrinsics_calibrator.cpp:348-351). Per LM iteration:
-//   sweep  : per group, residuals + Jacobian rows + Huber scaling -> Gram block, cost, model term
+//   sweep  : per group, residuals + Jacobian rows + Huber scaling -> Gram sums / records, cost, model term
 //   init   : (first evaluation only) Jacobi scaling of the shared block, trust-region state
 //   elim   : trust-region decision; one wave per frame: 6x6 Cholesky of the frame block,
 //            Z = L^-1 [H_fs | g_f] staged in LDS, Y = L^-T Z for the back-substitution; the Schur
@@ -24,7 +31,7 @@
 //
 // EXTENSION (cc_rigk_*, SURVEY 8f rank 4, no counterpart in the reference): the same kernels, templated
 // where it matters, with 9 intrinsics appended to the shared block -- one set shared by all cameras or one
-// set per camera -- and pixel observations (see k_rig_sweep<true>).
+// set per camera -- and pixel observations (k_rig_sweep_k2; k_rig_sweep_adjk for the large-rig kernels).
 #include <algorithm>
 #include <chrono>
 #include <cstring>
@@ -40,11 +47,6 @@
 namespace cc {
 
 constexpr int kRigMaxS = 127;   // shared tangent coordinates: S + 1 (right-hand side) <= 128 = 8 column tiles of 16
-constexpr int kRigThreads = 256;
-constexpr int kRigSweepLdsBytes = (4 * kStageDoublesPerWave + 256) * 8;
-constexpr int kRigSweepLdsBytes2 = (2 * kStageDoublesPerWave + 256) * 8;   // two-wave workgroups
-constexpr int kRigSweepLdsBytes1 = (1 * kStageDoublesPerWave + 256) * 8;   // one-wave workgroups
-constexpr int kRigSweepLdsBytesK = (4 * kStageDoublesPerWave + 4 * 512 + 256) * 8;  // with intrinsics: per wave one 64 x 16 tile and one 64 x 8 (three workgroups per CU)
 constexpr int kRigK = 9;              // intrinsics per set (extension)
 constexpr int kRigMaxElimBlocks = 256;
 constexpr int kRigDirectPerLane = 24; // direct-sum accumulators per lane in the elim kernel (ND <= 1536)
@@ -215,27 +217,6 @@ __device__ __forceinline__ void rig_common(const double* Rf, const double* tf, c
   o.rv = o.y - v;
 }
 
-// row = sr * [d res / d cam rot(3) t(3) | d res / d frame rot(3) t(3) | res | 0 0 0],
-// B = d res / d x_cam for this row.
-__device__ __forceinline__ void rig_row(const RigObs& o, const double* Rc, double B0, double B1, double B2,
-                                        double res, double sr, bool cam_fixed, double* v) {
-  v[0] = 2.0 * (B2 * o.a1 - B1 * o.a2); v[1] = 2.0 * (B0 * o.a2 - B2 * o.a0); v[2] = 2.0 * (B1 * o.a0 - B0 * o.a1);
-  v[3] = B0; v[4] = B1; v[5] = B2;
-  const double m0 = B0 * Rc[0] + B1 * Rc[3] + B2 * Rc[6];
-  const double m1 = B0 * Rc[1] + B1 * Rc[4] + B2 * Rc[7];
-  const double m2 = B0 * Rc[2] + B1 * Rc[5] + B2 * Rc[8];
-  v[6] = 2.0 * (m2 * o.b1 - m1 * o.b2); v[7] = 2.0 * (m0 * o.b2 - m2 * o.b0); v[8] = 2.0 * (m1 * o.b0 - m0 * o.b1);
-  v[9] = m0; v[10] = m1; v[11] = m2;
-  v[12] = res;
-  v[13] = 0.0; v[14] = 0.0; v[15] = 0.0;
-#pragma unroll
-  for (int c = 0; c < 13; ++c) v[c] *= sr;
-  if (cam_fixed) {
-#pragma unroll
-    for (int c = 0; c < 6; ++c) v[c] = 0.0;
-  }
-}
-
 // EXTENSION: pixel model behind the rig chain. Given the normalised point (o.x, o.y, o.iz) it returns
 // the pixel residuals, B = d residual / d x_cam (what rig_row chains through both poses) and the two
 // rows of d residual / d k (DistortNormalized / DistortPixels, calibrator.cpp:70-95).
@@ -264,287 +245,12 @@ __device__ __forceinline__ void rigk_obs(const double* k, const RigObs& o, doubl
   r.Bv0 = fy * dxy * iz; r.Bv1 = fy * dyy * iz; r.Bv2 = -(fy * dxy * x + fy * dyy * y) * iz;
 }
 
-// Second product of the sweep with intrinsics. The 22 columns of a row are X = [J_cam(6) J_frame(6) r k0 k1 k2] (tile
-// T1, 64 x 16, swizzled) and Y = [k3 .. k8] (tile TY, 64 x 8, plain). X^T X covers every pair inside X; this product,
-// P2[a][b] = sum_rows A[a] * B[b] with A = [Y(6) | X0..X9] and B = [Y(6) | X10..X15 | 0 0 0 0], covers Y^T Y, X0..9^T Y
-// and Y^T X10..15 -- all 253 pairs with two matrix products per row set instead of the three of an [X | K]-by-halves
-// split (AA, AB, BB). Neither operand needs a tile of its own: a lane reads TY or a shifted column of T1.
-__device__ __forceinline__ void gram_rows_p2(const double* t1, const double* ty, int lane, d4& acc0, d4& acc1) {
-  const int c = lane & 15, sub = lane >> 4;
-  const int ca = c < 6 ? c : c - 6;                       // A: TY column c, or T1 column c - 6
-  const int cb = c < 6 ? c : (c < 12 ? c + 4 : 0);       // B: TY column c, T1 column c + 4, or nothing
-  const bool bz = c >= 12;
-#pragma unroll
-  for (int m = 0; m < 16; m += 2) {
-    const int r0 = 4 * m + sub, r1 = 4 * (m + 1) + sub;
-    const double a0 = c < 6 ? ty[r0 * 8 + ca] : t1[r0 * 16 + (((ca >> 1) ^ (r0 & 7)) << 1) + (ca & 1)];
-    const double a1 = c < 6 ? ty[r1 * 8 + ca] : t1[r1 * 16 + (((ca >> 1) ^ (r1 & 7)) << 1) + (ca & 1)];
-    const double x0 = c < 6 ? ty[r0 * 8 + cb] : t1[r0 * 16 + (((cb >> 1) ^ (r0 & 7)) << 1) + (cb & 1)];
-    const double x1 = c < 6 ? ty[r1 * 8 + cb] : t1[r1 * 16 + (((cb >> 1) ^ (r1 & 7)) << 1) + (cb & 1)];
-    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bz ? 0.0 : x0, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bz ? 0.0 : x1, acc1, 0, 0, 0);
-  }
-}
-
-// one row of TY per lane: six doubles at [lane][0..5] of a 64 x 8 tile
-__device__ __forceinline__ void stage_row_y(double* ty, int lane, const double* y) {
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    d2 val;
-    val.x = y[2 * j];
-    val.y = y[2 * j + 1];
-    *reinterpret_cast<d2*>(&ty[lane * 8 + 2 * j]) = val;
-  }
-}
-
-// Where entry (i, j) of output tile t (0: AA = [cam frame r]^2, 1: AB = [cam frame r] x K, 2: BB = K x K; the layout
-// the elimination and the solve step read) comes from: returns 0 (zero), 1 (P1 = X^T X) or 2 (P2), index in `e`.
-__device__ __forceinline__ int rigk_out_source(int t, int i, int j, int& e) {
-  e = 0;
-  if (t == 0) {
-    if (i < 13 && j < 13) { e = i * 16 + j; return 1; }
-    return 0;
-  }
-  if (t == 1) {   // <X_i, K_j>
-    if (i >= 13 || j >= 9) return 0;
-    if (j < 3) { e = i * 16 + 13 + j; return 1; }
-    const int m = j - 3;
-    e = i < 10 ? (6 + i) * 16 + m : m * 16 + 6 + (i - 10);
-    return 2;
-  }
-  // <K_i, K_j>
-  if (i >= 9 || j >= 9) return 0;
-  if (i < 3 && j < 3) { e = (13 + i) * 16 + 13 + j; return 1; }
-  if (i < 3) { e = (j - 3) * 16 + 9 + i; return 2; }
-  if (j < 3) { e = (i - 3) * 16 + 9 + j; return 2; }
-  e = (i - 3) * 16 + (j - 3);
-  return 2;
-}
-
-// ---------------------------------------------------------------------------------------------
-// sweep: one workgroup per (frame, camera) group. HK = false: the reference's problem (normalised
-// observations, poses only, one 16x16 Gram tile). HK = true (extension): pixel observations through the
-// camera's 9 intrinsics (its own set or the one shared by all cameras); the row has 22 columns
-// [J_cam(6) J_frame(6) r | J_k(9)]; two matrix products per row set cover all their pairs (gram_rows_p2) and the epilogue
-// scatters them into the group block's three tiles AA ([cam frame r]^2), AB ([cam frame r] x K), BB (K x K).
-// ---------------------------------------------------------------------------------------------
-#ifndef CC_RIG_SWEEP_WAVES
-#define CC_RIG_SWEEP_WAVES 4   // waves per SIMD the poses-only sweep is compiled for (A/B knob)
-#endif
-// NW = waves per workgroup: 4, or 2 for the poses-only problem when the groups are small and outnumber the
-// residency slots of four-wave workgroups (BASELINE configs[3]: 1600 groups of 300 observations = 5 chunks; twice as
-// many half-size workgroups are all resident at once and split the chunks 3 + 2 instead of 2 + 1 + 1 + 1).
-template <bool HK, int NW>
-__global__ __launch_bounds__(NW * 64, HK ? 3 : CC_RIG_SWEEP_WAVES) void k_rig_sweep(RigDev P) {
-  static_assert(NW == 4 || ((NW == 2 || NW == 1) && !HK), "small workgroups exist for the poses-only sweep");
-  constexpr int NT = NW * 64;      // threads
-  constexpr int EPT = 256 / NT;    // block entries per thread
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double* s_stage = reinterpret_cast<double*>(smem_raw);
-  double* s_blk = s_stage;
-  double* sm = s_stage + NW * kStageDoublesPerWave + (HK ? NW * 512 : 0);  // [256]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t g = blockIdx.x;
-  // (timing-only builds: the middle workgroup leaves wall-clock marks in shared_stats[32..], scripts/time_rig_reduce.py)
+// (timing-only builds: the middle workgroup leaves wall-clock marks in shared_stats[32..], scripts/time_rig_reduce.py)
 #ifdef CC_RIG_TIMING
 #define RSW_MARK(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) P.shared_stats[32 + (i)] = (double)wall_clock64(); } while (0)
 #else
 #define RSW_MARK(i) do { } while (0)
 #endif
-  RSW_MARK(0);
-  // the group's indices do not depend on the control block: all five loads leave in one round trip
-  const int f = P.gframe[g], c = P.gcam[g];
-  const int64_t s0 = P.goff[g], s1 = P.goff[g + 1];
-  const LmCtl* ctl = P.ctl;
-  const int done = ctl->done, phase = ctl->phase, step_valid = ctl->step_valid, cur = ctl->cur;
-  if (done) return;
-  if (phase != 0 && !step_valid) return;
-  const int dst = phase == 0 ? cur : (cur ^ 1);
-  const bool fixed = P.cam_fixed[c] != 0;
-  const int ks = HK ? P.kset[c] : 0;
-  // observations are fetched one pass ahead: pixel + world index, then the gathered world point (two
-  // dependent round trips); the first pass is issued here, under the prologue
-  // passes of THIS wave: a wave whose 64 slots of a pass all lie beyond the group skips that pass
-  // (wave-uniform; the main loop holds no workgroup barrier)
-  // The 64-observation chunks are dealt to the waves starting at wave (g mod NW): wave w of every workgroup of a CU
-  // sits on SIMD w, and with e.g. 300 observations per group (5 chunks) a fixed deal would give SIMD 0 twice the
-  // passes of the others.
-  const int otid = (((tid >> 6) - (int)(g & (NW - 1))) & (NW - 1)) * 64 + lane;   // this thread's slot in the group's pass
-  const int64_t wrem = s1 - s0 - (otid >> 6) * 64;
-  const int npass = wrem > 0 ? (int)((wrem + NT - 1) / NT) : 0;
-  const float2* uv2 = reinterpret_cast<const float2*>(P.uv);
-  // UNCONDITIONAL loads (idle slots re-read the group's first observation; groups are never empty): inside an `if`
-  // the loaded registers are merged with the defaults at the end of the region and that merge waits for the load,
-  // i.e. the prefetch would stall the wave for the full round trips where it is issued.
-  float2 nm;
-  float nX0, nX1, nX2;
-  {
-    const int64_t idx = s0 + otid;
-    const int64_t ic = idx < s1 ? idx : s0;
-    nm = uv2[ic];
-    nX0 = P.oxyz[ic * 3]; nX1 = P.oxyz[ic * 3 + 1]; nX2 = P.oxyz[ic * 3 + 2];
-  }
-  // sm[0..31] camera record, sm[32..63] frame record, sm[64..95] intrinsics record (candidate, step)
-  if (tid < 32) sm[tid] = P.camrec[c * 32 + tid];
-  else if (tid < 64) sm[tid] = P.frec[(size_t)f * 32 + (tid - 32)];
-  else if (HK && tid < 96) sm[tid] = P.krec[ks * 32 + (tid - 64)];
-  const size_t gs = (size_t)P.gstride;
-  double g_old[EPT], g_ab = 0.0, g_bb = 0.0;
-#pragma unroll
-  for (int e = 0; e < EPT; ++e) g_old[e] = 0.0;
-  if (phase != 0) {
-    const double* old = P.gblocks + ((size_t)cur * P.NG + g) * gs;
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) g_old[e] = old[tid + e * NT];
-    if (HK) { g_ab = old[256 + tid]; g_bb = old[512 + tid]; }
-  }
-  __syncthreads();
-  RSW_MARK(1);
-  // model-cost term of the group: d = [dc(6) df(6) (dk(9))], q = d^T g + 1/2 d^T H d over its block
-  double qterm = 0.0;
-  if (phase != 0) {
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-      const int a = (tid + e * NT) >> 4, b = tid & 15;
-      const double da = a < 6 ? sm[12 + a] : (a < 12 ? sm[32 + 12 + (a - 6)] : 0.0);
-      if (a < 12) {
-        if (b < 12) {
-          const double db = b < 6 ? sm[12 + b] : sm[32 + 12 + (b - 6)];
-          qterm += 0.5 * da * g_old[e] * db;
-        } else if (b == 12) {
-          qterm += da * g_old[e];
-        }
-      }
-    }
-    if (HK) {
-      const int a = tid >> 4, b = tid & 15;
-      const double da = a < 6 ? sm[12 + a] : (a < 12 ? sm[32 + 12 + (a - 6)] : 0.0);
-      const double dkb = b < 9 ? sm[64 + 16 + b] : 0.0;
-      if (a < 12) qterm += da * g_ab * dkb;            // cross term, counted once (1/2 * 2)
-      else if (a == 12) qterm += g_ab * dkb;           // gradient with respect to the intrinsics
-      if (a < 9) qterm += 0.5 * sm[64 + 16 + a] * g_bb * dkb;
-    }
-  }
-  double Rc[9], tc[3], Rf[9], tf[3], kk[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) { Rc[i] = rfl(sm[i]); Rf[i] = rfl(sm[32 + i]); kk[i] = HK ? rfl(sm[64 + i]) : 0.0; }
-#pragma unroll
-  for (int i = 0; i < 3; ++i) { tc[i] = rfl(sm[9 + i]); tf[i] = rfl(sm[32 + 9 + i]); }
-  const double ha = P.huber_a;
-  const uint32_t kmask = HK ? P.kmask[ks] : 0u;
-
-  double* stage = s_stage + wave * kStageDoublesPerWave;
-  double* stage_b = s_stage + NW * kStageDoublesPerWave + wave * 512;   // (with intrinsics) the 64 x 8 tile TY of this wave
-  d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-  d4 ab0 = {0.0, 0.0, 0.0, 0.0}, ab1 = {0.0, 0.0, 0.0, 0.0};   // (with intrinsics: the second product, gram_rows_p2)
-  double cost = 0.0;
-  RSW_MARK(2);
-  for (int p = 0; p < npass; ++p) {
-    const int64_t idx = s0 + (int64_t)p * NT + otid;
-    const bool valid = idx < s1;
-    const float2 m = nm;
-    const float X0 = nX0, X1 = nX1, X2 = nX2;
-    {   // next pass, unconditionally (see above)
-      const int64_t idn = idx + NT;
-      const int64_t ic = idn < s1 ? idn : s0;
-      nm = uv2[ic];
-      nX0 = P.oxyz[ic * 3]; nX1 = P.oxyz[ic * 3 + 1]; nX2 = P.oxyz[ic * 3 + 2];
-    }
-    RigObs o;
-    rig_common(Rf, tf, Rc, tc, (double)X0, (double)X1, (double)X2, (double)m.x, (double)m.y, o);
-    RigKObs ko;
-    double ru = o.ru, rv = o.rv;
-    double Bu0 = o.iz, Bu1 = 0.0, Bu2 = -o.x * o.iz, Bv0 = 0.0, Bv1 = o.iz, Bv2 = -o.y * o.iz;
-    if (HK) {
-      rigk_obs(kk, o, (double)m.x, (double)m.y, ko);
-      ru = ko.ru; rv = ko.rv;
-      Bu0 = ko.Bu0; Bu1 = ko.Bu1; Bu2 = ko.Bu2; Bv0 = ko.Bv0; Bv1 = ko.Bv1; Bv2 = ko.Bv2;
-    }
-    double rho, sr;
-    huber(ha, ru * ru + rv * rv, rho, sr);
-    if (valid) cost += 0.5 * rho;
-    double v[16], vb[6];
-    rig_row(o, Rc, Bu0, Bu1, Bu2, ru, sr, fixed, v);
-    if (!valid) {
-#pragma unroll
-      for (int k = 0; k < 16; ++k) v[k] = 0.0;
-    }
-    if (HK) {
-      // X = [cam frame r k0 k1 k2] -> T1, Y = [k3..k8] -> TY (see gram_rows_p2)
-      double jk[9];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) jk[k] = (valid && !(kmask & (1u << k))) ? sr * ko.ju[k] : 0.0;
-      v[13] = jk[0]; v[14] = jk[1]; v[15] = jk[2];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) vb[k] = jk[3 + k];
-    }
-    stage_row(stage, lane, v);
-    if (HK) stage_row_y(stage_b, lane, vb);
-    wave_lds_fence();
-    gram_rows(stage, lane, acc0, acc1);
-    if (HK) gram_rows_p2(stage, stage_b, lane, ab0, ab1);
-    wave_lds_fence();
-    rig_row(o, Rc, Bv0, Bv1, Bv2, rv, sr, fixed, v);
-    if (!valid) {
-#pragma unroll
-      for (int k = 0; k < 16; ++k) v[k] = 0.0;
-    }
-    if (HK) {
-      double jk[9];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) jk[k] = (valid && !(kmask & (1u << k))) ? sr * ko.jv[k] : 0.0;
-      v[13] = jk[0]; v[14] = jk[1]; v[15] = jk[2];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) vb[k] = jk[3 + k];
-    }
-    stage_row(stage, lane, v);
-    if (HK) stage_row_y(stage_b, lane, vb);
-    wave_lds_fence();
-    gram_rows(stage, lane, acc0, acc1);
-    if (HK) gram_rows_p2(stage, stage_b, lane, ab0, ab1);
-    wave_lds_fence();
-    if (p == 0) RSW_MARK(3);
-  }
-  RSW_MARK(4);
-  __syncthreads();
-  const int slot = ((lane >> 4)) * 16 + (lane & 15);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    s_blk[wave * 256 + slot + 64 * r] = acc0[r] + acc1[r];
-    if (HK) s_blk[1024 + wave * 256 + slot + 64 * r] = ab0[r] + ab1[r];
-  }
-  const double qw = wave_sum(qterm), cw = wave_sum(cost);
-  if (lane == 0) { sm[140 + wave] = qw; sm[144 + wave] = cw; }
-  __syncthreads();
-  double* out = P.gblocks + ((size_t)dst * P.NG + g) * gs;
-  if (!HK) {
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-      const int t = tid + e * NT;
-      const double gv = NW == 4 ? (s_blk[t] + s_blk[256 + t]) + (s_blk[512 + t] + s_blk[768 + t]) : (NW == 2 ? s_blk[t] + s_blk[256 + t] : s_blk[t]);
-      out[t] = gv;
-      if (phase == 0 && (t >> 4) < 6 && (t & 15) == (t >> 4)) P.ghd0[g * 8 + (t >> 4)] = gv;  // diag of H_cc
-    }
-  } else {
-    // the two products P1 = X^T X (s_blk[0..]) and P2 (s_blk[1024..]) scattered into the block layout [AA | AB | BB]
-    const int i = tid >> 4, j = tid & 15;
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      int e;
-      const int src = rigk_out_source(t, i, j, e);
-      const double* b = s_blk + (src == 2 ? 1024 : 0) + e;
-      const double val = src == 0 ? 0.0 : (b[0] + b[256]) + (b[512] + b[768]);
-      out[t * 256 + tid] = val;
-      if (t == 0 && phase == 0 && i < 6 && j == i) P.ghd0[g * 8 + i] = val;    // diag of H_cc
-      if (t == 2 && phase == 0 && i < 9 && j == i) P.ghdk[g * 16 + i] = val;   // diag of H_kk
-    }
-  }
-  if (tid == 0) {
-    P.gstats[g * 2] = NW == 4 ? (sm[144] + sm[145]) + (sm[146] + sm[147]) : (NW == 2 ? sm[144] + sm[145] : sm[144]);
-    P.gstats[g * 2 + 1] = NW == 4 ? (sm[140] + sm[141]) + (sm[142] + sm[143]) : (NW == 2 ? sm[140] + sm[141] : sm[140]);
-  }
-  RSW_MARK(5);
-}
 
 // ---------------------------------------------------------------------------------------------
 // sweep of the reference's problem (poses only) WITHOUT the matrix pipe. Inside a (frame, camera) group both poses are
@@ -568,7 +274,7 @@ __device__ __forceinline__ void untri(int idx, int& i, int& j) {  // packed lowe
 // 1 / z for the depth of a point in front of the camera (z far from the ends of the exponent range): the hardware
 // estimate and two Newton steps, five instructions instead of the twelve of the IEEE division sequence (scaling, fix-up).
 // Not correctly rounded: within an ulp or two of 1 / z, so the adjoint sweeps (the default) are not bit-identical to
-// the division form that k_rig_sweep, k_rig_obs_cost and the oracle keep (parity is to the stated tolerances under either;
+// the division form that k_rig_obs_cost and the oracle keep (parity is to the stated tolerances under either;
 // CC_RIG_EXACT_DIV keeps the division for A/B). Degenerate depths: z = 0 (and z = +-inf) give NaN here (0 * inf inside
 // the first fma) where the division gives +-inf / 0. Both are "not finite" to everything downstream -- the candidate
 // cost fails isfinite() in lm_trial and counts as DBL_MAX, a Gram block holding either fails the Cholesky's
@@ -684,7 +390,7 @@ __device__ __forceinline__ void rig_sweep_adj_body(const RigDev& P, const int64_
   const int dst = phase == 0 ? cur : (cur ^ 1);
   const bool fixed = P.cam_fixed[c] != 0;
   // chunks dealt to the waves starting at wave (g mod NW), observations fetched one pass ahead by unconditional loads:
-  // see k_rig_sweep
+  // (idle slots re-read the group's first observation)
   const int otid = (((tid >> 6) - (int)(g & (NW - 1))) & (NW - 1)) * 64 + lane;
   const int n = (int)(s1 - s0);                                   // observations of the group (never empty)
   const int wrem = n - (otid >> 6) * 64;
@@ -699,11 +405,7 @@ __device__ __forceinline__ void rig_sweep_adj_body(const RigDev& P, const int64_
   auto fetch = [&](int k, ObsRaw& r) {
     const int kc = k < n ? k : 0;
     r.m = uvg[kc];
-#ifdef CC_EXP_NOXYZ   // timing-only experiment (wrong numbers): the sweep without its 12 bytes of world point per observation --
-    r.X = xg[kc & 1];  // 57.5 vs 59 us at BASELINE configs[4] size, i.e. the kernel is not bound by these bytes
-#else
     r.X = xg[kc];
-#endif
   };
   ObsRaw oa, ob;
   fetch(otid, oa);
@@ -919,11 +621,7 @@ __global__ __launch_bounds__(NWF * 64, ONE ? 4 : (NWF <= 4 ? 3 : 2)) void k_rig_
   ObsRaw oa, ob;
   int64_t g0, s0_one = 0;
   int ng, n_one = 0, c_one = 0;
-#ifdef CC_RIG_NO_FWAVE
-  constexpr bool FW = false;   // (A/B build: the three-loads-deep chain of round 4's first frame form)
-#else
   constexpr bool FW = ONE;
-#endif
   if (FW) {
     const int4 sl = P.fwave[f * 8 + wave];
     s0_one = (int64_t)(((unsigned long long)(unsigned)sl.y << 32) | (unsigned)sl.x);
@@ -959,11 +657,7 @@ __global__ __launch_bounds__(NWF * 64, ONE ? 4 : (NWF <= 4 ? 3 : 2)) void k_rig_
     const int c = FW ? c_one : __builtin_amdgcn_readfirstlane(P.gcam[g]);
     const int64_t s0 = FW ? s0_one : P.goff[g];
     const int n = FW ? n_one : (int)(P.goff[g + 1] - s0);
-#ifdef CC_ABL_NO_PASS
-    const int npass = n < 0 ? 1 : 0;
-#else
     const int npass = (n + 63) >> 6;
-#endif
     const float2* uvg = reinterpret_cast<const float2*>(P.uv) + s0;
     const F3* xg = reinterpret_cast<const F3*>(P.oxyz) + s0;
     auto fetch = [&](int k, ObsRaw& r) {
@@ -1039,9 +733,7 @@ __global__ __launch_bounds__(NWF * 64, ONE ? 4 : (NWF <= 4 ? 3 : 2)) void k_rig_
       widen(oa, d);
       pass(p * 64 + lane, d);
     }
-#ifndef CC_ABL_NO_RS
     reduce_scatter32(acc, lane);   // value e in lanes 2e, 2e + 1
-#endif
     if ((lane & 1) == 0 && (lane >> 1) < 29) s_G[j * 32 + (lane >> 1)] = acc[0];
     // (loop form only) the NEXT group's first two passes (requested behind the reduction: held across it, the ten registers of the two sets
     // push the butterfly over the kernel's 128 and spill)
@@ -1076,11 +768,7 @@ __global__ __launch_bounds__(NWF * 64, ONE ? 4 : (NWF <= 4 ? 3 : 2)) void k_rig_
   double cost = 0.0, qm = 0.0;
   const double* comp_cur = P.gcomp + (size_t)cur * P.NG * 64;
   double* comp_dst = P.gcomp + (size_t)dst * P.NG * 64;
-#ifdef CC_ABL_NO_ASM
-  for (int jb = ng; jb < ng; jb += 8) {
-#else
   for (int jb = 0; jb < ng; jb += 8) {
-#endif
     const int j = jb + gi;
     const bool live = j < ng;
     const int64_t g = g0 + (live ? j : 0);
@@ -1203,7 +891,7 @@ __global__ __launch_bounds__(NWF * 64, ONE ? 4 : (NWF <= 4 ? 3 : 2)) void k_rig_
 // ---------------------------------------------------------------------------------------------
 // EXTENSION (pixel observations through the camera's intrinsics): the same idea with the matrix pipe. A row's 22 columns
 // [J_cam(6) J_frame(6) r | J_k(9)] carry only SIXTEEN independent ones, X = [J_cam(6) r J_k(9)]: one 16 x 16 product
-// per row set instead of the two of k_rig_sweep<true> (gram_rows_p2), one staged tile instead of two, no frame columns to
+// per row set instead of the two of the first formulation (all 22 columns of a row through the matrix pipe: retired in round 5), one staged tile instead of two, no frame columns to
 // form. The three tiles the other kernels read are assembled per group from G = X^T X and N (7 x 13) = [I6 M 0; 0 0 1]:
 // AA = N^T G[0:7, 0:7] N, AB = N^T G[0:7, 7:16], BB = G[7:16, 7:16]. The compact record kept for the next sweep's
 // model-cost term is G itself and M: q = 1/2 (e'^T G e' - G[6][6]), e' = [dc + M_old df, 1, dk].
@@ -3750,18 +3438,6 @@ __global__ __launch_bounds__(256) void k_rig_elim_big(RigDev P) {
   // (failure count and gradient maximum of the block live in LDS, s_fg[0] / s_fg[1]: thread 0 alone touches them)
   if (tid == 0) { s_fg[0] = 0.0; s_fg[1] = 0.0; }
   const int tr = tid >> 4, tc = tid & 15;
-#ifdef CC_EXP_ELIMBIG_TABLES
-  // FORENSICS ONLY (round 4): round 3's first version of this kernel, reconstructed from its description in DESIGN.md --
-  // the (a, b) of every tile pair read from the host tables ONCE into scalar registers (136 of them live across the frame
-  // loop) and the block's failure count / gradient maximum carried in registers. See DESIGN.md (rig item 7) for what its ISA shows.
-  int t_ab[kRigBigTiles];
-#pragma unroll
-  for (int t = 0; t < kRigBigTiles; ++t) {
-    const int tc2 = t < P.nT ? t : 0;
-    t_ab[t] = __builtin_amdgcn_readfirstlane((int)P.tile_i[tc2] | ((int)P.tile_j[tc2] << 8));
-  }
-  double nfail_r = 0.0, gmax_r = 0.0;
-#endif
   for (int64_t f = blockIdx.x; f < P.F; f += gridDim.x) {
     if (tid < 64) s_g[tid] = tid < CO ? P.fslot[f * CO + tid] : -1;
     __syncthreads();
@@ -3817,21 +3493,12 @@ __global__ __launch_bounds__(256) void k_rig_elim_big(RigDev P) {
           L[tri(i, j)] = a * inv;
         }
       }
-#ifdef CC_EXP_ELIMBIG_TABLES
-      {
-        if (!ok) nfail_r += 1.0;
-        const double* fqp = P.pose + ((size_t)cur * P.F + f) * 8;
-        const double q4[4] = {fqp[0], fqp[1], fqp[2], fqp[3]};
-        gmax_r = fmax(gmax_r, pose_grad_proj_max(q4, &A[21]));
-      }
-#else
       if (tid == 0) {
         if (!ok) s_fg[0] += 1.0;
         const double* fqp = P.pose + ((size_t)cur * P.F + f) * 8;
         const double q4[4] = {fqp[0], fqp[1], fqp[2], fqp[3]};
         s_fg[1] = fmax(s_fg[1], pose_grad_proj_max(q4, &A[21]));   // Ceres' gradient_max_norm (cc_common.hpp)
       }
-#endif
       if (tid < SW) {
         double w[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         if (c_kind == 0 || c_kind == 1) {
@@ -3890,18 +3557,6 @@ __global__ __launch_bounds__(256) void k_rig_elim_big(RigDev P) {
       // Schur products of this frame: entry (tr, tc) of every upper tile pair (a, b), a <= b < T. The loops run over the
       // largest tile grid with compile-time accumulator indices (no tables: 136 pairs of table entries in scalar registers
       // spilled hundreds of them); which pairs exist is a uniform test.
-#ifdef CC_EXP_ELIMBIG_TABLES
-#pragma unroll
-      for (int t = 0; t < kRigBigTiles; ++t) {
-        if (t < P.nT) {
-          const int a = t_ab[t] & 255, b = t_ab[t] >> 8;
-          double x = acc[t];
-#pragma unroll
-          for (int i = 0; i < 6; ++i) x = fma(s_Z[i * 256 + 16 * a + tr], s_Z[i * 256 + 16 * b + tc], x);
-          acc[t] = x;
-        }
-      }
-#else
 #pragma unroll
       for (int a = 0; a < 16; ++a) {
         if (a < T) {
@@ -3919,19 +3574,11 @@ __global__ __launch_bounds__(256) void k_rig_elim_big(RigDev P) {
           }
         }
       }
-#endif
     }
     __syncthreads();
   }
   double* prow = P.partial + (size_t)blockIdx.x * P.PC;
   // (the partial row numbers the pairs of the T x T grid in the same order: a, then b)
-#ifdef CC_EXP_ELIMBIG_TABLES
-#pragma unroll
-  for (int t = 0; t < kRigBigTiles; ++t)
-    if (t < P.nT) prow[(size_t)t * 256 + tid] = acc[t];
-  for (int e = tid; e < P.ND; e += 256) prow[P.pc_dir + e] = s_d[e];
-  if (tid == 0) { prow[P.pc_fail] = nfail_r; prow[P.pc_gmax] = gmax_r; }
-#else
 #pragma unroll
   for (int a = 0; a < 16; ++a)
 #pragma unroll
@@ -3939,7 +3586,6 @@ __global__ __launch_bounds__(256) void k_rig_elim_big(RigDev P) {
       if (b < T) prow[(size_t)(a * T - a * (a - 1) / 2 + (b - a)) * 256 + tid] = acc[big_tile(a, b)];
   for (int e = tid; e < P.ND; e += 256) prow[P.pc_dir + e] = s_d[e];
   if (tid == 0) { prow[P.pc_fail] = s_fg[0]; prow[P.pc_gmax] = s_fg[1]; }
-#endif
 }
 
 // accessor of the reduced system's lower triangle (rows 0..S, row S = right-hand side; S columns). In LDS: packed by
@@ -5219,7 +4865,6 @@ struct cc_rig {
   int sweep_waves = 4;       // waves per workgroup of the poses-only sweep (2: small groups that outnumber the slots)
   bool frame_allowed = true; // poses-only, three-kernel path: the FRAME form of the sweep (k_rig_sweep_frame); CC_RIG_SWEEP_FRAME=0: one workgroup per group (k_rig_sweep_adj)
   int frame_waves = 2;       // waves per frame workgroup of the frame form
-  bool sweep_adjoint = true; // poses-only sweep: 7-column Gram + per-group assembly (k_rig_sweep_adj); CC_RIG_SWEEP_MFMA=1: the 13-column matrix-pipe sweep
   int kmode = 0;
   std::vector<int64_t> perm;  // sorted position -> caller's observation index
   bool perm_inverse = false;   // perm[k] = regrouped position of the caller's observation k (records) instead of perm[i] = caller's index of position i
@@ -5382,11 +5027,11 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
   h->big = S > kRigMaxS || CO * DE > 64 * kRigDirectPerLane;
   if (const char* e = getenv("CC_RIG_FORCE_BIG")) h->big = h->big || atoi(e) != 0;   // (test knob: the plain kernels on any problem, sharded or not)
   // the frame form of the sweep feeds the tuned elimination only (the plain large-rig kernels read the 16 x 16 tiles)
-  d.fmode = (!kmode && h->sweep_adjoint && h->frame_allowed && S <= kRigMaxS && CO * DE <= 64 * kRigDirectPerLane &&
+  d.fmode = (!kmode && h->frame_allowed && S <= kRigMaxS && CO * DE <= 64 * kRigDirectPerLane &&
              !(getenv("CC_RIG_FORCE_BIG") && atoi(getenv("CC_RIG_FORCE_BIG")) != 0)) ? 1 : 0;
   // with intrinsics: compact records + the FMA sweep (k_rig_sweep_k2) feed the tuned elimination; the plain large-rig kernels
   // read the three tiles of k_rig_sweep_adjk. CC_RIG_K_COMPACT=0 keeps the tile form for A/B and the record-against-tile test.
-  d.kcm = (kmode && h->sweep_adjoint && !h->big && !(getenv("CC_RIG_K_COMPACT") && atoi(getenv("CC_RIG_K_COMPACT")) == 0)) ? 1 : 0;
+  d.kcm = (kmode && !h->big && !(getenv("CC_RIG_K_COMPACT") && atoi(getenv("CC_RIG_K_COMPACT")) == 0)) ? 1 : 0;
   if (d.kcm) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus < 1) { (void)hipGetLastError(); cus = 256; }
@@ -5477,7 +5122,7 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
   {
     // (frame form of the sweep: a group's record is the packed G7, whose index of direct entry e -- H_cc (i, j) at i (i + 1) / 2
     // + j, g_c,i at 21 + i -- IS e)
-    const bool fm = !kmode && h->sweep_adjoint && h->frame_allowed && !(S > kRigMaxS || CO * DE > 64 * kRigDirectPerLane || (getenv("CC_RIG_FORCE_BIG") && atoi(getenv("CC_RIG_FORCE_BIG")) != 0));
+    const bool fm = !kmode && h->frame_allowed && !(S > kRigMaxS || CO * DE > 64 * kRigDirectPerLane || (getenv("CC_RIG_FORCE_BIG") && atoi(getenv("CC_RIG_FORCE_BIG")) != 0));
     std::vector<int32_t> dent((size_t)CO * DE);
     for (int c = 0; c < CO; ++c) for (int e = 0; e < DE; ++e) dent[(size_t)c * DE + e] = (c << 16) | ((fm || d.kcm) ? e : (int)(uint16_t)dmap[(size_t)e]);   // (k_rig_sweep_k2's record starts with the direct entries in this order)
     if (int rc = dev_upload(h, &d.dent, dent)) return rc;
@@ -5673,9 +5318,8 @@ static int rig_enqueue_round(cc_rig* h, bool initial, bool profile, bool publish
   struct RoundCount { cc_rig* h; ~RoundCount() { h->enq_round++; } } count_round{h};
   { RigProbe p(h, CC_K_SWEEP, profile);
     if (d.kcm) hipLaunchKernelGGL(k_rig_sweep_k2, dim3((unsigned)std::min<int64_t>(h->NG, h->k2_grid)), dim3(128), 0, h->stream, d);   // (each workgroup loops over groups)
-    else if (d.kmode && h->sweep_adjoint && h->sweep_waves == 1) hipLaunchKernelGGL(k_rig_sweep_adjk<1>, dim3((unsigned)h->NG), dim3(64), 0, h->stream, d);
-    else if (d.kmode && h->sweep_adjoint) hipLaunchKernelGGL(k_rig_sweep_adjk<4>, dim3((unsigned)h->NG), dim3(256), 0, h->stream, d);
-    else if (d.kmode) hipLaunchKernelGGL((k_rig_sweep<true, 4>), dim3((unsigned)h->NG), dim3(kRigThreads), kRigSweepLdsBytesK, h->stream, d);
+    else if (d.kmode && h->sweep_waves == 1) hipLaunchKernelGGL(k_rig_sweep_adjk<1>, dim3((unsigned)h->NG), dim3(64), 0, h->stream, d);
+    else if (d.kmode) hipLaunchKernelGGL(k_rig_sweep_adjk<4>, dim3((unsigned)h->NG), dim3(256), 0, h->stream, d);
     else if (d.fmode) {
       const size_t fl = (size_t)kRigFrameLdsDoubles(d.CO) * 8;
       const bool one = d.CO <= h->frame_waves;   // a wave per group: no loop over groups in the kernel
@@ -5688,12 +5332,9 @@ static int rig_enqueue_round(cc_rig* h, bool initial, bool profile, bool publish
       else if (one) hipLaunchKernelGGL((k_rig_sweep_frame<8, true>), dim3((unsigned)h->F), dim3(512), fl, h->stream, d);
       else hipLaunchKernelGGL((k_rig_sweep_frame<8, false>), dim3((unsigned)h->F), dim3(512), fl, h->stream, d);
     }
-    else if (h->sweep_adjoint && h->sweep_waves == 4) hipLaunchKernelGGL((k_rig_sweep_adj<4>), dim3((unsigned)h->NG), dim3(256), 0, h->stream, d);
-    else if (h->sweep_adjoint && h->sweep_waves == 2) hipLaunchKernelGGL((k_rig_sweep_adj<2>), dim3((unsigned)h->NG), dim3(128), 0, h->stream, d);
-    else if (h->sweep_adjoint) hipLaunchKernelGGL((k_rig_sweep_adj<1>), dim3((unsigned)h->NG), dim3(64), 0, h->stream, d);
-    else if (h->sweep_waves == 2) hipLaunchKernelGGL((k_rig_sweep<false, 2>), dim3((unsigned)h->NG), dim3(128), kRigSweepLdsBytes2, h->stream, d);
-    else if (h->sweep_waves == 1) hipLaunchKernelGGL((k_rig_sweep<false, 1>), dim3((unsigned)h->NG), dim3(64), kRigSweepLdsBytes1, h->stream, d);
-    else hipLaunchKernelGGL((k_rig_sweep<false, 4>), dim3((unsigned)h->NG), dim3(kRigThreads), kRigSweepLdsBytes, h->stream, d); }
+    else if (h->sweep_waves == 4) hipLaunchKernelGGL((k_rig_sweep_adj<4>), dim3((unsigned)h->NG), dim3(256), 0, h->stream, d);
+    else if (h->sweep_waves == 2) hipLaunchKernelGGL((k_rig_sweep_adj<2>), dim3((unsigned)h->NG), dim3(128), 0, h->stream, d);
+    else hipLaunchKernelGGL((k_rig_sweep_adj<1>), dim3((unsigned)h->NG), dim3(64), 0, h->stream, d); }
   if (h->comm || h->exchange) {
     { RigProbe p(h, CC_K_DECIDE, profile); hipLaunchKernelGGL(k_rig_stats, dim3(1), dim3(256), 0, h->stream, d); }
     if (h->comm) { RigProbe p(h, CC_K_ALLREDUCE, profile); if (int rc = comm_allreduce_sum(h->comm, d.vec_stats, 4 + d.S, h->stream)) return rc; }
@@ -6060,7 +5701,6 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   }
   if (int rc = dev_upload(h, &d.cam_goff, cam_goff)) return rc;
   if (int rc = dev_upload(h, &d.cam_glist, cam_glist)) return rc;
-  if (const char* e = getenv("CC_RIG_SWEEP_MFMA")) h->sweep_adjoint = atoi(e) == 0;      // (before the layout: it decides the form of the records)
   if (const char* e = getenv("CC_RIG_SWEEP_FRAME")) h->frame_allowed = atoi(e) != 0;
   hp.mark("upload_idx");
   if (int rc = rig_layout(h, seen)) return rc;
@@ -6091,12 +5731,11 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
     // one wave when the groups alone oversubscribe the chip's 4096 wave slots or have a single 64-observation chunk,
     // two when they at least fill a quarter of them, four otherwise. CC_RIG_SWEEP_WG_WAVES forces one (A/B, tests).
     const double per_group = NG > 0 ? (double)N / (double)NG : 0.0;
-    if (const char* e = getenv("CC_RIG_SWEEP_MFMA")) h->sweep_adjoint = atoi(e) == 0;
     h->sweep_waves = kmode ? 4 : ((NG >= 4096 || per_group <= 64.0) ? 1 : (NG >= 1024 ? 2 : 4));
     // (k_rig_sweep_adj: one wave per group is the fastest at every measured shape that has a thousand groups)
-    if (!kmode && h->sweep_adjoint) h->sweep_waves = (NG >= 1024 || per_group <= 64.0) ? 1 : (NG >= 512 ? 2 : 4);
-    if (kmode && h->sweep_adjoint) h->sweep_waves = (NG >= 1024 || per_group <= 64.0) ? 1 : 4;
-    if (const char* e = getenv("CC_RIG_SWEEP_WG_WAVES")) { const int v = atoi(e); if ((!kmode && (v == 1 || v == 2 || v == 4)) || (kmode && h->sweep_adjoint && (v == 1 || v == 4))) h->sweep_waves = v; }
+    if (!kmode) h->sweep_waves = (NG >= 1024 || per_group <= 64.0) ? 1 : (NG >= 512 ? 2 : 4);
+    if (kmode) h->sweep_waves = (NG >= 1024 || per_group <= 64.0) ? 1 : 4;
+    if (const char* e = getenv("CC_RIG_SWEEP_WG_WAVES")) { const int v = atoi(e); if ((!kmode && (v == 1 || v == 2 || v == 4)) || (kmode && (v == 1 || v == 4))) h->sweep_waves = v; }
   }
   if (int rc = dev_zeroed(h, &d.intr, 2 * CKn * 16)) return rc;
   if (int rc = dev_zeroed(h, &d.krec, CKn * 32)) return rc;
@@ -6141,10 +5780,6 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
     CC_HIP(hipHostGetDevicePointer(&dev_view, pin, 0));
     d.host_pub = reinterpret_cast<unsigned long long*>(dev_view);
   }
-  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_sweep<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kRigSweepLdsBytes));
-  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_sweep<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kRigSweepLdsBytes2));
-  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_sweep<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kRigSweepLdsBytes1));
-  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_sweep<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kRigSweepLdsBytesK));
   CC_HIP(hipStreamSynchronize(h->stream));   // the observations are up (the staging block goes back to the cache)
   hp.mark("alloc_rest");
   guard.ok = true;
@@ -6223,6 +5858,7 @@ int cc_rigk_get_camera_intrinsics(cc_rig* h, int64_t camera, double* intr9) {
 int cc_rigk_get_intrinsics(cc_rig* h, double* intr9) { return cc_rigk_get_camera_intrinsics(h, 0, intr9); }
 
 void cc_rig_destroy(cc_rig* h) {
+  if (h) cc::last_call_status_record(cc_rig_solver_form(h), h->form_reruns, h->form_note);   // (what a one-shot call's caller can still ask for)
   if (!h) return;
   cc::HostPhases hp("cc_rig_destroy");
   hipSetDevice(h->device);
@@ -6367,7 +6003,7 @@ static int rig_begin(cc_rig* h, const cc_options* opt, RigRun* r) {
 
 static int rig_launch(cc_rig* h, RigRun* r, int chunk) {
   CC_HIP(hipSetDevice(h->device));
-  if (chunk == 0 && !r->no_persist && h->persist_w_ok && h->sweep_adjoint && !r->profile && !h->comm && !h->exchange && !h->big && h->co_resident <= 1) {
+  if (chunk == 0 && !r->no_persist && h->persist_w_ok && !r->profile && !h->comm && !h->exchange && !h->big && h->co_resident <= 1) {
     // the whole solve in one launch (k_rig_persist); the control workgroup publishes when it is over
     RigPersistDev q = h->pq;
     q.max_rounds = r->o.max_iterations + 2;
@@ -6543,7 +6179,7 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
   // process -- persist_mutex, cc_common.hpp; a second host thread waits here instead of inside a kernel for 1.3 s)
   std::unique_lock<std::mutex> lean_lock(persist_mutex(h->device), std::defer_lock);
   for (int chunk = 0;; ++chunk) {
-    if (chunk == 0 && !r.no_persist && h->persist_w_ok && h->sweep_adjoint && !r.profile && !h->comm && !h->exchange && !h->big && h->co_resident <= 1)
+    if (chunk == 0 && !r.no_persist && h->persist_w_ok && !r.profile && !h->comm && !h->exchange && !h->big && h->co_resident <= 1)
       lean_lock.lock();
     if (int rc = rig_launch(h, &r, chunk)) return rc;
     if (chunk == 0) hp.mark("launch0");
@@ -6584,7 +6220,7 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
 int cc_rig_solver_form(cc_rig* h) {
   using namespace cc;
   if (!h) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_solver_form: NULL handle");
-  if (!(h->persist_w_ok && h->sweep_adjoint && !h->comm && !h->exchange && !h->big && h->co_resident <= 1)) return 0;
+  if (!(h->persist_w_ok && !h->comm && !h->exchange && !h->big && h->co_resident <= 1)) return 0;
   return 2;
 }
 
@@ -6795,6 +6431,7 @@ int cc_rig_optimize(const cc_options* opt, int32_t device, int64_t C, int64_t F,
                     const float* obs_uv, const float* world_xyz, double* cam_q, double* cam_t,
                     const uint8_t* cam_frozen, double* frame_q, double* frame_t, double huber_a,
                     double* obs_cost, cc_summary* summary) {
+  cc::last_call_status_reset();
   cc_rig* h = nullptr;
   cc::HostPhases hp("cc_rig_optimize");
   int rc = cc_rig_create(device, C, F, n_world, off, obs_cam, obs_world, obs_uv, world_xyz, cam_frozen, huber_a, &h);
@@ -6822,6 +6459,7 @@ int cc_rig_optimize_frames(const cc_options* opt, int32_t device, int64_t C, int
                            void* const* frame_records, const int64_t* counts, const cc_obs_layout* layout,
                            const float* world_xyz, double* cam_q, double* cam_t, const uint8_t* cam_frozen,
                            double* frame_q, double* frame_t, double huber_a, cc_summary* summary) {
+  cc::last_call_status_reset();
   using namespace cc;
   if (F < 1 || !frame_records || !counts || !layout) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_optimize_frames: bad arguments");
   HostPhases hp("cc_rig_optimize_frames");
@@ -6896,6 +6534,7 @@ int cc_rig_optimize_multi(const cc_options* opt, int32_t n_devices, const int32_
                           const float* obs_uv, const float* world_xyz, double* cam_q, double* cam_t,
                           const uint8_t* cam_frozen, double* frame_q, double* frame_t, double huber_a,
                           double* obs_cost, cc_summary* summary) {
+  cc::last_call_status_reset();
   using namespace cc;
   if (n_devices < 1 || !devices || n_devices > kP2pMaxRanks)
     return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_optimize_multi: 1..%d devices", kP2pMaxRanks);

@@ -93,20 +93,20 @@ void ExtrinsicsCalibrator::Optimize() {
   for (size_t i = 0; i < C; ++i) AffineToQuaternionTranslation(cameras_[i], &cam_q[4 * i], &cam_t[3 * i]);
   for (size_t i = 0; i < F; ++i) AffineToQuaternionTranslation(frames_[i].pose, &frame_q[4 * i], &frame_t[3 * i]);
   std::vector<float> world(3 * Pn);
+  // (parallel phases run on the library's process-lifetime worker pool, cc_parallel_for: no thread is created per call)
+  auto run_parts = [](size_t parts, const std::function<void(size_t)>& fn) {
+    struct Ctx { const std::function<void(size_t)>* fn; } ctx{&fn};
+    cc_parallel_for((int32_t)parts, [](void* c, int32_t t) { (*static_cast<Ctx*>(c)->fn)((size_t)t); }, &ctx);
+  };
   {
-    const unsigned hw = std::thread::hardware_concurrency();
-    const size_t parts = Pn < ((size_t)1 << 17) ? 1 : std::min<size_t>({(size_t)16, hw ? (size_t)hw : 4, Pn >> 16});
-    auto fill = [&](size_t a, size_t b) {
-      for (size_t i = a; i < b; ++i) {
+    const size_t parts = (size_t)cc_parallel_parts((int64_t)Pn, (int64_t)1 << 16);
+    run_parts(parts, [&](size_t t) {
+      for (size_t i = Pn * t / parts, b = Pn * (t + 1) / parts; i < b; ++i) {
         const PointRef& info = point_refs_[i];
         const Point3D& p = frames_[info.frame].points[info.point_in_frame];
         world[3 * i] = p.x(); world[3 * i + 1] = p.y(); world[3 * i + 2] = p.z();
       }
-    };
-    std::vector<std::thread> th;
-    for (size_t t = 1; t < parts; ++t) th.emplace_back(fill, Pn * t / parts, Pn * (t + 1) / parts);
-    fill(0, Pn / parts);
-    for (auto& x : th) x.join();
+    });
   }
   std::vector<int64_t> offsets(F + 1, 0);
   for (size_t f = 0; f < F; ++f) offsets[f + 1] = offsets[f] + (int64_t)frames_[f].sightings.size();
@@ -115,18 +115,14 @@ void ExtrinsicsCalibrator::Optimize() {
   // frames in contiguous ranges of about equal observation counts, one host thread each (flattening for several devices)
   std::vector<size_t> part_first{0};
   {
-    const unsigned hw = std::thread::hardware_concurrency();
-    const size_t parts = N < ((size_t)1 << 18) ? 1 : std::min<size_t>({(size_t)16, hw ? (size_t)hw : 4, N >> 17});
+    const size_t parts = (size_t)cc_parallel_parts((int64_t)N, (int64_t)1 << 17);
     for (size_t t = 1; t < parts; ++t)
       part_first.push_back((size_t)(std::lower_bound(offsets.begin(), offsets.end(), (int64_t)(N * t / parts)) - offsets.begin()));
     part_first.push_back(F);
     for (size_t t = 1; t < part_first.size(); ++t) part_first[t] = std::min(F, std::max(part_first[t], part_first[t - 1]));
   }
   auto over_frames = [&](const std::function<void(size_t, size_t)>& fn) {
-    std::vector<std::thread> th;
-    for (size_t t = 1; t + 1 < part_first.size(); ++t) th.emplace_back([&, t] { fn(part_first[t], part_first[t + 1]); });
-    fn(part_first[0], part_first[1]);
-    for (auto& x : th) x.join();
+    run_parts(part_first.size() - 1, [&](size_t t) { fn(part_first[t], part_first[t + 1]); });
   };
   uint32_t* obs_cam = nullptr;
   uint64_t* obs_world = nullptr;
@@ -202,6 +198,14 @@ void ExtrinsicsCalibrator::Optimize() {
   }
   last_iterations_ = summary.iterations;
   last_final_cost_ = summary.final_cost;
+  {
+    char note[640] = "";
+    int32_t form = 0, reruns = 0;
+    cc_last_call_solver_status(&form, &reruns, note, (int32_t)sizeof(note));
+    last_solver_reruns_ = reruns;
+    last_solver_note_ = note;
+  }
+  if (verbose_ && last_solver_reruns_ > 0) std::printf("note: %s\n", last_solver_note_.c_str());
   if (verbose_) {  // the reference lets Ceres print its per-iteration table (extrinsics_calibrator.cpp:212-213)
     std::printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n");
     std::printf("%4d %.6e    0.00e+00\n", 0, summary.initial_cost);

@@ -45,6 +45,12 @@ class ExtrinsicsCalibrator {
   void SetVerbose(bool verbose) { verbose_ = verbose; }
   int LastStatus() const { return last_status_; }
   int LastIterations() const { return last_iterations_; }
+  /// Did the last call's solve have to be run AGAIN in another form of the solver (cc_last_call_solver_status: the persistent
+  /// one-launch kernel gave up because its workgroups were not resident together -- another tenant on the GPU, a tool that
+  /// serialises kernels, another host thread inside a device-wide runtime call)? > 0: that many times; the call was late by 42 ms
+  /// to 1.3 s each and its result equals the usual one to rounding only. LastSolverNote() says what the kernel reported.
+  int LastSolverReruns() const { return last_solver_reruns_; }
+  const std::string& LastSolverNote() const { return last_solver_note_; }
   double LastFinalCost() const { return last_final_cost_; }
   /// Wall milliseconds of the last Optimize(): [0] preparing the arguments (several devices: flattening the frames), [1] cc_rig_optimize_frames
   /// (regrouping, upload, solve, per-observation costs, read-back), [2] writing costs and poses back, [3] the whole call.
@@ -87,6 +93,8 @@ class ExtrinsicsCalibrator {
   bool verbose_{true};
   int last_status_{0};
   int last_iterations_{0};
+  int last_solver_reruns_{0};
+  std::string last_solver_note_;
   double last_final_cost_{0.0};
   // flat copies of the observations for the C ABI, kept between calls (grow-only: a caller that optimises again after adding
   // frames -- the reference's workflow -- does not fault in 200 MB of fresh vectors per call at BASELINE configs[4] size)

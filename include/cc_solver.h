@@ -119,6 +119,20 @@ const char* cc_version(void);
  * pooled device blocks of the last handles (at most 8 GB per device), one pinned host staging block, streams. This gives the
  * memory back (idle pieces only; safe at any time, the next call allocates again). */
 void cc_release_caches(void);
+/* Solver form and reruns of this thread's LAST one-shot call (cc_intrinsics_estimate / _optimize / _views / _multi,
+ * cc_rig_optimize / _frames / _multi): these calls destroy their handles before returning, so cc_*_solver_status cannot be asked.
+ * form: 0 several kernels per iteration, 1 / 2 / 4 the persistent per-solve kernel; reruns > 0: a persistent solve gave up
+ * (workgroups not co-resident: another tenant, a tool that serialises kernels, a host thread inside a device-wide runtime call)
+ * and the solve was run again in the several-kernel form -- late by 42 ms to 1.3 s, equal to rounding; note says what the
+ * kernel reported. The C++ classes expose it as LastSolverReruns() / LastSolverNote(). */
+int cc_last_call_solver_status(int32_t* form, int32_t* reruns, char* note, int32_t note_capacity);
+/* The library's host worker pool, for a caller's own parallel phases (the C++ classes flatten / fill their arrays with it,
+ * extrinsics_calibrator.cpp): fn(ctx, part) for part = 0 .. parts - 1, part 0 on the calling thread, returns when all are done.
+ * The threads are created at first use (at most 15), kept for the life of the process, joined by cc_release_caches.
+ * cc_parallel_parts: how many parts the library itself would use for n items of which a part should hold min_per_part. */
+void cc_parallel_for(int32_t parts, void (*fn)(void* ctx, int32_t part), void* ctx);
+int32_t cc_parallel_parts(int64_t n, int64_t min_per_part);
+int32_t cc_host_pool_threads(void);
 /* Number of usable HIP devices (0 if none); never touches the oracle or a CPU path. */
 int cc_device_count(void);
 

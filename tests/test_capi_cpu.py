@@ -109,3 +109,50 @@ def test_compute_entry_points_fail_loudly_without_gpu():
         capi.IntrinsicsProblem([0, 4], np.zeros((4, 2)), np.zeros((4, 3)))
     with pytest.raises(capi.CcError):
         capi.distort(np.eye(3), np.zeros(5), np.zeros((3, 2)))
+
+
+def test_host_worker_pool_runs_every_part_once_and_is_joined_by_release_caches():
+    """cc_parallel_for (round 5): the library's process-lifetime worker pool, which the C++ classes use for their fills instead
+    of creating threads per call. Every part runs exactly once; two host threads may submit at the same time (one job at a
+    time); cc_release_caches joins the workers and the next job starts them again. Host code only: no GPU needed."""
+    import ctypes as C
+    import threading
+    lib = capi.lib()
+    lib.cc_parallel_parts.restype = C.c_int32
+    lib.cc_parallel_parts.argtypes = [C.c_int64, C.c_int64]
+    lib.cc_host_pool_threads.restype = C.c_int32
+    FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32)
+    lib.cc_parallel_for.argtypes = [C.c_int32, FN, C.c_void_p]
+    lib.cc_parallel_for.restype = None
+    assert lib.cc_parallel_parts(10, 100) == 1 and 1 <= lib.cc_parallel_parts(1 << 24, 1 << 16) <= 16
+
+    def job(parts, counts):
+        lock = threading.Lock()
+
+        def body(_ctx, t):
+            with lock:
+                counts[t] += 1
+        cb = FN(body)
+        lib.cc_parallel_for(parts, cb, None)
+
+    a, b = [0] * 7, [0] * 12
+    ta, tb = threading.Thread(target=job, args=(7, a)), threading.Thread(target=job, args=(12, b))
+    ta.start(); tb.start(); ta.join(); tb.join()
+    assert a == [1] * 7 and b == [1] * 12
+    assert 1 <= lib.cc_host_pool_threads() <= 15
+    lib.cc_release_caches()
+    assert lib.cc_host_pool_threads() == 0
+    c = [0] * 5
+    job(5, c)
+    assert c == [1] * 5 and lib.cc_host_pool_threads() >= 1
+    one = [0]
+    job(1, one)            # a single part runs on the calling thread
+    assert one == [1]
+
+
+def test_last_call_solver_status_is_exported_and_empty_before_any_call():
+    import ctypes as C
+    lib = capi.lib()
+    form, reruns, note = C.c_int32(-1), C.c_int32(-1), C.create_string_buffer(64)
+    assert lib.cc_last_call_solver_status(C.byref(form), C.byref(reruns), note, 64) == 0
+    assert reruns.value == 0 and note.value == b""

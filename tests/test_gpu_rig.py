@@ -1,7 +1,11 @@
 """Parity of the HIP rig path (cc_rig_*, through the C ABI) against the CPU oracle.
-Scenario: src/test_extrinsics_calibrator.cpp:48-134 at several sizes. Tolerances: costs 1e-9
-relative with identical accept/reject sequence; converged camera/frame translations 1e-9,
-quaternions 1e-9; per-observation costs 1e-9 relative (+1e-18 absolute)."""
+Scenario: src/test_extrinsics_calibrator.cpp:48-134 at several sizes. Tolerances (round 5) at the MEASURED floor of the path
+with its approximate arithmetic in (1 / z from the hardware estimate + two Newton steps, Huber tail from refined v_rsq_f64,
+pivots and quaternion norms through rsqrt_pos) -- profiles/r05/rig_deviation.jsonl (scripts/rig_deviation.py: seven shapes up to
+BASELINE configs[3] with 1.6 - 22 % of the blocks in the Huber tail, default build and -DCC_RIG_EXACT_DIV -DCC_RIG_EXACT_HUBER
+side by side -- the two builds deviate alike, i.e. what is left is the order of the sums): identical iteration count and
+accept / reject sequence; per-iteration costs <= 2e-12 relative (asserted 1e-10); converged poses <= 7e-15 (asserted 1e-11; were
+1e-9); per-observation costs <= 3.3e-10 relative (asserted 1e-8); final cost <= 3e-14 (asserted 1e-12)."""
 import os
 import subprocess
 import sys
@@ -32,14 +36,24 @@ def _both(sc, n_cams, huber_a=capi.HUBER_A, frozen=None, **kw):
     return g, o
 
 
-def _assert_same(g, o, atol=1e-9):
+def _assert_same(g, o, atol=1e-11):
     assert g[5]["iterations"] == o[5]["iterations"] and g[5]["termination"] == o[5]["termination"]
     assert [l["accepted"] for l in g[5]["log"]] == [l["accepted"] for l in o[5]["log"]]
-    assert np.allclose([l["cost"] for l in g[5]["log"]], [l["cost"] for l in o[5]["log"]], rtol=1e-9)
+    assert np.allclose([l["cost"] for l in g[5]["log"]], [l["cost"] for l in o[5]["log"]], rtol=1e-10)
     for k in range(4):
         assert np.abs(g[k] - o[k]).max() < atol
-    assert np.allclose(g[4], o[4], rtol=1e-9, atol=1e-18)
-    assert np.isclose(g[5]["final_cost"], o[5]["final_cost"], rtol=1e-10)
+    assert np.allclose(g[4], o[4], rtol=1e-8, atol=1e-16), np.abs(g[4] / np.maximum(o[4], 1e-300) - 1).max()
+    assert np.isclose(g[5]["final_cost"], o[5]["final_cost"], rtol=1e-12)
+
+
+def _noise_floor_step(log):
+    """Step norm of the first iteration of a tight solve whose cost change is below the rounding of the cost sum (1e-13
+    relative): from there on which steps are accepted depends on the order of the sums, and every implementation ends within
+    that step of the minimiser -- on its own iterate (tests/test_golden.py::_rigk_noise_floor, same bound)."""
+    for l in log:
+        if abs(l["cost_change"]) < 1e-13 * l["cost"]:
+            return float(l["step_norm"])
+    return None
 
 
 @pytest.mark.parametrize("cams,frames,pts", [(2, 50, 4), (2, 1000, 4), (4, 40, 30), (3, 20, 300), (8, 25, 70)])
@@ -160,13 +174,15 @@ def test_rig_c5_full_size_against_the_committed_oracle_result_and_properties():
     r1 = prob.get_state()
     assert s1["termination"] == str(gld["termination"]) and s1["iterations"] == int(gld["iterations"])
     assert [l["accepted"] for l in s1["log"]] == list(gld["accepted"])
-    assert np.allclose([l["cost"] for l in s1["log"]], gld["costs"], rtol=1e-9)
+    # (tolerances at the measured floor of this very configuration against the live oracle, profiles/r05/rig_deviation.jsonl: costs
+    # of 8 M-term sums 5.7e-11, poses <= 1e-13, per-observation costs 2e-9; were 1e-9 / 1e-9 / 1e-7)
+    assert np.allclose([l["cost"] for l in s1["log"]], gld["costs"], rtol=2e-10)
     assert np.isclose(s1["initial_cost"], float(gld["initial_cost"]), rtol=1e-10)
     assert np.isclose(s1["final_cost"], float(gld["final_cost"]), rtol=1e-10)
-    assert np.abs(r1[0] - gld["cam_q"]).max() < 1e-9 and np.abs(r1[1] - gld["cam_t"]).max() < 1e-9
+    assert np.abs(r1[0] - gld["cam_q"]).max() < 1e-11 and np.abs(r1[1] - gld["cam_t"]).max() < 1e-11
     pick = gld["frame_pick"]
-    assert np.abs(r1[2][pick] - gld["frame_q"]).max() < 1e-9 and np.abs(r1[3][pick] - gld["frame_t"]).max() < 1e-9
-    assert np.allclose(r1[4][:64], gld["obs_cost_head"], rtol=1e-7, atol=1e-14)
+    assert np.abs(r1[2][pick] - gld["frame_q"]).max() < 1e-11 and np.abs(r1[3][pick] - gld["frame_t"]).max() < 1e-11
+    assert np.allclose(r1[4][:64], gld["obs_cost_head"], rtol=1e-8, atol=1e-14)
     assert np.isclose(r1[4].sum(), float(gld["obs_cost_sum"]), rtol=1e-10)
     # properties
     assert np.array_equal(r1[0][0], cq[0]) and np.array_equal(r1[1][0], ct[0])
@@ -265,10 +281,15 @@ def test_rig_huber_active_at_the_minimiser_matches_oracle(cams, frames, pts):
     g = capi.rig_optimize(*args, huber_a=a, options=capi.default_options(**kw))
     o = po.rig_solve(*args, huber_a=a, options=po.default_options(**kw))
     assert g[5]["termination"] in ("FUNCTION", "GRADIENT", "PARAMETER")
-    assert np.isclose(g[5]["final_cost"], o[5]["final_cost"], rtol=1e-11)
+    # the iterate: within the step at which the oracle's cost changes drop into the rounding of the cost sum -- the bound the data
+    # gives (measured: poses 9e-16 .. 1.6e-11 against floors 6e-9 .. 5e-8, profiles/r05/rig_deviation.jsonl), not 1e-6 / 1e-4
+    floor = _noise_floor_step(o[5]["log"])
+    assert floor is not None and 1e-10 < floor < 1e-6, floor
+    assert np.isclose(g[5]["final_cost"], o[5]["final_cost"], rtol=1e-13)
     for k in range(4):
-        assert np.abs(g[k] - o[k]).max() < 1e-6
-    assert np.allclose(g[4], o[4], rtol=1e-4, atol=1e-12)
+        assert np.abs(g[k] - o[k]).max() < floor, (k, np.abs(g[k] - o[k]).max(), floor)
+    # per-observation costs 1/2 rho(|r|^2), |r| <= 0.06 here: d cost <= |r| |J| |d x| -- below the floor itself
+    assert np.abs(g[4] - o[4]).max() < floor
     tail_ok(g)
 
 
@@ -284,8 +305,9 @@ def test_rigs_with_more_than_21_optimised_cameras_match_the_oracle(cams, frames,
     assert np.array_equal(g[0][0], o[0][0]) and np.array_equal(g[1][0], o[1][0])   # frozen camera untouched
     g, o = _both(sc, cams, **{k: v for k, v in TIGHT.items() if k != "max_iterations"})
     assert np.isclose(g[5]["final_cost"], o[5]["final_cost"], rtol=1e-12)
+    bound = _noise_floor_step(o[5]["log"]) or 1e-8   # (measured at 23 cameras: 1e-15 against a floor of 4e-9; was 1e-8)
     for k in range(4):
-        assert np.abs(g[k] - o[k]).max() < 1e-8
+        assert np.abs(g[k] - o[k]).max() < bound
 
 
 def test_more_than_255_shared_coordinates_are_refused_loudly():
