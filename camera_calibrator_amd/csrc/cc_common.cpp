@@ -97,22 +97,34 @@ std::vector<Scratch> g_scratch;   // per device, guarded by g_cache_mu
 constexpr size_t kScratchKeep = (size_t)64 << 20;
 }  // namespace
 
+// (a piece that has to grow is marked busy and its old block detached UNDER the lock; hipFree / hipMalloc --
+// device-wide waits -- run outside it, so one thread growing a piece no longer stalls every other thread's handle creation and
+// teardown behind another thread's persistent solve)
 int scratch_get(int device, size_t bytes, void** out, bool* cached) {
   *cached = false;
   if (bytes <= kScratchKeep) {
-    std::lock_guard<std::mutex> lk(g_cache_mu);
-    if ((int)g_scratch.size() <= device) g_scratch.resize((size_t)device + 1);
-    Scratch& s = g_scratch[(size_t)device];
-    if (!s.busy) {
-      if (s.bytes < bytes) {
-        if (s.p) hipFree(s.p);
-        s.p = nullptr; s.bytes = 0;
-        if (hipMalloc(&s.p, bytes) != hipSuccess) { (void)hipGetLastError(); s.p = nullptr; return fail(CC_ERR_HIP, "hipMalloc(%zu) failed", bytes); }
-        s.bytes = bytes;
+    void* old = nullptr;
+    bool grow = false, mine = false;
+    {
+      std::lock_guard<std::mutex> lk(g_cache_mu);
+      if ((int)g_scratch.size() <= device) g_scratch.resize((size_t)device + 1);
+      Scratch& s = g_scratch[(size_t)device];
+      if (!s.busy) {
+        mine = true;
+        s.busy = true;
+        if (s.bytes < bytes) { grow = true; old = s.p; s.p = nullptr; s.bytes = 0; }
+        else { *out = s.p; *cached = true; return CC_OK; }
       }
-      s.busy = true;
-      *out = s.p;
-      *cached = true;
+    }
+    if (mine && grow) {
+      if (old) (void)hipFree(old);
+      void* fresh = nullptr;
+      const hipError_t e = hipMalloc(&fresh, bytes);
+      std::lock_guard<std::mutex> lk(g_cache_mu);
+      Scratch& s = g_scratch[(size_t)device];
+      if (e != hipSuccess) { (void)hipGetLastError(); s.busy = false; return fail(CC_ERR_HIP, "hipMalloc(%zu) failed", bytes); }
+      s.p = fresh; s.bytes = bytes;
+      *out = fresh; *cached = true;
       return CC_OK;
     }
   }
@@ -161,20 +173,32 @@ Piece* pick_piece(std::vector<Piece>& v, size_t bytes) {
 int arena_get(int device, size_t bytes, void** out, bool* cached) {
   *cached = false;
   if (bytes <= kArenaKeep) {
-    std::lock_guard<std::mutex> lk(g_cache_mu);
-    if ((int)g_arena.size() <= device) g_arena.resize((size_t)device + 1);
-    if (g_arena[(size_t)device].capacity() < (size_t)kPiecesKept) g_arena[(size_t)device].reserve(kPiecesKept);   // (pointers into it stay valid)
-    if (Piece* a = pick_piece(g_arena[(size_t)device], bytes)) {
-      if (a->bytes < bytes) {
-        if (a->p) (void)hipFree(a->p);
-        a->p = nullptr; a->bytes = 0;
-        const size_t want = bytes + bytes / 4;   // (room for a problem that grows by a few frames per call)
-        if (hipMalloc(&a->p, want) != hipSuccess) { (void)hipGetLastError(); a->p = nullptr; return fail(CC_ERR_HIP, "hipMalloc(%zu) failed", want); }
-        a->bytes = want;
+    void* old = nullptr;
+    size_t slot = 0;
+    bool grow = false, mine = false;
+    {
+      std::lock_guard<std::mutex> lk(g_cache_mu);
+      if ((int)g_arena.size() <= device) g_arena.resize((size_t)device + 1);
+      auto& v = g_arena[(size_t)device];
+      if (v.capacity() < (size_t)kPiecesKept) v.reserve(kPiecesKept);
+      if (Piece* a = pick_piece(v, bytes)) {
+        mine = true;
+        a->busy = true;
+        slot = (size_t)(a - v.data());
+        if (a->bytes < bytes) { grow = true; old = a->p; a->p = nullptr; a->bytes = 0; }
+        else { *out = a->p; *cached = true; return CC_OK; }
       }
-      a->busy = true;
-      *out = a->p;
-      *cached = true;
+    }
+    if (mine && grow) {
+      if (old) (void)hipFree(old);
+      const size_t want = bytes + bytes / 4;   // (room for a problem that grows by a few frames per call)
+      void* fresh = nullptr;
+      const hipError_t e = hipMalloc(&fresh, want);
+      std::lock_guard<std::mutex> lk(g_cache_mu);
+      Piece& a = g_arena[(size_t)device][slot];
+      if (e != hipSuccess) { (void)hipGetLastError(); a.busy = false; return fail(CC_ERR_HIP, "hipMalloc(%zu) failed", want); }
+      a.p = fresh; a.bytes = want;
+      *out = fresh; *cached = true;
       return CC_OK;
     }
   }
@@ -196,19 +220,31 @@ void arena_put(int device, void* p, bool cached) {
 void* staging_get(size_t bytes, bool* cached) {
   *cached = false;
   if (bytes <= kStagingKeep) {
-    std::lock_guard<std::mutex> lk(g_cache_mu);
-    if (g_staging.capacity() < (size_t)kPiecesKept) g_staging.reserve(kPiecesKept);
-    if (Piece* st = pick_piece(g_staging, bytes)) {
-      if (st->bytes < bytes) {
-        if (st->p) (void)hipHostFree(st->p);
-        st->p = nullptr; st->bytes = 0;
-        const size_t want = bytes + bytes / 4;
-        if (hipHostMalloc(&st->p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); st->p = nullptr; return nullptr; }
-        st->bytes = want;
+    void* old = nullptr;
+    size_t slot = 0;
+    bool grow = false, mine = false;
+    {
+      std::lock_guard<std::mutex> lk(g_cache_mu);
+      if (g_staging.capacity() < (size_t)kPiecesKept) g_staging.reserve(kPiecesKept);
+      if (Piece* st = pick_piece(g_staging, bytes)) {
+        mine = true;
+        st->busy = true;
+        slot = (size_t)(st - g_staging.data());
+        if (st->bytes < bytes) { grow = true; old = st->p; st->p = nullptr; st->bytes = 0; }
+        else { *cached = true; return st->p; }
       }
-      st->busy = true;
+    }
+    if (mine && grow) {
+      if (old) (void)hipHostFree(old);
+      const size_t want = bytes + bytes / 4;
+      void* fresh = nullptr;
+      const hipError_t e = hipHostMalloc(&fresh, want, hipHostMallocDefault);
+      std::lock_guard<std::mutex> lk(g_cache_mu);
+      Piece& st = g_staging[slot];
+      if (e != hipSuccess) { (void)hipGetLastError(); st.busy = false; return nullptr; }
+      st.p = fresh; st.bytes = want;
       *cached = true;
-      return st->p;
+      return fresh;
     }
   }
   void* p = nullptr;

@@ -36,6 +36,7 @@
 #include <chrono>
 #include <cstring>
 #include <numeric>
+#include <tuple>
 #include <type_traits>
 #include <vector>
 
@@ -2191,17 +2192,29 @@ __device__ __forceinline__ void rig_elim_body(const RigDev& P, char* smem_raw, c
         }
       }
       if (HK && P.kmode == RIG_K_SHARED) {
-        // columns of the intrinsics shared by all cameras: sum of the frame's groups
-        for (int j = 0; j < CO; ++j) {
-          const int g = __builtin_amdgcn_readlane(gj, j);
-          if (g < 0) continue;
-          const double* G = blocks + (size_t)g * gs + (KC ? kRkFK : 256);
+        // columns of the intrinsics shared by all cameras: sum of the frame's groups. Four groups per round trip, unconditional
+        // loads (group 0 stands in for a camera that does not see the frame) and selects: written as a loop over the groups with
+        // a `continue`, every group's six loads waited for on their own -- CO dependent round trips per frame (round 5: the
+        // elimination at 8 x 2000 x 500 with shared intrinsics 43 -> ... us)
+        for (int j0 = 0; j0 < CO; j0 += 4) {
 #pragma unroll
-          for (int h = 0; h < 2; ++h)
-            if (c_kind[h] == 2) {
+          for (int h = 0; h < 2; ++h) {
+            if (c_kind[h] != 2) continue;   // (nine lanes own such a column; the others skip the batch)
+            double t[4][6];
+            bool ok[4];
 #pragma unroll
-              for (int i = 0; i < 6; ++i) w[h][i] += KC ? G[i * 9 + c_comp[h]] : G[(6 + i) * 16 + c_comp[h]];
+            for (int u = 0; u < 4; ++u) {
+              const int g = j0 + u < CO ? __builtin_amdgcn_readlane(gj, j0 + u < CO ? j0 + u : 0) : -1;
+              ok[u] = g >= 0;
+              const double* G = blocks + (size_t)(ok[u] ? g : 0) * gs + (KC ? kRkFK : 256);
+#pragma unroll
+              for (int i = 0; i < 6; ++i) t[u][i] = KC ? G[i * 9 + c_comp[h]] : G[(6 + i) * 16 + c_comp[h]];
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int i = 0; i < 6; ++i) w[h][i] += ok[u] ? t[u][i] : 0.0;
+          }
         }
       }
       // direct entries, eight registers per round trip: unconditional loads (group 0 stands in where a lane has
@@ -4869,6 +4882,10 @@ struct cc_rig {
   std::vector<int64_t> perm;  // sorted position -> caller's observation index
   bool perm_inverse = false;   // perm[k] = regrouped position of the caller's observation k (records) instead of perm[i] = caller's index of position i
   std::vector<std::pair<void*, size_t>> allocs;   // the chunks dev_alloc carves buffers from (cc::pool_alloc: recycled between handles)
+  // pinned staging of the small host-built tables while the handle is being created (rig_create_impl): dev_upload copies a table
+  // in and enqueues an asynchronous copy on the handle's stream instead of one synchronous hipMemcpy per table (~25 of them)
+  char* up_stage = nullptr;
+  size_t up_cap = 0, up_used = 0;
   char* chunk_cur = nullptr;
   size_t chunk_left = 0;
   double* init_cam = nullptr;
@@ -4948,14 +4965,23 @@ static int dev_alloc(cc_rig* h, T** p, size_t n) {
 template <class T>
 static int dev_zeroed(cc_rig* h, T** p, size_t n) {
   if (int rc = dev_alloc(h, p, n)) return rc;
-  CC_HIP(hipMemset(*p, 0, std::max<size_t>(n, 1) * sizeof(T)));
+  // (on the handle's stream: everything that reads the buffer runs there, and the creating call synchronises it before it returns)
+  if (h->stream) CC_HIP(hipMemsetAsync(*p, 0, std::max<size_t>(n, 1) * sizeof(T), h->stream));
+  else CC_HIP(hipMemset(*p, 0, std::max<size_t>(n, 1) * sizeof(T)));
   return 0;
 }
 template <class T>
 static int dev_upload(cc_rig* h, const T** p, const std::vector<T>& v) {
   T* q = nullptr;
   if (int rc = dev_alloc(h, &q, v.size())) return rc;
-  if (!v.empty()) CC_HIP(hipMemcpy(q, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  const size_t bytes = v.size() * sizeof(T), padded = (bytes + 63) & ~(size_t)63;
+  if (bytes && h->up_stage && h->stream && h->up_used + padded <= h->up_cap) {
+    std::memcpy(h->up_stage + h->up_used, v.data(), bytes);
+    CC_HIP(hipMemcpyAsync(q, h->up_stage + h->up_used, bytes, hipMemcpyHostToDevice, h->stream));
+    h->up_used += padded;
+  } else if (bytes) {
+    CC_HIP(hipMemcpy(q, v.data(), bytes, hipMemcpyHostToDevice));
+  }
   *p = q;
   return 0;
 }
@@ -4974,6 +5000,22 @@ struct RigProbe {  // optional hipEvent bracket around one launch
     if (on) { hipEventRecord(e1, h->stream); h->events.push_back(e0); h->events.push_back(e1); h->event_kind.push_back(kind); h->event_round.push_back(h->enq_round + round_shift); }
   }
 };
+
+// hipFuncAttributeMaxDynamicSharedMemorySize, set once per (device, kernel) and size: a handle's layout asks for ~20 of them, a
+// fresh handle per call (the reference's workflow) would pay ~10 us each every time
+static int lds_attr(int device, const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::vector<std::tuple<int, const void*, int>> seen;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    for (const auto& e : seen) if (std::get<0>(e) == device && std::get<1>(e) == fn && std::get<2>(e) >= bytes) return 0;
+  }
+  CC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  std::lock_guard<std::mutex> lk(mu);
+  for (auto& e : seen) if (std::get<0>(e) == device && std::get<1>(e) == fn) { std::get<2>(e) = std::max(std::get<2>(e), bytes); return 0; }
+  seen.emplace_back(device, fn, bytes);
+  return 0;
+}
 
 // Shared-block layout for the cameras in `seen_any` (observed by at least one rank): which camera owns which
 // columns, the tile grid of the Schur products, the direct-sum table -- and every buffer whose size depends on
@@ -5152,25 +5194,25 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
     h->solve_lds = h->big_packed ? packed : fixed_lds;
     if (!h->big_packed)
       if (int rc = dev_zeroed(h, &h->bigA, (size_t)(S + 2) * ((S + 1) | 1))) return rc;
-    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim_big<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
-    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim_big<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
-    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_solve_big<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
-    CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_solve_big<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
+    if (int rc_ = lds_attr(h->device, reinterpret_cast<const void*>(k_rig_elim_big<false>), (int)h->elim_lds)) return rc_;
+    if (int rc_ = lds_attr(h->device, reinterpret_cast<const void*>(k_rig_elim_big<true>), (int)h->elim_lds)) return rc_;
+    if (int rc_ = lds_attr(h->device, reinterpret_cast<const void*>(k_rig_solve_big<true>), (int)h->solve_lds)) return rc_;
+    if (int rc_ = lds_attr(h->device, reinterpret_cast<const void*>(k_rig_solve_big<false>), (int)h->solve_lds)) return rc_;
     rig_drop_graphs(h);
     return 0;
   }
-  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
-  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<false, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
-  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<false, kRigDirectPerLane, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
-  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
-  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<false, kRigDirectPerLane>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
-  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<true, kRigDirectPerLane>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
-  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<true, 8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
-  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_elim<true, kRigDirectPerLane, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->elim_lds));
-  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_reduce<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
-  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_reduce<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
-  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_solve<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
-  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rig_solve<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
+  if (int rc_ = lds_attr(h->device, reinterpret_cast<const void*>(k_rig_elim<false, 8>), (int)h->elim_lds)) return rc_;
+  if (int rc_ = lds_attr(h->device, reinterpret_cast<const void*>(k_rig_elim<false, 8, true>), (int)h->elim_lds)) return rc_;
+  if (int rc_ = lds_attr(h->device, reinterpret_cast<const void*>(k_rig_elim<false, kRigDirectPerLane, true>), (int)h->elim_lds)) return rc_;
+  if (int rc_ = lds_attr(h->device, reinterpret_cast<const void*>(k_rig_elim<true, 8>), (int)h->elim_lds)) return rc_;
+  if (int rc_ = lds_attr(h->device, reinterpret_cast<const void*>(k_rig_elim<false, kRigDirectPerLane>), (int)h->elim_lds)) return rc_;
+  if (int rc_ = lds_attr(h->device, reinterpret_cast<const void*>(k_rig_elim<true, kRigDirectPerLane>), (int)h->elim_lds)) return rc_;
+  if (int rc_ = lds_attr(h->device, reinterpret_cast<const void*>(k_rig_elim<true, 8, false, true>), (int)h->elim_lds)) return rc_;
+  if (int rc_ = lds_attr(h->device, reinterpret_cast<const void*>(k_rig_elim<true, kRigDirectPerLane, false, true>), (int)h->elim_lds)) return rc_;
+  if (int rc_ = lds_attr(h->device, reinterpret_cast<const void*>(k_rig_reduce<0>), (int)h->solve_lds)) return rc_;
+  if (int rc_ = lds_attr(h->device, reinterpret_cast<const void*>(k_rig_reduce<3>), (int)h->solve_lds)) return rc_;
+  if (int rc_ = lds_attr(h->device, reinterpret_cast<const void*>(k_rig_solve<0>), (int)h->solve_lds)) return rc_;
+  if (int rc_ = lds_attr(h->device, reinterpret_cast<const void*>(k_rig_solve<2>), (int)h->solve_lds)) return rc_;
   // ---- the persistent per-solve form (k_rig_persist_w + k_rig_persist_ctl): poses only, at most four frames per compute
   // unit, every workgroup resident. (Round 3 also kept a GLUED form, k_rig_persist -- the three kernels' bodies in one
   // launch, 444 registers a thread, 81 us per iteration where the three kernels take 47: retired in round 4, no
@@ -5594,6 +5636,18 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   float* uv_s = reinterpret_cast<float*>(st);
   int32_t* widx_s = reinterpret_cast<int32_t*>(st + b_uv);
   if (int rc = stream_get(device, &h->stream)) return rc;
+  struct UpGuard {   // pinned staging of the table uploads (dev_upload): given back once the stream has drained
+    cc_rig* h; void* p = nullptr;
+    ~UpGuard() { if (p) { if (h->stream) (void)hipStreamSynchronize(h->stream); h->up_stage = nullptr; h->up_cap = h->up_used = 0; staging_put(p); } }
+  } upg{h};
+  {
+    // tables: per group 16 B, per frame 4 CO + 128 B, per shared column / direct entry a few words -- 4 MB covers BASELINE configs[4]
+    // several times over; a table that does not fit takes the synchronous copy
+    const size_t cap = (size_t)4 << 20;
+    bool up_cached = false;
+    upg.p = staging_get(cap, &up_cached);
+    if (upg.p) { h->up_stage = static_cast<char*>(upg.p); h->up_cap = cap; h->up_used = 0; }
+  }
   float* duv = nullptr;
   int32_t* dw = nullptr;
   if (int rc = dev_alloc(h, &duv, (size_t)N * 2)) return rc;
@@ -5613,7 +5667,7 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   std::vector<uint8_t> seen((size_t)C, 0);
   {
     // (per-thread tables of C entries: one thread when the camera ids are sparse in a huge range)
-    const int parts = C <= 65536 ? parallel_parts(N, (int64_t)1 << 17) : 1;
+    const int parts = C <= 65536 ? parallel_parts(N, (int64_t)1 << 15) : 1;   // (parts of >= 32 k observations on the worker pool: no thread is created per call, so fine parts are cheap)
     std::vector<int64_t> pf((size_t)parts + 1, 0);
     if (int rc = cc_partition_frames(F, off, parts, pf.data())) return rc;
     using Part = RigRegroupPart;
@@ -6268,7 +6322,7 @@ int cc_rig_get_state(cc_rig* h, double* cam_q, double* cam_t, double* frame_q, d
     CC_HIP(hipMemcpyAsync(sorted, h->d_cost, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     CC_HIP(hipStreamSynchronize(h->stream));
     const int64_t* perm = h->perm.data();
-    parallel_ranges(h->N, (int64_t)1 << 18, [&](int, int64_t a, int64_t b) {
+    parallel_ranges(h->N, (int64_t)1 << 15, [&](int, int64_t a, int64_t b) {
       if (h->perm_inverse) { for (int64_t i = a; i < b; ++i) obs_cost[i] = sorted[perm[i]]; }
       else { for (int64_t i = a; i < b; ++i) obs_cost[perm[i]] = sorted[i]; }
     });
@@ -6397,7 +6451,7 @@ int cc_rig_debug_chol_bench(int32_t S, int32_t reps, int32_t which, double* out)
   CC_HIP(hipMalloc(&dout, 64));
   CC_HIP(hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice));
   const size_t lds = ((size_t)(S + 1) * LD + 5 * 128) * 8;
-  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_bench), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (int rc_ = lds_attr(h->device, reinterpret_cast<const void*>(k_chol_bench), (int)lds)) return rc_;
   hipLaunchKernelGGL(k_chol_bench, dim3(1), dim3(256), lds, 0, dA, S, reps, which, dout);
   CC_HIP(hipDeviceSynchronize());
   CC_HIP(hipMemcpy(out, dout, 24, hipMemcpyDeviceToHost));
@@ -6495,7 +6549,7 @@ int cc_rig_optimize_frames(const cc_options* opt, int32_t device, int64_t C, int
       if (!sorted) return fail(CC_ERR_HIP, "cc_rig_optimize_frames: pinned staging memory could not be allocated");
       struct StGuard { void* p; hipStream_t s; ~StGuard() { (void)hipStreamSynchronize(s); staging_put(p); } } stg{sorted, h->stream};
       const int64_t* perm = h->perm.data();
-      const int parts = parallel_parts(h->N, (int64_t)1 << 17);
+      const int parts = parallel_parts(h->N, (int64_t)1 << 15);
       std::vector<int64_t> pf((size_t)parts + 1, 0);
       if (int r2 = cc_partition_frames(F, off.data(), parts, pf.data())) return r2;
       // one transfer and one event per thread's range of frames: a thread writes its range into the records as soon as it has

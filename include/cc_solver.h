@@ -115,9 +115,11 @@ void cc_host_staging_release(void* p);
 void cc_last_call_timing(double out_ms[5]);
 const char* cc_version(void);
 /* The library keeps a few things between calls so that a caller that re-estimates as images arrive (the reference's workflow
- * builds a fresh solver per call: cam_calibration.py:290-322) does not pay for allocation every time: the device arena /
- * pooled device blocks of the last handles (at most 8 GB per device), one pinned host staging block, streams. This gives the
- * memory back (idle pieces only; safe at any time, the next call allocates again). */
+ * builds a fresh solver per call: cam_calibration.py:290-322) does not pay for allocation every time. What is retained, at most:
+ * per device four arena pieces (the device memory of a solver handle, each <= 1.25 GB) and pooled device blocks up to 8 GB, one
+ * 64 MB scratch block; per process four pinned host staging pieces (each <= 1.25 GB), a few 512-byte pinned blocks, streams, the
+ * host worker threads (cc_parallel_for) and the regrouping arrays of the last rig call. This gives the idle ones back (safe at
+ * any time from any thread; pieces in use by a running call stay; the next call allocates / starts them again). */
 void cc_release_caches(void);
 /* Solver form and reruns of this thread's LAST one-shot call (cc_intrinsics_estimate / _optimize / _views / _multi,
  * cc_rig_optimize / _frames / _multi): these calls destroy their handles before returning, so cc_*_solver_status cannot be asked.
