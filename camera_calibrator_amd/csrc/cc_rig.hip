@@ -79,6 +79,9 @@ struct RigDev {
   const int4* fwave;      // [F][8] (frames of at most eight groups: k_rig_sweep_frame<.., true>) group j of frame f in ONE
                           // 16-byte record {first observation (lo, hi), observations, camera}: the wave that sweeps it reads this
                           // and nothing else before its observations (fgoff -> goff / gcam -> observations was three loads deep)
+  const int4* gk2;        // [NG][2] (with intrinsics) everything k_rig_sweep_k2 needs to know about a group in ONE 32-byte record:
+                          // {first observation lo, hi, observations, frame} {camera, intrinsics set, camera held constant, 0} -- the
+                          // chain group -> camera -> intrinsics set was three dependent scalar loads deep before the first record load
   const int32_t* cam_goff;   // [C+1]
   const int32_t* cam_glist;  // [NG] groups of each camera
   const uint8_t* cam_fixed;  // [C] pose held constant (frozen, or unobserved by every rank)
@@ -1278,13 +1281,12 @@ __global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P)
   struct ObsRaw { float2 m; F3 X; };
   struct ObsD { double u, v, X0, X1, X2; };
   auto widen = [](const ObsRaw& r, ObsD& d) { d.u = (double)r.m.x; d.v = (double)r.m.y; d.X0 = (double)r.X.x; d.X1 = (double)r.X.y; d.X2 = (double)r.X.z; };
-  auto group_indices = [&](int64_t g, K2Group& q) {   // scalar loads: first round trip (group), second (its camera's flags)
+  auto group_indices = [&](int64_t g, K2Group& q) {   // ONE round trip: the group's record (then the mask of its intrinsics set)
     const int64_t gc = g < NG ? g : 0;
-    q.f = P.gframe[gc]; q.c = P.gcam[gc];
-    q.s0 = P.goff[gc];
-    q.n = (int)(P.goff[gc + 1] - q.s0);
-    q.fixed = P.cam_fixed[q.c];
-    q.ks = P.kset[q.c];
+    const int4 a = P.gk2[2 * gc], b = P.gk2[2 * gc + 1];
+    q.s0 = (int64_t)(((unsigned long long)(unsigned)a.y << 32) | (unsigned)a.x);
+    q.n = a.z; q.f = a.w;
+    q.c = b.x; q.ks = b.y; q.fixed = b.z;
     q.kmask = P.kmask[q.ks];
   };
   // vector loads of a group: the lane's first observation, one value of the three records, two of the group's old record
@@ -1514,16 +1516,20 @@ __global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P)
         for (int k = 0; k < 6; ++k) t = fma(s_m[k * 6 + a], G(k, 6), t);
       }
       s_T[tid_t] = t;
-    }
-    lds_barrier();
-    if (tid_t < 21) {   // share of the frame block: (M^T T)[i][j], i >= j
+    } else if (tid_t < 117) {   // share of the frame block, (M^T G_cc M)[i][j], i >= j -- in the same phase, straight from G (no T: no second barrier)
+      const int e = tid_t - 96;
       int i = 0;
-      while ((i + 1) * (i + 2) / 2 <= tid_t) ++i;
-      const int j = tid_t - i * (i + 1) / 2;
+      while ((i + 1) * (i + 2) / 2 <= e) ++i;
+      const int j = e - i * (i + 1) / 2;
       double t = 0.0;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) t = fma(s_m[k * 6 + i], s_T[k * 6 + j], t);
-      s_T[96 + tid_t] = t;
+      for (int k = 0; k < 6; ++k) {
+        double u = 0.0;
+#pragma unroll
+        for (int l = 0; l < 6; ++l) u = fma(G(k, l), s_m[l * 6 + j], u);
+        t = fma(s_m[k * 6 + i], u, t);
+      }
+      s_T[tid_t] = t;
     }
     lds_barrier();
     double* rec = P.gcomp + ((size_t)dst * NG + g) * kRigRecK;
@@ -4907,6 +4913,7 @@ struct cc_rig {
   std::vector<uint8_t> seen_any;           // cameras observed by any rank (what the column layout is built for)
   std::vector<int32_t> gframe_h, gcam_h;   // host copies of the group tables (layout rebuilds)
   std::vector<int64_t> fgoff_h;
+  std::vector<int64_t> goff_h;             // [NG + 1] observation range of each group
   size_t elim_lds = 0, solve_lds = 0;
   bool big = false;             // 128 <= S <= 255: the plain kernels (k_rig_elim_big, k_rig_solve_big), no exchange
   bool persist_lean_allowed = true;   // CC_RIG_PERSIST=0: three kernels per iteration always
@@ -5073,7 +5080,17 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
              !(getenv("CC_RIG_FORCE_BIG") && atoi(getenv("CC_RIG_FORCE_BIG")) != 0)) ? 1 : 0;
   // with intrinsics: compact records + the FMA sweep (k_rig_sweep_k2) feed the tuned elimination; the plain large-rig kernels
   // read the three tiles of k_rig_sweep_adjk. CC_RIG_K_COMPACT=0 keeps the tile form for A/B and the record-against-tile test.
-  d.kcm = (kmode && !h->big && !(getenv("CC_RIG_K_COMPACT") && atoi(getenv("CC_RIG_K_COMPACT")) == 0)) ? 1 : 0;
+  // Which one: k_rig_sweep_k2 pays ~6 us per group beyond its passes (two dependent round trips in front, lane sums of 66 + 66
+  // accumulators and the assembly behind) against ~2 us per 128 observations in them, k_rig_sweep_adjk runs at 91 % of the fp64
+  // pipe whatever the group size (profiles/r05/pmc_rigk_c5_*.csv). Measured at 8 M observations, sweep alone, k2 / tiles:
+  // 250 per group 297 / 232 us, 500: 201-213 / 208, 1000: 165 / 197, 2000: 148 / 200, 4000: 140 / 209
+  // (profiles/r05/rigk_sweep_vs_group_size.txt) -- compact records from ~450 observations per group on. CC_RIG_K_COMPACT=1 / 0 forces.
+  {
+    const double per_group = h->NG > 0 ? (double)h->N / (double)h->NG : 0.0;
+    bool on = per_group >= 448.0;
+    if (const char* e = getenv("CC_RIG_K_COMPACT")) on = atoi(e) != 0;
+    d.kcm = (kmode && !h->big && on) ? 1 : 0;
+  }
   if (d.kcm) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus < 1) { (void)hipGetLastError(); cus = 256; }
@@ -5178,6 +5195,17 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
   if (int rc = dev_upload(h, &d.dir_sb, dir_sb)) return rc;
   if (int rc = dev_upload(h, &d.tile_dst, tile_dst)) return rc;
   if (int rc = dev_upload(h, &d.colpin, colpin)) return rc;
+  if (kmode) {   // group records of k_rig_sweep_k2 (a camera held constant depends on who observes it: rebuilt with every layout)
+    std::vector<int4> gk((size_t)h->NG * 2);
+    for (int64_t g = 0; g < h->NG; ++g) {
+      const int64_t s0 = h->goff_h[(size_t)g];
+      const int c = h->gcam_h[(size_t)g];
+      gk[(size_t)2 * g] = int4{(int)(unsigned)((unsigned long long)s0 & 0xffffffffull), (int)(unsigned)((unsigned long long)s0 >> 32),
+                               (int)(h->goff_h[(size_t)g + 1] - s0), h->gframe_h[(size_t)g]};
+      gk[(size_t)2 * g + 1] = int4{c, kset[(size_t)c], fixed[(size_t)c] ? 1 : 0, 0};
+    }
+    if (int rc = dev_upload(h, &d.gk2, gk)) return rc;
+  }
   if (!h->d_cam_fixed) { if (int rc = dev_alloc(h, &h->d_cam_fixed, (size_t)C)) return rc; d.cam_fixed = h->d_cam_fixed; }
   CC_HIP(hipMemcpy(h->d_cam_fixed, fixed.data(), fixed.size(), hipMemcpyHostToDevice));
   if (int rc = dev_zeroed(h, &d.Y, (size_t)F * 6 * d.SW)) return rc;
@@ -5660,7 +5688,8 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
     return hipMemcpyAsync(duv + 2 * a, uv_s + 2 * a, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, h->stream) == hipSuccess &&
            hipMemcpyAsync(dw + a, widx_s + a, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream) == hipSuccess;
   };
-  std::vector<int64_t> goff{0};
+  std::vector<int64_t>& goff = h->goff_h;
+  goff.assign(1, 0);
   h->fgoff_h.assign((size_t)F + 1, 0);
   std::vector<int32_t>& gframe = h->gframe_h;
   std::vector<int32_t>& gcam = h->gcam_h;

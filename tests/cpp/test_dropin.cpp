@@ -170,6 +170,7 @@ static void rig() {
   calib = loaded;
   calib.Optimize();
   CHECK(calib.LastStatus() == 0);
+  CHECK(calib.LastSolverReruns() == 0 && calib.LastSolverNote().empty());
   CHECK(translation_error(calib.GetCameraTRig(0), cams_true[0]) == 0.f);   // frozen camera untouched
   const float before = translation_error(cams_start[1], cams_true[1]);
   const float after = translation_error(calib.GetCameraTRig(1), cams_true[1]);

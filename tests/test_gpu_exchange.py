@@ -172,10 +172,13 @@ def test_sharded_rig_where_one_shard_does_not_observe_a_camera(cams, force_big, 
             assert max(dev.values()) < 1e-11, dev
 
 
+@pytest.mark.parametrize("compact", [0, 1])
 @pytest.mark.parametrize("world,cams,frames,pts", [(2, 3, 30, 20), (3, 6, 45, 12)])
-def test_sharded_rig_with_intrinsics_over_the_mailbox_exchange(world, cams, frames, pts, tmp_path):
-    """The extension (cc_rigk_*) sharded over ranks: intrinsics replicated, bit-identical on every rank."""
+def test_sharded_rig_with_intrinsics_over_the_mailbox_exchange(world, cams, frames, pts, compact, tmp_path, monkeypatch):
+    """The extension (cc_rigk_*) sharded over ranks: intrinsics replicated, bit-identical on every rank -- under either sweep
+    (compact records of k_rig_sweep_k2, the default from ~450 observations per group on; tiles of k_rig_sweep_adjk)."""
     from tests.helpers import rigk_case
+    monkeypatch.setenv("CC_RIG_K_COMPACT", str(compact))   # (inherited by the rank processes; the one-GPU reference below reads it too)
     ranks = _run_ranks(world, frames, pts, tmp_path, extra=(f"rigk:{cams}",))
     k = rigk_case(cams, frames, pts)
     prob = capi.RigProblem(cams, k["frame_offsets"], k["obs_cam"], k["obs_world"], k["obs_uv_pix"], k["world_xyz"], k["cam_frozen"],

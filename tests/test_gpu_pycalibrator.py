@@ -32,6 +32,7 @@ def test_calibration_estimation_works():
             else:
                 assert new_K[i, j] == 0
     assert c.LastStatus() == 0 and c.LastIterations() > 0
+    assert c.LastSolverReruns() == 0 and c.LastSolverNote() == ""   # (the solve ran in its usual form: nothing to report)
     # same pipeline through the oracle: float32 outputs equal within 1 ulp... of the LM minimiser;
     # the two Zhang initialisations differ in the last float bits, so compare at 1e-5 relative
     K0, q0, t0 = po.zhang_init(off, uv, xyz)
@@ -112,3 +113,4 @@ def test_simple_extrinsics_like_the_reference_test(tmp_path, capfd):
     cam, idx, wpid, uv, cost = e.GetObservation(3, 5)
     assert np.isclose(cost, r[4][sc["frame_offsets"][3] + 5], rtol=1e-6, atol=1e-15)
     assert e.LastIterations() == r[5]["iterations"]
+    assert e.LastSolverReruns() == 0 and e.LastSolverNote() == ""

@@ -461,6 +461,13 @@ def test_lean_persistent_solve_that_cannot_get_its_grid_is_rerun_in_the_three_ke
             "assert (form, reruns) == (0, 2) and 'stays on that form' in note, (form, reruns, note)\n"
             "assert s1['iterations'] == s['iterations'] and s1['final_cost'] == s['final_cost']\n"
             "s2 = p.solve(); assert s2['iterations'] <= 2 and p.solver_status()[1] == 2\n"
+            # round 5 (ADVICE): a ONE-SHOT call destroys its handle before it returns -- its caller asks cc_last_call_solver_status
+            "import ctypes as C\n"
+            "r = capi.rig_optimize(*args, cq, ct, sc['cam_frozen'], fq, ft)\n"
+            "form, reruns, note = C.c_int32(-1), C.c_int32(-1), C.create_string_buffer(640)\n"
+            "assert capi.lib().cc_last_call_solver_status(C.byref(form), C.byref(reruns), note, 640) == 0\n"
+            "assert reruns.value == 1 and b'NEVER RAN' in note.value and b'three kernels' in note.value, (form.value, reruns.value, note.value)\n"
+            "assert r[5]['iterations'] == s['iterations'] and all(np.abs(r[k] - g[k]).max() < 1e-11 for k in range(4))\n"
             "print('rerun ok', dt)\n") % root
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CC_RIG_PERSIST_TEST_NO_CONTROL="1"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "rerun ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
