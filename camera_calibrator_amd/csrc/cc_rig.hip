@@ -1459,6 +1459,26 @@ __global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P)
       K2_T(4);
     };
     // one register set, observations one pass ahead (two sets -- the pair of passes unrolled -- spill: 607 us against 209 at 8 x 2000 x 500)
+#ifdef CC_RIG_K2_TWO_AHEAD   // (A/B: two register sets, observations two passes ahead, the pair of passes unrolled)
+    ObsRaw ob;
+    fetch(tid + 128, ob);
+    int p = 0;
+    for (; p + 1 < npass; p += 2) {
+      const int k = p * 128 + tid;
+      ObsD d;
+      widen(oa, d);
+      fetch(k + 256, oa);
+      pass(k, d);
+      widen(ob, d);
+      fetch(k + 384, ob);
+      pass(k + 128, d);
+    }
+    if (p < npass) {
+      ObsD d;
+      widen(oa, d);
+      pass(p * 128 + tid, d);
+    }
+#else
     for (int p = 0; p < npass; ++p) {
       const int k = p * 128 + tid;
       ObsD d;
@@ -1466,6 +1486,7 @@ __global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P)
       fetch(k + 128, oa);
       pass(k, d);
     }
+#endif
     // ---- the NEXT group's loads go out now: they travel under this group's lane sums and assembly
     if (more) group_loads(g + stride, qn, oa, recv, old0, old1);
     // ---- sums over the lanes: 64 accumulators by the butterfly (value s ends in lane s), the others and the scalars by wave_sum
