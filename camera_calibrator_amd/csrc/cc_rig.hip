@@ -1187,7 +1187,6 @@ constexpr K2Split k2_make_split() {
 }
 constexpr K2Split kK2 = k2_make_split();
 static_assert(kK2.n[0] <= 68 && kK2.n[1] <= 68 && kK2.n[0] + kK2.n[1] == 132, "pairs per wave");
-__device__ const K2Split kK2Dev = k2_make_split();   // (the same tables where a lane indexes them at run time)
 constexpr int kK2Acc = 68;
 
 // the products of ONE row (ROW 0: u, 1: v) that wave W accumulates
@@ -1215,31 +1214,55 @@ __device__ __forceinline__ void reduce_scatter64(double* p, int lane) {
   reduce_dpp<2, 0x4E, 2>(p, lane);    // quad_perm:[2,3,0,1]
   reduce_dpp<1, 0xB1, 1>(p, lane);    // quad_perm:[1,0,3,2]
 }
-// weight of entry e of a group's OLD record in the model-cost term q = g^T d + 1/2 d^T H d of the step d = (dc, df, dk);
-// the steps are read where the records lie in LDS (sm: camera [12..17], frame [44..49], intrinsics [80..88]) -- indexed by a
-// lane-dependent entry, register arrays become chains of selects (300 instructions per group)
-__device__ __forceinline__ double k2_qcoef(int e, const double* sm, double cam_on) {
-  auto tri_ij = [](int idx, int& i, int& j) { i = 0; while ((i + 1) * (i + 2) / 2 <= idx) ++i; j = idx - i * (i + 1) / 2; };
-  // entry -> (kind of first factor, index, kind of second factor, index, weight); kinds: 0 one, 1 dc, 2 df, 3 dk
-  int ka = 0, ia = 0, kb = 0, ib = 0;
-  double wgt = 1.0;
-  int i, j;
-  if (e < 21) { tri_ij(e, i, j); ka = 1; ia = i; kb = 1; ib = j; wgt = i == j ? 0.5 : 1.0; }
+// Weight of entry e of a group's OLD record in the model-cost term q = g^T d + 1/2 d^T H d of the step d = (dc, df, dk): a product
+// of (at most) two step components and 1/2 or 1. The steps lie where the records lie in LDS (sm: camera [12..17], frame
+// [44..49], intrinsics [80..88]); WHICH two, per entry, is a compile-time table (one word per entry: index of the first factor
+// | index of the second << 8 | flags << 16; index 255 = the constant one; flag 1 / 2: the first / second factor is a camera
+// component and vanishes for a camera held constant; flag 4: weight 1/2; flag 8: weight 0). Computed by index arithmetic per
+// thread and group (division by 6 and 9, two triangular-index searches) it was 2.5 k cycles of a group's 27 k.
+constexpr unsigned k2_qdesc(int e) {
+  int ka = 0, ia = 0, kb = 0, ib = 0, half = 0, zero = 0;
+  auto tri_i = [](int idx) { int i = 0; while ((i + 1) * (i + 2) / 2 <= idx) ++i; return i; };
+  if (e < 21) { const int i = tri_i(e), j = e - i * (i + 1) / 2; ka = 1; ia = i; kb = 1; ib = j; half = i == j; }
   else if (e < 27) { ka = 1; ia = e - 21; }
-  else if (e < 81) { i = (e - 27) / 9; j = (e - 27) - 9 * i; ka = 1; ia = i; kb = 3; ib = j; }
-  else if (e < 126) { tri_ij(e - 81, i, j); ka = 3; ia = i; kb = 3; ib = j; wgt = i == j ? 0.5 : 1.0; }
+  else if (e < 81) { const int i = (e - 27) / 9, j = (e - 27) - 9 * i; ka = 1; ia = i; kb = 3; ib = j; }
+  else if (e < 126) { const int i = tri_i(e - 81), j = (e - 81) - i * (i + 1) / 2; ka = 3; ia = i; kb = 3; ib = j; half = i == j; }
   else if (e < 135) { ka = 3; ia = e - 126; }
-  else if (e < kRkT) { wgt = 0.0; }
-  else if (e < kRkFK) { i = (e - kRkT) / 6; j = (e - kRkT) - 6 * i; ka = 1; ia = i; kb = 2; ib = j; }
-  else if (e < kRkHff) { i = (e - kRkFK) / 9; j = (e - kRkFK) - 9 * i; ka = 2; ia = i; kb = 3; ib = j; }
-  else if (e < kRkGf) { tri_ij(e - kRkHff, i, j); ka = 2; ia = i; kb = 2; ib = j; wgt = i == j ? 0.5 : 1.0; }
+  else if (e < kRkT) { zero = 1; }
+  else if (e < kRkFK) { const int i = (e - kRkT) / 6, j = (e - kRkT) - 6 * i; ka = 1; ia = i; kb = 2; ib = j; }
+  else if (e < kRkHff) { const int i = (e - kRkFK) / 9, j = (e - kRkFK) - 9 * i; ka = 2; ia = i; kb = 3; ib = j; }
+  else if (e < kRkGf) { const int i = tri_i(e - kRkHff), j = (e - kRkHff) - i * (i + 1) / 2; ka = 2; ia = i; kb = 2; ib = j; half = i == j; }
   else if (e < kRkEnd) { ka = 2; ia = e - kRkGf; }
-  else wgt = 0.0;
-  auto factor = [&](int k, int idx) {
-    const double v = sm[(k == 1 ? 12 : (k == 2 ? 44 : 80)) + idx];   // (k == 0: reads sm[80 + 0], discarded)
-    return k == 0 ? 1.0 : (k == 1 ? v * cam_on : v);
-  };
-  return wgt * factor(ka, ia) * factor(kb, ib);
+  else zero = 1;
+  const unsigned xa = ka == 0 ? 255u : (unsigned)((ka == 1 ? 12 : (ka == 2 ? 44 : 80)) + ia);
+  const unsigned xb = kb == 0 ? 255u : (unsigned)((kb == 1 ? 12 : (kb == 2 ? 44 : 80)) + ib);
+  return xa | (xb << 8) | ((unsigned)((ka == 1 ? 1 : 0) | (kb == 1 ? 2 : 0) | (half ? 4 : 0) | (zero ? 8 : 0)) << 16);
+}
+// The tables a LANE indexes at run time, as one array of words that a workgroup copies into LDS once, under its first round
+// trip (read from device memory where they are needed -- behind the lane sums, in the record assembly -- each was a memory
+// round trip on the tail's chain): [0..255] k2_qdesc, [256..287] inv (bytes), [288..321] dir (bytes), [322..323] extra (bytes).
+constexpr int kK2TabWords = 324;
+struct K2Tab { unsigned w[kK2TabWords]; };
+constexpr K2Tab k2_make_tab() {
+  K2Tab t{};
+  for (int e = 0; e < 256; ++e) t.w[e] = k2_qdesc(e);
+  const K2Split s = k2_make_split();
+  for (int i = 0; i < 128; ++i) t.w[256 + i / 4] |= (unsigned)s.inv[i / 64][i % 64] << (8 * (i % 4));
+  for (int i = 0; i < 136; ++i) t.w[288 + i / 4] |= (unsigned)s.dir[i] << (8 * (i % 4));
+  for (int i = 0; i < 8; ++i) t.w[322 + i / 4] |= (unsigned)s.extra[i / 4][i % 4] << (8 * (i % 4));
+  return t;
+}
+__device__ const K2Tab kK2Tab = k2_make_tab();
+__device__ __forceinline__ int k2_tab_byte(const unsigned* tab, int word0, int i) { return (int)((tab[word0 + (i >> 2)] >> (8 * (i & 3))) & 255u); }
+__device__ __forceinline__ double k2_qcoef(const unsigned* tab, int e, const double* sm, double cam_on) {
+  const unsigned d = tab[e];
+  const int xa = (int)(d & 255u), xb = (int)((d >> 8) & 255u);
+  const unsigned fl = d >> 16;
+  double fa = sm[xa == 255 ? 0 : xa], fb = sm[xb == 255 ? 0 : xb];
+  fa = xa == 255 ? 1.0 : ((fl & 1u) ? fa * cam_on : fa);
+  fb = xb == 255 ? 1.0 : ((fl & 2u) ? fb * cam_on : fb);
+  const double w = (fl & 8u) ? 0.0 : ((fl & 4u) ? 0.5 : 1.0);
+  return w * fa * fb;
 }
 
 #ifndef CC_RIG_K2_WAVES
@@ -1261,15 +1284,24 @@ __global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P)
   __shared__ double s_G[144];      // lower triangle of G by pair, [136] cost of wave 0, [137] of wave 1, [138..139] model-cost sums
   __shared__ double s_m[36];       // M
   __shared__ double s_T[128];      // T (36) | H_fk (54) | g_f share (6) | H_ff share (21)
+  __shared__ long long s_next;     // persistent grid: the group this workgroup sweeps next
+  __shared__ unsigned s_tab[kK2TabWords];   // the lane-indexed tables (kK2Tab), staged once
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const LmCtl* ctl = P.ctl;
   const int done = ctl->done, phase = ctl->phase, step_valid = ctl->step_valid, cur = ctl->cur;
   if (done) return;
   if (phase != 0 && !step_valid) return;
   const int dst = phase == 0 ? cur : (cur ^ 1);
+  {   // (the first group's loop-top barrier is in front of every read of the tables)
+    const unsigned t0 = kK2Tab.w[tid], t1 = kK2Tab.w[tid + 128], t2 = kK2Tab.w[tid + 256 < kK2TabWords ? tid + 256 : 0];
+    s_tab[tid] = t0; s_tab[tid + 128] = t1;
+    if (tid + 256 < kK2TabWords) s_tab[tid + 256] = t2;
+  }
   const int64_t NG = P.NG, stride = gridDim.x;
+  const bool dynamic = stride < NG;   // (uniform) arrive[14] work counter, arrive[15] workgroups that have left: zeroed at the start of a solve
+                                      // and by the last workgroup of every launch to leave (every fetch of the launch is over by then)
 #ifdef CC_RIG_K2_TIMING   // (timing-only build: shader-clock cycles per phase, summed over the groups and passes of wave 0 of the middle workgroup -> shared_stats[40..])
-  long long k2t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long k2t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long k2last = clock64();
   const long long k2wall0 = wall_clock64();
   int k2groups = 0;
@@ -1321,10 +1353,19 @@ __global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P)
     int tid_h = threadIdx.x;
     asm volatile("" : "+v"(tid_h));
     if (tid_h < 96) sm[tid_h] = recv;
+    // persistent grid (fewer workgroups than groups): the next group comes from a counter, so that a workgroup that was handed
+    // cheap groups takes more of them (static strides ended 8 us behind one workgroup per group)
+    if (dynamic && tid_h == 0) s_next = (long long)stride + (long long)__hip_atomic_fetch_add(P.arrive + 14, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    lds_barrier();   // (LDS only: __syncthreads() would also wait for the previous group's record STORES, a memory round trip per group in a persistent grid)
+    K2_T(8);
+    int64_t gn = g + stride;
+    if (dynamic) {
+      const long long v = s_next;
+      gn = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+    }
     K2Group qn = q;
-    const bool more = g + stride < NG;   // (uniform)
-    if (more) group_indices(g + stride, qn);
-    __syncthreads();
+    const bool more = gn < NG;   // (uniform)
+    if (more) group_indices(gn, qn);
     const int n = q.n, npass = (n + 127) >> 7;      // (the same for both waves: they meet at two barriers per pass)
     const bool fixed = q.fixed != 0;
     const uint32_t kmask = q.kmask;
@@ -1346,6 +1387,7 @@ __global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P)
     }
 #pragma unroll
     for (int i = 0; i < 9; ++i) kk[i] = rfl(sm[64 + i]);
+    K2_T(9);
     if (tid_h < 48) {   // M[a][b], a = tid >> 3, b = tid & 7 < 6 (see k_rig_sweep_adj)
       const int a = tid_h >> 3, b = tid_h & 7;
       const int a3 = a < 3 ? a : a - 3, b3 = b < 3 ? b : b - 3;
@@ -1355,9 +1397,10 @@ __global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P)
       const double v = (a < 3) == (b < 3) ? diag : (a >= 3 ? cross : 0.0);
       if (b < 6) s_m[a * 6 + b] = v;
     }
+    K2_T(10);
     // model-cost term of the step at the accepted point, from the group's old record (two entries per thread)
     double qterm = 0.0;
-    if (phase != 0) qterm = k2_qcoef(tid_h, sm, fixed ? 0.0 : 1.0) * old0 + k2_qcoef(tid_h + 128, sm, fixed ? 0.0 : 1.0) * old1;
+    if (phase != 0) qterm = k2_qcoef(s_tab, tid_h, sm, fixed ? 0.0 : 1.0) * old0 + k2_qcoef(s_tab, tid_h + 128, sm, fixed ? 0.0 : 1.0) * old1;
     K2_T(0);
     double acc[kK2Acc];
 #pragma unroll
@@ -1479,6 +1522,9 @@ __global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P)
       pass(p * 128 + tid, d);
     }
 #else
+    // (measured and dropped: one word of the observations two passes ahead, loaded and thrown away so that the real prefetch finds
+    // its lines in L2 -- 210.7 us against 207.9 at 8 x 2000 x 500: the ~0.7 k cycles a pass waits for its observations are not
+    // cache misses of the prefetch)
     for (int p = 0; p < npass; ++p) {
       const int k = p * 128 + tid;
       ObsD d;
@@ -1488,14 +1534,14 @@ __global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P)
     }
 #endif
     // ---- the NEXT group's loads go out now: they travel under this group's lane sums and assembly
-    if (more) group_loads(g + stride, qn, oa, recv, old0, old1);
+    if (more) group_loads(gn, qn, oa, recv, old0, old1);
     // ---- sums over the lanes: 64 accumulators by the butterfly (value s ends in lane s), the others and the scalars by wave_sum
     int tid_t = threadIdx.x;
     asm volatile("" : "+v"(tid_t));
     const int lane_t = tid_t & 63;
     reduce_scatter64(acc, lane_t);
     {
-      const int pr = kK2Dev.inv[W][lane_t];
+      const int pr = k2_tab_byte(s_tab, 256, W * 64 + lane_t);
       if (pr != 255) s_G[pr] = acc[0];
     }
     {
@@ -1511,7 +1557,7 @@ __global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P)
       t += dpp_f64<0xB1>(t);                 // quad_perm:[1,0,3,2]
       const int e8 = ((lane_t >> 5) & 1) * 4 + ((lane_t >> 4) & 1) * 2 + ((lane_t >> 3) & 1);
       if ((lane_t & 7) == 0) {
-        if (e8 < 4) { const int pr = kK2Dev.extra[W][e8]; if (pr != 255) s_G[pr] = t; }
+        if (e8 < 4) { const int pr = k2_tab_byte(s_tab, 322, W * 4 + e8); if (pr != 255) s_G[pr] = t; }
         else if (e8 == 4) s_G[136 + W] = t;
         else if (e8 == 5) s_G[138 + W] = t;
       }
@@ -1558,7 +1604,7 @@ __global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P)
     for (int h = 0; h < 2; ++h) {
       const int e = tid_t + 128 * h;
       double v = 0.0;
-      if (e <= kRkR2) v = s_G[kK2Dev.dir[e]];
+      if (e <= kRkR2) v = s_G[k2_tab_byte(s_tab, 288, e)];
       else if (e < kRkHff) v = s_T[e - kRkT];
       else if (e < kRkGf) v = s_T[96 + (e - kRkHff)];
       else if (e < kRkEnd) v = s_T[90 + (e - kRkGf)];
@@ -1576,16 +1622,24 @@ __global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P)
 #ifdef CC_RIG_K2_TIMING
     ++k2groups;
 #endif
-    g += stride;
+    g = gn;
     q = qn;
     // (the next group's first barrier -- behind its store of the records into sm -- separates this group's last reads of s_G, s_T
     // and s_m from the writes that follow)
+  }
+  if (dynamic && tid == 0) {
+    const unsigned left = __hip_atomic_fetch_add(P.arrive + 15, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (left == (unsigned)stride - 1u) {
+      __hip_atomic_store(P.arrive + 14, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(P.arrive + 15, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 #ifdef CC_RIG_K2_TIMING
   if (blockIdx.x == gridDim.x / 2 && tid == 0) {
     for (int qq = 0; qq < 8; ++qq) P.shared_stats[40 + qq] = (double)k2t[qq];
     P.shared_stats[48] = (double)(wall_clock64() - k2wall0);
     P.shared_stats[49] = (double)k2groups;
+    for (int qq = 8; qq < 12; ++qq) P.shared_stats[42 + qq] = (double)k2t[qq];   // [50..53]: head of a group in pieces
   }
 #endif
   };

@@ -24,12 +24,14 @@ for _ in range(5):
     prob.solve(capi.default_options(max_iterations=3), log_capacity=0)
     buf = np.zeros(64)
     capi._check(capi.lib().cc_rig_debug_fetch(prob._h, b"shared_stats", buf.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(64)))
-    rows.append(buf[40:50].copy())
+    rows.append(buf[40:54].copy())
 prob.close()
 r = np.median(np.array(rows), axis=0)
-names = ["prologue (records, M, model-cost term)", "evaluation + own rows (summed over passes)", "first barrier", "partner rows + accumulation",
+head_names = ["loads + records into LDS + barrier", "pose chain and intrinsics into scalar registers", "adjoint M", "model-cost weights + accumulators zeroed (= the rest of the head)"]
+names = ["head: model-cost weights + accumulators zeroed", "evaluation + own rows (summed over passes)", "first barrier", "partner rows + accumulation",
          "second barrier + loop control", "wait for the pass's observations", "lane sums", "assembly + record store"]
 wall_us = r[8] / 100.0
 cyc = r[:8].sum()
-print(json.dumps({"kernel": "k_rig_sweep_k2, wave 0 of the middle workgroup", "cams": Cc, "frames": F, "pts": M, "passes": int(r[9]), "wall_us": round(float(wall_us), 2),
-                  "shader_clock_mhz": round(float(cyc / max(wall_us, 1e-9)), 1), "cycles": {n: int(v) for n, v in zip(names, r[:8])}}))
+print(json.dumps({"kernel": "k_rig_sweep_k2, wave 0 of the middle workgroup", "cams": Cc, "frames": F, "pts": M, "wall_us": round(float(wall_us), 2),
+                  "shader_clock_mhz": round(float(cyc / max(wall_us, 1e-9)), 1), "groups_of_this_workgroup": int(r[9]), "cycles": {n: int(v) for n, v in zip(names, r[:8])},
+                  "head_cycles": {n: int(v) for n, v in zip(head_names[:3], r[10:13])}}))
