@@ -599,7 +599,7 @@ __global__ __launch_bounds__(NW * 64, NW == 1 ? CC_RIG_ADJ_WAVES : 3) void k_rig
 // Arithmetic of a row and of G7: k_rig_sweep_adj's, instruction for instruction (same sums in the same order per lane, same
 // butterfly). LDS (dynamic): per group slot 32 doubles (G7, cost), staging 64 per group of an assembly pass, small scratch.
 // ---------------------------------------------------------------------------------------------
-constexpr int kRigFrameLdsDoubles(int CO) { return CO * 32 + 8 * 64 + 64; }
+constexpr int kRigFrameLdsDoubles(int CO) { return CO * 32 + 8 * 64 + 64 + CO * 16; }
 // ONE: every wave sweeps at most ONE group (a frame has no more groups than the workgroup has waves: rigs of up to eight
 // observed cameras) -- no loop over groups, and the kernel fits the 128 registers of four waves per SIMD like k_rig_sweep_adj<1>
 // does; with the loop (more groups than waves) the passes spill 12 - 19 registers at 128, so that variant is compiled for
@@ -610,6 +610,9 @@ __global__ __launch_bounds__(NWF * 64, ONE ? 4 : (NWF <= 4 ? 3 : 2)) void k_rig_
   double* s_G = sf_lds;                     // [CO][32]  G7 (28), cost (28) of every group of the frame
   double* s_rec = s_G + (size_t)P.CO * 32;  // [8][64]   records of an assembly pass, staged for one coalesced store
   double* s_fr = s_rec + 8 * 64;            // [64]      frame record of the evaluated point (32), then scratch
+  double* s_cam = s_fr + 64;                // [CO][16]  per group: its camera's rotation (9), unscaled step (6), held-constant flag -- left here by the
+                                            //           wave that sweeps the group, at its START, for the assembly at the workgroup's end (round 5: the
+                                            //           assembly fetched them itself, group -> camera -> record, two dependent round trips on the tail)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t f = blockIdx.x;
   const double* fr = P.frec + (size_t)f * 32;
@@ -669,6 +672,10 @@ __global__ __launch_bounds__(NWF * 64, ONE ? 4 : (NWF <= 4 ? 3 : 2)) void k_rig_
       r.m = uvg[kc];
       r.X = xg[kc];
     };
+    if (lane < 16) {   // the group's camera for the assembly (one coalesced load, requested with the first observations)
+      const double v = lane < 15 ? P.camrec[(size_t)c * 32 + (lane < 9 ? lane : lane + 3)] : (double)P.cam_fixed[c];
+      s_cam[j * 16 + lane] = v;
+    }
     // the chain of both poses as one: a = Rc (Rf X + tf) = Rca X + tca. Uniform addresses: scalar loads, values in SGPRs.
     double Rca[9], tca[3], tcs[3];
     {
@@ -776,9 +783,8 @@ __global__ __launch_bounds__(NWF * 64, ONE ? 4 : (NWF <= 4 ? 3 : 2)) void k_rig_
     const int j = jb + gi;
     const bool live = j < ng;
     const int64_t g = g0 + (live ? j : 0);
-    const int c = P.gcam[g];
-    const bool fixed = P.cam_fixed[c] != 0;
-    const double* cr = P.camrec + (size_t)c * 32;
+    const double* crl = s_cam + (size_t)(live ? j : 0) * 16;   // [0..8] rotation, [9..14] step, [15] held constant
+    const bool fixed = crl[15] != 0.0;
     // model-cost term of the group from its OLD record (lanes l < 6: row a = l): 1/2 dc_a (G_cc dc)_a + dc_a g_c,a + dc_a (T df)_a
     // (first, on its own: nothing of it stays in registers across the assembly below)
     if (phase != 0) {
@@ -788,15 +794,15 @@ __global__ __launch_bounds__(NWF * 64, ONE ? 4 : (NWF <= 4 ? 3 : 2)) void k_rig_
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
         const int hi = a > k ? a : k, lo = a > k ? k : a;
-        gd = fma(old[hi * (hi + 1) / 2 + lo], fixed ? 0.0 : cr[12 + k], gd);
+        gd = fma(old[hi * (hi + 1) / 2 + lo], fixed ? 0.0 : crl[9 + k], gd);
         td = fma(old[28 + a * 6 + k], s_fr[12 + k], td);
       }
-      const double dca = fixed ? 0.0 : cr[12 + a];
+      const double dca = fixed ? 0.0 : crl[9 + a];
       if (live && l < 6) qm += dca * (0.5 * gd + old[21 + a] + td);
     }
     double Rc[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) Rc[i] = cr[i];
+    for (int i = 0; i < 9; ++i) Rc[i] = crl[i];
     const double* G = s_G + (size_t)(live ? j : 0) * 32;
     // K[i][b] = 2 (Rc_i x tf)_b: the rotation block of the adjoint's lower left
     double K[9];
