@@ -44,6 +44,9 @@ FLOP_PER_OBS = 800.0       # ~0.8 kflop fp64 per observation and
 # composed pose chain, projection, division, Huber test, two 7-entry rows, 42 FMAs of the 7-column Gram; with intrinsics,
 # k_rig_sweep_adjk -- ~200 of pixel model and rows + 1024 of the 16 x 16 product of two rows on the matrix pipe
 RIG_FLOP_PER_OBS = {"poses": 210.0, "shared_intrinsics": 1230.0, "per_camera_intrinsics": 1230.0}
+# ... and k_rig_sweep_k2 (groups of >= 448 observations): ~200 of pixel model and rows + 2 x 210 of the lower-triangle Gram with the
+# structural zeros of the pixel model skipped
+RIG_FLOP_PER_OBS_K2 = 620.0
 
 
 def algorithmic_bytes_sweep(n_obs, n_frames):
@@ -78,13 +81,14 @@ def load_traffic(frames, points, kernel="k_intr_sweep"):
 
 
 def load_rig_traffic(cams, frames, points, variant):
-    """HBM bytes per launch of the rig sweep from the committed PMC profile -- only for the profiled shape and variant."""
+    """HBM bytes per launch of the rig sweep from the committed PMC profiles -- only for a profiled shape and variant."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            t = json.load(f).get("rig_sweep", {})
-        sh = t.get("shape", {})
-        if (sh.get("cams"), sh.get("frames"), sh.get("points_per_frame"), sh.get("variant")) == (cams, frames, points, variant):
-            return t.get("hbm_bytes_per_launch")
+            t = json.load(f)
+        for e in [t.get("rig_sweep", {})] + list(t.get("rig_sweeps", [])):
+            sh = e.get("shape", {})
+            if (sh.get("cams"), sh.get("frames"), sh.get("points_per_frame"), sh.get("variant")) == (cams, frames, points, variant):
+                return e.get("hbm_bytes_per_launch")
     except Exception:
         pass
     return None
@@ -661,7 +665,9 @@ def rig_configs(capi, device):
             per_launch = {k: (p["kernel_ms"][k] / p["kernel_launches"][k] if p["kernel_launches"][k] else None) for k in p["kernel_ms"]}
             sweep_ms = per_launch["sweep"]
             ab = algorithmic_bytes_rig_sweep(n_obs, n_world, F, C_)
-            sweep_name = "k_rig_sweep_frame (one workgroup per frame, a wave per (frame, camera) group)" if variant == "poses" else "k_rig_sweep_adjk"
+            flop_per_obs = RIG_FLOP_PER_OBS_K2 if (variant != "poses" and n_obs / max(1, F * C_) >= 448) else RIG_FLOP_PER_OBS[variant]
+            sweep_name = ("k_rig_sweep_frame (one workgroup per frame, a wave per (frame, camera) group)" if variant == "poses" else
+                          ("k_rig_sweep_k2 (16-column Gram on plain FMAs, two waves per group, compact records)" if n_obs / max(1, F * C_) >= 448 else "k_rig_sweep_adjk (tiles)"))
             names = {"sweep": sweep_name, "decide": "k_rig_init", "elim": "k_rig_elim", "solve": "k_rig_reduce (column sums + reduced solve + pose update)",
                      "update": "k_rig_update", "reduce": "k_rig_reduce<2>", "allreduce": "ncclAllReduce"}
             # the kernel that takes the largest share of the profiled solve's kernel time -- NOT assumed to be the sweep: at
@@ -671,7 +677,7 @@ def rig_configs(capi, device):
             dominant = {"kernel": names.get(dom, dom), "ms_per_full_launch": per_launch[dom], "share_of_kernel_time": p["kernel_ms"][dom] / total_ms}
             if dom == "sweep":
                 dominant.update(bound="fp64 issue / hbm", hbm_frac=ab / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                fp64_frac=RIG_FLOP_PER_OBS[variant] * n_obs / (sweep_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS)
+                                fp64_frac=flop_per_obs * n_obs / (sweep_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS)
             else:
                 dominant.update(bound="latency", note="a chain of dependent steps on one workgroup (column sums, assembly, Cholesky of the "
                                 "reduced system, pose update behind a flag): no bandwidth or flop roofline applies; stage times in "
@@ -694,12 +700,13 @@ def rig_configs(capi, device):
                 "dominant_kernel": dominant,
                 "sweep_kernel": {"kernel": sweep_name, "ms_per_full_launch": sweep_ms,
                                  "hbm_frac": ab / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                 "fp64_frac": RIG_FLOP_PER_OBS[variant] * n_obs / (sweep_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                                 "fp64_frac": flop_per_obs * n_obs / (sweep_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                                 "fp64_flop_executed_per_observation": flop_per_obs,
                                  "algorithmic_bytes_per_launch": ab, "traffic": load_rig_traffic(C_, F, M, variant)},
                 "kernel_ms_per_full_launch_eager": per_launch,
                 "idle_launches_of_the_profiled_solve": {k: v for k, v in p["kernel_idle_launches"].items() if v},
                 "kernel_ms_labels": "(the THREE-KERNEL form: what profile_kernels = 1 runs) sweep = k_rig_sweep_frame (poses: per group the 7-column Gram of [J_cam r], per frame ONE "
-                                    "assembly of the coupling blocks and the frame block through the groups' adjoints) / k_rig_sweep_adjk (with intrinsics), decide = k_rig_init "
+                                    "assembly of the coupling blocks and the frame block through the groups' adjoints) / k_rig_sweep_k2 or k_rig_sweep_adjk (with intrinsics: sweep_kernel.kernel says which), decide = k_rig_init "
                                     "(once per solve), elim = k_rig_elim, solve = k_rig_reduce (column sums + reduced solve + pose update in one launch)",
                 "final_cost": s["final_cost"],
             }

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_sample_line_has_every_contract_field():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r03", "bench_sample.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05", "bench_sample.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -31,7 +31,8 @@ def test_committed_sample_line_has_every_contract_field():
     # round 3: every rig configuration names the kernel that dominates ITS profiled solve, and keeps the sweep's fractions apart
     for v in d["configs"].values():
         assert set(("iterations", "ms_per_iteration", "dominant_kernel", "sweep_kernel")) <= set(v)
-        assert set(("kernel", "ms_per_launch", "share_of_kernel_time", "bound")) <= set(v["dominant_kernel"])
+        assert set(("kernel", "ms_per_full_launch", "share_of_kernel_time", "bound")) <= set(v["dominant_kernel"])   # (round 5: one number per kernel, launches that did work)
+        assert "ms_per_launch" not in v["dominant_kernel"] and "ms_per_full_launch" in v["sweep_kernel"]
         assert set(("hbm_frac", "fp64_frac", "algorithmic_bytes_per_launch")) <= set(v["sweep_kernel"])
     assert d["configs"]["rig_c4_poses"]["dominant_kernel"]["bound"] == "latency"
 
