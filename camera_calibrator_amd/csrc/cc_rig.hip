@@ -766,6 +766,51 @@ __global__ __launch_bounds__(NWF * 64, ONE ? 4 : (NWF <= 4 ? 3 : 2)) void k_rig_
   else for (int j = wave; j < ng; j += NWF) sweep_group(j);
   if (tid < 32) s_fr[tid] = fr[tid];
   if (NWF > 1) __syncthreads(); else wave_lds_fence();
+  // model-cost term of the step at the accepted point: per group from its OLD record (lanes l < 6: row a = l), 1/2 dc_a (G_cc dc)_a
+  // + dc_a g_c,a + dc_a (T df)_a, and the frame's own block from the old frame record. It needs nothing of THIS sweep's sums, so
+  // in a workgroup of several waves WAVE 1 forms it while wave 0 assembles the frame (round 5: the old records' round trip was
+  // on wave 0's chain, behind the barrier).
+  const double* comp_old = P.gcomp + (size_t)cur * P.NG * 64;
+  auto model_cost_group = [&](int j, int gi_, int l_) -> double {
+    if (phase == 0) return 0.0;
+    const bool live = j < ng;
+    const int64_t g = g0 + (live ? j : 0);
+    const double* crl = s_cam + (size_t)(live ? j : 0) * 16;
+    const bool fixed = crl[15] != 0.0;
+    const int a = l_ < 6 ? l_ : 0;
+    const double* old = comp_old + (size_t)g * 64;
+    double gd = 0.0, td = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int hi = a > k ? a : k, lo = a > k ? k : a;
+      gd = fma(old[hi * (hi + 1) / 2 + lo], fixed ? 0.0 : crl[9 + k], gd);
+      td = fma(old[28 + a * 6 + k], s_fr[12 + k], td);
+    }
+    const double dca = fixed ? 0.0 : crl[9 + a];
+    (void)gi_;
+    return (live && l_ < 6) ? dca * (0.5 * gd + old[21 + a] + td) : 0.0;
+  };
+  auto model_cost_frame = [&](int gi_, int l_) -> double {
+    if (!(phase != 0 && gi_ == 0 && l_ < 6 && ng > 0)) return 0.0;
+    const double* fo = P.fsum + ((size_t)cur * P.F + f) * 32;
+    double hd = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int hi = l_ > k ? l_ : k, lo = l_ > k ? k : l_;
+      hd = fma(fo[hi * (hi + 1) / 2 + lo], s_fr[12 + k], hd);
+    }
+    return s_fr[12 + l_] * (0.5 * hd + fo[21 + l_]);
+  };
+  if (NWF > 1 && wave == 1) {
+    int lane_q = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane_q));
+    const int gq = lane_q >> 3, lq = lane_q & 7;
+    double q = model_cost_frame(gq, lq);
+    for (int jb = 0; jb < ng; jb += 8) q += model_cost_group(jb + gq, gq, lq);
+    q = wave_sum(q);
+    if (lane_q == 0) P.gstats[f * 2 + 1] = q;
+    return;
+  }
   if (wave != 0) return;
   // ---- the frame's assembly: eight lanes per group, eight groups per pass. Lane (gi, l): l < 6 owns column l of T and of the
   // group's share of H_ff; l == 6 the gradient column (g_c -> M^T g_c); l == 7 idles.
@@ -777,7 +822,6 @@ __global__ __launch_bounds__(NWF * 64, ONE ? 4 : (NWF <= 4 ? 3 : 2)) void k_rig_
   const double tf0 = s_fr[9], tf1 = s_fr[10], tf2 = s_fr[11];
   double hsum[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // column l of H_ff (l < 6) / g_f (l == 6), over this lane's groups
   double cost = 0.0, qm = 0.0;
-  const double* comp_cur = P.gcomp + (size_t)cur * P.NG * 64;
   double* comp_dst = P.gcomp + (size_t)dst * P.NG * 64;
   for (int jb = 0; jb < ng; jb += 8) {
     const int j = jb + gi;
@@ -785,21 +829,7 @@ __global__ __launch_bounds__(NWF * 64, ONE ? 4 : (NWF <= 4 ? 3 : 2)) void k_rig_
     const int64_t g = g0 + (live ? j : 0);
     const double* crl = s_cam + (size_t)(live ? j : 0) * 16;   // [0..8] rotation, [9..14] step, [15] held constant
     const bool fixed = crl[15] != 0.0;
-    // model-cost term of the group from its OLD record (lanes l < 6: row a = l): 1/2 dc_a (G_cc dc)_a + dc_a g_c,a + dc_a (T df)_a
-    // (first, on its own: nothing of it stays in registers across the assembly below)
-    if (phase != 0) {
-      const int a = l < 6 ? l : 0;
-      const double* old = comp_cur + (size_t)g * 64;
-      double gd = 0.0, td = 0.0;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const int hi = a > k ? a : k, lo = a > k ? k : a;
-        gd = fma(old[hi * (hi + 1) / 2 + lo], fixed ? 0.0 : crl[9 + k], gd);
-        td = fma(old[28 + a * 6 + k], s_fr[12 + k], td);
-      }
-      const double dca = fixed ? 0.0 : crl[9 + a];
-      if (live && l < 6) qm += dca * (0.5 * gd + old[21 + a] + td);
-    }
+    if (NWF == 1) qm += model_cost_group(j, gi, l);   // (workgroups of several waves: wave 1's, below)
     double Rc[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) Rc[i] = crl[i];
@@ -879,22 +909,12 @@ __global__ __launch_bounds__(NWF * 64, ONE ? 4 : (NWF <= 4 ? 3 : 2)) void k_rig_
 #pragma unroll
     for (int r = 0; r < 6; ++r) fs[21 + r] = hsum[r];
   }
-  // model-cost term of the frame's own block at the accepted point
-  if (phase != 0 && gi == 0 && l < 6 && ng > 0) {
-    const double* fo = P.fsum + ((size_t)cur * P.F + f) * 32;
-    double hd = 0.0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const int hi = l > k ? l : k, lo = l > k ? k : l;
-      hd = fma(fo[hi * (hi + 1) / 2 + lo], s_fr[12 + k], hd);
-    }
-    qm += s_fr[12 + l] * (0.5 * hd + fo[21 + l]);
-  }
+  if (NWF == 1) qm += model_cost_frame(gi, l);
   cost = wave_sum(cost);
-  qm = wave_sum(qm);
+  if (NWF == 1) qm = wave_sum(qm);
   if (lane_a == 0) {
     P.gstats[f * 2] = cost;
-    P.gstats[f * 2 + 1] = qm;
+    if (NWF == 1) P.gstats[f * 2 + 1] = qm;
   }
 }
 
