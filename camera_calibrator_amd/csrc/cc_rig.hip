@@ -6581,7 +6581,7 @@ int cc_rig_debug_chol_bench(int32_t S, int32_t reps, int32_t which, double* out)
   CC_HIP(hipMalloc(&dout, 64));
   CC_HIP(hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice));
   const size_t lds = ((size_t)(S + 1) * LD + 5 * 128) * 8;
-  if (int rc_ = lds_attr(h->device, reinterpret_cast<const void*>(k_chol_bench), (int)lds)) return rc_;
+  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_bench), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_chol_bench, dim3(1), dim3(256), lds, 0, dA, S, reps, which, dout);
   CC_HIP(hipDeviceSynchronize());
   CC_HIP(hipMemcpy(out, dout, 24, hipMemcpyDeviceToHost));
