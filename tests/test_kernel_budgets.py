@@ -70,3 +70,36 @@ def test_intrinsics_kernels_keep_their_register_allocation():
     t = _table("cc_intrinsics.hip")
     k = "cc::k_intr_sweep"
     assert t[k]["vspill"] == 0 and t[k]["scratch"] == 0 and t[k]["vgpr"] <= 128, (k, t[k])
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_every_rig_kernel_is_a_named_form():
+    """Round 5 (prune): the rig path's kernels, by name. A form that is added (or an A/B partner that comes back) has to be
+    written down here, next to what it is for -- the first formulation of the sweeps (k_rig_sweep, every column through the
+    matrix pipe) and the glued persistent kernel (k_rig_persist) are gone and stay gone."""
+    t = _table("cc_rig.hip")
+    names = {k.replace("cc::", "").split("(")[0] for k in t}
+    forms = {
+        # sweeps: per (frame, camera) group with 16 x 16 tiles (large rigs, tests), per frame with compact records (default),
+        # with intrinsics on the matrix pipe / tiles and on plain FMAs / compact records
+        "k_rig_sweep_adj<1>", "k_rig_sweep_adj<2>", "k_rig_sweep_adj<4>",
+        *("k_rig_sweep_frame<%d, %s>" % (n, o) for n in (1, 2, 4, 8) for o in ("true", "false")),
+        "k_rig_sweep_adjk<1>", "k_rig_sweep_adjk<4>", "k_rig_sweep_k2",
+        # steps behind the sweep
+        "k_rig_update", "k_rig_stats", "k_rig_flag_exchange", "k_rig_init", "k_rig_collect", "k_rig_records",
+        *("k_rig_elim<%s>" % a for a in ("false, 8, false, false", "false, 8, true, false", "false, 24, true, false", "true, 8, false, false",
+                                         "false, 24, false, false", "true, 24, false, false", "true, 8, false, true", "true, 24, false, true")),
+        "k_rig_reduce<0>", "k_rig_reduce<2>", "k_rig_reduce<3>", "k_rig_reduce<4>", "k_rig_solve<0>", "k_rig_solve<2>",
+        # reduced systems of 128 .. 255 coordinates
+        "k_rig_elim_big<false>", "k_rig_elim_big<true>", "k_rig_solve_big<true>", "k_rig_solve_big<false>",
+        # the lean persistent form
+        "k_rig_persist_w<1>", "k_rig_persist_w<2>", "k_rig_persist_w<4>", "k_rig_persist_ctl",
+        # creation / read-back helpers
+        "k_rig_expand_xyz", "k_rig_obs_cost",
+    }
+    assert names == forms, (sorted(names - forms), sorted(forms - names))
+    assert not any(n.startswith("k_rig_sweep<") or n.startswith("k_rig_persist<") or n == "k_rig_persist" for n in names)
+    # the file split of round 5: the host side + launches stay under 2,500 lines, no part above 2,000
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "camera_calibrator_amd", "csrc")
+    sizes = {f: sum(1 for _ in open(os.path.join(root, f))) for f in ("cc_rig.hip", "cc_rig_sweeps.hpp", "cc_rig_steps.hpp", "cc_rig_big.hpp", "cc_rig_lean.hpp")}
+    assert sizes["cc_rig.hip"] < 2500 and max(sizes.values()) < 2500, sizes
