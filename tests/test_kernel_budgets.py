@@ -13,7 +13,16 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+_tables = {}
+
+
 def _table(src):
+    if src not in _tables:   # (one cross-compilation per source file and session: ~40 s each)
+        _tables[src] = _compile_table(src)
+    return _tables[src]
+
+
+def _compile_table(src):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "kernel_regs.py"), os.path.join(ROOT, "camera_calibrator_amd", "csrc", src)],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
