@@ -1135,27 +1135,22 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   if ((int64_t)h->perm.size() < N) h->perm.resize((size_t)N);
   const size_t b_uv = ((size_t)N * 2 * sizeof(float) + 255) & ~(size_t)255;
   bool st_cached = false;
-  char* st = static_cast<char*>(staging_get(b_uv + (size_t)N * sizeof(int32_t) + 256, &st_cached));
+  // one pinned piece for both: the regrouped observations and (behind them) the handle's small host-built tables -- dev_upload
+  // copies a table in and enqueues an asynchronous copy (per group 16 B, per frame 4 CO + 128 B, per shared column / direct entry
+  // a few words: 4 MB covers BASELINE configs[4] several times over; a table that does not fit takes the synchronous copy).
+  // ONE piece per call: the staging cache lends four, and a call that needed two would leave two concurrent callers without.
+  const size_t up_cap = (size_t)4 << 20;
+  const size_t b_obs = (b_uv + (size_t)N * sizeof(int32_t) + 255) & ~(size_t)255;
+  char* st = static_cast<char*>(staging_get(b_obs + up_cap + 256, &st_cached));
   if (!st) return fail(CC_ERR_HIP, "cc_rig_create: pinned staging memory could not be allocated");
   struct StGuard {   // the uploads read the block until the handle's stream has drained
     void* p; cc_rig* h;
-    ~StGuard() { if (h->stream) (void)hipStreamSynchronize(h->stream); staging_put(p); }
+    ~StGuard() { if (h->stream) (void)hipStreamSynchronize(h->stream); h->up_stage = nullptr; h->up_cap = h->up_used = 0; staging_put(p); }
   } stg{st, h};
   float* uv_s = reinterpret_cast<float*>(st);
   int32_t* widx_s = reinterpret_cast<int32_t*>(st + b_uv);
   if (int rc = stream_get(device, &h->stream)) return rc;
-  struct UpGuard {   // pinned staging of the table uploads (dev_upload): given back once the stream has drained
-    cc_rig* h; void* p = nullptr;
-    ~UpGuard() { if (p) { if (h->stream) (void)hipStreamSynchronize(h->stream); h->up_stage = nullptr; h->up_cap = h->up_used = 0; staging_put(p); } }
-  } upg{h};
-  {
-    // tables: per group 16 B, per frame 4 CO + 128 B, per shared column / direct entry a few words -- 4 MB covers BASELINE configs[4]
-    // several times over; a table that does not fit takes the synchronous copy
-    const size_t cap = (size_t)4 << 20;
-    bool up_cached = false;
-    upg.p = staging_get(cap, &up_cached);
-    if (upg.p) { h->up_stage = static_cast<char*>(upg.p); h->up_cap = cap; h->up_used = 0; }
-  }
+  h->up_stage = st + b_obs; h->up_cap = up_cap; h->up_used = 0;
   float* duv = nullptr;
   int32_t* dw = nullptr;
   if (int rc = dev_alloc(h, &duv, (size_t)N * 2)) return rc;
