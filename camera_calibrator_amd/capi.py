@@ -85,7 +85,7 @@ EXPORTED_SYMBOLS = [
     "cc_rig_create", "cc_rig_destroy", "cc_rig_set_state", "cc_rig_reset", "cc_rig_solve",
     "cc_rig_get_state", "cc_rig_solver_form", "cc_rig_solver_status", "cc_rig_eval", "cc_rig_optimize", "cc_rig_comm_init", "cc_rig_exchange_export", "cc_rig_exchange_attach", "cc_rigk_create",
     "cc_rigk_set_intrinsics", "cc_rigk_get_intrinsics", "cc_rigk_create_per_camera", "cc_rigk_set_camera_intrinsics",
-    "cc_rigk_get_camera_intrinsics", "cc_zhang_init", "cc_intrinsics_optimize_multi", "cc_rig_optimize_multi", "cc_rig_optimize_frames",
+    "cc_rigk_get_camera_intrinsics", "cc_zhang_init", "cc_intrinsics_optimize_multi", "cc_rig_optimize_multi", "cc_rig_optimize_frames", "cc_rig_optimize_columns",
 ]
 # every symbol include/cc_harness.h declares (synthetic-input harness, host code)
 HARNESS_SYMBOLS = [
@@ -411,6 +411,53 @@ def rig_optimize_frames(n_cams, frame_offsets, obs_cam, obs_world, obs_uv, world
                                         _p(frozen, C.c_uint8), _p(frame_q, C.c_double), _p(frame_t, C.c_double),
                                         C.c_double(huber_a), C.byref(s)))
     cost = np.concatenate([a["cost"] for a in frames]) if F else np.zeros(0)
+    return cam_q, cam_t, frame_q, frame_t, cost, _summary_dict(s, log)
+
+
+class ObsColumns(C.Structure):
+    _fields_ = [("camera", C.POINTER(C.c_void_p)), ("camera_stride", C.c_int64), ("camera_width", C.c_int32),
+                ("world", C.POINTER(C.c_void_p)), ("world_stride", C.c_int64), ("world_width", C.c_int32),
+                ("uv", C.POINTER(C.c_void_p)), ("uv_stride", C.c_int64),
+                ("cost", C.POINTER(C.c_void_p)), ("cost_stride", C.c_int64)]
+
+
+def rig_optimize_columns(n_cams, frame_offsets, obs_cam, obs_world, obs_uv, world_xyz, cam_q, cam_t, cam_frozen,
+                         frame_q, frame_t, huber_a=HUBER_A, options=None, device=0, log_capacity=2048,
+                         camera_dtype=np.uint32, world_dtype=np.uint64, want_cost=True):
+    """cc_rig_optimize_columns: the observations handed over frame by frame as four arrays per frame (camera ids, world point ids,
+    image points, costs -- what the C++ class holds since round 5); ids 4 or 8 bytes wide.
+    Returns (cam_q, cam_t, frame_q, frame_t, obs_cost, summary) like rig_optimize (obs_cost None with want_cost=False)."""
+    off = np.ascontiguousarray(frame_offsets, dtype=np.int64)
+    F = len(off) - 1
+    obs_cam, obs_world = np.asarray(obs_cam), np.asarray(obs_world)
+    uv = _f32(obs_uv).reshape(-1, 2)
+    world_xyz = _f32(world_xyz)
+    cols = {"camera": [], "world": [], "uv": [], "cost": []}
+    for f in range(F):
+        a, b = int(off[f]), int(off[f + 1])
+        cols["camera"].append(np.ascontiguousarray(obs_cam[a:b], dtype=camera_dtype))
+        cols["world"].append(np.ascontiguousarray(obs_world[a:b], dtype=world_dtype))
+        cols["uv"].append(np.ascontiguousarray(uv[a:b]))
+        cols["cost"].append(np.full(b - a, -1.0))
+    ptr = {k: (C.c_void_p * F)(*[x.ctypes.data if len(x) else None for x in v]) for k, v in cols.items()}
+    oc = ObsColumns(ptr["camera"], np.dtype(camera_dtype).itemsize, np.dtype(camera_dtype).itemsize,
+                    ptr["world"], np.dtype(world_dtype).itemsize, np.dtype(world_dtype).itemsize,
+                    ptr["uv"], 8, ptr["cost"] if want_cost else None, 8)
+    counts = np.ascontiguousarray(np.diff(off), dtype=np.int64)
+    frozen = np.ascontiguousarray(cam_frozen, dtype=np.uint8)
+    cam_q, cam_t = _f64(cam_q).copy(), _f64(cam_t).copy()
+    frame_q, frame_t = _f64(frame_q).copy(), _f64(frame_t).copy()
+    opt = options if options is not None else default_options(max_iterations=1000)
+    log = (Iteration * max(1, log_capacity))()
+    s = Summary()
+    s.log = C.cast(log, C.POINTER(Iteration))
+    s.log_capacity = log_capacity
+    _check(lib().cc_rig_optimize_columns(C.byref(opt), C.c_int32(device), C.c_int64(n_cams), C.c_int64(F),
+                                         C.c_int64(world_xyz.size // 3), C.byref(oc), _p(counts, C.c_int64),
+                                         _p(world_xyz, C.c_float), _p(cam_q, C.c_double), _p(cam_t, C.c_double),
+                                         _p(frozen, C.c_uint8), _p(frame_q, C.c_double), _p(frame_t, C.c_double),
+                                         C.c_double(huber_a), C.byref(s)))
+    cost = (np.concatenate(cols["cost"]) if F else np.zeros(0)) if want_cost else None
     return cam_q, cam_t, frame_q, frame_t, cost, _summary_dict(s, log)
 
 

@@ -366,7 +366,7 @@ struct cc_rig {
   int frame_waves = 2;       // waves per frame workgroup of the frame form
   int kmode = 0;
   std::vector<int64_t> perm;  // sorted position -> caller's observation index
-  bool perm_inverse = false;   // perm[k] = regrouped position of the caller's observation k (records) instead of perm[i] = caller's index of position i
+  bool perm_inverse = false;   // columns: the storage holds int32 entries, [k] = where the caller's observation k went, counted from its frame's first position -- instead of perm[i] = caller's index of position i
   std::vector<std::pair<void*, size_t>> allocs;   // the chunks dev_alloc carves buffers from (cc::pool_alloc: recycled between handles)
   // pinned staging of the small host-built tables while the handle is being created (rig_create_impl): dev_upload copies a table
   // in and enqueues an asynchronous copy on the handle's stream instead of one synchronous hipMemcpy per table (~25 of them)
@@ -1021,8 +1021,8 @@ namespace cc {
 // Where cc_rig_create reads the observations: three flat arrays (cc_rig_create), or records the caller keeps frame by frame
 // (cc_rig_optimize_frames: ExtrinsicsCalibrator's per-frame lists, read in place).
 struct RigObsSource {
-  const uint32_t* cam = nullptr; const uint64_t* world = nullptr; const float* uv = nullptr;
-  const void* const* frames = nullptr; cc_obs_layout lay{};
+  const uint32_t* cam = nullptr; const uint64_t* world = nullptr; const float* uv = nullptr;   // flat arrays, or
+  const cc_obs_columns* cols = nullptr;                                                         // the caller's per-frame columns, read in place
 };
 struct RigFlatFrame {
   const uint32_t* cam; const uint64_t* world; const float* uv;
@@ -1031,13 +1031,19 @@ struct RigFlatFrame {
   uint64_t point(int64_t i) const { return world[i]; }
   void pixel(int64_t i, float* o) const { o[0] = uv[2 * i]; o[1] = uv[2 * i + 1]; }
 };
-struct RigRecordFrame {
-  const unsigned char* p; int64_t stride, oc, ow, ou;
-  RigRecordFrame(const RigObsSource& s, int64_t f, int64_t)
-      : p(static_cast<const unsigned char*>(s.frames[f])), stride(s.lay.stride), oc(s.lay.camera_offset), ow(s.lay.world_offset), ou(s.lay.uv_offset) {}
-  uint64_t camera(int64_t i) const { uint64_t v; std::memcpy(&v, p + i * stride + oc, 8); return v; }
-  uint64_t point(int64_t i) const { uint64_t v; std::memcpy(&v, p + i * stride + ow, 8); return v; }
-  void pixel(int64_t i, float* o) const { std::memcpy(o, p + i * stride + ou, 8); }
+struct RigColumnFrame {   // one frame of cc_obs_columns (records with a stride, or arrays: stride = width)
+  const unsigned char *pc, *pw, *pu; int64_t sc, sw, su; bool c4, w4;
+  RigColumnFrame(const RigObsSource& s, int64_t f, int64_t)
+      : pc(static_cast<const unsigned char*>(s.cols->camera[f])), pw(static_cast<const unsigned char*>(s.cols->world[f])),
+        pu(static_cast<const unsigned char*>(s.cols->uv[f])), sc(s.cols->camera_stride), sw(s.cols->world_stride), su(s.cols->uv_stride),
+        c4(s.cols->camera_width == 4), w4(s.cols->world_width == 4) {}
+  static uint64_t id(const unsigned char* p, bool four) {
+    if (four) { uint32_t v; std::memcpy(&v, p, 4); return v; }
+    uint64_t v; std::memcpy(&v, p, 8); return v;
+  }
+  uint64_t camera(int64_t i) const { return id(pc + i * sc, c4); }
+  uint64_t point(int64_t i) const { return id(pw + i * sw, w4); }
+  void pixel(int64_t i, float* o) const { std::memcpy(o, pu + i * su, 8); }
 };
 struct RigRegroupPart { std::vector<int32_t> gframe, gcam, per_frame; std::vector<int64_t> gend; int64_t bad = -1; int bad_kind = 0; };
 
@@ -1084,7 +1090,7 @@ static void rig_regroup_part(const RigObsSource& src, int64_t C, int64_t n_world
     L.per_frame.push_back((int32_t)present.size());
     for (int64_t i = 0; i < n; ++i) {
       const int64_t dst = start[fr.camera(i)]++;
-      if (INV) perm[base + i] = dst; else perm[dst] = base + i;   // (records: where observation i of the frame went -- the costs are written record by record)
+      if (INV) reinterpret_cast<int32_t*>(perm)[base + i] = (int32_t)(dst - base); else perm[dst] = base + i;   // (columns: where observation i of the frame went, 32 bits -- the costs are written frame by frame)
       fr.pixel(i, uv_s + 2 * dst);
       widx_s[dst] = (int32_t)fr.point(i);
     }
@@ -1109,14 +1115,15 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   // device-side indices are 32-bit (world point, group, camera) and launch grids are unsigned
   if (C > (1 << 20) || F >= INT32_MAX || n_world >= INT32_MAX || N >= ((int64_t)1 << 40))
     return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: problem too large (cameras < 2^20, frames and world points < 2^31)");
-  if (N > 0 && ((!src.frames && (!src.cam || !src.world || !src.uv)) || !world_xyz)) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: NULL arrays");
-  if (src.frames) {
-    const cc_obs_layout& l = src.lay;
-    if (l.stride < 8 || l.camera_offset < 0 || l.world_offset < 0 || l.uv_offset < 0 || l.camera_offset + 8 > l.stride ||
-        l.world_offset + 8 > l.stride || l.uv_offset + 8 > l.stride || (l.cost_offset >= 0 && l.cost_offset + 8 > l.stride))
-      return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_optimize_frames: record layout does not fit its stride");
+  if (N > 0 && ((!src.cols && (!src.cam || !src.world || !src.uv)) || !world_xyz)) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_create: NULL arrays");
+  if (src.cols) {
+    const cc_obs_columns& l = *src.cols;
+    if (!l.camera || !l.world || !l.uv || (l.camera_width != 4 && l.camera_width != 8) || (l.world_width != 4 && l.world_width != 8) ||
+        l.camera_stride < l.camera_width || l.world_stride < l.world_width || l.uv_stride < 8 || (l.cost && l.cost_stride < 8))
+      return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_optimize_columns: a column is missing, an id is not 4 or 8 bytes wide or a stride is below its field");
     for (int64_t f = 0; f < F; ++f)
-      if (off[f + 1] > off[f] && !src.frames[f]) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_optimize_frames: frame %lld has no records", (long long)f);
+      if (off[f + 1] > off[f] && (!l.camera[f] || !l.world[f] || !l.uv[f] || (l.cost && !l.cost[f])))
+        return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_optimize_columns: frame %lld has observations but a NULL column", (long long)f);
   }
   hp.mark("checks");   // (camera and world point ids: inside the regrouping pass)
   if (int rc = select_device(device)) return rc;
@@ -1177,10 +1184,10 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
     using Part = RigRegroupPart;
     std::vector<Part> part((size_t)parts);
     int64_t* perm = h->perm.data();
-    h->perm_inverse = src.frames != nullptr;
+    h->perm_inverse = src.cols != nullptr;
     uint8_t* seen_p = seen.data();
     parallel_tasks(parts, [&](int t) {
-      if (src.frames) rig_regroup_part<RigRecordFrame, true>(src, C, n_world, off, pf[(size_t)t], pf[(size_t)t + 1], perm, uv_s, widx_s, seen_p, part[(size_t)t], flush);
+      if (src.cols) rig_regroup_part<RigColumnFrame, true>(src, C, n_world, off, pf[(size_t)t], pf[(size_t)t + 1], perm, uv_s, widx_s, seen_p, part[(size_t)t], flush);
       else rig_regroup_part<RigFlatFrame, false>(src, C, n_world, off, pf[(size_t)t], pf[(size_t)t + 1], perm, uv_s, widx_s, seen_p, part[(size_t)t], flush);
     });
     for (const Part& L : part)   // (parts are in frame order: the first one with a bad id holds the first bad observation)
@@ -1826,10 +1833,15 @@ int cc_rig_get_state(cc_rig* h, double* cam_q, double* cam_t, double* frame_q, d
     CC_HIP(hipMemcpyAsync(sorted, h->d_cost, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     CC_HIP(hipStreamSynchronize(h->stream));
     const int64_t* perm = h->perm.data();
-    parallel_ranges(h->N, (int64_t)1 << 15, [&](int, int64_t a, int64_t b) {
-      if (h->perm_inverse) { for (int64_t i = a; i < b; ++i) obs_cost[i] = sorted[perm[i]]; }
-      else { for (int64_t i = a; i < b; ++i) obs_cost[perm[i]] = sorted[i]; }
-    });
+    if (h->perm_inverse) {   // (a handle made from columns: frame by frame)
+      const int32_t* rel = reinterpret_cast<const int32_t*>(perm);
+      for (int64_t f = 0; f < h->F; ++f) {
+        const int64_t a = h->goff_h[(size_t)h->fgoff_h[(size_t)f]], b = h->goff_h[(size_t)h->fgoff_h[(size_t)f + 1]];
+        for (int64_t i = a; i < b; ++i) obs_cost[i] = sorted[a + rel[i]];
+      }
+    } else {
+      parallel_ranges(h->N, (int64_t)1 << 15, [&](int, int64_t a, int64_t b) { for (int64_t i = a; i < b; ++i) obs_cost[perm[i]] = sorted[i]; });
+    }
   }
   return CC_OK;
 }
@@ -2013,22 +2025,21 @@ int cc_rig_optimize(const cc_options* opt, int32_t device, int64_t C, int64_t F,
 // Multi-device rig solve driven by ONE host thread (SURVEY.md 8(b) thread model; cf. cc_intrinsics_optimize_multi):
 // frames sharded contiguously by observation count, cameras and world points replicated, mailboxes wired inside the
 // process, every device's chunk enqueued before any is waited for. A device id may appear several times.
-int cc_rig_optimize_frames(const cc_options* opt, int32_t device, int64_t C, int64_t F, int64_t n_world,
-                           void* const* frame_records, const int64_t* counts, const cc_obs_layout* layout,
-                           const float* world_xyz, double* cam_q, double* cam_t, const uint8_t* cam_frozen,
-                           double* frame_q, double* frame_t, double huber_a, cc_summary* summary) {
+int cc_rig_optimize_columns(const cc_options* opt, int32_t device, int64_t C, int64_t F, int64_t n_world,
+                            const cc_obs_columns* columns, const int64_t* counts,
+                            const float* world_xyz, double* cam_q, double* cam_t, const uint8_t* cam_frozen,
+                            double* frame_q, double* frame_t, double huber_a, cc_summary* summary) {
   cc::last_call_status_reset();
   using namespace cc;
-  if (F < 1 || !frame_records || !counts || !layout) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_optimize_frames: bad arguments");
-  HostPhases hp("cc_rig_optimize_frames");
+  if (F < 1 || !columns || !counts) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_optimize_columns: bad arguments");
+  HostPhases hp("cc_rig_optimize_columns");
   std::vector<int64_t> off((size_t)F + 1, 0);
   for (int64_t f = 0; f < F; ++f) {
-    if (counts[f] < 0) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_optimize_frames: negative count");
+    if (counts[f] < 0 || counts[f] >= INT32_MAX) return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_optimize_columns: a frame's count is negative or beyond 2^31 - 2");
     off[(size_t)f + 1] = off[(size_t)f] + counts[f];
   }
   RigObsSource src;
-  src.frames = const_cast<const void* const*>(frame_records);
-  src.lay = *layout;
+  src.cols = columns;
   cc_rig* h = nullptr;
   int rc = rig_create_impl(device, C, F, n_world, off.data(), src, world_xyz, cam_frozen, huber_a, RIG_K_NONE, &h);
   if (rc) return rc;
@@ -2040,8 +2051,8 @@ int cc_rig_optimize_frames(const cc_options* opt, int32_t device, int64_t C, int
   if (!rc) rc = cc_rig_solve(h, &o, summary);
   hp.mark("solve");
   if (!rc) rc = cc_rig_get_state(h, cam_q, cam_t, frame_q, frame_t, nullptr);
-  if (!rc && layout->cost_offset >= 0 && h->N > 0) {
-    // per-observation costs (extrinsics_calibrator.cpp:219-225) through the pinned block, then into the caller's records on
+  if (!rc && columns->cost && h->N > 0) {
+    // per-observation costs (extrinsics_calibrator.cpp:219-225) through the pinned block, then into the caller's column on
     // several host threads (a frame's observations stay inside the frame's range of the regrouped order)
     rc = [&]() -> int {
       LmCtl c;
@@ -2050,10 +2061,10 @@ int cc_rig_optimize_frames(const cc_options* opt, int32_t device, int64_t C, int
       CC_HIP(hipGetLastError());
       bool st_cached = false;
       double* sorted = static_cast<double*>(staging_get((size_t)h->N * sizeof(double), &st_cached));
-      if (!sorted) return fail(CC_ERR_HIP, "cc_rig_optimize_frames: pinned staging memory could not be allocated");
+      if (!sorted) return fail(CC_ERR_HIP, "cc_rig_optimize_columns: pinned staging memory could not be allocated");
       struct StGuard { void* p; hipStream_t s; ~StGuard() { (void)hipStreamSynchronize(s); staging_put(p); } } stg{sorted, h->stream};
-      const int64_t* perm = h->perm.data();
-      const int parts = parallel_parts(h->N, (int64_t)1 << 15);
+      const int32_t* rel = reinterpret_cast<const int32_t*>(h->perm.data());   // (perm_inverse: positions inside the frame)
+      const int parts = parallel_parts(h->N, (int64_t)1 << 17);   // (a transfer of a megabyte and more per part)
       std::vector<int64_t> pf((size_t)parts + 1, 0);
       if (int r2 = cc_partition_frames(F, off.data(), parts, pf.data())) return r2;
       // one transfer and one event per thread's range of frames: a thread writes its range into the records as soon as it has
@@ -2066,18 +2077,19 @@ int cc_rig_optimize_frames(const cc_options* opt, int32_t device, int64_t C, int
         CC_HIP(hipEventCreateWithFlags(&ev[(size_t)t], hipEventDisableTiming));
         CC_HIP(hipEventRecord(ev[(size_t)t], h->stream));
       }
-      const int64_t stride = layout->stride, oc = layout->cost_offset;
+      const int64_t stride = columns->cost_stride;
       std::vector<char> bad((size_t)parts, 0);
       parallel_tasks(parts, [&](int t) {
         if (hipSetDevice(h->device) != hipSuccess || hipEventSynchronize(ev[(size_t)t]) != hipSuccess) { bad[(size_t)t] = 1; return; }
         // record after record (the inverse permutation: sequential stores, the reads stay inside the frame's range of `sorted`)
         for (int64_t f = pf[(size_t)t]; f < pf[(size_t)t + 1]; ++f) {
-          unsigned char* rec = static_cast<unsigned char*>(frame_records[f]) + oc;
-          for (int64_t k = off[(size_t)f]; k < off[(size_t)f + 1]; ++k, rec += stride) std::memcpy(rec, &sorted[perm[k]], sizeof(double));
+          unsigned char* rec = static_cast<unsigned char*>(columns->cost[f]);
+          const double* from = sorted + off[(size_t)f];
+          for (int64_t k = off[(size_t)f]; k < off[(size_t)f + 1]; ++k, rec += stride) std::memcpy(rec, &from[rel[k]], sizeof(double));
         }
       });
       CC_HIP(hipStreamSynchronize(h->stream));
-      for (char b : bad) if (b) return fail(CC_ERR_HIP, "cc_rig_optimize_frames: the read-back of the costs failed");
+      for (char b : bad) if (b) return fail(CC_ERR_HIP, "cc_rig_optimize_columns: the read-back of the costs failed");
       return CC_OK;
     }();
   }
@@ -2085,6 +2097,37 @@ int cc_rig_optimize_frames(const cc_options* opt, int32_t device, int64_t C, int
   cc_rig_destroy(h);
   hp.mark("destroy");
   return rc;
+}
+
+// The same for observations kept as one record each (stride, field offsets): columns that share their base pointers.
+int cc_rig_optimize_frames(const cc_options* opt, int32_t device, int64_t C, int64_t F, int64_t n_world,
+                           void* const* frame_records, const int64_t* counts, const cc_obs_layout* layout,
+                           const float* world_xyz, double* cam_q, double* cam_t, const uint8_t* cam_frozen,
+                           double* frame_q, double* frame_t, double huber_a, cc_summary* summary) {
+  using namespace cc;
+  if (F < 1 || !frame_records || !counts || !layout) { last_call_status_reset(); return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_optimize_frames: bad arguments"); }
+  const cc_obs_layout& l = *layout;
+  if (l.stride < 8 || l.camera_offset < 0 || l.world_offset < 0 || l.uv_offset < 0 || l.camera_offset + 8 > l.stride ||
+      l.world_offset + 8 > l.stride || l.uv_offset + 8 > l.stride || (l.cost_offset >= 0 && l.cost_offset + 8 > l.stride)) {
+    last_call_status_reset();
+    return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_optimize_frames: record layout does not fit its stride");
+  }
+  std::vector<const void*> pc((size_t)F), pw((size_t)F), pu((size_t)F);
+  std::vector<void*> pr((size_t)F);
+  for (int64_t f = 0; f < F; ++f) {
+    unsigned char* r = static_cast<unsigned char*>(frame_records[f]);
+    if (!r && counts[f] > 0) { last_call_status_reset(); return fail(CC_ERR_BAD_ARGUMENT, "cc_rig_optimize_frames: frame %lld has no records", (long long)f); }
+    pc[(size_t)f] = r ? r + l.camera_offset : nullptr;
+    pw[(size_t)f] = r ? r + l.world_offset : nullptr;
+    pu[(size_t)f] = r ? r + l.uv_offset : nullptr;
+    pr[(size_t)f] = (r && l.cost_offset >= 0) ? r + l.cost_offset : nullptr;
+  }
+  cc_obs_columns cols{};
+  cols.camera = pc.data(); cols.camera_stride = l.stride; cols.camera_width = 8;
+  cols.world = pw.data(); cols.world_stride = l.stride; cols.world_width = 8;
+  cols.uv = pu.data(); cols.uv_stride = l.stride;
+  cols.cost = l.cost_offset >= 0 ? pr.data() : nullptr; cols.cost_stride = l.stride;
+  return cc_rig_optimize_columns(opt, device, C, F, n_world, &cols, counts, world_xyz, cam_q, cam_t, cam_frozen, frame_q, frame_t, huber_a, summary);
 }
 
 int cc_rig_optimize_multi(const cc_options* opt, int32_t n_devices, const int32_t* devices, int64_t C, int64_t F,

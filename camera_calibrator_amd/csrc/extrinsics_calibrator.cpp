@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <functional>
 #include <limits>
@@ -41,28 +42,28 @@ size_t ExtrinsicsCalibrator::AddWorldPoint(const size_t frame_id, const Point3D&
   Frame& frame = frames_[frame_id];
   point_refs_.push_back(PointRef{frame_id, frame.points.size()});
   frame.points.push_back(world_point);
+  world_flat_.push_back(world_point.x()); world_flat_.push_back(world_point.y()); world_flat_.push_back(world_point.z());
   return point_refs_.size() - 1;
 }
 
 void ExtrinsicsCalibrator::AddObservation(const size_t camera, const size_t point_global, const Point2D& normalised) {
   const PointRef& info = point_refs_[point_global];
-  Frame::Sighting obs;
-  obs.camera = camera;
-  obs.point_in_frame = info.point_in_frame;
-  obs.point_global = point_global;
-  obs.normalised = normalised;
-  obs.half_rho = std::numeric_limits<double>::quiet_NaN();  // "not evaluated yet"
-  frames_[info.frame].sightings.push_back(obs);  // stored with the point's frame
+  Frame& frame = frames_[info.frame];  // stored with the point's frame
+  frame.obs_camera.push_back(camera < 0xFFFFFFFFull ? (uint32_t)camera : 0xFFFFFFFFu);
+  frame.obs_point_in_frame.push_back((uint32_t)info.point_in_frame);
+  frame.obs_point_global.push_back((uint64_t)point_global);
+  frame.obs_normalised.push_back(normalised);
+  frame.obs_half_rho.push_back(std::numeric_limits<double>::quiet_NaN());  // "not evaluated yet"
 }
 
 void ExtrinsicsCalibrator::GetObservation(size_t frame_id, size_t k, size_t* camera, size_t* point_in_frame,
                                           size_t* point_global, Point2D* normalised, double* half_rho) const {
-  const auto& o = frames_[frame_id].sightings[k];
-  if (camera) *camera = o.camera;
-  if (point_in_frame) *point_in_frame = o.point_in_frame;
-  if (point_global) *point_global = o.point_global;
-  if (normalised) *normalised = o.normalised;
-  if (half_rho) *half_rho = o.half_rho;
+  const Frame& fr = frames_[frame_id];
+  if (camera) *camera = fr.obs_camera[k];
+  if (point_in_frame) *point_in_frame = fr.obs_point_in_frame[k];
+  if (point_global) *point_global = (size_t)fr.obs_point_global[k];
+  if (normalised) *normalised = fr.obs_normalised[k];
+  if (half_rho) *half_rho = fr.obs_half_rho[k];
 }
 
 // ---- the solve -----------------------------------------------------------------------------------
@@ -92,24 +93,29 @@ void ExtrinsicsCalibrator::Optimize() {
   std::vector<double> cam_q(4 * C), cam_t(3 * C), frame_q(4 * F), frame_t(3 * F);
   for (size_t i = 0; i < C; ++i) AffineToQuaternionTranslation(cameras_[i], &cam_q[4 * i], &cam_t[3 * i]);
   for (size_t i = 0; i < F; ++i) AffineToQuaternionTranslation(frames_[i].pose, &frame_q[4 * i], &frame_t[3 * i]);
-  std::vector<float> world(3 * Pn);
+  // the world points by global id, as the solve takes them: kept up to date by AddWorldPoint (no gather, no fresh 12 MB vector per
+  // call at BASELINE configs[4] size); a removed frame leaves it to be rebuilt here
   // (parallel phases run on the library's process-lifetime worker pool, cc_parallel_for: no thread is created per call)
   auto run_parts = [](size_t parts, const std::function<void(size_t)>& fn) {
     struct Ctx { const std::function<void(size_t)>* fn; } ctx{&fn};
     cc_parallel_for((int32_t)parts, [](void* c, int32_t t) { (*static_cast<Ctx*>(c)->fn)((size_t)t); }, &ctx);
   };
-  {
+  if (world_flat_stale_ || world_flat_.size() != 3 * Pn) {
+    world_flat_.resize(3 * Pn);
+    float* wf = world_flat_.data();
     const size_t parts = (size_t)cc_parallel_parts((int64_t)Pn, (int64_t)1 << 16);
     run_parts(parts, [&](size_t t) {
       for (size_t i = Pn * t / parts, b = Pn * (t + 1) / parts; i < b; ++i) {
         const PointRef& info = point_refs_[i];
         const Point3D& p = frames_[info.frame].points[info.point_in_frame];
-        world[3 * i] = p.x(); world[3 * i + 1] = p.y(); world[3 * i + 2] = p.z();
+        wf[3 * i] = p.x(); wf[3 * i + 1] = p.y(); wf[3 * i + 2] = p.z();
       }
     });
+    world_flat_stale_ = false;
   }
+  const std::vector<float>& world = world_flat_;
   std::vector<int64_t> offsets(F + 1, 0);
-  for (size_t f = 0; f < F; ++f) offsets[f + 1] = offsets[f] + (int64_t)frames_[f].sightings.size();
+  for (size_t f = 0; f < F; ++f) offsets[f + 1] = offsets[f] + (int64_t)frames_[f].NumObservations();
   const size_t N = (size_t)offsets[F];
   const bool several = devices_.size() > 1;
   // frames in contiguous ranges of about equal observation counts, one host thread each (flattening for several devices)
@@ -142,14 +148,12 @@ void ExtrinsicsCalibrator::Optimize() {
     half_rho = flat_.rho.data();   // (cc_rig_optimize_multi writes every entry)
     over_frames([&](size_t f0, size_t f1) {
       for (size_t f = f0; f < f1; ++f) {
-        size_t k = (size_t)offsets[f];
-        for (const auto& o : frames_[f].sightings) {
-          obs_cam[k] = (uint32_t)o.camera;
-          obs_world[k] = (uint64_t)o.point_global;
-          obs_uv[2 * k] = o.normalised.x();
-          obs_uv[2 * k + 1] = o.normalised.y();
-          ++k;
-        }
+        const Frame& fr = frames_[f];
+        const size_t k0 = (size_t)offsets[f], n = fr.NumObservations();
+        if (n == 0) continue;
+        std::memcpy(obs_cam + k0, fr.obs_camera.data(), n * sizeof(uint32_t));
+        std::memcpy(obs_world + k0, fr.obs_point_global.data(), n * sizeof(uint64_t));
+        std::memcpy(obs_uv + 2 * k0, fr.obs_normalised.data(), n * 2 * sizeof(float));
       }
     });
   }
@@ -174,24 +178,26 @@ void ExtrinsicsCalibrator::Optimize() {
                                            obs_cam, obs_world, obs_uv, world.data(), cam_q.data(), cam_t.data(),
                                            frozen.data(), frame_q.data(), frame_t.data(), huber_a, half_rho, &summary);
     } else {
-      // one device: the library reads the per-frame lists of sightings where they are and writes the costs into them
-      // (cc_rig_optimize_frames) -- no flat copies, no write-back loop on this side
-      using Sighting = Frame::Sighting;
-      static_assert(sizeof(size_t) == 8 && sizeof(Point2D) == 2 * sizeof(float), "record fields as cc_obs_layout reads them");
-      std::vector<void*> records(F);
+      // one device: the library reads the frames' columns where they are and writes the costs into them
+      // (cc_rig_optimize_columns) -- no flat copies, no write-back loop on this side
+      static_assert(sizeof(Point2D) == 2 * sizeof(float), "an image point is two floats, as cc_obs_columns reads it");
+      std::vector<const void*> p_cam(F), p_world(F), p_uv(F);
+      std::vector<void*> p_cost(F);
       std::vector<int64_t> counts(F);
-      for (size_t f = 0; f < F; ++f) { records[f] = frames_[f].sightings.data(); counts[f] = (int64_t)frames_[f].sightings.size(); }
-      Sighting probe{};
-      const char* p0 = reinterpret_cast<const char*>(&probe);
-      cc_obs_layout lay;
-      lay.stride = (int64_t)sizeof(Sighting);
-      lay.camera_offset = reinterpret_cast<const char*>(&probe.camera) - p0;
-      lay.world_offset = reinterpret_cast<const char*>(&probe.point_global) - p0;
-      lay.uv_offset = reinterpret_cast<const char*>(&probe.normalised) - p0;
-      lay.cost_offset = reinterpret_cast<const char*>(&probe.half_rho) - p0;
-      last_status_ = cc_rig_optimize_frames(&options, device_, (int64_t)C, (int64_t)F, (int64_t)Pn, records.data(), counts.data(), &lay,
-                                            world.data(), cam_q.data(), cam_t.data(), frozen.data(), frame_q.data(), frame_t.data(),
-                                            huber_a, &summary);
+      for (size_t f = 0; f < F; ++f) {
+        Frame& fr = frames_[f];
+        counts[f] = (int64_t)fr.NumObservations();
+        p_cam[f] = fr.obs_camera.data(); p_world[f] = fr.obs_point_global.data(); p_uv[f] = fr.obs_normalised.data();
+        p_cost[f] = fr.obs_half_rho.data();
+      }
+      cc_obs_columns cols{};
+      cols.camera = p_cam.data(); cols.camera_stride = 4; cols.camera_width = 4;
+      cols.world = p_world.data(); cols.world_stride = 8; cols.world_width = 8;
+      cols.uv = p_uv.data(); cols.uv_stride = (int64_t)sizeof(Point2D);
+      cols.cost = p_cost.data(); cols.cost_stride = 8;
+      last_status_ = cc_rig_optimize_columns(&options, device_, (int64_t)C, (int64_t)F, (int64_t)Pn, &cols, counts.data(),
+                                             world.data(), cam_q.data(), cam_t.data(), frozen.data(), frame_q.data(), frame_t.data(),
+                                             huber_a, &summary);
     }
     if (last_status_ == CC_ERR_NO_DEVICE || last_status_ == CC_ERR_HIP || last_status_ == CC_ERR_BAD_ARGUMENT || last_status_ == CC_ERR_COMM)
       throw std::runtime_error(std::string("ExtrinsicsCalibrator::Optimize: ") + cc_last_error());  // no silent CPU path
@@ -220,13 +226,12 @@ void ExtrinsicsCalibrator::Optimize() {
   // recycled from an earlier object, and on one device the library skips its write-back -- zeros in both cases.
   if (last_status_ != 0 && N > 0)
     over_frames([&](size_t f0, size_t f1) {
-      for (size_t f = f0; f < f1; ++f) for (auto& o : frames_[f].sightings) o.half_rho = 0.0;
+      for (size_t f = f0; f < f1; ++f) std::fill(frames_[f].obs_half_rho.begin(), frames_[f].obs_half_rho.end(), 0.0);
     });
   else if (several && N > 0 && C > 0 && F > 0)
     over_frames([&](size_t f0, size_t f1) {
       for (size_t f = f0; f < f1; ++f) {
-        size_t k = (size_t)offsets[f];
-        for (auto& o : frames_[f].sightings) o.half_rho = half_rho[k++];
+        if (frames_[f].NumObservations()) std::memcpy(frames_[f].obs_half_rho.data(), half_rho + offsets[f], frames_[f].NumObservations() * sizeof(double));
       }
     });
   // poses back through float (extrinsics_calibrator.cpp:228-256)
@@ -277,15 +282,15 @@ void ExtrinsicsCalibrator::Serialize(const std::string& fname) const {
     Value f = Value::object();
     f.obj["rig_T_world"] = transform_to_json(frame.pose);
     Value obs = Value::array();
-    for (const auto& o : frame.sightings) {
+    for (size_t k = 0; k < frame.NumObservations(); ++k) {
       Value e = Value::object();
-      e.obj["camera_id"] = Value::integer(o.camera);
-      e.obj["world_point_id"] = Value::integer(o.point_global);
+      e.obj["camera_id"] = Value::integer(frame.obs_camera[k]);
+      e.obj["world_point_id"] = Value::integer(frame.obs_point_global[k]);
       Value ip = Value::array();
-      ip.arr.push_back(Value::number(o.normalised.x()));
-      ip.arr.push_back(Value::number(o.normalised.y()));
+      ip.arr.push_back(Value::number(frame.obs_normalised[k].x()));
+      ip.arr.push_back(Value::number(frame.obs_normalised[k].y()));
       e.obj["image_point"] = ip;
-      e.obj["cost"] = Value::number(o.half_rho);  // NaN -> null
+      e.obj["cost"] = Value::number(frame.obs_half_rho[k]);  // NaN -> null
       obs.arr.push_back(e);
     }
     f.obj["observations"] = obs;
@@ -341,7 +346,8 @@ void ExtrinsicsCalibrator::RemoveObservationFrame(const size_t frame) {
   frames_.erase(frames_.begin() + (std::ptrdiff_t)frame);
   // world point ids of all later frames slide down by the removed frame's point count
   for (size_t f = frame; f < frames_.size(); ++f)
-    for (auto& o : frames_[f].sightings) o.point_global -= removed_points;
+    for (uint64_t& g : frames_[f].obs_point_global) g -= removed_points;
+  world_flat_stale_ = true;   // (rebuilt by the next Optimize)
   point_refs_.erase(std::remove_if(point_refs_.begin(), point_refs_.end(),
                                           [=](const PointRef& w) { return w.frame == frame; }),
                            point_refs_.end());

@@ -60,7 +60,7 @@ class ExtrinsicsCalibrator {
   size_t NumObservationFrames() const { return frames_.size(); }
   size_t NumWorldPoints() const { return point_refs_.size(); }
   bool IsCameraFrozen(size_t id) const { return frozen_.count(id) != 0; }
-  size_t NumObservations(size_t frame_id) const { return frames_[frame_id].sightings.size(); }
+  size_t NumObservations(size_t frame_id) const { return frames_[frame_id].NumObservations(); }
   /// (camera, point_in_frame, point_global, half_rho) of observation k of a frame
   void GetObservation(size_t frame_id, size_t k, size_t* camera, size_t* point_in_frame,
                       size_t* point_global, Point2D* normalised, double* half_rho) const;
@@ -70,14 +70,16 @@ class ExtrinsicsCalibrator {
     explicit Frame(const Eigen::Affine3f& T) : pose(T) {}
     Eigen::Affine3f pose;
     Points3D points;
-    struct Sighting {
-      size_t camera;
-      size_t point_in_frame;  // index inside the frame's points
-      size_t point_global;   // global id
-      Point2D normalised;
-      double half_rho{0.0};
-    };
-    std::vector<Sighting, Eigen::aligned_allocator<Sighting>> sightings;
+    // The observations of the frame's points as COLUMNS, one entry each per observation (round 5; a record per observation
+    // before): the solve streams camera + point + image point (20 bytes) per observation and writes the costs as one array --
+    // at BASELINE configs[4] size (8 M observations) 160 MB read and 64 MB written where 40-byte records cost 320 MB read and
+    // 320 MB read-modified-written (cc_rig_optimize_columns reads and writes these arrays in place).
+    std::vector<uint32_t> obs_camera;          // camera id (ids beyond 2^32 - 2 are kept as 2^32 - 1: never a valid camera)
+    std::vector<uint32_t> obs_point_in_frame;  // index inside the frame's points
+    std::vector<uint64_t> obs_point_global;    // global id
+    std::vector<Point2D, Eigen::aligned_allocator<Point2D>> obs_normalised;
+    std::vector<double> obs_half_rho;
+    size_t NumObservations() const { return obs_camera.size(); }
   };
   struct PointRef {
     size_t frame;
@@ -87,6 +89,8 @@ class ExtrinsicsCalibrator {
   std::vector<Eigen::Affine3f, Eigen::aligned_allocator<Eigen::Affine3f>> cameras_;
   std::vector<Frame, Eigen::aligned_allocator<Frame>> frames_;
   std::vector<PointRef> point_refs_;
+  std::vector<float> world_flat_;   // x y z of every world point by global id (what cc_rig_optimize_* takes), appended by AddWorldPoint
+  bool world_flat_stale_{false};    // a frame was removed: rebuilt from the frames by the next Optimize
   std::set<size_t> frozen_;
   int device_{0};
   std::vector<int> devices_;

@@ -357,6 +357,24 @@ int cc_rig_optimize_frames(const cc_options* opt, int32_t device, int64_t n_cams
                            const float* world_xyz, double* cam_q, double* cam_t, const uint8_t* cam_frozen,
                            double* frame_q, double* frame_t, double huber_a, cc_summary* summary);
 
+/* The same for observations kept frame by frame as COLUMNS (round 5: what ExtrinsicsCalibrator holds now -- per frame one
+ * array of camera ids, one of global world point ids, one of normalised image points, one of costs): column[f] is the first
+ * entry of frame f, entries `*_stride` bytes apart (arrays: the stride is the entry's size; records: the stride of the record
+ * and column pointers into it -- cc_rig_optimize_frames is exactly that). Ids are unsigned, 4 or 8 bytes wide (`*_width`);
+ * the image point two floats; the cost a double, WRITTEN (cost == NULL: not written). A frame without observations may have
+ * NULL entries. Why columns: at 8 M observations the solve streams 20 bytes per observation instead of a 40-byte record and
+ * the costs come back as sequential stores instead of one partial store per record. */
+typedef struct cc_obs_columns {
+  const void* const* camera; int64_t camera_stride; int32_t camera_width;
+  const void* const* world;  int64_t world_stride;  int32_t world_width;
+  const void* const* uv;     int64_t uv_stride;
+  void* const* cost;         int64_t cost_stride;
+} cc_obs_columns;
+int cc_rig_optimize_columns(const cc_options* opt, int32_t device, int64_t n_cams, int64_t n_frames, int64_t n_world,
+                            const cc_obs_columns* columns, const int64_t* counts,
+                            const float* world_xyz, double* cam_q, double* cam_t, const uint8_t* cam_frozen,
+                            double* frame_q, double* frame_t, double huber_a, cc_summary* summary);
+
 /* The same over several devices from one host thread (cf. cc_intrinsics_optimize_multi): frames sharded, cameras and
  * world points replicated; ExtrinsicsCalibrator::SetDevices selects it behind the class surface. */
 int cc_rig_optimize_multi(const cc_options* opt, int32_t n_devices, const int32_t* devices, int64_t n_cams,

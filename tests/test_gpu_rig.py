@@ -497,6 +497,43 @@ def test_frame_by_frame_records_give_the_bits_of_the_flat_arrays(cams, frames, p
         assert np.array_equal(a[k], b[k])
 
 
+@pytest.mark.parametrize("camera_dtype,world_dtype", [(np.uint32, np.uint64), (np.uint64, np.uint32), (np.uint32, np.uint32)])
+def test_frame_by_frame_columns_give_the_bits_of_the_flat_arrays(camera_dtype, world_dtype):
+    """cc_rig_optimize_columns (round 5: what ExtrinsicsCalibrator::Optimize calls on one device -- per frame one array of camera
+    ids, one of point ids, one of image points, one of costs) against cc_rig_optimize on the flattened arrays, ids 4 or 8 bytes
+    wide, with frames that lost observations (one of them empty: NULL column entries)."""
+    sc = po.rig_scenario(4, 40, 30)
+    cq, ct, fq, ft = _inputs(sc)
+    off, cam, world, uv = sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"]
+    rng = np.random.default_rng(5)
+    keep = rng.random(len(cam)) < 0.8
+    keep[off[7]:off[8]] = False
+    counts = np.array([keep[off[f]:off[f + 1]].sum() for f in range(40)])
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    cam, world, uv = cam[keep], world[keep], np.asarray(uv).reshape(-1, 2)[keep]
+    args = (4, off, cam, world, uv, sc["world_xyz"], cq, ct, sc["cam_frozen"], fq, ft)
+    opts = capi.default_options(max_iterations=30)
+    a = capi.rig_optimize(*args, options=opts)
+    b = capi.rig_optimize_columns(*args, options=opts, camera_dtype=camera_dtype, world_dtype=world_dtype)
+    assert a[5]["iterations"] == b[5]["iterations"] and a[5]["final_cost"] == b[5]["final_cost"]
+    for k in range(5):
+        assert np.array_equal(a[k], b[k])
+    c = capi.rig_optimize_columns(*args, options=opts, want_cost=False)     # (no cost column: nothing written, same poses)
+    assert c[4] is None and all(np.array_equal(a[k], c[k]) for k in range(4))
+
+
+def test_columns_that_do_not_make_sense_are_refused():
+    sc = po.rig_scenario(2, 10, 4)
+    cq, ct, fq, ft = _inputs(sc)
+    args = (2, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"], sc["world_xyz"], cq, ct, sc["cam_frozen"], fq, ft)
+    with pytest.raises(capi.CcError, match="not 4 or 8 bytes wide"):
+        capi.rig_optimize_columns(*args, camera_dtype=np.uint16)
+    cam = sc["obs_cam"].copy()
+    cam[17] = 9
+    with pytest.raises(capi.CcError, match="observation 17: camera id out of range"):
+        capi.rig_optimize_columns(2, sc["frame_offsets"], cam, *args[3:])
+
+
 def test_frame_by_frame_records_with_a_bad_id_are_refused():
     sc = po.rig_scenario(2, 10, 4)
     cq, ct, fq, ft = _inputs(sc)
