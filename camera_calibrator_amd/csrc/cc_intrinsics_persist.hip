@@ -189,7 +189,9 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
   if (tid < 9) s_intr[tid] = (Q.restart ? P.init_intr : P.intr)[tid];
   if (tid == 0) s_int[1] = 0;
   __syncthreads();
-  const LmOpts o = *s_opts;
+  // (a reference into LDS, not a copy: twelve doubles alive across the round loop were spilled in the 128-register build of
+  // four teams, and reloaded one by one inside the reduced solve)
+  const LmOpts& o = *s_opts;
   const uint32_t mask = P.mask;
 
   for (int round = 0; round < Q.max_rounds; ++round) {
@@ -318,6 +320,11 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
     __syncthreads();
     PC_MARK(4);
     if (wave == 0) {
+      // (the lane index of THIS round, opaque to the compiler: with the plain one it computes the nine per-lane selects and unit-row
+      // constants of the pinned coordinates once, before the round loop, and keeps them in registers it does not have -- the
+      // 128-register build of four teams reloaded them from scratch one at a time in front of the factorisation, 0.9 us per round)
+      int lane = tid & 63;
+      asm volatile("" : "+v"(lane));
       const int cur = s_ctl->cur & 1;
       const double radius = s_ctl->radius;
       double gmax = sv[PC_GMAXP];   // (the maximum over the pose gradients of all ranks)

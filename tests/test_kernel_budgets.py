@@ -73,9 +73,11 @@ def test_intrinsics_kernels_keep_their_register_allocation():
     t = _table("cc_intrinsics_persist.hip")
     for k in ("k_intr_persist<1>", "k_intr_persist<2>"):
         assert t[k]["vspill"] == 0 and t[k]["scratch"] == 0, (k, t[k])
-    # 1024-thread workgroups: 128 registers; the control workgroup's code (not the workers' main loop) spills, 42 registers in
-    # round 3, 45 now
-    assert t["k_intr_persist<4>"]["vgpr"] <= 128 and t["k_intr_persist<4>"]["vspill"] <= 45, t["k_intr_persist<4>"]
+    # 1024-thread workgroups: 128 registers. Until round 5 the control workgroup's code spilled 45 registers (the options copied out
+    # of LDS and the per-lane selects of the reduced solve, hoisted out of the round loop) and reloaded nine of them one at a time
+    # in front of the 9 x 9 factorisation: 0.9 us per round (profiles/r05/intr_control_spills.jsonl). What is left: four
+    # round-level values of the workers.
+    assert t["k_intr_persist<4>"]["vgpr"] <= 128 and t["k_intr_persist<4>"]["vspill"] <= 8 and t["k_intr_persist<4>"]["scratch"] <= 40, t["k_intr_persist<4>"]
     t = _table("cc_intrinsics.hip")
     k = "cc::k_intr_sweep"
     assert t[k]["vspill"] == 0 and t[k]["scratch"] == 0 and t[k]["vgpr"] <= 128, (k, t[k])
