@@ -75,6 +75,32 @@ def test_struct_layouts_match_header():
     assert C.sizeof(capi.Summary) == 4 * 4 + 3 * 8 + 8 + 2 * 4 + 2 * (8 * 8 + 8 * 4)
 
 
+def test_observation_column_structs_are_what_the_c_compiler_lays_out(tmp_path):
+    """cc_obs_columns / cc_obs_layout as ctypes sees them against the header compiled by gcc (sizes and every field offset)."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("needs gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fields = {"cc_obs_columns": [f for f, _ in capi.ObsColumns._fields_], "cc_obs_layout": [f for f, _ in capi.ObsLayout._fields_]}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "cc_solver.h"', "int main(void) {"]
+    for st, fs in fields.items():
+        src.append('printf("%%zu", sizeof(%s));' % st)
+        src += ['printf(" %%zu", offsetof(%s, %s));' % (st, f) for f in fs]
+        src.append('printf("\\n");')
+    src.append("return 0; }")
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(c), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).split("\n")
+    for line, (st, cls) in zip(out, [("cc_obs_columns", capi.ObsColumns), ("cc_obs_layout", capi.ObsLayout)]):
+        nums = [int(x) for x in line.split()]
+        assert nums[0] == C.sizeof(cls), st
+        assert nums[1:] == [getattr(cls, f).offset for f, _ in cls._fields_], st
+
+
 @pytest.mark.parametrize("nranks", [1, 2, 3, 4, 8])
 def test_partition_frames_uniform(nranks):
     off = np.arange(0, 1001) * 500
