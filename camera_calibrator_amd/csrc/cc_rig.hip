@@ -1830,17 +1830,34 @@ int cc_rig_get_state(cc_rig* h, double* cam_q, double* cam_t, double* frame_q, d
     double* sorted = static_cast<double*>(staging_get((size_t)h->N * sizeof(double), &st_cached));
     if (!sorted) return fail(CC_ERR_HIP, "cc_rig_get_state: pinned staging memory could not be allocated");
     struct StGuard { void* p; hipStream_t s; ~StGuard() { (void)hipStreamSynchronize(s); staging_put(p); } } stg{sorted, h->stream};
-    CC_HIP(hipMemcpyAsync(sorted, h->d_cost, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    CC_HIP(hipStreamSynchronize(h->stream));
     const int64_t* perm = h->perm.data();
     if (h->perm_inverse) {   // (a handle made from columns: frame by frame)
+      CC_HIP(hipMemcpyAsync(sorted, h->d_cost, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      CC_HIP(hipStreamSynchronize(h->stream));
       const int32_t* rel = reinterpret_cast<const int32_t*>(perm);
       for (int64_t f = 0; f < h->F; ++f) {
         const int64_t a = h->goff_h[(size_t)h->fgoff_h[(size_t)f]], b = h->goff_h[(size_t)h->fgoff_h[(size_t)f + 1]];
         for (int64_t i = a; i < b; ++i) obs_cost[i] = sorted[a + rel[i]];
       }
     } else {
-      parallel_ranges(h->N, (int64_t)1 << 15, [&](int, int64_t a, int64_t b) { for (int64_t i = a; i < b; ++i) obs_cost[perm[i]] = sorted[i]; });
+      // one transfer and one event per worker's range: a worker scatters its range as soon as it has arrived, under the
+      // transfers of the ranges behind it (as cc_rig_optimize_columns does)
+      const int parts = parallel_parts(h->N, (int64_t)1 << 17);
+      std::vector<hipEvent_t> ev((size_t)parts, nullptr);
+      struct EvGuard { std::vector<hipEvent_t>& e; ~EvGuard() { for (auto x : e) if (x) (void)hipEventDestroy(x); } } evg{ev};
+      for (int t = 0; t < parts; ++t) {
+        const int64_t a = h->N * t / parts, b = h->N * (t + 1) / parts;
+        if (b > a) CC_HIP(hipMemcpyAsync(sorted + a, h->d_cost + a, (size_t)(b - a) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        CC_HIP(hipEventCreateWithFlags(&ev[(size_t)t], hipEventDisableTiming));
+        CC_HIP(hipEventRecord(ev[(size_t)t], h->stream));
+      }
+      std::vector<char> bad((size_t)parts, 0);
+      parallel_tasks(parts, [&](int t) {
+        if (hipSetDevice(h->device) != hipSuccess || hipEventSynchronize(ev[(size_t)t]) != hipSuccess) { bad[(size_t)t] = 1; return; }
+        for (int64_t i = h->N * t / parts, b = h->N * (t + 1) / parts; i < b; ++i) obs_cost[perm[i]] = sorted[i];
+      });
+      CC_HIP(hipStreamSynchronize(h->stream));
+      for (char b : bad) if (b) return fail(CC_ERR_HIP, "cc_rig_get_state: the read-back of the costs failed");
     }
   }
   return CC_OK;
