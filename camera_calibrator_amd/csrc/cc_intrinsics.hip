@@ -251,20 +251,13 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
     ObsCommon oc;
     obs_common(kk, R, tt, (double)X0, (double)X1, (double)X2, oc);
     double v[16];
-    row_u(kk, oc, (double)m.x, mask, v);
-    if (!valid) {
-#pragma unroll
-      for (int c = 0; c < 16; ++c) v[c] = 0.0;
-    }
+    const double wrow = valid ? 1.0 : 0.0;   // (an idle lane's rows are zero: the weight rides on the rows' factors)
+    row_u(kk, oc, (double)m.x, v, wrow);
     stage_row(stage, lane, v);
     wave_lds_fence();
     gram_rows(stage, lane, acc0, acc1);
     wave_lds_fence();
-    row_v(kk, oc, (double)m.y, mask, v);
-    if (!valid) {
-#pragma unroll
-      for (int c = 0; c < 16; ++c) v[c] = 0.0;
-    }
+    row_v(kk, oc, (double)m.y, v, wrow);
     stage_row(stage, lane, v);
     wave_lds_fence();
     gram_rows(stage, lane, acc0, acc1);
@@ -279,7 +272,7 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
 #pragma unroll
   for (int r = 0; r < 4; ++r) s_blk[wave * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc0[r] + acc1[r];
   __syncthreads();
-  const double g = (s_blk[tid] + s_blk[256 + tid]) + (s_blk[512 + tid] + s_blk[768 + tid]);
+  const double g = gram_entry_held(mask, tid) ? 0.0 : (s_blk[tid] + s_blk[256 + tid]) + (s_blk[512 + tid] + s_blk[768 + tid]);   // (constant coordinates: zero rows and columns)
   P.blocks[(((size_t)dst * P.F + f) * T + tile) * 256 + tid] = g;
   SW_MARK(6);
   // per-tile statistics row (the per-frame quantities ride on tile 0): written by the thread that holds entry (15, 15)

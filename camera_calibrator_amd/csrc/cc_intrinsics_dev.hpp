@@ -87,34 +87,37 @@ __device__ __forceinline__ void obs_common(const double* k, const double* R, con
   c.dyy = m + 2.0 * mp * yy + 2.0 * p2 * c.x + 6.0 * p1 * c.y;
 }
 
-// row of the u residual: d (fx xd + px - u) / d [fx fy px py k1 k2 p1 p2 k3 | rot(3) t(3)], then r
-__device__ __forceinline__ void row_u(const double* k, const ObsCommon& c, double u, uint32_t mask, double* v) {
-  const double fx = k[0];
-  v[15] = fx * c.xd + k[2] - u;
-  v[0] = c.xd; v[1] = 0.0; v[2] = 1.0; v[3] = 0.0;
+// row of the u residual: d (fx xd + px - u) / d [fx fy px py k1 k2 p1 p2 k3 | rot(3) t(3)], then r.
+// w = 1: the row; w = 0 (a lane beyond the frame's last observation; it evaluates a real observation of the frame, so everything
+// is finite): a row of zeros. The weight rides on the row's factors -- fx w takes the ten entries that carry fx, three more
+// products take the rest -- where zeroing the 14 entries afterwards took 28 conditional moves (round 5; with w = 1 the bits
+// are the same as before). (Written as selects -- `valid ? fx : 0` -- the compiler builds a divergent region around the row and
+// parks all sixteen entries in scratch: 90 spilled registers at four teams.)
+// Coordinates held constant (SubsetManifold, calibrator.cpp:305-312) are NOT zeroed here, nine selects a row: their rows and
+// columns of the frame's Gram block are zeroed once, where the block is assembled (gram_entry_held) -- sums of zeros are zero.
+__device__ __forceinline__ void row_u(const double* k, const ObsCommon& c, double u, double* v, double w = 1.0) {
+  const double fx = k[0] * w;
+  v[15] = (k[0] * c.xd + k[2] - u) * w;
+  v[0] = c.xd * w; v[1] = 0.0; v[2] = w; v[3] = 0.0;
   const double fxx = fx * c.x;
   v[4] = fxx * c.r2; v[5] = fxx * c.r4; v[6] = fx * 2.0 * c.xy; v[7] = fx * c.ax; v[8] = fxx * c.r6;
   const double b0 = fx * c.dxx * c.iz, b1 = fx * c.dxy * c.iz, b2 = -(b0 * c.x + b1 * c.y);
   v[9] = 2.0 * (b2 * c.a1 - b1 * c.a2); v[10] = 2.0 * (b0 * c.a2 - b2 * c.a0); v[11] = 2.0 * (b1 * c.a0 - b0 * c.a1);
   v[12] = b0; v[13] = b1; v[14] = b2;
-#pragma unroll
-  for (int j = 0; j < 9; ++j)
-    if (mask & (1u << j)) v[j] = 0.0;  // SubsetManifold (calibrator.cpp:305-312)
 }
 
-__device__ __forceinline__ void row_v(const double* k, const ObsCommon& c, double vm, uint32_t mask, double* v) {
-  const double fy = k[1];
-  v[15] = fy * c.yd + k[3] - vm;
-  v[0] = 0.0; v[1] = c.yd; v[2] = 0.0; v[3] = 1.0;
+__device__ __forceinline__ void row_v(const double* k, const ObsCommon& c, double vm, double* v, double w = 1.0) {
+  const double fy = k[1] * w;
+  v[15] = (k[1] * c.yd + k[3] - vm) * w;
+  v[0] = 0.0; v[1] = c.yd * w; v[2] = 0.0; v[3] = w;
   const double fyy = fy * c.y;
   v[4] = fyy * c.r2; v[5] = fyy * c.r4; v[6] = fy * c.ay; v[7] = fy * 2.0 * c.xy; v[8] = fyy * c.r6;
   const double b0 = fy * c.dxy * c.iz, b1 = fy * c.dyy * c.iz, b2 = -(b0 * c.x + b1 * c.y);
   v[9] = 2.0 * (b2 * c.a1 - b1 * c.a2); v[10] = 2.0 * (b0 * c.a2 - b2 * c.a0); v[11] = 2.0 * (b1 * c.a0 - b0 * c.a1);
   v[12] = b0; v[13] = b1; v[14] = b2;
-#pragma unroll
-  for (int j = 0; j < 9; ++j)
-    if (mask & (1u << j)) v[j] = 0.0;
 }
+// entry e = 16 row + col of a frame's 16 x 16 Gram block: does it belong to a coordinate held constant (mask bit j = intrinsic j)?
+__device__ __forceinline__ bool gram_entry_held(uint32_t mask, int e) { return (((mask >> (e >> 4)) | (mask >> (e & 15))) & 1u) != 0; }
 
 // Hands the control block to the host without a copy engine in the way: payload words first, then the
 // sequence word the host spins on (system-scope stores into pinned host memory; one thread).

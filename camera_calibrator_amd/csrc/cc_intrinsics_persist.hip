@@ -179,7 +179,7 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
   LmOpts* s_opts = reinterpret_cast<LmOpts*>(lds + 1252);      // 12 doubles
   cc_iteration* s_log = reinterpret_cast<cc_iteration*>(lds + 1264);
   int* s_int = reinterpret_cast<int*>(lds + 1296);             // [0] gather ok, [1] a record was logged this round
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, wave = tid >> 6;
   static_assert(sizeof(cc_iteration) <= 32 * 8, "log record scratch");
   // initial state: a fresh control block (every launch is a whole solve), options, intrinsics of the starting point
   if (tid < (int)(sizeof(LmCtl) / 8)) reinterpret_cast<double*>(s_ctl)[tid] = 0.0;
@@ -624,20 +624,13 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
         ObsCommon oc;
         obs_common(kk, R, tt, (double)X0, (double)X1, (double)X2, oc);
         double v[16];
-        row_u(kk, oc, (double)m.x, mask, v);
-        if (!valid) {
-#pragma unroll
-          for (int c = 0; c < 16; ++c) v[c] = 0.0;
-        }
+        const double wrow = valid ? 1.0 : 0.0;   // (an idle lane's rows are zero: the weight rides on the rows' factors)
+        row_u(kk, oc, (double)m.x, v, wrow);
         stage_row(stage, lane, v);
         wave_lds_fence();
         gram_rows_ahead(stage, lane, acc0, acc1);
         wave_lds_fence();
-        row_v(kk, oc, (double)m.y, mask, v);
-        if (!valid) {
-#pragma unroll
-          for (int c = 0; c < 16; ++c) v[c] = 0.0;
-        }
+        row_v(kk, oc, (double)m.y, v, wrow);
         stage_row(stage, lane, v);
         wave_lds_fence();
         gram_rows_ahead(stage, lane, acc0, acc1);
@@ -654,7 +647,7 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) s_blk[twave * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc0[r] + acc1[r];
       __syncthreads();
-      const double g = (s_blk[ttid] + s_blk[256 + ttid]) + (s_blk[512 + ttid] + s_blk[768 + ttid]);
+      const double g = gram_entry_held(mask, ttid) ? 0.0 : (s_blk[ttid] + s_blk[256 + ttid]) + (s_blk[512 + ttid] + s_blk[768 + ttid]);   // (constant coordinates: zero rows and columns)
       s_G[(team * 2 + dst) * 256 + ttid] = g;
       if (ttid == 255) {
         sm[TM_STAT + ST_COST] = 0.5 * g;
