@@ -1410,7 +1410,7 @@ __device__ void rig_solve_block(const RigDev& P, double* smem, const LmCtl* cn_i
     }
     __syncthreads();
 #ifndef CC_RIG_PANEL8
-  } else if (s_go && S <= 63) {   // (chol_block4: the right-hand side is row S on lane S of wave 0)
+  } else if (SRC != 3 && s_go && S <= 63) {   // (chol_block4: the right-hand side is row S on lane S of wave 0; SRC 3 -- the lean form's control workgroup -- only ever has S <= 24: the larger routines are not compiled into its kernel)
     // ---- medium systems: four columns at a time on all four waves, right-hand side as row S (chol_block4)
 #ifdef CC_RIG_TIMING
     const long long tf0 = wall_clock64();
@@ -1437,7 +1437,7 @@ __device__ void rig_solve_block(const RigDev& P, double* smem, const LmCtl* cn_i
     if (tid == 0) P.shared_stats[19] = (double)wall_clock64();
 #endif
 #endif
-  } else if (s_go) {
+  } else if (SRC != 3 && s_go) {
     // ---- Cholesky of the damped reduced system in LDS, eight columns at a time (S <= 127):
     //   panel:    wave 0 (chol_panel), forward substitution included;
     //   trailing: all 256 threads, A[i][k] -= sum_c L[i][c] L[k][c] over the panel's columns; two barriers per panel.
