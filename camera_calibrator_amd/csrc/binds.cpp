@@ -153,6 +153,7 @@ PYBIND11_MODULE(pycalibrator, m) {
       .def("LastStatus", &Calibrator::LastStatus)
       .def("LastIterations", &Calibrator::LastIterations)
       .def("LastSolverReruns", &Calibrator::LastSolverReruns)
+      .def("LastSolverForm", &Calibrator::LastSolverForm)
       .def("LastSolverNote", &Calibrator::LastSolverNote)
       .def("LastFinalCost", &Calibrator::LastFinalCost);
 
@@ -176,6 +177,7 @@ PYBIND11_MODULE(pycalibrator, m) {
       .def("LastStatus", &ExtrinsicsCalibrator::LastStatus)
       .def("LastIterations", &ExtrinsicsCalibrator::LastIterations)
       .def("LastSolverReruns", &ExtrinsicsCalibrator::LastSolverReruns)
+      .def("LastSolverForm", &ExtrinsicsCalibrator::LastSolverForm)
       .def("LastSolverNote", &ExtrinsicsCalibrator::LastSolverNote)
       .def("LastFinalCost", &ExtrinsicsCalibrator::LastFinalCost)
       .def("NumCameras", &ExtrinsicsCalibrator::NumCameras)

@@ -62,6 +62,17 @@ struct PackedViews {
 
 Calibrator::Calibrator(const int image_width, const int image_height) : image_w_(image_width), image_h_(image_height) {}
 
+// What LastSolverReruns() / LastSolverNote() report: the status of the library call this thread has just made
+// (cc_last_call_solver_status) -- a persistent solve that gave up and was run again in the several-kernel form shows here.
+void Calibrator::ReadSolverStatus() {
+  char note[640] = "";
+  int32_t form = 0, reruns = 0;
+  cc_last_call_solver_status(&form, &reruns, note, (int32_t)sizeof(note));
+  last_solver_reruns_ = reruns;
+  last_solver_form_ = form;
+  last_solver_note_ = note;
+}
+
 void Calibrator::EstimateOpenCv(const std::vector<Points2D>&, const std::vector<Points3D>&) {
   (void)image_w_;
   (void)image_h_;
@@ -107,20 +118,7 @@ void Calibrator::Estimate(const std::vector<Points2D>& pixels_per_view, const st
     if (last_status_ == CC_ERR_NO_DEVICE || last_status_ == CC_ERR_HIP || last_status_ == CC_ERR_COMM || last_status_ == CC_ERR_BAD_ARGUMENT)
       throw std::runtime_error(std::string("Calibrator::Estimate: ") + cc_last_error());
     last_iterations_ = summary.iterations;
-  {
-    char note[640] = "";
-    int32_t form = 0, reruns = 0;
-    cc_last_call_solver_status(&form, &reruns, note, (int32_t)sizeof(note));
-    last_solver_reruns_ = reruns;
-    last_solver_note_ = note;
-  }
-    {
-      char note[640] = "";
-      int32_t form = 0, reruns = 0;
-      cc_last_call_solver_status(&form, &reruns, note, (int32_t)sizeof(note));
-      last_solver_reruns_ = reruns;
-      last_solver_note_ = note;
-    }
+    ReadSolverStatus();
     last_final_cost_ = summary.final_cost;
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) camera_matrix_(r, c) = K9[r * 3 + c];
     camera_matrix_(0, 0) = static_cast<float>(intr[FX]);
@@ -199,6 +197,13 @@ void Calibrator::Optimize(const std::vector<Points2D>& pixels_per_view, const st
   }
   last_iterations_ = summary.iterations;
   last_final_cost_ = summary.final_cost;
+  if (n_img == 0) {
+    last_solver_reruns_ = 0;
+    last_solver_form_ = 0;
+    last_solver_note_.clear();
+  } else {
+    ReadSolverStatus();  // (the several-device route included: cc_intrinsics_optimize_multi records its call the same way)
+  }
   if (last_status_ == CC_ERR_NO_DEVICE || last_status_ == CC_ERR_HIP || last_status_ == CC_ERR_COMM)
     throw std::runtime_error(std::string("Calibrator::Optimize: ") + cc_last_error());  // no silent CPU path
 

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -307,6 +308,61 @@ void pool_free(int device, void* p, size_t bytes) {
 std::mutex& persist_mutex(int device) {
   static std::mutex table[64];
   return table[device >= 0 && device < 64 ? device : 0];
+}
+
+namespace {
+struct PersistBackoff {
+  int level = 0;            // give-ups in a row (0: no window)
+  int64_t calls_left = 0;   // solves still to be turned away
+  std::chrono::steady_clock::time_point until{};
+  bool probing = false;     // one solve is out probing: the others keep to the several-kernel form until it reports
+};
+std::mutex g_backoff_mu;
+PersistBackoff g_backoff[64][2];
+PersistBackoff& backoff_of(int device, int kind) { return g_backoff[device >= 0 && device < 64 ? device : 0][kind ? 1 : 0]; }
+}  // namespace
+
+bool persist_test_drop_control(const char* env_name, int* remaining) {
+  std::lock_guard<std::mutex> lk(g_backoff_mu);
+  if (*remaining == -2) {
+    const char* e = getenv(env_name);
+    if (!e || !*e || std::strcmp(e, "0") == 0) *remaining = 0;
+    else if (std::strncmp(e, "first", 5) == 0) *remaining = std::max(0, atoi(e + 5));
+    else *remaining = -1;   // every launch
+  }
+  if (*remaining == -1) return true;
+  if (*remaining > 0) { --*remaining; return true; }
+  return false;
+}
+
+bool persist_device_try(int device, int kind) {
+  std::lock_guard<std::mutex> lk(g_backoff_mu);
+  PersistBackoff& b = backoff_of(device, kind);
+  if (b.level == 0) return true;
+  if (b.probing) return false;
+  if (b.calls_left > 0) --b.calls_left;
+  if (b.calls_left > 0 || std::chrono::steady_clock::now() < b.until) return false;
+  b.probing = true;
+  return true;
+}
+
+void persist_device_gave_up(int device, int kind) {
+  static const char* e_calls = getenv("CC_PERSIST_BACKOFF_CALLS");     // (tests: a window short enough to watch the re-probe)
+  static const char* e_ms = getenv("CC_PERSIST_BACKOFF_MS");
+  std::lock_guard<std::mutex> lk(g_backoff_mu);
+  PersistBackoff& b = backoff_of(device, kind);
+  b.level = std::min(b.level + 1, 8);
+  b.probing = false;
+  const int64_t calls0 = e_calls ? std::max(1, atoi(e_calls)) : 8;
+  const int64_t ms0 = e_ms ? std::max(0, atoi(e_ms)) : 2000;
+  b.calls_left = std::min<int64_t>(calls0 << (b.level - 1), 1024) + 1;   // (+ 1: persist_device_try counts before it looks)
+  b.until = std::chrono::steady_clock::now() + std::chrono::milliseconds(std::min<int64_t>(ms0 << (b.level - 1), 600000));
+}
+
+void persist_device_completed(int device, int kind) {
+  std::lock_guard<std::mutex> lk(g_backoff_mu);
+  PersistBackoff& b = backoff_of(device, kind);
+  if (b.level != 0) b = PersistBackoff{};
 }
 
 // Solver form / reruns of the handles this thread's last one-shot call worked with (the call destroys them before it returns:

@@ -58,6 +58,20 @@ void pool_free(int device, void* p, size_t bytes);
 // each other's compute units or hardware queues (a process has four; streams share them) until both give up after 1.3 s.
 // The second caller waits here instead. Not taken by the sharded forms (their ranks must run together by construction).
 std::mutex& persist_mutex(int device);
+// What a device has told this PROCESS about persistent solves (the one-shot entry points create and destroy a handle per
+// call, so a handle's own memory of a give-up dies with it: a second tenant on the GPU, or a tool that serialises kernels,
+// would otherwise make EVERY Calibrator::Estimate / ExtrinsicsCalibrator::Optimize wait out the kernel's timeout). After a
+// give-up the device is in a back-off window: persist_device_try() says no for the next `calls` solves AND `seconds`
+// (both must have passed), then lets exactly one solve probe the persistent form again; a second give-up doubles the
+// window (8 solves / 2 s at first, at most 1024 solves / 10 min), a solve that completes ends it. kind: 0 the intrinsics
+// kernel, 1 the lean rig pair.
+// Test hook of the persistent forms (CC_INTR_PERSIST_TEST_NO_CONTROL / CC_RIG_PERSIST_TEST_NO_CONTROL: launch the grid WITHOUT its
+// control workgroup so that the workers' first wait gives up): "1" every launch of the process, "firstN" its first N only,
+// unset / "0" none. `remaining` is the caller's static counter (-2: not parsed yet).
+bool persist_test_drop_control(const char* env_name, int* remaining);
+bool persist_device_try(int device, int kind);
+void persist_device_gave_up(int device, int kind);
+void persist_device_completed(int device, int kind);
 void rig_release_host_caches();   // (cc_rig.hip: the permutation storage kept for the next rig handle; part of cc_release_caches)
 int parallel_parts(int64_t n, int64_t min_per_part);
 void parallel_tasks(int parts, const std::function<void(int)>& fn);   // fn(0 .. parts-1), one host thread each

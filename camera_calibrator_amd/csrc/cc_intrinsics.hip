@@ -1044,6 +1044,7 @@ struct cc_intrinsics {
   std::vector<int> event_round;   // round of the solve a probed launch belongs to (summarise_probes)
   int enq_round = 0;
   // persistent per-solve kernel (cc_intrinsics_persist.hip): usable when every frame gets a team of a resident workgroup
+  int ran_form = -1;            // the form the handle's LAST solve ran in to its end (-1: none yet): 0 two kernels per iteration, else frames per persistent workgroup
   int form_reruns = 0;          // persistent solves that gave up and were run again in the two-kernel form (cc_intrinsics_solver_status)
   std::string form_note;        // why
   bool persist_ok = false;      // ... on a device of its own
@@ -1423,7 +1424,7 @@ int intr_create_impl(cc_intrinsics* h, const int64_t* off, const float* uv, cons
 extern "C" {
 
 void cc_intrinsics_destroy(cc_intrinsics* h) {
-  if (h) cc::last_call_status_record(cc_intrinsics_solver_form(h), h->form_reruns, h->form_note);   // (what a one-shot call's caller can still ask for)
+  if (h) cc::last_call_status_record(h->ran_form >= 0 ? h->ran_form : cc_intrinsics_solver_form(h), h->form_reruns, h->form_note);   // (what a one-shot call's caller can still ask for)
   if (!h) return;
   hipSetDevice(h->device);
   bool stream_ok = true;
@@ -1671,9 +1672,11 @@ static int persistent_launch(cc_intrinsics* h, SolveRun* r) {
   q.epoch0 = h->p_epoch;
   h->p_epoch += need;
   q.timeout_shift = h->exchange ? 30 : 27;
+  q.first_shift = h->exchange ? 30 : 20;
   // (CC_INTR_PERSIST_TEST_NO_CONTROL: test hook for the rerun in the two-kernel form, tests/test_gpu_intrinsics.py)
-  static const bool drop_control = getenv("CC_INTR_PERSIST_TEST_NO_CONTROL") != nullptr;
-  persist_launch(h->d, q, drop_control && !h->exchange, h->stream);
+  static int drop_left = -2;
+  const bool drop_control = !h->exchange && persist_test_drop_control("CC_INTR_PERSIST_TEST_NO_CONTROL", &drop_left);
+  persist_launch(h->d, q, drop_control, h->stream);
   CC_HIP(hipGetLastError());
   h->reset_pending = false;
   r->launched = q.max_rounds;
@@ -1749,11 +1752,17 @@ int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* sum
   if (!h || !h->have_state) return fail(CC_ERR_STATE, "cc_intrinsics_solve: no state set");
   SolveRun r;
   if (int rc = solve_begin(h, opt, &r)) return rc;
-  if (use_persistent(h, &r)) {
+  // (alone on its device the handle also asks what the DEVICE has said about persistent solves lately -- persist_device_try,
+  // cc_common.hpp: a one-shot caller's handle is new every call, so after a give-up the device's back-off window, not this
+  // handle's memory, keeps the next solves on the two-kernel form; one solve probes again when the window is over. The
+  // sharded forms decide collectively, once, at attach time.)
+  const bool alone = !h->exchange && !h->comm;
+  if (use_persistent(h, &r) && (!alone || persist_device_try(h->device, 0))) {
     // ONE launch runs the whole solve (cc_intrinsics_persist.hip); the host waits for its publication
     const bool was_restart = h->reset_pending;
     const int rc = solve_persistent(h, &r);
-    if (rc == CC_OK) return solve_finish(h, &r, summary);
+    if (alone) { if (rc == CC_OK) persist_device_completed(h->device, 0); else persist_device_gave_up(h->device, 0); }
+    if (rc == CC_OK) { h->ran_form = h->pq.teams; return solve_finish(h, &r, summary); }
     if (rc != CC_ERR_COMM || h->exchange) return rc;
     // A wait inside the kernel gave up after 1.3 s: its workgroups were not all resident (another process on the device,
     // a compute-unit mask). Nothing was written back, so the solve is run again -- and this handle keeps to -- the
@@ -1778,6 +1787,7 @@ int cc_intrinsics_solve(cc_intrinsics* h, const cc_options* opt, cc_summary* sum
     if (int rc = solve_wait(h, &r)) return rc;
     if (r.st.done) break;
   }
+  h->ran_form = 0;
   return solve_finish(h, &r, summary);
 }
 

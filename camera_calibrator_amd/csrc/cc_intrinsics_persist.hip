@@ -202,8 +202,8 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
     // outcome of an LM step that works. A decision that says otherwise (rejection, a mediocre step, the first round) is
     // a MISS: it is broadcast on its own and the workers eliminate again with what it says.
     PC_MARK(0);
-    if (phase0) gather_rows<kPStatCols, THREADS / kPStatCols>(Q.sbox, Q.G, e1, 13, -1, s_part, s_tot, Q.fail, s_int, Q.timeout_shift);
-    else gather_stats4<THREADS>(Q.sbox, Q.G, e1, s_part, s_tot, Q.fail, s_int, Q.timeout_shift);
+    if (phase0) gather_rows<kPStatCols, THREADS / kPStatCols>(Q.sbox, Q.G, e1, 13, -1, s_part, s_tot, Q.fail, s_int, (phase0 ? Q.first_shift : Q.timeout_shift));
+    else gather_stats4<THREADS>(Q.sbox, Q.G, e1, s_part, s_tot, Q.fail, s_int, (phase0 ? Q.first_shift : Q.timeout_shift));
     if (P.x.on) {
       // several GPUs (mailbox exchange, cc_device.hpp): this rank's sums go into every rank's mailbox, the slots are added
       // in rank order -- the same sequence of exchanges, payloads and sums as k_intr_decide_elim<3> makes, skipped like
@@ -282,7 +282,7 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
     const unsigned erow = hit ? e2 : e3;
     PC_MARK(3);
     // (the leaders among the workers have added the elimination rows sixteen at a time: one round trip here)
-    gather_rows<kPartialCols, THREADS / kPartialCols, (kPLeaderRows + THREADS / kPartialCols - 1) / (THREADS / kPartialCols)>(Q.lbox, (Q.G + kPLeaderRows - 1) / kPLeaderRows, erow, kPartialCols, PC_GMAXP, s_part, sv, Q.fail, s_int, Q.timeout_shift);
+    gather_rows<kPartialCols, THREADS / kPartialCols, (kPLeaderRows + THREADS / kPartialCols - 1) / (THREADS / kPartialCols)>(Q.lbox, (Q.G + kPLeaderRows - 1) / kPLeaderRows, erow, kPartialCols, PC_GMAXP, s_part, sv, Q.fail, s_int, (phase0 ? Q.first_shift : Q.timeout_shift));
     if (P.x.on) {
       // all-reduce of the 112 sums through the mailboxes (kind 0): the maximum of the pose gradients rides in a slot per rank
       if (tid >= kPartialCols && tid < kVecSolve) sv[tid] = 0.0;
@@ -831,7 +831,7 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
       const int g0 = (int)blockIdx.x, n = Q.G - g0 < kPLeaderRows ? Q.G - g0 : kPLeaderRows;
       double* lout = s_wg + 128;        // [80]; the group sums go through team 0's staging tiles (idle between sweeps)
       gather_rows<kPartialCols, THREADS / kPartialCols, (kPLeaderRows + THREADS / kPartialCols - 1) / (THREADS / kPartialCols)>(box + (size_t)g0 * (2 * kPartialCols), n, tag, kPartialCols, PC_GMAXP, s_stage + 2048, lout,
-                                                        Q.fail, s_lok, Q.timeout_shift);
+                                                        Q.fail, s_lok, (phase0 ? Q.first_shift : Q.timeout_shift));
       PW_MARK(11);
       CC_FRESH_TID(tid);
       // (rows that did not arrive: nothing is posted, the control's own wait gives up and ends the solve -- as a failure)
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
     // one wave waits for the control's broadcast `tag` (flags, radius, nine doubles) -> s_wg[WG_X ..]
     auto wait_bcast = [&](const unsigned tag) {
       CC_FRESH_TID(tid);
-      if (wave == 0 && !bcast_wait(Q.xbox, tag, 11, s_wg + WG_X, Q.fail, tid & 63, Q.timeout_shift)) s_wg[WG_X] = 17.0;   // done + failed
+      if (wave == 0 && !bcast_wait(Q.xbox, tag, 11, s_wg + WG_X, Q.fail, tid & 63, (phase0 ? Q.first_shift : Q.timeout_shift))) s_wg[WG_X] = 17.0;   // done + failed
       __syncthreads();
     };
 

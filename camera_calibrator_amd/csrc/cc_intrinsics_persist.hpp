@@ -28,6 +28,9 @@ struct PersistDev {
   int32_t stagger;            // team k enters the sweep's main loop k * stagger sleep units late (0: in lockstep)
   int32_t timeout_shift;      // a wait gives up after 2^shift ticks of the 100 MHz wall clock: 27 (1.3 s) alone on the device,
                               // 30 (10.7 s, the mailbox exchange's patience) with peer ranks
+  int32_t first_shift;        // ... and the waits of the FIRST round: 20 (10.5 ms) alone on the device -- a first round that has not
+                              // come together by then (every workgroup started, one sweep of at most ~0.1 ms) never will, and the
+                              // caller gets its rerun in the two-kernel form after 10 ms instead of 1.3 s; with peer ranks as above
 };
 
 // workgroups of the `teams`-frame variant that can be resident on `device` at once (occupancy query x CUs)

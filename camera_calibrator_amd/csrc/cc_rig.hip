@@ -400,6 +400,7 @@ struct cc_rig {
   double* d_cam_backup = nullptr;   // [C][8] cameras of the starting point (the lean persistent solve may be run again in the three-kernel form)
   int p_teams = 4;              // frames per workgroup of the lean form
   bool persist_w_ok = false;    // ... and so can its lean form (k_rig_persist_w + k_rig_persist_ctl: <= 4 observed cameras, <= 24 shared coordinates)
+  int ran_form = -1;               // the form the handle's LAST solve ran in to its end (-1: none yet): 0 three kernels per iteration, 2 the lean persistent pair
   int form_reruns = 0;             // lean persistent solves that gave up and were run again in the three-kernel form
   int lean_strikes = 0;            // ... of them in the first round, in a row (two demote the handle)
   std::string form_note;           // why (cc_rig_solver_status)
@@ -1423,7 +1424,7 @@ int cc_rigk_get_camera_intrinsics(cc_rig* h, int64_t camera, double* intr9) {
 int cc_rigk_get_intrinsics(cc_rig* h, double* intr9) { return cc_rigk_get_camera_intrinsics(h, 0, intr9); }
 
 void cc_rig_destroy(cc_rig* h) {
-  if (h) cc::last_call_status_record(cc_rig_solver_form(h), h->form_reruns, h->form_note);   // (what a one-shot call's caller can still ask for)
+  if (h) cc::last_call_status_record(h->ran_form >= 0 ? h->ran_form : cc_rig_solver_form(h), h->form_reruns, h->form_note);   // (what a one-shot call's caller can still ask for)
   if (!h) return;
   cc::HostPhases hp("cc_rig_destroy");
   hipSetDevice(h->device);
@@ -1592,7 +1593,8 @@ static int rig_launch(cc_rig* h, RigRun* r, int chunk) {
     if (!h->ev_begin) CC_HIP(hipEventCreateWithFlags(&h->ev_begin, hipEventDisableTiming));
     CC_HIP(hipEventRecord(h->ev_begin, h->stream));
     CC_HIP(hipStreamWaitEvent(h->stream2, h->ev_begin, 0));
-    static const bool drop_control = getenv("CC_RIG_PERSIST_TEST_NO_CONTROL") && atoi(getenv("CC_RIG_PERSIST_TEST_NO_CONTROL")) != 0;   // (test hook: the workers' first wait gives up)
+    static int drop_left = -2;
+    const bool drop_control = persist_test_drop_control("CC_RIG_PERSIST_TEST_NO_CONTROL", &drop_left);   // (test hook: the workers' first wait gives up)
     // Workers first; the control's candidates are launched when every worker is RESIDENT (the last worker to start stores the
     // solve's tag into a pinned word this thread spins on: ~10 us, once per solve), so that whichever candidate runs first sits
     // on a compute unit no worker needs. (First version of the round: hipStreamWaitValue32 on signal memory -- right, but a
@@ -1740,6 +1742,15 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
   HostPhases hp("cc_rig_solve");
   if (int rc = rig_begin(h, opt, &r)) return rc;
   hp.mark("begin");
+  // What the DEVICE has said about lean solves lately (persist_device_try, cc_common.hpp): a one-shot caller's handle is new
+  // every call, so after a give-up the device's back-off window -- not this handle's memory -- keeps the next solves on the
+  // three-kernel form; one solve probes the lean form again when the window is over.
+  const bool lean_wanted = h->persist_w_ok && !r.profile && !h->comm && !h->exchange && !h->big && h->co_resident <= 1;
+  bool lean_tried = false;
+  if (lean_wanted) {
+    lean_tried = persist_device_try(h->device, 1);
+    r.no_persist = !lean_tried;
+  }
   // (the lean form is two launches that wait for each other inside their kernels: one such solve at a time per device and
   // process -- persist_mutex, cc_common.hpp; a second host thread waits here instead of inside a kernel for 1.3 s)
   std::unique_lock<std::mutex> lean_lock(persist_mutex(h->device), std::defer_lock);
@@ -1748,11 +1759,16 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
       lean_lock.lock();
     if (int rc = rig_launch(h, &r, chunk)) return rc;
     if (chunk == 0) hp.mark("launch0");
-    if (int rc = rig_wait(h, &r)) return rc;
+    if (int rc = rig_wait(h, &r)) {
+      if (chunk == 0 && lean_tried && r.persist) persist_device_gave_up(h->device, 1);   // (the probe is over, whatever ended it)
+      return rc;
+    }
     // (a lean solve that gave up: its control launch on the second stream may still be queued or spinning -- the lock is kept
     // until both streams have drained below, or another thread's lean solve would start next to that late control workgroup)
     if (lean_lock.owns_lock() && !r.rerun) lean_lock.unlock();
     if (chunk == 0) hp.mark("wait0");
+    if (r.rerun) persist_device_gave_up(h->device, 1);
+    else if (chunk == 0 && lean_tried && r.persist) persist_device_completed(h->device, 1);
     if (r.rerun) {
       // The lean persistent launch could not get every workgroup resident (a device shared with another process, or the
       // control launch not scheduled next to the workers): a wait inside it gave up after 1.3 s. Frame poses go back to
@@ -1777,6 +1793,7 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
     if (r.st.done) break;
   }
   hp.mark("chunks");
+  h->ran_form = r.persist ? 2 : 0;
   const int rc_fin = rig_finish(h, &r, summary);
   hp.mark("finish");
   return rc_fin;

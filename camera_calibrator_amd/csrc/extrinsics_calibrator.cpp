@@ -209,6 +209,7 @@ void ExtrinsicsCalibrator::Optimize() {
     int32_t form = 0, reruns = 0;
     cc_last_call_solver_status(&form, &reruns, note, (int32_t)sizeof(note));
     last_solver_reruns_ = reruns;
+    last_solver_form_ = form;
     last_solver_note_ = note;
   }
   if (verbose_ && last_solver_reruns_ > 0) std::printf("note: %s\n", last_solver_note_.c_str());

@@ -50,6 +50,10 @@ class ExtrinsicsCalibrator {
   /// serialises kernels, another host thread inside a device-wide runtime call)? > 0: that many times; the call was late by 42 ms
   /// to 1.3 s each and its result equals the usual one to rounding only. LastSolverNote() says what the kernel reported.
   int LastSolverReruns() const { return last_solver_reruns_; }
+  /// The form the last call's solve ran in to its end: 0 several kernels per LM iteration, 1 / 2 / 4 the persistent per-solve
+  /// kernel(s). 0 on a device that holds persistent solves means the device's back-off window after a give-up (the next 8 solves
+  /// and 2 s, doubling on every further give-up; one solve then probes the persistent form again).
+  int LastSolverForm() const { return last_solver_form_; }
   const std::string& LastSolverNote() const { return last_solver_note_; }
   double LastFinalCost() const { return last_final_cost_; }
   /// Wall milliseconds of the last Optimize(): [0] preparing the arguments (several devices: flattening the frames), [1] cc_rig_optimize_frames
@@ -98,6 +102,7 @@ class ExtrinsicsCalibrator {
   int last_status_{0};
   int last_iterations_{0};
   int last_solver_reruns_{0};
+  int last_solver_form_{0};
   std::string last_solver_note_;
   double last_final_cost_{0.0};
   // flat copies of the observations for the C ABI, kept between calls (grow-only: a caller that optimises again after adding

@@ -125,8 +125,12 @@ void cc_release_caches(void);
  * cc_rig_optimize / _frames / _multi): these calls destroy their handles before returning, so cc_*_solver_status cannot be asked.
  * form: 0 several kernels per iteration, 1 / 2 / 4 the persistent per-solve kernel; reruns > 0: a persistent solve gave up
  * (workgroups not co-resident: another tenant, a tool that serialises kernels, a host thread inside a device-wide runtime call)
- * and the solve was run again in the several-kernel form -- late by 42 ms to 1.3 s, equal to rounding; note says what the
- * kernel reported. The C++ classes expose it as LastSolverReruns() / LastSolverNote(). */
+ * and the solve was run again in the several-kernel form -- late by 10 ms (intrinsics) / 42 ms (rig) when the first round never
+ * came together, 1.3 s in a later round; equal to rounding; note says what the kernel reported. form is what the solve RAN in.
+ * A give-up is remembered per device and process, not per handle (these calls make a new handle every time): the next 8 solves
+ * AND 2 s on that device do not try the persistent form at all (form 0, reruns 0), then ONE solve probes it; a probe that gives
+ * up doubles the window (at most 1024 solves / 10 min), one that completes ends it. The C++ classes expose this as
+ * LastSolverReruns() / LastSolverNote() / LastSolverForm(). */
 int cc_last_call_solver_status(int32_t* form, int32_t* reruns, char* note, int32_t note_capacity);
 /* The library's host worker pool, for a caller's own parallel phases (the C++ classes flatten / fill their arrays with it,
  * extrinsics_calibrator.cpp): fn(ctx, part) for part = 0 .. parts - 1, part 0 on the calling thread, returns when all are done.

@@ -211,7 +211,7 @@ def test_rccl_path_with_a_single_rank_communicator():
 
 def test_persistent_solve_that_cannot_get_its_grid_is_rerun_in_the_two_kernel_form():
     """The persistent per-solve kernel needs every one of its workgroups resident at once; on a device it does not have
-    to itself (another process, a compute-unit mask) a wait inside it gives up after 1.3 s, nothing is written back, and
+    to itself (another process, a compute-unit mask) a wait inside it gives up (first round: after 10.5 ms; later: 1.3 s), nothing is written back, and
     cc_intrinsics_solve runs the solve again in the two-kernel form -- same answer, and the handle stays with that form.
     Forced here by launching the grid WITHOUT its control workgroup (CC_INTR_PERSIST_TEST_NO_CONTROL, read once per
     process: hence a process of its own)."""
@@ -233,7 +233,7 @@ def test_persistent_solve_that_cannot_get_its_grid_is_rerun_in_the_two_kernel_fo
         t0 = time.time()
         s = prob.solve(capi.default_options())
         dt = time.time() - t0
-        assert prob.solver_form() == 0 and dt > 1.0, (prob.solver_form(), dt)
+        assert prob.solver_form() == 0 and 0.008 < dt < 0.5, (prob.solver_form(), dt)
         form, reruns, note = prob.solver_status()        # the demotion is visible, with the kernel's own words
         assert (form, reruns) == (0, 1) and "two kernels" in note and "never ran" in note, (form, reruns, note)
         ig, qg, tg = prob.get_state()
