@@ -392,6 +392,14 @@ int parallel_parts(int64_t n, int64_t min_per_part) {
 // times per Optimize(). One job at a time (a second host thread waits its turn; the phases are memory-bound copies, running
 // two at once on the same cores gains nothing). Task 0 runs on the calling thread, which also helps with the rest.
 namespace {
+// This thread is inside a job of the pool -- as its caller or as one of its workers. A job started from there (a callback of
+// cc_parallel_for that calls cc_parallel_for, or a library entry point that uses the pool) runs INLINE on this thread: job_mu is
+// not recursive, and a worker that waited for the pool would wait for itself.
+thread_local int t_in_pool_job = 0;
+struct InPoolJob {
+  InPoolJob() { ++t_in_pool_job; }
+  ~InPoolJob() { --t_in_pool_job; }
+};
 struct WorkerPool {
   std::mutex job_mu;                 // one job at a time
   std::mutex mu;
@@ -412,9 +420,9 @@ struct WorkerPool {
         const int t = next++;
         const std::function<void(int)>* f = fn;
         lk.unlock();
-        (*f)(t);
+        { InPoolJob mark; (*f)(t); }
         lk.lock();
-        if (--pending == 0) cv_done.notify_all();
+        if (--pending <= 0) cv_done.notify_all();
       }
     }
   }
@@ -424,8 +432,25 @@ WorkerPool& pool() { static WorkerPool* p = new WorkerPool; return *p; }   // (n
 
 void parallel_tasks(int parts, const std::function<void(int)>& fn) {
   if (parts <= 1) { fn(0); return; }
+  if (t_in_pool_job > 0) {   // nested: no second job, the parts one after the other
+    for (int t = 0; t < parts; ++t) fn(t);
+    return;
+  }
   WorkerPool& P = pool();
   std::lock_guard<std::mutex> job(P.job_mu);
+  InPoolJob mark;
+  // (an exception out of fn on this thread must not leave the workers with a pointer to a dead job: the guard below waits for
+  // the parts already started and clears the job before the stack unwinds further)
+  struct JobGuard {
+    WorkerPool& P;
+    ~JobGuard() {
+      std::unique_lock<std::mutex> lk(P.mu);
+      P.pending -= P.parts - P.next;   // parts nobody has started: nobody will
+      P.next = P.parts;
+      P.cv_done.wait(lk, [&] { return P.pending <= 0; });
+      P.fn = nullptr; P.parts = 0; P.next = 0; P.pending = 0;
+    }
+  } guard{P};
   {
     std::unique_lock<std::mutex> lk(P.mu);
     P.stop = false;
@@ -438,16 +463,16 @@ void parallel_tasks(int parts, const std::function<void(int)>& fn) {
   std::unique_lock<std::mutex> lk(P.mu);
   while (P.next < P.parts) {   // (the caller takes what no worker has started yet)
     const int t = P.next++;
+    --P.pending;   // (before the call: a part that throws on this thread is nobody's to wait for)
     lk.unlock();
     fn(t);
     lk.lock();
-    --P.pending;
   }
   P.cv_done.wait(lk, [&] { return P.pending == 0; });
-  P.fn = nullptr; P.parts = 0; P.next = 0;
 }
 
 void parallel_pool_release() {
+  if (t_in_pool_job > 0) return;   // (cc_release_caches from inside a task of the pool: the threads stay, they are in use)
   WorkerPool& P = pool();
   std::lock_guard<std::mutex> job(P.job_mu);
   std::vector<std::thread> th;

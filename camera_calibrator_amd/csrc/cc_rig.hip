@@ -2056,9 +2056,9 @@ int cc_rig_optimize(const cc_options* opt, int32_t device, int64_t C, int64_t F,
 }
 
 
-// Multi-device rig solve driven by ONE host thread (SURVEY.md 8(b) thread model; cf. cc_intrinsics_optimize_multi):
-// frames sharded contiguously by observation count, cameras and world points replicated, mailboxes wired inside the
-// process, every device's chunk enqueued before any is waited for. A device id may appear several times.
+// The one-shot solve on ONE device with the observations as per-frame COLUMNS (what ExtrinsicsCalibrator::Optimize holds: one array
+// of camera ids, one of point ids, one of image points and one of costs per frame, extrinsics_calibrator.hh): regrouped by
+// (frame, camera) straight from those arrays, the costs scattered back into them. Replaces extrinsics_calibrator.cpp:92-225.
 int cc_rig_optimize_columns(const cc_options* opt, int32_t device, int64_t C, int64_t F, int64_t n_world,
                             const cc_obs_columns* columns, const int64_t* counts,
                             const float* world_xyz, double* cam_q, double* cam_t, const uint8_t* cam_frozen,
@@ -2164,6 +2164,9 @@ int cc_rig_optimize_frames(const cc_options* opt, int32_t device, int64_t C, int
   return cc_rig_optimize_columns(opt, device, C, F, n_world, &cols, counts, world_xyz, cam_q, cam_t, cam_frozen, frame_q, frame_t, huber_a, summary);
 }
 
+// Multi-device rig solve driven by ONE host thread (SURVEY.md 8(b) thread model; cf. cc_intrinsics_optimize_multi):
+// frames sharded contiguously by observation count, cameras and world points replicated, mailboxes wired inside the
+// process, every device's chunk enqueued before any is waited for. A device id may appear several times.
 int cc_rig_optimize_multi(const cc_options* opt, int32_t n_devices, const int32_t* devices, int64_t C, int64_t F,
                           int64_t n_world, const int64_t* off, const uint32_t* obs_cam, const uint64_t* obs_world,
                           const float* obs_uv, const float* world_xyz, double* cam_q, double* cam_t,

@@ -40,6 +40,7 @@ Eigen::Affine3f ExtrinsicsCalibrator::GetObservationFrame(const size_t id) const
 
 size_t ExtrinsicsCalibrator::AddWorldPoint(const size_t frame_id, const Point3D& world_point) {
   Frame& frame = frames_[frame_id];
+  if (frame.points.size() >= 0xFFFFFFFFull) throw std::length_error("ExtrinsicsCalibrator::AddWorldPoint: a frame holds at most 2^32 - 1 world points");
   point_refs_.push_back(PointRef{frame_id, frame.points.size()});
   frame.points.push_back(world_point);
   world_flat_.push_back(world_point.x()); world_flat_.push_back(world_point.y()); world_flat_.push_back(world_point.z());
@@ -49,6 +50,7 @@ size_t ExtrinsicsCalibrator::AddWorldPoint(const size_t frame_id, const Point3D&
 void ExtrinsicsCalibrator::AddObservation(const size_t camera, const size_t point_global, const Point2D& normalised) {
   const PointRef& info = point_refs_[point_global];
   Frame& frame = frames_[info.frame];  // stored with the point's frame
+  if (camera >= 0xFFFFFFFFull) frame.obs_camera_wide[frame.obs_camera.size()] = camera;   // (kept as given for GetObservation / Serialize)
   frame.obs_camera.push_back(camera < 0xFFFFFFFFull ? (uint32_t)camera : 0xFFFFFFFFu);
   frame.obs_point_in_frame.push_back((uint32_t)info.point_in_frame);
   frame.obs_point_global.push_back((uint64_t)point_global);
@@ -59,7 +61,7 @@ void ExtrinsicsCalibrator::AddObservation(const size_t camera, const size_t poin
 void ExtrinsicsCalibrator::GetObservation(size_t frame_id, size_t k, size_t* camera, size_t* point_in_frame,
                                           size_t* point_global, Point2D* normalised, double* half_rho) const {
   const Frame& fr = frames_[frame_id];
-  if (camera) *camera = fr.obs_camera[k];
+  if (camera) *camera = fr.CameraOf(k);
   if (point_in_frame) *point_in_frame = fr.obs_point_in_frame[k];
   if (point_global) *point_global = (size_t)fr.obs_point_global[k];
   if (normalised) *normalised = fr.obs_normalised[k];
@@ -285,7 +287,7 @@ void ExtrinsicsCalibrator::Serialize(const std::string& fname) const {
     Value obs = Value::array();
     for (size_t k = 0; k < frame.NumObservations(); ++k) {
       Value e = Value::object();
-      e.obj["camera_id"] = Value::integer(frame.obs_camera[k]);
+      e.obj["camera_id"] = Value::integer(frame.CameraOf(k));
       e.obj["world_point_id"] = Value::integer(frame.obs_point_global[k]);
       Value ip = Value::array();
       ip.arr.push_back(Value::number(frame.obs_normalised[k].x()));
@@ -312,6 +314,8 @@ void ExtrinsicsCalibrator::Parse(const std::string& fname) {
   frozen_.clear();
   point_refs_.clear();
   frames_.clear();
+  world_flat_.clear();          // (the flat copy of the world points belongs to the frames just dropped: AddWorldPoint below refills it)
+  world_flat_stale_ = false;
   std::ifstream in(fname.c_str());
   if (!in) throw std::runtime_error("ExtrinsicsCalibrator::Parse: cannot open " + fname);
   std::stringstream ss;

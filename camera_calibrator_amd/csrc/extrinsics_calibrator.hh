@@ -3,6 +3,7 @@
 // the GPU through cc_rig_optimize (include/cc_solver.h) instead of Ceres.
 #pragma once
 #include <cstdint>
+#include <map>
 #include <set>
 #include <string>
 #include <vector>
@@ -78,12 +79,19 @@ class ExtrinsicsCalibrator {
     // before): the solve streams camera + point + image point (20 bytes) per observation and writes the costs as one array --
     // at BASELINE configs[4] size (8 M observations) 160 MB read and 64 MB written where 40-byte records cost 320 MB read and
     // 320 MB read-modified-written (cc_rig_optimize_columns reads and writes these arrays in place).
-    std::vector<uint32_t> obs_camera;          // camera id (ids beyond 2^32 - 2 are kept as 2^32 - 1: never a valid camera)
-    std::vector<uint32_t> obs_point_in_frame;  // index inside the frame's points
+    std::vector<uint32_t> obs_camera;          // camera id as the solve reads it: 4 bytes, ids beyond 2^32 - 2 (never a valid camera) as 2^32 - 1 ...
+    std::map<size_t, size_t> obs_camera_wide;  // ... and, for exactly those, observation index -> the id AddObservation was given (GetObservation and
+                                               // Serialize return what came in, like the reference's size_t member, extrinsics_calibrator.hh:58)
+    std::vector<uint32_t> obs_point_in_frame;  // index inside the frame's points (AddWorldPoint refuses a 2^32-th point in one frame: 48 GB of them)
     std::vector<uint64_t> obs_point_global;    // global id
     std::vector<Point2D, Eigen::aligned_allocator<Point2D>> obs_normalised;
     std::vector<double> obs_half_rho;
     size_t NumObservations() const { return obs_camera.size(); }
+    size_t CameraOf(size_t k) const {
+      if (obs_camera[k] != 0xFFFFFFFFu) return obs_camera[k];
+      const auto it = obs_camera_wide.find(k);
+      return it == obs_camera_wide.end() ? (size_t)obs_camera[k] : it->second;
+    }
   };
   struct PointRef {
     size_t frame;

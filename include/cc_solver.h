@@ -135,6 +135,9 @@ int cc_last_call_solver_status(int32_t* form, int32_t* reruns, char* note, int32
 /* The library's host worker pool, for a caller's own parallel phases (the C++ classes flatten / fill their arrays with it,
  * extrinsics_calibrator.cpp): fn(ctx, part) for part = 0 .. parts - 1, part 0 on the calling thread, returns when all are done.
  * The threads are created at first use (at most 15), kept for the life of the process, joined by cc_release_caches.
+ * One job at a time (a second host thread waits its turn). Re-entry is allowed: a cc_parallel_for -- or any library call that
+ * uses the pool (cc_rig_optimize*, cc_rig_get_state) -- made FROM a part runs its parts inline on that thread, one after the
+ * other, and cc_release_caches called from a part leaves the pool's threads alone.
  * cc_parallel_parts: how many parts the library itself would use for n items of which a part should hold min_per_part. */
 void cc_parallel_for(int32_t parts, void (*fn)(void* ctx, int32_t part), void* ctx);
 int32_t cc_parallel_parts(int64_t n, int64_t min_per_part);

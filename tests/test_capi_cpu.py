@@ -176,6 +176,40 @@ def test_host_worker_pool_runs_every_part_once_and_is_joined_by_release_caches()
     assert one == [1]
 
 
+def test_host_worker_pool_can_be_entered_again_from_one_of_its_parts():
+    """the pool's job lock is not recursive -- a part that calls cc_parallel_for (or cc_release_caches) again
+    used to deadlock. A nested job now runs its parts inline on the calling part's thread; release from inside a part is a
+    no-op for the pool. Run in a child process with a timeout, so that a deadlock is a failure and not a hang."""
+    import subprocess, sys, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, threading, ctypes as C
+        sys.path.insert(0, %r)
+        from camera_calibrator_amd import capi
+        lib = capi.lib()
+        FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32)
+        lib.cc_parallel_for.argtypes = [C.c_int32, FN, C.c_void_p]; lib.cc_parallel_for.restype = None
+        lib.cc_host_pool_threads.restype = C.c_int32
+        lock = threading.Lock()
+        inner, outer = [0] * 6, [0] * 5
+        def inner_body(_c, t):
+            with lock: inner[t] += 1
+        icb = FN(inner_body)
+        def outer_body(_c, t):
+            with lock: outer[t] += 1
+            lib.cc_parallel_for(6, icb, None)      # nested: inline on this part's thread
+            if t == 2: lib.cc_release_caches()     # from inside a part: the pool's threads stay
+        lib.cc_parallel_for(5, FN(outer_body), None)
+        assert outer == [1] * 5 and inner == [5] * 6, (outer, inner)
+        assert lib.cc_host_pool_threads() >= 1
+        lib.cc_parallel_for(5, FN(outer_body), None)   # the pool still works afterwards
+        assert outer == [2] * 5 and inner == [10] * 6, (outer, inner)
+        print("nested ok")
+    """ % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "nested ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_last_call_solver_status_is_exported_and_empty_before_any_call():
     import ctypes as C
     lib = capi.lib()

@@ -5,7 +5,7 @@ pivots and quaternion norms through rsqrt_pos) -- profiles/r05/rig_deviation.jso
 BASELINE configs[3] with 1.6 - 22 % of the blocks in the Huber tail, default build and -DCC_RIG_EXACT_DIV -DCC_RIG_EXACT_HUBER
 side by side -- the two builds deviate alike, i.e. what is left is the order of the sums): identical iteration count and
 accept / reject sequence; per-iteration costs <= 2e-12 relative (asserted 1e-10); converged poses <= 7e-15 (asserted 1e-11; were
-1e-9); per-observation costs <= 3.3e-10 relative (asserted 1e-8); final cost <= 3e-14 (asserted 1e-12)."""
+1e-9); per-observation costs <= 3.3e-10 relative (asserted 1e-9: three times the floor); final cost <= 3e-14 (asserted 1e-12)."""
 import os
 import subprocess
 import sys
@@ -42,7 +42,7 @@ def _assert_same(g, o, atol=1e-11):
     assert np.allclose([l["cost"] for l in g[5]["log"]], [l["cost"] for l in o[5]["log"]], rtol=1e-10)
     for k in range(4):
         assert np.abs(g[k] - o[k]).max() < atol
-    assert np.allclose(g[4], o[4], rtol=1e-8, atol=1e-16), np.abs(g[4] / np.maximum(o[4], 1e-300) - 1).max()
+    assert np.allclose(g[4], o[4], rtol=1e-9, atol=1e-18), np.abs(g[4] / np.maximum(o[4], 1e-300) - 1).max()
     assert np.isclose(g[5]["final_cost"], o[5]["final_cost"], rtol=1e-12)
 
 

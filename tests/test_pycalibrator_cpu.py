@@ -100,6 +100,28 @@ def test_parse_round_trip_and_camera_quirk(tmp_path):
     assert not e.IsCameraFrozen(0) and e.IsCameraFrozen(n)
 
 
+def test_camera_ids_beyond_32_bits_come_back_as_given(tmp_path):
+    """The reference keeps camera_id as size_t (extrinsics_calibrator.hh:58). The build's columns hold 4-byte ids for the solve
+    (no valid camera lies beyond 2^32 - 2), but what AddObservation was given is what GetObservation, Serialize and a
+    Parse of that file return (such ids used to come back as 2^32 - 1)."""
+    import json
+    e = pc.ExtrinsicsCalibrator()
+    e.AddCameraTRig(np.eye(4, dtype=np.float32))
+    f = e.AddObservationFrame(np.eye(4, dtype=np.float32))
+    w = e.AddWorldPoint(f, np.array([0.1, 0.2, 1.0], np.float32))
+    ids = [0, 2**32 - 2, 2**32 - 1, 2**32, 2**40 + 5]
+    for c in ids:
+        e.AddObservation(c, w, np.array([0.0, 0.0], np.float32))
+    assert [e.GetObservation(f, k)[0] for k in range(len(ids))] == ids
+    fn = str(tmp_path / "wide.json")
+    e.Serialize(fn)
+    got = [o["camera_id"] for o in json.load(open(fn))["observation_frames"][0]["observations"]]
+    assert got == ids
+    fresh = pc.ExtrinsicsCalibrator()
+    fresh.Parse(fn)
+    assert [fresh.GetObservation(0, k)[0] for k in range(len(ids))] == ids
+
+
 def test_affine_caster_reads_top_3x4_only():
     e = pc.ExtrinsicsCalibrator()
     T = np.arange(16, dtype=np.float32).reshape(4, 4)
