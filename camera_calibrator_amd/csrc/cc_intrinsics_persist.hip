@@ -856,6 +856,30 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
     const double radius_spec = phase0 ? s_wg[WG_R0] : persist_spec_radius(radius, s_wg[WG_OPT + 3]);
     if (spec) eliminate_and_post(dst, radius_spec, phase0, Q.pbox, e2);
     PW_MARK(7);
+#ifdef CC_PERSIST_PROBE_ALLGATHER
+    // MEASUREMENT ONLY (review of round 5, item 4b): what a worker-side decision + solve would wait for -- EVERY worker gathers the
+    // leaders' rows itself (waves 1..3: 192 lanes, every word of the <= 16 rows of 160 in flight at once), next to the usual path.
+    // The completion times of the middle worker's three waves go to vec_solve[27..29].
+    if (spec && threadIdx.x >= 64 && threadIdx.x < 256) {
+      const int nw = ((Q.G + kPLeaderRows - 1) / kPLeaderRows) * 2 * kPartialCols, t = (int)threadIdx.x - 64;
+      u64 v[14];
+      double acc = 0.0;
+      for (unsigned spins = 0; spins < (1u << 14); ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 14; ++k) { const int w = t + 192 * k; v[k] = ag_ld(Q.lbox + (w < nw ? w : t)); }
+#pragma unroll
+        for (int k = 0; k < 14; ++k) ok = ok && (unsigned)(v[k] >> 32) == e2;
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int k = 0; k < 14; ++k) acc += (double)(unsigned)v[k];
+      if (acc == -1.0) s_wg[WG_X + 12] = acc;   // (keeps the loads alive)
+      if (round == CC_PERSIST_TIMING_ROUND && (int)blockIdx.x == (Q.G / 2 / kPLeaderRows) * kPLeaderRows && (threadIdx.x & 63) == 0)
+        P.vec_solve[27 + ((int)threadIdx.x >> 6) - 1] = (double)wall_clock64();
+    }
+#endif
     wait_bcast(e2);
     PW_MARK(10);
     PG_MARK(3);

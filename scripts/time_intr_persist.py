@@ -39,6 +39,8 @@ sk = np.median(np.array(skews), axis=0)     # [G][4]: round start, statistics st
 names = ["round start", "statistics stored", "elimination row stored", "broadcast received"]
 print(json.dumps({"frames": F, "pts": M, "workgroups": G, "per_workgroup_marks_us": {n: {"min": round(float(sk[:, i].min()), 2), "median": round(float(np.median(sk[:, i])), 2),
       "max": round(float(sk[:, i].max()), 2)} for i, n in enumerate(names)}}))
+if t[27] > 0:   # (-DCC_PERSIST_PROBE_ALLGATHER: every worker also gathered the leaders' rows itself)
+    print(json.dumps({"probe": "all workers gather the leaders' rows", "middle worker's waves 1..3 had every row at (us)": [round(float(x), 2) for x in t[27:30]]}))
 print(json.dumps({"frames": F, "pts": M, "round_us": round(float(max(t[10], t[12])), 2),
                   "worker": {n: round(float(t[i]), 2) for i, n in enumerate(wn) if t[i] > -1e6},
                   "control": {n: round(float(t[16 + i]), 2) for i, n in enumerate(cn)}}))
