@@ -80,6 +80,21 @@ def load_traffic(frames, points, kernel="k_intr_sweep"):
     return None
 
 
+def load_pipe_busy(frames, points, kernel):
+    """Matrix-pipe / vector-issue busy fractions of `kernel` from the committed counter pass (profiles/traffic.json, intr_persist.pipe_busy:
+    rocprofv3 --pmc, scripts/pmc_busy_summary.py) -- only when this run has the profiled shape. Measured once per round on the same
+    command; a reported figure next to the live one, not part of it."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f).get("intr_persist", {})
+        shape = t.get("shape", {})
+        if kernel.startswith("k_intr_persist") and shape.get("frames") == frames and shape.get("points_per_frame") == points:
+            return t.get("pipe_busy")
+    except Exception:
+        pass
+    return None
+
+
 def load_rig_traffic(cams, frames, points, variant):
     """HBM bytes per launch of the rig sweep from the committed PMC profiles -- only for a profiled shape and variant."""
     try:
@@ -564,6 +579,7 @@ def main():
             "roofline_fp64": {
                 "kernel": dom_kernel, "bound": "fp64 mfma/valu", "achieved": fp64_tflops,
                 "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fp64_tflops / FP64_PEAK_TFLOPS,
+                "pmc": load_pipe_busy(my_frames, args.points, dom_kernel),
             },
             "sweep_kernel_alone": {
                 "kernel": "k_intr_sweep", "avg_launch_ms": sweep_ms, "algorithmic_bytes_per_launch": bytes_sweep,
