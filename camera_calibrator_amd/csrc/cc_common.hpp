@@ -336,11 +336,7 @@ __device__ __forceinline__ double rsqrt_pos(double d) {
 
 // Rotation matrix of q/|q| (ceres::QuaternionRotatePoint normalises; calibrator.cpp:201)
 __device__ inline void quat_to_R(const double* q, double* R) {
-#ifdef CC_EXACT_QUAT_NORM
-  const double n = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-#else
   const double n = rsqrt_pos(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);   // (a pose's quaternion is never zero)
-#endif
   const double w = q[0] * n, x = q[1] * n, y = q[2] * n, z = q[3] * n;
   R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z);     R[2] = 2 * (x * z + w * y);
   R[3] = 2 * (x * y + w * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);

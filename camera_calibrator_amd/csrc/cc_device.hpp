@@ -35,11 +35,6 @@ __device__ __forceinline__ double half_pair_sum(double v) {   // lanes l and l ^
 template <int LOG2 = 0>
 __device__ __forceinline__ double wave_sum_mod(double v) {
   static_assert(LOG2 >= 0 && LOG2 <= 3, "strides 1, 2, 4, 8");
-#ifdef CC_SHFL_WAVE_SUM   // (A/B: the ds_bpermute butterfly)
-#pragma unroll
-  for (int o = 1 << LOG2; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
-  return v;
-#endif
   if (LOG2 == 0) v += dpp_f64<0xB1>(v);    // quad_perm:[1,0,3,2]
   if (LOG2 <= 1) v += dpp_f64<0x4E>(v);    // quad_perm:[2,3,0,1]
   if (LOG2 <= 2) v += dpp_f64<0x124>(v);   // row_ror:4
@@ -49,11 +44,6 @@ __device__ __forceinline__ double wave_sum_mod(double v) {
 __device__ __forceinline__ double wave_sum(double v) { return wave_sum_mod<0>(v); }
 // sum / maximum over the sixteen lanes of a row (lanes 16k .. 16k+15), in every lane
 __device__ __forceinline__ double row16_sum(double v) {
-#ifdef CC_SHFL_WAVE_SUM
-#pragma unroll
-  for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
-  return v;
-#endif
   v += dpp_f64<0xB1>(v);    // quad_perm:[1,0,3,2]
   v += dpp_f64<0x4E>(v);    // quad_perm:[2,3,0,1]
   v += dpp_f64<0x141>(v);   // row_half_mirror: the other quad of the half row
@@ -61,11 +51,6 @@ __device__ __forceinline__ double row16_sum(double v) {
   return v;
 }
 __device__ __forceinline__ double row16_max(double v) {
-#ifdef CC_SHFL_WAVE_SUM
-#pragma unroll
-  for (int o = 1; o < 16; o <<= 1) v = fmax(v, __shfl_xor(v, o, 64));
-  return v;
-#endif
   v = fmax(v, dpp_f64<0xB1>(v));
   v = fmax(v, dpp_f64<0x4E>(v));
   v = fmax(v, dpp_f64<0x141>(v));
@@ -129,10 +114,6 @@ __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOM
 // the ds_write_b128 groups (8 consecutive lanes) and the ds_read_b64 operand reads (two 32-lane
 // halves, each two consecutive rows) are both bank-conflict free.
 __device__ __forceinline__ void stage_row(double* stage, int lane, const double* v) {
-#if defined(CC_ABLATE) && CC_ABLATE == 2
-  asm volatile("" ::"v"(v[0] + v[5] + v[9] + v[12] + v[15]));
-  return;
-#endif
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     d2 val;
@@ -145,10 +126,6 @@ __device__ __forceinline__ void stage_row(double* stage, int lane, const double*
 // 16 MFMAs over the 64 staged rows: MFMA m consumes rows 4m..4m+3; lane l supplies component
 // (l & 15) of row 4m + (l >> 4) as both the A[i][k] and the B[k][j] operand of the Gram product.
 __device__ __forceinline__ void gram_rows(const double* stage, int lane, d4& acc0, d4& acc1) {
-#if defined(CC_ABLATE) && CC_ABLATE == 1
-  asm volatile("" ::"v"(stage[lane]));
-  return;
-#endif
   const int c = lane & 15, sub = lane >> 4;
 #pragma unroll
   for (int m = 0; m < 16; m += 2) {

@@ -24,9 +24,6 @@
 #include "cc_intrinsics_dev.hpp"
 #include "cc_intrinsics_persist.hpp"
 
-#ifndef CC_ABLATE
-#define CC_ABLATE 0  // timing-only experiments (scripts/ablate_sweep.sh); 0 = product build
-#endif
 
 #include <algorithm>
 #include <chrono>
@@ -50,12 +47,6 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
   double* sm = s_stage + 4 * kStageDoublesPerWave;              // [256] prologue scratch
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // (timing-only builds, scripts/time_intr_decide.py: the middle workgroup leaves wall-clock marks in vec_solve[48..])
-#ifdef CC_INTR_TIMING
-#define SW_MARK(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) P.vec_solve[48 + (i)] = (double)wall_clock64(); } while (0)
-#else
-#define SW_MARK(i) do { } while (0)
-#endif
-  SW_MARK(0);
   const int T = P.T;
   const int64_t f = (int64_t)blockIdx.x / T;
   const int tile = (int)(blockIdx.x - f * T);
@@ -153,7 +144,6 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
   const int dst = phase == 0 ? cur : (cur ^ 1);
   const double g_old = (flags & 4) ? g_old0 : (cur ? g_old1 : g_old0);
   __syncthreads();
-  SW_MARK(1);
   const int pose_o = cur ? 67 : 60, intr_o = cur ? 83 : 74;
   if (tid < 6) {
     const double* Yr = sm + tid * 10;
@@ -170,7 +160,6 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
     if (blockIdx.x == 0 && phase != 0) P.intr[dst * 16 + j] = kc;
   }
   __syncthreads();
-  SW_MARK(2);
   if (tid == 0) {
     double q[4], t[3], dp[6];
 #pragma unroll
@@ -205,7 +194,6 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
     sm[159] = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + t[0] * t[0] + t[1] * t[1] + t[2] * t[2];
   }
   __syncthreads();
-  SW_MARK(3);
 
   // model-cost term of this frame: q_f = d^T g_f + 1/2 d^T H_f d over the frame's 15x15 block at
   // the accepted point (Ceres: model_cost_change = -(J d)^T (r + J d / 2))
@@ -245,9 +233,6 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
       nm = uv2[ic];
       nX0 = P.xyz[ic * 3]; nX1 = P.xyz[ic * 3 + 1]; nX2 = P.xyz[ic * 3 + 2];
     }
-#if CC_ABLATE == 3
-    if (p >= 0) continue;
-#endif
     ObsCommon oc;
     obs_common(kk, R, tt, (double)X0, (double)X1, (double)X2, oc);
     double v[16];
@@ -262,19 +247,16 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
     wave_lds_fence();
     gram_rows(stage, lane, acc0, acc1);
     wave_lds_fence();
-    if (p == 0) SW_MARK(4);
   }
 
   // ---- cross-wave reduction of the 16x16 block + model-cost term ---------------------------
   // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
   __syncthreads();  // s_blk aliases the staging buffers
-  SW_MARK(5);
 #pragma unroll
   for (int r = 0; r < 4; ++r) s_blk[wave * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc0[r] + acc1[r];
   __syncthreads();
   const double g = gram_entry_held(mask, tid) ? 0.0 : (s_blk[tid] + s_blk[256 + tid]) + (s_blk[512 + tid] + s_blk[768 + tid]);   // (constant coordinates: zero rows and columns)
   P.blocks[(((size_t)dst * P.F + f) * T + tile) * 256 + tid] = g;
-  SW_MARK(6);
   // per-tile statistics row (the per-frame quantities ride on tile 0): written by the thread that holds entry (15, 15)
   // = sum r^2 of the block, no third barrier and no LDS copy of the block
   if (tid == 255) {
@@ -287,7 +269,6 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_intr_sweep(IntrDev P, int 
   // initial evaluation: diagonal of the shared block for its Jacobi scale, by the threads that hold it (the pose
   // blocks' scale needs the sum over the tiles: the first elimination derives it, k_intr_decide_elim)
   if (phase == 0 && tid < 9 * 17 && tid % 17 == 0) P.hd0[(size_t)blockIdx.x * 16 + tid / 17] = g;
-  SW_MARK(7);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -475,18 +456,6 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
   __shared__ unsigned char pj[48], pk[48];
   constexpr bool kFused = MODE != 2;
   const int tid = threadIdx.x, g = tid >> 4, l = tid & 15;
-  // Timing-only builds (-DCC_INTR_TIMING, scripts/time_intr_decide.py): thread 0 keeps wall-clock marks (100 MHz) of the
-  // stages in registers; the block that turns out to be the last to arrive -- the critical path -- leaves them in
-  // vec_solve[32..] (unused on a single GPU). The product build compiles this away.
-#ifdef CC_INTR_TIMING
-  long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define DE_MARK(i) do { tm[i] = wall_clock64(); } while (0)
-#define DE_MARK_LATE(i) do { if (tid == 0 && tm[3] != 0) P.vec_solve[32 + (i)] = (double)wall_clock64(); } while (0)   // (full launches only)
-#else
-#define DE_MARK(i) do { } while (0)
-#define DE_MARK_LATE(i) do { } while (0)
-#endif
-  DE_MARK(0);
   const LmCtl* ctl = P.ctl;
   // bit 2 of `publish`: RESTART, first elimination of a solve from the initial state: the control block in memory
   // is stale and counts as zero (cf. the restart sweep)
@@ -530,10 +499,6 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
   const int phase = restart ? 0 : c_in.phase;
   const bool pending = !restart && c_in.cand_pending != 0;
   const bool need = phase == 0 || (pending && c_in.step_valid);
-#if CC_ABLATE_D == 1
-  if (ctl->gmax == 1e30) return;  // marker set by cc_intrinsics_profile_kernel
-#endif
-  DE_MARK(1);
   bool exchange_ok = true;
   if (MODE == 0) {
     // (an initial evaluation that was not announced by the launch flag -- the first solve after set_state -- needs
@@ -607,9 +572,6 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
       *P.ctl_next = c;
     }
   }
-#if CC_ABLATE_D == 2
-  if (ctl->gmax == 1e30) return;  // marker set by cc_intrinsics_profile_kernel
-#endif
   if (phase != 0 && tid < 9) s_ss[tid] = P.ss[tid];
   if (tid == 32) {
     int o = 0;
@@ -618,11 +580,7 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
   }
   __syncthreads();
   const bool stop = s_ctl.done != 0;   // the same answer in every block
-  DE_MARK(2);
   if (stop && !kFused) return;
-#if CC_ABLATE_D == 3
-  if (ctl->gmax == 1e30) return;  // marker set by cc_intrinsics_profile_kernel
-#endif
   if (!stop) {
   const int cur = s_ctl.cur;
   const int T = P.T;
@@ -737,10 +695,6 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
         }
       }
       if (!ok) fail = 1.0;
-      if (base == (int64_t)blockIdx.x * 16) DE_MARK(3);
-#if CC_ABLATE_D == 4
-      if (L[20] != 123.0 && ctl->gmax == 1e30) return;
-#endif
       if (l < 10) {
         // z = L^-1 w (for the Schur sums), y = L^-T z (for the back-substitution)
         const double sc = l < 9 ? s_ss[l] : 1.0;
@@ -767,10 +721,6 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
       }
     }
     __syncthreads();
-    if (base == (int64_t)blockIdx.x * 16) DE_MARK(4);
-#if CC_ABLATE_D == 5
-    if (ctl->gmax == 1e30) return;
-#endif
     if (valid) {
 #pragma unroll
       for (int r = 0; r < 5; ++r) {
@@ -791,10 +741,6 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
     }
     __syncthreads();
   }
-  DE_MARK(5);
-#if CC_ABLATE_D == 6
-  if (ctl->gmax == 1e30) { if (acc[0] + acc[1] + acc[2] + acc[3] + acc[4] + gacc + facc == 123.0) P.partial[tid] = 0; return; }
-#endif
 #pragma unroll
   for (int r = 0; r < 5; ++r)
     if (l * 5 + r != PC_FAIL && l * 5 + r != PC_GMAXP) red[g][l * 5 + r] = acc[r];
@@ -824,13 +770,6 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
   __syncthreads();
   if (!s_last) return;
   if (tid == 0) __hip_atomic_store(P.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
-#ifdef CC_INTR_TIMING
-  if (tid == 0 && tm[3] != 0) { for (int i = 0; i < 6; ++i) P.vec_solve[32 + i] = (double)tm[i]; }
-#endif
-  DE_MARK_LATE(6);
-#if CC_ABLATE_D == 7
-  if (ctl->gmax == 1e30) return;
-#endif
   double* sv = &red[0][0];            // [kVecSolve] reduced sums (the staging rows are no longer needed)
   double* s_part = &red[2][0];        // [3][kPartialCols]
   if (!stop) {
@@ -881,10 +820,6 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
       __syncthreads();
     }
   }
-#if CC_ABLATE_D == 8
-  if (ctl->gmax == 1e30) return;
-#endif
-  DE_MARK_LATE(7);
   if (tid != 0) return;
   LmCtl c = s_ctl;
   cc_iteration* e = s_logged ? &s_log : nullptr;
@@ -895,7 +830,6 @@ __global__ __launch_bounds__(256) void k_intr_decide_elim(IntrDev P, int publish
   *P.ctl = c;
   *P.ctl_next = c;
   if (publish) publish_to_host(P, c);
-  DE_MARK_LATE(8);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1084,9 +1018,8 @@ static void launch_sweep(cc_intrinsics* h, bool profile, int flags = 0) {
   // Only the CURRENT Gram buffer of a frame is fetched for the model-cost term (flag bit 2). Round 1 fetched both ping-pong
   // buffers so as not to wait for the control block; with the control block read by scalar loads at the top of the kernel
   // the index is there when the gather is issued: A/B at 1000 x 500, sweep 17.41 vs 17.42 us, iteration 42.50 vs 42.41 us,
-  // and 2 KB per frame less traffic. CC_SWEEP_SINGLE_BUFFER=0 brings the double fetch back for that A/B.
-  static const bool both_env = [] { const char* e = getenv("CC_SWEEP_SINGLE_BUFFER"); return e && atoi(e) == 0; }();
-  if (!both_env || h->F * h->d.T > 1024) flags |= 4;
+  // and 2 KB per frame less traffic.
+  flags |= 4;
   hipLaunchKernelGGL(k_intr_sweep, dim3((unsigned)(h->F * h->d.T)), dim3(kSweepThreads), kSweepLdsBytes, h->stream, h->d, flags);
 }
 
@@ -1406,10 +1339,6 @@ int intr_create_impl(cc_intrinsics* h, const int64_t* off, const float* uv, cons
   h->pq.lbox = reinterpret_cast<unsigned long long*>(base + o_lbox);
   h->pq.G = (int32_t)PG;
   h->pq.teams = p_teams;
-  {
-    const char* e = getenv("CC_INTR_PERSIST_STAGGER");
-    h->pq.stagger = e ? std::max(0, atoi(e)) : 0;
-  }
   h->p_epoch = 0;
   // every workgroup of the persistent launch waits for the others inside the kernel: it is only used when all of them
   // (workers + control) are resident at once, alone on the device (shards that share a device keep the two-kernel path)
@@ -1546,9 +1475,7 @@ static int capture_chunk(cc_intrinsics* h, bool with_reset, bool initial, int ro
   hipGraph_t g = nullptr;
   CC_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
   int rc = 0;
-  static const bool restore_kernel = getenv("CC_RESTORE_KERNEL") != nullptr;   // A/B knob: restore by a kernel of its own
-  if (with_reset && restore_kernel) launch_reset(h);
-  for (int i = 0; i < rounds && !rc; ++i) rc = enqueue_round(h, false, initial && i == 0, i == rounds - 1, with_reset && !restore_kernel && i == 0);
+  for (int i = 0; i < rounds && !rc; ++i) rc = enqueue_round(h, false, initial && i == 0, i == rounds - 1, with_reset && i == 0);
   const hipError_t e_end = hipStreamEndCapture(h->stream, &g);
   if (rc || e_end != hipSuccess) {
     if (g) hipGraphDestroy(g);

@@ -27,22 +27,8 @@
 
 namespace cc {
 
-// Timing-only builds (-DCC_PERSIST_TIMING, scripts/time_intr_persist.py): in round CC_PERSIST_TIMING_ROUND the middle worker
-// workgroup and the control workgroup leave wall-clock marks (100 MHz, one counter for the whole chip) in vec_solve, which
-// the persistent path does not use otherwise: worker marks [0..15], control marks [16..31]. Compiled away in the product.
-#ifdef CC_PERSIST_TIMING
-#ifndef CC_PERSIST_TIMING_ROUND
-#define CC_PERSIST_TIMING_ROUND 2
-#endif
-#define PW_MARK(i) do { if (round == CC_PERSIST_TIMING_ROUND && (int)blockIdx.x == (Q.G / 2 / kPLeaderRows) * kPLeaderRows && threadIdx.x == 0) P.vec_solve[(i)] = (double)wall_clock64(); } while (0)
-#define PC_MARK(i) do { if (round == CC_PERSIST_TIMING_ROUND && threadIdx.x == 0) P.vec_solve[16 + (i)] = (double)wall_clock64(); } while (0)
-// every worker workgroup: four marks per round in P.stats (unused by the persistent path) -> the skew between workgroups
-#define PG_MARK(i) do { if (round == CC_PERSIST_TIMING_ROUND && threadIdx.x == 0) P.stats[(size_t)blockIdx.x * 4 + (i)] = (double)wall_clock64(); } while (0)
-#else
-#define PG_MARK(i) do { } while (0)
-#define PW_MARK(i) do { } while (0)
-#define PC_MARK(i) do { } while (0)
-#endif
+// (Where a round's time goes is measured with a variant of this file that leaves wall-clock marks in vec_solve:
+// scripts/variants/timing.patch, scripts/time_intr_persist.py.)
 
 // LDS of a workgroup with TEAMS frames: one staging tile per wave, both Gram blocks and the scratch of every team, the
 // workgroup's scratch. 157,696 B at four teams (one workgroup per compute unit), 42,496 B at one.
@@ -201,7 +187,6 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
     // a quality >= 0.937, where Ceres' radius update r / max(1/3, 1 - (2 rho - 1)^3) is exactly r / (1/3): the usual
     // outcome of an LM step that works. A decision that says otherwise (rejection, a mediocre step, the first round) is
     // a MISS: it is broadcast on its own and the workers eliminate again with what it says.
-    PC_MARK(0);
     if (phase0) gather_rows<kPStatCols, THREADS / kPStatCols>(Q.sbox, Q.G, e1, 13, -1, s_part, s_tot, Q.fail, s_int, (phase0 ? Q.first_shift : Q.timeout_shift));
     else gather_stats4<THREADS>(Q.sbox, Q.G, e1, s_part, s_tot, Q.fail, s_int, (phase0 ? Q.first_shift : Q.timeout_shift));
     if (P.x.on) {
@@ -221,7 +206,6 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
         __syncthreads();
       }
     }
-    PC_MARK(1);
     if (tid == 0) {
       LmCtl c = *s_ctl;
       const int len0 = c.log_len, prev_cur = c.cur & 1, was_valid = c.step_valid;
@@ -268,7 +252,6 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
       for (int i = 0; i < 9; ++i) s_bc[2 + i] = 0.0;
     }
     __syncthreads();
-    PC_MARK(2);
     const bool hit = s_int[2] != 0;
     if (s_ctl->done || !hit) {
       if (tid < 22) ag_st(Q.xbox + tid, granule(e2, s_bc[tid >> 1], tid & 1));
@@ -280,7 +263,6 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
     }
     // ---- elimination rows (of the assumption, or of the second elimination after a miss) -> gradient tests, reduced solve
     const unsigned erow = hit ? e2 : e3;
-    PC_MARK(3);
     // (the leaders among the workers have added the elimination rows sixteen at a time: one round trip here)
     gather_rows<kPartialCols, THREADS / kPartialCols, (kPLeaderRows + THREADS / kPartialCols - 1) / (THREADS / kPartialCols)>(Q.lbox, (Q.G + kPLeaderRows - 1) / kPLeaderRows, erow, kPartialCols, PC_GMAXP, s_part, sv, Q.fail, s_int, (phase0 ? Q.first_shift : Q.timeout_shift));
     if (P.x.on) {
@@ -318,7 +300,6 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
       sv[tid] *= f2;
     }
     __syncthreads();
-    PC_MARK(4);
     if (wave == 0) {
       // (the lane index of THIS round, opaque to the compiler: with the plain one it computes the nine per-lane selects and unit-row
       // constants of the pinned coordinates once, before the round loop, and keeps them in registers it does not have -- the
@@ -333,7 +314,6 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
         if (!(mask & (1u << j))) gmax = fmax(gmax, fabs(sv[PC_GS + j]));
       const bool go = s_int[0] && !(gmax <= o.gradient_tolerance) && !(radius < o.min_radius);
       bool ok = !(sv[PC_FAIL] > 0.0);
-      PC_MARK(7);
       double x[9];
       {
         // row `lane` of the damped reduced system (sv[0..44]: upper triangle, row-major pairs j <= k). Built and solved
@@ -354,9 +334,7 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
           a[k] = v;
         }
         const double b = pin_i ? 0.0 : sv[PC_B + i];
-        PC_MARK(8);
         ok = chol_solve_rows<9>(a, b, x) && ok;
-        PC_MARK(9);
 #pragma unroll
         for (int j = 0; j < 9; ++j) ok = ok && isfinite(x[j]);
       }
@@ -376,12 +354,9 @@ __device__ __forceinline__ void persist_control(const IntrDev& P, const PersistD
         s_bc[0] = (double)((go ? 0 : 1) | (go && ok ? 2 : 0) | (hit ? 4 : 0) | (cur << 3));
         s_bc[1] = radius;
       }
-      PC_MARK(10);
     }
     __syncthreads();
-    PC_MARK(5);
     if (tid < 22) ag_st(Q.xbox + tid, granule(erow, s_bc[tid >> 1], tid & 1));
-    PC_MARK(6);
     if (tid == 0) {
       // (on the control block in LDS: only the fields lm_finalize touches move, not 144 bytes each way)
       double gmax = sv[PC_GMAXP];
@@ -525,8 +500,6 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
     const int dst = phase0 ? cur : (cur ^ 1);
     // =========================== sweep (candidate point, or the starting point in the first round)
     d4 acc0, acc1;
-    PW_MARK(0);
-    PG_MARK(0);
     if (do_sweep) {
       CC_FRESH_TID(tid);
       const int ttid = tid & 255, lane = tid & 63;
@@ -581,7 +554,6 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
         sm[TM_XN2] = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + t[0] * t[0] + t[1] * t[1] + t[2] * t[2];
       }
       __syncthreads();
-      PW_MARK(1);
       // model-cost term of the frame over its 15 x 15 block at the accepted point (cf. k_intr_sweep)
       {
         double qterm = 0.0;
@@ -604,12 +576,8 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
       double* stage = s_stage + wave * kStageDoublesPerWave;
       acc0 = d4{0.0, 0.0, 0.0, 0.0};
       acc1 = d4{0.0, 0.0, 0.0, 0.0};
-      // Waves that share a SIMD (one per team) would enter the loop in lockstep -- all in the fp64 row arithmetic, then
-      // all storing to LDS, then all on the matrix pipe: team k starts k * stagger sleep units late so that one team's
-      // LDS staging falls under another's matrix products (the separately launched workgroups of k_intr_sweep were
-      // skewed by their dispatch). PersistDev::stagger, CC_INTR_PERSIST_STAGGER.
-      for (int w = 0; w < team * Q.stagger; ++w) __builtin_amdgcn_s_sleep(4);
-      PW_MARK(2);
+      // (Waves that share a SIMD -- one per team -- enter the loop in lockstep. A start staggered by k sleep units per team, so that one
+      // team's LDS staging falls under another's matrix products, was measured at several k and never paid: removed in round 6.)
       for (int p = 0; p < npass; ++p) {
         const int64_t idx = s0 + (int64_t)p * kSweepThreads + ttid;
         const bool valid = idx < s1;
@@ -637,9 +605,7 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
         wave_lds_fence();
       }
       // ---- cross-wave reduction of the 16 x 16 block into the frame's LDS slot
-      PW_MARK(3);
       __syncthreads();   // s_blk aliases the staging tiles
-      PW_MARK(4);
     }
     if (do_sweep) {
       CC_FRESH_TID(tid);
@@ -659,7 +625,6 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
       __syncthreads();
     }
     // ---- statistics row of the workgroup (teams in order) -> control
-    PW_MARK(5);
     {
       CC_FRESH_TID(tid);
       const int ncols = phase0 ? 13 : 4;
@@ -728,7 +693,6 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
           L[tri(i, j)] = a * inv;
         }
       }
-      PW_MARK(13);
       // the factor is the same in all sixteen lanes: from here on it lives in scalar registers (48 of them), not in 54
       // vector registers next to each lane's own columns
 #pragma unroll
@@ -761,7 +725,6 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
           sm[TM_Y + i * 10 + l] = y[i];
         }
       }
-      PW_MARK(14);
       if (l == 0) red[PC_FAIL] = ok ? 0.0 : 1.0;
     }
     // ---- the frame's elimination row: slot o of eighty on lane o mod 64 of the SAME wave (its LDS operations execute in
@@ -806,7 +769,6 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
     }
     __syncthreads();
     // ---- elimination row of the workgroup (teams in order)
-    PW_MARK(8);
     {
       CC_FRESH_TID(tid);
       if (tid < 2 * kPartialCols) {
@@ -822,8 +784,6 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
         ag_st(box + (size_t)blockIdx.x * (2 * kPartialCols) + tid, granule(tag, a, tid & 1));
       }
     }
-    PW_MARK(9);
-    PG_MARK(2);
     // ---- every sixteenth workgroup is a LEADER: it adds up the rows of its sixteen (it would only be waiting for the
     // step otherwise) and posts ONE row for the control, which then reads G / 16 rows in a single round trip instead of G
     if ((blockIdx.x % kPLeaderRows) == 0) {
@@ -832,7 +792,6 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
       double* lout = s_wg + 128;        // [80]; the group sums go through team 0's staging tiles (idle between sweeps)
       gather_rows<kPartialCols, THREADS / kPartialCols, (kPLeaderRows + THREADS / kPartialCols - 1) / (THREADS / kPartialCols)>(box + (size_t)g0 * (2 * kPartialCols), n, tag, kPartialCols, PC_GMAXP, s_stage + 2048, lout,
                                                         Q.fail, s_lok, (phase0 ? Q.first_shift : Q.timeout_shift));
-      PW_MARK(11);
       CC_FRESH_TID(tid);
       // (rows that did not arrive: nothing is posted, the control's own wait gives up and ends the solve -- as a failure)
       if (!*s_lok && tid == 0) __hip_atomic_store(Q.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -848,41 +807,12 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
 
     // =========================== the assumed decision: candidate accepted, radius at its clamp (see the control).
     // Eliminating NOW, next to the control's gathering and deciding, takes a seam out of the round when it holds.
-    PW_MARK(6);
-    PG_MARK(1);
     // (first round: the starting point is "accepted" at the initial radius unless the solve ends before it begins; its
     // elimination also computes the frame's Jacobi scale)
     const bool spec = do_sweep;
     const double radius_spec = phase0 ? s_wg[WG_R0] : persist_spec_radius(radius, s_wg[WG_OPT + 3]);
     if (spec) eliminate_and_post(dst, radius_spec, phase0, Q.pbox, e2);
-    PW_MARK(7);
-#ifdef CC_PERSIST_PROBE_ALLGATHER
-    // MEASUREMENT ONLY (review of round 5, item 4b): what a worker-side decision + solve would wait for -- EVERY worker gathers the
-    // leaders' rows itself (waves 1..3: 192 lanes, every word of the <= 16 rows of 160 in flight at once), next to the usual path.
-    // The completion times of the middle worker's three waves go to vec_solve[27..29].
-    if (spec && threadIdx.x >= 64 && threadIdx.x < 256) {
-      const int nw = ((Q.G + kPLeaderRows - 1) / kPLeaderRows) * 2 * kPartialCols, t = (int)threadIdx.x - 64;
-      u64 v[14];
-      double acc = 0.0;
-      for (unsigned spins = 0; spins < (1u << 14); ++spins) {
-        bool ok = true;
-#pragma unroll
-        for (int k = 0; k < 14; ++k) { const int w = t + 192 * k; v[k] = ag_ld(Q.lbox + (w < nw ? w : t)); }
-#pragma unroll
-        for (int k = 0; k < 14; ++k) ok = ok && (unsigned)(v[k] >> 32) == e2;
-        if (__all(ok)) break;
-        __builtin_amdgcn_s_sleep(1);
-      }
-#pragma unroll
-      for (int k = 0; k < 14; ++k) acc += (double)(unsigned)v[k];
-      if (acc == -1.0) s_wg[WG_X + 12] = acc;   // (keeps the loads alive)
-      if (round == CC_PERSIST_TIMING_ROUND && (int)blockIdx.x == (Q.G / 2 / kPLeaderRows) * kPLeaderRows && (threadIdx.x & 63) == 0)
-        P.vec_solve[27 + ((int)threadIdx.x >> 6) - 1] = (double)wall_clock64();
-    }
-#endif
     wait_bcast(e2);
-    PW_MARK(10);
-    PG_MARK(3);
     int fl = (int)s_wg[WG_X];
     if (fl & 16) failed = true;
     if (fl & 1) { cur = (fl >> 3) & 1; break; }
@@ -894,7 +824,6 @@ __global__ __launch_bounds__(TEAMS * 256, TEAMS) void k_intr_persist(IntrDev P, 
       radius = s_wg[WG_X + 1];
       eliminate_and_post(cur, radius, false, Q.rbox, e3);   // (never the first round: that one always holds or ends the solve)
       wait_bcast(e3);
-      PW_MARK(12);
       fl = (int)s_wg[WG_X];
       if (fl & 16) failed = true;
       if (fl & 1) { cur = (fl >> 3) & 1; break; }

@@ -25,7 +25,6 @@ struct PersistDev {
   uint32_t epoch0;            // epochs of this launch: epoch0 + 1 ...
   int32_t max_rounds;         // hard bound of the round loop (max_iterations + 2); three epochs per round
   int32_t restart;            // start from the state of the last set_state (init arrays) instead of buffer 0
-  int32_t stagger;            // team k enters the sweep's main loop k * stagger sleep units late (0: in lockstep)
   int32_t timeout_shift;      // a wait gives up after 2^shift ticks of the 100 MHz wall clock: 27 (1.3 s) alone on the device,
                               // 30 (10.7 s, the mailbox exchange's patience) with peer ranks
   int32_t first_shift;        // ... and the waits of the FIRST round: 20 (10.5 ms) alone on the device -- a first round that has not

@@ -175,17 +175,12 @@ __device__ __forceinline__ double wave_max(double v) {
 // (each within an ulp or two: 17 instructions). The correctly rounded sqrt, divide, sqrt sequence is 34 with its scaling and
 // special-case selects, and the WHOLE wave executes it whenever one of its 64 rows is an outlier -- with the reference's
 // threshold of three pixels that is most waves of a noisy scenario: 56.3 -> 50.5 us per launch of the frame sweep at
-// 8 x 2000 x 500. -DCC_RIG_EXACT_HUBER restores the library calls (A/B and parity forensics).
+// 8 x 2000 x 500. (The library calls are kept as a variant for parity forensics: scripts/variants/exact_arith.patch.)
 __device__ __forceinline__ void huber_outlier(double a, double s, double& r, double& sr) {
-#ifdef CC_RIG_EXACT_HUBER
-  r = sqrt(s);
-  sr = sqrt(fmax(2.2250738585072014e-308, a / r));
-#else
   const double y = rsqrt_pos(s);
   r = s * y;
   const double q = fmax(2.2250738585072014e-308, a * y);   // (a = 0: the same tiny weight the guarded divide gives)
   sr = q * rsqrt_pos(q);
-#endif
 }
 __device__ __forceinline__ void huber(double a, double s, double& rho, double& sr) {
   const double b = a * a;
@@ -249,56 +244,11 @@ __device__ __forceinline__ void rigk_obs(const double* k, const RigObs& o, doubl
   r.Bv0 = fy * dxy * iz; r.Bv1 = fy * dyy * iz; r.Bv2 = -(fy * dxy * x + fy * dyy * y) * iz;
 }
 
-// (timing-only builds: the middle workgroup leaves wall-clock marks in shared_stats[32..], scripts/time_rig_reduce.py)
-#ifdef CC_RIG_TIMING
-#define RSW_MARK(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) P.shared_stats[32 + (i)] = (double)wall_clock64(); } while (0)
-#else
-#define RSW_MARK(i) do { } while (0)
-#endif
-
 #include "cc_rig_sweeps.hpp"
 #include "cc_rig_steps.hpp"
 #include "cc_rig_big.hpp"
 #include "cc_rig_lean.hpp"
 
-#ifdef CC_RIG_TIMING
-// Timing-only: the factorisation routines alone, hot, on one workgroup (scripts/time_chol.py): `reps` factorisations of the same
-// S x S matrix (+ right-hand side) from global memory; out[0] = 100 MHz ticks per factorisation, out[1] = shader cycles.
-__global__ __launch_bounds__(256) void k_chol_bench(const double* Ain, int S, int reps, int which, double* out) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double* A = reinterpret_cast<double*>(smem_raw);
-  const int LD = (S + 1) | 1, tid = threadIdx.x, lane = tid & 63;
-  double* s_b = A + (size_t)S * LD;
-  double* s_inv = s_b + 128;
-  long long ticks = 0, cyc = 0;
-  double chk = 0.0;
-  for (int r = 0; r < reps; ++r) {
-    for (int i = tid; i < (S + 1) * LD; i += 256) A[i] = Ain[i];
-    __syncthreads();
-    const long long t0 = wall_clock64(), c0 = clock64();
-    if (which == 0 || which >= 2) {
-      chol_block4(A, S, LD, s_inv, nullptr, which == 2 ? 1 : 0);
-    } else {
-      double b0 = 0.0, b1 = 0.0, v0 = 0.0, v1 = 0.0;
-      bool okw = true;
-      if (tid < 64) b0 = lane < S ? s_b[lane] : 0.0;
-      for (int j0 = 0; j0 < S; j0 += 8) {
-        const int nc = S - j0 < 8 ? S - j0 : 8;
-        if (tid < 64) chol_panel<false>(A, S, LD, j0, nc, s_inv, b0, b1, v0, v1, okw);
-        __syncthreads();
-        const int t0c = j0 + nc;
-        if (t0c < S) chol_trail_mfma<2>(A, S, LD, j0, nc, t0c, S);
-        __syncthreads();
-      }
-      if (tid < 64 && lane < S) s_b[lane] = b0;
-    }
-    __syncthreads();
-    ticks += wall_clock64() - t0; cyc += clock64() - c0;
-    chk += s_b[S - 1];
-  }
-  if (tid == 0) { out[0] = (double)ticks / reps; out[1] = (double)cyc / reps; out[2] = chk; }
-}
-#endif
 
 // creation: world point of every observation
 __global__ void k_rig_expand_xyz(int64_t n, const int32_t* widx, const float* wxyz, float* oxyz) {
@@ -404,7 +354,6 @@ struct cc_rig {
   int form_reruns = 0;             // lean persistent solves that gave up and were run again in the three-kernel form
   int lean_strikes = 0;            // ... of them in the first round, in a row (two demote the handle)
   std::string form_note;           // why (cc_rig_solver_status)
-  bool gated = false;              // the last lean solve launched its control behind the workers' residency word
   hipStream_t stream2 = nullptr;   // the control workgroup's launch of the lean form
   hipEvent_t ev_begin = nullptr;
   cc::RigPersistDev pq{};
@@ -423,7 +372,6 @@ struct cc_rig {
   int reduce_blocks = 0;       // grid of the fused reduce + solve + update launch (rig_size_reduce_grid)
   size_t reduce_key = ~(size_t)0;
   std::vector<hipEvent_t> events;
-  int k2_grid = 1024;          // workgroups of k_rig_sweep_k2: four per compute unit (rig_layout)
   std::vector<int> event_kind;
   std::vector<int> event_round;   // round of the solve a probed launch belongs to (summarise_probes)
   int enq_round = 0;
@@ -571,16 +519,6 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
     bool on = per_group >= 448.0;
     if (const char* e = getenv("CC_RIG_K_COMPACT")) on = atoi(e) != 0;
     d.kcm = (kmode && !h->big && on) ? 1 : 0;
-  }
-  if (d.kcm) {
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus < 1) { (void)hipGetLastError(); cus = 256; }
-    // a workgroup per group by default: the persistent form (CC_RIG_K2_GRID=1024: four workgroups per compute unit, each looping over
-    // groups with the next group's loads under the current one's tail) measured SLOWER, 241 against 201 us at 8 x 2000 x 500 --
-    // what a group costs beyond its passes is instructions (lane sums, assembly), not latency, and other workgroups already cover the latency
-    (void)cus;
-    h->k2_grid = INT32_MAX;
-    if (const char* e = getenv("CC_RIG_K2_GRID")) { const int v = atoi(e); if (v >= 1) h->k2_grid = v; }   // (A/B; any grid is correct)
   }
   d.C = (int32_t)C; d.CO = CO; d.CK = CK; d.S = S; d.SW = S + 1;
   d.T = (d.SW + 15) / 16; d.nT = d.T * (d.T + 1) / 2; d.ZS = 16 * d.T + ((d.T & 1) ? 0 : 16);
@@ -812,7 +750,7 @@ static void rig_exchange_bounds(const cc_rig* h, int* doubles_kind0, int* double
 // S = 114: one block per CU) times the CUs, divided by the launches that share the device; one block per CU is kept in
 // hand where several fit (the query reads one high for kernels with 81..112 SGPRs: MI355X guide, residency). The column
 // sums and the pose update loop over chunks, so any grid >= 1 is correct; 128 blocks are the most that ever paid
-// (2000 frames: 124.4 us per iteration with 128, 127.2 with 64; CC_RIG_REDUCE_BLOCKS for A/B).
+// (2000 frames: 124.4 us per iteration with 128, 127.2 with 64).
 // Launches of this rank that share the device with other shards of the same solve (cc_rig_optimize_multi with a repeated
 // device id) or with other processes' ranks (cc_rig_exchange_attach with more ranks than visible devices).
 static int rig_co_resident(const cc_rig* h) {
@@ -831,7 +769,7 @@ static int rig_co_resident(const cc_rig* h) {
 static bool rig_unfused_exchange(const cc_rig* h) { return h->exchange && !h->big && rig_co_resident(h) > 1; }
 
 static int rig_size_reduce_grid(cc_rig* h) {
-  static const int rcap = getenv("CC_RIG_REDUCE_BLOCKS") ? std::max(1, atoi(getenv("CC_RIG_REDUCE_BLOCKS"))) : 128;
+  constexpr int rcap = 128;
   const int co = rig_co_resident(h);
   const size_t key = (h->solve_lds << 8) ^ ((size_t)co << 1) ^ (h->exchange ? 1u : 0u) ^ ((size_t)h->d.PC << 40) ^ ((size_t)h->F << 20);
   if (key == h->reduce_key && h->reduce_blocks > 0) return 0;
@@ -868,7 +806,7 @@ static int rig_enqueue_round(cc_rig* h, bool initial, bool profile, bool publish
   const RigDev& d = h->d;
   struct RoundCount { cc_rig* h; ~RoundCount() { h->enq_round++; } } count_round{h};
   { RigProbe p(h, CC_K_SWEEP, profile);
-    if (d.kcm) hipLaunchKernelGGL(k_rig_sweep_k2, dim3((unsigned)std::min<int64_t>(h->NG, h->k2_grid)), dim3(128), 0, h->stream, d);   // (each workgroup loops over groups)
+    if (d.kcm) hipLaunchKernelGGL(k_rig_sweep_k2, dim3((unsigned)h->NG), dim3(128), 0, h->stream, d);   // (a workgroup of two waves per group)
     else if (d.kmode && h->sweep_waves == 1) hipLaunchKernelGGL(k_rig_sweep_adjk<1>, dim3((unsigned)h->NG), dim3(64), 0, h->stream, d);
     else if (d.kmode) hipLaunchKernelGGL(k_rig_sweep_adjk<4>, dim3((unsigned)h->NG), dim3(256), 0, h->stream, d);
     else if (d.fmode) {
@@ -1316,7 +1254,7 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
   if (int rc = dev_zeroed(h, &d.sp, (size_t)F * 8)) return rc;
   if (int rc = dev_zeroed(h, &d.ss, (size_t)256)) return rc;
   if (int rc = dev_zeroed(h, &d.ds, (size_t)256)) return rc;
-  if (int rc = dev_zeroed(h, &d.shared_stats, (size_t)64)) return rc;   // [0..3] statistics, [8..] timing marks (CC_RIG_TIMING builds)
+  if (int rc = dev_zeroed(h, &d.shared_stats, (size_t)64)) return rc;   // [0..3] statistics; the rest is what the timing variants leave their marks in (scripts/variants/timing.patch)
   // one piece: control block | its copy for the host (ctl_next) | 16 synchronisation words (RigDev::arrive) | publication
   // counter -- a solve starts by zeroing the first three with ONE fill (rig_begin)
   if (int rc = dev_zeroed(h, &d.ctl, (size_t)4)) return rc;
@@ -1600,10 +1538,8 @@ static int rig_launch(cc_rig* h, RigRun* r, int chunk) {
     // on a compute unit no worker needs. (First version of the round: hipStreamWaitValue32 on signal memory -- right, but a
     // command processor that finds the value not there yet goes to sleep: +154 us per solve at 250 workgroups of 1024
     // threads. Without any gate a candidate that starts BEFORE the workers can claim the last compute unit of an XCD that
-    // 32 workers need: seen at once on the first box tried, CC_RIG_CTL_GATE=0.)
-    static const bool use_gate = !(getenv("CC_RIG_CTL_GATE") && atoi(getenv("CC_RIG_CTL_GATE")) == 0);
-    q.gate = use_gate ? const_cast<unsigned long long*>(h->host_pub) + 22 : nullptr;
-    h->gated = q.gate != nullptr;
+    // 32 workers need: seen at once on the first box tried.)
+    q.gate = const_cast<unsigned long long*>(h->host_pub) + 22;
     const size_t lb = (size_t)rpw_lds_doubles(h->p_teams) * 8;
     if (h->p_teams == 1) hipLaunchKernelGGL(k_rig_persist_w<1>, dim3((unsigned)q.G), dim3(256), lb, h->stream, h->d, q);
     else if (h->p_teams == 2) hipLaunchKernelGGL(k_rig_persist_w<2>, dim3((unsigned)q.G), dim3(512), lb, h->stream, h->d, q);
@@ -1681,11 +1617,11 @@ static int rig_wait(cc_rig* h, RigRun* r) {
     if (hipMemcpy(w, h->d.arrive, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) (void)hipGetLastError();
     char note[512];
     std::snprintf(note, sizeof(note), "lean persistent solve gave up in round %d after a %s wait (%d worker workgroups of %d threads + control): "
-                  "%u workers had started, control workgroup %s (candidate %u, XCD %d)%s; the solve was run again with three kernels per "
+                  "%u workers had started, control workgroup %s (candidate %u, XCD %d); the solve was run again with three kernels per "
                   "iteration and the handle %s (kernel-serialising tools, a CU mask, another tenant on the device or another host thread "
                   "in a call that waits for the device cause this)",
                   r->st.iter, first_round ? "42 ms" : "1.3 s", h->pq.G, h->p_teams * 256, w[13], w[12] ? "claimed a compute unit" : "NEVER RAN", w[12] >> 8,
-                  (int)(w[12] & 0xffu) - 1, h->gated ? "" : ", control launched without waiting for the workers (CC_RIG_CTL_GATE=0)",
+                  (int)(w[12] & 0xffu) - 1,
                   h->persist_w_ok ? "tries the lean form again next time" : "stays on that form");
     h->form_note = note;
     r->rerun = true;
@@ -1986,29 +1922,6 @@ int cc_rig_exchange_attach(cc_rig* h, int32_t rank, int32_t nranks, const uint8_
   return rig_adopt_global_cameras(h, flags);
 }
 
-#ifdef CC_RIG_TIMING
-// timing-only builds: out[0..2] = ticks (100 MHz) and shader cycles per factorisation of a random SPD S x S system, checksum
-int cc_rig_debug_chol_bench(int32_t S, int32_t reps, int32_t which, double* out) {
-  using namespace cc;
-  const int LD = (S + 1) | 1;
-  std::vector<double> A((size_t)(S + 1) * LD + 256, 0.0);
-  for (int i = 0; i < S; ++i) {
-    for (int j = 0; j <= i; ++j) A[(size_t)i * LD + j] = i == j ? S + 1.0 : 1.0 / (1 + i + j);
-    A[(size_t)S * LD + i] = 1.0 + i;
-  }
-  double *dA = nullptr, *dout = nullptr;
-  CC_HIP(hipMalloc(&dA, A.size() * 8));
-  CC_HIP(hipMalloc(&dout, 64));
-  CC_HIP(hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice));
-  const size_t lds = ((size_t)(S + 1) * LD + 5 * 128) * 8;
-  CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_bench), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_chol_bench, dim3(1), dim3(256), lds, 0, dA, S, reps, which, dout);
-  CC_HIP(hipDeviceSynchronize());
-  CC_HIP(hipMemcpy(out, dout, 24, hipMemcpyDeviceToHost));
-  hipFree(dA); hipFree(dout);
-  return CC_OK;
-}
-#endif
 
 // Debug/test aid (not declared in the public header): copies a named device buffer to the host.
 int cc_rig_debug_fetch(cc_rig* h, const char* name, double* out, int64_t n) {

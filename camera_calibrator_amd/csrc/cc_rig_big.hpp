@@ -283,7 +283,6 @@ __global__ __launch_bounds__(256) void k_rig_solve_big(RigDev P, double* Aglobal
   __shared__ int s_cholok, s_stepok, s_go;
   __shared__ double s4[4];
   __shared__ double s8[8];
-  __shared__ double s_r;
   __shared__ LmCtl s_c;
   const int tid = threadIdx.x, lane = tid & 63;
   const int cur = cn->cur, dst = cur ^ 1;

@@ -138,13 +138,6 @@ __device__ __forceinline__ bool rig_gather_cols(const u64* box, int G, int rowle
   return s_good != 0;
 }
 
-#ifdef CC_RIG_PTIMING
-#define RPW_MARK(i) do { if (round == 3 && blockIdx.x == 0 && threadIdx.x == 0) P.vec_stats[8 + (i)] = (double)wall_clock64(); } while (0)
-#define RPC_MARK(i) do { if (round == 3 && threadIdx.x == 0) P.vec_stats[40 + (i)] = (double)wall_clock64(); } while (0)
-#else
-#define RPW_MARK(i) do { } while (0)
-#define RPC_MARK(i) do { } while (0)
-#endif
 // The control workgroup of the persistent rig kernels (256 threads; dynamic LDS: the solve step's, rig_solve_block): block G of
 // k_rig_persist, or a launch of its own next to the lean workers of k_rig_persist_w (k_rig_persist_ctl).
 __device__ __forceinline__ void rig_persist_control(const RigDev& P, const RigPersistDev& Q, char* smem_raw) {
@@ -190,7 +183,6 @@ __device__ __forceinline__ void rig_persist_control(const RigDev& P, const RigPe
       const unsigned e = Q.epoch0 + (unsigned)round + 1u;
       const bool phase0 = round == 0;
       // ---- broadcast B(e): what this round's sweep evaluates
-      RPC_MARK(0);
       if (tid == 0) {
         s_bc[0] = (double)((s_ctl.done ? 1 : 0) | ((phase0 || s_ctl.step_valid) ? 2 : 0) | ((s_ctl.cur & 1) << 3));
         s_bc[1] = s_ctl.radius;
@@ -202,7 +194,6 @@ __device__ __forceinline__ void rig_persist_control(const RigDev& P, const RigPe
       for (int w = tid; w < 2 * NB; w += 256) ag_st(Q.ybox + w, granule(e, s_bc[w >> 1], w & 1));
       if (s_ctl.done) break;
       // ---- statistics rows -> decision
-      RPC_MARK(1);
       const bool swept = phase0 || s_ctl.step_valid;
       {
         const int nst = phase0 ? KS : 4;
@@ -222,7 +213,6 @@ __device__ __forceinline__ void rig_persist_control(const RigDev& P, const RigPe
       }
       if (failed) break;
       // |x|^2 of the shared block at the starting point (k_rig_init)
-      RPC_MARK(2);
       double x2_shared = 0.0;
       if (phase0) {
         double x2 = 0.0;
@@ -263,7 +253,6 @@ __device__ __forceinline__ void rig_persist_control(const RigDev& P, const RigPe
       if (tid < S) { s_a[2 + tid] = phase0 ? s_ss[tid] : 0.0; if (phase0) P.ss[tid] = s_ss[tid]; }
       __syncthreads();
       for (int w = tid; w < 2 * (2 + S); w += 256) ag_st(Q.abox + w, granule(e, s_a[w >> 1], w & 1));
-      RPC_MARK(3);
       if (s_ctl.done) {
         if (tid == 0) { *P.ctl = s_ctl; *P.ctl_next = s_ctl; }
         break;
@@ -305,12 +294,10 @@ __device__ __forceinline__ void rig_persist_control(const RigDev& P, const RigPe
       }
       __syncthreads();
       if (s_flag == 1) { failed = true; break; }
-      RPC_MARK(4);
       if (tid == 0) { *P.ctl = s_ctl; *P.ctl_next = s_ctl; }   // (rig_solve_block finishes the record of this round in P.log)
       __syncthreads();
       rig_solve_block<3>(Pc, smem, &s_ctl, vl);
       __syncthreads();
-      RPC_MARK(5);
       if (tid == 0) s_ctl = *P.ctl;   // as the solve step left it (this workgroup wrote it)
       __syncthreads();
     }
@@ -509,11 +496,9 @@ __global__ __launch_bounds__(TEAMS * 256) void k_rig_persist_w(RigDev P, RigPers
     const unsigned e = Q.epoch0 + (unsigned)round + 1u;
     const bool phase0 = round == 0;
     // ---- broadcast B: step and camera records
-    RPW_MARK(0);
     if (wave == 0 && !rig_bcast_wait(Q.ybox, e, NB, s_bc, fail, phase0 ? Q.first_shift : Q.timeout_shift)) s_bc[0] = 1.0;
     __syncthreads();
     const int flb = (int)s_bc[0];
-    RPW_MARK(1);
     if (flb & 1) { cur = (flb >> 3) & 1; break; }
     cur = (flb >> 3) & 1;
     const bool swept = (flb & 2) != 0;
@@ -573,14 +558,12 @@ __global__ __launch_bounds__(TEAMS * 256) void k_rig_persist_w(RigDev P, RigPers
       }
       __syncthreads();
       // ---- sweep: one wave per group
-      RPW_MARK(2);
       if (g_mine >= 0) {
         const RigSweepIO io{s_bc + 2 + S, tm + RPW_FREC, s_comp + ((team * 4 + twave) * 2 + cur) * 64, s_tile + ((team * 4 + twave) * 2 + dst) * 256,
                             s_comp + ((team * 4 + twave) * 2 + dst) * 64, tm + RPW_GST + 2 * twave, tm + RPW_HD0 + 8 * twave};
         rig_sweep_adj_body<1, true>(P, g_mine, phase0 ? 0 : 1, cur, s_sw + wave * 256, io);
       }
       __syncthreads();
-      RPW_MARK(3);
     }
     // ---- statistics row of the workgroup (teams and slots in order)
     {
@@ -608,7 +591,6 @@ __global__ __launch_bounds__(TEAMS * 256) void k_rig_persist_w(RigDev P, RigPers
       const int nst = phase0 ? KS : 4;
       if (tid < 2 * nst) ag_st(Q.sbox + ((size_t)blockIdx.x * KS) * 2 + tid, granule(e, s_row[tid >> 1], tid & 1));
     }
-    RPW_MARK(4);
     // ---- the assumed decision (cf. cc_intrinsics_persist.hip): candidate accepted, radius at its clamp -- the normal outcome of a
     // step that works. The workers eliminate the candidate NOW, next to the control's gathering and deciding; when the
     // decision is what was assumed (broadcast A says so) the rows are already where the control looks for them.
@@ -744,7 +726,6 @@ __global__ __launch_bounds__(TEAMS * 256) void k_rig_persist_w(RigDev P, RigPers
     }
     __syncthreads();
     // ---- the workgroup's row (teams in order) -> granules
-    if (!is_spec) RPW_MARK(6); else RPW_MARK(9);
     {
       int tid = tid0;
       asm volatile("" : "+v"(tid));
@@ -759,7 +740,6 @@ __global__ __launch_bounds__(TEAMS * 256) void k_rig_persist_w(RigDev P, RigPers
         ag_st(q + 1, granule(e, v, 1));
       }
     }
-    if (!is_spec) RPW_MARK(7); else RPW_MARK(10);
     // ---- this workgroup's share of the column sums: columns b, b + G, ...
     for (int c0 = (int)blockIdx.x; c0 < K; c0 += 8 * G) {
       int tidc = tid0;
@@ -786,7 +766,6 @@ __global__ __launch_bounds__(TEAMS * 256) void k_rig_persist_w(RigDev P, RigPers
     if (wave == 0 && !rig_bcast_wait(Q.abox, e, 2 + S, s_a, fail, Q.timeout_shift)) s_a[0] = 1.0;
     __syncthreads();
     const int fla = (int)s_a[0];
-    RPW_MARK(5);
     if (fla & 1) { cur = (fla >> 3) & 1; break; }
     if (fla & 4) {   // the assumption held
       cur = dst;
@@ -802,7 +781,6 @@ __global__ __launch_bounds__(TEAMS * 256) void k_rig_persist_w(RigDev P, RigPers
       __syncthreads();
       eliminate_and_post(cur, radius, phase0, Q.rbox, Q.cbox, false);
     }
-    RPW_MARK(8);
   }
   // ---- the solve is over: the frame's accepted pose goes back to global memory (cc_rig_get_state, the next solve)
   __syncthreads();

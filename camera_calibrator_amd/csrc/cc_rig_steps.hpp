@@ -413,13 +413,6 @@ __global__ __launch_bounds__(256) void k_rig_init(RigDev P) {
 //   the (SW x SW) product Z^T Z goes to wave (index mod 4), 6 k-steps of v_mfma_f64_16x16x4_f64.
 // Partial row of a block: [nT tiles x 256 | ND direct sums | Cholesky failures | max |g_frame|].
 // ---------------------------------------------------------------------------------------------
-// (timing-only builds: block 0 leaves wall-clock marks in shared_stats[20..], scripts/time_rig_reduce.py)
-#ifdef CC_RIG_TIMING
-#define ELIM_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) P.shared_stats[20 + (i)] = (double)wall_clock64(); } while (0)
-#else
-#define ELIM_MARK(i) do { } while (0)
-#endif
-
 // NR = direct-sum accumulators per lane: 8 covers ND <= 512 (the usual rigs: <= 18 observed cameras with poses only, 3 with
 // intrinsics), 24 the full range; the small variant exists because the kernel sits at the register limit.
 // The elimination as a function: k_rig_elim (a launch of its own: trust-region decision, then the elimination) and the
@@ -449,9 +442,6 @@ __device__ __forceinline__ void rig_elim_body(const RigDev& P, char* smem_raw, c
                                               //  being hoisted out of its round loop and kept -- spilled -- across the sweep)
   const int tid = tid_, lane = tid & 63, wave = tid >> 6;
   const LmCtl* ctl = P.ctl;
-#ifdef CC_RIG_TIMING
-  const long long tm0 = wall_clock64();
-#endif
   const int ctl_done = PS ? 0 : ctl->done, ctl_phase = PS ? 1 : ctl->phase;
   // what thread 0 needs for the trust-region decision, fetched now instead of behind the statistics barrier
   LmCtl c_in;
@@ -522,9 +512,6 @@ __device__ __forceinline__ void rig_elim_body(const RigDev& P, char* smem_raw, c
     t_ij[u] = __builtin_amdgcn_readfirstlane((int)P.tile_i[ic] | ((int)P.tile_j[ic] << 8));
   }
   if (ctl_done || ctl_phase == 0) return;
-#ifdef CC_RIG_TIMING
-  const long long tm1 = wall_clock64();
-#endif
   bool pending = false;
   if constexpr (!PS) {
   pending = ctl->cand_pending != 0;
@@ -553,9 +540,6 @@ __device__ __forceinline__ void rig_elim_body(const RigDev& P, char* smem_raw, c
   if (tid < P.S) s_ss[tid] = (PS ? ps_ss : P.ss)[tid];
   for (int i = tid; i < 24 * P.ZS; i += 256) s_Z[i] = 0.0;   // padding columns stay zero
   __syncthreads();
-#ifdef CC_RIG_TIMING
-  const long long tm2 = wall_clock64();
-#endif
   if (!PS && s_ctl.done) return;
   const int cur = PS ? ps_cur : s_ctl.cur;
   const double inv_radius = 1.0 / (PS ? ps_radius : s_ctl.radius);
@@ -574,10 +558,6 @@ __device__ __forceinline__ void rig_elim_body(const RigDev& P, char* smem_raw, c
   for (int u = 0; u < kRigTilesPerWave; ++u) acc[u] = d4{0.0, 0.0, 0.0, 0.0};
   double gmax = 0.0, nfail = 0.0;
   double* As = s_A + wave * 32;
-#ifdef CC_RIG_TIMING
-  if (blockIdx.x == 0 && tid == 0) { P.shared_stats[20] = (double)tm0; P.shared_stats[21] = (double)tm1; P.shared_stats[22] = (double)tm2; }
-#endif
-  ELIM_MARK(3);
 
   int gj_next = gj_first;
   const int nr = (P.ND + 63) >> 6;   // direct-sum registers in use (uniform)
@@ -684,7 +664,6 @@ __device__ __forceinline__ void rig_elim_body(const RigDev& P, char* smem_raw, c
 #pragma unroll
       for (int i = 0; i < 27; ++i) A[i] = As[i];
       wave_lds_fence();
-      if (fb == (int64_t)blockIdx.x * 4) ELIM_MARK(4);
       if (first_elim) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) sf[i] = jac ? 1.0 / (1.0 + sqrt(A[tri(i, i)])) : 1.0;
@@ -716,7 +695,6 @@ __device__ __forceinline__ void rig_elim_body(const RigDev& P, char* smem_raw, c
         }
       }
       if (!ok) nfail += 1.0;
-      if (fb == (int64_t)blockIdx.x * 4) ELIM_MARK(5);
       {   // the frame's share of Ceres' gradient_max_norm, ||x - Plus(x, -g)||_inf (pose_grad_proj_max, cc_common.hpp)
         const double q4[4] = {fq0, fq1, fq2, fq3};
         gmax = fmax(gmax, pose_grad_proj_max(q4, &A[21]));
@@ -754,7 +732,6 @@ __device__ __forceinline__ void rig_elim_body(const RigDev& P, char* smem_raw, c
         for (int i = 0; i < 6; ++i) s_Z[(wave * 6 + i) * ZS + k] = 0.0;
     }
     __syncthreads();
-    if (fb == (int64_t)blockIdx.x * 4) ELIM_MARK(6);
     // ---- Schur products of the four staged frames on the matrix cores
 #pragma unroll
     for (int u = 0; u < kRigTilesPerWave; ++u) {
@@ -771,9 +748,7 @@ __device__ __forceinline__ void rig_elim_body(const RigDev& P, char* smem_raw, c
       }
     }
     __syncthreads();
-    if (fb == (int64_t)blockIdx.x * 4) ELIM_MARK(7);
   }
-  ELIM_MARK(8);
 
   // ---- one partial row per block
   double* prow = P.partial + (size_t)blockIdx.x * P.PC;
@@ -812,7 +787,6 @@ __device__ __forceinline__ void rig_elim_body(const RigDev& P, char* smem_raw, c
     prow[P.pc_fail] = (s_fg[4] + s_fg[5]) + (s_fg[6] + s_fg[7]);
     prow[P.pc_gmax] = fmax(fmax(s_fg[0], s_fg[1]), fmax(s_fg[2], s_fg[3]));
   }
-  ELIM_MARK(9);
 }
 
 template <bool HK, int NR, bool FM = false, bool KC = false>
@@ -1093,18 +1067,10 @@ __device__ __forceinline__ void chol_trail_mfma(double* A, int S, int LD, int j0
 // the dependent chain (~12 instructions per column: 42 x 240 cycles = 4.2 us is the floor), and everything that can
 // leave the chain's wave must. s_inv[j] receives 1 / L_jj (backward substitution). All 256 threads call; returns whether
 // every pivot was positive and finite (valid in every thread).
-#ifdef CC_RIG_TIMING
-#define B4_MARK(k) do { if (marks) { const long long t_ = wall_clock64(); b4t[k] += t_ - b4last; b4last = t_; } } while (0)
-#else
-#define B4_MARK(k) do { } while (0)
-#endif
-__device__ __forceinline__ bool chol_block4(double* A, int S, int LD, double* s_inv, double* marks = nullptr, int ablate = 0) {
+__device__ __forceinline__ bool chol_block4(double* A, int S, int LD, double* s_inv) {
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63, kq = ln >> 4, c16 = ln & 15;
   __shared__ int s_okb;
   if (tid == 0) s_okb = 1;
-#ifdef CC_RIG_TIMING
-  long long b4t[6] = {0, 0, 0, 0, 0, 0}, b4last = wall_clock64();
-#endif
   // ---- waves 1..3: the tiles of the trailing update, dealt round robin; fixed rows / columns 16 ti.. / 16 tj.. (ti >= tj)
   const int n16 = (S + 1 + 15) >> 4, ntile = n16 * (n16 + 1) / 2;
   constexpr int kMaxT = 4;   // tiles per wave: ntile <= 10 over three waves (S <= 63)
@@ -1159,7 +1125,6 @@ __device__ __forceinline__ bool chol_block4(double* A, int S, int LD, double* s_
           for (int c2 = c + 1; c2 < 4; ++c2) x[c2] = fma(-y, readlane_d(y, (j0 + c2) & 63), x[c2]);
         }
       }
-      B4_MARK(0);
       if (ln <= S) {
         double* W = A + (size_t)ln * LD + j0;
 #pragma unroll
@@ -1168,7 +1133,6 @@ __device__ __forceinline__ bool chol_block4(double* A, int S, int LD, double* s_
       }
     }
     __syncthreads();   // panel j0 is in LDS; waves 1..3 have finished the previous block's trailing update
-    B4_MARK(1);
     if (t0 >= S) break;
     if (wv == 0) {
       // ---- look-ahead: this panel's update of the NEXT block's columns. The row's entries there (final but for this
@@ -1192,8 +1156,7 @@ __device__ __forceinline__ bool chol_block4(double* A, int S, int LD, double* s_
       }
 #pragma unroll
       for (int c = 0; c < 4; ++c) x[c] = (ln <= S && c < nbn && t0 + c <= ln) ? xn[c] : 0.0;
-      B4_MARK(2);
-    } else if (t0 + 4 < S && !(ablate & 1)) {
+    } else if (t0 + 4 < S) {
       // ---- waves 1..3: rank-nb update of the rest, columns >= t0 + 4 (the next block's are wave 0's), rows up to S
       const int kc = j0 + (kq < nb ? kq : 0);   // the lane's panel column (one k-step: column kq)
 #pragma unroll
@@ -1226,24 +1189,12 @@ __device__ __forceinline__ bool chol_block4(double* A, int S, int LD, double* s_
           }
         }
       }
-      B4_MARK(3);
     }
   }
   if (wv == 0 && ln == 0 && !ok) s_okb = 0;
   __syncthreads();
-#ifdef CC_RIG_TIMING
-  if (marks && tid == 0) { for (int k = 0; k < 5; ++k) marks[k] = (double)b4t[k]; }
-#endif
   return s_okb != 0;
 }
-
-// Timing-only builds (-DCC_RIG_TIMING, scripts/time_rig_reduce.py): the solving block leaves wall-clock marks
-// (100 MHz) in shared_stats[8..]; the product build compiles them away.
-#ifdef CC_RIG_TIMING
-#define RIG_MARK(i) do { if (threadIdx.x == 0) P.shared_stats[8 + (i)] = (double)wall_clock64(); } while (0)
-#else
-#define RIG_MARK(i) do { } while (0)
-#endif
 
 template <int SRC>
 __device__ void rig_solve_block(const RigDev& P, double* smem, const LmCtl* cn_in = nullptr, const double* vec_lds = nullptr, unsigned flag_epoch = 0u) {   // cn_in: the persistent kernels' control block (LDS); vec_lds: their reduced row (SRC 3)
@@ -1328,7 +1279,6 @@ __device__ void rig_solve_block(const RigDev& P, double* smem, const LmCtl* cn_i
     }
   }
   __syncthreads();
-  RIG_MARK(3);
   // ---- 2. right-hand side, LM diagonal, constant coordinates (held intrinsics) become identity rows
   if (tid < S) s_b[tid] = pinned ? 0.0 : s_b[tid] + s_ss[tid] * s_gs[tid];
   __syncthreads();
@@ -1373,17 +1323,11 @@ __device__ void rig_solve_block(const RigDev& P, double* smem, const LmCtl* cn_i
     s_c = c;
   }
   __syncthreads();
-  RIG_MARK(4);
   // Small reduced systems (poses of one to four optimised cameras: S = 6, 12, 18, 24 -- BASELINE configs[3] is S = 18): the
   // whole solve on wave 0 with the matrix distributed by rows over the lanes (chol_solve_rows, cc_device.hpp): pivots and
   // multipliers travel through v_readlane, no LDS vector, no panel loop, no barrier. S = 18: 7.5 -> ~3 us for the
-  // factorisation and both substitutions (profiles/r03/rig_stage_marks.jsonl). CC_RIG_PANEL_ONLY=1 (build flag) keeps the
-  // panel form for A/B.
-#ifndef CC_RIG_PANEL_ONLY
+  // factorisation and both substitutions (profiles/r03/rig_stage_marks.jsonl).
   const bool small_rows = S == 6 || S == 12 || S == 18 || S == 24;
-#else
-  const bool small_rows = false;
-#endif
   if (s_go && small_rows) {
     if (tid < 64) {
       bool okw = true;
@@ -1409,18 +1353,9 @@ __device__ void rig_solve_block(const RigDev& P, double* smem, const LmCtl* cn_i
       if (lane == 0) s_stepok = step_ok ? 1 : 0;
     }
     __syncthreads();
-#ifndef CC_RIG_PANEL8
   } else if (SRC != 3 && s_go && S <= 63) {   // (chol_block4: the right-hand side is row S on lane S of wave 0; SRC 3 -- the lean form's control workgroup -- only ever has S <= 24: the larger routines are not compiled into its kernel)
     // ---- medium systems: four columns at a time on all four waves, right-hand side as row S (chol_block4)
-#ifdef CC_RIG_TIMING
-    const long long tf0 = wall_clock64();
-    const long long cy0 = clock64();
-#endif
-    const bool okb = chol_block4(A, S, LD, s_inv, P.shared_stats + 48);
-#ifdef CC_RIG_TIMING
-    if (tid == 0) { P.shared_stats[16] = (double)(wall_clock64() - tf0); P.shared_stats[17] = 0.0; P.shared_stats[18] = (double)wall_clock64();
-                    P.shared_stats[54] = (double)(clock64() - cy0); P.shared_stats[55] = (double)(wall_clock64() - tf0); }   // shader cycles / 100 MHz ticks: the clock the solving block runs at
-#endif
+    const bool okb = chol_block4(A, S, LD, s_inv);
     if (tid < 64) {
       const int i0 = lane;
       double b0 = i0 < S ? s_b[i0] : 0.0, b1 = 0.0;          // y = L^-1 b (row S of the matrix)
@@ -1433,10 +1368,6 @@ __device__ void rig_solve_block(const RigDev& P, double* smem, const LmCtl* cn_i
       if (lane == 0) s_stepok = step_ok ? 1 : 0;
     }
     __syncthreads();
-#ifdef CC_RIG_TIMING
-    if (tid == 0) P.shared_stats[19] = (double)wall_clock64();
-#endif
-#endif
   } else if (SRC != 3 && s_go) {
     // ---- Cholesky of the damped reduced system in LDS, eight columns at a time (S <= 127):
     //   panel:    wave 0 (chol_panel), forward substitution included;
@@ -1445,33 +1376,19 @@ __device__ void rig_solve_block(const RigDev& P, double* smem, const LmCtl* cn_i
     double b0 = 0.0, b1 = 0.0, v0 = 0.0, v1 = 0.0;
     bool okw = true;
     if (tid < 64) { b0 = i0 < S ? s_b[i0] : 0.0; b1 = i1 < S ? s_b[i1] : 0.0; }
-#ifdef CC_RIG_TIMING
-    long long tw = 0, tt = 0;
-#endif
     for (int j0 = 0; j0 < S; j0 += 8) {
       const int nc = S - j0 < 8 ? S - j0 : 8;
-#ifdef CC_RIG_TIMING
-      const long long ta = wall_clock64();
-#endif
       if (tid < 64) {
         if (S <= 64) chol_panel<false>(A, S, LD, j0, nc, s_inv, b0, b1, v0, v1, okw);
         else chol_panel<true>(A, S, LD, j0, nc, s_inv, b0, b1, v0, v1, okw);
       }
       __syncthreads();
-#ifdef CC_RIG_TIMING
-      const long long tb = wall_clock64();
-      tw += tb - ta;
-#endif
       const int t0 = j0 + nc;
-#ifndef CC_CHOL_TRAIL_VALU
       if (t0 < S && S > 64) {
         // (large systems only -- cameras with their own intrinsics; for S <= 64 the element-wise form below is as fast
         // or faster: S = 18, 48.7 vs 49.6 us per iteration)
         chol_trail_mfma<2>(A, S, LD, j0, nc, t0, S);
       } else if (t0 < S) {
-#else
-      if (t0 < S) {
-#endif
         // trailing triangle rows t0..S-1, columns t0..row, as a flat list of elements dealt to the threads three at a
         // time: all LDS reads of a batch are issued before its first write (the elements are distinct and none lies
         // in the panel's columns, which the compiler cannot know), so a batch costs one LDS round trip, not three
@@ -1512,13 +1429,7 @@ __device__ void rig_solve_block(const RigDev& P, double* smem, const LmCtl* cn_i
         }
       }
       __syncthreads();
-#ifdef CC_RIG_TIMING
-      tt += wall_clock64() - tb;
-#endif
     }
-#ifdef CC_RIG_TIMING
-    if (tid == 0) { P.shared_stats[16] = (double)tw; P.shared_stats[17] = (double)tt; P.shared_stats[18] = (double)wall_clock64(); }
-#endif
     if (tid < 64) {
       if (S <= 64) chol_backward<false>(A, S, LD, b0, b1, v0, v1);
       else chol_backward<true>(A, S, LD, b0, b1, v0, v1);
@@ -1530,11 +1441,7 @@ __device__ void rig_solve_block(const RigDev& P, double* smem, const LmCtl* cn_i
       if (lane == 0) s_stepok = step_ok ? 1 : 0;
     }
     __syncthreads();
-#ifdef CC_RIG_TIMING
-    if (tid == 0) P.shared_stats[19] = (double)wall_clock64();
-#endif
   }
-  RIG_MARK(5);
   const bool have_step = s_go != 0 && s_stepok != 0;
   // Fused launch (k_rig_reduce<0>, flag_epoch != 0): the blocks waiting to update their frames need the shared step -- stored
   // and drained above -- and three bits of the control block that are final by now (done and cur do not change below,
@@ -1568,7 +1475,6 @@ __device__ void rig_solve_block(const RigDev& P, double* smem, const LmCtl* cn_i
     *P.ctl = c;
     *P.ctl_next = c;
   }
-  RIG_MARK(6);
 }
 
 // Hands the control block (and the failure word of the in-kernel waits) to the host without a copy engine in the way:
@@ -1674,9 +1580,6 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P, int publish) {
     return;
   }
   const int tid = threadIdx.x, c = tid & 15, grp = tid >> 4;  // 16 columns x 16 row groups per step
-#ifdef CC_RIG_TIMING
-  const long long t_entry = wall_clock64();
-#endif
   unsigned epoch0 = 0;
   if (FUSED) epoch0 = __hip_atomic_load(P.arrive + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 3;   // before we arrive
   for (int first = blockIdx.x * 16; first < P.PC; first += gridDim.x * 16) {
@@ -1733,9 +1636,6 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P, int publish) {
     }
   }
   if (!FUSED) return;
-#ifdef CC_RIG_TIMING
-  const long long t_sums = wall_clock64();
-#endif
   // ---- last-block-done: every storing wave drains its stores, the block arrives, the last one solves
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -1751,10 +1651,6 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P, int publish) {
   rig_update_prefetch(P, (int64_t)blockIdx.x * 16 + (tid >> 4), pre);   // (unconditional: loads inside an `if` would be waited for at its end)
   if (s_last) {
     if (tid == 0) __hip_atomic_store(P.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
-#ifdef CC_RIG_TIMING
-    if (tid == 0) { P.shared_stats[8] = (double)t_entry; P.shared_stats[9] = (double)t_sums; }
-#endif
-    RIG_MARK(2);
     rig_solve_block<MODE == 0 ? 1 : 2>(P, reinterpret_cast<double*>(smem_raw), nullptr, nullptr, MODE == 0 ? epoch0 + 1u : 0u);   // (MODE 0: raises the flag itself, early)
     // the shared step (sc1 stores of wave 0) has been drained inside; hand the outcome to the waiting blocks
     __syncthreads();
@@ -1791,9 +1687,5 @@ __global__ __launch_bounds__(256) void k_rig_reduce(RigDev P, int publish) {
   if (use_pre) rig_update_body<true, true>(P, 1, cur, (int64_t)blockIdx.x * 16 + (tid >> 4), pre);
   for (int64_t fblk = use_pre ? (int64_t)blockIdx.x + gridDim.x : (int64_t)blockIdx.x; fblk * 16 < P.F; fblk += gridDim.x)
     rig_update_body<true, false>(P, 1, cur, fblk * 16 + (tid >> 4), pre);
-#ifdef CC_RIG_TIMING
-  __syncthreads();
-  if (threadIdx.x == 0 && s_last) P.shared_stats[15] = (double)wall_clock64();   // mark 7 (written this way: RIG_MARK(7) inside `if (s_last)` trips a register-class bug of the compiler)
-#endif
 }
 

@@ -26,21 +26,17 @@ __device__ __forceinline__ void untri(int idx, int& i, int& j) {  // packed lowe
 // estimate and two Newton steps, five instructions instead of the twelve of the IEEE division sequence (scaling, fix-up).
 // Not correctly rounded: within an ulp or two of 1 / z, so the adjoint sweeps (the default) are not bit-identical to
 // the division form that k_rig_obs_cost and the oracle keep (parity is to the stated tolerances under either;
-// CC_RIG_EXACT_DIV keeps the division for A/B). Degenerate depths: z = 0 (and z = +-inf) give NaN here (0 * inf inside
+// the division form is kept as a variant, scripts/variants/exact_arith.patch). Degenerate depths: z = 0 (and z = +-inf) give NaN here (0 * inf inside
 // the first fma) where the division gives +-inf / 0. Both are "not finite" to everything downstream -- the candidate
 // cost fails isfinite() in lm_trial and counts as DBL_MAX, a Gram block holding either fails the Cholesky's
 // `d > 0 && isfinite(d)` test -> invalid step -> the radius shrinks -- so a point that lands on the camera plane is
 // rejected the same way in both forms; a select on the result would cost three instructions per observation of ~165.
 // A point BEHIND the camera (z < 0) is an ordinary finite value in both.
 __device__ __forceinline__ double recip_depth(double z) {
-#ifdef CC_RIG_EXACT_DIV
-  return 1.0 / z;
-#else
   double r = __builtin_amdgcn_rcp(z);
   r = fma(fma(-z, r, 1.0), r, r);
   r = fma(fma(-z, r, 1.0), r, r);
   return r;
-#endif
 }
 
 template <int SKIP>
@@ -99,9 +95,7 @@ __device__ __forceinline__ void reduce_scatter32(double* p, int lane) {
   p[0] += dpp_f64<0xB1>(p[0]);        // quad_perm:[1,0,3,2]
 }
 
-#ifndef CC_RIG_ADJ_WAVES
-#define CC_RIG_ADJ_WAVES 4   // waves per SIMD this sweep is compiled for (A/B knob)
-#endif
+constexpr int kRigAdjWaves = 4;    // waves per SIMD the one-wave-per-group sweep is compiled for (128 registers)
 // The sweep of one group as a function: k_rig_sweep_adj (one workgroup per group) and the persistent per-solve kernel
 // (k_rig_persist: WL -- "wave-local": the caller is ONE wave of a larger workgroup sweeping the groups of its frame one
 // after the other, so there is no workgroup barrier in here, the scratch `lds` is the wave's own, and the camera records
@@ -135,10 +129,8 @@ __device__ __forceinline__ void rig_sweep_adj_body(const RigDev& P, const int64_
   int tid_ = WL ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
   if (WL) asm volatile("" : "+v"(tid_));   // (a fresh copy per call: nothing derived from it is hoisted out of the persistent kernel's round loop)
   const int tid = tid_, lane = tid & 63, wave = tid >> 6;
-  RSW_MARK(0);
-  const int f = P.gframe[g], c = P.gcam[g];
+  const int c = P.gcam[g];
   const int64_t s0 = P.goff[g], s1 = P.goff[g + 1];
-  const int dst = phase == 0 ? cur : (cur ^ 1);
   const bool fixed = P.cam_fixed[c] != 0;
   // chunks dealt to the waves starting at wave (g mod NW), observations fetched one pass ahead by unconditional loads:
   // (idle slots re-read the group's first observation)
@@ -169,7 +161,6 @@ __device__ __forceinline__ void rig_sweep_adj_body(const RigDev& P, const int64_
     s_old[tid] = old;
   }
   sync();
-  RSW_MARK(1);
   double acc[32];
 #pragma unroll
   for (int e = 0; e < 32; ++e) acc[e] = 0.0;
@@ -206,7 +197,6 @@ __device__ __forceinline__ void rig_sweep_adj_body(const RigDev& P, const int64_
     s_e[tid] = e;
   }
   const double ha = P.huber_a;
-  RSW_MARK(2);
   struct ObsD { double u, v, X0, X1, X2; };
   auto widen = [](const ObsRaw& r, ObsD& d) { d.u = (double)r.m.x; d.v = (double)r.m.y; d.X0 = (double)r.X.x; d.X1 = (double)r.X.y; d.X2 = (double)r.X.z; };
   auto pass = [&](int k, const ObsD& r) {
@@ -246,7 +236,6 @@ __device__ __forceinline__ void rig_sweep_adj_body(const RigDev& P, const int64_
     widen(oa, d);
     fetch(k + 2 * NT, oa);
     pass(k, d);
-    if (p == 0) RSW_MARK(3);
     widen(ob, d);
     fetch(k + 3 * NT, ob);
     pass(k + NT, d);
@@ -256,7 +245,6 @@ __device__ __forceinline__ void rig_sweep_adj_body(const RigDev& P, const int64_
     widen(oa, d);
     pass(p * NT + otid, d);
   }
-  RSW_MARK(4);
   if (phase != 0 && tid < 27) {
     int i, j;
     untri(tid, i, j);
@@ -314,11 +302,10 @@ __device__ __forceinline__ void rig_sweep_adj_body(const RigDev& P, const int64_
     io.stats_out[0] = s_g[28];
     io.stats_out[1] = s_g[29];
   }
-  RSW_MARK(5);
 }
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64, NW == 1 ? CC_RIG_ADJ_WAVES : 3) void k_rig_sweep_adj(RigDev P) {   // (NW > 1: few, large groups -- registers rather than residency)
+__global__ __launch_bounds__(NW * 64, NW == 1 ? kRigAdjWaves : 3) void k_rig_sweep_adj(RigDev P) {   // (NW > 1: few, large groups -- registers rather than residency)
   __shared__ double s_lds[kRigSweepAdjLds(NW)];
   const LmCtl* ctl = P.ctl;
   const int done = ctl->done, phase = ctl->phase, step_valid = ctl->step_valid, cur = ctl->cur;
@@ -673,14 +660,12 @@ __global__ __launch_bounds__(NWF * 64, ONE ? 4 : (NWF <= 4 ? 3 : 2)) void k_rig_
 // AA = N^T G[0:7, 0:7] N, AB = N^T G[0:7, 7:16], BB = G[7:16, 7:16]. The compact record kept for the next sweep's
 // model-cost term is G itself and M: q = 1/2 (e'^T G e' - G[6][6]), e' = [dc + M_old df, 1, dk].
 // ---------------------------------------------------------------------------------------------
-#ifndef CC_RIG_ADJK_WAVES
-#define CC_RIG_ADJK_WAVES 3   // waves per SIMD the sweep with intrinsics is compiled for (A/B knob)
-#endif
+constexpr int kRigAdjkWaves = 3;   // waves per SIMD the sweep with intrinsics is compiled for
 constexpr int kRigCompK = 320;   // doubles per group and buffer of the compact record with intrinsics: G (256), M (36)
 // NW = waves per workgroup: one when the groups alone fill the chip (every wave then amortises the prologue, the
 // cross-lane epilogue and the assembly over all passes of its group and there is no cross-wave reduction), four otherwise.
 template <int NW>
-__global__ __launch_bounds__(NW * 64, CC_RIG_ADJK_WAVES) void k_rig_sweep_adjk(RigDev P) {
+__global__ __launch_bounds__(NW * 64, kRigAdjkWaves) void k_rig_sweep_adjk(RigDev P) {
   constexpr int NT = NW * 64, EPT = 256 / NT;
   __shared__ __attribute__((aligned(16))) double s_stage[NW * kStageDoublesPerWave];   // per wave 64 x 16; then the partial products
   __shared__ double sm[96];        // camera record, frame record, intrinsics record (candidate [0..8], step [16..24])
@@ -1038,26 +1023,23 @@ __device__ __forceinline__ double k2_qcoef(const unsigned* tab, int e, const dou
   return w * fa * fb;
 }
 
-#ifndef CC_RIG_K2_WAVES
-#define CC_RIG_K2_WAVES 2   // waves per SIMD the kernel is compiled for (256 registers)
-#endif
-// A workgroup (two waves) sweeps groups blockIdx.x, blockIdx.x + gridDim.x, ... one after the other (the grid is four workgroups
-// per compute unit: what fits next to the 248 registers). What a group needs before its first pass -- its indices, then its
-// records, old record and first observations: two dependent round trips of ~2 us each under load, a third of a workgroup's life
-// at 500 observations per group when every group was a workgroup of its own (profiles/r05/k2_stage_marks.jsonl) -- is requested
-// during the PREVIOUS group: the indices at its start, the rest right behind its main loop, under its lane sums and assembly.
+constexpr int kRigK2Waves = 2;     // waves per SIMD the kernel is compiled for (256 registers)
+// ONE workgroup (two waves) per group. What a group needs before its first pass -- its indices, then its records, old record and
+// first observations -- are two dependent round trips; a persistent form (four workgroups per compute unit looping over groups, the
+// next group's loads under the current one's tail) was built in round 5 and measured SLOWER (241 against 201 us at 8 x 2000 x 500:
+// what a group costs beyond its passes is instructions -- lane sums, assembly -- not latency, and the other workgroups of a compute
+// unit already cover the latency); removed in round 6.
 struct K2Group {   // what is known about a group before its sweep starts
   int f, c, ks, n, fixed;
   int64_t s0;
   uint32_t kmask;
 };
-__global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P) {
+__global__ __launch_bounds__(128, kRigK2Waves) void k_rig_sweep_k2(RigDev P) {
   __shared__ __attribute__((aligned(16))) d2 s_rows[2 * 14 * 64];   // [wave][q][lane]: u row entries (q < 7), v row entries
   __shared__ double sm[96];        // camera record, frame record, intrinsics record (candidate [0..8], step [16..24])
   __shared__ double s_G[144];      // lower triangle of G by pair, [136] cost of wave 0, [137] of wave 1, [138..139] model-cost sums
   __shared__ double s_m[36];       // M
   __shared__ double s_T[128];      // T (36) | H_fk (54) | g_f share (6) | H_ff share (21)
-  __shared__ long long s_next;     // persistent grid: the group this workgroup sweeps next
   __shared__ unsigned s_tab[kK2TabWords];   // the lane-indexed tables (kK2Tab), staged once
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const LmCtl* ctl = P.ctl;
@@ -1070,18 +1052,7 @@ __global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P)
     s_tab[tid] = t0; s_tab[tid + 128] = t1;
     if (tid + 256 < kK2TabWords) s_tab[tid + 256] = t2;
   }
-  const int64_t NG = P.NG, stride = gridDim.x;
-  const bool dynamic = stride < NG;   // (uniform) arrive[14] work counter, arrive[15] workgroups that have left: zeroed at the start of a solve
-                                      // and by the last workgroup of every launch to leave (every fetch of the launch is over by then)
-#ifdef CC_RIG_K2_TIMING   // (timing-only build: shader-clock cycles per phase, summed over the groups and passes of wave 0 of the middle workgroup -> shared_stats[40..])
-  long long k2t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  long long k2last = clock64();
-  const long long k2wall0 = wall_clock64();
-  int k2groups = 0;
-#define K2_T(i) do { const long long now_ = clock64(); k2t[i] += now_ - k2last; k2last = now_; } while (0)
-#else
-#define K2_T(i) do { } while (0)
-#endif
+  const int64_t NG = P.NG;
   struct F3 { float x, y, z; };
   struct ObsRaw { float2 m; F3 X; };
   struct ObsD { double u, v, X0, X1, X2; };
@@ -1107,11 +1078,12 @@ __global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P)
     old1 = rec_old[tid + 128];
   };
   const double ha = P.huber_a;
-  // ONE branch on the wave for the whole loop over groups (each arm its own register allocation: with a branch per row the arms
+  // ONE branch on the wave for the whole sweep (each arm its own register allocation: with a branch per row the arms
   // met four times a pass, ~90 register moves each to reconcile them)
   auto sweep = [&](auto wtag) {
   constexpr int W = decltype(wtag)::value;
-  int64_t g = blockIdx.x;
+  const int64_t g = blockIdx.x;
+  if (g >= NG) return;   // (uniform; the launch has one workgroup per group)
   K2Group q;
   group_indices(g, q);
   ObsRaw oa;
@@ -1119,26 +1091,14 @@ __global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P)
   group_loads(g, q, oa, recv, old0, old1);
   d2* mine = s_rows + (size_t)W * 14 * 64 + lane;
   const d2* theirs = s_rows + (size_t)(W ^ 1) * 14 * 64 + lane;
-  while (g < NG) {
-    // ---- the group's records into LDS; indices of the NEXT group requested
+  {
+    // ---- the group's records into LDS
     // (every per-lane index of the group's head and tail comes from a LAUNDERED copy of the thread id: derived from the original
-    // they are hoisted out of the loop over groups and kept alive -- spilled -- across its passes)
+    // they are kept alive -- spilled -- across the passes)
     int tid_h = threadIdx.x;
     asm volatile("" : "+v"(tid_h));
     if (tid_h < 96) sm[tid_h] = recv;
-    // persistent grid (fewer workgroups than groups): the next group comes from a counter, so that a workgroup that was handed
-    // cheap groups takes more of them (static strides ended 8 us behind one workgroup per group)
-    if (dynamic && tid_h == 0) s_next = (long long)stride + (long long)__hip_atomic_fetch_add(P.arrive + 14, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    lds_barrier();   // (LDS only: __syncthreads() would also wait for the previous group's record STORES, a memory round trip per group in a persistent grid)
-    K2_T(8);
-    int64_t gn = g + stride;
-    if (dynamic) {
-      const long long v = s_next;
-      gn = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v));
-    }
-    K2Group qn = q;
-    const bool more = gn < NG;   // (uniform)
-    if (more) group_indices(gn, qn);
+    lds_barrier();
     const int n = q.n, npass = (n + 127) >> 7;      // (the same for both waves: they meet at two barriers per pass)
     const bool fixed = q.fixed != 0;
     const uint32_t kmask = q.kmask;
@@ -1160,7 +1120,6 @@ __global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P)
     }
 #pragma unroll
     for (int i = 0; i < 9; ++i) kk[i] = rfl(sm[64 + i]);
-    K2_T(9);
     if (tid_h < 48) {   // M[a][b], a = tid >> 3, b = tid & 7 < 6 (see k_rig_sweep_adj)
       const int a = tid_h >> 3, b = tid_h & 7;
       const int a3 = a < 3 ? a : a - 3, b3 = b < 3 ? b : b - 3;
@@ -1170,20 +1129,15 @@ __global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P)
       const double v = (a < 3) == (b < 3) ? diag : (a >= 3 ? cross : 0.0);
       if (b < 6) s_m[a * 6 + b] = v;
     }
-    K2_T(10);
     // model-cost term of the step at the accepted point, from the group's old record (two entries per thread)
     double qterm = 0.0;
     if (phase != 0) qterm = k2_qcoef(s_tab, tid_h, sm, fixed ? 0.0 : 1.0) * old0 + k2_qcoef(s_tab, tid_h + 128, sm, fixed ? 0.0 : 1.0) * old1;
-    K2_T(0);
     double acc[kK2Acc];
 #pragma unroll
     for (int e = 0; e < kK2Acc; ++e) acc[e] = 0.0;
     double cost = 0.0;
     auto pass = [&](int k, const ObsD& r) {
       const bool valid = k < n;
-#ifdef CC_RIG_K2_TIMING
-      { double t_ = r.u + r.X0; asm volatile("" : "+v"(t_)); K2_T(5); }   // (the wait for this pass's observations, on its own)
-#endif
       RigObs o;
       o.a0 = Rca[0] * r.X0 + Rca[1] * r.X1 + Rca[2] * r.X2 + tca[0];
       o.a1 = Rca[3] * r.X0 + Rca[4] * r.X1 + Rca[5] * r.X2 + tca[1];
@@ -1247,9 +1201,7 @@ __global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P)
         mine[11 * 64] = d2{w[10], w[11]}; mine[12 * 64] = d2{w[12], w[13]}; mine[13 * 64] = d2{w[14], w[15]};
         k2_accumulate<W, 1>(w, acc);
       }
-      K2_T(1);
       lds_barrier();
-      K2_T(2);
       {
         double w[16];
         d2 t;
@@ -1270,31 +1222,9 @@ __global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P)
         w[7] = 0.0; w[9] = 0.0;
         k2_accumulate<W, 1>(w, acc);
       }
-      K2_T(3);
       lds_barrier();   // (both waves have read: the rows may be overwritten by the next pass)
-      K2_T(4);
     };
     // one register set, observations one pass ahead (two sets -- the pair of passes unrolled -- spill: 607 us against 209 at 8 x 2000 x 500)
-#ifdef CC_RIG_K2_TWO_AHEAD   // (A/B: two register sets, observations two passes ahead, the pair of passes unrolled)
-    ObsRaw ob;
-    fetch(tid + 128, ob);
-    int p = 0;
-    for (; p + 1 < npass; p += 2) {
-      const int k = p * 128 + tid;
-      ObsD d;
-      widen(oa, d);
-      fetch(k + 256, oa);
-      pass(k, d);
-      widen(ob, d);
-      fetch(k + 384, ob);
-      pass(k + 128, d);
-    }
-    if (p < npass) {
-      ObsD d;
-      widen(oa, d);
-      pass(p * 128 + tid, d);
-    }
-#else
     // (measured and dropped: one word of the observations two passes ahead, loaded and thrown away so that the real prefetch finds
     // its lines in L2 -- 210.7 us against 207.9 at 8 x 2000 x 500: the ~0.7 k cycles a pass waits for its observations are not
     // cache misses of the prefetch)
@@ -1305,9 +1235,6 @@ __global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P)
       fetch(k + 128, oa);
       pass(k, d);
     }
-#endif
-    // ---- the NEXT group's loads go out now: they travel under this group's lane sums and assembly
-    if (more) group_loads(gn, qn, oa, recv, old0, old1);
     // ---- sums over the lanes: 64 accumulators by the butterfly (value s ends in lane s), the others and the scalars by wave_sum
     int tid_t = threadIdx.x;
     asm volatile("" : "+v"(tid_t));
@@ -1335,7 +1262,6 @@ __global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P)
         else if (e8 == 5) s_G[138 + W] = t;
       }
     }
-    K2_T(6);
     if (tid_t < 4) s_G[tid_t == 0 ? 43 : (tid_t == 1 ? 62 : (tid_t == 2 ? 53 : 64))] = 0.0;   // the structurally zero pairs (fy, fx) (py, fx) (px, fy) (py, px)
     lds_barrier();
     auto G = [&](int i, int j) { const int hi = i > j ? i : j, lo = i > j ? j : i; return s_G[hi * (hi + 1) / 2 + lo]; };
@@ -1391,30 +1317,7 @@ __global__ __launch_bounds__(128, CC_RIG_K2_WAVES) void k_rig_sweep_k2(RigDev P)
       P.gstats[g * 2] = s_G[136] + s_G[137];
       P.gstats[g * 2 + 1] = s_G[138] + s_G[139];
     }
-    K2_T(7);
-#ifdef CC_RIG_K2_TIMING
-    ++k2groups;
-#endif
-    g = gn;
-    q = qn;
-    // (the next group's first barrier -- behind its store of the records into sm -- separates this group's last reads of s_G, s_T
-    // and s_m from the writes that follow)
   }
-  if (dynamic && tid == 0) {
-    const unsigned left = __hip_atomic_fetch_add(P.arrive + 15, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (left == (unsigned)stride - 1u) {
-      __hip_atomic_store(P.arrive + 14, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(P.arrive + 15, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-#ifdef CC_RIG_K2_TIMING
-  if (blockIdx.x == gridDim.x / 2 && tid == 0) {
-    for (int qq = 0; qq < 8; ++qq) P.shared_stats[40 + qq] = (double)k2t[qq];
-    P.shared_stats[48] = (double)(wall_clock64() - k2wall0);
-    P.shared_stats[49] = (double)k2groups;
-    for (int qq = 8; qq < 12; ++qq) P.shared_stats[42 + qq] = (double)k2t[qq];   // [50..53]: head of a group in pieces
-  }
-#endif
   };
   if (wave == 0) sweep(std::integral_constant<int, 0>{}); else sweep(std::integral_constant<int, 1>{});
 }

@@ -1,9 +1,6 @@
 #!/bin/bash
-# Timing-only ablation builds of the sweep kernel (results are wrong by construction):
-# 1 = no MFMA, 2 = no LDS staging writes, 3 = empty main loop (prologue + epilogue only).
+# Timing-only ablation builds of the sweep kernel k_intr_sweep (results are wrong by construction):
+# 1 = no MFMA, 2 = no LDS staging writes, 3 = empty main loop (prologue + epilogue only). The early returns live in
+# scripts/variants/timing.patch, not in the product sources.  ->  scripts/ablate_build/libcc_ab{1,2,3}.so (CC_LIB_PATH)
 set -e
-cd "$(dirname "$0")/../camera_calibrator_amd/csrc"
-for v in 1 2 3; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DCC_ABLATE=$v -c cc_intrinsics.hip -o /tmp/cc_intr_ab$v.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../scripts/ablate_build/libcc_ab$v.so /tmp/cc_intr_ab$v.o cc_rig.o cc_points.o cc_common.o cc_comm.o -ldl
-done
+for v in 1 2 3; do bash "$(dirname "$0")/build_variant.sh" ab$v cc_intrinsics.hip --patch timing -DCC_ABLATE=$v; done

@@ -51,8 +51,8 @@ bash scripts/ab_rig_sweep.sh > /dev/null 2>&1 && cp gpurun_out/ab_rig_sweep.txt 
 echo "rig done"
 bash scripts/pmc_compute.sh > /dev/null 2>&1 && (head -1 gpurun_out/pmc2/compute_summary.csv; grep "k_intr_" gpurun_out/pmc2/compute_summary.csv) > $OUT/pmc_compute.csv
 # stage breakdowns from the timing-only builds (wall-clock marks inside the kernels)
-bash scripts/build_variant.sh intrtime cc_intrinsics.hip -DCC_INTR_TIMING > /dev/null 2>&1
-bash scripts/build_variant.sh rigtime cc_rig.hip -DCC_RIG_TIMING > /dev/null 2>&1
+bash scripts/build_variant.sh intrtime cc_intrinsics.hip --patch timing -DCC_INTR_TIMING > /dev/null 2>&1
+bash scripts/build_variant.sh rigtime cc_rig.hip --patch timing -DCC_RIG_TIMING > /dev/null 2>&1
 (CC_LIB_PATH=scripts/ablate_build/libcc_intrtime.so python scripts/time_intr_decide.py; CC_LIB_PATH=scripts/ablate_build/libcc_intrtime.so F=125 python scripts/time_intr_decide.py) > $OUT/intr_stage_marks.jsonl 2>/dev/null
 (CC_LIB_PATH=scripts/ablate_build/libcc_rigtime.so python scripts/time_rig_reduce.py; CC_LIB_PATH=scripts/ablate_build/libcc_rigtime.so C=8 F=2000 M=500 python scripts/time_rig_reduce.py; CC_LIB_PATH=scripts/ablate_build/libcc_rigtime.so C=2 F=1000 M=4 python scripts/time_rig_reduce.py) > $OUT/rig_stage_marks.jsonl 2>/dev/null
 C=2 F=1000 M=4 python scripts/bench_rig.py >> $OUT/rig_bench.jsonl

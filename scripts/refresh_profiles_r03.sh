@@ -36,8 +36,8 @@ cp $(find $OUT/rigtrace -name "*kernel_stats.csv" | head -1) $OUT/rig_c4_kernel_
 cp $(find $OUT/rigtrace5 -name "*kernel_stats.csv" | head -1) $OUT/rig_c5_kernel_stats.csv
 echo "rig traces done"
 # stage breakdowns from the timing-only builds (wall-clock marks inside the kernels)
-bash scripts/build_variant.sh ptime cc_intrinsics_persist.hip -DCC_PERSIST_TIMING > /dev/null 2>&1
-bash scripts/build_variant.sh rigtime cc_rig.hip -DCC_RIG_TIMING > /dev/null 2>&1
+bash scripts/build_variant.sh ptime cc_intrinsics_persist.hip --patch timing -DCC_PERSIST_TIMING > /dev/null 2>&1
+bash scripts/build_variant.sh rigtime cc_rig.hip --patch timing -DCC_RIG_TIMING > /dev/null 2>&1
 (CC_LIB_PATH=scripts/ablate_build/libcc_ptime.so python scripts/time_intr_persist.py; CC_LIB_PATH=scripts/ablate_build/libcc_ptime.so F=500 python scripts/time_intr_persist.py; CC_LIB_PATH=scripts/ablate_build/libcc_ptime.so F=250 python scripts/time_intr_persist.py; CC_LIB_PATH=scripts/ablate_build/libcc_ptime.so F=125 python scripts/time_intr_persist.py) > $OUT/intr_persist_marks.jsonl 2>/dev/null
 # (the stage marks of the THREE-KERNEL form: small rigs run the lean persistent kernel by default)
 export CC_RIG_PERSIST=0
@@ -46,7 +46,7 @@ python scripts/bench_rig.py > $OUT/rig_bench_three_kernel.jsonl
 C=2 F=1000 M=4 python scripts/bench_rig.py >> $OUT/rig_bench_three_kernel.jsonl
 unset CC_RIG_PERSIST
 # round timelines of the persistent rig kernels (lean: default; glued: opt-in)
-bash scripts/build_variant.sh rptime cc_rig.hip -DCC_RIG_PTIMING > /dev/null 2>&1
+bash scripts/build_variant.sh rptime cc_rig.hip --patch timing -DCC_RIG_PTIMING > /dev/null 2>&1
 (CC_LIB_PATH=scripts/ablate_build/libcc_rptime.so python scripts/time_rig_persist.py; CC_LIB_PATH=scripts/ablate_build/libcc_rptime.so C=2 F=1000 M=4 python scripts/time_rig_persist.py; CC_RIG_PERSIST=1 CC_RIG_PERSIST_LEAN=0 CC_LIB_PATH=scripts/ablate_build/libcc_rptime.so python scripts/time_rig_persist.py) > $OUT/rig_persist_marks_raw.jsonl 2>/dev/null
 echo "marks done"
 # the two forms of the intrinsics solver on one box, per counted LM iteration (complete solves)

@@ -48,7 +48,7 @@ export CC_RIG_HOST_TIMING=1
 unset CC_RIG_HOST_TIMING
 echo "big / scaling / class surface done"
 # stage breakdowns from the timing-only build (wall-clock marks inside the kernels)
-bash scripts/build_variant.sh rigtime cc_rig.hip -DCC_RIG_TIMING > /dev/null 2>&1
+bash scripts/build_variant.sh rigtime cc_rig.hip --patch timing -DCC_RIG_TIMING > /dev/null 2>&1
 export CC_LIB_PATH=scripts/ablate_build/libcc_rigtime.so
 (CC_RIG_PERSIST=0 python scripts/time_rig_reduce.py; CC_RIG_PERSIST=0 C=8 F=2000 M=500 python scripts/time_rig_reduce.py; CC_RIG_PERSIST=0 C=8 F=2000 M=500 K=shared python scripts/time_rig_reduce.py) 2>/dev/null | grep "^{" > $OUT/rig_stage_marks.jsonl
 sed -i 's/for S in (30, 42, 63):/for S in (18, 30, 42, 51, 63):/' scripts/time_chol.py

@@ -1,5 +1,5 @@
 """The reduced system's factorisation routines alone, hot, on one workgroup (timing-only build -DCC_RIG_TIMING:
-scripts/build_variant.sh rigtime cc_rig.hip -DCC_RIG_TIMING; CC_LIB_PATH=scripts/ablate_build/libcc_rigtime.so).
+scripts/build_variant.sh rigtime cc_rig.hip --patch timing -DCC_RIG_TIMING; CC_LIB_PATH=scripts/ablate_build/libcc_rigtime.so).
 which 0: chol_block4 (four columns at a time, all waves), 1: eight-column panels on wave 0 + trailing updates on the matrix pipe."""
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

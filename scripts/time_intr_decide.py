@@ -1,5 +1,5 @@
 """Where the time of k_intr_decide_elim goes: wall-clock marks (100 MHz) of the block that arrives last -- the critical
-path -- left by a timing-only build (scripts/build_variant.sh intrtime cc_intrinsics.hip -DCC_INTR_TIMING;
+path -- left by a timing-only build (scripts/build_variant.sh intrtime cc_intrinsics.hip --patch timing -DCC_INTR_TIMING;
 CC_LIB_PATH=scripts/ablate_build/libcc_intrtime.so). Env F, M. Stage durations in microseconds, median over solves
 (marks of the last launch of a solve that runs MAXIT iterations without converging checks)."""
 import ctypes as C, json, os, sys

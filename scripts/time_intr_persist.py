@@ -1,6 +1,6 @@
 """Where a round of the persistent intrinsics kernel goes: wall-clock marks (100 MHz, one counter for the chip) left in
 round CC_PERSIST_TIMING_ROUND by a worker workgroup in the middle of the grid (a leader) and by the control workgroup of a timing-only build
-(scripts/build_variant.sh ptime cc_intrinsics_persist.hip -DCC_PERSIST_TIMING; CC_LIB_PATH=scripts/ablate_build/libcc_ptime.so).
+(scripts/build_variant.sh ptime cc_intrinsics_persist.hip --patch timing -DCC_PERSIST_TIMING; CC_LIB_PATH=scripts/ablate_build/libcc_ptime.so).
 Env F, M. Microseconds, median over solves; `t` = time since the worker's round start."""
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

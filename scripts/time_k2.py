@@ -1,5 +1,5 @@
 """Where the time of k_rig_sweep_k2 goes: shader-clock cycles per phase of wave 0 of the middle workgroup, from a timing-only build
-(scripts/build_variant.sh k2time cc_rig.hip -DCC_RIG_K2_TIMING; CC_LIB_PATH=scripts/ablate_build/libcc_k2time.so). Env: C F M K."""
+(scripts/build_variant.sh k2time cc_rig.hip --patch timing -DCC_RIG_K2_TIMING; CC_LIB_PATH=scripts/ablate_build/libcc_k2time.so). Env: C F M K."""
 import ctypes as C
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

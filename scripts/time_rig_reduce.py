@@ -1,5 +1,5 @@
 """Where the time of the rig path's reduce + solve + update launch goes: wall-clock marks left by the solving block of
-a timing-only build (scripts/build_variant.sh rigtime cc_rig.hip -DCC_RIG_TIMING; CC_LIB_PATH=scripts/ablate_build/libcc_rigtime.so).
+a timing-only build (scripts/build_variant.sh rigtime cc_rig.hip --patch timing -DCC_RIG_TIMING; CC_LIB_PATH=scripts/ablate_build/libcc_rigtime.so).
 Env: C F M (cameras, frames, points per frame). Prints the stage durations in microseconds (last iteration of a solve)."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

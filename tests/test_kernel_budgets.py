@@ -118,3 +118,60 @@ def test_every_rig_kernel_is_a_named_form():
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "camera_calibrator_amd", "csrc")
     sizes = {f: sum(1 for _ in open(os.path.join(root, f))) for f in ("cc_rig.hip", "cc_rig_sweeps.hpp", "cc_rig_steps.hpp", "cc_rig_big.hpp", "cc_rig_lean.hpp")}
     assert sizes["cc_rig.hip"] < 2500 and max(sizes.values()) < 2500, sizes
+
+
+# ---- round 6: the product translation units carry no timing / ablation / A-B text -----------------------------------------
+# Stage marks, early returns of ablation builds, the exact-arithmetic forms and the all-gather probe live in scripts/variants/*.patch
+# (applied to a scratch copy by scripts/build_variant.sh); A/B switches that had been decided were deleted. What is left to switch:
+_ALLOWED_ENV = {
+    # forms of the solvers the test-suite runs side by side
+    "CC_INTR_PERSIST", "CC_INTR_PERSIST_TEAMS", "CC_SWEEP_TILES", "CC_RIG_PERSIST", "CC_RIG_FORCE_BIG", "CC_RIG_SWEEP_FRAME",
+    "CC_RIG_SWEEP_WG_WAVES", "CC_RIG_FRAME_WAVES", "CC_RIG_K_COMPACT",
+    # test hooks of the persistent forms and of the per-device back-off
+    "CC_INTR_PERSIST_TEST_NO_CONTROL", "CC_RIG_PERSIST_TEST_NO_CONTROL", "CC_PERSIST_BACKOFF_CALLS", "CC_PERSIST_BACKOFF_MS",
+    # a user's business: launches of several processes / shards that share one device; host-side phase times to stderr
+    "CC_INTR_CO_RESIDENT", "CC_RIG_CO_RESIDENT", "CC_RIG_HOST_TIMING",
+}
+_ALLOWED_IFDEF = {"CC_HAVE_EIGEN", "CC_FORCE_MINI_EIGEN", "__has_include", "Eigen", "Dense", "__HIPCC__"}   # (types.hh: real Eigen when the include path has it)
+
+
+def _product_sources():
+    d = os.path.join(ROOT, "camera_calibrator_amd", "csrc")
+    for n in sorted(os.listdir(d)):
+        if n.endswith((".hip", ".hpp", ".cpp", ".hh")):
+            yield n, open(os.path.join(d, n)).read()
+
+
+def test_no_timing_or_ablation_text_in_the_product_sources():
+    banned = re.compile(r"CC_\w*TIMING(?<!CC_RIG_HOST_TIMING)\b|CC_ABLATE\w*|CC_\w*EXACT_\w+|CC_PERSIST_PROBE\w*|\b[A-Z0-9]+_MARK\(|\bK2_T\(")
+    hits = [(n, m.group(0)) for n, text in _product_sources() for m in banned.finditer(text)]
+    assert not hits, hits
+    for p in ("timing.patch", "exact_arith.patch"):
+        assert os.path.exists(os.path.join(ROOT, "scripts", "variants", p)), p
+
+
+def test_only_the_listed_switches_are_left():
+    envs, conds = set(), set()
+    for n, text in _product_sources():
+        envs |= set(re.findall(r'getenv\("(\w+)"\)', text))
+        envs |= set(re.findall(r'persist_test_drop_control\("(\w+)"', text))
+        for m in re.finditer(r"^\s*#\s*(?:ifdef|ifndef|if|elif)\s+(.*)$", text, flags=re.M):
+            conds |= set(re.findall(r"[A-Za-z_]\w*", m.group(1))) - {"defined"}
+    assert envs <= _ALLOWED_ENV, sorted(envs - _ALLOWED_ENV)
+    assert conds <= _ALLOWED_IFDEF, sorted(conds - _ALLOWED_IFDEF)
+
+
+@pytest.mark.parametrize("name", ["timing", "exact_arith"])
+def test_variant_patches_still_apply_to_the_product_sources(name, tmp_path):
+    """scripts/variants/*.patch carry the text that left the product sources; an edit of a patched region must regenerate them
+    (scripts/build_variant.sh says how) -- a patch that no longer applies fails HERE, not on the GPU box in the middle of a measurement."""
+    import shutil
+    src = os.path.join(ROOT, "camera_calibrator_amd", "csrc")
+    dst = tmp_path / "csrc"
+    dst.mkdir()
+    for n in os.listdir(src):
+        if n.endswith((".hip", ".hpp", ".cpp", ".hh")):
+            shutil.copy(os.path.join(src, n), dst / n)
+    r = subprocess.run(["patch", "-p0", "--dry-run", "-F", "0", "-i", os.path.join(ROOT, "scripts", "variants", name + ".patch")],
+                       cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0 and "FAILED" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
