@@ -1,4 +1,4 @@
-"""The two forms of the intrinsics solver (DESIGN.md 4.0 / 4.1) against the same parity suite.
+"""The two forms of the intrinsics solver (DESIGN.md 4.1 / 4.2) against the same parity suite.
 
 cc_intrinsics_solve runs the persistent per-solve kernel whenever every frame fits a resident workgroup -- with the
 FEWEST frames per workgroup that do, i.e. one frame per workgroup for every problem the parity tests are small enough to

@@ -53,7 +53,7 @@ def test_rig_sweeps_keep_their_register_allocation():
         assert t[k]["vspill"] == 0 and t[k]["scratch"] == 0, (k, t[k])            # (sits at the 512-register limit by design)
     # the plain large-rig elimination keeps 136 tile accumulators per thread: compile-time pair indices leave it at 8 spilled
     # vector registers and < 100 scalar ones (table-driven pair indices: 229 + 375 -- the reconstruction of round 3's first
-    # version, -DCC_EXP_ELIMBIG_TABLES, which passes the suites all the same: DESIGN.md rig item 7)
+    # version, -DCC_EXP_ELIMBIG_TABLES, which passes the suites all the same: DESIGN.md 4.5 item 4; git show 5a0d480:DESIGN.md for the account)
     for k in ("k_rig_elim_big<false>", "k_rig_elim_big<true>"):
         assert t[k]["vspill"] <= 8 and t[k]["sspill"] <= 100, (k, t[k])
     # frame form of the sweep: a wave per group (ONE) at four waves per SIMD -- its few spills are in the once-per-frame assembly,
