@@ -1000,23 +1000,32 @@ __device__ __forceinline__ void chol_backward(const double* A, int S, int LD, do
 // step). Two tiles per round: every LDS read of both (operands and the elements to update) is issued before the first
 // matrix instruction -- one LDS round trip and one matrix-pipe latency per pair instead of per tile. All 256 threads call.
 // RE: one past the last ROW updated -- S, or S + 1 when the right-hand side rides along as row S of the matrix (chol_block4).
-template <int KS>
-__device__ __forceinline__ void chol_trail_mfma(double* A, int S, int LD, int j0, int nc, int t0, int RE) {
+// PART / w / nw (round 6, look-ahead of the eight-column panels): which tiles and on which waves. PART 0: every tile; 1: the tiles
+// of the FIRST tile column only (columns t0 .. t0 + 15: the next two panels' columns); 2: all the others. The caller's wave is
+// number w of the NWV that take part (tiles dealt round robin, two per round as before).
+template <int KS, int PART = 0, int NWV = 4>
+__device__ __forceinline__ void chol_trail_mfma(double* A, int S, int LD, int j0, int nc, int t0, int RE, int w = -1) {
   const int tid = threadIdx.x;
-  const int nt = RE - t0, n16 = (nt + 15) >> 4, ntile = n16 * (n16 + 1) / 2;
-  const int wv = tid >> 6, ln = tid & 63, kq = ln >> 4, c16 = ln & 15;
-  for (int tb = wv; tb < ntile; tb += 8) {
+  const int nt = RE - t0, n16 = (nt + 15) >> 4;
+  const int ntile = PART == 0 ? n16 * (n16 + 1) / 2 : (PART == 1 ? n16 : (n16 - 1) * n16 / 2);
+  const int wv = w >= 0 ? w : tid >> 6, ln = tid & 63, kq = ln >> 4, c16 = ln & 15;
+  for (int tb = wv; tb < ntile; tb += 2 * NWV) {
     double am[2][KS], bm[2][KS], old[2][4];
     int at[2][4];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int t = tb + 4 * u;
+      const int t = tb + NWV * u;
       const bool live = t < ntile;
       const int tc = live ? t : 0;
-      int ti = (int)((sqrtf(8.0f * (float)tc + 1.0f) - 1.0f) * 0.5f);
-      ti = ti * (ti + 1) / 2 > tc ? ti - 1 : ti;
-      ti = (ti + 1) * (ti + 2) / 2 <= tc ? ti + 1 : ti;
-      const int tj = tc - ti * (ti + 1) / 2;
+      int ti, tj;
+      if (PART == 1) { ti = tc; tj = 0; }
+      else {
+        ti = (int)((sqrtf(8.0f * (float)tc + 1.0f) - 1.0f) * 0.5f);
+        ti = ti * (ti + 1) / 2 > tc ? ti - 1 : ti;
+        ti = (ti + 1) * (ti + 2) / 2 <= tc ? ti + 1 : ti;
+        tj = tc - ti * (ti + 1) / 2;
+        if (PART == 2) { ti += 1; tj += 1; }   // (the lower triangle without its first column is a lower triangle again)
+      }
       const int R = t0 + 16 * ti, Cc = t0 + 16 * tj;
       const bool ina = live && R + c16 < RE, inb = live && Cc + c16 < S;
       const int ra = ina ? R + c16 : S - 1, rb = inb ? Cc + c16 : S - 1;      // (unconditional loads, then selects)
@@ -1376,19 +1385,31 @@ __device__ void rig_solve_block(const RigDev& P, double* smem, const LmCtl* cn_i
     double b0 = 0.0, b1 = 0.0, v0 = 0.0, v1 = 0.0;
     bool okw = true;
     if (tid < 64) { b0 = i0 < S ? s_b[i0] : 0.0; b1 = i1 < S ? s_b[i1] : 0.0; }
-    for (int j0 = 0; j0 < S; j0 += 8) {
-      const int nc = S - j0 < 8 ? S - j0 : 8;
-      if (tid < 64) {
-        if (S <= 64) chol_panel<false>(A, S, LD, j0, nc, s_inv, b0, b1, v0, v1, okw);
-        else chol_panel<true>(A, S, LD, j0, nc, s_inv, b0, b1, v0, v1, okw);
+    if (S > 64) {
+      // ---- 65 .. 127 coordinates (rigs of 11 .. 21 optimised cameras; cameras with their own intrinsics): trailing updates on the
+      // matrix pipe, with LOOK-AHEAD since round 6. Before, a panel's whole trailing update (all four waves, ~2 us at S = 114)
+      // stood between two panels (wave 0 alone, ~2.5 us): 68 us of factorisation. Now only the tiles of the first tile column --
+      // the next panel's columns -- are updated by all four waves first (part 1: at most eight tiles, one round); then wave 0
+      // factors the next panel WHILE waves 1..3 give the rest of the trailing matrix (part 2: columns beyond t0 + 15, which the
+      // next panel neither reads nor writes) the same update. Every element still receives the panels' updates one panel after
+      // the other, each as `old - T` with T summed over the panel's eight columns in the same two k-steps: the bits do not change.
+      if (tid < 64) chol_panel<true>(A, S, LD, 0, 8, s_inv, b0, b1, v0, v1, okw);
+      __syncthreads();
+      for (int j0 = 0; j0 + 8 < S; j0 += 8) {
+        const int t0 = j0 + 8, nn = S - t0 < 8 ? S - t0 : 8;
+        chol_trail_mfma<2, 1, 4>(A, S, LD, j0, 8, t0, S, tid >> 6);
+        __syncthreads();
+        if (tid < 64) chol_panel<true>(A, S, LD, t0, nn, s_inv, b0, b1, v0, v1, okw);
+        else chol_trail_mfma<2, 2, 3>(A, S, LD, j0, 8, t0, S, (tid >> 6) - 1);
+        __syncthreads();
       }
+    } else
+    for (int j0 = 0; j0 < S; j0 += 8) {   // (S = 64: the element-wise trailing update)
+      const int nc = S - j0 < 8 ? S - j0 : 8;
+      if (tid < 64) chol_panel<false>(A, S, LD, j0, nc, s_inv, b0, b1, v0, v1, okw);
       __syncthreads();
       const int t0 = j0 + nc;
-      if (t0 < S && S > 64) {
-        // (large systems only -- cameras with their own intrinsics; for S <= 64 the element-wise form below is as fast
-        // or faster: S = 18, 48.7 vs 49.6 us per iteration)
-        chol_trail_mfma<2>(A, S, LD, j0, nc, t0, S);
-      } else if (t0 < S) {
+      if (t0 < S) {
         // trailing triangle rows t0..S-1, columns t0..row, as a flat list of elements dealt to the threads three at a
         // time: all LDS reads of a batch are issued before its first write (the elements are distinct and none lies
         // in the panel's columns, which the compiler cannot know), so a batch costs one LDS round trip, not three
