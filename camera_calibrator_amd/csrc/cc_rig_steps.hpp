@@ -62,15 +62,35 @@ __device__ __forceinline__ void rig_update_body(const RigDev& P, int phase, int 
       }
     }
   } else if (phase != 0) {
+    // Eight columns per lane (128 of the shared step) in ONE round trip: every load of the batch -- 48 of Y, 8 of the step -- is
+    // issued before the first product (round 6; the rolled loop waited for each column's seven loads on their own: eight
+    // dependent round trips behind the flag at S = 114, 14 us of the reduce launch). Same products in the same order.
     const double* Yf = P.Y + (size_t)fc * 6 * P.SW;
-    for (int k = l; k < P.SW; k += 16) {
-      double d = 1.0;
-      if (k < P.S)
-        d = ds_lds ? ds_lds[k]
-          : SC1 ? __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(P.ds) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                : P.ds[k];
+    if (ds_lds) {   // (the lean persistent workers: at most 25 columns, a register budget of their own -- the plain loop)
+      for (int k = l; k < P.SW; k += 16) {
+        const double d = k < P.S ? ds_lds[k] : 1.0;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) u[i] += Yf[i * P.SW + k] * d;
+        for (int i = 0; i < 6; ++i) u[i] += Yf[i * P.SW + k] * d;
+      }
+    } else
+    for (int k0 = l; k0 < P.SW; k0 += 128) {
+      double y[8][6], d[8];
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        const int k = k0 + 16 * h, kc = k < P.SW ? k : 0, ks = k < P.S ? k : 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) y[h][i] = Yf[i * P.SW + kc];
+        const double dk = SC1 ? __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(P.ds) + ks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                        : P.ds[ks];
+        d[h] = k < P.S ? dk : 1.0;   // (column S is the right-hand side)
+      }
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        if (k0 + 16 * h < P.SW) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) u[i] += y[h][i] * d[h];
+        }
+      }
     }
   }
   if (phase != 0) {   // the sixteen lanes of a frame add up their columns
@@ -970,28 +990,49 @@ __device__ __forceinline__ void chol_panel(double* A, int S, int LD, int j0, int
 template <bool TWO>
 __device__ __forceinline__ void chol_backward(const double* A, int S, int LD, double& b0, double& b1, double v0, double v1) {
   const int lane = threadIdx.x & 63, i0 = lane, i1 = lane + 64;
-  for (int j0 = S - 1; j0 >= 0; j0 -= 8) {
-    double a0[8], a1[8];
+  if (TWO) {
+    // Rows S - 1 .. 64 first: their pivots live in b1 and nowhere else, so a step is two lane reads + two FMAs with nothing to
+    // select (round 6: one loop over all rows chose between b0 and b1 on every step -- four lane reads and two scalar selects on
+    // the dependent chain, 114 times). Same products, same order: same bits.
+    for (int j0 = S - 1; j0 >= 64; j0 -= 8) {
+      double a0[8], a1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = j0 - u, jr = j >= 64 ? j : 64;
+        const double x0 = A[(size_t)jr * LD + i0];
+        const double x1 = A[(size_t)jr * LD + (i1 < LD ? i1 : 0)];
+        const double vj = readlane_d(v1, jr - 64);
+        a0[u] = j >= 64 ? x0 * vj : 0.0;              // (every row i0 < 64 <= j)
+        a1[u] = (j >= 64 && i1 < j) ? x1 * vj : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int jr = j0 - u >= 64 ? j0 - u : 64;   // (steps below row 64 multiply by the zeros selected above)
+        const double bj = readlane_d(b1, jr - 64);
+        b0 -= a0[u] * bj;
+        b1 -= a1[u] * bj;
+      }
+    }
+    b1 *= v1;
+  }
+  for (int j0 = TWO ? 63 : S - 1; j0 >= 0; j0 -= 8) {
+    double a0[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int j = j0 - u, jr = j >= 0 ? j : 0;
       // (unconditional loads from row jr, then a select: a conditional load is a branch and a wait of its own)
       const double x0 = A[(size_t)jr * LD + i0];
-      const double x1 = TWO ? A[(size_t)jr * LD + (i1 < LD ? i1 : 0)] : 0.0;
-      const double vj = (!TWO || jr < 64) ? readlane_d(v0, jr & 63) : readlane_d(v1, jr & 63);
+      const double vj = readlane_d(v0, jr);
       a0[u] = (j >= 0 && i0 < j) ? x0 * vj : 0.0;
-      a1[u] = (TWO && j >= 0 && i1 < j) ? x1 * vj : 0.0;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int jr = j0 - u >= 0 ? j0 - u : 0;   // (steps below row 0 multiply by the zeros selected above)
-      const double bj = (!TWO || jr < 64) ? readlane_d(b0, jr & 63) : readlane_d(b1, jr & 63);   // final: rows > j are done
+      const double bj = readlane_d(b0, jr);      // final: rows > j are done
       b0 -= a0[u] * bj;
-      if (TWO) b1 -= a1[u] * bj;
     }
   }
   b0 *= v0;
-  if (TWO) b1 *= v1;
 }
 
 // Trailing update A[t0.., t0..] -= P P^T (P = the panel's nc <= 4 KS columns from j0, rows t0..S-1) ON THE MATRIX PIPE: the
