@@ -808,7 +808,6 @@ static int rig_enqueue_round(cc_rig* h, bool initial, bool profile, bool publish
   { RigProbe p(h, CC_K_SWEEP, profile);
     if (d.kcm) hipLaunchKernelGGL(k_rig_sweep_k2, dim3((unsigned)h->NG), dim3(128), 0, h->stream, d);   // (a workgroup of two waves per group)
     else if (d.kmode && h->sweep_waves == 1) hipLaunchKernelGGL(k_rig_sweep_adjk<1>, dim3((unsigned)h->NG), dim3(64), 0, h->stream, d);
-    else if (d.kmode && h->sweep_waves == 2) hipLaunchKernelGGL(k_rig_sweep_adjk<2>, dim3((unsigned)h->NG), dim3(128), 0, h->stream, d);
     else if (d.kmode) hipLaunchKernelGGL(k_rig_sweep_adjk<4>, dim3((unsigned)h->NG), dim3(256), 0, h->stream, d);
     else if (d.fmode) {
       const size_t fl = (size_t)kRigFrameLdsDoubles(d.CO) * 8;
@@ -1240,7 +1239,7 @@ static int rig_create_impl(int32_t device, int64_t C, int64_t F, int64_t n_world
     // (k_rig_sweep_adj: one wave per group is the fastest at every measured shape that has a thousand groups)
     if (!kmode) h->sweep_waves = (NG >= 1024 || per_group <= 64.0) ? 1 : (NG >= 512 ? 2 : 4);
     if (kmode) h->sweep_waves = (NG >= 1024 || per_group <= 64.0) ? 1 : 4;
-    if (const char* e = getenv("CC_RIG_SWEEP_WG_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) h->sweep_waves = v; }
+    if (const char* e = getenv("CC_RIG_SWEEP_WG_WAVES")) { const int v = atoi(e); if ((!kmode && (v == 1 || v == 2 || v == 4)) || (kmode && (v == 1 || v == 4))) h->sweep_waves = v; }
   }
   if (int rc = dev_zeroed(h, &d.intr, 2 * CKn * 16)) return rc;
   if (int rc = dev_zeroed(h, &d.krec, CKn * 32)) return rc;

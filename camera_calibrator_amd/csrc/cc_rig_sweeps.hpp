@@ -821,12 +821,8 @@ __global__ __launch_bounds__(NW * 64, kRigAdjkWaves) void k_rig_sweep_adjk(RigDe
   const double qw = wave_sum(qterm), cw = wave_sum(cost);
   if (lane == 0) { s_w[wave] = qw; s_w[4 + wave] = cw; }
   __syncthreads();
-  if (NW == 4) {
+  if (NW > 1) {
     s_G[tid] = (s_stage[tid] + s_stage[256 + tid]) + (s_stage[512 + tid] + s_stage[768 + tid]);
-    __syncthreads();
-  } else if (NW == 2) {
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) s_G[tid + e * NT] = s_stage[tid + e * NT] + s_stage[256 + tid + e * NT];
     __syncthreads();
   }
   double* out = P.gblocks + ((size_t)dst * P.NG + g) * (size_t)P.gstride;
@@ -875,16 +871,14 @@ __global__ __launch_bounds__(NW * 64, kRigAdjkWaves) void k_rig_sweep_adjk(RigDe
       }
     } else {
       if (lane == 0) {
-        P.gstats[g * 2] = NW == 4 ? (s_w[4] + s_w[5]) + (s_w[6] + s_w[7]) : (NW == 2 ? s_w[4] + s_w[5] : s_w[4]);
-        P.gstats[g * 2 + 1] = NW == 4 ? (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]) : (NW == 2 ? s_w[0] + s_w[1] : s_w[0]);
+        P.gstats[g * 2] = NW > 1 ? (s_w[4] + s_w[5]) + (s_w[6] + s_w[7]) : s_w[4];
+        P.gstats[g * 2 + 1] = NW > 1 ? (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]) : s_w[0];
       }
       if (lane < 36) P.gcomp[((size_t)dst * P.NG + g) * kRigCompK + 256 + lane] = s_m[lane];
     }
   };
-  if (NW == 4) {
+  if (NW > 1) {
     role(wave);
-  } else if (NW == 2) {
-    role(wave); role(wave + 2);
   } else {
     role(0); role(1); role(2); role(3);
   }
