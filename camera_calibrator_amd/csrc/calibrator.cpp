@@ -73,10 +73,26 @@ void Calibrator::ReadSolverStatus() {
   last_solver_note_ = note;
 }
 
-void Calibrator::EstimateOpenCv(const std::vector<Points2D>&, const std::vector<Points3D>&) {
-  (void)image_w_;
+// The reference's EstimateOpenCv (calibrator.cpp:16-45) hands the views to cv::calibrateCamera with flags = 0 and keeps K and the
+// five distortion coefficients it returns. OpenCV is not part of this build. What that call computes is the minimiser of the SAME
+// objective over the SAME nine parameters as Estimate() -- pinhole + (k1, k2, p1, p2, k3), every coefficient free, the distortion
+// started from zero, K and the poses initialised from the views' homographies -- so it is served by this library's own path:
+// Zhang initialisation + bundle adjustment with NOTHING held constant (calibrateCamera knows nothing of ForceDistortionToConstant)
+// and the current distortion ignored (flags = 0 carries no CALIB_USE_INTRINSIC_GUESS). Same minimiser, another trajectory and
+// stopping rule than OpenCV's LM; parity unpinned (there is no OpenCV here to compare with). Throws only where Estimate() does.
+void Calibrator::EstimateOpenCv(const std::vector<Points2D>& pixels_per_view, const std::vector<Points3D>& board_points_per_view) {
+  (void)image_w_;   // (cv::calibrateCamera takes the image size for its initial principal point; Zhang's closed form needs none)
   (void)image_h_;
-  throw std::runtime_error("Calibrator::EstimateOpenCv wraps cv::calibrateCamera; OpenCV is not part of the MI355X build");
+  const std::set<int> held = frozen_intrinsics_;
+  frozen_intrinsics_.clear();
+  distortion_ = DynamicVector::Zero(5);
+  try {
+    Estimate(pixels_per_view, board_points_per_view);
+  } catch (...) {
+    frozen_intrinsics_ = held;
+    throw;
+  }
+  frozen_intrinsics_ = held;
 }
 
 void Calibrator::Estimate(const std::vector<Points2D>& pixels_per_view, const std::vector<Points3D>& board_points_per_view) {

@@ -28,8 +28,10 @@ class Calibrator {
   /// Closed-form start (homography per view -> K -> board poses) followed by Optimize
   /// (reference: calibrator.cpp:47-68). The closed form runs on the GPU too (cc_zhang_init).
   void Estimate(const std::vector<Points2D>& pixels_per_view, const std::vector<Points3D>& board_points_per_view);
-  /// The reference's cv::calibrateCamera wrapper (calibrator.cpp:16-45). OpenCV is not part of this
-  /// build: the method exists for source compatibility and throws std::runtime_error.
+  /// The reference's cv::calibrateCamera wrapper (calibrator.cpp:16-45). OpenCV is not part of this build; the call computes what
+  /// calibrateCamera(flags = 0) minimises -- the same objective over the same nine parameters as Estimate(), nothing held
+  /// constant, distortion started from zero -- with this library's Zhang initialisation + bundle adjustment (round 6; it threw
+  /// before). Same minimiser, not OpenCV's trajectory; parity unpinned.
   void EstimateOpenCv(const std::vector<Points2D>& pixels_per_view, const std::vector<Points3D>& board_points_per_view);
   /// Reprojection-error bundle adjustment over the 9 intrinsics and one pose per view, starting from
   /// the given poses (reference: calibrator.cpp:221-336). Updates K and the distortion; like the

@@ -42,6 +42,33 @@ def test_calibration_estimation_works():
     assert np.allclose(c.GetDistortion(), io[4:], rtol=1e-3, atol=1e-6)
 
 
+def test_estimate_opencv_is_the_unconstrained_estimate():
+    """src/calibrator.cpp:16-45 wraps cv::calibrateCamera(flags = 0): the nine-parameter model with nothing held constant and the
+    distortion started from zero. Served by the library's own path (no OpenCV in the build): equal to Estimate() on a fresh
+    object, whatever was frozen or set before; the frozen set itself survives the call. Parity with OpenCV: unpinned."""
+    import pycalibrator as pc
+    off, uv, xyz = po.make_intrinsics_problem(8, 120)
+    img, world = _frames(off, uv, xyz)
+    a = pc.Calibrator(1600, 1000)
+    a.Estimate(img, world)
+    b = pc.Calibrator(1600, 1000)
+    b.ForceDistortionToConstant(4)
+    b.SetDistortion(np.array([0.1, 0, 0, 0, 0.2], np.float32))
+    b.EstimateOpenCv(img, world)
+    assert b.LastStatus() == 0
+    assert np.array_equal(a.GetK(), b.GetK()) and np.array_equal(a.GetDistortion(), b.GetDistortion())
+    assert b.GetDistortion()[4] != 0.0                       # k3 was free in the call ...
+    c = pc.Calibrator(1600, 1000)
+    c.ForceDistortionToConstant(4)
+    c.Estimate(img, world)
+    b2 = pc.Calibrator(1600, 1000)
+    b2.ForceDistortionToConstant(4)
+    b2.EstimateOpenCv(img, world)
+    b2.SetDistortion(np.zeros(5, np.float32))
+    b2.Estimate(img, world)                                   # ... and is held again afterwards
+    assert np.array_equal(b2.GetK(), c.GetK()) and b2.GetDistortion()[4] == 0.0
+
+
 def test_optimize_matches_oracle_bitwise_in_float32():
     import pycalibrator as pc
     off, uv, xyz = po.make_intrinsics_problem(20, 88)
