@@ -347,6 +347,7 @@ struct cc_rig {
   size_t elim_lds = 0, solve_lds = 0;
   bool big = false;             // 128 <= S <= 255: the plain kernels (k_rig_elim_big, k_rig_solve_big), no exchange
   bool persist_lean_allowed = true;   // CC_RIG_PERSIST=0: three kernels per iteration always
+  bool persist_lean_forced = false;   // CC_RIG_PERSIST=1: the lean form wherever it FITS, also where the three kernels measured faster (tests)
   double* d_cam_backup = nullptr;   // [C][8] cameras of the starting point (the lean persistent solve may be run again in the three-kernel form)
   int p_teams = 4;              // frames per workgroup of the lean form
   bool persist_w_ok = false;    // ... and so can its lean form (k_rig_persist_w + k_rig_persist_ctl: <= 4 observed cameras, <= 24 shared coordinates)
@@ -458,7 +459,7 @@ static int lds_attr(int device, const void* fn, int bytes) {
 // them. Called by create (with the locally observed cameras) and again by the multi-GPU attach calls when
 // another rank observes a camera this one does not.
 static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
-  if (const char* e = getenv("CC_RIG_PERSIST")) h->persist_lean_allowed = atoi(e) != 0;
+  if (const char* e = getenv("CC_RIG_PERSIST")) { h->persist_lean_allowed = atoi(e) != 0; h->persist_lean_forced = atoi(e) != 0; }
   RigDev& d = h->d;
   const int64_t C = h->C, F = h->F;
   const int kmode = h->kmode;
@@ -723,6 +724,15 @@ static int rig_layout(cc_rig* h, const std::vector<uint8_t>& seen_any) {
                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&pw, k_rig_persist_w<4>, 1024, (size_t)lb);
       if (e2 != hipSuccess) (void)hipGetLastError();
       h->persist_w_ok = e2 == hipSuccess && pw >= 1;
+      // Where it FITS is not where it PAYS (round 6, profiles/r06/lean_vs_three_kernel_grid.txt: 2 and 4 cameras x 256 .. 1020
+      // frames x 4 .. 500 points, both forms on one box). With one or two frames per workgroup (<= 510 frames) the lean form
+      // takes 10 - 30 % less time per iteration at every shape measured; with FOUR (up to 1020 frames: sixteen waves a compute
+      // unit, 128 registers, every round as long as its slowest of four frames) it ties at best and loses up to 30 % wherever
+      // the solve rejects steps -- 4 x 1020 x 300: 63.4 against 50.4 us per iteration -- except for rigs of two observed cameras
+      // with a handful of points per frame (the reference's own test, 2 x 1000 x 4: 34.8 against 40.2). CC_RIG_PERSIST=1 keeps
+      // the old rule (wherever it fits) for the tests of the four-frame workers.
+      const bool pays = h->p_teams <= 2 || (CO <= 2 && h->N <= 32 * F);
+      if (!pays && !h->persist_lean_forced) h->persist_w_ok = false;
     }
   }
   rig_drop_graphs(h);

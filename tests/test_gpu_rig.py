@@ -397,6 +397,20 @@ def test_rig_with_no_camera_held_constant_runs_the_lean_form_at_24_shared_coordi
     assert np.isclose(g[5]["final_cost"], o[5]["final_cost"], rtol=1e-6)
 
 
+def test_four_frame_lean_workers_on_a_four_camera_rig_when_forced(monkeypatch):
+    """Four frames per workgroup x four groups per frame = sixteen waves a worker: the shape the default rule no longer picks
+    (round 6) stays correct when CC_RIG_PERSIST=1 asks for it."""
+    if os.environ.get("CC_RIG_FORCE_BIG"):
+        pytest.skip("the plain large-rig kernels are forced in this environment")
+    monkeypatch.setenv("CC_RIG_PERSIST", "1")
+    sc = po.rig_scenario(4, 600, 12)
+    prob = capi.RigProblem(4, sc["frame_offsets"], sc["obs_cam"], sc["obs_world"], sc["obs_uv"], sc["world_xyz"], sc["cam_frozen"])
+    assert prob.solver_form() == 2
+    prob.close()
+    g, o = _both(sc, 4)
+    _assert_same(g, o)
+
+
 def _form_of(cams, frames, pts, env):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import sys; sys.path.insert(0, %r)\n"
@@ -423,6 +437,13 @@ def test_the_rig_suite_in_every_form_of_the_solver():
     assert _form_of(3, 40, 20, dict(os.environ, CC_RIG_PERSIST="1")) == 2
     assert _form_of(3, 40, 20, env) == 0
     assert _form_of(8, 30, 10, dict(os.environ)) == 0      # 42 shared coordinates: not the lean form's
+    # round 6: where the lean form FITS but does not PAY (four frames per workgroup -- more than 510 frames -- unless the rig has two
+    # observed cameras and a handful of points per frame: profiles/r06/lean_vs_three_kernel_grid.txt) the three kernels run by
+    # default; CC_RIG_PERSIST=1 still forces the lean form wherever it fits (and the suite below solves 2 x 1000 x 4 with it)
+    assert _form_of(4, 800, 12, dict(os.environ)) == 0
+    assert _form_of(4, 800, 12, dict(os.environ, CC_RIG_PERSIST="1")) == 2
+    assert _form_of(4, 500, 12, dict(os.environ)) == 2
+    assert _form_of(2, 1000, 4, dict(os.environ)) == 2
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_rig.py", "-q", "-m", "gpu", "-x",
                         "-k", "not rccl and not exchange and not plain_kernels and not every_form and not ranks and not rerun", "-p", "no:cacheprovider"],
