@@ -1703,7 +1703,10 @@ int cc_rig_solve(cc_rig* h, const cc_options* opt, cc_summary* summary) {
   for (int chunk = 0;; ++chunk) {
     if (chunk == 0 && !r.no_persist && h->persist_w_ok && !r.profile && !h->comm && !h->exchange && !h->big && h->co_resident <= 1)
       lean_lock.lock();
-    if (int rc = rig_launch(h, &r, chunk)) return rc;
+    if (int rc = rig_launch(h, &r, chunk)) {
+      if (chunk == 0 && lean_tried) persist_device_gave_up(h->device, 1);   // (a probe that never started is over too)
+      return rc;
+    }
     if (chunk == 0) hp.mark("launch0");
     if (int rc = rig_wait(h, &r)) {
       if (chunk == 0 && lean_tried && r.persist) persist_device_gave_up(h->device, 1);   // (the probe is over, whatever ended it)
