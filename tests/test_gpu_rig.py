@@ -235,6 +235,18 @@ def test_rig_twenty_two_cameras_take_the_large_elimination_variant():
     _assert_same(g, o)
 
 
+@pytest.mark.parametrize("cams", [12, 13, 18, 21])
+def test_reduced_systems_between_65_and_127_coordinates_at_the_edges_of_the_panel_loop(cams):
+    """Round 6: the factorisation of 65 .. 127 shared coordinates runs its eight-column panels with look-ahead (the next panel's
+    tile column first, then the panel on wave 0 next to the rest of the trailing update) and its backward substitution in two
+    phases (rows >= 64, then rows < 64). Sizes chosen for the loop's edges: 12 cameras = 66 coordinates (eight full panels and a
+    last one of two columns, two rows beyond 64), 13 = 72 (nine panels exactly), 18 = 102 (six columns in the last panel, a
+    partial block of the upper phase), 21 = 120 (fifteen panels exactly). Same bar as every other rig test."""
+    sc = po.rig_scenario(cams, 20, 10)
+    g, o = _both(sc, cams)
+    _assert_same(g, o)
+
+
 def test_rig_kernel_profile_of_a_solve():
     sc = po.rig_scenario(3, 40, 20)
     cq, ct, fq, ft = _inputs(sc)
